@@ -1,0 +1,126 @@
+"""Generate golden fixtures from the reference's own pure-numpy test oracles.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference's test modules `import nnabla` at the top and therefore cannot be imported
+here.  The numpy oracle functions inside them are pure numpy, so this script parses the
+test files with `ast`, compiles ONLY the named function definitions from where they lie
+under /root/reference, and executes them with numpy -- no stub library, no copied source.
+Inputs are constructed exactly as the reference tests do (RandomState(412), same shapes,
+same parametrisation).  Outputs: small .npz files of inputs + expected outputs.
+
+Sources:
+  python/intersection/test/test_ray_aabb_intersection.py:23-108, 113-147
+  python/intersection/test/test_ray_sphere_intersection.py:24-75, 78-113
+  python/intersection/ray_sphere_intersection.py:115-131 (sample_inside_sphere, test input sampler)
+  python/sampler/test_sampler.py:23-70, 72-111
+"""
+import ast
+import os
+
+import numpy as np
+
+REF = "/root/reference/python"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def extract(path, names):
+    src = open(path).read()
+    tree = ast.parse(src)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(body) == len(names), (path, names)
+    mod = ast.Module(body=body, type_ignores=[])
+    ns = {"np": np}
+    exec(compile(mod, path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def golden_aabb():
+    (ref_fn,) = extract(f"{REF}/intersection/test/test_ray_aabb_intersection.py",
+                        ["ray_aabb_intersection_python"])
+    out = {}
+    B, R = 2, 3
+    for k, (radius, size) in enumerate([(3, 1), (3, 1.5), (1, 2)]):
+        rng = np.random.RandomState(412)
+        camloc = rng.randn(B, 3)
+        camloc /= np.linalg.norm(camloc, ord=2, axis=-1, keepdims=True)
+        camloc *= radius
+        raydir = rng.rand(B, R, 3) * size * 2 - size
+        raydir = raydir - camloc.reshape((B, 1, 3))
+        raydir /= np.linalg.norm(raydir, ord=2, axis=-1, keepdims=True)
+        camloc = camloc.astype(np.float32)
+        raydir = raydir.astype(np.float32)
+        t_near, t_far, n_hits = ref_fn(camloc, raydir, size)
+        out[f"c{k}_camloc"] = camloc
+        out[f"c{k}_raydir"] = raydir
+        out[f"c{k}_size"] = np.float32(size)
+        out[f"c{k}_t_near"] = np.asarray(t_near, np.float64)
+        out[f"c{k}_t_far"] = np.asarray(t_far, np.float64)
+        out[f"c{k}_n_hits"] = np.asarray(n_hits, np.float64)
+    np.savez(os.path.join(OUT, "ray_aabb_intersection.npz"), **out)
+
+
+def golden_sphere():
+    (ref_fn,) = extract(f"{REF}/intersection/test/test_ray_sphere_intersection.py",
+                        ["ray_sphere_intersection_python"])
+    # input sampler used by the reference test; pure numpy, lives in the wrapper module
+    (sample_inside_sphere,) = extract(f"{REF}/intersection/ray_sphere_intersection.py",
+                                      ["sample_inside_sphere"])
+    out = {}
+    B, R = 2, 3
+    for k, (radius, ratio) in enumerate([(1, 2), (1.5, 2), (1.0, 0.5)]):
+        rng = np.random.RandomState(412)
+        camloc = rng.randn(B, 3)
+        camloc /= np.linalg.norm(camloc, ord=2, axis=-1, keepdims=True)
+        camloc *= (radius * ratio)
+        raydir = sample_inside_sphere(B, R, radius, rng) - camloc.reshape((B, 1, 3))
+        raydir /= np.linalg.norm(raydir, ord=2, axis=-1, keepdims=True)
+        camloc = camloc.astype(np.float32)
+        raydir = raydir.astype(np.float32)
+        radius_q = 1.0  # the reference test queries with radius = 1.0 (:104)
+        t_near, t_far, n_hits = ref_fn(camloc, raydir, radius_q)
+        out[f"c{k}_camloc"] = camloc
+        out[f"c{k}_raydir"] = raydir
+        out[f"c{k}_radius"] = np.float32(radius_q)
+        out[f"c{k}_t_near"] = np.asarray(t_near, np.float64)
+        out[f"c{k}_t_far"] = np.asarray(t_far, np.float64)
+        out[f"c{k}_n_hits"] = np.asarray(n_hits, np.float64)
+    np.savez(os.path.join(OUT, "ray_sphere_intersection.npz"), **out)
+
+
+def golden_directions():
+    (ref_fn,) = extract(f"{REF}/sampler/test_sampler.py", ["sample_directions_numpy"])
+    out = {}
+    k = 0
+    for (B, R) in [(1, 1), (2, 4)]:
+        for n_thetas in [1, 4]:
+            for typ in ["uniform", "importance"]:
+                rng = np.random.RandomState(412)
+                normal = rng.randn(B, R, 3).astype(np.float32)
+                normal = normal / np.linalg.norm(normal, ord=2, axis=-1, keepdims=True)
+                cdf_the = rng.rand(B, R, n_thetas).astype(np.float32)
+                cdf_phi = rng.rand(B, R, 2 * n_thetas).astype(np.float32)
+                out[f"c{k}_normal"] = normal
+                out[f"c{k}_cdf_the"] = cdf_the
+                out[f"c{k}_cdf_phi"] = cdf_phi
+                if typ == "uniform":
+                    dirs = ref_fn(normal, cdf_the, cdf_phi)
+                else:
+                    alpha = rng.randn(B, R, 1).astype(np.float32)
+                    out[f"c{k}_alpha"] = alpha
+                    dirs = ref_fn(normal, cdf_the, cdf_phi, alpha)
+                out[f"c{k}_light_dirs"] = np.asarray(dirs, np.float64)
+                k += 1
+    out["n_cases"] = np.int64(k)
+    np.savez(os.path.join(OUT, "sample_directions.npz"), **out)
+
+
+if __name__ == "__main__":
+    golden_aabb()
+    golden_sphere()
+    golden_directions()
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
