@@ -1,0 +1,200 @@
+/*
+ * ndjir_hip.h -- C ABI of libndjir_hip.so, the MI355X (gfx950) drop-in for the native
+ * extension modules of sony/NDJIR (reference: /root/reference/csrc, 19 pybind11 modules built
+ * one-per-.cu by Makefile:16-23 and called from python/grid_feature/ *.py,
+ * python/intersection/ *.py, python/sampler.py).
+ *
+ * Conventions (identical to the reference's pybind11 functions unless stated):
+ *   - symbol name = ndjir_<reference module without "_cuda">_<reference function>
+ *   - same argument order; raw DEVICE pointers to contiguous row-major fp32 (the reference passes
+ *     them as int64); std::vector<float/int> min/max/grid_sizes become `const float[3]` /
+ *     `const int[3]` HOST pointers; bool becomes int
+ *   - N is the reference's thread count (P*D, P*D*3 or L*P), kept for signature parity
+ *   - one trailing `hipStream_t stream` (the reference always uses the default stream)
+ *   - returns 0 on success, NDJIR_ERR_* otherwise (the reference returns void and only printf's
+ *     launch errors, csrc/cuda_common.cuh:24-32)
+ *   - caller owns every buffer; kernels never allocate.  `accum == 0` => destination is
+ *     zero-filled first, for exactly the entry points where the reference does so
+ *     (grad_query, grad_feature); grad_query_grad_query, grad_query_grad_feature,
+ *     grad_feature_grad_query and every TV backward ALWAYS accumulate, as in the reference
+ *   - `boundary_check` is accepted and ignored, as in every reference kernel
+ *   - launches are asynchronous on `stream`; no global state; thread-safe per stream
+ *
+ * No torch types appear here; the library links only libamdhip64.
+ */
+#ifndef NDJIR_HIP_H
+#define NDJIR_HIP_H
+
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDJIR_OK 0
+#define NDJIR_ERR_LAUNCH 1
+#define NDJIR_ERR_UNSUPPORTED 2
+#define NDJIR_ERR_ARG 3
+
+const char* ndjir_version(void);
+int ndjir_zero(float* p, long long n, hipStream_t stream);
+
+/* ---- hash-grid host helpers: csrc/grid_feature/common_voxel_hash.cuh:24-55 -------------------- */
+int ndjir_hash_force_align(int size, int mod);                      /* size + size % mod (sic) */
+int ndjir_hash_grid_size(int G0, float growth_factor, int level);
+int ndjir_hash_table_size(int G, int T0);
+long long ndjir_hash_num_params(int G0, float growth_factor, int T0, int L, int D);
+
+/* ---- dense voxel grids (G0,G1,G2,D) -----------------------------------------------------------
+ * voxel_feature          <- csrc/grid_feature/voxel_feature_cuda.cu:101-115,207-228,289-311,414-438,522-546,616-638,709-731,816-838 (exports :844-863)
+ * cosine_voxel_feature   <- csrc/grid_feature/cosine_voxel_feature_cuda.cu (same export list)
+ * lanczos_voxel_feature  <- csrc/grid_feature/lanczos_voxel_feature_cuda.cu (same export list)
+ * Python callers: python/grid_feature/{,cosine_,lanczos_}voxel_feature.py:85,119,213,242,257      */
+#define NDJIR_DECL_VOXEL_FAMILY(P)                                                                                          \
+  int ndjir_##P##_query_on_voxel(int N, float* output, const float* query, const float* feature, const int* grid_sizes,     \
+                                 int D, const float* min, const float* max, int boundary_check, hipStream_t stream);       \
+  int ndjir_##P##_grad_query(int N, float* grad_query, const float* grad_output, const float* query, const float* feature,  \
+                             const int* grid_sizes, int D, const float* min, const float* max, int boundary_check,         \
+                             int accum, hipStream_t stream);                                                                \
+  int ndjir_##P##_grad_feature(int N, float* grad_feature, const float* grad_output, const float* query,                    \
+                               const int* grid_sizes, int D, const float* min, const float* max, int boundary_check,       \
+                               int accum, hipStream_t stream);                                                              \
+  int ndjir_##P##_grad_query_grad_grad_output(int N, float* grad_grad_output, const float* grad_grad_query,                 \
+                                              const float* query, const float* feature, const int* grid_sizes, int D,      \
+                                              const float* min, const float* max, int boundary_check, int accum,           \
+                                              hipStream_t stream);                                                          \
+  int ndjir_##P##_grad_query_grad_feature(int N, float* grad_feature, const float* grad_grad_query,                         \
+                                          const float* grad_output, const float* query, const int* grid_sizes, int D,      \
+                                          const float* min, const float* max, int boundary_check, int accum,               \
+                                          hipStream_t stream);
+NDJIR_DECL_VOXEL_FAMILY(voxel_feature)
+NDJIR_DECL_VOXEL_FAMILY(cosine_voxel_feature)
+NDJIR_DECL_VOXEL_FAMILY(lanczos_voxel_feature)
+
+/* linear dense voxel only: voxel_feature_cuda.cu:522-546 (1-2), :709-731 (2-1), :816-838 (2-2) */
+int ndjir_voxel_feature_grad_query_grad_query(int N, float* grad_query, const float* grad_grad_query,
+                                              const float* grad_output, const float* query, const float* feature,
+                                              const int* grid_sizes, int D, const float* min, const float* max,
+                                              int boundary_check, int accum, hipStream_t stream);
+int ndjir_voxel_feature_grad_feature_grad_grad_output(int N, float* grad_grad_output, const float* grad_grad_feature,
+                                                      const float* query, const int* grid_sizes, int D, const float* min,
+                                                      const float* max, int boundary_check, int accum, hipStream_t stream);
+int ndjir_voxel_feature_grad_feature_grad_query(int N, float* grad_query, const float* grad_grad_feature,
+                                                const float* grad_output, const float* query, const int* grid_sizes, int D,
+                                                const float* min, const float* max, int boundary_check, int accum,
+                                                hipStream_t stream);
+
+/* ---- tri-plane (3,G,G,D) and tri-line (3,G,D); output (P, D, 3) plane-fastest ----------------------
+ * triplane_feature <- csrc/grid_feature/triplane_feature_cuda.cu:91-112,179-200,257-279,363-385,558-580 (exports :783-805)
+ * triline_feature  <- csrc/grid_feature/triline_feature_cuda.cu (same list); cosine_ / lanczos_ variants alike.
+ * Python callers: python/grid_feature/{,cosine_,lanczos_}tri{plane,line}_feature.py:85,119,213,240,256 */
+#define NDJIR_DECL_PLANE_FAMILY(P, FWD)                                                                                      \
+  int ndjir_##P##_##FWD(int N, float* output, const float* query, const float* feature, int G, int D, const float* min,      \
+                        const float* max, int boundary_check, hipStream_t stream);                                          \
+  int ndjir_##P##_grad_query(int N, float* grad_query, const float* grad_output, const float* query, const float* feature,  \
+                             int G, int D, const float* min, const float* max, int boundary_check, int accum,              \
+                             hipStream_t stream);                                                                           \
+  int ndjir_##P##_grad_feature(int N, float* grad_feature, const float* grad_output, const float* query, int G, int D,      \
+                               const float* min, const float* max, int boundary_check, int accum, hipStream_t stream);     \
+  int ndjir_##P##_grad_query_grad_grad_output(int N, float* grad_grad_output, const float* grad_grad_query,                 \
+                                              const float* query, const float* feature, int G, int D, const float* min,    \
+                                              const float* max, int boundary_check, int accum, hipStream_t stream);        \
+  int ndjir_##P##_grad_query_grad_feature(int N, float* grad_feature, const float* grad_grad_query,                         \
+                                          const float* grad_output, const float* query, int G, int D, const float* min,    \
+                                          const float* max, int boundary_check, int accum, hipStream_t stream);
+NDJIR_DECL_PLANE_FAMILY(triplane_feature, query_on_triplane)
+NDJIR_DECL_PLANE_FAMILY(cosine_triplane_feature, query_on_triplane)
+NDJIR_DECL_PLANE_FAMILY(lanczos_triplane_feature, query_on_triplane)
+NDJIR_DECL_PLANE_FAMILY(triline_feature, query_on_triline)
+NDJIR_DECL_PLANE_FAMILY(cosine_triline_feature, query_on_triline)
+NDJIR_DECL_PLANE_FAMILY(lanczos_triline_feature, query_on_triline)
+
+/* ---- multi-resolution hash grid; N = L*P; feature outputs / grad_output in layout (D, L, P) --------
+ * voxel_hash_feature         <- csrc/grid_feature/voxel_hash_feature_cuda.cu:102-119,197-217,312-332,406-427,540-563,751-773 (exports :976-1000)
+ * lanczos_voxel_hash_feature <- csrc/grid_feature/lanczos_voxel_hash_feature_cuda.cu (same list)
+ * Python callers: python/grid_feature/{,lanczos_}voxel_hash_feature.py:145,192,301,338,357           */
+#define NDJIR_DECL_HASH_FAMILY(P)                                                                                            \
+  int ndjir_##P##_hash_index(int N, float* output, const float* query, int G, int T, const float* min, const float* max,     \
+                             int boundary_check, hipStream_t stream);                                                       \
+  int ndjir_##P##_voxel_hash_feature(int N, float* output, const float* query, const float* feature, int G0,                \
+                                     float growth_factor, int T0, int L, int D, const float* min, const float* max,        \
+                                     int boundary_check, hipStream_t stream);                                               \
+  int ndjir_##P##_grad_query(int N, float* grad_query, const float* grad_output, const float* query, const float* feature,  \
+                             int G0, float growth_factor, int T0, int L, int D, const float* min, const float* max,        \
+                             int boundary_check, int accum, hipStream_t stream);                                            \
+  int ndjir_##P##_grad_feature(int N, float* grad_feature, const float* grad_output, const float* query, int G0,            \
+                               float growth_factor, int T0, int L, int D, const float* min, const float* max,              \
+                               int boundary_check, int accum, hipStream_t stream);                                          \
+  int ndjir_##P##_grad_query_grad_grad_output(int N, float* grad_grad_output, const float* grad_grad_query,                 \
+                                              const float* query, const float* feature, int G0, float growth_factor,       \
+                                              int T0, int L, int D, const float* min, const float* max,                    \
+                                              int boundary_check, int accum, hipStream_t stream);                           \
+  int ndjir_##P##_grad_query_grad_feature(int N, float* grad_feature, const float* grad_grad_query,                         \
+                                          const float* grad_output, const float* query, int G0, float growth_factor,       \
+                                          int T0, int L, int D, const float* min, const float* max, int boundary_check,    \
+                                          int accum, hipStream_t stream);
+NDJIR_DECL_HASH_FAMILY(voxel_hash_feature)
+NDJIR_DECL_HASH_FAMILY(lanczos_voxel_hash_feature)
+
+/* ---- sampled total-variation loss ----------------------------------------------------------------
+ * csrc/grid_feature/total_variation_loss_cuda.cu:86-105,177-199; ..._on_triplane_cuda.cu; ..._on_triline_cuda.cu;
+ * ..._on_voxel_hash_cuda.cu.  Python callers: python/grid_feature/total_variation_loss*.py:75,100 */
+int ndjir_total_variation_loss_tv_loss_on_voxel(int N, float* output, const float* query, const float* feature,
+                                                const int* grid_sizes, int D, const float* min, const float* max,
+                                                int boundary_check, hipStream_t stream);
+int ndjir_total_variation_loss_tv_loss_on_voxel_backward(int N, float* grad_feature, const float* grad_output,
+                                                         const float* query, const float* feature, const int* grid_sizes,
+                                                         int D, const float* min, const float* max, int sym_backward,
+                                                         int boundary_check, int accum, hipStream_t stream);
+int ndjir_total_variation_loss_on_triplane_tv_loss_on_triplane(int N, float* output, const float* query, const float* feature,
+                                                               int G, int D, const float* min, const float* max,
+                                                               int boundary_check, hipStream_t stream);
+int ndjir_total_variation_loss_on_triplane_tv_loss_on_triplane_backward(int N, float* grad_feature, const float* grad_output,
+                                                                        const float* query, const float* feature, int G, int D,
+                                                                        const float* min, const float* max, int sym_backward,
+                                                                        int boundary_check, int accum, hipStream_t stream);
+int ndjir_total_variation_loss_on_triline_tv_loss_on_triline(int N, float* output, const float* query, const float* feature,
+                                                             int G, int D, const float* min, const float* max,
+                                                             int boundary_check, hipStream_t stream);
+int ndjir_total_variation_loss_on_triline_tv_loss_on_triline_backward(int N, float* grad_feature, const float* grad_output,
+                                                                      const float* query, const float* feature, int G, int D,
+                                                                      const float* min, const float* max, int sym_backward,
+                                                                      int boundary_check, int accum, hipStream_t stream);
+int ndjir_total_variation_loss_on_voxel_hash_tv_loss_on_voxel_hash(int N, float* output, const float* query,
+                                                                   const float* feature, int G0, float growth_factor, int T0,
+                                                                   int L, int D, const float* min, const float* max,
+                                                                   int boundary_check, hipStream_t stream);
+int ndjir_total_variation_loss_on_voxel_hash_tv_loss_on_voxel_hash_backward(int N, float* grad_feature,
+                                                                            const float* grad_output, const float* query,
+                                                                            const float* feature, int G0, float growth_factor,
+                                                                            int T0, int L, int D, const float* min,
+                                                                            const float* max, int sym_backward,
+                                                                            int boundary_check, int accum, hipStream_t stream);
+
+/* ---- intersection: csrc/intersection/ray_aabb_intersection_cuda.cu:145-162, ray_sphere_intersection_cuda.cu:81-96;
+ * callers python/intersection/ray_aabb_intersection.py:82-101, ray_sphere_intersection.py:80-97.
+ * n_hits is stored as float, as in the reference. */
+int ndjir_ray_aabb_intersection(int N, float* t_near, float* t_far, float* n_hits, const float* camloc,
+                                const float* raydir, int B, int R, const float* min, const float* max, hipStream_t stream);
+int ndjir_ray_sphere_intersection(int N, float* t_near, float* t_far, float* n_hits, const float* camloc,
+                                  const float* raydir, int B, int R, float radius, hipStream_t stream);
+
+/* ---- light-direction sampling: csrc/sampling/inverse_transform_cuda.cu:72-90,139-160;
+ * caller python/sampler.py:376-389 */
+int ndjir_inverse_transform_sample_uniform_directions(int size, float* light_dirs, const float* normal,
+                                                      const float* cdf_the, const float* cdf_phi, int batch_size,
+                                                      int n_lights, int n_thes, int n_phis, float eps, hipStream_t stream);
+int ndjir_inverse_transform_sample_importance_directions(int size, float* light_dirs, const float* normal,
+                                                         const float* cdf_the, const float* cdf_phi, const float* alpha,
+                                                         int batch_size, int n_lights, int n_thes, int n_phis, float eps,
+                                                         hipStream_t stream);
+
+/* ---- csrc/activation/squareplus_cuda.cu:62-93 (built by the reference, unused by its model) */
+int ndjir_squareplus_forward(int size, float* output, const float* input, float b, hipStream_t stream);
+int ndjir_squareplus_backward(int size, float* dinput, const float* doutput, const float* input, float b, int accum,
+                              hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDJIR_HIP_H */

@@ -1,0 +1,575 @@
+// grid.hip -- grid-feature interpolation kernels for gfx950 (MI355X), written from scratch.
+//
+// What the reference does (csrc/grid_feature/*.cu): one CUDA thread per (point, channel), eight
+// scalar gathers, one scalar atomicAdd per (point, channel, corner).  Here: one lane per
+// (sub-grid, point) handles ALL channels with 16-byte (float4) / 8-byte corner loads, so a
+// D=4 voxel corner is one dwordx4 load and the 8 corners of a cell share 4 cache lines along z;
+// sub-grid-major lane order keeps adjacent lanes on adjacent ray samples (coherent cells).
+// Scatter kernels use hardware fp32 atomics (global_atomic_add_f32, -munsafe-fp-atomics).
+//
+// One templated stencil covers every family:
+//   topology  VOXEL (G,G,G,D) | TRIPLANE (3,G,G,D) | TRILINE (3,G,D) | HASH (levels of (T,D))
+//   interp    LINEAR | COSINE (2 taps/axis) | LANCZOS a=2 (4 taps/axis)
+// Arithmetic definitions follow the reference kernels (file:line cited at each piece).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "grid.h"
+
+namespace ndjir {
+
+template <int I> struct NTaps { static constexpr int v = (I == LANCZOS) ? 4 : 2; };
+
+// --- per-axis taps ---------------------------------------------------------------------------
+__device__ __forceinline__ float sincf_(float x) { return x == 0.f ? 1.0f : sinf(x) / x; }
+
+// common.cuh:54-69 (z computed in double, rounded to float before sinf)
+__device__ __forceinline__ float lanczos2(float x) {
+  double z = M_PI * (double)x;
+  return sincf_((float)z) * sincf_((float)(z / 2));
+}
+// common.cuh:82-97
+__device__ __forceinline__ float lanczos2_grad(float x) {
+  if (x == 0.f) return 0.0f;
+  double z0 = M_PI * (double)x, z1 = M_PI * (double)x / 2;
+  float s0 = sincf_((float)z0), s1 = sincf_((float)z1);
+  float t0 = (cosf((float)z0) - s0) * s1;
+  float t1 = (cosf((float)z1) - s1) * s0;
+  return (t0 + t1) / x;
+}
+
+template <int I>
+struct AxisTaps {
+  static constexpr int NT = NTaps<I>::v;
+  unsigned idx[NT];
+  float w[NT];    // interpolation coefficient
+  float dw[NT];   // d(coefficient)/d(continuous coordinate), up to the factor gm
+  float gm;       // 1 (linear, lanczos) or 0.5*pi*sin(pi*frac) (cosine)
+};
+
+// x: continuous grid coordinate, G1 = G - 1
+template <int I>
+__device__ __forceinline__ void axis_taps(AxisTaps<I>& t, float x, float G1) {
+  if constexpr (I == LANCZOS) {
+    // lanczos_voxel_feature_cuda.cu:57-70: floor is NOT clamped, each tap index is
+    float x0 = floorf(x);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float xi = fminf(fmaxf(x0 + (float)(i - 1), 0.f), G1);
+      t.idx[i] = (unsigned)xi;
+      t.w[i] = lanczos2(x - xi);
+      t.dw[i] = lanczos2_grad(x - xi);
+    }
+    t.gm = 1.f;
+  } else {
+    // voxel_feature_cuda.cu:56-64
+    float x0 = fminf(fmaxf(floorf(x), 0.f), G1);
+    float x1 = fminf(x0 + 1.f, G1);
+    t.idx[0] = (unsigned)x0;
+    t.idx[1] = (unsigned)x1;
+    if constexpr (I == LINEAR) {
+      t.w[0] = x1 - x;
+      t.gm = 1.f;
+    } else {
+      // cosine_voxel_feature_cuda.cu:65-66, 157
+      const float pi = (float)M_PI;
+      float fr = x - x0;
+      t.w[0] = 0.5f * cosf(pi * fr) + 0.5f;
+      t.gm = (float)(0.5 * M_PI) * sinf(pi * fr);
+    }
+    t.w[1] = 1.f - t.w[0];
+    t.dw[0] = -1.f;
+    t.dw[1] = 1.f;
+  }
+}
+
+// voxel_hash_feature_cuda.cu:37-48 (tiny-cuda-nn primes)
+__device__ __forceinline__ unsigned hash3(unsigned x, unsigned y, unsigned z, int T) {
+  unsigned r = 0;
+  r ^= x * 1u;
+  r ^= y * 2654435761u;
+  r ^= z * 805459861u;
+  return r % (unsigned)T;
+}
+
+// --- stencil of one (point, sub-grid) -----------------------------------------------------------
+template <int TOPO> struct NDims { static constexpr int v = (TOPO == TRIPLANE) ? 2 : (TOPO == TRILINE ? 1 : 3); };
+
+template <int TOPO, int I>
+struct Stencil {
+  static constexpr int ND = NDims<TOPO>::v;
+  static constexpr int NT = NTaps<I>::v;
+  AxisTaps<I> ax[ND];
+  float scale[ND];       // (G-1)/(max-min) of the axis
+  int axis[ND];          // which query component (0,1,2) each stencil axis follows
+  long long base;        // float offset of the sub-grid inside the feature tensor
+  unsigned stride[ND];   // dense strides in floats (incl. D)
+  int T;                 // hash table size of the level
+  int D;
+};
+
+template <int TOPO, int I>
+__device__ __forceinline__ void make_stencil(Stencil<TOPO, I>& st, const GridDesc& g, int s, const float* __restrict__ q) {
+  constexpr int ND = NDims<TOPO>::v;
+  st.D = g.D;
+  st.T = 0;
+  if constexpr (TOPO == VOXEL) {
+    st.base = 0;
+    st.stride[0] = (unsigned)(g.G[1] * g.G[2] * g.D);
+    st.stride[1] = (unsigned)(g.G[2] * g.D);
+    st.stride[2] = (unsigned)g.D;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) st.axis[a] = a;
+  } else if constexpr (TOPO == TRIPLANE) {
+    // common_triplane.cuh:23-33: plane 0 = (x,y), 1 = (y,z), 2 = (z,x)
+    st.base = (long long)s * g.G[0] * g.G[0] * g.D;
+    st.stride[0] = (unsigned)(g.G[0] * g.D);
+    st.stride[1] = (unsigned)g.D;
+    st.axis[0] = s;
+    st.axis[1] = (s + 1) % 3;
+  } else if constexpr (TOPO == TRILINE) {
+    st.base = (long long)s * g.G[0] * g.D;
+    st.stride[0] = (unsigned)g.D;
+    st.axis[0] = s;
+  } else {
+    st.base = g.lvlOff[s];
+    st.T = g.lvlT[s];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { st.axis[a] = a; st.stride[a] = 0; }
+  }
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    int c = st.axis[a];
+    float G1 = (TOPO == HASH) ? (float)g.lvlG[s] - 1.f : (float)g.G[(TOPO == VOXEL) ? a : 0] - 1.f;
+    float sc = G1 / (g.mx[c] - g.mn[c]);
+    st.scale[a] = sc;
+    axis_taps<I>(st.ax[a], (q[c] - g.mn[c]) * sc, G1);
+  }
+}
+
+template <int TOPO, int I>
+__device__ __forceinline__ long long cell_offset(const Stencil<TOPO, I>& st, int i, int j, int k) {
+  constexpr int ND = NDims<TOPO>::v;
+  if constexpr (TOPO == HASH) {
+    return st.base + (long long)hash3(st.ax[0].idx[i], st.ax[1].idx[j], st.ax[2].idx[k], st.T) * st.D;
+  } else {
+    unsigned o = st.ax[0].idx[i] * st.stride[0];
+    if constexpr (ND > 1) o += st.ax[1].idx[j] * st.stride[1];
+    if constexpr (ND > 2) o += st.ax[2].idx[k] * st.stride[2];
+    return st.base + (long long)o;
+  }
+}
+
+// loop helper over all tap combinations of the stencil
+#define NDJIR_FOR_TAPS(ND, NT)                          \
+  _Pragma("unroll") for (int i = 0; i < NT; ++i)        \
+  _Pragma("unroll") for (int j = 0; j < ((ND) > 1 ? NT : 1); ++j) \
+  _Pragma("unroll") for (int k = 0; k < ((ND) > 2 ? NT : 1); ++k)
+
+template <int TOPO, int I>
+__device__ __forceinline__ float tap_w(const Stencil<TOPO, I>& st, int i, int j, int k) {
+  constexpr int ND = NDims<TOPO>::v;
+  float w = st.ax[0].w[i];
+  if constexpr (ND > 1) w = w * st.ax[1].w[j];
+  if constexpr (ND > 2) w = w * st.ax[2].w[k];
+  return w;
+}
+
+// derivative weight of the tap along stencil axis a (before scale*gm)
+template <int TOPO, int I>
+__device__ __forceinline__ float tap_dw(const Stencil<TOPO, I>& st, int a, int i, int j, int k) {
+  constexpr int ND = NDims<TOPO>::v;
+  float w = (a == 0) ? st.ax[0].dw[i] : st.ax[0].w[i];
+  if constexpr (ND > 1) w = w * ((a == 1) ? st.ax[1].dw[j] : st.ax[1].w[j]);
+  if constexpr (ND > 2) w = w * ((a == 2) ? st.ax[2].dw[k] : st.ax[2].w[k]);
+  return w;
+}
+
+// vector access helpers
+template <int VW> struct Vec;
+template <> struct Vec<4> { using T = float4; };
+template <> struct Vec<2> { using T = float2; };
+template <> struct Vec<1> { using T = float; };
+
+template <int VW>
+__device__ __forceinline__ void vload(float* dst, const float* __restrict__ src) {
+  if constexpr (VW == 4) { float4 v = *reinterpret_cast<const float4*>(src); dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+  else if constexpr (VW == 2) { float2 v = *reinterpret_cast<const float2*>(src); dst[0] = v.x; dst[1] = v.y; }
+  else dst[0] = *src;
+}
+
+// output channel index (reference layouts)
+template <int TOPO>
+__device__ __forceinline__ long long out_index(const GridDesc& g, long long P, long long b, int s, int d) {
+  if constexpr (TOPO == VOXEL) return b * g.D + d;
+  else if constexpr (TOPO == HASH) return (long long)d * g.S * P + (long long)s * P + b;   // (D, L, P)
+  else return b * (g.D * 3) + d * 3 + s;                                                  // plane fastest
+}
+
+#define NDJIR_GRID_THREAD_PROLOGUE                                                   \
+  long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;                  \
+  long long total = P * g.S;                                                         \
+  for (; tid < total; tid += (long long)gridDim.x * blockDim.x) {                    \
+    int s = (int)(tid / P);                                                          \
+    long long b = tid - (long long)s * P;                                            \
+    float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};                 \
+    Stencil<TOPO, I> st;                                                             \
+    make_stencil<TOPO, I>(st, g, s, q);
+
+#define NDJIR_GRID_THREAD_EPILOGUE }
+
+// ------------------------------------------------------------------------------------------------
+// forward: out = sum_taps w * F           (voxel_feature_cuda.cu:33-98 and siblings)
+// ------------------------------------------------------------------------------------------------
+template <int TOPO, int I, int VW, bool ACCUM>
+__global__ void __launch_bounds__(256) k_query(long long P, float* __restrict__ out, const float* __restrict__ query,
+                                               const float* __restrict__ feature, GridDesc g) {
+  constexpr int ND = NDims<TOPO>::v, NT = NTaps<I>::v;
+  NDJIR_GRID_THREAD_PROLOGUE
+  for (int d0 = 0; d0 < g.D; d0 += VW) {
+    float acc[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) acc[v] = 0.f;
+    NDJIR_FOR_TAPS(ND, NT) {
+      float f[VW];
+      vload<VW>(f, feature + cell_offset(st, i, j, k) + d0);
+      float w = tap_w(st, i, j, k);
+#pragma unroll
+      for (int v = 0; v < VW; ++v) acc[v] += w * f[v];
+    }
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+      long long o = out_index<TOPO>(g, P, b, s, d0 + v);
+      out[o] = ACCUM ? out[o] + acc[v] : acc[v];
+    }
+  }
+  NDJIR_GRID_THREAD_EPILOGUE
+}
+
+// ------------------------------------------------------------------------------------------------
+// grad_query: gq[b, axis] += sum_d og[d] * scale * gm * sum_taps dw * F   (voxel_feature_cuda.cu:124-204)
+// grad_query_grad_grad_output: ggo[d] = sum_axis gg[axis] * scale * gm * sum_taps dw * F  (:328-412)
+// MODE 0 = grad_query (atomic into gq), MODE 1 = ggo
+// ------------------------------------------------------------------------------------------------
+template <int TOPO, int I, int VW, int MODE, bool ACCUM>
+__global__ void __launch_bounds__(256) k_dquery(long long P, float* __restrict__ dst, const float* __restrict__ src,
+                                                const float* __restrict__ query, const float* __restrict__ feature,
+                                                GridDesc g) {
+  constexpr int ND = NDims<TOPO>::v, NT = NTaps<I>::v;
+  NDJIR_GRID_THREAD_PROLOGUE
+  float gq[ND];
+#pragma unroll
+  for (int a = 0; a < ND; ++a) gq[a] = 0.f;
+  for (int d0 = 0; d0 < g.D; d0 += VW) {
+    float ga[ND][VW];
+#pragma unroll
+    for (int a = 0; a < ND; ++a)
+#pragma unroll
+      for (int v = 0; v < VW; ++v) ga[a][v] = 0.f;
+    NDJIR_FOR_TAPS(ND, NT) {
+      float f[VW];
+      vload<VW>(f, feature + cell_offset(st, i, j, k) + d0);
+#pragma unroll
+      for (int a = 0; a < ND; ++a) {
+        float dw = tap_dw(st, a, i, j, k);
+#pragma unroll
+        for (int v = 0; v < VW; ++v) ga[a][v] += dw * f[v];
+      }
+    }
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int v = 0; v < VW; ++v) {
+        float og = src[out_index<TOPO>(g, P, b, s, d0 + v)];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) gq[a] += og * st.scale[a] * st.ax[a].gm * ga[a][v];
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < VW; ++v) {
+        float r = 0.f;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) r += src[b * 3 + st.axis[a]] * st.scale[a] * st.ax[a].gm * ga[a][v];
+        long long o = out_index<TOPO>(g, P, b, s, d0 + v);
+        dst[o] = ACCUM ? dst[o] + r : r;
+      }
+    }
+  }
+  if constexpr (MODE == 0) {
+    if constexpr (TOPO == VOXEL) {
+      // one lane owns the point: plain read-modify-write, no atomics needed
+#pragma unroll
+      for (int a = 0; a < ND; ++a) dst[b * 3 + a] += gq[a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < ND; ++a) atomicAdd(dst + b * 3 + st.axis[a], gq[a]);
+    }
+  }
+  NDJIR_GRID_THREAD_EPILOGUE
+}
+
+// ------------------------------------------------------------------------------------------------
+// scatter kernels:
+//  MODE 0 grad_feature:            gf[cell,d] += og[d] * w                        (:230-286)
+//  MODE 1 grad_query_grad_feature: gf[cell,d] += og[d] * sum_a gg[a]*scale*gm*dw  (:548-614)
+// ------------------------------------------------------------------------------------------------
+template <int TOPO, int I, int VW, int MODE>
+__global__ void __launch_bounds__(256) k_scatter(long long P, float* __restrict__ gf, const float* __restrict__ gg_query,
+                                                 const float* __restrict__ grad_output, const float* __restrict__ query,
+                                                 GridDesc g) {
+  constexpr int ND = NDims<TOPO>::v, NT = NTaps<I>::v;
+  NDJIR_GRID_THREAD_PROLOGUE
+  float ggs[ND];
+  if constexpr (MODE == 1) {
+#pragma unroll
+    for (int a = 0; a < ND; ++a) ggs[a] = gg_query[b * 3 + st.axis[a]] * st.scale[a] * st.ax[a].gm;
+  }
+  for (int d0 = 0; d0 < g.D; d0 += VW) {
+    float og[VW];
+#pragma unroll
+    for (int v = 0; v < VW; ++v) og[v] = grad_output[out_index<TOPO>(g, P, b, s, d0 + v)];
+    NDJIR_FOR_TAPS(ND, NT) {
+      float w;
+      if constexpr (MODE == 0) {
+        w = tap_w(st, i, j, k);
+      } else {
+        w = 0.f;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) w += ggs[a] * tap_dw(st, a, i, j, k);
+      }
+      float* p = gf + cell_offset(st, i, j, k) + d0;
+#pragma unroll
+      for (int v = 0; v < VW; ++v) atomicAdd(p + v, og[v] * w);
+    }
+  }
+  NDJIR_GRID_THREAD_EPILOGUE
+}
+
+// ------------------------------------------------------------------------------------------------
+// grad_query_grad_query, linear dense voxel only (voxel_feature_cuda.cu:440-520). Accumulates.
+// ------------------------------------------------------------------------------------------------
+template <int VW>
+__global__ void __launch_bounds__(256) k_voxel_gq_gq(long long P, float* __restrict__ gq, const float* __restrict__ gg_query,
+                                                     const float* __restrict__ grad_output, const float* __restrict__ query,
+                                                     const float* __restrict__ feature, GridDesc g) {
+  constexpr int TOPO = VOXEL, I = LINEAR;
+  NDJIR_GRID_THREAD_PROLOGUE
+  float p0 = st.ax[0].w[0], p1 = st.ax[0].w[1], q0 = st.ax[1].w[0], q1 = st.ax[1].w[1], r0 = st.ax[2].w[0], r1 = st.ax[2].w[1];
+  float sx = st.scale[0], sy = st.scale[1], sz = st.scale[2];
+  float ggx = gg_query[b * 3], ggy = gg_query[b * 3 + 1], ggz = gg_query[b * 3 + 2];
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (int d0 = 0; d0 < g.D; d0 += VW) {
+    float f[2][2][2][VW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) vload<VW>(f[i][j][k], feature + cell_offset(st, i, j, k) + d0);
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+      float go = grad_output[b * g.D + d0 + v];
+      float ti = go * sy * sz * (p0 * (f[0][0][0][v] - f[0][0][1][v] - f[0][1][0][v] + f[0][1][1][v]) +
+                                 p1 * (f[1][0][0][v] - f[1][0][1][v] - f[1][1][0][v] + f[1][1][1][v]));
+      float tj = go * sx * sz * (q0 * (f[0][0][0][v] - f[0][0][1][v] - f[1][0][0][v] + f[1][0][1][v]) +
+                                 q1 * (f[0][1][0][v] - f[0][1][1][v] - f[1][1][0][v] + f[1][1][1][v]));
+      float tk = go * sx * sy * (r0 * (f[0][0][0][v] - f[0][1][0][v] - f[1][0][0][v] + f[1][1][0][v]) +
+                                 r1 * (f[0][0][1][v] - f[0][1][1][v] - f[1][0][1][v] + f[1][1][1][v]));
+      ax += ggy * tk + ggz * tj;
+      ay += ggz * ti + ggx * tk;
+      az += ggx * tj + ggy * ti;
+    }
+  }
+  gq[b * 3] += ax; gq[b * 3 + 1] += ay; gq[b * 3 + 2] += az;
+  NDJIR_GRID_THREAD_EPILOGUE
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampled total-variation loss (total_variation_loss*_cuda.cu); backward always accumulates.
+// ------------------------------------------------------------------------------------------------
+template <int TOPO, int VW, bool BWD>
+__global__ void __launch_bounds__(256) k_tv(long long P, float* __restrict__ dst, const float* __restrict__ grad_output,
+                                            const float* __restrict__ query, const float* __restrict__ feature,
+                                            GridDesc g, int sym_backward) {
+  constexpr int I = LINEAR;
+  constexpr int ND = NDims<TOPO>::v;
+  NDJIR_GRID_THREAD_PROLOGUE
+  long long o0 = cell_offset(st, 0, 0, 0);
+  long long oa[ND];
+  oa[0] = cell_offset(st, 1, 0, 0);
+  if constexpr (ND > 1) oa[1] = cell_offset(st, 0, 1, 0);
+  if constexpr (ND > 2) oa[2] = cell_offset(st, 0, 0, 1);
+  for (int d0 = 0; d0 < g.D; d0 += VW) {
+    float f0[VW], fa[ND][VW];
+    vload<VW>(f0, feature + o0 + d0);
+#pragma unroll
+    for (int a = 0; a < ND; ++a) vload<VW>(fa[a], feature + oa[a] + d0);
+#pragma unroll
+    for (int v = 0; v < VW; ++v) {
+      float del[ND], s2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < ND; ++a) { del[a] = fa[a][v] - f0[v]; s2 += del[a] * del[a]; }
+      long long o = out_index<TOPO>(g, P, b, s, d0 + v);
+      if constexpr (!BWD) {
+        dst[o] = sqrtf(s2);
+      } else {
+        // total_variation_loss_cuda.cu:158-170: rsqrt(.. + 1e-12) evaluated in double
+        double common = (double)grad_output[o] * (1.0 / sqrt((double)s2 + 1e-12));
+        double gsum = 0.0;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          double ga = common * (double)del[a];
+          gsum += ga;
+          atomicAdd(dst + oa[a] + d0 + v, (float)ga);
+        }
+        if (sym_backward) atomicAdd(dst + o0 + d0 + v, (float)(-gsum));
+      }
+    }
+  }
+  NDJIR_GRID_THREAD_EPILOGUE
+}
+
+// hash_index (voxel_hash_feature_cuda.cu:54-100): 8 hashed corner indices as floats
+__global__ void __launch_bounds__(256) k_hash_index(long long P, float* __restrict__ out, const float* __restrict__ query,
+                                                    GridDesc g) {
+  constexpr int TOPO = HASH, I = LINEAR;
+  NDJIR_GRID_THREAD_PROLOGUE
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        out[b * 8 + i * 4 + j * 2 + k] = (float)hash3(st.ax[0].idx[i], st.ax[1].idx[j], st.ax[2].idx[k], st.T);
+  NDJIR_GRID_THREAD_EPILOGUE
+}
+
+__global__ void __launch_bounds__(256) k_zero(long long n, float* __restrict__ p) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  long long n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  bool aligned = ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+  if (aligned) {
+    for (long long j = i; j < n4; j += stride) p4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long j = (n4 << 2) + i; j < n; j += stride) p[j] = 0.f;
+  } else {
+    for (long long j = i; j < n; j += stride) p[j] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------------
+static inline int grid_blocks(long long threads) {
+  long long b = (threads + 255) / 256;
+  const long long cap = 256LL * 16;   // 256 CUs x 16 blocks; grid-stride beyond that
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static inline int pick_vw(int D) { return (D % 4 == 0) ? 4 : ((D % 2 == 0) ? 2 : 1); }
+
+void zero_fill(float* p, long long n, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_zero, dim3(grid_blocks((n + 3) / 4)), dim3(256), 0, stream, n, p);
+}
+
+#define NDJIR_DISPATCH_VW(VWV, ...)                    \
+  switch (VWV) {                                       \
+    case 4: { constexpr int VW = 4; __VA_ARGS__; } break; \
+    case 2: { constexpr int VW = 2; __VA_ARGS__; } break; \
+    default: { constexpr int VW = 1; __VA_ARGS__; } break; \
+  }
+
+#define NDJIR_DISPATCH_TI(TOPOV, INTERPV, ...)                                              \
+  switch ((TOPOV) * 3 + (INTERPV)) {                                                        \
+    case 0: { constexpr int TOPO = VOXEL, I = LINEAR; __VA_ARGS__; } break;                 \
+    case 1: { constexpr int TOPO = VOXEL, I = COSINE; __VA_ARGS__; } break;                 \
+    case 2: { constexpr int TOPO = VOXEL, I = LANCZOS; __VA_ARGS__; } break;                \
+    case 3: { constexpr int TOPO = TRIPLANE, I = LINEAR; __VA_ARGS__; } break;              \
+    case 4: { constexpr int TOPO = TRIPLANE, I = COSINE; __VA_ARGS__; } break;              \
+    case 5: { constexpr int TOPO = TRIPLANE, I = LANCZOS; __VA_ARGS__; } break;             \
+    case 6: { constexpr int TOPO = TRILINE, I = LINEAR; __VA_ARGS__; } break;               \
+    case 7: { constexpr int TOPO = TRILINE, I = COSINE; __VA_ARGS__; } break;               \
+    case 8: { constexpr int TOPO = TRILINE, I = LANCZOS; __VA_ARGS__; } break;              \
+    case 9: { constexpr int TOPO = HASH, I = LINEAR; __VA_ARGS__; } break;                  \
+    case 11: { constexpr int TOPO = HASH, I = LANCZOS; __VA_ARGS__; } break;                \
+    default: return NDJIR_ERR_UNSUPPORTED;                                                  \
+  }
+
+int launch_query(int interp, const GridDesc& g, long long P, float* out, const float* query, const float* feature,
+                 bool accum, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  int blocks = grid_blocks(P * g.S);
+  NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
+    if (accum) hipLaunchKernelGGL((k_query<TOPO, I, VW, true>), dim3(blocks), dim3(256), 0, stream, P, out, query, feature, g);
+    else hipLaunchKernelGGL((k_query<TOPO, I, VW, false>), dim3(blocks), dim3(256), 0, stream, P, out, query, feature, g);
+  }))
+  return ndjir_check_launch();
+}
+
+// mode 0: grad_query (dst = gq (P,3), src = grad_output); mode 1: ggo (dst = (P,C), src = gg_query)
+int launch_dquery(int interp, const GridDesc& g, long long P, int mode, float* dst, const float* src, const float* query,
+                  const float* feature, bool accum, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  if (mode == 0 && !accum) zero_fill(dst, P * 3, stream);
+  int blocks = grid_blocks(P * g.S);
+  NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
+    if (mode == 0) hipLaunchKernelGGL((k_dquery<TOPO, I, VW, 0, true>), dim3(blocks), dim3(256), 0, stream, P, dst, src, query, feature, g);
+    else if (accum) hipLaunchKernelGGL((k_dquery<TOPO, I, VW, 1, true>), dim3(blocks), dim3(256), 0, stream, P, dst, src, query, feature, g);
+    else hipLaunchKernelGGL((k_dquery<TOPO, I, VW, 1, false>), dim3(blocks), dim3(256), 0, stream, P, dst, src, query, feature, g);
+  }))
+  return ndjir_check_launch();
+}
+
+// mode 0: grad_feature ; mode 1: grad_query_grad_feature.  The caller zero-fills when !accum.
+int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* gf, const float* gg_query,
+                   const float* grad_output, const float* query, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  int blocks = grid_blocks(P * g.S);
+  NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
+    if (mode == 0) hipLaunchKernelGGL((k_scatter<TOPO, I, VW, 0>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
+    else hipLaunchKernelGGL((k_scatter<TOPO, I, VW, 1>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
+  }))
+  return ndjir_check_launch();
+}
+
+int launch_voxel_gq_gq(const GridDesc& g, long long P, float* gq, const float* gg_query, const float* grad_output,
+                       const float* query, const float* feature, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  int blocks = grid_blocks(P);
+  NDJIR_DISPATCH_VW(pick_vw(g.D), {
+    hipLaunchKernelGGL((k_voxel_gq_gq<VW>), dim3(blocks), dim3(256), 0, stream, P, gq, gg_query, grad_output, query, feature, g);
+  })
+  return ndjir_check_launch();
+}
+
+int launch_tv(const GridDesc& g, long long P, bool bwd, float* dst, const float* grad_output, const float* query,
+              const float* feature, int sym_backward, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  int blocks = grid_blocks(P * g.S);
+#define NDJIR_TV_CASE(T)                                                                                         \
+  NDJIR_DISPATCH_VW(pick_vw(g.D), {                                                                              \
+    if (bwd) hipLaunchKernelGGL((k_tv<T, VW, true>), dim3(blocks), dim3(256), 0, stream, P, dst, grad_output, query, feature, g, sym_backward); \
+    else hipLaunchKernelGGL((k_tv<T, VW, false>), dim3(blocks), dim3(256), 0, stream, P, dst, grad_output, query, feature, g, sym_backward);    \
+  })
+  switch (g.topo) {
+    case VOXEL: NDJIR_TV_CASE(VOXEL) break;
+    case TRIPLANE: NDJIR_TV_CASE(TRIPLANE) break;
+    case TRILINE: NDJIR_TV_CASE(TRILINE) break;
+    case HASH: NDJIR_TV_CASE(HASH) break;
+    default: return NDJIR_ERR_UNSUPPORTED;
+  }
+#undef NDJIR_TV_CASE
+  return ndjir_check_launch();
+}
+
+int launch_hash_index(const GridDesc& g, long long P, float* out, const float* query, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  hipLaunchKernelGGL(k_hash_index, dim3(grid_blocks(P)), dim3(256), 0, stream, P, out, query, g);
+  return ndjir_check_launch();
+}
+
+}  // namespace ndjir

@@ -1,0 +1,151 @@
+"""ctypes binding of libndjir_hip.so (the C ABI declared in include/ndjir_hip.h).
+
+This replaces the reference's `import voxel_feature_cuda` etc. (pybind11 modules, one per .cu;
+python/grid_feature/voxel_feature.py:21).  The library is built in-tree by
+`__graft_entry__.build()` / `make -C ndjir_amd/csrc` for gfx950.  There is NO fallback: if the
+shared object is missing or a kernel launch fails, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "_lib", "libndjir_hip.so")
+
+_vp = ctypes.c_void_p
+_CT = {"i": ctypes.c_int, "f": ctypes.c_float, "p": _vp, "F": ctypes.POINTER(ctypes.c_float),
+       "I": ctypes.POINTER(ctypes.c_int), "l": ctypes.c_longlong}
+
+# signature strings (without the trailing stream): i=int f=float l=long long p=device pointer
+# F=float[3] host  I=int[3] host
+_VOX_TAIL, _PLN_TAIL, _HSH_TAIL = "IiFFi", "iiFFi", "ifiiiFFi"
+
+
+def _family(prefix, fwd, tail):
+    return {
+        f"{prefix}_{fwd}": "ippp" + tail,
+        f"{prefix}_grad_query": "ipppp" + tail + "i",
+        f"{prefix}_grad_feature": "ippp" + tail + "i",
+        f"{prefix}_grad_query_grad_grad_output": "ipppp" + tail + "i",
+        f"{prefix}_grad_query_grad_feature": "ipppp" + tail + "i",
+    }
+
+
+SIGS = {
+    "zero": "pl",
+    "ray_aabb_intersection": "ipppppiiFF",
+    "ray_sphere_intersection": "ipppppiif",
+    "inverse_transform_sample_uniform_directions": "ippppiiiif",
+    "inverse_transform_sample_importance_directions": "ipppppiiiif",
+    "squareplus_forward": "ippf",
+    "squareplus_backward": "ipppfi",
+    "voxel_feature_grad_query_grad_query": "ippppp" + _VOX_TAIL + "i",
+    "voxel_feature_grad_feature_grad_grad_output": "ippp" + _VOX_TAIL + "i",
+    "voxel_feature_grad_feature_grad_query": "ipppp" + _VOX_TAIL + "i",
+    "total_variation_loss_tv_loss_on_voxel": "ipppIiFFi",
+    "total_variation_loss_tv_loss_on_voxel_backward": "ippppIiFFiii",
+    "total_variation_loss_on_triplane_tv_loss_on_triplane": "ipppiiFFi",
+    "total_variation_loss_on_triplane_tv_loss_on_triplane_backward": "ippppiiFFiii",
+    "total_variation_loss_on_triline_tv_loss_on_triline": "ipppiiFFi",
+    "total_variation_loss_on_triline_tv_loss_on_triline_backward": "ippppiiFFiii",
+    "total_variation_loss_on_voxel_hash_tv_loss_on_voxel_hash": "ipppifiiiFFi",
+    "total_variation_loss_on_voxel_hash_tv_loss_on_voxel_hash_backward": "ippppifiiiFFiii",
+}
+for _p in ("voxel_feature", "cosine_voxel_feature", "lanczos_voxel_feature"):
+    SIGS.update(_family(_p, "query_on_voxel", _VOX_TAIL))
+for _p in ("triplane_feature", "cosine_triplane_feature", "lanczos_triplane_feature"):
+    SIGS.update(_family(_p, "query_on_triplane", _PLN_TAIL))
+for _p in ("triline_feature", "cosine_triline_feature", "lanczos_triline_feature"):
+    SIGS.update(_family(_p, "query_on_triline", _PLN_TAIL))
+for _p in ("voxel_hash_feature", "lanczos_voxel_hash_feature"):
+    SIGS.update(_family(_p, "voxel_hash_feature", _HSH_TAIL))
+    SIGS[f"{_p}_hash_index"] = "ippiiFFi"
+
+_lib = None
+_fns = {}
+
+
+class NdjirHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared object (no GPU needed for loading / symbol lookup)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise NdjirHipError(
+                f"{SO_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback).")
+        _lib = ctypes.CDLL(SO_PATH)
+        _lib.ndjir_version.restype = ctypes.c_char_p
+        _lib.ndjir_hash_num_params.restype = ctypes.c_longlong
+        _lib.ndjir_hash_num_params.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        _lib.ndjir_hash_grid_size.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int]
+        _lib.ndjir_hash_table_size.argtypes = [ctypes.c_int, ctypes.c_int]
+    return _lib
+
+
+def register(sigs):
+    """Add signatures of further entry points (used by other op modules)."""
+    SIGS.update(sigs)
+
+
+def _fn(name):
+    f = _fns.get(name)
+    if f is None:
+        lib = load()
+        f = getattr(lib, "ndjir_" + name)
+        f.argtypes = [_CT[c] for c in SIGS[name]] + [_vp]
+        f.restype = ctypes.c_int
+        _fns[name] = (f, SIGS[name])
+        f = _fns[name]
+    return f
+
+
+def _f3(v):
+    return (ctypes.c_float * 3)(float(v[0]), float(v[1]), float(v[2]))
+
+
+def _i3(v):
+    return (ctypes.c_int * 3)(int(v[0]), int(v[1]), int(v[2]))
+
+
+def call(name, *args):
+    """Launch entry point `ndjir_<name>` on the current torch HIP stream."""
+    f, sig = _fn(name)
+    if len(args) != len(sig):
+        raise TypeError(f"ndjir_{name}: expected {len(sig)} arguments, got {len(args)}")
+    cargs = []
+    for c, v in zip(sig, args):
+        if c == "p":
+            if v is None:
+                cargs.append(None)
+            else:
+                if not (v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()):
+                    raise NdjirHipError(f"ndjir_{name}: tensors must be contiguous float32 on the GPU "
+                                        f"(got {v.dtype}, {v.device}, contiguous={v.is_contiguous()})")
+                cargs.append(v.data_ptr())
+        elif c == "F":
+            cargs.append(_f3(v))
+        elif c == "I":
+            cargs.append(_i3(v))
+        elif c == "f":
+            cargs.append(float(v))
+        else:
+            cargs.append(int(v))
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = f(*cargs, stream)
+    if rc != 0:
+        raise NdjirHipError(f"ndjir_{name} failed with status {rc}")
+
+
+def symbols():
+    """Every symbol include/ndjir_hip.h declares (for the load/export test)."""
+    return ["ndjir_" + n for n in SIGS] + ["ndjir_version", "ndjir_hash_force_align", "ndjir_hash_grid_size",
+                                            "ndjir_hash_table_size", "ndjir_hash_num_params"]
+
+
+def hash_num_params(G0, growth_factor, T0, L, D):
+    return int(load().ndjir_hash_num_params(int(G0), float(growth_factor), int(T0), int(L), int(D)))

@@ -1,0 +1,95 @@
+"""Training loss of the hot path.
+
+Reference: python/loss.py:27-192 (total_loss).  The stratified / background random samples that
+the reference draws with fixed seeds (:40-41) are explicit inputs in `rand` (see
+renderer.make_rand).
+"""
+import torch
+
+from . import functions as F
+from . import parameter as P
+from .grid_feature import (total_variation_loss, total_variation_loss_on_triline,  # noqa: F401
+                           total_variation_loss_on_triplane, total_variation_loss_on_voxel_hash)
+from .renderer import pb_render
+from .sampler import sample_points
+
+
+def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand, record=None):
+    """camloc (B,3), raydir (B,R,3), color_gt (B,R,3), obj_mask (B,R,1) or None, cos_anneal_ratio (1,)."""
+    B, R, _ = color_gt.shape
+    tr = conf.train
+
+    # Points on ray (loss.py:40-43)
+    x_fg, t_fg, x_bg, t_bg, mask = sample_points(camloc, raydir, rand["stratified_sample"],
+                                                 rand["background_sample"], conf, record)
+    x_fg = x_fg.requires_grad_(True)
+
+    res = pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, conf, rand)
+    zero = torch.zeros((), dtype=x_fg.dtype, device=x_fg.device)
+    N = x_fg.shape[2]
+
+    # RGB loss (loss.py:59-66)
+    color = res["color_pixel"]
+    err = (color - color_gt).abs() if tr.rgb_loss == "l1" else (color - color_gt) ** 2
+    if tr.mask_weight > 0.0:
+        loss_rgb = (err * obj_mask).sum() / (obj_mask.sum() + 1e-5)
+    else:
+        loss_rgb = err.sum() / (B * R)
+
+    denorm = mask.sum() * N + 1e-5
+
+    # Eikonal loss (loss.py:68-76)
+    loss_eikonal = zero
+    if tr.eikonal_weight > 0.0:
+        g = res["grad_x_fg"]
+        gn = torch.sqrt((g * g).sum(-1, keepdim=True))
+        loss_eikonal = (((gn - 1) * mask) ** 2.0).sum() / denorm
+
+    # TV loss over every `.../<grid>_feature/F` parameter (loss.py:78-105)
+    loss_tv = zero
+    tv_loss_map = dict(voxel_feature=F.tv_loss_on_voxel, voxel_hash_feature=F.tv_loss_on_voxel_hash,
+                       triplane_feature=F.tv_loss_on_triplane, triline_feature=F.tv_loss_on_triline)
+    if conf.geometric_network.voxel.type != "none" and tr.tv_weight > 0.0:
+        for name, feature in P.get_parameters().items():
+            if not name.endswith("feature/F"):
+                continue
+            fn = tv_loss_map[name.split("/")[-2]]
+            tv = fn(x_fg.detach(), feature, sym_backward=tr.tv_sym_backward)
+            loss_tv = loss_tv + (tv * mask).sum() / denorm
+
+    # Mask loss (loss.py:107-115)
+    loss_mask = zero
+    if tr.mask_weight > 0.0:
+        pred = res["obj_mask_pred"].clamp(1e-3, 1.0 - 1e-3)
+        bce = -(obj_mask * torch.log(pred) + (1 - obj_mask) * torch.log(1 - pred))
+        loss_mask = bce.sum() / (mask.sum() + 1e-5)
+
+    # Priors (loss.py:117-166)
+    prior_base_color = zero
+    if tr.base_color_prior_weight > 0.0:
+        bc = res["base_color"] if tr.base_color_prior_sym_backward else res["base_color"].detach()
+        prior_base_color = ((bc - res["base_color_ptb"]).abs() * mask).sum() / denorm
+
+    prior_roughness = reg_std_roughness = zero
+    if tr.roughness_prior_weight > 0.0:
+        pr = (res["roughness"] - conf.roughness_network.prior_value).abs() / res["std_roughness"]
+        prior_roughness = (pr * mask).sum() / denorm
+        reg_std_roughness = (torch.log(res["std_roughness"]).clamp(1e-5, 1e5) * mask).sum() / denorm
+
+    prior_spec = reg_std_spec = zero
+    if tr.specular_reflectance_prior_weight > 0.0:
+        ps = (res["specular_reflectance"] - conf.specular_reflectance_network.prior_value).abs() \
+            / res["std_specular_reflectance"]
+        prior_spec = (ps * mask).sum() / denorm
+        reg_std_spec = (torch.log(res["std_specular_reflectance"]).clamp(1e-5, 1e5) * mask).sum() / denorm
+
+    loss = (loss_rgb + tr.eikonal_weight * loss_eikonal + tr.tv_weight * loss_tv + tr.mask_weight * loss_mask
+            + tr.base_color_prior_weight * prior_base_color + tr.roughness_prior_weight * prior_roughness
+            + tr.specular_reflectance_prior_weight * prior_spec + tr.roughness_prior_weight * reg_std_roughness
+            + tr.specular_reflectance_prior_weight * reg_std_spec)
+
+    return dict(loss=loss, loss_rgb=loss_rgb, loss_eikonal=loss_eikonal, loss_tv=loss_tv, loss_mask=loss_mask,
+                prior_base_color=prior_base_color, prior_roughness=prior_roughness,
+                prior_specular_reflectance=prior_spec, reg_std_roughness=reg_std_roughness,
+                reg_std_specular_reflectance=reg_std_spec, render=res,
+                samples=dict(x_fg=x_fg, t_fg=t_fg, x_bg=x_bg, t_bg=t_bg, mask=mask))

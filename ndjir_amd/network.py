@@ -1,0 +1,285 @@
+"""Networks of the hot path with the reference's function signatures.
+
+Reference: python/network.py -- positional_encoding :96-117, query_on_grid :120-151,
+geometric_network :154-232, base_color_network :235-263, environment_light_network :266-297,
+implicit_illumination_network :300-336, soft_visibility_light_network :339-377,
+photogrammetric_light_network :380-424, roughness_network :427-464,
+specular_reflectance_network :467-509, background_network :512-561.
+
+Parameters live in `ndjir_amd.parameter` under the reference's nnabla scope names (W is (in, out),
+y = x @ W + b).  Grid queries go to the HIP ops of `ndjir_amd.grid_feature`; dense layers run as
+device GEMMs (see DESIGN.md for the hand-written MFMA path that replaces them).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+from . import parameter as P
+from . import parametric_functions as PF
+# these imports attach the ops to the F / PF namespaces (network.py:25-33)
+from .grid_feature import (cosine_triline_feature, cosine_triplane_feature, cosine_voxel_feature,  # noqa: F401
+                           lanczos_triline_feature, lanczos_triplane_feature, lanczos_voxel_feature,
+                           triline_feature, triplane_feature, voxel_feature)
+
+prng = np.random.RandomState(313)  # nnabla.random.prng default seed
+
+
+def seed(s):
+    global prng
+    prng = np.random.RandomState(s)
+
+
+class GeometricInitializer:
+    """network.py:36-56: SAL/IDR-style geometric initialisation (sphere of radius r)."""
+
+    def __init__(self, Di, Do, sigma, zero_start=None, last=False):
+        self.Di, self.Do, self.sigma, self.zero_start, self.last = Di, Do, sigma, zero_start, last
+
+    def __call__(self, shape):
+        w = np.sqrt(self.sigma) * prng.randn(self.Di, self.Do)
+        if self.zero_start is not None:
+            w[self.zero_start:, :] = 0.0
+        if self.last:
+            w[:, 0] = np.sqrt(np.pi / self.Di) * np.ones([self.Di]) + prng.randn(self.Di) * 1e-4
+        return w
+
+
+def _glorot_uniform(shape):
+    """nnabla PF.affine default: UniformInitializer(calc_uniform_lim_glorot(in, out))."""
+    lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+    return prng.uniform(-lim, lim, size=shape)
+
+
+def affine(h, D, use_wn=False, w_init=None, b_init=None, name=None):
+    """network.py:88-93: PF.affine on the last axis inside parameter scope `name`/affine."""
+    assert not use_wn, "weight normalisation (use_wn) is off in every shipped config"
+    Din = h.shape[-1]
+    with P.parameter_scope(name), P.parameter_scope("affine"):
+        W = P.get_parameter_or_create("W", (Din, D), w_init if w_init is not None else _glorot_uniform, True)
+        b = P.get_parameter_or_create("b", (D,), b_init, True)
+    return torch.addmm(b, h.reshape(-1, Din), W).view(h.shape[:-1] + (D,))
+
+
+def softplus(x, beta=100):
+    return TF.softplus(x, beta=beta)
+
+
+def _act(name):
+    return {"relu": torch.relu, "softplus": softplus}[name]
+
+
+def positional_encoding(x, M=6, include_input=True):
+    """network.py:96-117: [x, cos(x_i 2^k), sin(x_i 2^k)] with the band index fastest."""
+    bands = 2.0 ** torch.arange(0, M, dtype=x.dtype, device=x.device)
+    b = (bands.reshape((1,) * x.dim() + (M,)) * x.unsqueeze(-1)).reshape(x.shape[:-1] + (-1,))
+    g = [x, torch.cos(b), torch.sin(b)] if include_input else [torch.cos(b), torch.sin(b)]
+    return torch.cat(g, dim=-1)
+
+
+def _big_normal_init(std):
+    """Device-side N(0, std) initialiser for grids too large to stage through numpy."""
+    def init(shape):
+        gen = torch.Generator(device=P.get_device())
+        gen.manual_seed(int(prng.randint(0, 2 ** 31 - 1)))
+        return torch.randn(tuple(shape), generator=gen, device=P.get_device(), dtype=torch.float32) * std
+    return init
+
+
+def query_on_grid(x, G, D, use_ste, type):
+    """network.py:120-151."""
+    if type == "none":
+        return None
+    n = G ** 3 * D if type.endswith("voxel") else 3 * G * G * D
+    f_init = _big_normal_init(1e-3) if n > (1 << 24) else None
+    if type.endswith("triplaneline"):
+        pre = type[:-len("triplaneline")]
+        feat0 = getattr(PF, pre + "query_on_triplane")(x, G, D, use_ste=use_ste, f_init=f_init)
+        feat1 = getattr(PF, pre + "query_on_triline")(x, G, D, use_ste=use_ste)
+        return torch.cat([feat0, feat1], dim=-1)
+    pre, topo = ("", type) if "_" not in type else type.split("_", 1)
+    pre = pre + "_" if pre else ""
+    return getattr(PF, f"{pre}query_on_{topo}")(x, G, D, use_ste=use_ste, f_init=f_init)
+
+
+def geometric_network(x, conf):
+    """network.py:154-232.  x (..., 3) -> sdf (..., 1), feature (..., 256), gain (1,)."""
+    with P.parameter_scope("geometric-network"):
+        g = conf.geometric_network
+        D, L, M = g.feature_size, g.layers, g.pe_bands
+        act = _act(g.act)
+        use_wn = conf.use_wn
+        skip_layers = list(g.skip_layers)
+        v = g.voxel
+
+        pe_x = positional_encoding(x, M) if M > 0 else x
+        vfeat = query_on_grid(x, v.grid_size, v.feature_size, v.use_ste, v.type)
+        inputs = torch.cat([pe_x, vfeat], dim=-1) if vfeat is not None else pe_x
+        h = inputs
+
+        if not g.geometric_init:
+            for l in range(L - 1):
+                h = affine(h, D, use_wn, name=f"affine-{l:02d}")
+                h = torch.cat([h, pe_x], dim=-1) if l in skip_layers else h
+                h = act(h)
+            h = affine(h, D + 1, use_wn, name=f"affine-{L - 1:02d}")
+        else:
+            r0 = g.initial_sphere_radius
+            Dx = x.shape[-1]
+            Dinputs = inputs.shape[-1]
+            for l in range(L):
+                if l == 0:
+                    w_init = GeometricInitializer(h.shape[-1], D, 2 / D, Dx)
+                    h = act(affine(h, D, use_wn, w_init=w_init, name=f"affine-{l:02d}"))
+                elif l in skip_layers:
+                    w_init = GeometricInitializer(D, D, 2 / (D - Dinputs), -Dinputs)
+                    h = act(affine(h, D, use_wn, w_init=w_init, name=f"affine-{l:02d}"))
+                elif l == L - 1:
+                    Do = 1 + D
+                    w_init = GeometricInitializer(D, Do, 2 / Do, last=True)
+                    h = affine(h, Do, use_wn, w_init=w_init, b_init=np.full((Do,), -r0), name="affine-last")
+                else:
+                    Do = D - Dinputs if l + 1 in skip_layers else D
+                    w_init = GeometricInitializer(h.shape[-1], Do, 2 / Do)
+                    h = act(affine(h, Do, use_wn, w_init=w_init, name=f"affine-{l:02d}"))
+                    if l + 1 in skip_layers:
+                        h = torch.cat([h, inputs], dim=-1)
+                        if g.use_inv_square:
+                            h = h / np.sqrt(2)
+        sdf, feature = h[..., 0:1], h[..., 1:]
+        gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain]), True)
+        gain = torch.exp(gain * 10).clamp(1e-6, 5e4)
+    return sdf, feature, gain
+
+
+def _last_act(name, beta):
+    return {"softplus": lambda v: TF.softplus(v, beta=beta), "relu": torch.relu, "sigmoid": torch.sigmoid}[name]
+
+
+def _hidden(h, D, L, act, use_wn, shift=0):
+    for l in range(L - 1):
+        h = act(affine(h, D, use_wn, name=f"affine-{l - shift:02d}"))
+    return h
+
+
+def _cat_inputs(x, feature, normal, c):
+    inputs = [x] + ([feature] if c.use_geometric_feature else []) + ([normal] if c.use_normal else [])
+    return torch.cat(inputs, dim=-1) if len(inputs) > 1 else x
+
+
+def base_color_network(x, feature, normal, conf):
+    """network.py:235-263."""
+    with P.parameter_scope("base-color-network"):
+        c = conf.base_color_network
+        h = _hidden(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, _act(c.act), conf.use_wn)
+        return torch.sigmoid(affine(h, 3, conf.use_wn, name=f"affine-{c.layers - 1:02d}"))
+
+
+def environment_light_network(light_dirs, conf):
+    """network.py:266-297."""
+    with P.parameter_scope("environment-light-network"):
+        c = conf.environment_light_network
+        h = positional_encoding(light_dirs, c.pe_bands) if c.pe_bands > 0 else light_dirs
+        h = _hidden(h, c.feature_size, c.layers, _act(c.act), conf.use_wn)
+        h = affine(h, c.channels, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        out = _last_act(c.act_last, c.inverse_black_degree)(h)
+        if c.upper_bound > 0:
+            out = out.clamp(0.0, c.upper_bound)
+        return out
+
+
+def implicit_illumination_network(x, feature, normal, conf):
+    """network.py:300-336."""
+    with P.parameter_scope("implicit-illumination-network"):
+        c = conf.implicit_illumination_network
+        if not c.use_me:
+            return torch.zeros(x.shape[:-1] + (1,), dtype=x.dtype, device=x.device)
+        h = _hidden(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, _act(c.act), conf.use_wn)
+        h = affine(h, c.channels, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        return _last_act(c.act_last, c.inverse_black_degree)(h)
+
+
+def soft_visibility_light_network(x, light_dirs, feature, normal, conf):
+    """network.py:339-377."""
+    with P.parameter_scope("soft-visibility-light-network"):
+        c = conf.soft_visibility_light_network
+        pe = positional_encoding(light_dirs, c.pe_bands) if c.pe_bands > 0 else light_dirs
+        inputs = [x, pe] + ([feature] if c.use_geometric_feature else []) + ([normal] if c.use_normal else [])
+        h = _hidden(torch.cat(inputs, dim=-1), c.feature_size, c.layers, _act(c.act), conf.use_wn)
+        h = affine(h, c.channels, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        return _last_act(c.act_last, c.inverse_black_degree)(h)
+
+
+def photogrammetric_light_network(x, camloc, view, feature, normal, conf):
+    """network.py:380-424."""
+    with P.parameter_scope("photogrammetric-light-network"):
+        c = conf.photogrammetric_light_network
+        B, R, N, _ = x.shape
+        view = view.expand(B, R, N, 3)
+        pe_view = positional_encoding(view, c.pe_bands) if c.pe_bands > 0 else view
+        inputs = [x, pe_view, feature, normal]
+        if c.use_inverse_distance:
+            d = x - camloc.reshape(B, 1, 1, 3)
+            dist2 = torch.sqrt((d * d).sum(-1, keepdim=True)) ** 2
+            inputs.append(1.0 / (dist2 + 1e-5))
+        h = _hidden(torch.cat(inputs, dim=-1), c.feature_size, c.layers, _act(c.act), conf.use_wn)
+        h = affine(h, c.channels, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain_lv_start]), False)
+        return torch.sigmoid(gain.reshape((1,) * h.dim()) * h)
+
+
+def roughness_network(x, feature, normal, conf):
+    """network.py:427-464 (hidden layers are named affine--1, affine-00, affine-01; :450-454)."""
+    with P.parameter_scope("roughness-network"):
+        c = conf.roughness_network
+        h = _hidden(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, _act(c.act), conf.use_wn, shift=1)
+        h = affine(h, 2, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        h0, h1 = h[..., 0:1], h[..., 1:2]
+        std = TF.softplus(h1)
+        r = torch.sigmoid(h0)
+        if conf.specular_brdf.model == "filament" and conf.specular_brdf.remap:
+            r = r ** 2
+        return r.clamp(c.lower_bound, 1.0), std
+
+
+def specular_reflectance_network(x, feature, normal, conf):
+    """network.py:467-509."""
+    with P.parameter_scope("specular-reflectance-network"):
+        c = conf.specular_reflectance_network
+        Do = c.channels
+        if c.fixme:
+            return torch.full(x.shape[:-1] + (Do,), 0.04, dtype=x.dtype, device=x.device), None
+        h = _hidden(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, _act(c.act), conf.use_wn, shift=1)
+        h = affine(h, Do * 2, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        h0, h1 = h[..., :-Do], h[..., Do:]
+        std = TF.softplus(h1)
+        s = torch.sigmoid(h0)
+        if conf.specular_brdf.model == "filament" and conf.specular_brdf.remap:
+            s = 0.16 * (s ** 2)
+        else:
+            s = c.upper_bound_scale * s
+        return s, std
+
+
+def background_network(x, view, delta, conf):
+    """network.py:512-561.  x (B,R,N,4) inverted-sphere coordinates."""
+    with P.parameter_scope("background-network"):
+        c = conf.background_network
+        B, R, N, _ = x.shape
+        act = _act(c.act)
+        with P.parameter_scope("geometric-network"):
+            h = positional_encoding(x, c.pe_bands0) if c.pe_bands0 > 0 else x
+            h = _hidden(h, c.feature_size0, c.layers0, act, conf.use_wn)
+            h = affine(h, c.feature_size0 + 1, conf.use_wn, name=f"affine-{c.layers0 - 1:02d}")
+            density, feature = softplus(h[..., 0:1], 100), h[..., 1:]
+            alpha = 1 - torch.exp(-density * delta)
+        with P.parameter_scope("lighting-network"):
+            view = view.expand(B, R, N, 3)
+            if c.pe_bands1 > 0:
+                h = torch.cat([x, feature, view, positional_encoding(view, c.pe_bands1)], dim=-1)
+            else:
+                h = torch.cat([x, feature, view], dim=-1)
+            h = _hidden(h, c.feature_size1, c.layers1, act, conf.use_wn)
+            color = torch.sigmoid(affine(h, 3, conf.use_wn, name=f"affine-{c.layers1 - 1:02d}"))
+    return alpha, color

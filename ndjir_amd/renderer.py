@@ -1,0 +1,205 @@
+"""Physically-based volume renderer.
+
+Reference: python/renderer.py -- pb_render :32-209, render_image :212-272.
+
+The reference draws its light-sampling CDF tables and the base-colour perturbation with fixed
+seeds inside the graph (`F.rand(seed=412/124/810/108)` :97-98,131-132; `F.randn(seed=913)` :191),
+i.e. they are constants of the step.  Here they are explicit inputs (`rand` dict:
+diffuse_cdf_the, diffuse_cdf_phi, specular_cdf_the, specular_cdf_phi, noise) so that every
+backend sees identical values; `make_rand` draws them with the configured seeds.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .grid_feature import grad as nn_grad
+from .helper import generate_all_pixels, generate_raydir_camloc
+from .network import (background_network, base_color_network, environment_light_network, geometric_network,
+                      implicit_illumination_network, photogrammetric_light_network, roughness_network,
+                      soft_visibility_light_network, specular_reflectance_network)
+from .sampler import sample_importance_directions, sample_points, sample_uniform_directions
+from .specular_brdf import dot, specular_brdf_model
+
+
+def make_rand(B, R, conf, device, n_fg=None, include_samples=True):
+    """Draw the step's random tensors with the reference's seeds (default.yaml:115-120, 146)."""
+    r = conf.renderer
+    N0, Nb, nt = r.n_samples0, r.n_bg_samples, r.n_thetas
+    N = n_fg if n_fg is not None else r.n_samples0 + r.n_samples1 * r.n_upsamples
+
+    def uni(seed, shape, lo=0.0, hi=1.0):
+        return torch.from_numpy(np.random.RandomState(seed).uniform(lo, hi, size=shape).astype(np.float32)).to(device)
+
+    out = dict(
+        diffuse_cdf_the=uni(r.diffuse_cdf_the_seed, (B, R, nt)),
+        diffuse_cdf_phi=uni(r.diffuse_cdf_phi_seed, (B, R, 2 * nt)),
+        specular_cdf_the=uni(r.specular_cdf_the_seed, (B, R, nt)),
+        specular_cdf_phi=uni(r.specular_cdf_phi_seed, (B, R, 2 * nt)),
+        noise=torch.from_numpy(np.random.RandomState(conf.train.base_color_perturb_seed)
+                               .randn(B, R, N, 3).astype(np.float32)).to(device),
+    )
+    if include_samples:
+        out["stratified_sample"] = uni(r.stratified_sample_seed, (B, R, N0, 1))
+        out["background_sample"] = uni(r.background_sample_seed, (B, R, Nb + 1, 1), 1e-5, 1.0)
+    return out
+
+
+def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, conf, rand):
+    """renderer.py:32-209.
+      x_fg (B,R,N,3) requires grad; t_fg (B,R,N+1,1); x_bg (B,R,Nb,4); t_bg (B,R,Nb+1,1);
+      camloc (B,3); raydir (B,R,3); mask (B,R,1,1); cos_anneal_ratio (1,)."""
+    B, R, N, _ = x_fg.shape
+    raydir = raydir.reshape(B, R, 1, 3)
+    view_dir = -raydir
+    eps_normal = conf.renderer.eps_normal
+
+    # Geometric network and its spatial gradient (nn.grad, renderer.py:51-52)
+    sdf_x_fg, feature_x_fg, gain = geometric_network(x_fg, conf)
+    grad_x_fg = nn_grad([sdf_x_fg], [x_fg])[0]
+
+    # Foreground alpha (renderer.py:55-67)
+    car = cos_anneal_ratio.reshape((1,) * x_fg.dim())
+    true_cos = (raydir * grad_x_fg).sum(-1, keepdim=True)
+    iter_cos = -(torch.relu(-true_cos * 0.5 + 0.5) * (1.0 - car) + torch.relu(-true_cos) * car)
+    delta_t_fg = t_fg[:, :, 1:, :] - t_fg[:, :, :-1, :]
+    sdf1 = sdf_x_fg + iter_cos * delta_t_fg * 0.5
+    sdf0 = sdf_x_fg - iter_cos * delta_t_fg * 0.5
+    gain = gain.reshape((1,) * sdf_x_fg.dim())
+    cdf0 = torch.sigmoid(gain * sdf0)
+    cdf1 = torch.sigmoid(gain * sdf1)
+    alpha_fg = ((cdf0 - cdf1 + 1e-5) / (cdf0 + 1e-5)).clamp(0.0, 1.0)
+
+    # Background alpha (renderer.py:70-76)
+    if conf.background_modeling:
+        delta_bg = (t_bg[:, :, 1:, :] - t_bg[:, :, :-1, :]).detach()
+        alpha_bg, color_bg = background_network(x_bg, view_dir, delta_bg, conf)
+    else:
+        alpha_bg = torch.ones(B, R, 1, 1, dtype=x_fg.dtype, device=x_fg.device)
+        color_bg = torch.full((B, R, 1, 3), conf.background_color, dtype=x_fg.dtype, device=x_fg.device)
+
+    # Weights (renderer.py:79-87)
+    alpha = torch.cat([alpha_fg * mask, alpha_bg], dim=2)
+    one_m = 1 - alpha
+    trans = torch.cat([torch.ones_like(one_m[:, :, :1]), torch.cumprod(one_m, dim=2)[:, :, :-1]], dim=2)
+    weights = alpha * trans
+    trans_fg, weights_fg, weights_bg = trans[:, :, :N, :], weights[:, :, :N, :], weights[:, :, N:, :]
+
+    def VR(x, weights=weights_fg, axis=2):
+        return (weights * x).sum(dim=axis)
+
+    # Normal (renderer.py:90-91)
+    grad_pixel = VR(grad_x_fg) + eps_normal
+    normal_pixel = grad_pixel / torch.sqrt((grad_pixel * grad_pixel).sum(-1, keepdim=True))
+
+    n_thetas = conf.renderer.n_thetas
+    M = n_thetas * 2 * n_thetas
+    D = feature_x_fg.shape[-1]
+    x_fg_pixel = VR(x_fg).reshape(B, R, 1, 3).expand(B, R, M, 3)
+    feature_pixel = VR(feature_x_fg).reshape(B, R, 1, D).expand(B, R, M, D)
+    normal_bc = normal_pixel[:, :, None, :].expand(B, R, M, 3)
+
+    # Direct light + visibility (renderer.py:103-110)
+    uniform_light_dir = sample_uniform_directions(normal_pixel, rand["diffuse_cdf_the"], rand["diffuse_cdf_phi"])
+    env = environment_light_network(uniform_light_dir, conf)
+    soft_vis = soft_visibility_light_network(x_fg_pixel, uniform_light_dir, feature_pixel, normal_bc, conf)
+
+    # Implicit light (renderer.py:113-114)
+    implicit = implicit_illumination_network(x_fg, feature_x_fg, grad_x_fg, conf)
+    implicit_pixel = VR(implicit)
+
+    # Diffuse colour (renderer.py:117-120)
+    cos = dot(normal_bc, uniform_light_dir)
+    env_pixel = (soft_vis * env * cos).mean(dim=2)
+    diffuse_light_pixel = env_pixel + implicit_pixel
+    base_color = base_color_network(x_fg, feature_x_fg, grad_x_fg, conf)
+
+    # Roughness / specular reflectance (renderer.py:123-128)
+    roughness, std_roughness = roughness_network(x_fg, feature_x_fg, grad_x_fg, conf)
+    roughness_pixel = VR(roughness)
+    spec_refl, std_spec_refl = specular_reflectance_network(x_fg, feature_x_fg, grad_x_fg, conf)
+    spec_refl_pixel = VR(spec_refl)
+
+    # Specular colour (renderer.py:131-161)
+    if conf.specular_brdf.sampling == "importance":
+        imp_dir = sample_importance_directions(normal_pixel, rand["specular_cdf_the"], rand["specular_cdf_phi"],
+                                               roughness_pixel)
+    else:
+        imp_dir = sample_uniform_directions(normal_pixel, rand["specular_cdf_the"], rand["specular_cdf_phi"])
+    sBRDF, cos = specular_brdf_model(normal_pixel, view_dir, imp_dir, roughness_pixel, spec_refl_pixel, conf)
+    env = environment_light_network(imp_dir, conf)
+    soft_vis = soft_visibility_light_network(x_fg_pixel, imp_dir, feature_pixel, normal_bc, conf)
+    if conf.specular_brdf.use_split_sum:
+        spec_pixel = (soft_vis * env).mean(dim=2) * (sBRDF * cos).mean(dim=2)
+    else:
+        spec_pixel = (sBRDF * soft_vis * env * cos).mean(dim=2)
+    ii = conf.implicit_illumination_network
+    if ii.use_me and ii.use_me_on_specular:
+        spec_pixel = spec_pixel + (sBRDF * implicit_pixel[:, :, :, None]).mean(dim=2)
+    spec_pixel = conf.specular_brdf.weight * spec_pixel
+
+    # Diffuse + specular composition (renderer.py:163-176)
+    if conf.photogrammetric_light_network.use_me:
+        photo = photogrammetric_light_network(x_fg, camloc, view_dir, feature_x_fg, grad_x_fg, conf)
+        photo_pixel = VR(photo)
+        if conf.diffuse_brdf.entangle:
+            color_fg_pixel = VR(base_color * photo) * diffuse_light_pixel + photo_pixel * spec_pixel
+        else:
+            color_fg_pixel = photo_pixel * (VR(base_color) * diffuse_light_pixel + spec_pixel)
+    else:
+        color_fg_pixel = VR(base_color) + spec_pixel
+
+    color_pixel = color_fg_pixel + VR(color_bg, weights_bg)
+
+    obj_mask_pred = torch.zeros((), dtype=x_fg.dtype, device=x_fg.device)
+    if conf.train.mask_weight > 0.0:
+        obj_mask_pred = (alpha_fg * trans_fg).sum(dim=2)
+
+    # Base-colour perturbation (renderer.py:186-193)
+    G = conf.geometric_network.voxel.grid_size
+    r = conf.renderer.bounding_sphere_radius
+    x_fg_ptb = x_fg + rand["noise"] * (math.sqrt(3) * 2 * r / G)
+    _, feature_ptb, _ = geometric_network(x_fg_ptb, conf)
+    base_color_ptb = base_color_network(x_fg_ptb, feature_ptb, None, conf)
+
+    return dict(color_pixel=color_pixel, sdf_x_fg=sdf_x_fg, grad_x_fg=grad_x_fg, alpha_fg=alpha_fg,
+                trans_fg=trans_fg, obj_mask_pred=obj_mask_pred, base_color=base_color,
+                base_color_ptb=base_color_ptb, roughness=roughness, specular_reflectance=spec_refl,
+                std_roughness=std_roughness, std_specular_reflectance=std_spec_refl)
+
+
+def render_image(pose, intrinsic, resolution, conf, device=None, progress=None):
+    """renderer.py:212-272: tiled forward render of one view.
+    pose (1,4,4), intrinsic (1,3,3) numpy; resolution (W, H).  Returns (1,3,H,W) in [0,1]."""
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    scale = 1.0 / 2 ** conf.valid.n_down_samples
+    W, H = resolution
+    W, H = int(W * scale), int(H * scale)
+    P = conf.valid.n_rays
+    intrinsic = intrinsic.copy()
+    for (i, j) in ((0, 0), (1, 1), (0, 2), (1, 2), (0, 1)):
+        intrinsic[:, i, j] = intrinsic[:, i, j] * scale
+    xy = generate_all_pixels(W, H).reshape((1, H * W, 2))
+    _, m = divmod(W * H, P)
+    P = P - m   # renderer.py:237-241 (sic: makes P a divisor only in the reference's use cases)
+
+    rand = make_rand(1, P, conf, device)
+    cos_anneal_ratio = torch.ones(1, device=device)
+    rimage = np.zeros([1, H * W, 3])
+    for p in range(0, H * W, P):
+        xy_b = xy[:, p:p + P, :]
+        n = xy_b.shape[1]
+        if n < P:  # last partial tile: pad (the reference assumes divisibility)
+            xy_b = np.concatenate([xy_b, np.repeat(xy_b[:, -1:, :], P - n, axis=1)], axis=1)
+        raydir_np, camloc_np = generate_raydir_camloc(pose, intrinsic, xy_b)
+        raydir = torch.from_numpy(raydir_np.astype(np.float32)).to(device)
+        camloc = torch.from_numpy(camloc_np.astype(np.float32)).to(device)
+        x_fg, t_fg, x_bg, t_bg, mask = sample_points(camloc, raydir, rand["stratified_sample"],
+                                                     rand["background_sample"], conf)
+        x_fg = x_fg.requires_grad_(True)
+        res = pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, conf, rand)
+        rimage[0, p:p + n, :] = res["color_pixel"].detach().reshape(P, 3)[:n].cpu().numpy()
+        if progress is not None:
+            progress(p, H * W)
+    rimage = rimage.reshape((1, H, W, 3)).transpose((0, 3, 1, 2))
+    return np.clip(rimage, 0.0, 1.0)

@@ -241,11 +241,26 @@ def query_on_voxel_hash(query, feature, G0, growth_factor, T0, L, D, min_=-1.0, 
 
 
 # ---- sampled TV loss: total_variation_loss*_composite.py --------------------------------------
-def _tv_finish(deltas, eps=0.0):
+class _SqrtTV(torch.autograd.Function):
+    """sqrt whose backward is g * 0.5 * rsqrt(s + 1e-12): with s = sum(delta^2) this gives the
+    kernels' d/d(delta) = g * delta * rsqrt(s + 1e-12) (total_variation_loss_cuda.cu:158-163)."""
+
+    @staticmethod
+    def forward(ctx, s):
+        ctx.save_for_backward(s)
+        return torch.sqrt(s)
+
+    @staticmethod
+    def backward(ctx, g):
+        (s,) = ctx.saved_tensors
+        return g * 0.5 / torch.sqrt(s + 1e-12)
+
+
+def _tv_finish(deltas):
     s = 0
     for d in deltas:
         s = s + d * d
-    return torch.sqrt(s + eps) if eps else s ** 0.5
+    return _SqrtTV.apply(s)
 
 
 def tv_loss_on_voxel(query, feature, min_=-1.0, max_=1.0, sym_backward=False):
