@@ -1,0 +1,201 @@
+"""bench.py -- rays/s (forward + backward of total_loss) at 512 rays x 128 samples per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W            (single GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = sample_points -> pb_render -> total_loss -> backward to every parameter gradient
+(MLP weights + the 512^3 x 4 feature grid), config/default.yaml, B=1, R=512, N=128 (+32 bg
+samples, 128 lights), synthetic rays, reference-initialised weights.  Rays shard across ranks
+(weak scaling: 512 rays per GPU); one gradient exchange per step over RCCL.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# dense-GEMM FLOPs (2*in*out per affine per point), default config
+MFLOP_PER_RAY_FWD_BWD = 2168.9
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=512, help="rays per GPU per step (B=1)")
+    ap.add_argument("--config", default="default")
+    ap.add_argument("--override", action="append", default=[])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=8)
+    return ap.parse_args()
+
+
+class Step:
+    """Owns parameters, gradient buffers and the synthetic inputs of one rank."""
+
+    def __init__(self, conf, R, device, rank, world):
+        from ndjir_amd import network, parameter as P
+        from ndjir_amd.grid_feature import set_grad_buffer
+        from ndjir_amd.renderer import make_rand
+        from ndjir_amd.synthetic import make_rays
+
+        self.conf, self.device, self.rank, self.world = conf, device, rank, world
+        P.clear_parameters()
+        P.set_device(device)
+        network.seed(313)
+        B = 1
+        # every rank draws the full (world*R)-ray set and keeps its contiguous slice
+        self.camloc, self.raydir, self.color_gt = make_rays(B, R, seed=412, device=device, ray_offset=rank * R,
+                                                            total_rays=world * R)
+        full = make_rand(B, world * R, conf, "cpu")
+        self.rand = {k: v[:, rank * R:(rank + 1) * R].contiguous().to(device) for k, v in full.items()}
+        self.car = torch.ones(1, device=device)
+        self.P = P
+        self.set_grad_buffer = set_grad_buffer
+        self.grid_bufs = {}
+        self.mlp_names = None
+        self.forward_backward()          # creates the parameters (untimed)
+        for name, p in P.get_parameters().items():
+            if name.endswith("feature/F"):
+                buf = torch.zeros_like(p)
+                set_grad_buffer(p, buf)
+                self.grid_bufs[name] = buf
+        params = P.get_parameters(grad_only=True)
+        self.mlp_names = [k for k in params if not k.endswith("feature/F")]
+        self.mlp_params = [params[k] for k in self.mlp_names]
+        self.flat_grad = torch.zeros(sum(p.numel() for p in self.mlp_params), device=device)
+
+    def forward_backward(self):
+        from ndjir_amd.loss import total_loss
+        for buf in self.grid_bufs.values():
+            buf.zero_()
+        out = total_loss(self.camloc, self.raydir, self.color_gt, None, self.car, self.conf, self.rand)
+        loss = out["loss"]
+        if self.mlp_names is None:
+            params = [p for p in self.P.get_parameters(grad_only=True).values()]
+            torch.autograd.grad(loss, params, allow_unused=True)
+            return loss.detach()
+        grid_params = [p for k, p in self.P.get_parameters().items() if k.endswith("feature/F")]
+        grads = torch.autograd.grad(loss, self.mlp_params + grid_params, allow_unused=True)
+        off = 0
+        for p, g in zip(self.mlp_params, grads):
+            n = p.numel()
+            if g is not None:
+                self.flat_grad[off:off + n].copy_(g.reshape(-1))
+            else:
+                self.flat_grad[off:off + n].zero_()
+            off += n
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_grad)           # one flat bucket, SUM
+            for buf in self.grid_bufs.values():       # TODO(round 2): exchange scatter operands, not the dense grid
+                dist.all_reduce(buf)
+        return loss.detach()
+
+
+def cpu_baseline(conf, step, n_rays):
+    """The CPU oracle (restatement of the reference graph) timed on this box's host cores on a
+    bounded sample: `n_rays` of rank 0's rays, same parameters, same random tensors."""
+    from tests.parity_utils import run_oracle_step
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params_cpu = {k: v.detach().cpu() for k, v in step.P.get_parameters().items()}
+    sl = slice(0, n_rays)
+    inputs = dict(camloc=step.camloc.cpu(), raydir=step.raydir[:, sl].cpu().contiguous(),
+                  color_gt=step.color_gt[:, sl].cpu().contiguous(),
+                  rand={k: v[:, sl].cpu().contiguous() for k, v in step.rand.items()},
+                  cos_anneal=step.car.cpu())
+    run_oracle_step(conf, params_cpu, inputs)            # warm-up (page-in, thread pools)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        run_oracle_step(conf, params_cpu, inputs)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 5:
+            break
+    return dict(value=n_rays * reps / el, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{reps} x fwd+bwd of {n_rays} rays (B=1) of the same workload, oracle/graph.py torch-CPU fp32, "
+                       f"{cores} host cores, {el:.1f} s")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from ndjir_amd import config as cfg
+    from ndjir_amd import lib
+    lib.load()  # fail loudly if the HIP extension is missing
+    conf = cfg.load(a.config, a.override)
+    R = a.rays
+    step = Step(conf, R, device, rank, world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step.forward_backward()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step.forward_backward()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        r = conf.renderer
+        N = r.n_samples0 + r.n_samples1 * r.n_upsamples
+        rays_per_s = world * R * a.steps / el
+        ms = 1e3 * el / a.steps
+        achieved = MFLOP_PER_RAY_FWD_BWD * 1e6 * R / (ms * 1e-3) / 1e12      # per GPU
+        out = {
+            "metric": "rays/sec (fwd+bwd) at 512 rays x 128 samples",
+            "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config/{a.config}.yaml, B=1, R={R} rays/GPU x N={N} fg samples (+{r.n_bg_samples} bg, "
+                                   f"{r.n_thetas * 2 * r.n_thetas} lights), voxel {conf.geometric_network.voxel.type} "
+                                   f"{conf.geometric_network.voxel.grid_size}^3x{conf.geometric_network.voxel.feature_size}, "
+                                   f"total_loss fwd+bwd to all parameter gradients",
+                       "rays_per_gpu": R, "samples_per_ray": N, "parallelism": f"ray-sharded x{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "scope": "whole step: algorithmic dense-GEMM FLOPs (2168.9 MFLOP/ray fwd+bwd, SURVEY 8d) / step time"},
+            "loss": float(loss),
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(conf, step, a.cpu_rays)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
