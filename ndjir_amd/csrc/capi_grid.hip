@@ -77,26 +77,33 @@ static long long desc_numel(const GridDesc& g, int G0 = 0, float gf = 0, int T0 
 }
 
 // shared bodies ---------------------------------------------------------------------------------
+#define CHECK_PTRS_N(N_, ...) do { if ((N_) <= 0) return NDJIR_OK; CHECK_PTRS(__VA_ARGS__); } while (0)
 #define CHECK_PTRS(...) do { const void* _p[] = {__VA_ARGS__}; for (auto q : _p) if (!q) return NDJIR_ERR_ARG; } while (0)
 
 static int do_query(int interp, const GridDesc& g, long long P, float* out, const float* q, const float* f, hipStream_t s) {
+  if (P <= 0) return NDJIR_OK;
   CHECK_PTRS(out, q, f);
   return launch_query(interp, g, P, out, q, f, false, s);
 }
 static int do_grad_query(int interp, const GridDesc& g, long long P, float* gq, const float* go, const float* q, const float* f, int accum, hipStream_t s) {
+  if (P <= 0) return NDJIR_OK;
   CHECK_PTRS(gq, go, q, f);
   return launch_dquery(interp, g, P, 0, gq, go, q, f, accum != 0, s);
 }
 static int do_grad_feature(int interp, const GridDesc& g, long long numel, long long P, float* gf, const float* go, const float* q, int accum, hipStream_t s) {
-  CHECK_PTRS(gf, go, q);
+  if (!gf) return NDJIR_ERR_ARG;
   if (!accum) zero_fill(gf, numel, s);
+  if (P <= 0) return ndjir_check_launch();
+  CHECK_PTRS(go, q);
   return launch_scatter(interp, g, P, 0, gf, nullptr, go, q, s);
 }
 static int do_ggo(int interp, const GridDesc& g, long long P, float* ggo, const float* ggq, const float* q, const float* f, int accum, hipStream_t s) {
+  if (P <= 0) return NDJIR_OK;
   CHECK_PTRS(ggo, ggq, q, f);
   return launch_dquery(interp, g, P, 1, ggo, ggq, q, f, accum != 0, s);
 }
 static int do_gq_gf(int interp, const GridDesc& g, long long P, float* gf, const float* ggq, const float* go, const float* q, hipStream_t s) {
+  if (P <= 0) return NDJIR_OK;
   CHECK_PTRS(gf, ggq, go, q);
   return launch_scatter(interp, g, P, 1, gf, ggq, go, q, s);   // never zeroes (reference behaviour)
 }

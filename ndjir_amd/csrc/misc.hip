@@ -6,6 +6,10 @@
 #include "common.h"
 #include "grid.h"
 
+// scalar geometry kernels: keep the reference's unfused expression order (bit-comparable with the
+// CPU oracle apart from libm calls)
+#pragma clang fp contract(off)
+
 namespace ndjir {
 
 static inline int blocks_for(long long n) {

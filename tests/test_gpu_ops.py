@@ -63,8 +63,8 @@ def test_intersection_large_vs_oracle(gpu):
     # Y == 0 / Y > 0 decisions may differ by one fma rounding only at grazing rays
     agree = (c.cpu().numpy() == nh)
     assert agree.mean() > 0.999
-    np.testing.assert_allclose(a.cpu().numpy()[agree], tn[agree], atol=2e-6)
-    np.testing.assert_allclose(b.cpu().numpy()[agree], tf[agree], atol=2e-6)
+    np.testing.assert_allclose(a.cpu().numpy()[agree], tn[agree], atol=1e-6, rtol=2e-6)
+    np.testing.assert_allclose(b.cpu().numpy()[agree], tf[agree], atol=1e-6, rtol=2e-6)
 
 
 @pytest.mark.parametrize("eps", [0.0, 1e-12])
@@ -102,7 +102,9 @@ def test_grid_family_vs_oracle(gpu, family, P, G, hash_cfg):
     o = K.GridOracle(family, hash=hash_cfg)
     D = 4 if hash_cfg is None else hash_cfg[4]
     fs = feature_shape(o, G, 4, hash_cfg)
-    lo, hi = (-1.0, 1.0) if P <= 16 else (-1.2, 1.2)      # larger cases include out-of-box queries
+    # larger dense cases include out-of-box queries (extrapolation, clamped cells); fine hash levels
+    # would extrapolate with coefficients ~1e2 there (ill-conditioned), so those stay inside the box
+    lo, hi = (-1.0, 1.0) if (P <= 16 or hash_cfg is not None) else (-1.2, 1.2)
     q = (rng.rand(P, 3) * (hi - lo) + lo).astype(np.float32)
     f = (rng.randn(*fs) * 0.01).astype(np.float32)
     lz = o.lanczos
@@ -118,7 +120,8 @@ def test_grid_family_vs_oracle(gpu, family, P, G, hash_cfg):
     scale = max(1.0, np.abs(gq_ref).max())
     np.testing.assert_allclose(gq.detach().cpu().numpy(), gq_ref, atol=(2e-5 if lz else 2e-6) * scale)
     gf = _core.grad_feature(family, ogd, qd, fd, hcfg=hash_cfg)
-    np.testing.assert_allclose(gf.detach().cpu().numpy(), o.grad_feature(og, q, fs), atol=5e-5 if lz else 5e-6)
+    gf_ref = o.grad_feature(og, q, fs)
+    np.testing.assert_allclose(gf.detach().cpu().numpy(), gf_ref, atol=(5e-5 if lz else 5e-6) * max(1.0, np.abs(gf_ref).max()))
     ggq = rng.randn(P, 3).astype(np.float32)
     g_go, g_f = torch.autograd.grad(gq, [ogd, fd], T(ggq, gpu))
     ggo_ref = o.grad_query_grad_grad_output(ggq, q, f)
