@@ -194,6 +194,34 @@ int ndjir_squareplus_forward(int size, float* output, const float* input, float 
 int ndjir_squareplus_backward(int size, float* dinput, const float* doutput, const float* input, float b, int accum,
                               hipStream_t stream);
 
+/* ---- fused MLP engine ------------------------------------------------------------------------------
+ * Replaces the reference's per-layer nnabla launches (PF.affine -> cuBLAS GEMM, F.softplus(beta=100),
+ * python/network.py:88-93,165 and every network function :154-561) by ONE launch per net and
+ * direction: a tile of 64 points runs through all layers with activations kept in LDS
+ * (ndjir_amd/csrc/mlp.hip).  Weights W are (in, out) row-major as in nnabla (y = x W + b).
+ *
+ * ndjir_mlp_pack: W (K x N) -> MFMA-fragment order, or W^T when transpose != 0 (for backward).
+ *                 dst needs ndjir_mlp_packed_size(K, N, transpose) floats.
+ * ndjir_mlp_chain (bwd == 0), forward:  h_l = softplus_beta(h_{l-1} W_l + b_l), Y = h_{L-1} W_L + b_L;
+ *                 side_out[l] (P x N_l) receives h_l when non-null (needed by backward).
+ * ndjir_mlp_chain (bwd != 0), backward of the data path, chain input X = dL/dY:
+ *                 step i uses packed W_{L-i}^T; side_in[i] = stored forward activation of the layer
+ *                 below (softplus' = 1 - exp(-beta h)); side_out[i] receives delta of that layer
+ *                 (P x N), bgrad[i] its column sums (atomically accumulated); with has_output the
+ *                 last step writes dL/dX to Y.  Weight gradients are plain GEMMs H^T delta.
+ * Per-layer arrays are HOST arrays of length L; Ks/Ns are each step's logical input/output width.
+ * skip_layer (-1 = none): forward, the output of that layer is scaled by skip_scale and the scaled
+ * chain input is appended (python/network.py:221-224); backward, the step whose output is the
+ * gradient of that concatenation: columns >= skip_split go (scaled) to Xskip. */
+long long ndjir_mlp_packed_size(int K, int N, int transpose);
+int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
+int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L,
+                    const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
+                    const float* const* side_in, float* const* side_out, const int* ld_side,
+                    float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
+                    int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
+                    hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

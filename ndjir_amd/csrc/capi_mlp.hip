@@ -1,0 +1,57 @@
+// capi_mlp.hip -- C ABI of the fused MLP engine (declarations: include/ndjir_hip.h).
+#include <hip/hip_runtime.h>
+
+#include "../../include/ndjir_hip.h"
+#include "common.h"
+#include "mlp.h"
+
+using namespace ndjir;
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" long long ndjir_mlp_packed_size(int K, int N, int transpose) {
+  int Kp = round_up(transpose ? N : K, 8), Np = round_up(transpose ? K : N, 32);
+  return (long long)Kp * Np;
+}
+
+extern "C" int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream) {
+  if (!W || !dst || K <= 0 || N <= 0) return NDJIR_ERR_ARG;
+  return launch_pack(W, dst, K, N, transpose, stream);
+}
+
+extern "C" int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L,
+                               const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
+                               const float* const* side_in, float* const* side_out, const int* ld_side,
+                               float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
+                               int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
+                               hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  if (!X || L < 1 || L > MAX_CHAIN_LAYERS || !Wp || !Ks || !Ns) return NDJIR_ERR_ARG;
+  if (has_output && !Y) return NDJIR_ERR_ARG;
+  ChainArgs a{};
+  a.P = P; a.X = X; a.ldx = ldx; a.K0 = K0; a.K0p = round_up(K0, 8); a.L = L;
+  a.Y = Y; a.ldy = ldy; a.accum_y = accum_y; a.has_output = has_output; a.beta = beta;
+  a.skip_layer = skip_layer; a.skip_scale = skip_scale; a.skip_split = skip_split; a.Xskip = Xskip; a.ld_xskip = ld_xskip;
+  int kin = K0;
+  for (int i = 0; i < L; ++i) {
+    ChainLayer& ly = a.layers[i];
+    if (!Wp[i] || Ks[i] <= 0 || Ns[i] <= 0) return NDJIR_ERR_ARG;
+    ly.Wp = Wp[i];
+    ly.bias = bias ? bias[i] : nullptr;
+    ly.side_in = side_in ? side_in[i] : nullptr;
+    ly.side_out = side_out ? side_out[i] : nullptr;
+    ly.bgrad = bgrad ? bgrad[i] : nullptr;
+    ly.K = Ks[i]; ly.N = Ns[i]; ly.Kp = round_up(Ks[i], 8); ly.Np = round_up(Ns[i], 32);
+    ly.ld_side = ld_side ? ld_side[i] : Ns[i];
+    const bool last = has_output && (i == L - 1);
+    // the input width of layer i must match what the previous epilogue leaves in LDS
+    int expect = (i == 0) ? K0 : kin;
+    if (ly.K != expect) return NDJIR_ERR_ARG;
+    if (ly.Np == 32 && !last) return NDJIR_ERR_UNSUPPORTED;   // narrow layers only as the output layer
+    if (bwd && !last && !ly.side_in) return NDJIR_ERR_ARG;
+    kin = ly.N;
+    if (!bwd && i == skip_layer) kin = ly.N + K0;
+    if (bwd && i == skip_layer) kin = skip_split;
+  }
+  return launch_chain(a, bwd != 0, stream);
+}

@@ -1,0 +1,43 @@
+// mlp.h -- argument block of the fused MLP chain kernel (mlp.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ndjir {
+
+constexpr int MAX_CHAIN_LAYERS = 10;
+
+struct ChainLayer {
+  const float* Wp;      // packed matrix [Np/32][Kp/8][64][4]
+  const float* bias;    // forward only (may be null)
+  const float* side_in; // backward: stored forward activation of the layer below (P x N)
+  float* side_out;      // forward: activation store (P x N); backward: delta store (P x N)
+  float* bgrad;         // backward: bias gradient accumulator (N), atomically accumulated
+  int K, N;             // logical dims of this GEMM (input width, output width)
+  int Kp, Np;           // padded: Kp % 8 == 0, Np % 32 == 0
+  int ld_side;
+};
+
+struct ChainArgs {
+  long long P;          // points (rows)
+  long long n_tiles;    // filled by launch_chain
+  const float* X;       // chain input (P x K0), row stride ldx
+  float* Y;             // chain output (P x N_last), row stride ldy
+  float* Xskip;         // backward: stash of the skip-connection part of the input gradient
+  int ldx, ldy, ld_xskip;
+  int K0, K0p;
+  int L;
+  int accum_y;          // Y += result
+  int has_output;       // last layer writes Y (else the chain ends with a hidden epilogue)
+  int skip_layer;       // -1: none.  fwd: layer whose output is concatenated with X and scaled;
+                        // bwd: layer whose output is that concatenated gradient
+  int skip_split;       // bwd: first column of the concatenated-input part
+  int lds_split;        // filled by launch_chain
+  float skip_scale;
+  float beta;
+  ChainLayer layers[MAX_CHAIN_LAYERS];
+};
+
+int launch_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
+int launch_chain(const ChainArgs& a, bool bwd, hipStream_t stream);
+
+}  // namespace ndjir

@@ -15,7 +15,8 @@ SO_PATH = os.path.join(_HERE, "_lib", "libndjir_hip.so")
 
 _vp = ctypes.c_void_p
 _CT = {"i": ctypes.c_int, "f": ctypes.c_float, "p": _vp, "F": ctypes.POINTER(ctypes.c_float),
-       "I": ctypes.POINTER(ctypes.c_int), "l": ctypes.c_longlong}
+       "I": ctypes.POINTER(ctypes.c_int), "l": ctypes.c_longlong, "P": ctypes.POINTER(_vp),
+       "A": ctypes.POINTER(ctypes.c_int)}
 
 # signature strings (without the trailing stream): i=int f=float l=long long p=device pointer
 # F=float[3] host  I=int[3] host
@@ -34,6 +35,9 @@ def _family(prefix, fwd, tail):
 
 SIGS = {
     "zero": "pl",
+    "mlp_pack": "ppiii",
+    # bwd P X ldx K0 L Wp bias Ks Ns side_in side_out ld_side bgrad Y ldy accum has_out beta skip scale split Xskip ld
+    "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi",
     "ray_aabb_intersection": "ipppppiiFF",
     "ray_sphere_intersection": "ipppppiif",
     "inverse_transform_sample_uniform_directions": "ippppiiiif",
@@ -84,6 +88,8 @@ def load():
         _lib.ndjir_hash_num_params.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.ndjir_hash_grid_size.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int]
         _lib.ndjir_hash_table_size.argtypes = [ctypes.c_int, ctypes.c_int]
+        _lib.ndjir_mlp_packed_size.restype = ctypes.c_longlong
+        _lib.ndjir_mlp_packed_size.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     return _lib
 
 
@@ -127,6 +133,16 @@ def call(name, *args):
                     raise NdjirHipError(f"ndjir_{name}: tensors must be contiguous float32 on the GPU "
                                         f"(got {v.dtype}, {v.device}, contiguous={v.is_contiguous()})")
                 cargs.append(v.data_ptr())
+        elif c == "P":     # host array of device pointers (list of tensors / None)
+            arr = (_vp * len(v))()
+            for i, t in enumerate(v):
+                if t is not None:
+                    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                        raise NdjirHipError(f"ndjir_{name}: pointer-array entries must be contiguous float32 GPU tensors")
+                    arr[i] = t.data_ptr()
+            cargs.append(arr)
+        elif c == "A":     # host int array
+            cargs.append((ctypes.c_int * len(v))(*[int(x) for x in v]))
         elif c == "F":
             cargs.append(_f3(v))
         elif c == "I":
@@ -144,7 +160,8 @@ def call(name, *args):
 def symbols():
     """Every symbol include/ndjir_hip.h declares (for the load/export test)."""
     return ["ndjir_" + n for n in SIGS] + ["ndjir_version", "ndjir_hash_force_align", "ndjir_hash_grid_size",
-                                            "ndjir_hash_table_size", "ndjir_hash_num_params"]
+                                            "ndjir_hash_table_size", "ndjir_hash_num_params",
+                                            "ndjir_mlp_packed_size"]
 
 
 def hash_num_params(G0, growth_factor, T0, L, D):

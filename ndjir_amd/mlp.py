@@ -1,0 +1,149 @@
+"""Fused MLP operator: one HIP launch per net and direction (ndjir_amd/csrc/mlp.hip).
+
+Replaces the reference's chains of `PF.affine` + `F.softplus(beta=100)` launches
+(python/network.py:88-93, 165) for every net whose gradient is needed to first order.  Weights
+keep nnabla's layout, W (in, out) and y = x W + b.
+
+    y = fused_mlp(x, weights, biases)            # hidden activation softplus(beta), linear output
+
+Backward: one fused chain launch for the data path (delta of every layer + bias gradients + input
+gradient); weight gradients are plain GEMMs H^T delta (library GEMM).
+"""
+import weakref
+
+import torch
+from torch.autograd import Function
+
+from . import lib
+
+_PACK_CACHE = {}
+
+
+def _packed(W, transpose):
+    """MFMA-fragment-order copy of W (or W^T); cached per (storage, version)."""
+    key = (W.data_ptr(), W._version, tuple(W.shape), bool(transpose))
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0]() is W:     # same live tensor object, same version
+        return hit[1]
+    K, N = W.shape
+    n = lib.load().ndjir_mlp_packed_size(K, N, int(transpose))
+    dst = torch.empty(n, device=W.device, dtype=torch.float32)
+    lib.call("mlp_pack", W.detach().contiguous(), dst, K, N, int(transpose))
+    if len(_PACK_CACHE) > 512:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = (weakref.ref(W), dst)
+    return dst
+
+
+def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, keep_hidden=False):
+    """x (P, K0) contiguous.  Returns y (P, N_last) and the list of stored activations
+    A_1..A_{L-1} (inputs of layers 1..L-1) when keep_hidden."""
+    P, K0 = x.shape
+    L = len(weights)
+    Ks, Ns, Wp, hidden = [], [], [], []
+    kin = K0
+    for j, W in enumerate(weights):
+        assert W.shape[0] == kin, (j, tuple(W.shape), kin)
+        Ks.append(W.shape[0])
+        Ns.append(W.shape[1])
+        Wp.append(_packed(W, False))
+        kin = W.shape[1] + (K0 if j == skip_layer else 0)
+        if keep_hidden and j < L - 1:
+            hidden.append(torch.empty((P, kin), device=x.device, dtype=torch.float32))
+    y = torch.empty((P, Ns[-1]), device=x.device, dtype=torch.float32)
+    side_out = (hidden + [None]) if keep_hidden else [None] * L
+    ld_side = [h.shape[1] if h is not None else 0 for h in side_out]
+    lib.call("mlp_chain", 0, P, x, x.shape[1], K0, L, Wp, [b.detach() if b is not None else None for b in biases],
+             Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
+             int(skip_layer), float(skip_scale), 0, None, 0)
+    return y, hidden
+
+
+class FusedMLP(Function):
+    @staticmethod
+    def forward(ctx, x, beta, skip_layer, skip_scale, *params):
+        L = len(params) // 2
+        weights, biases = list(params[:L]), list(params[L:])
+        x2 = x.detach().reshape(-1, x.shape[-1]).contiguous()
+        train = any(ctx.needs_input_grad)
+        y, hidden = chain_forward(x2, weights, biases, beta, skip_layer, skip_scale,
+                                  keep_hidden=train)
+        if train:
+            ctx.save_for_backward(x2, *hidden, *weights)
+            ctx.cfg = (beta, skip_layer, skip_scale, L, tuple(x.shape))
+        return y.view(x.shape[:-1] + (y.shape[-1],))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        beta, skip_layer, skip_scale, L, xshape = ctx.cfg
+        saved = ctx.saved_tensors
+        x2 = saved[0]
+        A = [x2] + list(saved[1:L])          # A[j] = input activation of layer j
+        W = list(saved[L:2 * L])
+        P, K0 = x2.shape
+        need_x = ctx.needs_input_grad[0]
+        need_w = any(ctx.needs_input_grad[4:4 + L])
+        gy2 = gy.reshape(P, -1).contiguous()
+        # backward chain: step i applies W_{L-1-i}^T
+        steps = L if need_x else L - 1
+        deltas = [None] * L                  # deltas[j] = dL/dz_j
+        deltas[L - 1] = gy2
+        bgrads = [None] * L
+        gx = None
+        if steps > 0:
+            Wp, Ks, Ns, side_in, side_out, ld_side, bg = [], [], [], [], [], [], []
+            bwd_skip, split = -1, 0
+            for i in range(steps):
+                j = L - 1 - i
+                Wp.append(_packed(W[j], True))
+                Ks.append(W[j].shape[1])
+                Ns.append(W[j].shape[0])
+                if i < L - 1:
+                    below = j - 1                       # layer whose delta this step produces
+                    width = W[below].shape[1]
+                    deltas[below] = torch.empty((P, width), device=x2.device, dtype=torch.float32)
+                    bgrads[below] = torch.zeros((width,), device=x2.device, dtype=torch.float32)
+                    side_in.append(A[j])
+                    side_out.append(deltas[below])
+                    ld_side.append(A[j].shape[1])
+                    bg.append(bgrads[below])
+                    if below == skip_layer:
+                        bwd_skip, split = i, width
+                        # delta store of the skip layer shares the activation's row stride only if equal
+                        ld_side[-1] = A[j].shape[1]
+                else:
+                    side_in.append(None)
+                    side_out.append(None)
+                    ld_side.append(0)
+                    bg.append(None)
+            if bwd_skip >= 0:
+                # side_in (stride = concatenated width) and side_out (stride = split) differ: give the
+                # delta buffer the activation's stride and slice afterwards
+                j = L - 1 - bwd_skip
+                wide = torch.empty((P, A[j].shape[1]), device=x2.device, dtype=torch.float32)
+                side_out[bwd_skip] = wide
+                deltas[skip_layer] = wide[:, :split]
+            if need_x:
+                gx = torch.zeros((P, K0), device=x2.device, dtype=torch.float32) if bwd_skip >= 0 else \
+                    torch.empty((P, K0), device=x2.device, dtype=torch.float32)
+            lib.call("mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
+                     side_in, side_out, ld_side, bg, gx, K0, 1 if bwd_skip >= 0 else 0, 1 if need_x else 0,
+                     float(beta), int(bwd_skip), float(skip_scale), int(split),
+                     gx if bwd_skip >= 0 else None, K0)
+        gW = [None] * L
+        gb = [None] * L
+        if need_w:
+            for j in range(L):
+                if ctx.needs_input_grad[4 + j]:
+                    gW[j] = A[j].t().mm(deltas[j])              # plain library GEMM, reduction over P
+                if ctx.needs_input_grad[4 + L + j]:
+                    gb[j] = bgrads[j] if j < L - 1 else gy2.sum(0)
+        return (gx.view(xshape) if gx is not None else None, None, None, None, *gW, *gb)
+
+
+def fused_mlp(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0):
+    """x (..., K0); weights[j] (K_j, N_j); biases[j] (N_j,).  softplus(beta) hidden activations,
+    linear output; optional IDR-style skip: output of `skip_layer` is scaled by `skip_scale` and the
+    scaled input is appended (python/network.py:221-224)."""
+    return FusedMLP.apply(x, beta, skip_layer, skip_scale, *weights, *biases)
