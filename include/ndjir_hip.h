@@ -221,6 +221,13 @@ int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L
                     float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                     int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                     hipStream_t stream);
+/* Weight gradient of one layer: out (K x N) (+)= A^T B with A (P x K, row stride lda) the layer's
+ * input activations and B (P x N, row stride ldb) its deltas (ndjir_amd/csrc/wgrad.hip; the
+ * reference gets this from nnabla's affine backward, a cuBLAS GEMM).  `workspace` needs
+ * ndjir_mlp_wgrad_workspace(K, N, P) floats (split-P partial sums). */
+long long ndjir_mlp_wgrad_workspace(int K, int N, long long P);
+int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out,
+                    int accum, float* workspace, hipStream_t stream);
 
 #ifdef __cplusplus
 }

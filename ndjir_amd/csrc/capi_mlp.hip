@@ -55,3 +55,12 @@ extern "C" int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, in
   }
   return launch_chain(a, bwd != 0, stream);
 }
+
+extern "C" long long ndjir_mlp_wgrad_workspace(int K, int N, long long P) { return wgrad_workspace(K, N, P); }
+
+extern "C" int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out,
+                               int accum, float* workspace, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  if (!A || !B || !out || !workspace || lda < K || ldb < N) return NDJIR_ERR_ARG;
+  return launch_wgrad(A, lda, B, ldb, K, N, P, out, accum, workspace, stream);
+}

@@ -39,5 +39,8 @@ struct ChainArgs {
 
 int launch_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
 int launch_chain(const ChainArgs& a, bool bwd, hipStream_t stream);
+long long wgrad_workspace(int K, int N, long long P);
+int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out, int accum,
+                 float* workspace, hipStream_t stream);
 
 }  // namespace ndjir

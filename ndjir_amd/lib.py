@@ -38,6 +38,7 @@ SIGS = {
     "mlp_pack": "ppiii",
     # bwd P X ldx K0 L Wp bias Ks Ns side_in side_out ld_side bgrad Y ldy accum has_out beta skip scale split Xskip ld
     "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi",
+    "mlp_wgrad": "pipiiilpip",
     "ray_aabb_intersection": "ipppppiiFF",
     "ray_sphere_intersection": "ipppppiif",
     "inverse_transform_sample_uniform_directions": "ippppiiiif",
@@ -90,6 +91,8 @@ def load():
         _lib.ndjir_hash_table_size.argtypes = [ctypes.c_int, ctypes.c_int]
         _lib.ndjir_mlp_packed_size.restype = ctypes.c_longlong
         _lib.ndjir_mlp_packed_size.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        _lib.ndjir_mlp_wgrad_workspace.restype = ctypes.c_longlong
+        _lib.ndjir_mlp_wgrad_workspace.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong]
     return _lib
 
 
@@ -161,7 +164,7 @@ def symbols():
     """Every symbol include/ndjir_hip.h declares (for the load/export test)."""
     return ["ndjir_" + n for n in SIGS] + ["ndjir_version", "ndjir_hash_force_align", "ndjir_hash_grid_size",
                                             "ndjir_hash_table_size", "ndjir_hash_num_params",
-                                            "ndjir_mlp_packed_size"]
+                                            "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace"]
 
 
 def hash_num_params(G0, growth_factor, T0, L, D):

@@ -7,7 +7,7 @@ keep nnabla's layout, W (in, out) and y = x W + b.
     y = fused_mlp(x, weights, biases)            # hidden activation softplus(beta), linear output
 
 Backward: one fused chain launch for the data path (delta of every layer + bias gradients + input
-gradient); weight gradients are plain GEMMs H^T delta (library GEMM).
+gradient); weight gradients H^T delta by the split-P MFMA kernel of csrc/wgrad.hip.
 """
 import weakref
 
@@ -57,6 +57,40 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
              Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
              int(skip_layer), float(skip_scale), 0, None, 0)
     return y, hidden
+
+
+_WORKSPACE = {}
+
+
+def wgrad(A, B):
+    """dW = A^T B with A (P, K) and B (P, N) row-major views (column stride 1): the weight gradient
+    of one layer, reduction over the P points (ndjir_amd/csrc/wgrad.hip)."""
+    P, K = A.shape
+    N = B.shape[1]
+    assert A.stride(1) == 1 and B.stride(1) == 1 and B.shape[0] == P
+    need = lib.load().ndjir_mlp_wgrad_workspace(K, N, P)
+    ws = _WORKSPACE.get(A.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 22), device=A.device, dtype=torch.float32)
+        _WORKSPACE[A.device] = ws
+    out = torch.empty((K, N), device=A.device, dtype=torch.float32)
+    lib.call("mlp_wgrad", _Strided(A), A.stride(0), _Strided(B), B.stride(0), K, N, P, out, 0, ws)
+    return out
+
+
+class _Strided:
+    """Lets lib.call pass a row-strided 2-D view (column stride 1) as a raw pointer."""
+    is_cuda, dtype = True, torch.float32
+
+    def __init__(self, t):
+        assert t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1
+        self.t = t
+
+    def is_contiguous(self):
+        return True
+
+    def data_ptr(self):
+        return self.t.data_ptr()
 
 
 class FusedMLP(Function):
@@ -136,7 +170,7 @@ class FusedMLP(Function):
         if need_w:
             for j in range(L):
                 if ctx.needs_input_grad[4 + j]:
-                    gW[j] = A[j].t().mm(deltas[j])              # plain library GEMM, reduction over P
+                    gW[j] = wgrad(A[j], deltas[j])
                 if ctx.needs_input_grad[4 + L + j]:
                     gb[j] = bgrads[j] if j < L - 1 else gy2.sum(0)
         return (gx.view(xshape) if gx is not None else None, None, None, None, *gW, *gb)

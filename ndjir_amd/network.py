@@ -52,14 +52,41 @@ def _glorot_uniform(shape):
     return prng.uniform(-lim, lim, size=shape)
 
 
-def affine(h, D, use_wn=False, w_init=None, b_init=None, name=None):
-    """network.py:88-93: PF.affine on the last axis inside parameter scope `name`/affine."""
+# Dense layers run through the fused MFMA chain kernel (ndjir_amd/mlp.py) wherever only
+# first-order gradients are needed; the geometric network's main pass (differentiated twice through
+# nn.grad) still runs layer by layer.  `USE_FUSED = False` forces the layer-by-layer GPU path
+# everywhere (debugging / A-B timing only; both paths run on the GPU).
+USE_FUSED = True
+
+
+def affine_params(Din, D, use_wn=False, w_init=None, b_init=None, name=None):
+    """Parameters of PF.affine inside scope `name`/affine (network.py:88-93)."""
     assert not use_wn, "weight normalisation (use_wn) is off in every shipped config"
-    Din = h.shape[-1]
     with P.parameter_scope(name), P.parameter_scope("affine"):
         W = P.get_parameter_or_create("W", (Din, D), w_init if w_init is not None else _glorot_uniform, True)
         b = P.get_parameter_or_create("b", (D,), b_init, True)
+    return W, b
+
+
+def affine(h, D, use_wn=False, w_init=None, b_init=None, name=None):
+    """network.py:88-93: PF.affine on the last axis inside parameter scope `name`/affine."""
+    Din = h.shape[-1]
+    W, b = affine_params(Din, D, use_wn, w_init, b_init, name)
     return torch.addmm(b, h.reshape(-1, Din), W).view(h.shape[:-1] + (D,))
+
+
+def _run_mlp(h, Ws, bs, act, skip_layer=-1, skip_scale=1.0, inputs=None):
+    """softplus-MLP on the last axis: fused chain kernel, or layer by layer."""
+    if USE_FUSED and act is softplus:
+        from .mlp import fused_mlp
+        return fused_mlp(h, Ws, bs, 100.0, skip_layer, skip_scale)
+    for j, (W, b) in enumerate(zip(Ws, bs)):
+        h = torch.addmm(b, h.reshape(-1, h.shape[-1]), W).view(h.shape[:-1] + (W.shape[1],))
+        if j < len(Ws) - 1:
+            h = act(h)
+            if j == skip_layer:
+                h = torch.cat([h, inputs], dim=-1) * skip_scale
+    return h
 
 
 def softplus(x, beta=100):
@@ -103,8 +130,14 @@ def query_on_grid(x, G, D, use_ste, type):
     return getattr(PF, f"{pre}query_on_{topo}")(x, G, D, use_ste=use_ste, f_init=f_init)
 
 
-def geometric_network(x, conf):
-    """network.py:154-232.  x (..., 3) -> sdf (..., 1), feature (..., 256), gain (1,)."""
+def geometric_network(x, conf, first_order_only=False, sdf_only=False):
+    """network.py:154-232.  x (..., 3) -> sdf (..., 1), feature (..., 256), gain (1,).
+
+    `first_order_only`: the caller will differentiate the outputs at most once w.r.t. the
+    parameters (sampler rounds, base-colour perturbation pass); the whole net then runs as one
+    fused MFMA chain.  The main pass of pb_render goes through `nn.grad` (second-order terms) and
+    runs layer by layer.  `sdf_only` (sampler) skips the 256 feature columns of the last layer --
+    the reference computes and discards them (sampler.py:193)."""
     with P.parameter_scope("geometric-network"):
         g = conf.geometric_network
         D, L, M = g.feature_size, g.layers, g.pe_bands
@@ -125,42 +158,85 @@ def geometric_network(x, conf):
                 h = act(h)
             h = affine(h, D + 1, use_wn, name=f"affine-{L - 1:02d}")
         else:
+            # parameters, created in the reference's order with its initialisers (network.py:195-224)
             r0 = g.initial_sphere_radius
             Dx = x.shape[-1]
             Dinputs = inputs.shape[-1]
+            Ws, bs = [], []
+            Din = Dinputs
+            skip_at = -1
             for l in range(L):
                 if l == 0:
-                    w_init = GeometricInitializer(h.shape[-1], D, 2 / D, Dx)
-                    h = act(affine(h, D, use_wn, w_init=w_init, name=f"affine-{l:02d}"))
+                    W, b = affine_params(Din, D, use_wn, GeometricInitializer(Din, D, 2 / D, Dx), name=f"affine-{l:02d}")
+                    Din = D
                 elif l in skip_layers:
-                    w_init = GeometricInitializer(D, D, 2 / (D - Dinputs), -Dinputs)
-                    h = act(affine(h, D, use_wn, w_init=w_init, name=f"affine-{l:02d}"))
+                    W, b = affine_params(D, D, use_wn, GeometricInitializer(D, D, 2 / (D - Dinputs), -Dinputs),
+                                         name=f"affine-{l:02d}")
+                    Din = D
                 elif l == L - 1:
                     Do = 1 + D
-                    w_init = GeometricInitializer(D, Do, 2 / Do, last=True)
-                    h = affine(h, Do, use_wn, w_init=w_init, b_init=np.full((Do,), -r0), name="affine-last")
+                    W, b = affine_params(D, Do, use_wn, GeometricInitializer(D, Do, 2 / Do, last=True),
+                                         np.full((Do,), -r0), name="affine-last")
                 else:
                     Do = D - Dinputs if l + 1 in skip_layers else D
-                    w_init = GeometricInitializer(h.shape[-1], Do, 2 / Do)
-                    h = act(affine(h, Do, use_wn, w_init=w_init, name=f"affine-{l:02d}"))
+                    W, b = affine_params(Din, Do, use_wn, GeometricInitializer(Din, Do, 2 / Do), name=f"affine-{l:02d}")
+                    Din = Do
                     if l + 1 in skip_layers:
-                        h = torch.cat([h, inputs], dim=-1)
-                        if g.use_inv_square:
-                            h = h / np.sqrt(2)
+                        skip_at = l
+                        Din = Do + Dinputs
+                Ws.append(W)
+                bs.append(b)
+            scale = 1.0 / np.sqrt(2) if g.use_inv_square else 1.0
+            if sdf_only:
+                Ws = Ws[:-1] + [_sdf_column(Ws[-1])]
+                bs = bs[:-1] + [_sdf_column(bs[-1])]
+            if first_order_only and USE_FUSED and act is softplus:
+                h = _run_mlp(inputs, Ws, bs, act, skip_at, scale)
+            else:
+                for l in range(L):
+                    h = torch.addmm(bs[l], h.reshape(-1, h.shape[-1]), Ws[l]).view(h.shape[:-1] + (Ws[l].shape[1],))
+                    if l < L - 1:
+                        h = act(h)
+                        if l == skip_at:
+                            h = torch.cat([h, inputs], dim=-1) * scale
         sdf, feature = h[..., 0:1], h[..., 1:]
         gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain]), True)
         gain = torch.exp(gain * 10).clamp(1e-6, 5e4)
     return sdf, feature, gain
 
 
+_SDF_COL_CACHE = {}
+
+
+def _sdf_column(t):
+    """Column 0 of the last layer (weights (D, 1+D) -> (D, 1), bias (1+D,) -> (1,)) as a stable
+    tensor object (so that its packed copy is cached); refreshed when the parameter changes."""
+    key = (t.data_ptr(), t._version)
+    hit = _SDF_COL_CACHE.get(key)
+    if hit is None or hit[0] is not t:
+        if len(_SDF_COL_CACHE) > 16:
+            _SDF_COL_CACHE.clear()
+        col = t.detach()[..., 0:1].contiguous()
+        hit = (t, col)
+        _SDF_COL_CACHE[key] = hit
+    return hit[1]
+
+
 def _last_act(name, beta):
     return {"softplus": lambda v: TF.softplus(v, beta=beta), "relu": torch.relu, "sigmoid": torch.sigmoid}[name]
 
 
-def _hidden(h, D, L, act, use_wn, shift=0):
+def _mlp(h, D, L, Dout, act, use_wn, shift=0):
+    """L-1 hidden layers of width D named affine-{l-shift:02d} + output layer affine-{L-1:02d}."""
+    Ws, bs = [], []
+    Din = h.shape[-1]
     for l in range(L - 1):
-        h = act(affine(h, D, use_wn, name=f"affine-{l - shift:02d}"))
-    return h
+        W, b = affine_params(Din, D, use_wn, name=f"affine-{l - shift:02d}")
+        Ws.append(W); bs.append(b)
+        Din = D
+    W, b = affine_params(Din, Dout, use_wn, name=f"affine-{L - 1:02d}")
+    Ws.append(W); bs.append(b)
+    return _run_mlp(h, Ws, bs, act)
 
 
 def _cat_inputs(x, feature, normal, c):
@@ -172,8 +248,8 @@ def base_color_network(x, feature, normal, conf):
     """network.py:235-263."""
     with P.parameter_scope("base-color-network"):
         c = conf.base_color_network
-        h = _hidden(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, _act(c.act), conf.use_wn)
-        return torch.sigmoid(affine(h, 3, conf.use_wn, name=f"affine-{c.layers - 1:02d}"))
+        h = _mlp(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, 3, _act(c.act), conf.use_wn)
+        return torch.sigmoid(h)
 
 
 def environment_light_network(light_dirs, conf):
@@ -181,8 +257,7 @@ def environment_light_network(light_dirs, conf):
     with P.parameter_scope("environment-light-network"):
         c = conf.environment_light_network
         h = positional_encoding(light_dirs, c.pe_bands) if c.pe_bands > 0 else light_dirs
-        h = _hidden(h, c.feature_size, c.layers, _act(c.act), conf.use_wn)
-        h = affine(h, c.channels, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        h = _mlp(h, c.feature_size, c.layers, c.channels, _act(c.act), conf.use_wn)
         out = _last_act(c.act_last, c.inverse_black_degree)(h)
         if c.upper_bound > 0:
             out = out.clamp(0.0, c.upper_bound)
@@ -195,8 +270,7 @@ def implicit_illumination_network(x, feature, normal, conf):
         c = conf.implicit_illumination_network
         if not c.use_me:
             return torch.zeros(x.shape[:-1] + (1,), dtype=x.dtype, device=x.device)
-        h = _hidden(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, _act(c.act), conf.use_wn)
-        h = affine(h, c.channels, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        h = _mlp(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, c.channels, _act(c.act), conf.use_wn)
         return _last_act(c.act_last, c.inverse_black_degree)(h)
 
 
@@ -206,8 +280,7 @@ def soft_visibility_light_network(x, light_dirs, feature, normal, conf):
         c = conf.soft_visibility_light_network
         pe = positional_encoding(light_dirs, c.pe_bands) if c.pe_bands > 0 else light_dirs
         inputs = [x, pe] + ([feature] if c.use_geometric_feature else []) + ([normal] if c.use_normal else [])
-        h = _hidden(torch.cat(inputs, dim=-1), c.feature_size, c.layers, _act(c.act), conf.use_wn)
-        h = affine(h, c.channels, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        h = _mlp(torch.cat(inputs, dim=-1), c.feature_size, c.layers, c.channels, _act(c.act), conf.use_wn)
         return _last_act(c.act_last, c.inverse_black_degree)(h)
 
 
@@ -223,8 +296,7 @@ def photogrammetric_light_network(x, camloc, view, feature, normal, conf):
             d = x - camloc.reshape(B, 1, 1, 3)
             dist2 = torch.sqrt((d * d).sum(-1, keepdim=True)) ** 2
             inputs.append(1.0 / (dist2 + 1e-5))
-        h = _hidden(torch.cat(inputs, dim=-1), c.feature_size, c.layers, _act(c.act), conf.use_wn)
-        h = affine(h, c.channels, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        h = _mlp(torch.cat(inputs, dim=-1), c.feature_size, c.layers, c.channels, _act(c.act), conf.use_wn)
         gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain_lv_start]), False)
         return torch.sigmoid(gain.reshape((1,) * h.dim()) * h)
 
@@ -233,8 +305,7 @@ def roughness_network(x, feature, normal, conf):
     """network.py:427-464 (hidden layers are named affine--1, affine-00, affine-01; :450-454)."""
     with P.parameter_scope("roughness-network"):
         c = conf.roughness_network
-        h = _hidden(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, _act(c.act), conf.use_wn, shift=1)
-        h = affine(h, 2, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        h = _mlp(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, 2, _act(c.act), conf.use_wn, shift=1)
         h0, h1 = h[..., 0:1], h[..., 1:2]
         std = TF.softplus(h1)
         r = torch.sigmoid(h0)
@@ -250,8 +321,7 @@ def specular_reflectance_network(x, feature, normal, conf):
         Do = c.channels
         if c.fixme:
             return torch.full(x.shape[:-1] + (Do,), 0.04, dtype=x.dtype, device=x.device), None
-        h = _hidden(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, _act(c.act), conf.use_wn, shift=1)
-        h = affine(h, Do * 2, conf.use_wn, name=f"affine-{c.layers - 1:02d}")
+        h = _mlp(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, Do * 2, _act(c.act), conf.use_wn, shift=1)
         h0, h1 = h[..., :-Do], h[..., Do:]
         std = TF.softplus(h1)
         s = torch.sigmoid(h0)
@@ -270,8 +340,7 @@ def background_network(x, view, delta, conf):
         act = _act(c.act)
         with P.parameter_scope("geometric-network"):
             h = positional_encoding(x, c.pe_bands0) if c.pe_bands0 > 0 else x
-            h = _hidden(h, c.feature_size0, c.layers0, act, conf.use_wn)
-            h = affine(h, c.feature_size0 + 1, conf.use_wn, name=f"affine-{c.layers0 - 1:02d}")
+            h = _mlp(h, c.feature_size0, c.layers0, c.feature_size0 + 1, act, conf.use_wn)
             density, feature = softplus(h[..., 0:1], 100), h[..., 1:]
             alpha = 1 - torch.exp(-density * delta)
         with P.parameter_scope("lighting-network"):
@@ -280,6 +349,5 @@ def background_network(x, view, delta, conf):
                 h = torch.cat([x, feature, view, positional_encoding(view, c.pe_bands1)], dim=-1)
             else:
                 h = torch.cat([x, feature, view], dim=-1)
-            h = _hidden(h, c.feature_size1, c.layers1, act, conf.use_wn)
-            color = torch.sigmoid(affine(h, 3, conf.use_wn, name=f"affine-{c.layers1 - 1:02d}"))
+            color = torch.sigmoid(_mlp(h, c.feature_size1, c.layers1, 3, act, conf.use_wn))
     return alpha, color

@@ -159,7 +159,7 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     G = conf.geometric_network.voxel.grid_size
     r = conf.renderer.bounding_sphere_radius
     x_fg_ptb = x_fg + rand["noise"] * (math.sqrt(3) * 2 * r / G)
-    _, feature_ptb, _ = geometric_network(x_fg_ptb, conf)
+    _, feature_ptb, _ = geometric_network(x_fg_ptb, conf, first_order_only=True)
     base_color_ptb = base_color_network(x_fg_ptb, feature_ptb, None, conf)
 
     return dict(color_pixel=color_pixel, sdf_x_fg=sdf_x_fg, grad_x_fg=grad_x_fg, alpha_fg=alpha_fg,

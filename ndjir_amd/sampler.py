@@ -115,7 +115,7 @@ class SamplePoints:
         tn, tf = t_near.reshape(B, R, 1, 1), t_far.reshape(B, R, 1, 1)
         for u in range(U):
             x = c + t * d
-            sdf, _, _ = geometric_network(x, self.conf)
+            sdf, _, _ = geometric_network(x, self.conf, first_order_only=True, sdf_only=True)
             gain = self.conf.renderer.sampling_sigmoid_gain * 2 ** u
             t_in = t
             t, idx = self.importance_round(t, sdf, tn, tf, gain, M)

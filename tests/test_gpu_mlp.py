@@ -110,3 +110,33 @@ def test_fused_mlp_throughput(gpu):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 10
         print(f"\nchain fwd geometric P={P} keep_hidden={keep}: {dt * 1e6:.0f} us, {flops / dt / 1e12:.1f} TFLOP/s")
+
+
+@pytest.mark.parametrize("P,K,N", [(1000, 301, 128), (65, 39, 1), (4096, 256, 257), (33, 5, 7), (20000, 213, 256)])
+def test_wgrad_kernel(gpu, P, K, N):
+    """split-P weight-gradient GEMM vs fp64; strided operand views (delta of the skip layer)."""
+    from ndjir_amd.mlp import wgrad
+    rng = np.random.RandomState(5)
+    A = torch.tensor(rng.randn(P, K + 3), dtype=torch.float32)
+    B = torch.tensor(rng.randn(P, N + 5), dtype=torch.float32)
+    out = wgrad(A.to(gpu)[:, :K], B.to(gpu)[:, 2:2 + N])
+    ref = A[:, :K].double().t() @ B[:, 2:2 + N].double()
+    err = float((out.cpu().double() - ref).norm() / ref.norm())
+    assert err < 2e-6, err
+
+
+def test_wgrad_throughput(gpu):
+    import time
+    from ndjir_amd.mlp import wgrad
+    P, K, N = 65536, 256, 256
+    A = torch.randn(P, K, device=gpu)
+    B = torch.randn(P, N, device=gpu)
+    for fn, name in ((wgrad, "ndjir wgrad"), (lambda a, b: a.t().mm(b), "library A^T B")):
+        fn(A, B)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            fn(A, B)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        print(f"\n{name}: {dt * 1e6:.0f} us, {2 * P * K * N / dt / 1e12:.1f} TFLOP/s")
