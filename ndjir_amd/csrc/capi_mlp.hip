@@ -1,5 +1,6 @@
 // capi_mlp.hip -- C ABI of the fused MLP engine (declarations: include/ndjir_hip.h).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/ndjir_hip.h"
 #include "common.h"
@@ -29,6 +30,8 @@ extern "C" int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, in
   if (!X || L < 1 || L > MAX_CHAIN_LAYERS || !Wp || !Ks || !Ns) return NDJIR_ERR_ARG;
   if (has_output && !Y) return NDJIR_ERR_ARG;
   ChainArgs a{};
+  static const int tile_rows = [] { const char* e = getenv("NDJIR_MLP_TILE"); return e ? atoi(e) : 64; }();
+  a.tile_rows = tile_rows;
   a.P = P; a.X = X; a.ldx = ldx; a.K0 = K0; a.K0p = round_up(K0, 8); a.L = L;
   a.Y = Y; a.ldy = ldy; a.accum_y = accum_y; a.has_output = has_output; a.beta = beta;
   a.skip_layer = skip_layer; a.skip_scale = skip_scale; a.skip_split = skip_split; a.Xskip = Xskip; a.ld_xskip = ld_xskip;

@@ -32,6 +32,7 @@ struct ChainArgs {
                         // bwd: layer whose output is that concatenated gradient
   int skip_split;       // bwd: first column of the concatenated-input part
   int lds_split;        // filled by launch_chain
+  int tile_rows;        // 64 (default) or 32 points per workgroup
   float skip_scale;
   float beta;
   ChainLayer layers[MAX_CHAIN_LAYERS];

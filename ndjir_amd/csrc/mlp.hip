@@ -29,10 +29,8 @@
 
 namespace ndjir {
 
-constexpr int TM = 64;
 constexpr int NWAVES = 8;
 constexpr int NTHREADS = NWAVES * 64;
-constexpr int GP = TM * 4 + 4;   // dwords per group of 4 features
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -68,8 +66,10 @@ __global__ void __launch_bounds__(256) k_pack(const float* __restrict__ W, float
 }
 
 // ---- the chain kernel ---------------------------------------------------------------------------
-template <bool BWD>
-__global__ void __launch_bounds__(NTHREADS, 2) k_mlp_chain(ChainArgs a) {
+template <bool BWD, int TM>
+__global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(ChainArgs a) {
+  constexpr int GP = TM * 4 + 4;   // dwords per group of 4 features
+  constexpr int RB = TM / 32;      // 32-row blocks per tile
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* bufA = lds;                             // input-side buffer (sized for Kmax0)
   float* bufB = lds + (size_t)(a.lds_split);     // second buffer
@@ -119,8 +119,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_chain(ChainArgs a) {
 
       if (NB == 1) {
         // ---- narrow output (N <= 32): split K over 4 wave groups, reduce through LDS ----
-        const int rb = wave & 1, ks = wave >> 1;
-        const int kb0 = (KB * ks) / 4, kb1 = (KB * (ks + 1)) / 4;
+        constexpr int KS = NWAVES / RB;          // K slices
+        const int rb = wave % RB, ks = wave / RB;
+        const int kb0 = (KB * ks) / KS, kb1 = (KB * (ks + 1)) / KS;
         f32x16 acc = {0};
         const f32x4* Bp = reinterpret_cast<const f32x4*>(ly.Wp) + lane;
         for (int kb = kb0; kb < kb1; ++kb) {
@@ -129,13 +130,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_chain(ChainArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b[j], acc, 0, 0, 0);
         }
-        // partials: nxt[ks][m][n] (4 x 64 x 32 floats = 32 KiB)
+        // partials: nxt[ks][m][n] (KS x TM x 32 floats = 32 KiB)
 #pragma unroll
         for (int i = 0; i < 16; ++i) nxt[(ks * TM + rb * 32 + acc_row(i, h)) * 32 + r] = acc[i];
         __syncthreads();
         for (int t = tid; t < TM * 32; t += NTHREADS) {
           int n = t & 31, m = t >> 5;
-          float z = nxt[t] + nxt[TM * 32 + t] + nxt[2 * TM * 32 + t] + nxt[3 * TM * 32 + t];
+          float z = 0.f;
+#pragma unroll
+          for (int q = 0; q < KS; ++q) z += nxt[q * TM * 32 + t];
           if (n < ly.N && m < rows) {
             if (!BWD) {
               z += ly.bias ? ly.bias[n] : 0.f;
@@ -154,26 +157,33 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_chain(ChainArgs a) {
 
       // ---- general layer: each wave owns column blocks nb = wave, wave + 8, ... ----
       for (int nb = wave; nb < NB; nb += NWAVES) {
-        f32x16 acc0 = {0}, acc1 = {0};
+        f32x16 acc[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) acc[q] = f32x16{0};
         const f32x4* Bp = reinterpret_cast<const f32x4*>(ly.Wp) + (long long)nb * KB * 64 + lane;
         const float* A0 = cur + h * GP + r * 4;
         f32x4 b = Bp[0];
-        f32x4 a0 = *reinterpret_cast<const f32x4*>(A0);
-        f32x4 a1 = *reinterpret_cast<const f32x4*>(A0 + 32 * 4);
+        f32x4 av[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) av[q] = *reinterpret_cast<const f32x4*>(A0 + q * 32 * 4);
         for (int kb = 0; kb < KB; ++kb) {
-          f32x4 bn = b, a0n = a0, a1n = a1;
+          f32x4 bn = b, avn[RB];
+#pragma unroll
+          for (int q = 0; q < RB; ++q) avn[q] = av[q];
           if (kb + 1 < KB) {                     // prefetch the next k-block
             bn = Bp[(long long)(kb + 1) * 64];
             const float* An = A0 + (kb + 1) * 2 * GP;
-            a0n = *reinterpret_cast<const f32x4*>(An);
-            a1n = *reinterpret_cast<const f32x4*>(An + 32 * 4);
+#pragma unroll
+            for (int q = 0; q < RB; ++q) avn[q] = *reinterpret_cast<const f32x4*>(An + q * 32 * 4);
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[j], acc1, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < RB; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], b[j], acc[q], 0, 0, 0);
           }
-          b = bn; a0 = a0n; a1 = a1n;
+          b = bn;
+#pragma unroll
+          for (int q = 0; q < RB; ++q) av[q] = avn[q];
         }
 
         // ---- epilogue, pass 1: raw accumulators -> LDS (activation layout, conflict-free) ----
@@ -183,88 +193,116 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_chain(ChainArgs a) {
           float* dst = nxt + (n >> 2) * GP + (n & 3);
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            dst[acc_row(i, h) * 4] = acc0[i];
-            dst[(32 + acc_row(i, h)) * 4] = acc1[i];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) dst[(q * 32 + acc_row(i, h)) * 4] = acc[q][i];
           }
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // ---- pass 2: this wave's 64 x 32 block, one float4 (4 columns of one row) per lane-step ----
+        // ---- pass 2: this wave's TM x 32 block, one float4 (4 columns of one row) per lane-step ----
         {
           const int g = lane & 7;                 // column group inside the block
           const int n4 = nb * 32 + g * 4;         // first of the 4 columns
-          f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-          if (!BWD && ly.bias) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (n4 + q < ly.N) bias4[q] = ly.bias[n4 + q];
-          }
-          f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
           const bool is_skip = (li == a.skip_layer);
           const float sc = is_skip ? a.skip_scale : 1.f;
-          for (int it = 0; it < 8; ++it) {
+          const int nlim = (BWD && is_skip) ? a.skip_split : ly.N;   // columns that take the activation path
+          // per-lane column masks (1/0) instead of branches
+          f32x4 cm, bias4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cm[q] = (n4 + q < nlim) ? 1.f : 0.f;
+          if (!BWD && ly.bias) {
+            if (n4 + 3 < ly.N) bias4 = *reinterpret_cast<const f32x4*>(ly.bias + n4);   // biases are 16-byte aligned rows
+            else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (n4 + q < ly.N) bias4[q] = ly.bias[n4 + q];
+            }
+          }
+          const bool vec_ok = (n4 + 3 < nlim);
+          const float inv_beta = 1.f / beta;
+          const float nbs = -beta / sc;
+          f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+          float* lp = nxt + ((last ? wave * 32 + g * 4 : n4) >> 2) * GP + (lane >> 3) * 4;
+          const long long grow0 = row0 + (lane >> 3);
+          for (int it = 0; it < TM / 8; ++it, lp += 32) {
             const int m = (lane >> 3) + 8 * it;
-            float* lp = nxt + ((last ? wave * 32 + g * 4 : n4) >> 2) * GP + m * 4;
-            f32x4 z = *reinterpret_cast<f32x4*>(lp);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const bool mrow = m < rows;
-            const long long grow = row0 + m;
-            if (!BWD) {
+            const float rm = mrow ? 1.f : 0.f;
+            const long long grow = grow0 + 8 * it;
+            f32x4 z = *reinterpret_cast<f32x4*>(lp);
+            f32x4 v;
+            if (!BWD && !last) {
+              // hidden forward layer: softplus_beta(z + b) [* skip scale]
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 float t = z[q] + bias4[q];
-                if (!last) t = softplus_beta(t, beta) * sc;
-                v[q] = (n4 + q < ly.N && mrow) ? t : 0.f;
+                float bz = beta * t;
+                float sp = __logf(1.f + __expf(bz)) * inv_beta;
+                t = bz > 20.f ? t : sp;
+                v[q] = t * (sc * cm[q] * rm);
               }
+              if (mrow && ly.side_out) {
+                float* o = ly.side_out + grow * ly.ld_side + n4;
+                if (vec_ok && (ly.ld_side & 3) == 0) *reinterpret_cast<f32x4*>(o) = v;
+                else {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) if (n4 + q < ly.N) o[q] = v[q];
+                }
+              }
+              *reinterpret_cast<f32x4*>(lp) = v;
+            } else if (last) {
+              // output layer (forward: + bias; backward: plain) -> Y
               if (mrow) {
-                if (last) {
-                  float* y = a.Y + grow * a.ldy + n4;
+                float* y = a.Y + grow * a.ldy + n4;
+                if (vec_ok && (a.ldy & 3) == 0 && !a.accum_y) {
+                  f32x4 t = z;
+                  if (!BWD) t += bias4;
+                  *reinterpret_cast<f32x4*>(y) = t;
+                } else {
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) if (n4 + q < ly.N) y[q] = a.accum_y ? y[q] + v[q] : v[q];
-                } else if (ly.side_out) {
-                  float* o = ly.side_out + grow * ly.ld_side + n4;
-                  if (n4 + 3 < ly.N && (ly.ld_side & 3) == 0) *reinterpret_cast<f32x4*>(o) = v;
-                  else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (n4 + q < ly.N) o[q] = v[q];
+                  for (int q = 0; q < 4; ++q) {
+                    if (n4 + q < ly.N) {
+                      float t = z[q] + (BWD ? 0.f : bias4[q]);
+                      y[q] = a.accum_y ? y[q] + t : t;
+                    }
                   }
                 }
               }
-            } else if (last) {
-              if (mrow) {
-                float* y = a.Y + grow * a.ldy + n4;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (n4 + q < ly.N) y[q] = a.accum_y ? y[q] + z[q] : z[q];
-              }
             } else {
-              // this GEMM produced dL/dh of the layer below; its stored activation gives softplus'
+              // backward hidden step: this GEMM produced dL/dh of the layer below; its stored
+              // activation h gives softplus'(z) = 1 - exp(-beta h)   (h is stored * skip_scale on the skip layer)
+              f32x4 hs = {0.f, 0.f, 0.f, 0.f};
               if (mrow) {
+                const float* hp = ly.side_in + grow * ly.ld_side + n4;
+                if (vec_ok && (ly.ld_side & 3) == 0) hs = *reinterpret_cast<const f32x4*>(hp);
+                else {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) if (n4 + q < nlim) hs[q] = hp[q];
+                }
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float sp = (1.f - __expf(nbs * hs[q])) * sc;
+                v[q] = z[q] * sp * (cm[q] * rm);
+              }
+              if (is_skip && mrow && a.Xskip) {
+                // gradient of the concatenated chain input: stash (scaled) for the final dL/dX
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                   const int n = n4 + q;
-                  if (n >= ly.N) continue;
-                  if (is_skip && n >= a.skip_split) {
-                    // gradient of the concatenated chain input: stash (scaled) for the final dL/dX
-                    if (a.Xskip) a.Xskip[grow * a.ld_xskip + (n - a.skip_split)] = z[q] * sc;
-                    continue;
-                  }
-                  // stored activation is h * skip_scale on the skip layer
-                  float hs = ly.side_in[grow * ly.ld_side + n];
-                  float sp = (1.f - __expf(-beta * hs / sc)) * sc;
-                  v[q] = z[q] * sp;
+                  if (n >= a.skip_split && n < ly.N) a.Xskip[grow * a.ld_xskip + (n - a.skip_split)] = z[q] * sc;
                 }
-                if (ly.side_out) {
-                  const int nlim = is_skip ? a.skip_split : ly.N;
-                  float* o = ly.side_out + grow * ly.ld_side + n4;
-                  if (n4 + 3 < nlim && (ly.ld_side & 3) == 0) *reinterpret_cast<f32x4*>(o) = v;
-                  else {
+              }
+              if (mrow && ly.side_out) {
+                float* o = ly.side_out + grow * ly.ld_side + n4;
+                if (vec_ok && (ly.ld_side & 3) == 0) *reinterpret_cast<f32x4*>(o) = v;
+                else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (n4 + q < nlim) o[q] = v[q];
-                  }
+                  for (int q = 0; q < 4; ++q) if (n4 + q < nlim) o[q] = v[q];
                 }
               }
               colsum += v;
+              *reinterpret_cast<f32x4*>(lp) = v;
             }
-            if (!last) *reinterpret_cast<f32x4*>(lp) = v;
           }
           if (BWD && !last && ly.bgrad) {
 #pragma unroll
@@ -273,7 +311,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_mlp_chain(ChainArgs a) {
               c += __shfl_xor(c, 8);
               c += __shfl_xor(c, 16);
               c += __shfl_xor(c, 32);
-              if (lane < 8 && n4 + q < (is_skip ? a.skip_split : ly.N)) atomicAdd(ly.bgrad + n4 + q, c);
+              if (lane < 8 && n4 + q < nlim) atomicAdd(ly.bgrad + n4 + q, c);
             }
           }
         }
@@ -321,26 +359,35 @@ int launch_chain(const ChainArgs& a, bool bwd, hipStream_t stream) {
   }
   if (a.skip_layer >= 0 && !bwd) { int w = round_up(a.layers[a.skip_layer].N + a.K0, 8); if (w > wmax) wmax = w; }
   int wa = a.K0p > wmax ? a.K0p : wmax;
+  const int TM = a.tile_rows == 32 ? 32 : 64;
+  const int GP = TM * 4 + 4;
   size_t szA = (size_t)(wa / 4) * GP * 4;
   size_t szB = (size_t)(wmax / 4) * GP * 4;
-  const size_t partials = (size_t)4 * TM * 32 * 4;                     // narrow-layer partial sums
+  const size_t partials = (size_t)8 * 32 * 32 * 4;                     // narrow-layer partial sums
   if (szA < partials) szA = partials;
   if (szB < partials) szB = partials;
   ChainArgs b = a;
   b.lds_split = (int)(szA / 4);
-  b.n_tiles = (a.P + TM - 1) / TM;
+  b.n_tiles = (a.P + TM - 1) / TM;   // TM defined above
   size_t lds_bytes = szA + szB;
   if (lds_bytes > 160 * 1024) return NDJIR_ERR_UNSUPPORTED;
   long long blocks = b.n_tiles;
   if (blocks > 256LL * 8) blocks = 256LL * 8;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[bwd]) {
-    if (bwd) hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    else hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set[bwd] = true;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
   }
-  if (bwd) hipLaunchKernelGGL((k_mlp_chain<true>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b);
-  else hipLaunchKernelGGL((k_mlp_chain<false>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b);
+  if (TM == 64) {
+    if (bwd) hipLaunchKernelGGL((k_mlp_chain<true, 64>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b);
+    else hipLaunchKernelGGL((k_mlp_chain<false, 64>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b);
+  } else {
+    if (bwd) hipLaunchKernelGGL((k_mlp_chain<true, 32>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b);
+    else hipLaunchKernelGGL((k_mlp_chain<false, 32>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b);
+  }
   return ndjir_check_launch();
 }
 

@@ -43,24 +43,35 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad(const float* __restrict
   f32x16 acc[2][2] = {};
   float ra[16], rb[16];
 
+  // element e = tid + 256 i of a 32 x 128 chunk: column = tid & 127 (fixed), row = (tid >> 7) + 2 i
+  const int col = tid & (WG_T - 1), rbase = tid >> 7;
+  const bool acol = (k0 + col) < K, bcol = (n0 + col) < N;
+  const float* Ap = A + (long long)rbase * lda + k0 + col;
+  const float* Bp = B + (long long)rbase * ldb + n0 + col;
+  const long long astep = 2LL * lda, bstep = 2LL * ldb;
   auto load_chunk = [&](long long p0) {
+    const float* ap = Ap + p0 * lda;
+    const float* bp = Bp + p0 * ldb;
+    if (p0 + WG_C <= p_end) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      int e = tid + WG_THREADS * i;
-      int col = e & (WG_T - 1), row = e >> 7;
-      long long p = p0 + row;
-      bool pv = p < p_end;
-      ra[i] = (pv && k0 + col < K) ? A[p * lda + k0 + col] : 0.f;
-      rb[i] = (pv && n0 + col < N) ? B[p * ldb + n0 + col] : 0.f;
+      for (int i = 0; i < 16; ++i) {
+        ra[i] = acol ? ap[i * astep] : 0.f;
+        rb[i] = bcol ? bp[i * bstep] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        bool pv = p0 + rbase + 2 * i < p_end;
+        ra[i] = (pv && acol) ? ap[i * astep] : 0.f;
+        rb[i] = (pv && bcol) ? bp[i * bstep] : 0.f;
+      }
     }
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      int e = tid + WG_THREADS * i;
-      int col = e & (WG_T - 1), row = e >> 7;
-      As[buf][row][col] = ra[i];
-      Bs[buf][row][col] = rb[i];
+      As[buf][rbase + 2 * i][col] = ra[i];
+      Bs[buf][rbase + 2 * i][col] = rb[i];
     }
   };
 
@@ -104,17 +115,40 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad(const float* __restrict
 
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ out,
                                                       long long KN, int S, int accum) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < KN; i += (long long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += partial[(long long)k * KN + i];
-    out[i] = accum ? out[i] + s : s;
+  // one float4 of the output per thread; 8 independent loads in flight per thread
+  const long long n4 = KN >> 2;
+  const bool vec = ((KN & 3) == 0);
+  if (vec) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4* p = reinterpret_cast<const float4*>(partial) + i;
+      int k = 0;
+      for (; k + 8 <= S; k += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(k + u) * n4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+      }
+      for (; k < S; ++k) { float4 v = p[(long long)k * n4]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+      float4* o = reinterpret_cast<float4*>(out) + i;
+      if (accum) { float4 c = *o; s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; }
+      *o = s;
+    }
+  } else {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < KN; i += (long long)gridDim.x * blockDim.x) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < S; ++k) s += partial[(long long)k * KN + i];
+      out[i] = accum ? out[i] + s : s;
+    }
   }
 }
 
 // workspace floats needed for (K, N): S * K * N with the S chosen below
 static inline int pick_splits(int K, int N, long long P) {
   int T = ((K + WG_T - 1) / WG_T) * ((N + WG_T - 1) / WG_T);
-  int S = (512 + T - 1) / T;                       // ~2 workgroups per CU
+  int S = (256 + T - 1) / T;                       // ~1 workgroup (4 waves) per CU keeps every SIMD's matrix pipe busy
   long long max_s = (P + WG_C - 1) / WG_C;
   if (S > max_s) S = (int)max_s;
   if (S < 1) S = 1;
@@ -134,8 +168,9 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
   hipLaunchKernelGGL(k_wgrad, dim3(S * tiles_k * tiles_n), dim3(WG_THREADS), 0, stream, A, lda, B, ldb, K, N, P, workspace, S,
                      tiles_k, tiles_n, rows);
   const long long KN = (long long)K * N;
-  int blocks = (int)((KN + 255) / 256);
+  int blocks = (int)(((KN + 3) / 4 + 255) / 256);
   if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, stream, workspace, out, KN, S, accum);
   return ndjir_check_launch();
 }
