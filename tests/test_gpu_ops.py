@@ -112,22 +112,25 @@ def test_grid_family_vs_oracle(gpu, family, P, G, hash_cfg):
     fd = T(f, gpu).requires_grad_(True)
     out = _core.query(family, qd, fd, hcfg=hash_cfg)
     ref = o.query(q, f)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=2e-6 if lz else 1e-6)
+    # the finest hash levels (G ~ 7000) resolve the cell fraction to ~1e-4 in fp32: 1-2 ulp of the
+    # continuous coordinate moves a coefficient by ~1e-3
+    fine = hash_cfg is not None and hash_cfg[3] > 8
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=2e-5 if fine else (2e-6 if lz else 1e-6))
     og = rng.randn(*ref.shape).astype(np.float32)
     ogd = T(og, gpu).requires_grad_(True)
     gq = _core.grad_query(family, ogd, qd, fd, hcfg=hash_cfg)
     gq_ref = o.grad_query(og, q, f)
     scale = max(1.0, np.abs(gq_ref).max())
-    np.testing.assert_allclose(gq.detach().cpu().numpy(), gq_ref, atol=(2e-5 if lz else 2e-6) * scale)
+    np.testing.assert_allclose(gq.detach().cpu().numpy(), gq_ref, atol=(2e-5 if lz else 2e-6) * scale, rtol=1e-3 if fine else 1e-7)
     gf = _core.grad_feature(family, ogd, qd, fd, hcfg=hash_cfg)
     gf_ref = o.grad_feature(og, q, fs)
-    np.testing.assert_allclose(gf.detach().cpu().numpy(), gf_ref, atol=(5e-5 if lz else 5e-6) * max(1.0, np.abs(gf_ref).max()))
+    np.testing.assert_allclose(gf.detach().cpu().numpy(), gf_ref, atol=(2e-3 if fine else (5e-5 if lz else 5e-6)) * max(1.0, np.abs(gf_ref).max()))
     ggq = rng.randn(P, 3).astype(np.float32)
     g_go, g_f = torch.autograd.grad(gq, [ogd, fd], T(ggq, gpu))
     ggo_ref = o.grad_query_grad_grad_output(ggq, q, f)
-    np.testing.assert_allclose(g_go.cpu().numpy(), ggo_ref, atol=(2e-5 if lz else 2e-6) * max(1.0, np.abs(ggo_ref).max()))
+    np.testing.assert_allclose(g_go.cpu().numpy(), ggo_ref, atol=(2e-5 if lz else 2e-6) * max(1.0, np.abs(ggo_ref).max()), rtol=1e-3 if fine else 1e-7)
     gqgf_ref = o.grad_query_grad_feature(ggq, og, q, fs)
-    np.testing.assert_allclose(g_f.cpu().numpy(), gqgf_ref, atol=(1e-3 if lz else 2e-5) * max(1.0, np.abs(gqgf_ref).max()))
+    np.testing.assert_allclose(g_f.cpu().numpy(), gqgf_ref, atol=(2e-3 if (lz or fine) else 2e-5) * max(1.0, np.abs(gqgf_ref).max()))
 
 
 def test_grid_empty_batch(gpu):

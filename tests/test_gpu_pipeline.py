@@ -57,7 +57,7 @@ def test_sampler_parity(gpu):
         total += idx.numel()
         mism += int((pi != idx).sum())
         ok = (pi == idx).all(dim=-1)
-        np.testing.assert_allclose(rec["t_out"][u].cpu()[ok], t_out[ok], atol=1e-6, rtol=2e-6)
+        np.testing.assert_allclose(rec["t_out"][u].cpu()[ok], t_out[ok], atol=2e-6, rtol=1e-5)
     assert mism <= 1e-3 * total, (mism, total)
 
 
