@@ -8,6 +8,11 @@ One step = sample_points -> pb_render -> total_loss -> backward to every paramet
 samples, 128 lights), synthetic rays, reference-initialised weights.  Rays shard across ranks
 (weak scaling: 512 rays per GPU); one gradient exchange per step over RCCL.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+
+`roofline` is for the dominant hand-written kernel, `ndjir::k_mlp_chain<false, TM>` (fused MLP
+forward chain): achieved = sum of the algorithmic FLOPs (2*in*out per affine per point)
+of its launches / sum of their durations, measured live with HIP events recorded on the launching
+stream around every launch inside the timed region.
 """
 import argparse
 import json
@@ -23,7 +28,7 @@ if ROOT not in sys.path:
 
 # dense-GEMM FLOPs (2*in*out per affine per point), default config
 MFLOP_PER_RAY_FWD_BWD = 2168.9
-PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 
 
 def parse():
@@ -60,7 +65,6 @@ class Step:
         self.rand = {k: v[:, rank * R:(rank + 1) * R].contiguous().to(device) for k, v in full.items()}
         self.car = torch.ones(1, device=device)
         self.P = P
-        self.set_grad_buffer = set_grad_buffer
         self.grid_bufs = {}
         self.mlp_names = None
         self.forward_backward()          # creates the parameters (untimed)
@@ -72,20 +76,21 @@ class Step:
         params = P.get_parameters(grad_only=True)
         self.mlp_names = [k for k in params if not k.endswith("feature/F")]
         self.mlp_params = [params[k] for k in self.mlp_names]
+        self.grid_params = [p for k, p in P.get_parameters().items() if k.endswith("feature/F")]
         self.flat_grad = torch.zeros(sum(p.numel() for p in self.mlp_params), device=device)
 
     def forward_backward(self):
         from ndjir_amd.loss import total_loss
         for buf in self.grid_bufs.values():
             buf.zero_()
-        out = total_loss(self.camloc, self.raydir, self.color_gt, None, self.car, self.conf, self.rand)
+        out = total_loss(self.camloc, self.raydir, self.color_gt, None, self.car, self.conf, self.rand,
+                         ray_shards=self.world)
         loss = out["loss"]
         if self.mlp_names is None:
             params = [p for p in self.P.get_parameters(grad_only=True).values()]
             torch.autograd.grad(loss, params, allow_unused=True)
             return loss.detach()
-        grid_params = [p for k, p in self.P.get_parameters().items() if k.endswith("feature/F")]
-        grads = torch.autograd.grad(loss, self.mlp_params + grid_params, allow_unused=True)
+        grads = torch.autograd.grad(loss, self.mlp_params + self.grid_params, allow_unused=True)
         off = 0
         for p, g in zip(self.mlp_params, grads):
             n = p.numel()
@@ -96,9 +101,10 @@ class Step:
             off += n
         if self.world > 1:
             import torch.distributed as dist
-            dist.all_reduce(self.flat_grad)           # one flat bucket, SUM
-            for buf in self.grid_bufs.values():       # TODO(round 2): exchange scatter operands, not the dense grid
-                dist.all_reduce(buf)
+            # total_loss already normalised by the GLOBAL ray / mask counts: gradients just add up
+            dist.all_reduce(self.flat_grad)           # one flat 5.9 MB bucket, SUM over xGMI
+            for buf in self.grid_bufs.values():
+                dist.all_reduce(buf)                  # dense; see DESIGN.md for the planned sparse exchange
         return loss.detach()
 
 
@@ -130,6 +136,21 @@ def cpu_baseline(conf, step, n_rays):
                        f"{cores} of {os.cpu_count()} host cores, {el:.1f} s")
 
 
+def kernel_report(profile):
+    """Aggregate the live HIP-event records of the MLP engine (ndjir_amd.mlp.PROFILE)."""
+    agg = {}
+    for kind, flops, e0, e1 in profile:
+        a = agg.setdefault(kind, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += e0.elapsed_time(e1) * 1e-3
+    rep = {}
+    for kind, (n, flops, sec) in agg.items():
+        rep[kind] = dict(launches=n, avg_us=1e6 * sec / max(n, 1), tflops=flops / max(sec, 1e-12) / 1e12,
+                         gflop_per_launch=flops / max(n, 1) / 1e9)
+    return rep
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,7 +164,7 @@ def main():
     device = torch.device("cuda", local_rank)
 
     from ndjir_amd import config as cfg
-    from ndjir_amd import lib
+    from ndjir_amd import lib, mlp
     lib.load()  # fail loudly if the HIP extension is missing
     conf = cfg.load(a.config, a.override)
     R = a.rays
@@ -157,11 +178,13 @@ def main():
     for _ in range(a.warmup):
         step.forward_backward()
     barrier()
+    mlp.PROFILE = [] if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step.forward_backward()
     barrier()
     el = time.perf_counter() - t0
+    profile, mlp.PROFILE = mlp.PROFILE, None
     if world > 1:
         t = torch.tensor([el], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -172,7 +195,10 @@ def main():
         N = r.n_samples0 + r.n_samples1 * r.n_upsamples
         rays_per_s = world * R * a.steps / el
         ms = 1e3 * el / a.steps
-        achieved = MFLOP_PER_RAY_FWD_BWD * 1e6 * R / (ms * 1e-3) / 1e12      # per GPU
+        kr = kernel_report(profile)
+        dom = kr.get("chain_fwd", dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0))
+        step_tflops = MFLOP_PER_RAY_FWD_BWD * 1e6 * R / (ms * 1e-3) / 1e12      # per GPU
+        tile = os.environ.get("NDJIR_MLP_TILE", "64")
         out = {
             "metric": "rays/sec (fwd+bwd) at 512 rays x 128 samples",
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -183,9 +209,16 @@ def main():
                                    f"{conf.geometric_network.voxel.grid_size}^3x{conf.geometric_network.voxel.feature_size}, "
                                    f"total_loss fwd+bwd to all parameter gradients",
                        "rays_per_gpu": R, "samples_per_ray": N, "parallelism": f"ray-sharded x{world}"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "scope": "whole step: algorithmic dense-GEMM FLOPs (2168.9 MFLOP/ray fwd+bwd, SURVEY 8d) / step time"},
+            "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": f"ndjir::k_mlp_chain<false, {tile}> (fused MLP forward chain, fp32 MFMA 32x32x2)",
+                         "launches_per_step": dom["launches"] / max(a.steps, 1), "avg_launch_us": dom["avg_us"],
+                         "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
+                         "method": "HIP events on the launching stream around every launch in the timed region"},
+            "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kr.items()},
+            "step_roofline": {"achieved": step_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": step_tflops / PEAK_FP32_MFMA_TFLOPS,
+                              "scope": "whole step: 2168.9 MFLOP/ray fwd+bwd (SURVEY 8d) / step time"},
             "loss": float(loss),
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -14,8 +14,13 @@ from .renderer import pb_render
 from .sampler import sample_points
 
 
-def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand, record=None):
-    """camloc (B,3), raydir (B,R,3), color_gt (B,R,3), obj_mask (B,R,1) or None, cos_anneal_ratio (1,)."""
+def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand, record=None, ray_shards=1):
+    """camloc (B,3), raydir (B,R,3), color_gt (B,R,3), obj_mask (B,R,1) or None, cos_anneal_ratio (1,).
+
+    `ray_shards` > 1: this process holds one of `ray_shards` equal slices of the ray batch
+    (torch.distributed initialised).  The loss normalisers -- B*R and sum(mask) -- are then taken
+    over ALL shards (one scalar all-reduce before backward), so the sum over ranks of the returned
+    losses, and of their gradients, equals the single-process loss / gradient of the whole batch."""
     B, R, _ = color_gt.shape
     tr = conf.train
 
@@ -34,9 +39,14 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
     if tr.mask_weight > 0.0:
         loss_rgb = (err * obj_mask).sum() / (obj_mask.sum() + 1e-5)
     else:
-        loss_rgb = err.sum() / (B * R)
+        loss_rgb = err.sum() / (B * R * ray_shards)
 
-    denorm = mask.sum() * N + 1e-5
+    mask_sum = mask.sum()
+    if ray_shards > 1:
+        import torch.distributed as dist
+        mask_sum = mask_sum.clone()
+        dist.all_reduce(mask_sum)
+    denorm = mask_sum * N + 1e-5
 
     # Eikonal loss (loss.py:68-76)
     loss_eikonal = zero
@@ -62,7 +72,7 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
     if tr.mask_weight > 0.0:
         pred = res["obj_mask_pred"].clamp(1e-3, 1.0 - 1e-3)
         bce = -(obj_mask * torch.log(pred) + (1 - obj_mask) * torch.log(1 - pred))
-        loss_mask = bce.sum() / (mask.sum() + 1e-5)
+        loss_mask = bce.sum() / (mask_sum + 1e-5)
 
     # Priors (loss.py:117-166)
     prior_base_color = zero

@@ -18,6 +18,22 @@ from . import lib
 
 _PACK_CACHE = {}
 
+# Optional live timing of the engine's launches with HIP events on the launching stream
+# (bench.py sets PROFILE = [] around its timed region): entries (kind, algorithmic_flops, e0, e1).
+PROFILE = None
+
+
+def _launch(kind, flops, name, *args):
+    if PROFILE is None:
+        lib.call(name, *args)
+        return
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.call(name, *args)
+    e1.record()
+    PROFILE.append((kind, flops, e0, e1))
+
 
 def _packed(W, transpose):
     """MFMA-fragment-order copy of W (or W^T); cached per (storage, version)."""
@@ -53,7 +69,8 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
     y = torch.empty((P, Ns[-1]), device=x.device, dtype=torch.float32)
     side_out = (hidden + [None]) if keep_hidden else [None] * L
     ld_side = [h.shape[1] if h is not None else 0 for h in side_out]
-    lib.call("mlp_chain", 0, P, x, x.shape[1], K0, L, Wp, [b.detach() if b is not None else None for b in biases],
+    flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
+    _launch("chain_fwd", flops, "mlp_chain", 0, P, x, x.shape[1], K0, L, Wp, [b.detach() if b is not None else None for b in biases],
              Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
              int(skip_layer), float(skip_scale), 0, None, 0)
     return y, hidden
@@ -74,7 +91,7 @@ def wgrad(A, B):
         ws = torch.empty(max(need, 1 << 22), device=A.device, dtype=torch.float32)
         _WORKSPACE[A.device] = ws
     out = torch.empty((K, N), device=A.device, dtype=torch.float32)
-    lib.call("mlp_wgrad", _Strided(A), A.stride(0), _Strided(B), B.stride(0), K, N, P, out, 0, ws)
+    _launch("wgrad", 2.0 * P * K * N, "mlp_wgrad", _Strided(A), A.stride(0), _Strided(B), B.stride(0), K, N, P, out, 0, ws)
     return out
 
 
@@ -161,7 +178,8 @@ class FusedMLP(Function):
             if need_x:
                 gx = torch.zeros((P, K0), device=x2.device, dtype=torch.float32) if bwd_skip >= 0 else \
                     torch.empty((P, K0), device=x2.device, dtype=torch.float32)
-            lib.call("mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
+            flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
+            _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
                      side_in, side_out, ld_side, bg, gx, K0, 1 if bwd_skip >= 0 else 0, 1 if need_x else 0,
                      float(beta), int(bwd_skip), float(skip_scale), int(split),
                      gx if bwd_skip >= 0 else None, K0)
