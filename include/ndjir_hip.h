@@ -221,6 +221,21 @@ int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L
                     float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                     int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                     hipStream_t stream);
+/* Extended chain used by the geometric network, whose output gradient d(sdf)/dx itself enters the
+ * loss (nn.grad, python/renderer.py:52; eikonal term python/loss.py:68-76):
+ *   mode 0 / 1: as ndjir_mlp_chain, plus side_add[i] (P x N): extra adjoint added to delta after the
+ *               softplus' product (mode 1);
+ *   mode 2:     tangent chain of the double backward -- forward-direction weights, no bias; step l
+ *               computes s-bar_l = g-bar_l W_l, writes g-bar_{l+1} = s-bar_l * softplus'(z_l) to
+ *               side_out[l] and the extra adjoint beta * s-bar_l * s_l * exp(-beta h_l) to
+ *               side_out2[l], with h_l = side_in[l] and s_l = side_in2[l] (delta of the sdf chain). */
+int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx, int K0, int L,
+                       const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
+                       const float* const* side_in, float* const* side_out, const int* ld_side,
+                       float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
+                       int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
+                       const float* const* side_in2, const float* const* side_add, float* const* side_out2,
+                       hipStream_t stream);
 /* Weight gradient of one layer: out (K x N) (+)= A^T B with A (P x K, row stride lda) the layer's
  * input activations and B (P x N, row stride ldb) its deltas (ndjir_amd/csrc/wgrad.hip; the
  * reference gets this from nnabla's affine backward, a cuBLAS GEMM).  `workspace` needs

@@ -20,11 +20,12 @@ extern "C" int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int tran
   return launch_pack(W, dst, K, N, transpose, stream);
 }
 
-extern "C" int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L,
+static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int L,
                                const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
                                const float* const* side_in, float* const* side_out, const int* ld_side,
                                float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                                int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
+                               const float* const* side_in2, const float* const* side_add, float* const* side_out2,
                                hipStream_t stream) {
   if (P <= 0) return NDJIR_OK;
   if (!X || L < 1 || L > MAX_CHAIN_LAYERS || !Wp || !Ks || !Ns) return NDJIR_ERR_ARG;
@@ -44,6 +45,9 @@ extern "C" int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, in
     ly.side_in = side_in ? side_in[i] : nullptr;
     ly.side_out = side_out ? side_out[i] : nullptr;
     ly.bgrad = bgrad ? bgrad[i] : nullptr;
+    ly.side_in2 = side_in2 ? side_in2[i] : nullptr;
+    ly.side_add = side_add ? side_add[i] : nullptr;
+    ly.side_out2 = side_out2 ? side_out2[i] : nullptr;
     ly.K = Ks[i]; ly.N = Ns[i]; ly.Kp = round_up(Ks[i], 8); ly.Np = round_up(Ns[i], 32);
     ly.ld_side = ld_side ? ld_side[i] : Ns[i];
     const bool last = has_output && (i == L - 1);
@@ -51,12 +55,38 @@ extern "C" int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, in
     int expect = (i == 0) ? K0 : kin;
     if (ly.K != expect) return NDJIR_ERR_ARG;
     if (ly.Np == 32 && !last) return NDJIR_ERR_UNSUPPORTED;   // narrow layers only as the output layer
-    if (bwd && !last && !ly.side_in) return NDJIR_ERR_ARG;
+    if (bwd != 0 && !last && !ly.side_in) return NDJIR_ERR_ARG;
     kin = ly.N;
-    if (!bwd && i == skip_layer) kin = ly.N + K0;
-    if (bwd && i == skip_layer) kin = skip_split;
+    if (bwd != 1 && i == skip_layer) kin = ly.N + K0;
+    if (bwd == 1 && i == skip_layer) kin = skip_split;
   }
-  return launch_chain(a, bwd != 0, stream);
+  return launch_chain(a, bwd, stream);
+}
+
+extern "C" int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L,
+                               const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
+                               const float* const* side_in, float* const* side_out, const int* ld_side,
+                               float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
+                               int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
+                               hipStream_t stream) {
+  if (bwd != 0 && bwd != 1) return NDJIR_ERR_ARG;
+  return chain_impl(bwd, P, X, ldx, K0, L, Wp, bias, Ks, Ns, side_in, side_out, ld_side, bgrad, Y, ldy, accum_y,
+                    has_output, beta, skip_layer, skip_scale, skip_split, Xskip, ld_xskip, nullptr, nullptr, nullptr, stream);
+}
+
+// Extended form used by the geometric network's double backward (python/renderer.py:52 nn.grad):
+// mode 1 with side_add = extra adjoints; mode 2 = tangent chain (side_in2 = s, side_out2 = extra adjoint).
+extern "C" int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx, int K0, int L,
+                                  const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
+                                  const float* const* side_in, float* const* side_out, const int* ld_side,
+                                  float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
+                                  int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
+                                  const float* const* side_in2, const float* const* side_add, float* const* side_out2,
+                                  hipStream_t stream) {
+  if (mode < 0 || mode > 2) return NDJIR_ERR_ARG;
+  return chain_impl(mode, P, X, ldx, K0, L, Wp, bias, Ks, Ns, side_in, side_out, ld_side, bgrad, Y, ldy, accum_y,
+                    has_output, beta, skip_layer, skip_scale, skip_split, Xskip, ld_xskip, side_in2, side_add, side_out2,
+                    stream);
 }
 
 extern "C" long long ndjir_mlp_wgrad_workspace(int K, int N, long long P) { return wgrad_workspace(K, N, P); }

@@ -9,7 +9,10 @@ constexpr int MAX_CHAIN_LAYERS = 10;
 struct ChainLayer {
   const float* Wp;      // packed matrix [Np/32][Kp/8][64][4]
   const float* bias;    // forward only (may be null)
-  const float* side_in; // backward: stored forward activation of the layer below (P x N)
+  const float* side_in; // backward / tangent: stored forward activation h of this width (P x N)
+  const float* side_in2;// tangent: s (delta of the sdf chain) of this width
+  const float* side_add;// backward: extra adjoint added after the softplus' product
+  float* side_out2;     // tangent: extra adjoint beta * z * s * exp(-beta h)
   float* side_out;      // forward: activation store (P x N); backward: delta store (P x N)
   float* bgrad;         // backward: bias gradient accumulator (N), atomically accumulated
   int K, N;             // logical dims of this GEMM (input width, output width)
@@ -39,7 +42,7 @@ struct ChainArgs {
 };
 
 int launch_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
-int launch_chain(const ChainArgs& a, bool bwd, hipStream_t stream);
+int launch_chain(const ChainArgs& a, int mode, hipStream_t stream);
 long long wgrad_workspace(int K, int N, long long P);
 int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out, int accum,
                  float* workspace, hipStream_t stream);

@@ -66,8 +66,13 @@ __global__ void __launch_bounds__(256) k_pack(const float* __restrict__ W, float
 }
 
 // ---- the chain kernel ---------------------------------------------------------------------------
-template <bool BWD, int TM>
+// MODE 0: forward (bias + softplus).  MODE 1: backward data path (x softplus' from the stored
+// activation, + optional extra adjoint).  MODE 2: tangent chain of the double backward (forward
+// direction, no bias: x softplus', and emits beta * z * s * exp(-beta h) as the extra adjoint).
+template <int MODE, int TM>
 __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(ChainArgs a) {
+  constexpr bool BWD = (MODE == 1);
+  constexpr bool TAN = (MODE == 2);
   constexpr int GP = TM * 4 + 4;   // dwords per group of 4 features
   constexpr int RB = TM / 32;      // 32-row blocks per tile
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -140,7 +145,7 @@ __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(Chai
 #pragma unroll
           for (int q = 0; q < KS; ++q) z += nxt[q * TM * 32 + t];
           if (n < ly.N && m < rows) {
-            if (!BWD) {
+            if (MODE == 0) {
               z += ly.bias ? ly.bias[n] : 0.f;
               if (!last) z = softplus_beta(z, beta);
             }
@@ -210,7 +215,7 @@ __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(Chai
           f32x4 cm, bias4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int q = 0; q < 4; ++q) cm[q] = (n4 + q < nlim) ? 1.f : 0.f;
-          if (!BWD && ly.bias) {
+          if (MODE == 0 && ly.bias) {
             if (n4 + 3 < ly.N) bias4 = *reinterpret_cast<const f32x4*>(ly.bias + n4);   // biases are 16-byte aligned rows
             else {
 #pragma unroll
@@ -218,8 +223,11 @@ __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(Chai
             }
           }
           const bool vec_ok = (n4 + 3 < nlim);
+          const bool vec_side = vec_ok && (ly.ld_side & 3) == 0;
           const float inv_beta = 1.f / beta;
-          const float nbs = -beta / sc;
+          // stored activations are h * skip_scale on the forward skip layer
+          const float hsc = ((MODE == 1 && is_skip) || (MODE == 2 && is_skip)) ? 1.f / sc : 1.f;
+          const float nbs = -beta * hsc;
           f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
           float* lp = nxt + ((last ? wave * 32 + g * 4 : n4) >> 2) * GP + (lane >> 3) * 4;
           const long long grow0 = row0 + (lane >> 3);
@@ -230,7 +238,25 @@ __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(Chai
             const long long grow = grow0 + 8 * it;
             f32x4 z = *reinterpret_cast<f32x4*>(lp);
             f32x4 v;
-            if (!BWD && !last) {
+            if (last) {
+              // output layer (forward: + bias; backward: plain) -> Y
+              if (mrow) {
+                float* y = a.Y + grow * a.ldy + n4;
+                if (vec_ok && (a.ldy & 3) == 0 && !a.accum_y) {
+                  f32x4 t = z;
+                  if (MODE == 0) t += bias4;
+                  *reinterpret_cast<f32x4*>(y) = t;
+                } else {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    if (n4 + q < ly.N) {
+                      float t = z[q] + (MODE == 0 ? bias4[q] : 0.f);
+                      y[q] = a.accum_y ? y[q] + t : t;
+                    }
+                  }
+                }
+              }
+            } else if (MODE == 0) {
               // hidden forward layer: softplus_beta(z + b) [* skip scale]
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
@@ -242,49 +268,42 @@ __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(Chai
               }
               if (mrow && ly.side_out) {
                 float* o = ly.side_out + grow * ly.ld_side + n4;
-                if (vec_ok && (ly.ld_side & 3) == 0) *reinterpret_cast<f32x4*>(o) = v;
+                if (vec_side) *reinterpret_cast<f32x4*>(o) = v;
                 else {
 #pragma unroll
                   for (int q = 0; q < 4; ++q) if (n4 + q < ly.N) o[q] = v[q];
                 }
               }
               *reinterpret_cast<f32x4*>(lp) = v;
-            } else if (last) {
-              // output layer (forward: + bias; backward: plain) -> Y
+            } else {
+              // MODE 1: this GEMM produced dL/dh of the layer below; MODE 2: the tangent s-bar of this layer.
+              // The stored activation h gives softplus'(z) = 1 - exp(-beta h).
+              f32x4 hs = {0.f, 0.f, 0.f, 0.f}, ex = {0.f, 0.f, 0.f, 0.f};
               if (mrow) {
-                float* y = a.Y + grow * a.ldy + n4;
-                if (vec_ok && (a.ldy & 3) == 0 && !a.accum_y) {
-                  f32x4 t = z;
-                  if (!BWD) t += bias4;
-                  *reinterpret_cast<f32x4*>(y) = t;
+                const long long off = grow * ly.ld_side + n4;
+                if (vec_side) {
+                  hs = *reinterpret_cast<const f32x4*>(ly.side_in + off);
+                  if (MODE == 1 && ly.side_add) ex = *reinterpret_cast<const f32x4*>(ly.side_add + off);
+                  if (MODE == 2 && ly.side_in2) ex = *reinterpret_cast<const f32x4*>(ly.side_in2 + off);
                 } else {
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) {
-                    if (n4 + q < ly.N) {
-                      float t = z[q] + (BWD ? 0.f : bias4[q]);
-                      y[q] = a.accum_y ? y[q] + t : t;
-                    }
+                  for (int q = 0; q < 4; ++q) if (n4 + q < nlim) {
+                    hs[q] = ly.side_in[off + q];
+                    if (MODE == 1 && ly.side_add) ex[q] = ly.side_add[off + q];
+                    if (MODE == 2 && ly.side_in2) ex[q] = ly.side_in2[off + q];
                   }
                 }
               }
-            } else {
-              // backward hidden step: this GEMM produced dL/dh of the layer below; its stored
-              // activation h gives softplus'(z) = 1 - exp(-beta h)   (h is stored * skip_scale on the skip layer)
-              f32x4 hs = {0.f, 0.f, 0.f, 0.f};
-              if (mrow) {
-                const float* hp = ly.side_in + grow * ly.ld_side + n4;
-                if (vec_ok && (ly.ld_side & 3) == 0) hs = *reinterpret_cast<const f32x4*>(hp);
-                else {
-#pragma unroll
-                  for (int q = 0; q < 4; ++q) if (n4 + q < nlim) hs[q] = hp[q];
-                }
-              }
+              f32x4 x2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                float sp = (1.f - __expf(nbs * hs[q])) * sc;
-                v[q] = z[q] * sp * (cm[q] * rm);
+                float e = __expf(nbs * hs[q]);            // exp(-beta h)
+                float sp = (1.f - e) * sc;
+                float mk = cm[q] * rm;
+                if (MODE == 1) v[q] = (z[q] * sp + ex[q]) * mk;
+                else { v[q] = z[q] * sp * mk; x2[q] = beta * z[q] * ex[q] * e * mk; }   // ex = s of the sdf chain
               }
-              if (is_skip && mrow && a.Xskip) {
+              if (MODE == 1 && is_skip && mrow && a.Xskip) {
                 // gradient of the concatenated chain input: stash (scaled) for the final dL/dX
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -292,19 +311,28 @@ __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(Chai
                   if (n >= a.skip_split && n < ly.N) a.Xskip[grow * a.ld_xskip + (n - a.skip_split)] = z[q] * sc;
                 }
               }
-              if (mrow && ly.side_out) {
-                float* o = ly.side_out + grow * ly.ld_side + n4;
-                if (vec_ok && (ly.ld_side & 3) == 0) *reinterpret_cast<f32x4*>(o) = v;
-                else {
+              if (mrow) {
+                const long long off = grow * ly.ld_side + n4;
+                if (ly.side_out) {
+                  if (vec_side) *reinterpret_cast<f32x4*>(ly.side_out + off) = v;
+                  else {
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) if (n4 + q < nlim) o[q] = v[q];
+                    for (int q = 0; q < 4; ++q) if (n4 + q < nlim) ly.side_out[off + q] = v[q];
+                  }
+                }
+                if (MODE == 2 && ly.side_out2) {
+                  if (vec_side) *reinterpret_cast<f32x4*>(ly.side_out2 + off) = x2;
+                  else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (n4 + q < nlim) ly.side_out2[off + q] = x2[q];
+                  }
                 }
               }
               colsum += v;
               *reinterpret_cast<f32x4*>(lp) = v;
             }
           }
-          if (BWD && !last && ly.bgrad) {
+          if (MODE != 0 && !last && ly.bgrad) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               float c = colsum[q];
@@ -318,7 +346,7 @@ __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(Chai
       }
 
       // ---- forward skip connection: append the (scaled) chain input after the skip layer's output ----
-      if (!BWD && li == a.skip_layer) {
+      if (MODE != 1 && li == a.skip_layer) {
         __syncthreads();   // the epilogues above zero-filled the padding columns this overwrites
         const int K0 = a.K0, base = ly.N;
         const float* X = a.X + row0 * a.ldx;
@@ -347,7 +375,8 @@ int launch_pack(const float* W, float* dst, int K, int N, int transpose, hipStre
   return ndjir_check_launch();
 }
 
-int launch_chain(const ChainArgs& a, bool bwd, hipStream_t stream) {
+int launch_chain(const ChainArgs& a, int mode, hipStream_t stream) {
+  const bool bwd = (mode == 1);
   if (a.P <= 0) return NDJIR_OK;
   // LDS: bufA holds the chain input (K0p) or any hidden width; bufB any hidden width / partials
   int wmax = 0;
@@ -375,19 +404,15 @@ int launch_chain(const ChainArgs& a, bool bwd, hipStream_t stream) {
   if (blocks > 256LL * 8) blocks = 256LL * 8;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define NDJIR_SET(M, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<M, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    NDJIR_SET(0, 64); NDJIR_SET(1, 64); NDJIR_SET(2, 64); NDJIR_SET(0, 32); NDJIR_SET(1, 32); NDJIR_SET(2, 32);
+#undef NDJIR_SET
     attr_set = true;
   }
-  if (TM == 64) {
-    if (bwd) hipLaunchKernelGGL((k_mlp_chain<true, 64>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b);
-    else hipLaunchKernelGGL((k_mlp_chain<false, 64>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b);
-  } else {
-    if (bwd) hipLaunchKernelGGL((k_mlp_chain<true, 32>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b);
-    else hipLaunchKernelGGL((k_mlp_chain<false, 32>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b);
-  }
+#define NDJIR_GO(M, T) hipLaunchKernelGGL((k_mlp_chain<M, T>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b)
+  if (TM == 64) { if (mode == 0) NDJIR_GO(0, 64); else if (mode == 1) NDJIR_GO(1, 64); else NDJIR_GO(2, 64); }
+  else { if (mode == 0) NDJIR_GO(0, 32); else if (mode == 1) NDJIR_GO(1, 32); else NDJIR_GO(2, 32); }
+#undef NDJIR_GO
   return ndjir_check_launch();
 }
 

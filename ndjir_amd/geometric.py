@@ -1,0 +1,253 @@
+"""Geometric network main pass: sdf, feature AND n = d(sdf)/dx in fused MFMA chains, with the
+hand-derived double backward.
+
+Reference: `sdf, feature, gain = geometric_network(x, conf)` followed by
+`grad_x = nn.grad([sdf], [x])[0]` (python/renderer.py:51-52).  The loss depends on grad_x (eikonal
+term python/loss.py:68-76, normals renderer.py:55-58/90-91, input of five nets renderer.py:113-127),
+so the weight gradients contain second-order terms.  nnabla builds them by differentiating its
+backward graph; here they are derived by hand and mapped onto three kinds of fused chains
+(ndjir_amd/csrc/mlp.hip):
+
+  forward      A_{j+1} = softplus(A_j W_j + b_j)            (skip: A_4 = [h_3, e] / sqrt 2)
+  sdf chain    s_j = (s_{j+1} W_{j+1}^T) * softplus'(z_j)    backward chain seeded with d sdf = 1;
+               g_0 = s_0 W_0^T (+ skip part)                 n = J_e(x)^T g_0   (e = PE + grid encoding)
+  --- backward, given sdf-bar, feature-bar, n-bar ---
+  tangent      g-bar_0 = J_e(x) n-bar;  s-bar_j = g-bar_j W_j;  g-bar_{j+1} = s-bar_j * softplus'(z_j);
+               extra_j = beta * s-bar_j * s_j * exp(-beta h_j)      (= s-bar_j * g_{j+1} * softplus''(z_j))
+  backward     delta_j = (delta_{j+1} W_{j+1}^T) * softplus'(z_j) + extra_j
+  weights      dW_j = A_j^T delta_j + g-bar_j^T s_j ;  dW_last[:, 0] += colsum(g-bar_last) ;  db_j = colsum(delta_j)
+  grid         dF = grad_feature(dX[:, 39:43]) + grad_query_grad_feature(n-bar, g_0[:, 39:43])
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import lib
+from .grid_feature import _core
+from .mlp import _launch, _packed, wgrad
+
+_VOX = _core.FAMILIES["voxel"]
+
+
+def _bands(M, device):
+    return 2.0 ** torch.arange(0, M, dtype=torch.float32, device=device)
+
+
+def _flops(P, Ks, Ns):
+    return 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
+
+
+def _sdf_col(W):
+    from .network import _sdf_column
+    return _sdf_column(W)
+
+
+class GeometricMain(Function):
+    """(x, feature|None, *W, *b) -> sdf (..,1), feature (..,D), n (..,3).  `cfg` = (M, skip_at, scale, min, max)."""
+
+    @staticmethod
+    def forward(ctx, x, feature, cfg, *params):
+        M, skip_at, scale, min_, max_ = cfg
+        L = len(params) // 2
+        W, b = list(params[:L]), list(params[L:])
+        beta = 100.0
+        xf = x.detach().reshape(-1, 3).contiguous()
+        P = xf.shape[0]
+        dev = xf.device
+        bands = _bands(M, dev)
+        xb = xf.unsqueeze(-1) * bands                      # (P, 3, M), band fastest (network.py:108-115)
+        cosb, sinb = torch.cos(xb), torch.sin(xb)
+        parts = [xf, cosb.reshape(P, -1), sinb.reshape(P, -1)]
+        has_grid = feature is not None
+        if has_grid:
+            fd = feature.detach().contiguous()
+            D0 = fd.shape[-1]
+            vf = torch.empty((P, D0), device=dev, dtype=torch.float32)
+            lib.call("voxel_feature_query_on_voxel", P * D0, vf, xf, fd, list(fd.shape[:3]), D0, min_, max_, 0)
+            parts.append(vf)
+        e = torch.cat(parts, dim=-1).contiguous()          # A_0 (P, K0)
+        K0 = e.shape[1]
+        npe = 3 + 6 * M
+
+        # ---- forward chain ----
+        Ks = [w.shape[0] for w in W]
+        Ns = [w.shape[1] for w in W]
+        A = [e]
+        for j in range(L - 1):
+            A.append(torch.empty((P, Ns[j] + (K0 if j == skip_at else 0)), device=dev, dtype=torch.float32))
+        y = torch.empty((P, Ns[-1]), device=dev, dtype=torch.float32)
+        _launch("chain_fwd", _flops(P, Ks, Ns), "mlp_chain", 0, P, e, K0, K0, L, [_packed(w, False) for w in W],
+                [t.detach() for t in b], Ks, Ns, [None] * L, A[1:] + [None], [a.shape[1] for a in A[1:]] + [0],
+                [None] * L, y, Ns[-1], 0, 1, beta, skip_at, scale, 0, None, 0)
+
+        # ---- sdf chain: backward chain seeded with d(sdf) = 1, first step = column 0 of the last layer ----
+        ones = torch.ones((P, 1), device=dev, dtype=torch.float32)
+        s = [None] * L                                     # s[j] = d sdf / d z_j, j < L-1
+        s_store = [None] * L
+        Wp, bK, bN, side_in, side_out, ld = [], [], [], [], [], []
+        bskip, split = -1, 0
+        for i in range(L):
+            j = L - 1 - i
+            Wj = _sdf_col(W[j]) if j == L - 1 else W[j]
+            Wp.append(_packed(Wj, True))
+            bK.append(Wj.shape[1])
+            bN.append(Wj.shape[0])
+            if i < L - 1:
+                below = j - 1
+                buf = torch.empty((P, A[j].shape[1]), device=dev, dtype=torch.float32)
+                s_store[below] = buf
+                s[below] = buf[:, :Ns[below]]
+                side_in.append(A[j])
+                side_out.append(buf)
+                ld.append(A[j].shape[1])
+                if below == skip_at:
+                    bskip, split = i, Ns[below]
+            else:
+                side_in.append(None)
+                side_out.append(None)
+                ld.append(0)
+        g0 = torch.zeros((P, K0), device=dev, dtype=torch.float32)
+        _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain", 1, P, ones, 1, 1, L, Wp, [None] * L, bK, bN, side_in,
+                side_out, ld, [None] * L, g0, K0, 1 if bskip >= 0 else 0, 1, beta, bskip, scale, split,
+                g0 if bskip >= 0 else None, K0)
+
+        # ---- n = J_e(x)^T g_0 ----
+        gc = g0[:, 3:3 + 3 * M].reshape(P, 3, M)
+        gs = g0[:, 3 + 3 * M:npe].reshape(P, 3, M)
+        n = g0[:, :3] + ((gs * cosb - gc * sinb) * bands).sum(-1)
+        if has_grid:
+            go = g0[:, npe:].contiguous()
+            gq = torch.empty((P, 3), device=dev, dtype=torch.float32)
+            lib.call("voxel_feature_grad_query", P * D0, gq, go, xf, fd, list(fd.shape[:3]), D0, min_, max_, 0, 0)
+            n = n + gq
+
+        ctx.cfg = (M, skip_at, scale, min_, max_, L, tuple(x.shape), has_grid, bskip, split)
+        ctx.A, ctx.s_store, ctx.s = A, s_store, s
+        ctx.aux = (xf, cosb, sinb, g0)
+        ctx.save_for_backward(*W, *([feature] if has_grid else []))
+        lead = x.shape[:-1]
+        return y[:, 0:1].reshape(lead + (1,)), y[:, 1:].reshape(lead + (Ns[-1] - 1,)), n.reshape(lead + (3,))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sdf, g_feat, g_n):
+        M, skip_at, scale, min_, max_, L, xshape, has_grid, bskip, split = ctx.cfg
+        saved = ctx.saved_tensors
+        W = list(saved[:L])
+        feature = saved[L] if has_grid else None
+        A, s_store, s = ctx.A, ctx.s_store, ctx.s
+        xf, cosb, sinb, g0 = ctx.aux
+        beta = 100.0
+        P = xf.shape[0]
+        dev = xf.device
+        K0 = A[0].shape[1]
+        npe = 3 + 6 * M
+        Ks = [w.shape[0] for w in W]
+        Ns = [w.shape[1] for w in W]
+        bands = _bands(M, dev)
+
+        gy = torch.empty((P, Ns[-1]), device=dev, dtype=torch.float32)
+        gy[:, 0:1] = g_sdf.reshape(P, 1) if g_sdf is not None else 0.0
+        gy[:, 1:] = g_feat.reshape(P, -1) if g_feat is not None else 0.0
+        nbar = g_n.reshape(P, 3).contiguous() if g_n is not None else None
+
+        grid_grad = None
+        buf = _core.get_grad_buffer(feature) if has_grid else None
+        if has_grid:
+            fd = feature.detach().contiguous()
+            D0 = fd.shape[-1]
+            gs_shape = list(fd.shape[:3])
+            grid_grad = buf if buf is not None else torch.zeros_like(fd)
+
+        extras = [None] * L
+        gbar = [None] * L                 # gbar[j] = adjoint of g_j = d sdf / d A_j  (P, width of A_j)
+        col_last = None
+        if nbar is not None:
+            # ---- g-bar_0 = J_e(x) n-bar ----
+            gb0 = torch.empty((P, K0), device=dev, dtype=torch.float32)
+            gb0[:, :3] = nbar
+            nb = nbar.unsqueeze(-1) * bands                                   # (P, 3, M)
+            gb0[:, 3:3 + 3 * M] = (-sinb * nb).reshape(P, -1)
+            gb0[:, 3 + 3 * M:npe] = (cosb * nb).reshape(P, -1)
+            if has_grid:
+                ggo = torch.empty((P, D0), device=dev, dtype=torch.float32)
+                lib.call("voxel_feature_grad_query_grad_grad_output", P * D0, ggo, nbar, xf, fd, gs_shape, D0, min_, max_, 0, 0)
+                gb0[:, npe:] = ggo
+                # n depends on the grid directly through the interpolation derivative
+                lib.call("voxel_feature_grad_query_grad_feature", P * D0, grid_grad, nbar, g0[:, npe:].contiguous(), xf,
+                         gs_shape, D0, min_, max_, 0, 1)
+            gbar[0] = gb0
+            # ---- tangent chain over layers 0..L-2 ----
+            T = L - 1
+            side_in, side_in2, side_out, side_out2, ld, bg = [], [], [], [], [], [None] * T
+            for l in range(T):
+                wide = A[l + 1].shape[1]
+                gbar[l + 1] = torch.empty((P, wide), device=dev, dtype=torch.float32)
+                extras[l] = torch.empty((P, wide), device=dev, dtype=torch.float32)
+                side_in.append(A[l + 1])
+                side_in2.append(s_store[l])
+                side_out.append(gbar[l + 1])
+                side_out2.append(extras[l])
+                ld.append(wide)
+            col_last = torch.zeros((Ns[L - 2],), device=dev, dtype=torch.float32)
+            bg[T - 1] = col_last
+            _launch("chain_tan", _flops(P, Ks[:T], Ns[:T]), "mlp_chain_ex", 2, P, gb0, K0, K0, T,
+                    [_packed(w, False) for w in W[:T]], [None] * T, Ks[:T], Ns[:T], side_in, side_out, ld, bg,
+                    None, 0, 0, 0, beta, skip_at, scale, 0, None, 0, side_in2, [None] * T, side_out2)
+
+        # ---- backward chain with the extra adjoints ----
+        need_x = has_grid
+        steps = L if need_x else L - 1
+        deltas = [None] * L
+        deltas[L - 1] = gy
+        bgrads = [None] * L
+        Wp, bK, bN, side_in, side_out, side_add, ld, bg = [], [], [], [], [], [], [], []
+        for i in range(steps):
+            j = L - 1 - i
+            Wp.append(_packed(W[j], True))
+            bK.append(Ns[j])
+            bN.append(Ks[j])
+            if i < L - 1:
+                below = j - 1
+                wide = A[j].shape[1]
+                dbuf = torch.empty((P, wide), device=dev, dtype=torch.float32)
+                deltas[below] = dbuf[:, :Ns[below]]
+                bgrads[below] = torch.zeros((Ns[below],), device=dev, dtype=torch.float32)
+                side_in.append(A[j])
+                side_out.append(dbuf)
+                side_add.append(extras[below])
+                ld.append(wide)
+                bg.append(bgrads[below])
+            else:
+                side_in.append(None); side_out.append(None); side_add.append(None); ld.append(0); bg.append(None)
+        gx = torch.zeros((P, K0), device=dev, dtype=torch.float32) if need_x else None
+        _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain_ex", 1, P, gy, Ns[-1], Ns[-1], steps, Wp, [None] * steps, bK, bN,
+                side_in, side_out, ld, bg, gx, K0, 1 if (bskip >= 0 and need_x) else 0, 1 if need_x else 0, beta,
+                bskip, scale, split, gx if (bskip >= 0 and need_x) else None, K0, [None] * steps, side_add, [None] * steps)
+
+        if has_grid:
+            lib.call("voxel_feature_grad_feature", P * D0, grid_grad, gx[:, npe:].contiguous(), xf, gs_shape, D0,
+                     min_, max_, 0, 1)
+
+        # ---- weight / bias gradients ----
+        gW, gb = [None] * L, [None] * L
+        for j in range(L):
+            if ctx.needs_input_grad[3 + j]:
+                gW[j] = wgrad(A[j], deltas[j])
+                if nbar is not None and j < L - 1:
+                    wgrad(gbar[j], s[j], out=gW[j], accum=True)
+                if nbar is not None and j == L - 1:
+                    gW[j][:, 0] += col_last
+            if ctx.needs_input_grad[3 + L + j]:
+                gb[j] = bgrads[j] if j < L - 1 else gy.sum(0)
+        g_feature = None
+        if has_grid and ctx.needs_input_grad[1] and buf is None:
+            g_feature = grid_grad
+        ctx.A = ctx.s_store = ctx.s = ctx.aux = None
+        return (None, g_feature, None, *gW, *gb)
+
+
+def geometric_main(x, feature, weights, biases, M, skip_at, scale, min_=(-1, -1, -1), max_=(1, 1, 1)):
+    cfg = (int(M), int(skip_at), float(scale), tuple(min_), tuple(max_))
+    return GeometricMain.apply(x, feature, cfg, *weights, *biases)

@@ -38,6 +38,7 @@ SIGS = {
     "mlp_pack": "ppiii",
     # bwd P X ldx K0 L Wp bias Ks Ns side_in side_out ld_side bgrad Y ldy accum has_out beta skip scale split Xskip ld
     "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi",
+    "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP",
     "mlp_wgrad": "pipiiilpip",
     "ray_aabb_intersection": "ipppppiiFF",
     "ray_sphere_intersection": "ipppppiif",

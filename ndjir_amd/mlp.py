@@ -79,9 +79,10 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
 _WORKSPACE = {}
 
 
-def wgrad(A, B):
+def wgrad(A, B, out=None, accum=False):
     """dW = A^T B with A (P, K) and B (P, N) row-major views (column stride 1): the weight gradient
-    of one layer, reduction over the P points (ndjir_amd/csrc/wgrad.hip)."""
+    of one layer, reduction over the P points (ndjir_amd/csrc/wgrad.hip).  `out` (K, N) with
+    `accum=True` adds to an existing gradient."""
     P, K = A.shape
     N = B.shape[1]
     assert A.stride(1) == 1 and B.stride(1) == 1 and B.shape[0] == P
@@ -90,8 +91,11 @@ def wgrad(A, B):
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 22), device=A.device, dtype=torch.float32)
         _WORKSPACE[A.device] = ws
-    out = torch.empty((K, N), device=A.device, dtype=torch.float32)
-    _launch("wgrad", 2.0 * P * K * N, "mlp_wgrad", _Strided(A), A.stride(0), _Strided(B), B.stride(0), K, N, P, out, 0, ws)
+    if out is None:
+        out = torch.empty((K, N), device=A.device, dtype=torch.float32)
+        accum = False
+    _launch("wgrad", 2.0 * P * K * N, "mlp_wgrad", _Strided(A), A.stride(0), _Strided(B), B.stride(0), K, N, P, out,
+            1 if accum else 0, ws)
     return out
 
 

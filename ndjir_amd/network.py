@@ -130,6 +130,50 @@ def query_on_grid(x, G, D, use_ste, type):
     return getattr(PF, f"{pre}query_on_{topo}")(x, G, D, use_ste=use_ste, f_init=f_init)
 
 
+def geometric_network_with_grad(x, conf):
+    """`sdf, feature, gain = geometric_network(x, conf); grad_x = nn.grad([sdf], [x])[0]`
+    (python/renderer.py:51-52) as one operator.  Dense-voxel / no-grid configurations with the
+    geometric initialisation run as fused MFMA chains with the hand-derived double backward
+    (ndjir_amd/geometric.py); other configurations run layer by layer through autograd."""
+    g = conf.geometric_network
+    v = g.voxel
+    if USE_FUSED and g.geometric_init and g.act == "softplus" and v.type in ("voxel", "none") and not v.use_ste:
+        from .geometric import geometric_main
+        _ensure_geometric_params(x, conf)
+        Ws, bs, skip_at, scale = _geometric_param_lists(conf)
+        feature = P.get_parameters().get("geometric-network/voxel_feature/F") if v.type == "voxel" else None
+        sdf, feat, grad_x = geometric_main(x, feature, Ws, bs, g.pe_bands, skip_at, scale)
+        with P.parameter_scope("geometric-network"):
+            gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain]), True)
+        return sdf, feat, torch.exp(gain * 10).clamp(1e-6, 5e4), grad_x
+    from .grid_feature import grad as nn_grad
+    sdf, feat, gain = geometric_network(x, conf)
+    return sdf, feat, gain, nn_grad([sdf], [x])[0]
+
+
+def _ensure_geometric_params(x, conf):
+    """Create the geometric network's parameters (lazily, in the reference's order) if missing."""
+    if "geometric-network/affine-last/affine/W" not in P.get_parameters():
+        with torch.no_grad():
+            geometric_network(x.detach()[..., :1, :] if x.dim() > 2 else x.detach()[:1], conf, first_order_only=True)
+
+
+def _geometric_param_lists(conf):
+    g = conf.geometric_network
+    L = g.layers
+    params = P.get_parameters()
+    names = [f"affine-{l:02d}" for l in range(L - 1)] + ["affine-last"]
+    Ws = [params[f"geometric-network/{n}/affine/W"] for n in names]
+    bs = [params[f"geometric-network/{n}/affine/b"] for n in names]
+    skip_layers = list(g.skip_layers)
+    skip_at = -1
+    for l in range(1, L - 1):
+        if l not in skip_layers and (l + 1) in skip_layers:
+            skip_at = l
+    scale = 1.0 / np.sqrt(2) if g.use_inv_square else 1.0
+    return Ws, bs, skip_at, scale
+
+
 def geometric_network(x, conf, first_order_only=False, sdf_only=False):
     """network.py:154-232.  x (..., 3) -> sdf (..., 1), feature (..., 256), gain (1,).
 

@@ -16,6 +16,7 @@ import torch
 from .grid_feature import grad as nn_grad
 from .helper import generate_all_pixels, generate_raydir_camloc
 from .network import (background_network, base_color_network, environment_light_network, geometric_network,
+                      geometric_network_with_grad,
                       implicit_illumination_network, photogrammetric_light_network, roughness_network,
                       soft_visibility_light_network, specular_reflectance_network)
 from .sampler import sample_importance_directions, sample_points, sample_uniform_directions
@@ -55,8 +56,7 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     eps_normal = conf.renderer.eps_normal
 
     # Geometric network and its spatial gradient (nn.grad, renderer.py:51-52)
-    sdf_x_fg, feature_x_fg, gain = geometric_network(x_fg, conf)
-    grad_x_fg = nn_grad([sdf_x_fg], [x_fg])[0]
+    sdf_x_fg, feature_x_fg, gain, grad_x_fg = geometric_network_with_grad(x_fg, conf)
 
     # Foreground alpha (renderer.py:55-67)
     car = cos_anneal_ratio.reshape((1,) * x_fg.dim())

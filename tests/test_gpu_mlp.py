@@ -140,3 +140,58 @@ def test_wgrad_throughput(gpu):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 10
         print(f"\n{name}: {dt * 1e6:.0f} us, {2 * P * K * N / dt / 1e12:.1f} TFLOP/s")
+
+
+@pytest.mark.parametrize("grid", [True, False])
+def test_geometric_main_double_backward(gpu, grid):
+    """sdf, feature, n = d sdf/dx and the gradients of a loss that depends on all three (second-order
+    terms through n) vs fp64 torch autograd of the composite restatement."""
+    from ndjir_amd.geometric import geometric_main
+    from oracle import composite as C
+    from oracle import graph as G
+    rng = np.random.RandomState(3)
+    P, Gs, D0, M = 200, 8, 4, 6
+    Dh = 128
+    K0 = 39 + (D0 if grid else 0)
+    dims = [K0, Dh, Dh, Dh, Dh - K0, Dh, Dh, Dh, Dh + 1]
+    Ws, bs = make(tuple(dims), 5, skip_layer=3)
+    Ws = [w * 1.5 for w in Ws]
+    x = (rng.rand(P, 3) * 1.6 - 0.8).astype(np.float32)
+    F = (rng.randn(Gs, Gs, Gs, D0) * 0.3).astype(np.float32)
+    w_sdf = rng.randn(P, 1).astype(np.float32)
+    w_feat = rng.randn(P, Dh).astype(np.float32)
+    w_n = rng.randn(P, 3).astype(np.float32)
+    c = 1.0 / np.sqrt(2.0)
+
+    xd = torch.tensor(x, device=gpu)
+    Fd = torch.tensor(F, device=gpu).requires_grad_(True) if grid else None
+    Wd = [w.to(gpu).requires_grad_(True) for w in Ws]
+    bd = [b.to(gpu).requires_grad_(True) for b in bs]
+    sdf, feat, n = geometric_main(xd, Fd, Wd, bd, M, 3, c)
+    loss = (sdf * torch.tensor(w_sdf, device=gpu)).sum() + (feat * torch.tensor(w_feat, device=gpu)).sum() \
+        + ((n * torch.tensor(w_n, device=gpu)).sum(-1) ** 2).sum()
+    params = Wd + bd + ([Fd] if grid else [])
+    grads = torch.autograd.grad(loss, params)
+
+    x64 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    F64 = torch.tensor(F, dtype=torch.float64, requires_grad=True)
+    W64 = [w.double().requires_grad_(True) for w in Ws]
+    b64 = [b.double().requires_grad_(True) for b in bs]
+    e = G.positional_encoding(x64, M)
+    if grid:
+        e = torch.cat([e, C.query_on_voxel(x64, F64)], dim=-1)
+    y = ref_mlp(e, W64, b64, 100.0, 3, c)
+    sdf64, feat64 = y[:, :1], y[:, 1:]
+    n64, = torch.autograd.grad(sdf64.sum(), x64, create_graph=True)
+    loss64 = (sdf64 * torch.tensor(w_sdf).double()).sum() + (feat64 * torch.tensor(w_feat).double()).sum() \
+        + ((n64 * torch.tensor(w_n).double()).sum(-1) ** 2).sum()
+    g64 = torch.autograd.grad(loss64, W64 + b64 + ([F64] if grid else []))
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b).norm() / max(float(b.norm()), 1e-30))
+
+    assert rel(sdf, sdf64) < 1e-5 and rel(feat, feat64) < 1e-5
+    assert rel(n, n64) < 2e-5, rel(n, n64)
+    names = [f"W{j}" for j in range(8)] + [f"b{j}" for j in range(8)] + (["F"] if grid else [])
+    for nm, a, b in zip(names, grads, g64):
+        assert rel(a, b) < 1e-3, (nm, rel(a, b))   # fp32 vs fp64 through beta=100 second-order terms
