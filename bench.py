@@ -100,11 +100,18 @@ class Step:
                 self.flat_grad[off:off + n].zero_()
             off += n
         if self.world > 1:
-            import torch.distributed as dist
-            # total_loss already normalised by the GLOBAL ray / mask counts: gradients just add up
-            dist.all_reduce(self.flat_grad)           # one flat 5.9 MB bucket, SUM over xGMI
-            for buf in self.grid_bufs.values():
-                dist.all_reduce(buf)                  # dense; see DESIGN.md for the planned sparse exchange
+            import math
+            from ndjir_amd.distributed import allreduce_step_gradients
+            # total_loss already normalised by the GLOBAL ray / mask counts: gradients just add up.
+            # MLP: one flat 5.9 MB bucket; voxel grid: touched cells only (ndjir_amd/distributed.py)
+            x_fg = out["samples"]["x_fg"].detach()
+            v = self.conf.geometric_network.voxel
+            queries = {}
+            if v.type.endswith("voxel"):
+                r = self.conf.renderer.bounding_sphere_radius
+                x_ptb = x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size)
+                queries["geometric-network/voxel_feature/F"] = ([x_fg, x_ptb], [v.grid_size] * 3)
+            allreduce_step_gradients(self.flat_grad, self.grid_bufs, queries)
         return loss.detach()
 
 

@@ -88,3 +88,56 @@ def test_ray_sharded_loss_and_gradients_match_single_process():
     assert abs(loss1 - loss2) < 1e-5 * abs(loss1), (loss1, loss2)
     err = np.linalg.norm(grad1 - grad2) / np.linalg.norm(grad1)
     assert err < 1e-4, err
+
+
+def _sparse_exchange(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ndjir_amd.distributed import allreduce_step_gradients, voxel_cell_ids
+    torch.manual_seed(100 + rank)
+    G, D = 16, 4
+    x = torch.rand(300 + 50 * rank, 3) * 2.4 - 1.2          # ragged point counts, some outside the box
+    ids = voxel_cell_ids(x, [G, G, G])
+    buf = torch.zeros(G, G, G, D)
+    buf.view(-1, D)[ids.unique()] = torch.randn(ids.unique().numel(), D)
+    dense = buf.clone()
+    flat = torch.randn(1000)
+    flat_ref = flat.clone()
+    dist.all_reduce(dense)
+    dist.all_reduce(flat_ref)
+    allreduce_step_gradients(flat, {"g": buf}, {"g": ([x], [G, G, G])})
+    ok = torch.allclose(buf, dense, atol=1e-6) and torch.allclose(flat, flat_ref)
+    q.put((rank, bool(ok), float((buf - dense).abs().max())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sparse_grid_gradient_exchange_equals_dense_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sparse_exchange, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=200) for _ in range(2)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+
+
+def test_voxel_cell_ids_match_oracle_corners():
+    """the touched-cell list covers exactly the cells the scatter kernels write."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from ndjir_amd.distributed import voxel_cell_ids
+    from oracle import kernels as K
+    rng = np.random.RandomState(0)
+    G, D, P = 8, 4, 500
+    q = (rng.rand(P, 3) * 2.6 - 1.3).astype(np.float32)
+    gf = K.GridOracle("voxel").grad_feature(np.ones((P, D), np.float32), q, (G, G, G, D))
+    touched = set(np.nonzero(np.abs(gf).reshape(-1, D).sum(-1))[0].tolist())
+    ids = set(voxel_cell_ids(torch.from_numpy(q), [G, G, G]).tolist())
+    assert touched <= ids

@@ -121,7 +121,7 @@ def test_grid_family_vs_oracle(gpu, family, P, G, hash_cfg):
     gq = _core.grad_query(family, ogd, qd, fd, hcfg=hash_cfg)
     gq_ref = o.grad_query(og, q, f)
     scale = max(1.0, np.abs(gq_ref).max())
-    np.testing.assert_allclose(gq.detach().cpu().numpy(), gq_ref, atol=(2e-5 if lz else 2e-6) * scale, rtol=1e-2 if fine else 1e-7)
+    np.testing.assert_allclose(gq.detach().cpu().numpy(), gq_ref, atol=(1e-3 if fine else (2e-5 if lz else 2e-6)) * scale, rtol=1e-2 if fine else 1e-7)
     gf = _core.grad_feature(family, ogd, qd, fd, hcfg=hash_cfg)
     gf_ref = o.grad_feature(og, q, fs)
     np.testing.assert_allclose(gf.detach().cpu().numpy(), gf_ref, atol=(2e-3 if fine else (5e-5 if lz else 5e-6)) * max(1.0, np.abs(gf_ref).max()))
