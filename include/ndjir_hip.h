@@ -194,6 +194,18 @@ int ndjir_squareplus_forward(int size, float* output, const float* input, float 
 int ndjir_squareplus_backward(int size, float* dinput, const float* doutput, const float* input, float b, int accum,
                               hipStream_t stream);
 
+/* ---- hierarchical sampler: one up-sampling round --------------------------------------------------
+ * Replaces the ~40 nnabla launches of one iteration of SamplePoints.sample_importance_dists
+ * (python/sampler.py:194-240) given the SDF at the current samples: robust slope, sigmoid CDF,
+ * alpha, transmittance weights, normalisation, inverse-transform sampling at the deterministic
+ * u_m = m / (M - 1 + 1/M), clip to [t_near, t_far], merge-sort.  t, sdf: (R, N); t_near, t_far: (R);
+ * t_out: (R, N + M) sorted; idx_out: (R, M) int32 bin indices.  N + M <= 128, M <= 32.
+ * exp and the scan / reduction orders are DEFINED in include/ndjir_math.h, so the integer indices
+ * are reproducible bit for bit on the host (oracle) and the device. */
+int ndjir_sampler_importance_round(int R, int N, int M, float gain, const float* t, const float* sdf,
+                                   const float* t_near, const float* t_far, float* t_out, int* idx_out,
+                                   hipStream_t stream);
+
 /* ---- fused MLP engine ------------------------------------------------------------------------------
  * Replaces the reference's per-layer nnabla launches (PF.affine -> cuBLAS GEMM, F.softplus(beta=100),
  * python/network.py:88-93,165 and every network function :154-561) by ONE launch per net and

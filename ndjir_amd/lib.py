@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "_lib", "libndjir_hip.so")
 
 _vp = ctypes.c_void_p
-_CT = {"i": ctypes.c_int, "f": ctypes.c_float, "p": _vp, "F": ctypes.POINTER(ctypes.c_float),
+_CT = {"i": ctypes.c_int, "f": ctypes.c_float, "p": _vp, "q": _vp, "F": ctypes.POINTER(ctypes.c_float),
        "I": ctypes.POINTER(ctypes.c_int), "l": ctypes.c_longlong, "P": ctypes.POINTER(_vp),
        "A": ctypes.POINTER(ctypes.c_int)}
 
@@ -40,6 +40,7 @@ SIGS = {
     "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi",
     "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP",
     "mlp_wgrad": "pipiiilpip",
+    "sampler_importance_round": "iiifpppppq",
     "ray_aabb_intersection": "ipppppiiFF",
     "ray_sphere_intersection": "ipppppiif",
     "inverse_transform_sample_uniform_directions": "ippppiiiif",
@@ -137,6 +138,10 @@ def call(name, *args):
                     raise NdjirHipError(f"ndjir_{name}: tensors must be contiguous float32 on the GPU "
                                         f"(got {v.dtype}, {v.device}, contiguous={v.is_contiguous()})")
                 cargs.append(v.data_ptr())
+        elif c == "q":     # int32 device tensor
+            if not (v.is_cuda and v.dtype == torch.int32 and v.is_contiguous()):
+                raise NdjirHipError(f"ndjir_{name}: expected a contiguous int32 GPU tensor")
+            cargs.append(v.data_ptr())
         elif c == "P":     # host array of device pointers (list of tensors / None)
             arr = (_vp * len(v))()
             for i, t in enumerate(v):

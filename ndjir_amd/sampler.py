@@ -71,7 +71,17 @@ class SamplePoints:
         return tn + step * (i + stratified_sample)
 
     def importance_round(self, t, sdf, t_near, t_far, gain, M):
-        """One up-sampling round (sampler.py:194-240) given the SDF at the current samples."""
+        """One up-sampling round (sampler.py:194-240) given the SDF at the current samples: one HIP
+        launch (csrc/sampler.hip), one wave per ray, scan orders fixed by include/ndjir_math.h."""
+        B, R, N, _ = t.shape
+        t_out = torch.empty((B, R, N + M, 1), device=t.device, dtype=torch.float32)
+        idx = torch.empty((B, R, M), device=t.device, dtype=torch.int32)
+        lib.call("sampler_importance_round", B * R, N, M, float(gain), t.contiguous(), sdf.contiguous(),
+                 t_near.expand(B, R, 1, 1).contiguous(), t_far.expand(B, R, 1, 1).contiguous(), t_out, idx)
+        return t_out, idx.long()
+
+    def importance_round_stock(self, t, sdf, t_near, t_far, gain, M):
+        """The same round with stock device ops (kept for A/B debugging; not on the product path)."""
         B, R, N, _ = t.shape
         dev, dt = t.device, t.dtype
         ts_end = t[:, :, N - 1:N, :]

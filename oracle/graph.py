@@ -269,7 +269,27 @@ def sample_stratified_dists(t_near, t_far, stratified_sample, conf):
 
 def importance_round(t, sdf, t_near, t_far, gain, M):
     """One up-sampling round of sampler.py:194-240 given the SDF at the current samples.
-    t, sdf: (B,R,N,1).  Returns new sorted t (B,R,N+M,1) and the integer idx (B,R,M)."""
+    t, sdf: (B,R,N,1).  Returns new sorted t (B,R,N+M,1) and the integer idx (B,R,M).
+    fp32: the C restatement with the scan orders / exp of include/ndjir_math.h (the definition the
+    HIP kernel is bit-compared against); other dtypes: the torch restatement below."""
+    if t.dtype == torch.float32:
+        return _importance_round_c(t, sdf, t_near, t_far, gain, M)
+    return importance_round_torch(t, sdf, t_near, t_far, gain, M)
+
+
+def _importance_round_c(t, sdf, t_near, t_far, gain, M):
+    import numpy as np
+    B, R, N, _ = t.shape
+    f = lambda a, shp: np.ascontiguousarray(a.detach().expand(shp).numpy().astype(np.float32).reshape(-1))
+    t_out = np.zeros((B * R, N + M), np.float32)
+    idx = np.zeros((B * R, M), np.int32)
+    _np_call("sampler_importance_round", B * R, N, M, float(gain), f(t, (B, R, N, 1)), f(sdf, (B, R, N, 1)),
+             f(t_near, (B, R, 1, 1)), f(t_far, (B, R, 1, 1)), t_out, idx)
+    return (torch.from_numpy(t_out).reshape(B, R, N + M, 1), torch.from_numpy(idx.astype(np.int64)).reshape(B, R, M))
+
+
+def importance_round_torch(t, sdf, t_near, t_far, gain, M):
+    """Stock-op restatement of sampler.py:194-240 (association of the scans left to torch)."""
     B, R, N, _ = t.shape
     ts_end = t[:, :, N - 1:N, :]
     sdf0, sdf1 = sdf[:, :, :-1, :], sdf[:, :, 1:, :]

@@ -29,7 +29,7 @@ def build(force=False):
 
 _c_float_p = ctypes.POINTER(ctypes.c_float)
 _c_int_p = ctypes.POINTER(ctypes.c_int)
-_CT = {"i": ctypes.c_int, "f": ctypes.c_float, "p": _c_float_p, "F": _c_float_p, "I": _c_int_p}
+_CT = {"i": ctypes.c_int, "f": ctypes.c_float, "p": _c_float_p, "F": _c_float_p, "I": _c_int_p, "Q": _c_int_p}
 
 # signature strings: i=int, f=float, p=float array (in/out), F=float[3], I=int[3]
 _VOX = "ipppIiFF"
@@ -95,6 +95,7 @@ _SIGS = {
     "tv_loss_on_triline_backward": "ippppiiFFi",
     "tv_loss_on_voxel_hash": "ipppifiiiFF",
     "tv_loss_on_voxel_hash_backward": "ippppifiiiFFi",
+    "sampler_importance_round": "iiifppppp" + "Q",
     "squareplus_forward": "ippf",
     "squareplus_backward": "ipppfi",
 }
@@ -129,6 +130,9 @@ def _conv(c, v, keep):
         assert isinstance(v, np.ndarray) and v.dtype == np.float32 and v.flags["C_CONTIGUOUS"], \
             "oracle arrays must be C-contiguous float32"
         return v.ctypes.data_as(_c_float_p)
+    if c == "Q":
+        assert isinstance(v, np.ndarray) and v.dtype == np.int32 and v.flags["C_CONTIGUOUS"]
+        return v.ctypes.data_as(_c_int_p)
     if c == "F":
         a = np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(3))
         keep.append(a)

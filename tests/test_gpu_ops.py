@@ -128,7 +128,7 @@ def test_grid_family_vs_oracle(gpu, family, P, G, hash_cfg):
     ggq = rng.randn(P, 3).astype(np.float32)
     g_go, g_f = torch.autograd.grad(gq, [ogd, fd], T(ggq, gpu))
     ggo_ref = o.grad_query_grad_grad_output(ggq, q, f)
-    np.testing.assert_allclose(g_go.cpu().numpy(), ggo_ref, atol=(2e-5 if lz else 2e-6) * max(1.0, np.abs(ggo_ref).max()), rtol=1e-2 if fine else 1e-7)
+    np.testing.assert_allclose(g_go.cpu().numpy(), ggo_ref, atol=(2e-3 if fine else (2e-5 if lz else 2e-6)) * max(1.0, np.abs(ggo_ref).max()), rtol=1e-2 if fine else 1e-7)
     gqgf_ref = o.grad_query_grad_feature(ggq, og, q, fs)
     np.testing.assert_allclose(g_f.cpu().numpy(), gqgf_ref, atol=(2e-3 if (lz or fine) else 2e-5) * max(1.0, np.abs(gqgf_ref).max()))
 
