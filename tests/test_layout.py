@@ -44,14 +44,19 @@ def test_header_declares_every_bound_symbol():
 
 
 def test_product_never_imports_oracle():
-    pat = re.compile(r"^\s*(from|import)\s+(\.+)?oracle\b|/oracle/|\boracle\.", re.M)
+    # python: any import of the oracle package; native: any #include / path into oracle/
+    py_pat = re.compile(r"^\s*(from|import)\s+\.*oracle\b|import_module\(.*oracle|[\"']oracle[/\"']", re.M)
+    c_pat = re.compile(r"#\s*include\s*[<\"][^>\"]*oracle|oracle/", re.M)
     bad = []
     for d, _, files in os.walk(os.path.join(ROOT, "ndjir_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
-                txt = open(os.path.join(d, f), errors="ignore").read()
-                if pat.search(txt):
-                    bad.append(os.path.join(d, f))
+            path = os.path.join(d, f)
+            if f.endswith(".py"):
+                if py_pat.search(open(path, errors="ignore").read()):
+                    bad.append(path)
+            elif f.endswith((".hip", ".h", ".cpp", ".c")) or f == "Makefile":
+                if c_pat.search(open(path, errors="ignore").read()):
+                    bad.append(path)
     assert not bad, bad
 
 
