@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "mlp.h"
 
@@ -70,7 +72,7 @@ __global__ void __launch_bounds__(256) k_pack(const float* __restrict__ W, float
 // activation, + optional extra adjoint).  MODE 2: tangent chain of the double backward (forward
 // direction, no bias: x softplus', and emits beta * z * s * exp(-beta h) as the extra adjoint).
 template <int MODE, int TM>
-__global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(ChainArgs a) {
+__global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k_mlp_chain(ChainArgs a) {
   constexpr bool BWD = (MODE == 1);
   constexpr bool TAN = (MODE == 2);
   constexpr int GP = TM * 4 + 4;   // dwords per group of 4 features
@@ -160,57 +162,97 @@ __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(Chai
         continue;
       }
 
-      // ---- general layer: each wave owns column blocks nb = wave, wave + 8, ... ----
-      for (int nb = wave; nb < NB; nb += NWAVES) {
-        f32x16 acc[RB];
+      // ---- general layer ----
+      // A work unit = (column block nb, RBU consecutive 32-row blocks starting at rb0).  Column blocks
+      // that fill whole rounds of 8 waves are processed with both row blocks by one wave (weights
+      // fetched once per tile); the NB % 8 remainder blocks are split by row block over twice as many
+      // waves, so e.g. a 257-wide output or a 43-wide input gradient does not leave 6-7 waves idle.
+      auto process = [&](auto rbu_tag, const int nb, const int rb0) {
+        constexpr int RBU = decltype(rbu_tag)::value;
+        constexpr int ITS = RBU * 4;               // pass-2 steps (8 rows each)
+        f32x16 acc[RBU];
 #pragma unroll
-        for (int q = 0; q < RB; ++q) acc[q] = f32x16{0};
+        for (int q = 0; q < RBU; ++q) acc[q] = f32x16{0};
         const f32x4* Bp = reinterpret_cast<const f32x4*>(ly.Wp) + (long long)nb * KB * 64 + lane;
-        const float* A0 = cur + h * GP + r * 4;
-        f32x4 b = Bp[0];
-        f32x4 av[RB];
+        const float* A0 = cur + h * GP + (rb0 * 32 + r) * 4;
+        const int mbase = rb0 * 32 + (lane >> 3);  // first row this lane handles in pass 2
+        // output-layer staging slot (host sizes LDS for min(NB, 8) slots): the block's own index while
+        // NB <= 8 (row-split units of one block share it on disjoint rows), else one slot per wave
+        const int slot = (NB <= NWAVES) ? nb : wave;
+
+        const int g = lane & 7;                   // column group inside the block
+        const int n4 = nb * 32 + g * 4;           // first of the 4 columns
+        const bool is_skip = (li == a.skip_layer);
+        const float sc = is_skip ? a.skip_scale : 1.f;
+        const int nlim = (BWD && is_skip) ? a.skip_split : ly.N;   // columns that take the activation path
+        const bool vec_ok = (n4 + 3 < nlim);
+        const bool vec_side = vec_ok && (ly.ld_side & 3) == 0;
+
+        // backward / tangent: start fetching this unit's stored activations now, so that they arrive
+        // while the matrix pipe works through the k-loop
+        f32x4 hsv[ITS];
+        if (MODE != 0 && !last) {
 #pragma unroll
-        for (int q = 0; q < RB; ++q) av[q] = *reinterpret_cast<const f32x4*>(A0 + q * 32 * 4);
-        for (int kb = 0; kb < KB; ++kb) {
-          f32x4 bn = b, avn[RB];
+          for (int it = 0; it < ITS; ++it) {
+            hsv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int m = mbase + 8 * it;
+            if (vec_side && m < rows) hsv[it] = *reinterpret_cast<const f32x4*>(ly.side_in + (row0 + m) * ly.ld_side + n4);
+          }
+        }
+
+        // k-loop, unrolled by two with ping-pong operand registers (no register rotation moves)
+        f32x4 b0 = Bp[0], b1 = b0;
+        f32x4 av0[RBU], av1[RBU];
 #pragma unroll
-          for (int q = 0; q < RB; ++q) avn[q] = av[q];
-          if (kb + 1 < KB) {                     // prefetch the next k-block
-            bn = Bp[(long long)(kb + 1) * 64];
+        for (int q = 0; q < RBU; ++q) { av0[q] = *reinterpret_cast<const f32x4*>(A0 + q * 32 * 4); av1[q] = av0[q]; }
+        int kb = 0;
+        for (; kb + 1 < KB; kb += 2) {
+          {
+            b1 = Bp[(long long)(kb + 1) * 64];
             const float* An = A0 + (kb + 1) * 2 * GP;
 #pragma unroll
-            for (int q = 0; q < RB; ++q) avn[q] = *reinterpret_cast<const f32x4*>(An + q * 32 * 4);
+            for (int q = 0; q < RBU; ++q) av1[q] = *reinterpret_cast<const f32x4*>(An + q * 32 * 4);
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int q = 0; q < RB; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], b[j], acc[q], 0, 0, 0);
+            for (int q = 0; q < RBU; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[q][j], b0[j], acc[q], 0, 0, 0);
           }
-          b = bn;
+          if (kb + 2 < KB) {
+            b0 = Bp[(long long)(kb + 2) * 64];
+            const float* An = A0 + (kb + 2) * 2 * GP;
 #pragma unroll
-          for (int q = 0; q < RB; ++q) av[q] = avn[q];
+            for (int q = 0; q < RBU; ++q) av0[q] = *reinterpret_cast<const f32x4*>(An + q * 32 * 4);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int q = 0; q < RBU; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[q][j], b1[j], acc[q], 0, 0, 0);
+          }
+        }
+        if (kb < KB) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int q = 0; q < RBU; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[q][j], b0[j], acc[q], 0, 0, 0);
+          }
         }
 
         // ---- epilogue, pass 1: raw accumulators -> LDS (activation layout, conflict-free) ----
         {
-          // the output layer only stages through LDS: its blocks use a compact per-wave slot
-          const int n = (last ? wave : nb) * 32 + r;
-          float* dst = nxt + (n >> 2) * GP + (n & 3);
+          // the output layer only stages through LDS: its units use a compact slot
+          const int n = (last ? slot : nb) * 32 + r;
+          float* dst = nxt + (n >> 2) * GP + (n & 3) + rb0 * 32 * 4;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
 #pragma unroll
-            for (int q = 0; q < RB; ++q) dst[(q * 32 + acc_row(i, h)) * 4] = acc[q][i];
+            for (int q = 0; q < RBU; ++q) dst[(q * 32 + acc_row(i, h)) * 4] = acc[q][i];
           }
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // ---- pass 2: this wave's TM x 32 block, one float4 (4 columns of one row) per lane-step ----
+        // ---- pass 2: this unit's (32 RBU) x 32 block, one float4 (4 columns of one row) per lane-step ----
         {
-          const int g = lane & 7;                 // column group inside the block
-          const int n4 = nb * 32 + g * 4;         // first of the 4 columns
-          const bool is_skip = (li == a.skip_layer);
-          const float sc = is_skip ? a.skip_scale : 1.f;
-          const int nlim = (BWD && is_skip) ? a.skip_split : ly.N;   // columns that take the activation path
           // per-lane column masks (1/0) instead of branches
           f32x4 cm, bias4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -222,17 +264,16 @@ __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(Chai
               for (int q = 0; q < 4; ++q) if (n4 + q < ly.N) bias4[q] = ly.bias[n4 + q];
             }
           }
-          const bool vec_ok = (n4 + 3 < nlim);
-          const bool vec_side = vec_ok && (ly.ld_side & 3) == 0;
           const float inv_beta = 1.f / beta;
           // stored activations are h * skip_scale on the forward skip layer
-          const float hsc = ((MODE == 1 && is_skip) || (MODE == 2 && is_skip)) ? 1.f / sc : 1.f;
+          const float hsc = (MODE != 0 && is_skip) ? 1.f / sc : 1.f;
           const float nbs = -beta * hsc;
           f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
-          float* lp = nxt + ((last ? wave * 32 + g * 4 : n4) >> 2) * GP + (lane >> 3) * 4;
-          const long long grow0 = row0 + (lane >> 3);
-          for (int it = 0; it < TM / 8; ++it, lp += 32) {
-            const int m = (lane >> 3) + 8 * it;
+          float* lp = nxt + ((last ? slot * 32 + g * 4 : n4) >> 2) * GP + mbase * 4;
+          const long long grow0 = row0 + mbase;
+#pragma unroll(MODE == 0 ? 1 : ITS)
+          for (int it = 0; it < ITS; ++it, lp += 32) {
+            const int m = mbase + 8 * it;
             const bool mrow = m < rows;
             const float rm = mrow ? 1.f : 0.f;
             const long long grow = grow0 + 8 * it;
@@ -278,11 +319,11 @@ __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(Chai
             } else {
               // MODE 1: this GEMM produced dL/dh of the layer below; MODE 2: the tangent s-bar of this layer.
               // The stored activation h gives softplus'(z) = 1 - exp(-beta h).
-              f32x4 hs = {0.f, 0.f, 0.f, 0.f}, ex = {0.f, 0.f, 0.f, 0.f};
+              f32x4 hs = hsv[it];                  // prefetched before the k-loop on the vector path
+              f32x4 ex = {0.f, 0.f, 0.f, 0.f};
               if (mrow) {
                 const long long off = grow * ly.ld_side + n4;
                 if (vec_side) {
-                  hs = *reinterpret_cast<const f32x4*>(ly.side_in + off);
                   if (MODE == 1 && ly.side_add) ex = *reinterpret_cast<const f32x4*>(ly.side_add + off);
                   if (MODE == 2 && ly.side_in2) ex = *reinterpret_cast<const f32x4*>(ly.side_in2 + off);
                 } else {
@@ -343,6 +384,13 @@ __global__ void __launch_bounds__(NTHREADS, (TM == 64 ? 2 : 4)) k_mlp_chain(Chai
             }
           }
         }
+      };
+
+      {
+        const int rem = (RB == 1) ? 0 : (NB % NWAVES);
+        const int full = NB - rem;
+        for (int nb = wave; nb < full; nb += NWAVES) process(std::integral_constant<int, RB>{}, nb, 0);
+        for (int u = wave; u < rem * RB; u += NWAVES) process(std::integral_constant<int, 1>{}, full + u / RB, u % RB);
       }
 
       // ---- forward skip connection: append the (scaled) chain input after the skip layer's output ----

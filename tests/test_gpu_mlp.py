@@ -40,6 +40,11 @@ CASES = [
     ((43, 256, 256, 256, 213, 256, 256, 256, 257), 200, 3),   # geometric net with skip
     ((43, 256, 256, 256, 213, 256, 256, 256, 1), 77, 3),      # sdf-only variant (sampler)
     ((5, 64, 2), 3, -1),
+    # output blocks that do not fill a round of 8 waves (row-split remainder units, shared output slots)
+    ((43, 128, 128, 129), 200, -1),
+    ((43, 128, 161), 130, -1),
+    ((32, 128, 97), 64, -1),
+    ((43, 320, 320, 289), 100, -1),
 ]
 
 
