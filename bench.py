@@ -146,7 +146,7 @@ def cpu_baseline(conf, step, n_rays):
 def kernel_report(profile):
     """Aggregate the live HIP-event records of the MLP engine (ndjir_amd.mlp.PROFILE)."""
     agg = {}
-    for kind, flops, e0, e1 in profile:
+    for kind, flops, e0, e1, _shape in profile:
         a = agg.setdefault(kind, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
@@ -156,6 +156,20 @@ def kernel_report(profile):
         rep[kind] = dict(launches=n, avg_us=1e6 * sec / max(n, 1), tflops=flops / max(sec, 1e-12) / 1e12,
                          gflop_per_launch=flops / max(n, 1) / 1e9)
     return rep
+
+
+def kernel_detail(profile, steps):
+    """Per (kind, shape) table of the engine's launches -> stderr (NDJIR_BENCH_DETAIL=1)."""
+    agg = {}
+    for kind, flops, e0, e1, shape in profile:
+        a = agg.setdefault((kind, shape), [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += e0.elapsed_time(e1) * 1e-3
+    print(f"{'kind':10s} {'shape':48s} {'n/step':>6s} {'avg us':>8s} {'ms/step':>8s} {'TFLOP/s':>8s}", file=sys.stderr)
+    for (kind, shape), (n, flops, sec) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+        print(f"{kind:10s} {shape:48s} {n / steps:6.1f} {1e6 * sec / n:8.1f} {1e3 * sec / steps:8.3f} "
+              f"{flops / max(sec, 1e-12) / 1e12:8.1f}", file=sys.stderr)
 
 
 def main():
@@ -203,6 +217,8 @@ def main():
         rays_per_s = world * R * a.steps / el
         ms = 1e3 * el / a.steps
         kr = kernel_report(profile)
+        if os.environ.get("NDJIR_BENCH_DETAIL"):
+            kernel_detail(profile, a.steps)
         dom = kr.get("chain_fwd", dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0))
         step_tflops = MFLOP_PER_RAY_FWD_BWD * 1e6 * R / (ms * 1e-3) / 1e12      # per GPU
         tile = os.environ.get("NDJIR_MLP_TILE", "64")

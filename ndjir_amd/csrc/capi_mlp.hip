@@ -20,6 +20,8 @@ extern "C" int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int tran
   return launch_pack(W, dst, K, N, transpose, stream);
 }
 
+static long long* g_timeline = nullptr;   // diagnostics only, see ndjir_mlp_debug_timeline
+
 static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int L,
                                const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
                                const float* const* side_in, float* const* side_out, const int* ld_side,
@@ -33,6 +35,7 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
   ChainArgs a{};
   static const int tile_rows = [] { const char* e = getenv("NDJIR_MLP_TILE"); return e ? atoi(e) : 64; }();
   a.tile_rows = tile_rows;
+  a.timeline = g_timeline;
   a.P = P; a.X = X; a.ldx = ldx; a.K0 = K0; a.K0p = round_up(K0, 8); a.L = L;
   a.Y = Y; a.ldy = ldy; a.accum_y = accum_y; a.has_output = has_output; a.beta = beta;
   a.skip_layer = skip_layer; a.skip_scale = skip_scale; a.skip_split = skip_split; a.Xskip = Xskip; a.ld_xskip = ld_xskip;
@@ -96,4 +99,11 @@ extern "C" int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb,
   if (P <= 0) return NDJIR_OK;
   if (!A || !B || !out || !workspace || lda < K || ldb < N) return NDJIR_ERR_ARG;
   return launch_wgrad(A, lda, B, ldb, K, N, P, out, accum, workspace, stream);
+}
+
+// Diagnostics: when `buf` (device, MAX_CHAIN_LAYERS * 5 * 8 int64) is non-null, subsequent chain
+// launches record shader-clock stamps of workgroup 0 (tools/chain_timeline.py).  Null switches it off.
+extern "C" int ndjir_mlp_debug_timeline(long long* buf) {
+  g_timeline = buf;
+  return NDJIR_OK;
 }

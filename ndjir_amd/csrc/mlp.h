@@ -38,6 +38,7 @@ struct ChainArgs {
   int tile_rows;        // 64 (default) or 32 points per workgroup
   float skip_scale;
   float beta;
+  long long* timeline;  // diagnostics (tools/chain_timeline.py): per-layer phase stamps of workgroup 0, else null
   ChainLayer layers[MAX_CHAIN_LAYERS];
 };
 

@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "_lib", "libndjir_hip.so")
+# NDJIR_HIP_LIB: alternative build of the same library (kernel experiments); never a different backend
+SO_PATH = os.environ.get("NDJIR_HIP_LIB") or os.path.join(_HERE, "_lib", "libndjir_hip.so")
 
 _vp = ctypes.c_void_p
 _CT = {"i": ctypes.c_int, "f": ctypes.c_float, "p": _vp, "q": _vp, "F": ctypes.POINTER(ctypes.c_float),
@@ -170,7 +171,8 @@ def symbols():
     """Every symbol include/ndjir_hip.h declares (for the load/export test)."""
     return ["ndjir_" + n for n in SIGS] + ["ndjir_version", "ndjir_hash_force_align", "ndjir_hash_grid_size",
                                             "ndjir_hash_table_size", "ndjir_hash_num_params",
-                                            "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace"]
+                                            "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace",
+                                            "ndjir_mlp_debug_timeline"]
 
 
 def hash_num_params(G0, growth_factor, T0, L, D):

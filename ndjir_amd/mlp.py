@@ -19,11 +19,11 @@ from . import lib
 _PACK_CACHE = {}
 
 # Optional live timing of the engine's launches with HIP events on the launching stream
-# (bench.py sets PROFILE = [] around its timed region): entries (kind, algorithmic_flops, e0, e1).
+# (bench.py sets PROFILE = [] around its timed region): entries (kind, algorithmic_flops, e0, e1, shape).
 PROFILE = None
 
 
-def _launch(kind, flops, name, *args):
+def _launch(kind, flops, name, *args, shape=""):
     if PROFILE is None:
         lib.call(name, *args)
         return
@@ -32,7 +32,7 @@ def _launch(kind, flops, name, *args):
     e0.record()
     lib.call(name, *args)
     e1.record()
-    PROFILE.append((kind, flops, e0, e1))
+    PROFILE.append((kind, flops, e0, e1, shape))
 
 
 def _packed(W, transpose):
@@ -72,7 +72,7 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
     flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
     _launch("chain_fwd", flops, "mlp_chain", 0, P, x, x.shape[1], K0, L, Wp, [b.detach() if b is not None else None for b in biases],
              Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
-             int(skip_layer), float(skip_scale), 0, None, 0)
+             int(skip_layer), float(skip_scale), 0, None, 0, shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
     return y, hidden
 
 
@@ -95,7 +95,7 @@ def wgrad(A, B, out=None, accum=False):
         out = torch.empty((K, N), device=A.device, dtype=torch.float32)
         accum = False
     _launch("wgrad", 2.0 * P * K * N, "mlp_wgrad", _Strided(A), A.stride(0), _Strided(B), B.stride(0), K, N, P, out,
-            1 if accum else 0, ws)
+            1 if accum else 0, ws, shape=f"{P}:{K}x{N}")
     return out
 
 
@@ -186,7 +186,7 @@ class FusedMLP(Function):
             _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
                      side_in, side_out, ld_side, bg, gx, K0, 1 if bwd_skip >= 0 else 0, 1 if need_x else 0,
                      float(beta), int(bwd_skip), float(skip_scale), int(split),
-                     gx if bwd_skip >= 0 else None, K0)
+                     gx if bwd_skip >= 0 else None, K0, shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)))
         gW = [None] * L
         gb = [None] * L
         if need_w:

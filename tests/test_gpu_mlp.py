@@ -44,7 +44,7 @@ CASES = [
     ((43, 128, 128, 129), 200, -1),
     ((43, 128, 161), 130, -1),
     ((32, 128, 97), 64, -1),
-    ((43, 320, 320, 289), 100, -1),
+    ((43, 288, 288, 289), 100, -1),
 ]
 
 

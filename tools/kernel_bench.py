@@ -1,11 +1,12 @@
 """Micro-benchmark of the MLP engine kernels at the bench shapes (used under rocprofv3)."""
+import os
 import sys
 import time
 
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ndjir_amd.mlp import chain_forward, fused_mlp, wgrad  # noqa: E402
 
 
