@@ -91,6 +91,10 @@ class Step:
             torch.autograd.grad(loss, params, allow_unused=True)
             return loss.detach()
         grads = torch.autograd.grad(loss, self.mlp_params + self.grid_params, allow_unused=True)
+        self.grads = grads               # the step's product: every parameter gradient, materialised
+        if self.world == 1:
+            return loss.detach()
+        # multi-GPU: pack the MLP gradients into one flat bucket for the all-reduce
         off = 0
         for p, g in zip(self.mlp_params, grads):
             n = p.numel()
@@ -99,7 +103,7 @@ class Step:
             else:
                 self.flat_grad[off:off + n].zero_()
             off += n
-        if self.world > 1:
+        if True:
             import math
             from ndjir_amd.distributed import allreduce_step_gradients
             # total_loss already normalised by the GLOBAL ray / mask counts: gradients just add up.

@@ -255,6 +255,11 @@ int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx, int K0, i
 long long ndjir_mlp_wgrad_workspace(int K, int N, long long P);
 int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out,
                     int accum, float* workspace, hipStream_t stream);
+/* Bias gradient of a layer: out (N) (+)= column sums of its deltas X (P x N, row stride ldx); the
+ * reference gets it from nnabla's affine backward (a reduction kernel per layer). */
+long long ndjir_mlp_colsum_workspace(int N, long long P);   /* floats */
+int ndjir_mlp_colsum(const float* X, int ldx, int N, long long P, float* out, int accum, float* workspace,
+                     hipStream_t stream);
 /* Diagnostics (no reference counterpart): with a non-null device buffer of 10 * 5 * 8 int64, later
  * chain launches record shader-clock stamps of workgroup 0, [layer][phase][wave], phases = layer
  * start / k-loop done / accumulators staged / epilogue done / barrier passed.  Null switches it off. */

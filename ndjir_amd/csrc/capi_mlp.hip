@@ -101,6 +101,16 @@ extern "C" int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb,
   return launch_wgrad(A, lda, B, ldb, K, N, P, out, accum, workspace, stream);
 }
 
+extern "C" long long ndjir_mlp_colsum_workspace(int N, long long P) { return colsum_workspace(N, P); }
+
+extern "C" int ndjir_mlp_colsum(const float* X, int ldx, int N, long long P, float* out, int accum, float* workspace,
+                                hipStream_t stream) {
+  if (N <= 0) return NDJIR_OK;
+  if (!out || (P > 0 && (!X || !workspace || ldx < N))) return NDJIR_ERR_ARG;
+  if (N > 2048) return NDJIR_ERR_UNSUPPORTED;
+  return launch_colsum(X, ldx, N, P, out, accum, workspace, stream);
+}
+
 // Diagnostics: when `buf` (device, MAX_CHAIN_LAYERS * 5 * 8 int64) is non-null, subsequent chain
 // launches record shader-clock stamps of workgroup 0 (tools/chain_timeline.py).  Null switches it off.
 extern "C" int ndjir_mlp_debug_timeline(long long* buf) {

@@ -48,4 +48,8 @@ long long wgrad_workspace(int K, int N, long long P);
 int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out, int accum,
                  float* workspace, hipStream_t stream);
 
+long long colsum_workspace(int N, long long P);
+int launch_colsum(const float* X, int ldx, int N, long long P, float* out, int accum, float* workspace,
+                  hipStream_t stream);
+
 }  // namespace ndjir

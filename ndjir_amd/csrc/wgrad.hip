@@ -156,23 +156,206 @@ static inline int pick_splits(int K, int N, long long P) {
   return S;
 }
 
-long long wgrad_workspace(int K, int N, long long P) { return (long long)pick_splits(K, N, P) * K * N; }
+
+// ---- narrow outputs (N <= 8) and column sums: streaming reductions, no matrix cores ----------------
+// The 128x128 MFMA tiles above would be > 90 % padding for the 1..6-wide output layers; these are
+// bandwidth problems (read A once).  Threads (tx = column phase, ty = row phase); every workgroup
+// writes one partial result, the split reduction kernel above sums the partials (no float atomics:
+// device-scope atomics on one address from 8 XCDs serialise in the memory-side cache).
+constexpr int SW_NMAX = 8;
+constexpr int SW_ROWS = 128;          // rows per workgroup
+
+__device__ __forceinline__ int pow2_at_least(int v) {
+  int t = 1;
+  while (t < v && t < 256) t <<= 1;
+  return t;
+}
+
+// A is read as float4 (needs K % 4 == 0, lda % 4 == 0, 16-byte aligned base): thread = (k quad, row phase)
+template <int NMAX>
+__global__ void __launch_bounds__(256) k_wgrad_narrow(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                      int ldb, int K, int N, long long P, float* __restrict__ ws) {
+  __shared__ float4 red[256];
+  const int KQ = K >> 2;
+  const int TX = pow2_at_least(KQ), TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const long long p0 = (long long)blockIdx.x * SW_ROWS;
+  const long long p1 = (p0 + SW_ROWS < P) ? p0 + SW_ROWS : P;
+  float* part = ws + (long long)blockIdx.x * K * N;
+  for (int q0 = 0; q0 < KQ; q0 += TX) {
+    const int kq = q0 + tx;
+    float4 acc[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kq < KQ) {
+#pragma unroll 4
+      for (long long p = p0 + ty; p < p1; p += TY) {
+        const float4 a = *reinterpret_cast<const float4*>(A + p * lda + 4 * kq);
+        const float* b = B + p * ldb;
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) if (n < N) {
+          const float bn = b[n];
+          acc[n].x = fmaf(a.x, bn, acc[n].x); acc[n].y = fmaf(a.y, bn, acc[n].y);
+          acc[n].z = fmaf(a.z, bn, acc[n].z); acc[n].w = fmaf(a.w, bn, acc[n].w);
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      if (n < N) {                                   // uniform
+        red[threadIdx.x] = acc[n];
+        __syncthreads();
+        for (int s = TY / 2; s > 0; s >>= 1) {
+          if (ty < s) {
+            float4 o = red[threadIdx.x + s * TX], m = red[threadIdx.x];
+            red[threadIdx.x] = make_float4(m.x + o.x, m.y + o.y, m.z + o.z, m.w + o.w);
+          }
+          __syncthreads();
+        }
+        if (ty == 0 && kq < KQ) {
+          const float4 t = red[tx];
+          float* o = part + (long long)(4 * kq) * N + n;
+          o[0] = t.x; o[N] = t.y; o[2 * N] = t.z; o[3 * N] = t.w;
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// partial column sums of X (P x N): ws[block][n].  Narrow N: threads (column, row phase) + LDS tree;
+// wide N (> 256): one thread per column phase, all of the row's column passes inside the row loop.
+constexpr int CS_MAXPASS = 8;          // wide path: N <= 2048
+__global__ void __launch_bounds__(256) k_colsum(const float* __restrict__ X, int ldx, int N, long long P,
+                                                float* __restrict__ ws, int rows_per_block) {
+  __shared__ float red[256];
+  const long long p0 = (long long)blockIdx.x * rows_per_block;
+  const long long p1 = (p0 + rows_per_block < P) ? p0 + rows_per_block : P;
+  float* part = ws + (long long)blockIdx.x * N;
+  if (N > 256) {
+    float acc[CS_MAXPASS];
+#pragma unroll
+    for (int j = 0; j < CS_MAXPASS; ++j) acc[j] = 0.f;
+#pragma unroll 2
+    for (long long p = p0; p < p1; ++p) {
+      const float* x = X + p * ldx + threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < CS_MAXPASS; ++j) if (j * 256 + (int)threadIdx.x < N) acc[j] += x[j * 256];
+    }
+#pragma unroll
+    for (int j = 0; j < CS_MAXPASS; ++j) if (j * 256 + (int)threadIdx.x < N) part[j * 256 + threadIdx.x] = acc[j];
+    return;
+  }
+  const int TX = pow2_at_least(N), TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  float acc = 0.f;
+  if (tx < N) {
+#pragma unroll 8
+    for (long long p = p0 + ty; p < p1; p += TY) acc += X[p * ldx + tx];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = TY / 2; s > 0; s >>= 1) {
+    if (ty < s) red[threadIdx.x] += red[threadIdx.x + s * TX];
+    __syncthreads();
+  }
+  if (ty == 0 && tx < N) part[tx] = red[tx];
+}
+
+// out[i] (+)= sum_s ws[s][i] for many partials (S > 32): 32 outputs x 8 split phases per workgroup
+__global__ void __launch_bounds__(256) k_reduce_tall(const float* __restrict__ ws, float* __restrict__ out, long long KN,
+                                                     int S, int accum) {
+  __shared__ float red[256];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long i = (long long)blockIdx.x * 32 + tx;
+  float acc = 0.f;
+  if (i < KN) {
+#pragma unroll 8
+    for (int sidx = ty; sidx < S; sidx += 8) acc += ws[(long long)sidx * KN + i];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (ty == 0 && i < KN) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q * 32 + tx];
+    out[i] = accum ? out[i] + t : t;
+  }
+}
+
+static void colsum_plan(int N, long long P, int* rows, int* blocks) {
+  int TX = 1;
+  while (TX < N && TX < 256) TX <<= 1;
+  const int TY = 256 / TX;
+  if (N > 256) TX = 256;
+  int r = (N > 256) ? 64 : 32 * TY;                     // rows per workgroup
+  long long b = (P + r - 1) / r;
+  if (b > 1024) { r = (int)((P + 1023) / 1024); r = (r + TY - 1) / TY * TY; b = (P + r - 1) / r; }
+  if (b < 1) b = 1;
+  *rows = r; *blocks = (int)b;
+}
+
+long long colsum_workspace(int N, long long P) {
+  int rows, blocks;
+  colsum_plan(N, P, &rows, &blocks);
+  return (long long)blocks * N;
+}
+
+static int launch_split_reduce(const float* ws, float* out, long long KN, int S, int accum, hipStream_t stream);
+
+int launch_colsum(const float* X, int ldx, int N, long long P, float* out, int accum, float* workspace,
+                  hipStream_t stream) {
+  if (N <= 0) return NDJIR_OK;
+  if (P <= 0) {
+    if (!accum && hipMemsetAsync(out, 0, (size_t)N * sizeof(float), stream) != hipSuccess) return NDJIR_ERR_LAUNCH;
+    return NDJIR_OK;
+  }
+  int rows, blocks;
+  colsum_plan(N, P, &rows, &blocks);
+  hipLaunchKernelGGL(k_colsum, dim3(blocks), dim3(256), 0, stream, X, ldx, N, P, workspace, rows);
+  return launch_split_reduce(workspace, out, N, blocks, accum, stream);
+}
+
+long long wgrad_workspace(int K, int N, long long P) {
+  long long splits = pick_splits(K, N, P);
+  if (N <= SW_NMAX) {                                  // narrow path: one partial per SW_ROWS rows
+    const long long nb = (P + SW_ROWS - 1) / SW_ROWS;
+    if (nb > splits) splits = nb;
+  }
+  return splits * K * N;
+}
+
+static int launch_split_reduce(const float* ws, float* out, long long KN, int S, int accum, hipStream_t stream) {
+  if (S > 32) {
+    hipLaunchKernelGGL(k_reduce_tall, dim3((unsigned)((KN + 31) / 32)), dim3(256), 0, stream, ws, out, KN, S, accum);
+    return ndjir_check_launch();
+  }
+  int blocks = (int)(((KN + 3) / 4 + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, stream, ws, out, KN, S, accum);
+  return ndjir_check_launch();
+}
 
 int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out, int accum,
                  float* workspace, hipStream_t stream) {
   if (K <= 0 || N <= 0) return NDJIR_OK;
+  if (N <= SW_NMAX && (K & 3) == 0 && (lda & 3) == 0 && ((uintptr_t)A & 15) == 0) {
+    if (P <= 0) {
+      if (!accum && hipMemsetAsync(out, 0, (size_t)K * N * sizeof(float), stream) != hipSuccess) return NDJIR_ERR_LAUNCH;
+      return NDJIR_OK;
+    }
+    const unsigned blocks = (unsigned)((P + SW_ROWS - 1) / SW_ROWS);
+    hipLaunchKernelGGL(k_wgrad_narrow<SW_NMAX>, dim3(blocks), dim3(256), 0, stream, A, lda, B, ldb, K, N, P, workspace);
+    return launch_split_reduce(workspace, out, (long long)K * N, (int)blocks, accum, stream);
+  }
   const int tiles_k = (K + WG_T - 1) / WG_T, tiles_n = (N + WG_T - 1) / WG_T;
   const int S = pick_splits(K, N, P);
   long long rows = (P + S - 1) / S;
   rows = (rows + WG_C - 1) / WG_C * WG_C;
   hipLaunchKernelGGL(k_wgrad, dim3(S * tiles_k * tiles_n), dim3(WG_THREADS), 0, stream, A, lda, B, ldb, K, N, P, workspace, S,
                      tiles_k, tiles_n, rows);
-  const long long KN = (long long)K * N;
-  int blocks = (int)(((KN + 3) / 4 + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(256), 0, stream, workspace, out, KN, S, accum);
-  return ndjir_check_launch();
+  return launch_split_reduce(workspace, out, (long long)K * N, S, accum, stream);
 }
 
 }  // namespace ndjir

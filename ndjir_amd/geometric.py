@@ -25,7 +25,7 @@ from torch.autograd import Function
 
 from . import lib
 from .grid_feature import _core
-from .mlp import _launch, _packed, wgrad
+from .mlp import _launch, _packed, colsum, wgrad
 
 _VOX = _core.FAMILIES["voxel"]
 
@@ -243,7 +243,7 @@ class GeometricMain(Function):
                 if nbar is not None and j == L - 1:
                     gW[j][:, 0] += col_last
             if ctx.needs_input_grad[3 + L + j]:
-                gb[j] = bgrads[j] if j < L - 1 else gy.sum(0)
+                gb[j] = bgrads[j] if j < L - 1 else colsum(gy)
         g_feature = None
         if has_grid and ctx.needs_input_grad[1] and buf is None:
             g_feature = grid_grad

@@ -41,6 +41,7 @@ SIGS = {
     "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi",
     "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP",
     "mlp_wgrad": "pipiiilpip",
+    "mlp_colsum": "piilpip",
     "sampler_importance_round": "iiifpppppq",
     "ray_aabb_intersection": "ipppppiiFF",
     "ray_sphere_intersection": "ipppppiif",
@@ -96,6 +97,8 @@ def load():
         _lib.ndjir_mlp_packed_size.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.ndjir_mlp_wgrad_workspace.restype = ctypes.c_longlong
         _lib.ndjir_mlp_wgrad_workspace.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong]
+        _lib.ndjir_mlp_colsum_workspace.restype = ctypes.c_longlong
+        _lib.ndjir_mlp_colsum_workspace.argtypes = [ctypes.c_int, ctypes.c_longlong]
     return _lib
 
 
@@ -171,7 +174,7 @@ def symbols():
     """Every symbol include/ndjir_hip.h declares (for the load/export test)."""
     return ["ndjir_" + n for n in SIGS] + ["ndjir_version", "ndjir_hash_force_align", "ndjir_hash_grid_size",
                                             "ndjir_hash_table_size", "ndjir_hash_num_params",
-                                            "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace",
+                                            "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_colsum_workspace",
                                             "ndjir_mlp_debug_timeline"]
 
 

@@ -79,6 +79,14 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
 _WORKSPACE = {}
 
 
+def _workspace(device, need):
+    ws = _WORKSPACE.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 22), device=device, dtype=torch.float32)
+        _WORKSPACE[device] = ws
+    return ws
+
+
 def wgrad(A, B, out=None, accum=False):
     """dW = A^T B with A (P, K) and B (P, N) row-major views (column stride 1): the weight gradient
     of one layer, reduction over the P points (ndjir_amd/csrc/wgrad.hip).  `out` (K, N) with
@@ -86,16 +94,25 @@ def wgrad(A, B, out=None, accum=False):
     P, K = A.shape
     N = B.shape[1]
     assert A.stride(1) == 1 and B.stride(1) == 1 and B.shape[0] == P
-    need = lib.load().ndjir_mlp_wgrad_workspace(K, N, P)
-    ws = _WORKSPACE.get(A.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 1 << 22), device=A.device, dtype=torch.float32)
-        _WORKSPACE[A.device] = ws
+    ws = _workspace(A.device, lib.load().ndjir_mlp_wgrad_workspace(K, N, P))
     if out is None:
         out = torch.empty((K, N), device=A.device, dtype=torch.float32)
         accum = False
     _launch("wgrad", 2.0 * P * K * N, "mlp_wgrad", _Strided(A), A.stride(0), _Strided(B), B.stride(0), K, N, P, out,
             1 if accum else 0, ws, shape=f"{P}:{K}x{N}")
+    return out
+
+
+def colsum(X, out=None, accum=False):
+    """Column sums of a (P, N) row-major view (column stride 1): the bias gradient of a layer."""
+    P, N = X.shape
+    assert X.stride(1) == 1
+    if out is None:
+        out = torch.empty((N,), device=X.device, dtype=torch.float32)
+        accum = False
+    ws = _workspace(X.device, lib.load().ndjir_mlp_colsum_workspace(N, P))
+    _launch("colsum", float(P) * N, "mlp_colsum", _Strided(X), X.stride(0) if P > 1 else N, N, P, out, 1 if accum else 0, ws,
+            shape=f"{P}:{N}")
     return out
 
 
@@ -194,7 +211,7 @@ class FusedMLP(Function):
                 if ctx.needs_input_grad[4 + j]:
                     gW[j] = wgrad(A[j], deltas[j])
                 if ctx.needs_input_grad[4 + L + j]:
-                    gb[j] = bgrads[j] if j < L - 1 else gy2.sum(0)
+                    gb[j] = bgrads[j] if j < L - 1 else colsum(gy2)
         return (gx.view(xshape) if gx is not None else None, None, None, None, *gW, *gb)
 
 

@@ -117,7 +117,8 @@ def test_fused_mlp_throughput(gpu):
         print(f"\nchain fwd geometric P={P} keep_hidden={keep}: {dt * 1e6:.0f} us, {flops / dt / 1e12:.1f} TFLOP/s")
 
 
-@pytest.mark.parametrize("P,K,N", [(1000, 301, 128), (65, 39, 1), (4096, 256, 257), (33, 5, 7), (20000, 213, 256)])
+@pytest.mark.parametrize("P,K,N", [(1000, 301, 128), (65, 39, 1), (4096, 256, 257), (33, 5, 7), (20000, 213, 256), (65536, 128, 6),
+                                   (3000, 600, 2), (100, 128, 8), (100, 128, 9)])
 def test_wgrad_kernel(gpu, P, K, N):
     """split-P weight-gradient GEMM vs fp64; strided operand views (delta of the skip layer)."""
     from ndjir_amd.mlp import wgrad
@@ -145,6 +146,21 @@ def test_wgrad_throughput(gpu):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 10
         print(f"\n{name}: {dt * 1e6:.0f} us, {2 * P * K * N / dt / 1e12:.1f} TFLOP/s")
+
+
+@pytest.mark.parametrize("P,N,ld", [(65536, 257, 257), (1000, 3, 3), (77, 1, 1), (4097, 256, 300), (5, 600, 600), (0, 4, 4), (70000, 2048, 2048)])
+def test_colsum_kernel(gpu, P, N, ld):
+    """bias-gradient column sums vs fp64, strided rows, accumulate flag."""
+    from ndjir_amd.mlp import colsum
+    rng = np.random.RandomState(P + N)
+    X = torch.tensor(rng.randn(max(P, 1), ld), dtype=torch.float32, device=gpu)[:P, :N]
+    ref = X.double().sum(0)
+    out = colsum(X)
+    scale = max(float(ref.abs().max()), 1.0)
+    assert float((out.double() - ref).abs().max()) / scale < 2e-5
+    base = torch.ones(N, device=gpu)
+    colsum(X, out=base, accum=True)
+    assert float((base.double() - 1.0 - ref).abs().max()) / scale < 2e-5
 
 
 @pytest.mark.parametrize("grid", [True, False])
