@@ -19,15 +19,25 @@ constexpr int WG_THREADS = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Tile = (WK*BK*32) x (WN*BN*32) outputs: WK x WN waves, each BK x BN MFMA blocks.  <2,2,2,2> is the
+// 128 x 128 main tile; <1,4,1,1> (32 x 128) and <4,1,1,1> (128 x 32) cover the ragged strips of shapes
+// like 259 x 256 or 256 x 257 without paying for a whole extra tile.  (k_off, n_off) = origin of the
+// region this launch covers; the output / partial layout is always the full K x N matrix.
+template <int WK, int WN, int BK, int BN>
 __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                          int ldb, int K, int N, long long P, float* __restrict__ partial,
-                                                         int S, int tiles_k, int tiles_n, long long rows_per_split) {
-  __shared__ float As[2][WG_C][WG_T];
-  __shared__ float Bs[2][WG_C][WG_T];
+                                                         int S, int tiles_k, int tiles_n, long long rows_per_split,
+                                                         int k_off, int n_off, int k_end, int n_end) {
+  static_assert(WK * WN == 4, "4 waves");
+  constexpr int TK = WK * BK * 32, TN = WN * BN * 32;
+  constexpr int EA = WG_C * TK / WG_THREADS, EB = WG_C * TN / WG_THREADS;   // staged elements per thread
+  constexpr int RA = WG_THREADS / TK, RB = WG_THREADS / TN;                 // rows covered per pass
+  __shared__ float As[2][WG_C][TK];
+  __shared__ float Bs[2][WG_C][TN];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int wk = wave >> 1, wn = wave & 1;          // 2 x 2 waves, each 64 x 64
+  const int wk = wave / WN, wn = wave % WN;
   const int T = tiles_k * tiles_n;
   // XCD-aware: blocks are dealt round-robin to the 8 XCDs; give every XCD whole splits
   const int nblk = gridDim.x;
@@ -35,44 +45,39 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad(const float* __restrict
   int vid = (nblk & 7) == 0 ? xcd * (nblk >> 3) + local : blockIdx.x;
   const int split = vid / T, tile = vid - split * T;
   const int tk = tile / tiles_n, tn = tile - tk * tiles_n;
-  const int k0 = tk * WG_T, n0 = tn * WG_T;
+  const int k0 = k_off + tk * TK, n0 = n_off + tn * TN;
   const long long p_begin = (long long)split * rows_per_split;
   long long p_end = p_begin + rows_per_split;
   if (p_end > P) p_end = P;
 
-  f32x16 acc[2][2] = {};
-  float ra[16], rb[16];
+  f32x16 acc[BK][BN] = {};
+  float ra[EA], rb[EB];
 
-  // element e = tid + 256 i of a 32 x 128 chunk: column = tid & 127 (fixed), row = (tid >> 7) + 2 i
-  const int col = tid & (WG_T - 1), rbase = tid >> 7;
-  const bool acol = (k0 + col) < K, bcol = (n0 + col) < N;
-  const float* Ap = A + (long long)rbase * lda + k0 + col;
-  const float* Bp = B + (long long)rbase * ldb + n0 + col;
-  const long long astep = 2LL * lda, bstep = 2LL * ldb;
+  const int cola = tid % TK, rowa = tid / TK, colb = tid % TN, rowb = tid / TN;
+  const bool acol = (k0 + cola) < k_end, bcol = (n0 + colb) < n_end;
+  const float* Ap = A + (long long)rowa * lda + k0 + cola;
+  const float* Bp = B + (long long)rowb * ldb + n0 + colb;
+  const long long astep = (long long)RA * lda, bstep = (long long)RB * ldb;
   auto load_chunk = [&](long long p0) {
     const float* ap = Ap + p0 * lda;
     const float* bp = Bp + p0 * ldb;
     if (p0 + WG_C <= p_end) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        ra[i] = acol ? ap[i * astep] : 0.f;
-        rb[i] = bcol ? bp[i * bstep] : 0.f;
-      }
+      for (int i = 0; i < EA; ++i) ra[i] = acol ? ap[i * astep] : 0.f;
+#pragma unroll
+      for (int i = 0; i < EB; ++i) rb[i] = bcol ? bp[i * bstep] : 0.f;
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        bool pv = p0 + rbase + 2 * i < p_end;
-        ra[i] = (pv && acol) ? ap[i * astep] : 0.f;
-        rb[i] = (pv && bcol) ? bp[i * bstep] : 0.f;
-      }
+      for (int i = 0; i < EA; ++i) ra[i] = (acol && p0 + rowa + RA * i < p_end) ? ap[i * astep] : 0.f;
+#pragma unroll
+      for (int i = 0; i < EB; ++i) rb[i] = (bcol && p0 + rowb + RB * i < p_end) ? bp[i * bstep] : 0.f;
     }
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      As[buf][rbase + 2 * i][col] = ra[i];
-      Bs[buf][rbase + 2 * i][col] = rb[i];
-    }
+    for (int i = 0; i < EA; ++i) As[buf][rowa + RA * i][cola] = ra[i];
+#pragma unroll
+    for (int i = 0; i < EB; ++i) Bs[buf][rowb + RB * i][colb] = rb[i];
   };
 
   if (p_begin < p_end) {
@@ -85,13 +90,17 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad(const float* __restrict
       if (more) load_chunk(p0 + WG_C);
 #pragma unroll 4
       for (int s = 0; s < WG_C / 2; ++s) {
-        const float* ar = &As[cur][2 * s + h][wk * 64 + r];
-        const float* br = &Bs[cur][2 * s + h][wn * 64 + r];
-        float a0 = ar[0], a1 = ar[32], b0 = br[0], b1 = br[32];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        const float* ar = &As[cur][2 * s + h][wk * BK * 32 + r];
+        const float* br = &Bs[cur][2 * s + h][wn * BN * 32 + r];
+        float av[BK], bv[BN];
+#pragma unroll
+        for (int i = 0; i < BK; ++i) av[i] = ar[32 * i];
+#pragma unroll
+        for (int j = 0; j < BN; ++j) bv[j] = br[32 * j];
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int j = 0; j < BN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
       }
       if (more) store_chunk(cur ^ 1);
       __syncthreads();
@@ -101,14 +110,14 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad(const float* __restrict
 
   float* out = partial + (long long)split * K * N;
 #pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
+  for (int bi = 0; bi < BK; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-      const int n = n0 + wn * 64 + bj * 32 + r;
+    for (int bj = 0; bj < BN; ++bj) {
+      const int n = n0 + (wn * BN + bj) * 32 + r;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int k = k0 + wk * 64 + bi * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (k < K && n < N) out[(long long)k * N + n] = acc[bi][bj][i];
+        const int k = k0 + (wk * BK + bi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (k < k_end && n < n_end) out[(long long)k * N + n] = acc[bi][bj][i];
       }
     }
 }
@@ -145,14 +154,40 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
   }
 }
 
-// workspace floats needed for (K, N): S * K * N with the S chosen below
+// Region plan of a K x N weight gradient: 128 x 128 main tiles over [0, Km) x [0, Nm); remainders of
+// at most 64 go to 32-wide strips (K strip spans all of N, N strip spans [0, Km)), larger ones to a
+// further (ragged) main tile.
+constexpr int WG_STRIP = 32;
+struct WgradPlan {
+  int Km, Nm;           // extent covered by main tiles (>= K / >= N when there is no strip)
+  int tk, tn;           // main tiles
+  int sk, sn;           // strips (of WG_STRIP) in K / in N
+  int units;            // work in 128x128-tile equivalents x 16 (a 32x128 strip tile = 4)
+};
+
+static inline WgradPlan wgrad_plan(int K, int N) {
+  WgradPlan p;
+  const int rk = K % WG_T, rn = N % WG_T;
+  p.Km = (rk != 0 && rk <= 2 * WG_STRIP) ? K - rk : K;
+  p.Nm = (rn != 0 && rn <= 2 * WG_STRIP) ? N - rn : N;
+  p.tk = (p.Km + WG_T - 1) / WG_T;
+  p.tn = (p.Nm + WG_T - 1) / WG_T;
+  p.sk = (K - p.Km + WG_STRIP - 1) / WG_STRIP;
+  p.sn = (N - p.Nm + WG_STRIP - 1) / WG_STRIP;
+  const int tn_all = (N + WG_T - 1) / WG_T;
+  p.units = 16 * p.tk * p.tn + 4 * p.sk * tn_all + 4 * p.sn * p.tk;
+  return p;
+}
+
+// number of point-axis splits: ~1 workgroup (4 waves) of main-tile work per CU keeps every SIMD's matrix pipe busy
 static inline int pick_splits(int K, int N, long long P) {
-  int T = ((K + WG_T - 1) / WG_T) * ((N + WG_T - 1) / WG_T);
-  int S = (256 + T - 1) / T;                       // ~1 workgroup (4 waves) per CU keeps every SIMD's matrix pipe busy
+  const WgradPlan pl = wgrad_plan(K, N);
+  int T16 = pl.units < 16 ? 16 : pl.units;
+  int S = (256 * 16 + T16 - 1) / T16;
   long long max_s = (P + WG_C - 1) / WG_C;
   if (S > max_s) S = (int)max_s;
   if (S < 1) S = 1;
-  while ((S * T) & 7) ++S;                         // whole splits per XCD
+  while (S & 7) ++S;                               // whole splits per XCD whatever the tile count
   return S;
 }
 
@@ -349,12 +384,22 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
     hipLaunchKernelGGL(k_wgrad_narrow<SW_NMAX>, dim3(blocks), dim3(256), 0, stream, A, lda, B, ldb, K, N, P, workspace);
     return launch_split_reduce(workspace, out, (long long)K * N, (int)blocks, accum, stream);
   }
-  const int tiles_k = (K + WG_T - 1) / WG_T, tiles_n = (N + WG_T - 1) / WG_T;
+  const WgradPlan pl = wgrad_plan(K, N);
   const int S = pick_splits(K, N, P);
   long long rows = (P + S - 1) / S;
   rows = (rows + WG_C - 1) / WG_C * WG_C;
-  hipLaunchKernelGGL(k_wgrad, dim3(S * tiles_k * tiles_n), dim3(WG_THREADS), 0, stream, A, lda, B, ldb, K, N, P, workspace, S,
-                     tiles_k, tiles_n, rows);
+  if (pl.tk > 0 && pl.tn > 0)
+    hipLaunchKernelGGL((k_wgrad<2, 2, 2, 2>), dim3(S * pl.tk * pl.tn), dim3(WG_THREADS), 0, stream, A, lda, B, ldb, K, N, P,
+                       workspace, S, pl.tk, pl.tn, rows, 0, 0, pl.Km < K ? pl.Km : K, pl.Nm < N ? pl.Nm : N);
+  if (pl.sk > 0) {       // rows [Km, K) of dW, all columns
+    const int tn_all = (N + WG_T - 1) / WG_T;
+    hipLaunchKernelGGL((k_wgrad<1, 4, 1, 1>), dim3(S * pl.sk * tn_all), dim3(WG_THREADS), 0, stream, A, lda, B, ldb, K, N, P,
+                       workspace, S, pl.sk, tn_all, rows, pl.Km, 0, K, N);
+  }
+  if (pl.sn > 0 && pl.tk > 0) {   // columns [Nm, N), rows [0, Km)
+    hipLaunchKernelGGL((k_wgrad<4, 1, 1, 1>), dim3(S * pl.tk * pl.sn), dim3(WG_THREADS), 0, stream, A, lda, B, ldb, K, N, P,
+                       workspace, S, pl.tk, pl.sn, rows, 0, pl.Nm, pl.Km, N);
+  }
   return launch_split_reduce(workspace, out, (long long)K * N, S, accum, stream);
 }
 

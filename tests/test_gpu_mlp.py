@@ -118,7 +118,8 @@ def test_fused_mlp_throughput(gpu):
 
 
 @pytest.mark.parametrize("P,K,N", [(1000, 301, 128), (65, 39, 1), (4096, 256, 257), (33, 5, 7), (20000, 213, 256), (65536, 128, 6),
-                                   (3000, 600, 2), (100, 128, 8), (100, 128, 9)])
+                                   (3000, 600, 2), (100, 128, 8), (100, 128, 9), (5000, 259, 256), (5000, 290, 256),
+                                   (5000, 43, 256), (777, 52, 40), (3000, 300, 300), (2000, 128, 192), (1000, 64, 64)])
 def test_wgrad_kernel(gpu, P, K, N):
     """split-P weight-gradient GEMM vs fp64; strided operand views (delta of the skip layer)."""
     from ndjir_amd.mlp import wgrad
