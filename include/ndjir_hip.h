@@ -219,8 +219,11 @@ int ndjir_sampler_importance_round(int R, int N, int M, float gain, const float*
  * ndjir_mlp_chain (bwd != 0), backward of the data path, chain input X = dL/dY:
  *                 step i uses packed W_{L-i}^T; side_in[i] = stored forward activation of the layer
  *                 below (softplus' = 1 - exp(-beta h)); side_out[i] receives delta of that layer
- *                 (P x N), bgrad[i] its column sums (atomically accumulated); with has_output the
- *                 last step writes dL/dX to Y.  Weight gradients are plain GEMMs H^T delta.
+ *                 (P x N), bgrad[i] (N) its column sums = the bias gradient (overwritten; summed per
+ *                 workgroup in LDS, then across workgroups from `workspace`, which must hold
+ *                 ndjir_mlp_chain_workspace(sum of the N_i that have a bgrad) floats -- may be null
+ *                 when no bgrad is requested); with has_output the last step writes dL/dX to Y.
+ *                 Weight gradients are plain GEMMs H^T delta (ndjir_mlp_wgrad).
  * Per-layer arrays are HOST arrays of length L; Ks/Ns are each step's logical input/output width.
  * skip_layer (-1 = none): forward, the output of that layer is scaled by skip_scale and the scaled
  * chain input is appended (python/network.py:221-224); backward, the step whose output is the
@@ -232,7 +235,8 @@ int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L
                     const float* const* side_in, float* const* side_out, const int* ld_side,
                     float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                     int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
-                    hipStream_t stream);
+                    float* workspace, hipStream_t stream);
+long long ndjir_mlp_chain_workspace(int bgrad_total);   /* floats */
 /* Extended chain used by the geometric network, whose output gradient d(sdf)/dx itself enters the
  * loss (nn.grad, python/renderer.py:52; eikonal term python/loss.py:68-76):
  *   mode 0 / 1: as ndjir_mlp_chain, plus side_add[i] (P x N): extra adjoint added to delta after the
@@ -247,7 +251,7 @@ int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx, int K0, i
                        float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                        int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                        const float* const* side_in2, const float* const* side_add, float* const* side_out2,
-                       hipStream_t stream);
+                       float* workspace, hipStream_t stream);
 /* Weight gradient of one layer: out (K x N) (+)= A^T B with A (P x K, row stride lda) the layer's
  * input activations and B (P x N, row stride ldb) its deltas (ndjir_amd/csrc/wgrad.hip; the
  * reference gets this from nnabla's affine backward, a cuBLAS GEMM).  `workspace` needs

@@ -28,14 +28,21 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
                                float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                                int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                                const float* const* side_in2, const float* const* side_add, float* const* side_out2,
-                               hipStream_t stream) {
-  if (P <= 0) return NDJIR_OK;
+                               float* workspace, hipStream_t stream) {
+  if (P <= 0) {
+    // nothing to process: bias gradients of an empty batch are zero
+    if (bwd != 0 && bgrad && Ns && L >= 1 && L <= MAX_CHAIN_LAYERS)
+      for (int i = 0; i < L; ++i)
+        if (bgrad[i] && hipMemsetAsync(bgrad[i], 0, (size_t)Ns[i] * sizeof(float), stream) != hipSuccess) return NDJIR_ERR_LAUNCH;
+    return NDJIR_OK;
+  }
   if (!X || L < 1 || L > MAX_CHAIN_LAYERS || !Wp || !Ks || !Ns) return NDJIR_ERR_ARG;
   if (has_output && !Y) return NDJIR_ERR_ARG;
   ChainArgs a{};
   static const int tile_rows = [] { const char* e = getenv("NDJIR_MLP_TILE"); return e ? atoi(e) : 64; }();
   a.tile_rows = tile_rows;
   a.timeline = g_timeline;
+  a.bg_partial = workspace;
   a.P = P; a.X = X; a.ldx = ldx; a.K0 = K0; a.K0p = round_up(K0, 8); a.L = L;
   a.Y = Y; a.ldy = ldy; a.accum_y = accum_y; a.has_output = has_output; a.beta = beta;
   a.skip_layer = skip_layer; a.skip_scale = skip_scale; a.skip_split = skip_split; a.Xskip = Xskip; a.ld_xskip = ld_xskip;
@@ -71,10 +78,11 @@ extern "C" int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, in
                                const float* const* side_in, float* const* side_out, const int* ld_side,
                                float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                                int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
-                               hipStream_t stream) {
+                               float* workspace, hipStream_t stream) {
   if (bwd != 0 && bwd != 1) return NDJIR_ERR_ARG;
   return chain_impl(bwd, P, X, ldx, K0, L, Wp, bias, Ks, Ns, side_in, side_out, ld_side, bgrad, Y, ldy, accum_y,
-                    has_output, beta, skip_layer, skip_scale, skip_split, Xskip, ld_xskip, nullptr, nullptr, nullptr, stream);
+                    has_output, beta, skip_layer, skip_scale, skip_split, Xskip, ld_xskip, nullptr, nullptr, nullptr, workspace,
+                    stream);
 }
 
 // Extended form used by the geometric network's double backward (python/renderer.py:52 nn.grad):
@@ -85,12 +93,14 @@ extern "C" int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx
                                   float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                                   int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                                   const float* const* side_in2, const float* const* side_add, float* const* side_out2,
-                                  hipStream_t stream) {
+                                  float* workspace, hipStream_t stream) {
   if (mode < 0 || mode > 2) return NDJIR_ERR_ARG;
   return chain_impl(mode, P, X, ldx, K0, L, Wp, bias, Ks, Ns, side_in, side_out, ld_side, bgrad, Y, ldy, accum_y,
                     has_output, beta, skip_layer, skip_scale, skip_split, Xskip, ld_xskip, side_in2, side_add, side_out2,
-                    stream);
+                    workspace, stream);
 }
+
+extern "C" long long ndjir_mlp_chain_workspace(int bgrad_total) { return chain_workspace(bgrad_total); }
 
 extern "C" long long ndjir_mlp_wgrad_workspace(int K, int N, long long P) { return wgrad_workspace(K, N, P); }
 

@@ -14,7 +14,8 @@ struct ChainLayer {
   const float* side_add;// backward: extra adjoint added after the softplus' product
   float* side_out2;     // tangent: extra adjoint beta * z * s * exp(-beta h)
   float* side_out;      // forward: activation store (P x N); backward: delta store (P x N)
-  float* bgrad;         // backward: bias gradient accumulator (N), atomically accumulated
+  float* bgrad;         // backward: bias gradient (N): column sums of this layer's delta (overwritten)
+  int bg_off;           // filled by launch_chain: offset of this layer in the workgroup's LDS accumulator
   int K, N;             // logical dims of this GEMM (input width, output width)
   int Kp, Np;           // padded: Kp % 8 == 0, Np % 32 == 0
   int ld_side;
@@ -38,12 +39,16 @@ struct ChainArgs {
   int tile_rows;        // 64 (default) or 32 points per workgroup
   float skip_scale;
   float beta;
+  float* bg_partial;    // bias gradients: per-workgroup partial sums [grid][bg_total] (workspace)
+  int bg_total, bg_lds; // filled by launch_chain: accumulator floats / its offset in LDS
   long long* timeline;  // diagnostics (tools/chain_timeline.py): per-layer phase stamps of workgroup 0, else null
   ChainLayer layers[MAX_CHAIN_LAYERS];
 };
 
 int launch_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
 int launch_chain(const ChainArgs& a, int mode, hipStream_t stream);
+constexpr int CHAIN_MAX_GRID_BG = 512;   // workgroups of a chain launch that produces bias gradients
+inline long long chain_workspace(int bg_total) { return (long long)CHAIN_MAX_GRID_BG * bg_total; }
 long long wgrad_workspace(int K, int N, long long P);
 int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out, int accum,
                  float* workspace, hipStream_t stream);

@@ -102,6 +102,12 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
     if (a.timeline && blockIdx.x == 0 && lane == 0) a.timeline[(li * 5 + phase) * NWAVES + wave] = (long long)__builtin_amdgcn_s_memtime();
   };
 
+  // bias gradients: column sums of the deltas accumulate in LDS over all tiles of this workgroup and
+  // leave as one partial row per workgroup (device-scope float atomics on a few hundred addresses
+  // from every tile serialise in the memory-side cache: measured 4x on the 128-wide nets)
+  float* bsum = lds + a.bg_lds;
+  if (MODE != 0) for (int i = tid; i < a.bg_total; i += NTHREADS) bsum[i] = 0.f;
+
   for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long row0 = tile * TM;
     const int rows = (int)((a.P - row0) < TM ? (a.P - row0) : TM);
@@ -150,7 +156,7 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
       const float* const p_side_add = pin(ly.side_add);
       float* const p_side_out = pin(ly.side_out);
       float* const p_side_out2 = pin(ly.side_out2);
-      float* const p_bgrad = pin(ly.bgrad);
+      float* const p_bgrad = (MODE != 0 && ly.bgrad) ? bsum + pin(ly.bg_off) : nullptr;
       const int l_N = pin(ly.N);
       const int l_ld = pin(ly.ld_side);
       const bool is_skip = (li == a.skip_layer);
@@ -444,7 +450,7 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
             c += __shfl_xor(c, 8);
             c += __shfl_xor(c, 16);
             c += __shfl_xor(c, 32);
-            if (lane < 8 && n4 + q < nlim) atomicAdd(p_bgrad + n4 + q, c);
+            if (lane < 8 && n4 + q < nlim) atomicAdd(p_bgrad + n4 + q, c);   // LDS (row-split units share columns)
           }
         }
       };
@@ -474,6 +480,38 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
       stamp(li, 4);
       float* t = cur; cur = nxt; nxt = t;
     }
+  }
+  if (MODE != 0 && a.bg_total > 0) {
+    __syncthreads();
+    float* part = a.bg_partial + (long long)blockIdx.x * a.bg_total;
+    for (int i = tid; i < a.bg_total; i += NTHREADS) part[i] = bsum[i];
+  }
+}
+
+// bias gradients: out_l[n] = sum over workgroups of partial[g][off_l + n]
+struct BgOut {
+  float* ptr[MAX_CHAIN_LAYERS];
+  int off[MAX_CHAIN_LAYERS + 1];
+  int n;
+};
+__global__ void __launch_bounds__(256) k_bgrad_reduce(const float* __restrict__ partial, int S, int total, BgOut o) {
+  __shared__ float red[256];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + tx;
+  float acc = 0.f;
+  if (i < total) {
+#pragma unroll 8
+    for (int sidx = ty; sidx < S; sidx += 8) acc += partial[(long long)sidx * total + i];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (ty == 0 && i < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q * 32 + tx];
+    int l = 0;
+    while (l + 1 < o.n && i >= o.off[l + 1]) ++l;
+    o.ptr[l][i - o.off[l]] = t;
   }
 }
 
@@ -512,9 +550,26 @@ int launch_chain(const ChainArgs& a, int mode, hipStream_t stream) {
   b.lds_split = (int)(szA / 4);
   b.n_tiles = (a.P + TM - 1) / TM;   // TM defined above
   size_t lds_bytes = szA + szB;
+  BgOut bg{};
+  int bg_total = 0;
+  if (mode != 0) {
+    for (int i = 0; i < a.L; ++i) if (a.layers[i].bgrad && !(a.has_output && i == a.L - 1)) {
+      b.layers[i].bg_off = bg_total;
+      bg.ptr[bg.n] = a.layers[i].bgrad;
+      bg.off[bg.n] = bg_total;
+      ++bg.n;
+      bg_total += a.layers[i].N;
+    } else b.layers[i].bgrad = nullptr;
+    bg.off[bg.n] = bg_total;
+  }
+  b.bg_total = bg_total;
+  b.bg_lds = (int)(lds_bytes / 4);
+  lds_bytes += (size_t)bg_total * 4;
+  if (bg_total > 0 && !a.bg_partial) return NDJIR_ERR_ARG;
   if (lds_bytes > 160 * 1024) return NDJIR_ERR_UNSUPPORTED;
   long long blocks = b.n_tiles;
   if (blocks > 256LL * 8) blocks = 256LL * 8;
+  if (bg_total > 0 && blocks > CHAIN_MAX_GRID_BG) blocks = CHAIN_MAX_GRID_BG;
   static bool attr_set = false;
   if (!attr_set) {
 #define NDJIR_SET(M, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_chain<M, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
@@ -526,6 +581,8 @@ int launch_chain(const ChainArgs& a, int mode, hipStream_t stream) {
   if (TM == 64) { if (mode == 0) NDJIR_GO(0, 64); else if (mode == 1) NDJIR_GO(1, 64); else NDJIR_GO(2, 64); }
   else { if (mode == 0) NDJIR_GO(0, 32); else if (mode == 1) NDJIR_GO(1, 32); else NDJIR_GO(2, 32); }
 #undef NDJIR_GO
+  if (bg_total > 0)
+    hipLaunchKernelGGL(k_bgrad_reduce, dim3((bg_total + 31) / 32), dim3(256), 0, stream, a.bg_partial, (int)blocks, bg_total, bg);
   return ndjir_check_launch();
 }
 

@@ -25,7 +25,7 @@ from torch.autograd import Function
 
 from . import lib
 from .grid_feature import _core
-from .mlp import _launch, _packed, colsum, wgrad
+from .mlp import _launch, _packed, chain_workspace, colsum, wgrad
 
 _VOX = _core.FAMILIES["voxel"]
 
@@ -79,7 +79,7 @@ class GeometricMain(Function):
         y = torch.empty((P, Ns[-1]), device=dev, dtype=torch.float32)
         _launch("chain_fwd", _flops(P, Ks, Ns), "mlp_chain", 0, P, e, K0, K0, L, [_packed(w, False) for w in W],
                 [t.detach() for t in b], Ks, Ns, [None] * L, A[1:] + [None], [a.shape[1] for a in A[1:]] + [0],
-                [None] * L, y, Ns[-1], 0, 1, beta, skip_at, scale, 0, None, 0,
+                [None] * L, y, Ns[-1], 0, 1, beta, skip_at, scale, 0, None, 0, None,
                 shape=f"{P}:geo {K0}-" + "-".join(map(str, Ns)))
 
         # ---- sdf chain: backward chain seeded with d(sdf) = 1, first step = column 0 of the last layer ----
@@ -111,7 +111,7 @@ class GeometricMain(Function):
         g0 = torch.zeros((P, K0), device=dev, dtype=torch.float32)
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain", 1, P, ones, 1, 1, L, Wp, [None] * L, bK, bN, side_in,
                 side_out, ld, [None] * L, g0, K0, 1 if bskip >= 0 else 0, 1, beta, bskip, scale, split,
-                g0 if bskip >= 0 else None, K0, shape=f"{P}:sdf 1-" + "-".join(map(str, bN)))
+                g0 if bskip >= 0 else None, K0, None, shape=f"{P}:sdf 1-" + "-".join(map(str, bN)))
 
         # ---- n = J_e(x)^T g_0 ----
         gc = g0[:, 3:3 + 3 * M].reshape(P, 3, M)
@@ -191,12 +191,12 @@ class GeometricMain(Function):
                 side_out.append(gbar[l + 1])
                 side_out2.append(extras[l])
                 ld.append(wide)
-            col_last = torch.zeros((Ns[L - 2],), device=dev, dtype=torch.float32)
+            col_last = torch.empty((Ns[L - 2],), device=dev, dtype=torch.float32)
             bg[T - 1] = col_last
             _launch("chain_tan", _flops(P, Ks[:T], Ns[:T]), "mlp_chain_ex", 2, P, gb0, K0, K0, T,
                     [_packed(w, False) for w in W[:T]], [None] * T, Ks[:T], Ns[:T], side_in, side_out, ld, bg,
                     None, 0, 0, 0, beta, skip_at, scale, 0, None, 0, side_in2, [None] * T, side_out2,
-                    shape=f"{P}:tan {K0}-" + "-".join(map(str, Ns[:T])))
+                    chain_workspace(dev, bg), shape=f"{P}:tan {K0}-" + "-".join(map(str, Ns[:T])))
 
         # ---- backward chain with the extra adjoints ----
         need_x = has_grid
@@ -215,7 +215,7 @@ class GeometricMain(Function):
                 wide = A[j].shape[1]
                 dbuf = torch.empty((P, wide), device=dev, dtype=torch.float32)
                 deltas[below] = dbuf[:, :Ns[below]]
-                bgrads[below] = torch.zeros((Ns[below],), device=dev, dtype=torch.float32)
+                bgrads[below] = torch.empty((Ns[below],), device=dev, dtype=torch.float32)
                 side_in.append(A[j])
                 side_out.append(dbuf)
                 side_add.append(extras[below])
@@ -227,7 +227,7 @@ class GeometricMain(Function):
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain_ex", 1, P, gy, Ns[-1], Ns[-1], steps, Wp, [None] * steps, bK, bN,
                 side_in, side_out, ld, bg, gx, K0, 1 if (bskip >= 0 and need_x) else 0, 1 if need_x else 0, beta,
                 bskip, scale, split, gx if (bskip >= 0 and need_x) else None, K0, [None] * steps, side_add, [None] * steps,
-                shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
+                chain_workspace(dev, bg), shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
 
         if has_grid:
             lib.call("voxel_feature_grad_feature", P * D0, grid_grad, gx[:, npe:].contiguous(), xf, gs_shape, D0,

@@ -38,8 +38,8 @@ SIGS = {
     "zero": "pl",
     "mlp_pack": "ppiii",
     # bwd P X ldx K0 L Wp bias Ks Ns side_in side_out ld_side bgrad Y ldy accum has_out beta skip scale split Xskip ld
-    "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi",
-    "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP",
+    "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi" + "p",
+    "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP" + "p",
     "mlp_wgrad": "pipiiilpip",
     "mlp_colsum": "piilpip",
     "sampler_importance_round": "iiifpppppq",
@@ -97,6 +97,8 @@ def load():
         _lib.ndjir_mlp_packed_size.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.ndjir_mlp_wgrad_workspace.restype = ctypes.c_longlong
         _lib.ndjir_mlp_wgrad_workspace.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_longlong]
+        _lib.ndjir_mlp_chain_workspace.restype = ctypes.c_longlong
+        _lib.ndjir_mlp_chain_workspace.argtypes = [ctypes.c_int]
         _lib.ndjir_mlp_colsum_workspace.restype = ctypes.c_longlong
         _lib.ndjir_mlp_colsum_workspace.argtypes = [ctypes.c_int, ctypes.c_longlong]
     return _lib
@@ -175,6 +177,7 @@ def symbols():
     return ["ndjir_" + n for n in SIGS] + ["ndjir_version", "ndjir_hash_force_align", "ndjir_hash_grid_size",
                                             "ndjir_hash_table_size", "ndjir_hash_num_params",
                                             "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_colsum_workspace",
+                                            "ndjir_mlp_chain_workspace",
                                             "ndjir_mlp_debug_timeline"]
 
 

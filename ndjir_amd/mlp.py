@@ -51,6 +51,12 @@ def _packed(W, transpose):
     return dst
 
 
+def chain_workspace(device, bgrads):
+    """Workspace of a chain launch that produces the bias gradients `bgrads` (list, None entries ok)."""
+    total = sum(b.numel() for b in bgrads if b is not None)
+    return _workspace(device, lib.load().ndjir_mlp_chain_workspace(total)) if total else None
+
+
 def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, keep_hidden=False):
     """x (P, K0) contiguous.  Returns y (P, N_last) and the list of stored activations
     A_1..A_{L-1} (inputs of layers 1..L-1) when keep_hidden."""
@@ -72,7 +78,7 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
     flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
     _launch("chain_fwd", flops, "mlp_chain", 0, P, x, x.shape[1], K0, L, Wp, [b.detach() if b is not None else None for b in biases],
              Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
-             int(skip_layer), float(skip_scale), 0, None, 0, shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
+             int(skip_layer), float(skip_scale), 0, None, 0, None, shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
     return y, hidden
 
 
@@ -175,7 +181,7 @@ class FusedMLP(Function):
                     below = j - 1                       # layer whose delta this step produces
                     width = W[below].shape[1]
                     deltas[below] = torch.empty((P, width), device=x2.device, dtype=torch.float32)
-                    bgrads[below] = torch.zeros((width,), device=x2.device, dtype=torch.float32)
+                    bgrads[below] = torch.empty((width,), device=x2.device, dtype=torch.float32)
                     side_in.append(A[j])
                     side_out.append(deltas[below])
                     ld_side.append(A[j].shape[1])
@@ -203,7 +209,8 @@ class FusedMLP(Function):
             _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
                      side_in, side_out, ld_side, bg, gx, K0, 1 if bwd_skip >= 0 else 0, 1 if need_x else 0,
                      float(beta), int(bwd_skip), float(skip_scale), int(split),
-                     gx if bwd_skip >= 0 else None, K0, shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)))
+                     gx if bwd_skip >= 0 else None, K0, chain_workspace(x2.device, bg),
+                     shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)))
         gW = [None] * L
         gb = [None] * L
         if need_w:

@@ -55,19 +55,19 @@ def main():
         so.ndjir_mlp_debug_timeline(None)
         show(buf, 8, "geometric net forward chain (43-256-256-256-213|+43-256-256-256-257), tile of 64 points")
     else:
-        dims2 = (259, 256, 256, 256, 3)
+        dims2 = (259, 256, 256, 256, 3) if mode == "bwd" else (39, 128, 128, 128, 1)
         W2, b2 = make(dims2, 2)
-        xg = torch.randn(P, 259, device="cuda").requires_grad_(True)
+        xg = torch.randn(P, dims2[0], device="cuda").requires_grad_(mode == "bwd")
         Wg = [w.clone().requires_grad_(True) for w in W2]
         bg = [b.clone().requires_grad_(True) for b in b2]
         y = fused_mlp(xg, Wg, bg)
         gy = torch.randn_like(y)
         torch.cuda.synchronize()
         so.ndjir_mlp_debug_timeline(buf.data_ptr())
-        torch.autograd.grad(y, [xg] + Wg + bg, gy)
+        torch.autograd.grad(y, ([xg] if mode == "bwd" else []) + Wg + bg, gy)
         torch.cuda.synchronize()
         so.ndjir_mlp_debug_timeline(None)
-        show(buf, 4, "base-colour net backward chain (3-256-256-256-259)")
+        show(buf, 4 if mode == "bwd" else 3, f"backward chain of net {dims2}")
 
 
 if __name__ == "__main__":
