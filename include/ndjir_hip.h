@@ -200,11 +200,14 @@ int ndjir_squareplus_backward(int size, float* dinput, const float* doutput, con
  * alpha, transmittance weights, normalisation, inverse-transform sampling at the deterministic
  * u_m = m / (M - 1 + 1/M), clip to [t_near, t_far], merge-sort.  t, sdf: (R, N); t_near, t_far: (R);
  * t_out: (R, N + M) sorted; idx_out: (R, M) int32 bin indices.  N + M <= 128, M <= 32.
+ * Optional (may be null): src_out (R, N + M) int32 = for every merged position the slot it came
+ * from (i < N: old sample i; N + m: new sample m) and tnew_out (R, M) the new distances, so that a
+ * caller can evaluate the SDF at the M new samples only and merge it into the values it already has.
  * exp and the scan / reduction orders are DEFINED in include/ndjir_math.h, so the integer indices
  * are reproducible bit for bit on the host (oracle) and the device. */
 int ndjir_sampler_importance_round(int R, int N, int M, float gain, const float* t, const float* sdf,
                                    const float* t_near, const float* t_far, float* t_out, int* idx_out,
-                                   hipStream_t stream);
+                                   int* src_out, float* tnew_out, hipStream_t stream);
 
 /* ---- fused MLP engine ------------------------------------------------------------------------------
  * Replaces the reference's per-layer nnabla launches (PF.affine -> cuBLAS GEMM, F.softplus(beta=100),

@@ -39,8 +39,10 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
   if (!X || L < 1 || L > MAX_CHAIN_LAYERS || !Wp || !Ks || !Ns) return NDJIR_ERR_ARG;
   if (has_output && !Y) return NDJIR_ERR_ARG;
   ChainArgs a{};
-  static const int tile_rows = [] { const char* e = getenv("NDJIR_MLP_TILE"); return e ? atoi(e) : 64; }();
-  a.tile_rows = tile_rows;
+  // 64-point tiles; 32-point tiles when 64 would leave CUs without a tile (small launches such as the
+  // sampler's 16-samples-per-ray rounds).  Results do not depend on the tile height.  NDJIR_MLP_TILE forces one.
+  static const int tile_env = [] { const char* e = getenv("NDJIR_MLP_TILE"); return e ? atoi(e) : 0; }();
+  a.tile_rows = tile_env ? tile_env : ((P + 63) / 64 < 256 ? 32 : 64);
   a.timeline = g_timeline;
   a.bg_partial = workspace;
   a.P = P; a.X = X; a.ldx = ldx; a.K0 = K0; a.K0p = round_up(K0, 8); a.L = L;

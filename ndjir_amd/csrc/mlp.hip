@@ -165,9 +165,11 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
 
       if (NB == 1) {
         // ---- narrow output (N <= 32): split K over 4 wave groups, reduce through LDS ----
-        constexpr int KS = NWAVES / RB;          // K slices
+        // KS is the same for both tile heights (the summation order, hence the bits of the result, must
+        // not depend on how many points a launch has); with 32-row tiles waves 4..7 only join the barriers
+        constexpr int KS = 4;                    // K slices
         const int rb = wave % RB, ks = wave / RB;
-        const int kb0 = (KB * ks) / KS, kb1 = (KB * (ks + 1)) / KS;
+        const int kb0 = ks < KS ? (KB * ks) / KS : 0, kb1 = ks < KS ? (KB * (ks + 1)) / KS : 0;
         f32x16 acc = {0};
         const f32x4* Bp = reinterpret_cast<const f32x4*>(ly.Wp) + lane;
         for (int kb = kb0; kb < kb1; ++kb) {
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
         }
         // partials: nxt[ks][m][n] (KS x TM x 32 floats = 32 KiB)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) nxt[(ks * TM + rb * 32 + acc_row(i, h)) * 32 + r] = acc[i];
+        for (int i = 0; i < 16; ++i) if (ks < KS) nxt[(ks * TM + rb * 32 + acc_row(i, h)) * 32 + r] = acc[i];
         __syncthreads();
         for (int t = tid; t < TM * 32; t += NTHREADS) {
           int n = t & 31, m = t >> 5;

@@ -18,7 +18,8 @@ constexpr int RAYS_PER_BLOCK = 4;
 
 __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK) k_importance_round(
     int R, int N, int M, float gain, float udenom, const float* __restrict__ t_in, const float* __restrict__ sdf_in,
-    const float* __restrict__ t_near, const float* __restrict__ t_far, float* __restrict__ t_out, int* __restrict__ idx_out) {
+    const float* __restrict__ t_near, const float* __restrict__ t_far, float* __restrict__ t_out, int* __restrict__ idx_out,
+    int* __restrict__ src_out, float* __restrict__ tnew_out) {
   __shared__ float s_t[RAYS_PER_BLOCK][SLOTS], s_a[RAYS_PER_BLOCK][SLOTS], s_b[RAYS_PER_BLOCK][SLOTS],
       s_w[RAYS_PER_BLOCK][SLOTS], s_c[RAYS_PER_BLOCK][SLOTS], s_new[RAYS_PER_BLOCK][32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -115,12 +116,16 @@ __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK) k_importance_round(
     float tv = T[idx] + step * ratio;
     tv = fmaxf(fminf(tv, tf), tn);
     TN[lane] = tv;
-    if (live) idx_out[(long long)ray * M + lane] = idx;
+    if (live) {
+      idx_out[(long long)ray * M + lane] = idx;
+      if (tnew_out) tnew_out[(long long)ray * M + lane] = tv;
+    }
   }
   __syncthreads();
   // merge the two sorted lists by rank
   if (live) {
     float* out = t_out + (long long)ray * (N + M);
+    int* src = src_out ? src_out + (long long)ray * (N + M) : nullptr;   // merged position -> source slot
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       int i = lane + 64 * h;
@@ -129,6 +134,7 @@ __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK) k_importance_round(
         int r = i;
         for (int m = 0; m < M; ++m) r += (TN[m] < v) ? 1 : 0;
         out[r] = v;
+        if (src) src[r] = i;
       }
     }
     if (lane < M) {
@@ -136,18 +142,20 @@ __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK) k_importance_round(
       int r = lane;
       for (int i = 0; i < N; ++i) r += (T[i] <= v) ? 1 : 0;
       out[r] = v;
+      if (src) src[r] = N + lane;
     }
   }
 }
 
 int launch_importance_round(int R, int N, int M, float gain, const float* t, const float* sdf, const float* t_near,
-                            const float* t_far, float* t_out, int* idx_out, hipStream_t stream) {
+                            const float* t_far, float* t_out, int* idx_out, int* src_out, float* tnew_out,
+                            hipStream_t stream) {
   if (R <= 0) return NDJIR_OK;
   if (N < 2 || M < 1 || M > 32 || N + M > SLOTS) return NDJIR_ERR_UNSUPPORTED;
   float udenom = (float)(M - 1 + 1.0 / M);
   int blocks = (R + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK;
   hipLaunchKernelGGL(k_importance_round, dim3(blocks), dim3(64 * RAYS_PER_BLOCK), 0, stream, R, N, M, gain, udenom, t, sdf,
-                     t_near, t_far, t_out, idx_out);
+                     t_near, t_far, t_out, idx_out, src_out, tnew_out);
   return ndjir_check_launch();
 }
 
@@ -155,7 +163,7 @@ int launch_importance_round(int R, int N, int M, float gain, const float* t, con
 
 extern "C" int ndjir_sampler_importance_round(int R, int N, int M, float gain, const float* t, const float* sdf,
                                               const float* t_near, const float* t_far, float* t_out, int* idx_out,
-                                              hipStream_t stream) {
+                                              int* src_out, float* tnew_out, hipStream_t stream) {
   if (R > 0 && (!t || !sdf || !t_near || !t_far || !t_out || !idx_out)) return NDJIR_ERR_ARG;
-  return ndjir::launch_importance_round(R, N, M, gain, t, sdf, t_near, t_far, t_out, idx_out, stream);
+  return ndjir::launch_importance_round(R, N, M, gain, t, sdf, t_near, t_far, t_out, idx_out, src_out, tnew_out, stream);
 }

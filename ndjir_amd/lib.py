@@ -42,7 +42,7 @@ SIGS = {
     "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP" + "p",
     "mlp_wgrad": "pipiiilpip",
     "mlp_colsum": "piilpip",
-    "sampler_importance_round": "iiifpppppq",
+    "sampler_importance_round": "iiifpppppqqp",
     "ray_aabb_intersection": "ipppppiiFF",
     "ray_sphere_intersection": "ipppppiif",
     "inverse_transform_sample_uniform_directions": "ippppiiiif",
@@ -144,7 +144,10 @@ def call(name, *args):
                     raise NdjirHipError(f"ndjir_{name}: tensors must be contiguous float32 on the GPU "
                                         f"(got {v.dtype}, {v.device}, contiguous={v.is_contiguous()})")
                 cargs.append(v.data_ptr())
-        elif c == "q":     # int32 device tensor
+        elif c == "q":     # int32 device tensor (None = null)
+            if v is None:
+                cargs.append(None)
+                continue
             if not (v.is_cuda and v.dtype == torch.int32 and v.is_contiguous()):
                 raise NdjirHipError(f"ndjir_{name}: expected a contiguous int32 GPU tensor")
             cargs.append(v.data_ptr())

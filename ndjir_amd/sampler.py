@@ -70,14 +70,19 @@ class SamplePoints:
         i = torch.arange(0, N, dtype=tn.dtype, device=tn.device).reshape(1, 1, N, 1)
         return tn + step * (i + stratified_sample)
 
-    def importance_round(self, t, sdf, t_near, t_far, gain, M):
+    def importance_round(self, t, sdf, t_near, t_far, gain, M, with_source=False):
         """One up-sampling round (sampler.py:194-240) given the SDF at the current samples: one HIP
-        launch (csrc/sampler.hip), one wave per ray, scan orders fixed by include/ndjir_math.h."""
+        launch (csrc/sampler.hip), one wave per ray, scan orders fixed by include/ndjir_math.h.
+        with_source: also return the M new distances and, per merged position, the slot it came from."""
         B, R, N, _ = t.shape
         t_out = torch.empty((B, R, N + M, 1), device=t.device, dtype=torch.float32)
         idx = torch.empty((B, R, M), device=t.device, dtype=torch.int32)
+        src = torch.empty((B, R, N + M), device=t.device, dtype=torch.int32) if with_source else None
+        t_new = torch.empty((B, R, M, 1), device=t.device, dtype=torch.float32) if with_source else None
         lib.call("sampler_importance_round", B * R, N, M, float(gain), t.contiguous(), sdf.contiguous(),
-                 t_near.expand(B, R, 1, 1).contiguous(), t_far.expand(B, R, 1, 1).contiguous(), t_out, idx)
+                 t_near.expand(B, R, 1, 1).contiguous(), t_far.expand(B, R, 1, 1).contiguous(), t_out, idx, src, t_new)
+        if with_source:
+            return t_out, idx.long(), src, t_new
         return t_out, idx.long()
 
     def importance_round_stock(self, t, sdf, t_near, t_far, gain, M):
@@ -123,12 +128,20 @@ class SamplePoints:
         c = camloc.reshape(B, 1, 1, 3)
         d = raydir.reshape(B, R, 1, 3)
         tn, tf = t_near.reshape(B, R, 1, 1), t_far.reshape(B, R, 1, 1)
+        # The reference re-evaluates the SDF at ALL current samples in every round (sampler.py:192-193).
+        # Old samples keep their positions (x = c + t d, same t) and the network is row-independent and
+        # deterministic, so their values cannot change: evaluate only the M samples the previous round
+        # added and merge them by the round kernel's source map.  Bit-identical, ~4x fewer points.
+        sdf, src, t_new = None, None, None
         for u in range(U):
-            x = c + t * d
-            sdf, _, _ = geometric_network(x, self.conf, first_order_only=True, sdf_only=True)
+            if sdf is None:
+                sdf, _, _ = geometric_network(c + t * d, self.conf, first_order_only=True, sdf_only=True)
+            else:
+                sdf_new, _, _ = geometric_network(c + t_new * d, self.conf, first_order_only=True, sdf_only=True)
+                sdf = torch.gather(torch.cat([sdf, sdf_new], dim=2), 2, src.long().unsqueeze(-1))
             gain = self.conf.renderer.sampling_sigmoid_gain * 2 ** u
             t_in = t
-            t, idx = self.importance_round(t, sdf, tn, tf, gain, M)
+            t, idx, src, t_new = self.importance_round(t, sdf, tn, tf, gain, M, with_source=True)
             if self.record is not None:
                 self.record.setdefault("t_in", []).append(t_in.clone())
                 self.record.setdefault("sdf", []).append(sdf.clone())

@@ -44,11 +44,48 @@ def test_importance_round_bit_exact(gpu, N, u, kind, R):
     d = lambda a: torch.from_numpy(a).to(gpu)
     t_out = torch.empty((R, N + M), device=gpu)
     idx = torch.empty((R, M), device=gpu, dtype=torch.int32)
-    lib.call("sampler_importance_round", R, N, M, gain, d(t), d(sdf), d(tn), d(tf), t_out, idx)
+    src = torch.empty((R, N + M), device=gpu, dtype=torch.int32)
+    t_new = torch.empty((R, M), device=gpu)
+    lib.call("sampler_importance_round", R, N, M, gain, d(t), d(sdf), d(tn), d(tf), t_out, idx, src, t_new)
+    # the optional source map reproduces the merge: gathering [old, new] by it gives the merged list
+    both = torch.cat([d(t).reshape(R, N), t_new], dim=1)
+    assert torch.equal(torch.gather(both, 1, src.long()), t_out)
+    assert torch.equal(torch.sort(src, dim=1).values, torch.arange(N + M, device=gpu, dtype=torch.int32).expand(R, -1))
+    t_out2 = torch.empty_like(t_out)
+    lib.call("sampler_importance_round", R, N, M, gain, d(t), d(sdf), d(tn), d(tf), t_out2, idx, None, None)
+    assert torch.equal(t_out2, t_out)
     assert np.array_equal(idx.cpu().numpy(), i_ref), "sample indices must be bit-exact"
     assert np.array_equal(t_out.cpu().numpy().view(np.uint32), t_ref.view(np.uint32)), "merged distances bit-exact"
     assert (np.diff(t_ref, axis=1) >= 0).all()
     assert (i_ref >= 0).all() and (i_ref <= N - 1).all()
+
+
+def test_incremental_sdf_matches_full_reevaluation(gpu):
+    """SamplePoints evaluates the SDF only at the samples a round added; the reference re-evaluates all
+    samples every round (sampler.py:192-193).  Both must give bit-identical distances."""
+    from ndjir_amd import parameter as P, network
+    from ndjir_amd.network import geometric_network
+    from ndjir_amd.sampler import SamplePoints
+    from tests.parity_utils import small_conf
+    from ndjir_amd.synthetic import make_rays
+    from ndjir_amd.renderer import make_rand
+    conf = small_conf(grid_size=32, n_rays=96)
+    P.clear_parameters(); P.set_device(gpu); network.seed(7)
+    camloc, raydir, _ = make_rays(1, 96, seed=3, device=gpu)
+    rand = make_rand(1, 96, conf, gpu)
+    sp = SamplePoints(conf)
+    with torch.no_grad():
+        x_fg, t_fg, *_ = sp(camloc, raydir, rand["stratified_sample"], rand["background_sample"])
+        # full re-evaluation, as the reference does
+        B, R = 1, 96
+        t_near, t_far, _ = sp.t_near_far(camloc, raydir)
+        t = sp.sample_stratified_dists(t_near, t_far, rand["stratified_sample"])
+        c, dd = camloc.reshape(B, 1, 1, 3), raydir.reshape(B, R, 1, 3)
+        tn, tf = t_near.reshape(B, R, 1, 1), t_far.reshape(B, R, 1, 1)
+        for u in range(conf.renderer.n_upsamples):
+            sdf, _, _ = geometric_network(c + t * dd, conf, first_order_only=True, sdf_only=True)
+            t, _ = sp.importance_round(t, sdf, tn, tf, conf.renderer.sampling_sigmoid_gain * 2 ** u, conf.renderer.n_samples1)
+    assert torch.equal(t_fg[:, :, :-1, :], t)
 
 
 def test_sampler_end_to_end_indices(gpu):
