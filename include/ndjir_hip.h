@@ -209,6 +209,30 @@ int ndjir_sampler_importance_round(int R, int N, int M, float gain, const float*
                                    const float* t_near, const float* t_far, float* t_out, int* idx_out,
                                    int* src_out, float* tnew_out, hipStream_t stream);
 
+/* ---- volume-rendering stage (ndjir_amd/csrc/render.hip) ----------------------------------------------
+ * python/renderer.py:55-67 (foreground alpha from sdf, n = d sdf/dx and the ray direction, with the
+ * cos-anneal blend), :79-87 (alpha = [alpha_fg * mask, alpha_bg]; transmittance = exclusive cumprod of
+ * 1 - alpha; weights = alpha * transmittance) as ONE launch, and its backward as one launch
+ * (reverse scan without division; the reference relies on nnabla's per-function backward).
+ * Rays r < R; sdf (R,N); n (R,N,3); raydir (R,3); t (R,N+1); gain, cos_anneal_ratio: 1-element device
+ * arrays; mask (R); alpha_bg (R,Nb); alpha_fg (R,N); trans, weights (R,N+Nb).  N + Nb <= 256.
+ * Backward: g_alpha_fg (R,N) / g_trans / g_weights (R,N+Nb) may be null (= 0); writes g_sdf (R,N),
+ * g_n (R,N,3), g_gain_ray (R) (per-ray partials of dL/dgain; sum them) and, if non-null, g_alpha_bg. */
+int ndjir_render_alpha_weights(int R, int N, int Nb, const float* sdf, const float* n, const float* raydir,
+                               const float* t, const float* gain, const float* cos_anneal_ratio, const float* mask,
+                               const float* alpha_bg, float* alpha_fg, float* trans, float* weights, hipStream_t stream);
+int ndjir_render_alpha_weights_backward(int R, int N, int Nb, const float* sdf, const float* n, const float* raydir,
+                                        const float* t, const float* gain, const float* cos_anneal_ratio,
+                                        const float* mask, const float* alpha_bg, const float* trans,
+                                        const float* g_alpha_fg, const float* g_trans, const float* g_weights,
+                                        float* g_sdf, float* g_n, float* g_gain_ray, float* g_alpha_bg,
+                                        hipStream_t stream);
+/* VR integral (renderer.py:84-87): out (R,C) = sum_i w[r][i] x[r][i][c], w rows of stride ldw >= S,
+ * x (R,S,C).  Backward: gx (R,S,C) = w g, gw[r][i] (row stride ldgw) = sum_c x g; either may be null. */
+int ndjir_render_integrate(int R, int S, int C, const float* w, int ldw, const float* x, float* out, hipStream_t stream);
+int ndjir_render_integrate_backward(int R, int S, int C, const float* w, int ldw, const float* x, const float* g,
+                                    float* gx, float* gw, int ldgw, hipStream_t stream);
+
 /* ---- fused MLP engine ------------------------------------------------------------------------------
  * Replaces the reference's per-layer nnabla launches (PF.affine -> cuBLAS GEMM, F.softplus(beta=100),
  * python/network.py:88-93,165 and every network function :154-561) by ONE launch per net and

@@ -42,6 +42,10 @@ SIGS = {
     "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP" + "p",
     "mlp_wgrad": "pipiiilpip",
     "mlp_colsum": "piilpip",
+    "render_alpha_weights": "iii" + "p" * 11,
+    "render_alpha_weights_backward": "iii" + "p" * 16,
+    "render_integrate": "iiipipp",
+    "render_integrate_backward": "iiipippppi",
     "sampler_importance_round": "iiifpppppqqp",
     "ray_aabb_intersection": "ipppppiiFF",
     "ray_sphere_intersection": "ipppppiif",

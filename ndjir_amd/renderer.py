@@ -21,6 +21,7 @@ from .network import (background_network, base_color_network, environment_light_
                       soft_visibility_light_network, specular_reflectance_network)
 from .sampler import sample_importance_directions, sample_points, sample_uniform_directions
 from .specular_brdf import dot, specular_brdf_model
+from .volume import alpha_weights, integrate
 
 
 def make_rand(B, R, conf, device, n_fg=None, include_samples=True):
@@ -58,18 +59,6 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     # Geometric network and its spatial gradient (nn.grad, renderer.py:51-52)
     sdf_x_fg, feature_x_fg, gain, grad_x_fg = geometric_network_with_grad(x_fg, conf)
 
-    # Foreground alpha (renderer.py:55-67)
-    car = cos_anneal_ratio.reshape((1,) * x_fg.dim())
-    true_cos = (raydir * grad_x_fg).sum(-1, keepdim=True)
-    iter_cos = -(torch.relu(-true_cos * 0.5 + 0.5) * (1.0 - car) + torch.relu(-true_cos) * car)
-    delta_t_fg = t_fg[:, :, 1:, :] - t_fg[:, :, :-1, :]
-    sdf1 = sdf_x_fg + iter_cos * delta_t_fg * 0.5
-    sdf0 = sdf_x_fg - iter_cos * delta_t_fg * 0.5
-    gain = gain.reshape((1,) * sdf_x_fg.dim())
-    cdf0 = torch.sigmoid(gain * sdf0)
-    cdf1 = torch.sigmoid(gain * sdf1)
-    alpha_fg = ((cdf0 - cdf1 + 1e-5) / (cdf0 + 1e-5)).clamp(0.0, 1.0)
-
     # Background alpha (renderer.py:70-76)
     if conf.background_modeling:
         delta_bg = (t_bg[:, :, 1:, :] - t_bg[:, :, :-1, :]).detach()
@@ -78,15 +67,15 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
         alpha_bg = torch.ones(B, R, 1, 1, dtype=x_fg.dtype, device=x_fg.device)
         color_bg = torch.full((B, R, 1, 3), conf.background_color, dtype=x_fg.dtype, device=x_fg.device)
 
-    # Weights (renderer.py:79-87)
-    alpha = torch.cat([alpha_fg * mask, alpha_bg], dim=2)
-    one_m = 1 - alpha
-    trans = torch.cat([torch.ones_like(one_m[:, :, :1]), torch.cumprod(one_m, dim=2)[:, :, :-1]], dim=2)
-    weights = alpha * trans
-    trans_fg, weights_fg, weights_bg = trans[:, :, :N, :], weights[:, :, :N, :], weights[:, :, N:, :]
+    # Foreground alpha, transmittance and weights (renderer.py:55-67, 79-87): one fused launch
+    # (csrc/render.hip) instead of ~25 elementwise functions and an exclusive cumprod
+    alpha_fg, trans, weights = alpha_weights(sdf_x_fg, grad_x_fg, raydir.reshape(B, R, 3), t_fg, gain, cos_anneal_ratio,
+                                             mask, alpha_bg)
+    trans_fg = trans[:, :, :N, :]
 
-    def VR(x, weights=weights_fg, axis=2):
-        return (weights * x).sum(dim=axis)
+    def VR(x, off=0):
+        """sum_i weights_i x_i over the foreground (off=0) or background (off=N) samples"""
+        return integrate(weights, x, off)
 
     # Normal (renderer.py:90-91)
     grad_pixel = VR(grad_x_fg) + eps_normal
@@ -149,7 +138,7 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     else:
         color_fg_pixel = VR(base_color) + spec_pixel
 
-    color_pixel = color_fg_pixel + VR(color_bg, weights_bg)
+    color_pixel = color_fg_pixel + VR(color_bg, N)
 
     obj_mask_pred = torch.zeros((), dtype=x_fg.dtype, device=x_fg.device)
     if conf.train.mask_weight > 0.0:

@@ -1,0 +1,94 @@
+"""Volume-rendering stage of pb_render as fused HIP operators (ndjir_amd/csrc/render.hip).
+
+Reference: python/renderer.py:55-67 (foreground alpha), :79-87 (transmittance, weights, the `VR`
+integrals).  `alpha_weights` and `integrate` are drop-ins for those lines with hand-derived
+backward kernels; tests/test_gpu_render.py checks both against the stock-op composite (autograd).
+"""
+import torch
+from torch.autograd import Function
+
+from . import lib
+from .mlp import _Strided
+
+
+
+def _c(t):
+    return t.detach().contiguous()
+
+
+class AlphaWeights(Function):
+    """sdf (B,R,N,1), n = d sdf/dx (B,R,N,3), raydir (B,R,3), t_fg (B,R,N+1,1), gain (1,),
+    cos_anneal_ratio (1,), mask (B,R,1,1), alpha_bg (B,R,Nb,1)
+    -> alpha_fg (B,R,N,1), trans (B,R,N+Nb,1), weights (B,R,N+Nb,1)."""
+
+    @staticmethod
+    def forward(ctx, sdf, n, raydir, t_fg, gain, car, mask, alpha_bg):
+        B, R, N, _ = sdf.shape
+        Nb = alpha_bg.shape[2]
+        dev = sdf.device
+        args = [_c(sdf), _c(n), _c(raydir), _c(t_fg), _c(gain), _c(car), _c(mask), _c(alpha_bg)]
+        alpha_fg = torch.empty((B, R, N, 1), device=dev, dtype=torch.float32)
+        trans = torch.empty((B, R, N + Nb, 1), device=dev, dtype=torch.float32)
+        weights = torch.empty((B, R, N + Nb, 1), device=dev, dtype=torch.float32)
+        lib.call("render_alpha_weights", B * R, N, Nb, *args, alpha_fg, trans, weights)
+        ctx.save_for_backward(*args, trans)
+        ctx.dims = (B, R, N, Nb)
+        return alpha_fg, trans, weights
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_alpha, g_trans, g_weights):
+        B, R, N, Nb = ctx.dims
+        sdf, n, raydir, t_fg, gain, car, mask, alpha_bg, trans = ctx.saved_tensors
+        dev = sdf.device
+        g_sdf = torch.empty((B, R, N, 1), device=dev, dtype=torch.float32)
+        g_n = torch.empty((B, R, N, 3), device=dev, dtype=torch.float32)
+        g_gain_ray = torch.empty((B * R,), device=dev, dtype=torch.float32)
+        g_bg = torch.empty((B, R, Nb, 1), device=dev, dtype=torch.float32) if ctx.needs_input_grad[7] else None
+        opt = lambda g: None if g is None else g.contiguous()
+        lib.call("render_alpha_weights_backward", B * R, N, Nb, sdf, n, raydir, t_fg, gain, car, mask, alpha_bg, trans,
+                 opt(g_alpha), opt(g_trans), opt(g_weights), g_sdf, g_n, g_gain_ray, g_bg)
+        g_gain = g_gain_ray.sum().reshape(gain.shape) if ctx.needs_input_grad[4] else None
+        return g_sdf, g_n, None, None, g_gain, None, None, g_bg
+
+
+def alpha_weights(sdf, n, raydir, t_fg, gain, cos_anneal_ratio, mask, alpha_bg):
+    return AlphaWeights.apply(sdf, n, raydir, t_fg, gain.reshape(-1), cos_anneal_ratio.reshape(-1), mask, alpha_bg)
+
+
+class Integrate(Function):
+    """VR (renderer.py:84-87): out (B,R,C) = sum_i weights[:, :, off+i] x[:, :, i, :] for the S
+    samples of x (B,R,S,C); `weights` is the full (B,R,S_all,1) tensor, `off` selects the
+    foreground (0) or background (N) part without a copy."""
+
+    @staticmethod
+    def forward(ctx, weights, off, x):
+        B, R, S, C = x.shape
+        S_all = weights.shape[2]
+        w = _c(weights)
+        xc = _c(x)
+        out = torch.empty((B, R, C), device=x.device, dtype=torch.float32)
+        lib.call("render_integrate", B * R, S, C, _Strided(w.view(B * R, S_all)[:, off:]), S_all, xc, out)
+        ctx.save_for_backward(w, xc)
+        ctx.off = off
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        w, x = ctx.saved_tensors
+        B, R, S, C = x.shape
+        S_all = w.shape[2]
+        off = ctx.off
+        need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
+        gx = torch.empty_like(x) if need_x else None
+        gw = None
+        if need_w:
+            gw = torch.zeros_like(w) if S != S_all else torch.empty_like(w)
+        lib.call("render_integrate_backward", B * R, S, C, _Strided(w.view(B * R, S_all)[:, off:]), S_all, x, g.contiguous(),
+                 gx, _Strided(gw.view(B * R, S_all)[:, off:]) if need_w else None, S_all)
+        return gw, None, gx
+
+
+def integrate(weights, x, off=0):
+    return Integrate.apply(weights, off, x)

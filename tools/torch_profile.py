@@ -30,6 +30,9 @@ def main():
     tot = sum(e.self_device_time_total for e in evs)
     print(f"self device time total {tot / n / 1e3:.2f} ms/step")
     print(f"{'op':40s} {'calls/step':>10s} {'ms/step':>8s}  shapes")
+    if os.environ.get("ATEN_ONLY"):
+        evs = [e for e in evs if e.key.startswith("aten::")]
+        print(f"aten ops only: {sum(e.self_device_time_total for e in evs) / n / 1e3:.2f} ms/step")
     for e in evs[:rows]:
         print(f"{e.key[:40]:40s} {e.count / n:10.1f} {e.self_device_time_total / n / 1e3:8.3f}  {str(e.input_shapes)[:110]}")
 
