@@ -255,6 +255,11 @@ int ndjir_render_integrate_backward(int R, int S, int C, const float* w, int ldw
  * skip_layer (-1 = none): forward, the output of that layer is scaled by skip_scale and the scaled
  * chain input is appended (python/network.py:221-224); backward, the step whose output is the
  * gradient of that concatenation: columns >= skip_split go (scaled) to Xskip. */
+#define NDJIR_MATH_FP32 0     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 vector rate */
+#define NDJIR_MATH_BF16X6 1   /* x = hi + mid + lo in bf16 (exact), six bf16 MFMA partial products accumulated in
+                                 fp32: ~2^-24 relative error like an fp32 FMA chain, 6/16 of the matrix time (default) */
+int ndjir_mlp_set_math(int math);   /* selects the arithmetic of pack / chain; packed weights are mode specific */
+int ndjir_mlp_get_math(void);
 long long ndjir_mlp_packed_size(int K, int N, int transpose);
 int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
 int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L,

@@ -10,13 +10,29 @@ using namespace ndjir;
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Matrix arithmetic of the chain engine: NDJIR_MATH_FP32 = v_mfma_f32_32x32x2_f32 (mlp.hip),
+// NDJIR_MATH_BF16X6 = three-way bf16 split, six v_mfma_f32_32x32x16_bf16 partial products (mlp6.hip):
+// the same ~2^-24 accuracy at 6/16 of the matrix time.  Packed weights are specific to the mode that
+// was active when they were packed.
+static int g_math = NDJIR_MATH_BF16X6;
+
+extern "C" int ndjir_mlp_set_math(int math) {
+  if (math != NDJIR_MATH_FP32 && math != NDJIR_MATH_BF16X6) return NDJIR_ERR_ARG;
+  g_math = math;
+  return NDJIR_OK;
+}
+
+extern "C" int ndjir_mlp_get_math(void) { return g_math; }
+
 extern "C" long long ndjir_mlp_packed_size(int K, int N, int transpose) {
+  if (g_math == NDJIR_MATH_BF16X6) return packed_size6(K, N, transpose);
   int Kp = round_up(transpose ? N : K, 8), Np = round_up(transpose ? K : N, 32);
   return (long long)Kp * Np;
 }
 
 extern "C" int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream) {
   if (!W || !dst || K <= 0 || N <= 0) return NDJIR_ERR_ARG;
+  if (g_math == NDJIR_MATH_BF16X6) return launch_pack6(W, dst, K, N, transpose, stream);
   return launch_pack(W, dst, K, N, transpose, stream);
 }
 
@@ -72,6 +88,7 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
     if (bwd != 1 && i == skip_layer) kin = ly.N + K0;
     if (bwd == 1 && i == skip_layer) kin = skip_split;
   }
+  if (g_math == NDJIR_MATH_BF16X6) return launch_chain6(a, bwd, stream);
   return launch_chain(a, bwd, stream);
 }
 

@@ -47,6 +47,11 @@ struct ChainArgs {
 
 int launch_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
 int launch_chain(const ChainArgs& a, int mode, hipStream_t stream);
+int launch_bgrad_reduce(const float* partial, int S, int total, float* const* ptr, const int* off, int n, hipStream_t stream);
+// bf16 3-way-split engine (mlp6.hip): same ChainArgs, weights packed by launch_pack6
+long long packed_size6(int K, int N, int transpose);   // in floats (for allocation through the same API)
+int launch_pack6(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
+int launch_chain6(const ChainArgs& a, int mode, hipStream_t stream);
 constexpr int CHAIN_MAX_GRID_BG = 512;   // workgroups of a chain launch that produces bias gradients
 inline long long chain_workspace(int bg_total) { return (long long)CHAIN_MAX_GRID_BG * bg_total; }
 long long wgrad_workspace(int K, int N, long long P);

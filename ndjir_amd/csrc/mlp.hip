@@ -517,6 +517,15 @@ __global__ void __launch_bounds__(256) k_bgrad_reduce(const float* __restrict__ 
   }
 }
 
+int launch_bgrad_reduce(const float* partial, int S, int total, float* const* ptr, const int* off, int n, hipStream_t stream) {
+  BgOut o{};
+  o.n = n;
+  for (int i = 0; i < n; ++i) { o.ptr[i] = ptr[i]; o.off[i] = off[i]; }
+  o.off[n] = total;
+  hipLaunchKernelGGL(k_bgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, stream, partial, S, total, o);
+  return ndjir_check_launch();
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 int launch_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream) {

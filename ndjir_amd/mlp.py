@@ -18,6 +18,27 @@ from . import lib
 
 _PACK_CACHE = {}
 
+MATH_FP32, MATH_BF16X6 = 0, 1
+
+
+def set_math(math):
+    """Arithmetic of the chain engine: MATH_BF16X6 (default; exact three-way bf16 split, six MFMA
+    partial products, fp32-equivalent accuracy) or MATH_FP32 (fp32-input MFMA).  NDJIR_MLP_MATH=fp32|bf16x6."""
+    if lib.load().ndjir_mlp_set_math(int(math)) != 0:
+        raise lib.NdjirHipError(f"unknown math mode {math}")
+    _PACK_CACHE.clear()
+
+
+def get_math():
+    return int(lib.load().ndjir_mlp_get_math())
+
+
+def _init_math():
+    import os
+    env = os.environ.get("NDJIR_MLP_MATH")
+    if env:
+        set_math({"fp32": MATH_FP32, "bf16x6": MATH_BF16X6}[env.lower()])
+
 # Optional live timing of the engine's launches with HIP events on the launching stream
 # (bench.py sets PROFILE = [] around its timed region): entries (kind, algorithmic_flops, e0, e1, shape).
 PROFILE = None
@@ -35,9 +56,16 @@ def _launch(kind, flops, name, *args, shape=""):
     PROFILE.append((kind, flops, e0, e1, shape))
 
 
+_MATH_READY = False
+
+
 def _packed(W, transpose):
     """MFMA-fragment-order copy of W (or W^T); cached per (storage, version)."""
-    key = (W.data_ptr(), W._version, tuple(W.shape), bool(transpose))
+    global _MATH_READY
+    if not _MATH_READY:
+        _init_math()
+        _MATH_READY = True
+    key = (W.data_ptr(), W._version, tuple(W.shape), bool(transpose), get_math())
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0]() is W:     # same live tensor object, same version
         return hit[1]
