@@ -49,10 +49,15 @@ __device__ __forceinline__ int pin(int v) {
   return v;
 }
 __device__ __forceinline__ float pin(float v) { return __int_as_float(pin(__float_as_int(v))); }
+// pointers from the argument block: keep them in SGPRs AND in the global address space (a pointer that
+// went through an asm barrier is generic to the compiler -> flat_load/flat_store, which also count
+// on lgkmcnt and so serialise with every LDS wait)
 template <class T>
-__device__ __forceinline__ T* pin(T* p) {
-  asm volatile("" : "+s"(p));      // kernarg-derived pointers are uniform already; keeps the global address space
-  return p;
+using gptr = T __attribute__((address_space(1)))*;
+template <class T>
+__device__ __forceinline__ gptr<T> pin(T* p) {
+  asm volatile("" : "+s"(p));
+  return (gptr<T>)p;
 }
 
 // row of accumulator register i for half-wave h (standard 32x32 C/D map)
@@ -149,13 +154,13 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
       // Per-layer parameters -> SGPRs, once.  The argument block lives in kernarg memory: left to itself
       // the compiler re-loads fields inside the epilogue loop, and every scalar-load wait also drains
       // the LDS queue (lgkmcnt is shared).
-      const float* const p_wp = pin(ly.Wp);
-      const float* const p_bias = pin(ly.bias);
-      const float* const p_side_in = pin(ly.side_in);
-      const float* const p_side_in2 = pin(ly.side_in2);
-      const float* const p_side_add = pin(ly.side_add);
-      float* const p_side_out = pin(ly.side_out);
-      float* const p_side_out2 = pin(ly.side_out2);
+      const gptr<const float> p_wp = pin(ly.Wp);
+      const gptr<const float> p_bias = pin(ly.bias);
+      const gptr<const float> p_side_in = pin(ly.side_in);
+      const gptr<const float> p_side_in2 = pin(ly.side_in2);
+      const gptr<const float> p_side_add = pin(ly.side_add);
+      const gptr<float> p_side_out = pin(ly.side_out);
+      const gptr<float> p_side_out2 = pin(ly.side_out2);
       float* const p_bgrad = (MODE != 0 && ly.bgrad) ? bsum + pin(ly.bg_off) : nullptr;
       const int l_N = pin(ly.N);
       const int l_ld = pin(ly.ld_side);
@@ -214,7 +219,7 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
         f32x16 acc[RBU];
 #pragma unroll
         for (int q = 0; q < RBU; ++q) acc[q] = f32x16{0};
-        const f32x4* Bp = reinterpret_cast<const f32x4*>(p_wp) + (long long)nb * KB * 64 + lane;
+        const gptr<const f32x4> Bp = ((gptr<const f32x4>)(p_wp)) + (long long)nb * KB * 64 + lane;
         const float* A0 = cur + h * GP + (rb0 * 32 + r) * 4;
         const int mbase = rb0 * 32 + (lane >> 3);  // first row this lane handles in pass 2
         // output-layer staging slot (host sizes LDS for min(NB, 8) slots): the block's own index while
@@ -235,7 +240,7 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
         auto load_hsv = [&]() {
           if (fast) {
 #pragma unroll
-            for (int it = 0; it < ITS; ++it) hsv[it] = *reinterpret_cast<const f32x4*>(p_side_in + off0 + (long long)it * 8 * l_ld);
+            for (int it = 0; it < ITS; ++it) hsv[it] = *((gptr<const f32x4>)(p_side_in + off0 + (long long)it * 8 * l_ld));
           }
         };
 
@@ -317,7 +322,7 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
         float* lp = nxt + ((last ? slot * 32 + g * 4 : n4) >> 2) * GP + mbase * 4;
         if (fast) {
           f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-          if (MODE == 0 && p_bias) bias4 = *reinterpret_cast<const f32x4*>(p_bias + n4);
+          if (MODE == 0 && p_bias) bias4 = *((gptr<const f32x4>)(p_bias + n4));
 #pragma unroll
           for (int it = 0; it < ITS; ++it) {
             const long long off = off0 + (long long)it * 8 * l_ld;
@@ -331,11 +336,11 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
                 float sp = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(u)) * ib2;
                 v[q] = (u > 20.f * LOG2E ? t : sp) * sc;
               }
-              if (p_side_out) *reinterpret_cast<f32x4*>(p_side_out + off) = v;
+              if (p_side_out) *((gptr<f32x4>)(p_side_out + off)) = v;
             } else {
               f32x4 ex = {0.f, 0.f, 0.f, 0.f}, x2;
-              if (MODE == 1 && p_side_add) ex = *reinterpret_cast<const f32x4*>(p_side_add + off);
-              if (MODE == 2 && p_side_in2) ex = *reinterpret_cast<const f32x4*>(p_side_in2 + off);
+              if (MODE == 1 && p_side_add) ex = *((gptr<const f32x4>)(p_side_add + off));
+              if (MODE == 2 && p_side_in2) ex = *((gptr<const f32x4>)(p_side_in2 + off));
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 float e = __builtin_amdgcn_exp2f(nb2 * hsv[it][q]);   // exp(-beta h)
@@ -343,8 +348,8 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
                 if (MODE == 1) v[q] = z[q] * sp + ex[q];
                 else { v[q] = z[q] * sp; x2[q] = beta * z[q] * ex[q] * e; }   // ex = s of the sdf chain
               }
-              if (p_side_out) *reinterpret_cast<f32x4*>(p_side_out + off) = v;
-              if (MODE == 2 && p_side_out2) *reinterpret_cast<f32x4*>(p_side_out2 + off) = x2;
+              if (p_side_out) *((gptr<f32x4>)(p_side_out + off)) = v;
+              if (MODE == 2 && p_side_out2) *((gptr<f32x4>)(p_side_out2 + off)) = x2;
               colsum += v;
             }
             *reinterpret_cast<f32x4*>(lp + it * 32) = v;
@@ -399,7 +404,7 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
                 v[q] = (u > 20.f * LOG2E ? t : sp) * (sc * cm[q] * rm);
               }
               if (mrow && p_side_out) {
-                if (vec_side) *reinterpret_cast<f32x4*>(p_side_out + off) = v;
+                if (vec_side) *((gptr<f32x4>)(p_side_out + off)) = v;
                 else {
 #pragma unroll
                   for (int q = 0; q < 4; ++q) if (n4 + q < l_N) p_side_out[off + q] = v[q];

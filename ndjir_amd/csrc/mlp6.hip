@@ -28,6 +28,12 @@
 #include "common.h"
 #include "mlp.h"
 
+#ifdef X6_NO_SCHEDB
+#define X6_SCHED_BARRIER()
+#else
+#define X6_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace ndjir {
 namespace x6 {
 
@@ -50,10 +56,15 @@ __device__ __forceinline__ int pin(int v) {
   return v;
 }
 __device__ __forceinline__ float pin(float v) { return __int_as_float(pin(__float_as_int(v))); }
+// pointers from the argument block: keep them in SGPRs AND in the global address space (a pointer that
+// went through an asm barrier is generic to the compiler -> flat_load/flat_store, which also count
+// on lgkmcnt and so serialise with every LDS wait)
 template <class T>
-__device__ __forceinline__ T* pin(T* p) {
+using gptr = T __attribute__((address_space(1)))*;
+template <class T>
+__device__ __forceinline__ gptr<T> pin(T* p) {
   asm volatile("" : "+s"(p));
-  return p;
+  return (gptr<T>)p;
 }
 
 __device__ __forceinline__ unsigned short bf16_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
@@ -169,13 +180,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
       const int NB = ly.Np >> 5;
       const bool last = a.has_output && (li == a.L - 1);
       stamp(li, 0);
-      const bf16x8* const p_wp = reinterpret_cast<const bf16x8*>(pin(ly.Wp));
-      const float* const p_bias = pin(ly.bias);
-      const float* const p_side_in = pin(ly.side_in);
-      const float* const p_side_in2 = pin(ly.side_in2);
-      const float* const p_side_add = pin(ly.side_add);
-      float* const p_side_out = pin(ly.side_out);
-      float* const p_side_out2 = pin(ly.side_out2);
+      const gptr<const bf16x8> p_wp = (gptr<const bf16x8>)pin(ly.Wp);
+      const gptr<const float> p_bias = pin(ly.bias);
+      const gptr<const float> p_side_in = pin(ly.side_in);
+      const gptr<const float> p_side_in2 = pin(ly.side_in2);
+      const gptr<const float> p_side_add = pin(ly.side_add);
+      const gptr<float> p_side_out = pin(ly.side_out);
+      const gptr<float> p_side_out2 = pin(ly.side_out2);
       float* const p_bgrad = (MODE != 0 && ly.bgrad) ? bsum + pin(ly.bg_off) : nullptr;
       const int l_N = pin(ly.N);
       const int l_ld = pin(ly.ld_side);
@@ -184,50 +195,80 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
       const int nlim = pin((BWD && is_skip) ? a.skip_split : l_N);
 
       // one k-loop: RBU row blocks of column block nb, accumulators acc[SLOT .. SLOT + RBU)
-      f32x16 acc[4];
+      f32x16 acc[4];   // static indices only (an accumulator array indexed under run-time branches goes to scratch)
       auto kloop = [&](auto rbu_tag, auto slot_tag, const int nb, const int rb0, const int ks0, const int ks1) {
         constexpr int RBU = decltype(rbu_tag)::value;
         constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
         for (int q = 0; q < RBU; ++q) acc[SLOT + q] = f32x16{0};
-        const bf16x8* Bp = p_wp + ((long long)nb * KS) * 3 * 64 + lane;
+        const gptr<const bf16x8> Bp = p_wp + ((long long)nb * KS) * 3 * 64 + lane;
         const bf16x8* A0 = act + h * TMP + rb0 * 32 + r;
-        bf16x8 b[3][3];
+        // Software pipeline (static register slots, unrolled by 3): weight fragments 3 steps ahead;
+        // the lo / mid activation planes are re-loaded in place as soon as their last MFMA of the step
+        // has issued, the hi plane (needed until the end of the step) rotates through 3 buffers.
+        bf16x8 b[3][3];                 // [slot][plane]
+        bf16x8 alo[RBU], amid[RBU], ahi[3][RBU];
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < 3; ++s) {
 #pragma unroll
           for (int p = 0; p < 3; ++p) b[s][p] = Bp[(long long)((ks0 + s < ks1 ? ks0 + s : ks0) * 3 + p) * 64];
-        for (int ks = ks0; ks < ks1; ks += 3) {
+          X6_SCHED_BARRIER();
+        }
+        {
+          const bf16x8* An = A0 + 2 * ks0 * TMP;
 #pragma unroll
-          for (int s = 0; s < 3; ++s) {
-            if (ks + s < ks1) {
-              bf16x8 av[RBU][3];
-              const bf16x8* An = A0 + 2 * (ks + s) * TMP;
+          for (int q = 0; q < RBU; ++q) { ahi[0][q] = An[q * 32]; amid[q] = An[PLANE + q * 32]; alo[q] = An[2 * PLANE + q * 32]; }
+        }
+        X6_SCHED_BARRIER();
+        auto kstep = [&](auto stag, auto gtag, const int ks) {
+          constexpr int S = decltype(stag)::value;
+          constexpr bool GUARD = decltype(gtag)::value;
+          const bool nxt = !GUARD || ks + 1 < ks1;
+          const bf16x8* An = A0 + 2 * (ks + 1) * TMP;
+          // six partial products; planes: hi, mid, lo.  Order: lo*hi, mid*mid, mid*hi, hi*lo, hi*mid, hi*hi
 #pragma unroll
-              for (int q = 0; q < RBU; ++q)
+          for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[q], b[S][0], acc[SLOT + q], 0, 0, 0);
+          if (nxt) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) av[q][p] = An[p * PLANE + q * 32];
-              // six partial products, small terms first; planes 0 = hi, 1 = mid, 2 = lo
+            for (int q = 0; q < RBU; ++q) alo[q] = An[2 * PLANE + q * 32];
+          }
+          X6_SCHED_BARRIER();
 #pragma unroll
-              for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][2], b[s][0], acc[SLOT + q], 0, 0, 0);
+          for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid[q], b[S][1], acc[SLOT + q], 0, 0, 0);
 #pragma unroll
-              for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], b[s][2], acc[SLOT + q], 0, 0, 0);
+          for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amid[q], b[S][0], acc[SLOT + q], 0, 0, 0);
+          if (nxt) {
 #pragma unroll
-              for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], b[s][1], acc[SLOT + q], 0, 0, 0);
+            for (int q = 0; q < RBU; ++q) { amid[q] = An[PLANE + q * 32]; ahi[(S + 1) % 3][q] = An[q * 32]; }
+          }
+          X6_SCHED_BARRIER();
 #pragma unroll
-              for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], b[s][0], acc[SLOT + q], 0, 0, 0);
+          for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[S][q], b[S][2], acc[SLOT + q], 0, 0, 0);
 #pragma unroll
-              for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], b[s][1], acc[SLOT + q], 0, 0, 0);
+          for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[S][q], b[S][1], acc[SLOT + q], 0, 0, 0);
 #pragma unroll
-              for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], b[s][0], acc[SLOT + q], 0, 0, 0);
-              if (ks + s + 3 < ks1) {
+          for (int q = 0; q < RBU; ++q) acc[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[S][q], b[S][0], acc[SLOT + q], 0, 0, 0);
+          if (!GUARD || ks + 3 < ks1) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[s][p] = Bp[(long long)((ks + s + 3) * 3 + p) * 64];
-              }
-            }
+            for (int p = 0; p < 3; ++p) b[S][p] = Bp[(long long)((ks + 3) * 3 + p) * 64];
+          }
+          X6_SCHED_BARRIER();
+        };
+        {
+          using T = std::true_type;
+          using F = std::false_type;
+          using S0 = std::integral_constant<int, 0>;
+          using S1 = std::integral_constant<int, 1>;
+          using S2 = std::integral_constant<int, 2>;
+          int ks = ks0;
+          for (; ks + 6 <= ks1; ks += 3) { kstep(S0{}, F{}, ks); kstep(S1{}, F{}, ks + 1); kstep(S2{}, F{}, ks + 2); }
+          for (; ks < ks1; ks += 3) {
+            kstep(S0{}, T{}, ks);
+            if (ks + 1 < ks1) kstep(S1{}, T{}, ks + 1);
+            if (ks + 2 < ks1) kstep(S2{}, T{}, ks + 2);
           }
         }
-      };
+            };
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
@@ -269,26 +310,25 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
       // fragments are fetched once per tile); the NB % 8 remainder blocks are split by row block.
       const int rem = (RB == 1) ? 0 : (NB % NWAVES);
       const int full = NB - rem;
-      int job_nb[4], job_rb[4], njobs = 0;
+      unsigned jobs = 0;    // job j (= accumulator slot j) in bits 8j..8j+7: column block | row block << 5
+      int njobs = 0;
+      auto job = [&](int j, int nb, int rb) { jobs |= (unsigned)(nb | (rb << 5)) << (8 * j); };
       if (RB == 2) {
-        if (wave < full) { kloop(IRB{}, I0{}, wave, 0, 0, KS); job_nb[0] = job_nb[1] = wave; job_rb[0] = 0; job_rb[1] = 1; njobs = 2; }
-        if (wave + NWAVES < full) {
-          kloop(IRB{}, I2{}, wave + NWAVES, 0, 0, KS);
-          job_nb[2] = job_nb[3] = wave + NWAVES; job_rb[2] = 0; job_rb[3] = 1; njobs = 4;
-        }
+        if (wave < full) { kloop(IRB{}, I0{}, wave, 0, 0, KS); job(0, wave, 0); job(1, wave, 1); njobs = 2; }
+        if (wave + NWAVES < full) { kloop(IRB{}, I2{}, wave + NWAVES, 0, 0, KS); job(2, wave + NWAVES, 0); job(3, wave + NWAVES, 1); njobs = 4; }
         if (wave < rem * RB) {
           const int nb = full + wave / RB, rb = wave % RB;
           if (njobs == 0) kloop(I1{}, I0{}, nb, rb, 0, KS); else kloop(I1{}, I2{}, nb, rb, 0, KS);
-          job_nb[njobs] = nb; job_rb[njobs] = rb; ++njobs;
+          job(njobs, nb, rb); ++njobs;
         }
         if (wave + NWAVES < rem * RB) {
           const int nb = full + (wave + NWAVES) / RB, rb = (wave + NWAVES) % RB;
           if (njobs == 1) kloop(I1{}, I1{}, nb, rb, 0, KS); else kloop(I1{}, I3{}, nb, rb, 0, KS);
-          job_nb[njobs] = nb; job_rb[njobs] = rb; ++njobs;
+          job(njobs, nb, rb); ++njobs;
         }
       } else {
-        if (wave < NB) { kloop(I1{}, I0{}, wave, 0, 0, KS); job_nb[0] = wave; job_rb[0] = 0; njobs = 1; }
-        if (wave + NWAVES < NB) { kloop(I1{}, I1{}, wave + NWAVES, 0, 0, KS); job_nb[1] = wave + NWAVES; job_rb[1] = 0; njobs = 2; }
+        if (wave < NB) { kloop(I1{}, I0{}, wave, 0, 0, KS); job(0, wave, 0); njobs = 1; }
+        if (wave + NWAVES < NB) { kloop(I1{}, I1{}, wave + NWAVES, 0, 0, KS); job(1, wave + NWAVES, 0); njobs = 2; }
       }
       stamp(li, 1);
       if (!last) __syncthreads();          // every wave has read the planes: they may be overwritten now
@@ -301,7 +341,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
       const int g = lane & 7;
 #pragma unroll 1
       for (int j = 0; j < njobs; ++j) {
-        const int nb = job_nb[j], rb0 = job_rb[j];
+        const int nb = (jobs >> (8 * j)) & 31, rb0 = (jobs >> (8 * j + 5)) & 7;
         // pass 1: accumulators -> staging tile (conflict-free: column groups GPS apart, rows 4 dwords apart)
         {
           float* dst = stage + (r >> 2) * GPS + (r & 3);
@@ -321,11 +361,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
         const float* lp = stage + g * GPS + (lane >> 3) * 4;
         if (fast) {
           f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-          if (MODE == 0 && p_bias) bias4 = *reinterpret_cast<const f32x4*>(p_bias + n4);
+          if (MODE == 0 && p_bias) bias4 = *((gptr<const f32x4>)(p_bias + n4));
           f32x4 hs[4];
           if (MODE != 0) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) hs[it] = *reinterpret_cast<const f32x4*>(p_side_in + off0 + (long long)it * 8 * l_ld);
+            for (int it = 0; it < 4; ++it) hs[it] = *((gptr<const f32x4>)(p_side_in + off0 + (long long)it * 8 * l_ld));
           }
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
@@ -340,11 +380,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
                 const float sp = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(u)) * ib2;
                 v[q] = (u > 20.f * LOG2E ? t : sp) * sc;
               }
-              if (p_side_out) *reinterpret_cast<f32x4*>(p_side_out + off) = v;
+              if (p_side_out) *((gptr<f32x4>)(p_side_out + off)) = v;
             } else {
               f32x4 ex = {0.f, 0.f, 0.f, 0.f}, x2;
-              if (MODE == 1 && p_side_add) ex = *reinterpret_cast<const f32x4*>(p_side_add + off);
-              if (MODE == 2 && p_side_in2) ex = *reinterpret_cast<const f32x4*>(p_side_in2 + off);
+              if (MODE == 1 && p_side_add) ex = *((gptr<const f32x4>)(p_side_add + off));
+              if (MODE == 2 && p_side_in2) ex = *((gptr<const f32x4>)(p_side_in2 + off));
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 const float e = __builtin_amdgcn_exp2f(nb2 * hs[it][q]);
@@ -352,8 +392,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
                 if (MODE == 1) v[q] = z[q] * sp + ex[q];
                 else { v[q] = z[q] * sp; x2[q] = beta * z[q] * ex[q] * e; }
               }
-              if (p_side_out) *reinterpret_cast<f32x4*>(p_side_out + off) = v;
-              if (MODE == 2 && p_side_out2) *reinterpret_cast<f32x4*>(p_side_out2 + off) = x2;
+              if (p_side_out) *((gptr<f32x4>)(p_side_out + off)) = v;
+              if (MODE == 2 && p_side_out2) *((gptr<f32x4>)(p_side_out2 + off)) = x2;
               colsum += v;
             }
             put4(n4, mbase + 8 * it, v);
@@ -405,7 +445,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
                 v[q] = (u > 20.f * LOG2E ? t : sp) * (sc * cm[q] * rm);
               }
               if (mrow && p_side_out) {
-                if (vec_side) *reinterpret_cast<f32x4*>(p_side_out + off) = v;
+                if (vec_side) *((gptr<f32x4>)(p_side_out + off)) = v;
                 else {
 #pragma unroll
                   for (int q = 0; q < 4; ++q) if (n4 + q < l_N) p_side_out[off + q] = v[q];
