@@ -127,7 +127,7 @@ extern "C" int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb,
                                int accum, float* workspace, hipStream_t stream) {
   if (P <= 0) return NDJIR_OK;
   if (!A || !B || !out || !workspace || lda < K || ldb < N) return NDJIR_ERR_ARG;
-  return launch_wgrad(A, lda, B, ldb, K, N, P, out, accum, workspace, stream);
+  return launch_wgrad(A, lda, B, ldb, K, N, P, out, accum, workspace, g_math == NDJIR_MATH_BF16X6, stream);
 }
 
 extern "C" long long ndjir_mlp_colsum_workspace(int N, long long P) { return colsum_workspace(N, P); }

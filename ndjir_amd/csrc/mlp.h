@@ -56,7 +56,7 @@ constexpr int CHAIN_MAX_GRID_BG = 512;   // workgroups of a chain launch that pr
 inline long long chain_workspace(int bg_total) { return (long long)CHAIN_MAX_GRID_BG * bg_total; }
 long long wgrad_workspace(int K, int N, long long P);
 int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out, int accum,
-                 float* workspace, hipStream_t stream);
+                 float* workspace, int bf16x6, hipStream_t stream);
 
 long long colsum_workspace(int N, long long P);
 int launch_colsum(const float* X, int ldx, int N, long long P, float* out, int accum, float* workspace,

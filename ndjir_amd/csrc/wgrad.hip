@@ -122,6 +122,174 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad(const float* __restrict
     }
 }
 
+
+// ---- the same tiles on the bf16 matrix cores (three-way split, six partial products; see mlp6.hip) ----
+// A and B arrive as fp32 rows [point][feature]; the MFMA wants, per lane, 8 consecutive POINTS of one
+// feature.  The loader therefore gives every thread one feature column and 4-point groups of it: the
+// global loads stay coalesced along the features, the three bf16 planes are written to LDS as
+// [plane][feature][point] (8-byte writes), and fragments are plain ds_read_b128.  Row pitch 40 bf16
+// (80 B) keeps both the writes and the fragment reads (almost) conflict-free.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short wg_u16x4 __attribute__((ext_vector_type(4)));
+constexpr int WG_CP = 40;
+
+__device__ __forceinline__ void wg_split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+  const __bf16 hb = (__bf16)x;
+  const float r1 = x - (float)hb;
+  const __bf16 mb = (__bf16)r1;
+  const float r2 = r1 - (float)mb;
+  const __bf16 lb = (__bf16)r2;
+  h = __builtin_bit_cast(unsigned short, hb);
+  m = __builtin_bit_cast(unsigned short, mb);
+  l = __builtin_bit_cast(unsigned short, lb);
+}
+
+template <int WK, int WN, int BK, int BN>
+__global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad6(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                          int ldb, int K, int N, long long P, float* __restrict__ partial,
+                                                          int S, int tiles_k, int tiles_n, long long rows_per_split,
+                                                          int k_off, int n_off, int k_end, int n_end) {
+  static_assert(WK * WN == 4, "4 waves");
+  constexpr int TK = WK * BK * 32, TN = WN * BN * 32;
+  constexpr int PA = TK / 8, PB = TN / 8;          // points per thread and chunk (multiples of 4)
+  extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
+  unsigned short* As = wg_lds;                      // [3][TK][WG_CP]
+  unsigned short* Bs = wg_lds + 3 * TK * WG_CP;     // [3][TN][WG_CP]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wk = wave / WN, wn = wave % WN;
+  const int T = tiles_k * tiles_n;
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  int vid = (nblk & 7) == 0 ? xcd * (nblk >> 3) + local : blockIdx.x;
+  const int split = vid / T, tile = vid - split * T;
+  const int tk = tile / tiles_n, tn = tile - tk * tiles_n;
+  const int k0 = k_off + tk * TK, n0 = n_off + tn * TN;
+  const long long p_begin = (long long)split * rows_per_split;
+  long long p_end = p_begin + rows_per_split;
+  if (p_end > P) p_end = P;
+
+  f32x16 acc[BK][BN] = {};
+  float ra[PA], rb[PB];
+  const int fa = tid % TK, ga = tid / TK, fb = tid % TN, gb = tid / TN;   // feature column, point group
+  const bool acol = (k0 + fa) < k_end, bcol = (n0 + fb) < n_end;
+  const float* Ap = A + (long long)(ga * PA) * lda + k0 + fa;
+  const float* Bp = B + (long long)(gb * PB) * ldb + n0 + fb;
+  auto load_chunk = [&](long long p0) {
+    const float* ap = Ap + p0 * lda;
+    const float* bp = Bp + p0 * ldb;
+    if (p0 + WG_C <= p_end) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = acol ? ap[(long long)i * lda] : 0.f;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) rb[i] = bcol ? bp[(long long)i * ldb] : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = (acol && p0 + ga * PA + i < p_end) ? ap[(long long)i * lda] : 0.f;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) rb[i] = (bcol && p0 + gb * PB + i < p_end) ? bp[(long long)i * ldb] : 0.f;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int g4 = 0; g4 < PA / 4; ++g4) {
+      wg_u16x4 ph, pm, pl;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { unsigned short x, y, z; wg_split3(ra[4 * g4 + q], x, y, z); ph[q] = x; pm[q] = y; pl[q] = z; }
+      unsigned short* d = As + fa * WG_CP + ga * PA + 4 * g4;
+      *reinterpret_cast<wg_u16x4*>(d) = ph;
+      *reinterpret_cast<wg_u16x4*>(d + TK * WG_CP) = pm;
+      *reinterpret_cast<wg_u16x4*>(d + 2 * TK * WG_CP) = pl;
+    }
+#pragma unroll
+    for (int g4 = 0; g4 < PB / 4; ++g4) {
+      wg_u16x4 ph, pm, pl;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { unsigned short x, y, z; wg_split3(rb[4 * g4 + q], x, y, z); ph[q] = x; pm[q] = y; pl[q] = z; }
+      unsigned short* d = Bs + fb * WG_CP + gb * PB + 4 * g4;
+      *reinterpret_cast<wg_u16x4*>(d) = ph;
+      *reinterpret_cast<wg_u16x4*>(d + TN * WG_CP) = pm;
+      *reinterpret_cast<wg_u16x4*>(d + 2 * TN * WG_CP) = pl;
+    }
+  };
+
+  if (p_begin < p_end) {
+    load_chunk(p_begin);
+    store_chunk();
+    __syncthreads();
+    for (long long p0 = p_begin; p0 < p_end; p0 += WG_C) {
+      const bool more = p0 + WG_C < p_end;
+      if (more) load_chunk(p0 + WG_C);
+#pragma unroll
+      for (int s = 0; s < WG_C / 16; ++s) {
+        wg_bf16x8 av[BK][3], bv[BN][3];
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            av[i][p] = *reinterpret_cast<const wg_bf16x8*>(As + p * TK * WG_CP + ((wk * BK + i) * 32 + r) * WG_CP + 16 * s + 8 * h);
+#pragma unroll
+        for (int j = 0; j < BN; ++j)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            bv[j][p] = *reinterpret_cast<const wg_bf16x8*>(Bs + p * TN * WG_CP + ((wn * BN + j) * 32 + r) * WG_CP + 16 * s + 8 * h);
+        // six partial products (planes 0 = hi, 1 = mid, 2 = lo), small terms first
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int j = 0; j < BN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][2], bv[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int j = 0; j < BN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][2], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int j = 0; j < BN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int j = 0; j < BN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int j = 0; j < BN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][1], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int j = 0; j < BN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[j][0], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();                 // every wave is done with this chunk's planes
+      if (more) store_chunk();
+      __syncthreads();
+    }
+  }
+
+  float* out = partial + (long long)split * K * N;
+#pragma unroll
+  for (int bi = 0; bi < BK; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < BN; ++bj) {
+      const int n = n0 + (wn * BN + bj) * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = k0 + (wk * BK + bi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (k < k_end && n < n_end) out[(long long)k * N + n] = acc[bi][bj][i];
+      }
+    }
+}
+
+template <int WK, int WN, int BK, int BN>
+static inline void wgrad6_go(int blocks, hipStream_t stream, const float* A, int lda, const float* B, int ldb, int K, int N,
+                             long long P, float* ws, int S, int tk, int tn, long long rows, int k_off, int n_off, int k_end,
+                             int n_end) {
+  constexpr int TK = WK * BK * 32, TN = WN * BN * 32;
+  const size_t lds = (size_t)3 * (TK + TN) * WG_CP * sizeof(unsigned short);
+  hipLaunchKernelGGL((k_wgrad6<WK, WN, BK, BN>), dim3(blocks), dim3(WG_THREADS), lds, stream, A, lda, B, ldb, K, N, P, ws, S, tk,
+                     tn, rows, k_off, n_off, k_end, n_end);
+}
+
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ out,
                                                       long long KN, int S, int accum) {
   // one float4 of the output per thread; 8 independent loads in flight per thread
@@ -373,7 +541,7 @@ static int launch_split_reduce(const float* ws, float* out, long long KN, int S,
 }
 
 int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out, int accum,
-                 float* workspace, hipStream_t stream) {
+                 float* workspace, int bf16x6, hipStream_t stream) {
   if (K <= 0 || N <= 0) return NDJIR_OK;
   if (N <= SW_NMAX && (K & 3) == 0 && (lda & 3) == 0 && ((uintptr_t)A & 15) == 0) {
     if (P <= 0) {
@@ -388,6 +556,23 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
   const int S = pick_splits(K, N, P);
   long long rows = (P + S - 1) / S;
   rows = (rows + WG_C - 1) / WG_C * WG_C;
+  if (bf16x6) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad6<2, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr = true;
+    }
+    if (pl.tk > 0 && pl.tn > 0)
+      wgrad6_go<2, 2, 2, 2>(S * pl.tk * pl.tn, stream, A, lda, B, ldb, K, N, P, workspace, S, pl.tk, pl.tn, rows, 0, 0,
+                            pl.Km < K ? pl.Km : K, pl.Nm < N ? pl.Nm : N);
+    if (pl.sk > 0) {
+      const int tn_all = (N + WG_T - 1) / WG_T;
+      wgrad6_go<1, 4, 1, 1>(S * pl.sk * tn_all, stream, A, lda, B, ldb, K, N, P, workspace, S, pl.sk, tn_all, rows, pl.Km, 0, K, N);
+    }
+    if (pl.sn > 0 && pl.tk > 0)
+      wgrad6_go<4, 1, 1, 1>(S * pl.tk * pl.sn, stream, A, lda, B, ldb, K, N, P, workspace, S, pl.tk, pl.sn, rows, 0, pl.Nm, pl.Km, N);
+    return launch_split_reduce(workspace, out, (long long)K * N, S, accum, stream);
+  }
   if (pl.tk > 0 && pl.tn > 0)
     hipLaunchKernelGGL((k_wgrad<2, 2, 2, 2>), dim3(S * pl.tk * pl.tn), dim3(WG_THREADS), 0, stream, A, lda, B, ldb, K, N, P,
                        workspace, S, pl.tk, pl.tn, rows, 0, 0, pl.Km < K ? pl.Km : K, pl.Nm < N ? pl.Nm : N);
