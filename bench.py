@@ -9,10 +9,13 @@ samples, 128 lights), synthetic rays, reference-initialised weights.  Rays shard
 (weak scaling: 512 rays per GPU); one gradient exchange per step over RCCL.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 
-`roofline` is for the dominant hand-written kernel, `ndjir::k_mlp_chain<false, TM>` (fused MLP
-forward chain): achieved = sum of the algorithmic FLOPs (2*in*out per affine per point)
-of its launches / sum of their durations, measured live with HIP events recorded on the launching
-stream around every launch inside the timed region.
+`roofline` is for the dominant hand-written kernel, the fused MLP forward chain
+(`ndjir::x6::k_chain6<0, TM>`, or `ndjir::k_mlp_chain<0, TM>` with NDJIR_MLP_MATH=fp32): achieved =
+sum of the algorithmic FLOPs (2*in*out per affine per point) of its launches / sum of
+their durations, measured live with HIP events recorded on the launching stream around every launch
+inside the timed region.  In the default bf16x6 arithmetic one algorithmic FLOP costs six bf16 MFMA
+FLOPs, so the peak it is priced against is the dense bf16 MFMA peak / 6.
+`hip_graph` (single GPU) re-measures the same step replayed from one captured HIP graph.
 """
 import argparse
 import json
@@ -29,6 +32,9 @@ if ROOT not in sys.path:
 # dense-GEMM FLOPs (2*in*out per affine per point), default config
 MFLOP_PER_RAY_FWD_BWD = 2168.9
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+# bf16x6 engine: every algorithmic fp32 FLOP is executed as 6 bf16 MFMA FLOPs (three-way operand split)
+PEAK_BF16X6_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def parse():
@@ -40,6 +46,7 @@ def parse():
     ap.add_argument("--config", default="default")
     ap.add_argument("--override", action="append", default=[])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="skip the extra HIP-graph replay measurement (single GPU)")
     ap.add_argument("--cpu-rays", type=int, default=32)
     return ap.parse_args()
 
@@ -54,6 +61,7 @@ class Step:
         from ndjir_amd.synthetic import make_rays
 
         self.conf, self.device, self.rank, self.world = conf, device, rank, world
+        self.R = R
         P.clear_parameters()
         P.set_device(device)
         network.seed(313)
@@ -147,6 +155,30 @@ def cpu_baseline(conf, step, n_rays):
                        f"{cores} of {os.cpu_count()} host cores, {el:.1f} s")
 
 
+def graph_replay(step, steps):
+    """The same step captured once into a HIP graph (torch.cuda.CUDAGraph: forward, backward and every
+    custom launch are stream-ordered and allocation-stable) and replayed `steps` times: what the step
+    costs without host-side launch overhead.  Informational; `value` is the eager number."""
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step.forward_backward()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        loss = step.forward_backward()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"ms_per_step": 1e3 * el / steps, "rays_per_s": step.R * steps / el, "loss": float(loss),
+            "note": "same step, one hipGraphLaunch per step"}
+
+
 def kernel_report(profile):
     """Aggregate the live HIP-event records of the MLP engine (ndjir_amd.mlp.PROFILE)."""
     agg = {}
@@ -226,28 +258,40 @@ def main():
         dom = kr.get("chain_fwd", dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0))
         step_tflops = MFLOP_PER_RAY_FWD_BWD * 1e6 * R / (ms * 1e-3) / 1e12      # per GPU
         tile = os.environ.get("NDJIR_MLP_TILE", "64")
+        x6 = mlp.get_math() == mlp.MATH_BF16X6
+        peak = PEAK_BF16X6_EFFECTIVE_TFLOPS if x6 else PEAK_FP32_MFMA_TFLOPS
+        kname = (f"ndjir::x6::k_chain6<0, {tile}> (fused MLP forward chain; fp32 operands split exactly into 3 bf16 planes, "
+                 f"6 v_mfma_f32_32x32x16_bf16 partial products per fp32 product, fp32 accumulate)") if x6 else \
+            f"ndjir::k_mlp_chain<0, {tile}> (fused MLP forward chain, fp32 MFMA 32x32x2)"
+        peak_note = ("dense bf16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 6 partial products per algorithmic FLOP"
+                     if x6 else "fp32-input MFMA peak (MI355X_MICROARCH.md)")
         out = {
             "metric": "rays/sec (fwd+bwd) at 512 rays x 128 samples",
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (bf16x3-split MFMA products, f32 accumulate)" if x6 else "f32", "data": "synthetic",
             "config": {"workload": f"config/{a.config}.yaml, B=1, R={R} rays/GPU x N={N} fg samples (+{r.n_bg_samples} bg, "
                                    f"{r.n_thetas * 2 * r.n_thetas} lights), voxel {conf.geometric_network.voxel.type} "
                                    f"{conf.geometric_network.voxel.grid_size}^3x{conf.geometric_network.voxel.feature_size}, "
                                    f"total_loss fwd+bwd to all parameter gradients",
                        "rays_per_gpu": R, "samples_per_ray": N, "parallelism": f"ray-sharded x{world}"},
-            "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": f"ndjir::k_mlp_chain<false, {tile}> (fused MLP forward chain, fp32 MFMA 32x32x2)",
+            "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
+                         "frac": dom["tflops"] / peak, "traffic": None,
+                         "kernel": kname, "peak_note": peak_note,
                          "launches_per_step": dom["launches"] / max(a.steps, 1), "avg_launch_us": dom["avg_us"],
                          "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
                          "method": "HIP events on the launching stream around every launch in the timed region"},
             "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kr.items()},
-            "step_roofline": {"achieved": step_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": step_tflops / PEAK_FP32_MFMA_TFLOPS,
+            "step_roofline": {"achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
+                              "frac": step_tflops / peak,
                               "scope": "whole step: 2168.9 MFLOP/ray fwd+bwd (SURVEY 8d) / step time"},
             "loss": float(loss),
         }
+        if world == 1 and not a.no_graph:
+            try:
+                out["hip_graph"] = graph_replay(step, a.steps)
+            except Exception as e:      # informational only
+                out["hip_graph"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(conf, step, a.cpu_rays)
