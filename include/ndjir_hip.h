@@ -233,6 +233,28 @@ int ndjir_render_integrate(int R, int S, int C, const float* w, int ldw, const f
 int ndjir_render_integrate_backward(int R, int S, int C, const float* w, int ldw, const float* x, const float* g,
                                     float* gx, float* gw, int ldgw, hipStream_t stream);
 
+/* Direct-light integrals over the M sampled light directions of each ray, one launch each way.
+ * diffuse (python/renderer.py:117-118):   out (R,C) = mean_m soft_vis * env * clamp(n.l, eps_dot)
+ * specular (python/renderer.py:136-161 with python/specular_brdf.py:40-118: filament model, importance
+ * sampling, no split sum):                  out (R,3) = weight * mean_m sBRDF * soft_vis * env * clamp(n.l, eps_dot)
+ * normal, view_dir (R,3) unit; light_dir (R,M,3); roughness (R); specular_color (R,3); soft_vis (R,M);
+ * env (R,M,C), C in {1..3} (specular: 1 or 3).  Light and view directions carry no gradient
+ * (python/sampler.py:391-392).  Backward writes g_normal (R,3), g_roughness (R), g_specular_color (R,3),
+ * g_soft_vis (R,M), g_env (R,M,C). */
+int ndjir_render_diffuse_light(int R, int M, int C, const float* normal, const float* light_dir, const float* soft_vis,
+                               const float* env, float eps_dot, float* out, hipStream_t stream);
+int ndjir_render_diffuse_light_backward(int R, int M, int C, const float* normal, const float* light_dir, const float* soft_vis,
+                                        const float* env, float eps_dot, const float* g, float* g_normal, float* g_soft_vis,
+                                        float* g_env, hipStream_t stream);
+int ndjir_render_specular_light_filament(int R, int M, int C, const float* normal, const float* view_dir, const float* light_dir,
+                                         const float* roughness, const float* specular_color, const float* soft_vis,
+                                         const float* env, float eps_dot, float weight, float* out, hipStream_t stream);
+int ndjir_render_specular_light_filament_backward(int R, int M, int C, const float* normal, const float* view_dir,
+                                                  const float* light_dir, const float* roughness, const float* specular_color,
+                                                  const float* soft_vis, const float* env, float eps_dot, float weight,
+                                                  const float* g, float* g_normal, float* g_roughness, float* g_specular_color,
+                                                  float* g_soft_vis, float* g_env, hipStream_t stream);
+
 /* ---- fused MLP engine ------------------------------------------------------------------------------
  * Replaces the reference's per-layer nnabla launches (PF.affine -> cuBLAS GEMM, F.softplus(beta=100),
  * python/network.py:88-93,165 and every network function :154-561) by ONE launch per net and

@@ -274,3 +274,259 @@ extern "C" int ndjir_render_integrate_backward(int R, int S, int C, const float*
   hipLaunchKernelGGL(k_integrate_bwd, dim3(R), dim3(256), 0, stream, S, C, w, ldw, x, g, gx, gw, ldgw);
   return ndjir_check_launch();
 }
+
+// ---- direct-light integrals over the M sampled light directions of a ray ----------------------------
+// python/renderer.py:117-118  env_pixel = mean_m( soft_vis * env * clamp(n.l, eps) )                     (diffuse)
+// python/renderer.py:136-161 + python/specular_brdf.py:40-118 (filament model, importance sampling, no
+// split sum):  spec_pixel_c = weight * mean_m( sBRDF_c * soft_vis * env * clamp(n.l, eps) )               (specular)
+// with the BRDF algebra (half vector, four clamped dots, Smith-GGX visibility, Schlick Fresnel) done
+// per (ray, light) in registers.  The reference spells each of these as ~50 nnabla functions over
+// (B,R,M,*) tensors; here it is one launch each way.  Light and view directions carry no gradient
+// (SampleDirections has none, python/sampler.py:391-392).  One workgroup of 128 threads per ray.
+namespace ndjir {
+
+constexpr int SH_THREADS = 128;
+
+__device__ __forceinline__ float sh_block_sum(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1];
+}
+
+// out (R,C) ; soft_vis (R,M) ; env (R,M,C) ; light (R,M,3) ; normal (R,3)
+__global__ void __launch_bounds__(SH_THREADS) k_diffuse_light(int M, int C, const float* __restrict__ normal,
+                                                              const float* __restrict__ light, const float* __restrict__ soft_vis,
+                                                              const float* __restrict__ env, float eps_dot,
+                                                              float* __restrict__ out) {
+  __shared__ float red[2];
+  const long long r = blockIdx.x;
+  const float nx = normal[r * 3], ny = normal[r * 3 + 1], nz = normal[r * 3 + 2];
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int m = threadIdx.x; m < M; m += SH_THREADS) {
+    const long long e = r * M + m;
+    const float c = fmaxf(nx * light[e * 3] + ny * light[e * 3 + 1] + nz * light[e * 3 + 2], eps_dot);
+    const float t = soft_vis[e] * c;
+    for (int k = 0; k < C; ++k) acc[k] += t * env[e * C + k];
+  }
+  for (int k = 0; k < C; ++k) {
+    const float s = sh_block_sum(acc[k], red);
+    if (threadIdx.x == 0) out[r * C + k] = s / (float)M;
+  }
+}
+
+__global__ void __launch_bounds__(SH_THREADS) k_diffuse_light_bwd(int M, int C, const float* __restrict__ normal,
+                                                                  const float* __restrict__ light, const float* __restrict__ soft_vis,
+                                                                  const float* __restrict__ env, float eps_dot,
+                                                                  const float* __restrict__ g, float* __restrict__ g_normal,
+                                                                  float* __restrict__ g_soft_vis, float* __restrict__ g_env) {
+  __shared__ float red[2];
+  const long long r = blockIdx.x;
+  const float nx = normal[r * 3], ny = normal[r * 3 + 1], nz = normal[r * 3 + 2];
+  const float inv = 1.f / (float)M;
+  float gn[3] = {0.f, 0.f, 0.f};
+  for (int m = threadIdx.x; m < M; m += SH_THREADS) {
+    const long long e = r * M + m;
+    const float lx = light[e * 3], ly = light[e * 3 + 1], lz = light[e * 3 + 2];
+    const float raw = nx * lx + ny * ly + nz * lz;
+    const float c = fmaxf(raw, eps_dot);
+    const float sv = soft_vis[e];
+    float ge = 0.f;                       // sum_k g_k env_k
+    for (int k = 0; k < C; ++k) {
+      const float gk = g[r * C + k] * inv;
+      ge += gk * env[e * C + k];
+      g_env[e * C + k] = gk * sv * c;
+    }
+    g_soft_vis[e] = ge * c;
+    const float gc = (raw >= eps_dot) ? ge * sv : 0.f;      // clamp(min) backward
+    gn[0] += gc * lx; gn[1] += gc * ly; gn[2] += gc * lz;
+  }
+  for (int k = 0; k < 3; ++k) {
+    const float s = sh_block_sum(gn[k], red);
+    if (threadIdx.x == 0) g_normal[r * 3 + k] = s;
+  }
+}
+
+struct SpecTerms {
+  float nol, nov, noh, voh;            // clamped dots
+  float rnol, rnov, rnoh;              // raw dots
+  float hx, hy, hz;
+  float mask, V1l, V1v, sl, sv_, a2;
+};
+
+__device__ __forceinline__ SpecTerms spec_terms(float nx, float ny, float nz, float vx, float vy, float vz, float lx, float ly,
+                                                float lz, float rough, float eps_dot) {
+  SpecTerms t;
+  float ux = lx + vx, uy = ly + vy, uz = lz + vz;
+  const float un = sqrtf(ux * ux + uy * uy + uz * uz);
+  t.hx = ux / un; t.hy = uy / un; t.hz = uz / un;
+  t.rnol = nx * lx + ny * ly + nz * lz;
+  t.rnov = nx * vx + ny * vy + nz * vz;
+  t.rnoh = nx * t.hx + ny * t.hy + nz * t.hz;
+  const float rvoh = vx * t.hx + vy * t.hy + vz * t.hz;
+  t.nol = fmaxf(t.rnol, eps_dot); t.nov = fmaxf(t.rnov, eps_dot); t.noh = fmaxf(t.rnoh, eps_dot); t.voh = fmaxf(rvoh, eps_dot);
+  t.mask = (t.rnol > eps_dot && t.rnov > eps_dot && t.rnoh > eps_dot) ? 1.f : 0.f;
+  t.a2 = rough * rough;
+  t.sl = sqrtf(t.a2 + (1.f - t.a2) * t.nol * t.nol);
+  t.sv_ = sqrtf(t.a2 + (1.f - t.a2) * t.nov * t.nov);
+  t.V1l = 1.f / (t.nol + t.sl + 1e-6f);
+  t.V1v = 1.f / (t.nov + t.sv_ + 1e-6f);
+  return t;
+}
+
+// out (R,3); spec (R,3); rough (R); env (R,M,C) with C = 1 or 3
+__global__ void __launch_bounds__(SH_THREADS) k_specular_light(int M, int C, const float* __restrict__ normal,
+                                                               const float* __restrict__ view, const float* __restrict__ light,
+                                                               const float* __restrict__ rough, const float* __restrict__ spec,
+                                                               const float* __restrict__ soft_vis, const float* __restrict__ env,
+                                                               float eps_dot, float weight, float* __restrict__ out) {
+  __shared__ float red[2];
+  const long long r = blockIdx.x;
+  const float nx = normal[r * 3], ny = normal[r * 3 + 1], nz = normal[r * 3 + 2];
+  const float vx = view[r * 3], vy = view[r * 3 + 1], vz = view[r * 3 + 2];
+  const float ro = rough[r];
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int m = threadIdx.x; m < M; m += SH_THREADS) {
+    const long long e = r * M + m;
+    SpecTerms t = spec_terms(nx, ny, nz, vx, vy, vz, light[e * 3], light[e * 3 + 1], light[e * 3 + 2], ro, eps_dot);
+    const float V = t.V1l * t.V1v;
+    const float f5 = powf(1.f - t.voh, 5.f);
+    const float Kf = 4.f * t.voh / t.noh * t.mask;
+    const float sv = soft_vis[e];
+    for (int k = 0; k < 3; ++k) {
+      const float sc = spec[r * 3 + k];
+      const float Fs = sc + (1.f - sc) * f5;
+      acc[k] += V * Fs * Kf * sv * env[e * C + (C == 1 ? 0 : k)] * t.nol;
+    }
+  }
+  for (int k = 0; k < 3; ++k) {
+    const float s = sh_block_sum(acc[k], red);
+    if (threadIdx.x == 0) out[r * 3 + k] = weight * s / (float)M;
+  }
+}
+
+__global__ void __launch_bounds__(SH_THREADS) k_specular_light_bwd(int M, int C, const float* __restrict__ normal,
+                                                                   const float* __restrict__ view, const float* __restrict__ light,
+                                                                   const float* __restrict__ rough, const float* __restrict__ spec,
+                                                                   const float* __restrict__ soft_vis, const float* __restrict__ env,
+                                                                   float eps_dot, float weight, const float* __restrict__ g,
+                                                                   float* __restrict__ g_normal, float* __restrict__ g_rough,
+                                                                   float* __restrict__ g_spec, float* __restrict__ g_soft_vis,
+                                                                   float* __restrict__ g_env) {
+  __shared__ float red[2];
+  const long long r = blockIdx.x;
+  const float nx = normal[r * 3], ny = normal[r * 3 + 1], nz = normal[r * 3 + 2];
+  const float vx = view[r * 3], vy = view[r * 3 + 1], vz = view[r * 3 + 2];
+  const float ro = rough[r];
+  const float wM = weight / (float)M;
+  float gk[3], sc[3];
+  for (int k = 0; k < 3; ++k) { gk[k] = g[r * 3 + k] * wM; sc[k] = spec[r * 3 + k]; }
+  float gn[3] = {0.f, 0.f, 0.f}, ga2 = 0.f, gsc[3] = {0.f, 0.f, 0.f};
+  for (int m = threadIdx.x; m < M; m += SH_THREADS) {
+    const long long e = r * M + m;
+    const float lx = light[e * 3], ly = light[e * 3 + 1], lz = light[e * 3 + 2];
+    SpecTerms t = spec_terms(nx, ny, nz, vx, vy, vz, lx, ly, lz, ro, eps_dot);
+    const float V = t.V1l * t.V1v;
+    const float omv = 1.f - t.voh;
+    const float f4 = omv * omv * omv * omv, f5 = f4 * omv;
+    const float Kf = 4.f * t.voh / t.noh * t.mask;
+    const float sv = soft_vis[e];
+    // out_k += sB_k * T_k,  sB_k = V Fs_k Kf,  T_k = sv env_k nol
+    float dV = 0.f, dK = 0.f, dFsum = 0.f /* sum_k dFs_k (1 - sc_k) */, dnol = 0.f, dsv = 0.f;
+    float denv[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; ++k) {
+      const float ek = env[e * C + (C == 1 ? 0 : k)];
+      const float Fs = sc[k] + (1.f - sc[k]) * f5;
+      const float sB = V * Fs * Kf;
+      const float dsB = gk[k] * sv * ek * t.nol;
+      dsv += gk[k] * sB * ek * t.nol;
+      denv[C == 1 ? 0 : k] += gk[k] * sB * sv * t.nol;
+      dnol += gk[k] * sB * sv * ek;
+      dV += dsB * Fs * Kf;
+      dK += dsB * V * Fs;
+      const float dFs = dsB * V * Kf;
+      gsc[k] += dFs * (1.f - f5);
+      dFsum += dFs * (1.f - sc[k]);
+    }
+    g_soft_vis[e] = dsv;
+    for (int k = 0; k < C; ++k) g_env[e * C + k] = denv[k];
+    // Kf = 4 voh / noh * mask ; Fs depends on voh -- voh only reaches h (no gradient) -> dropped
+    const float dnoh = -dK * 4.f * t.voh / (t.noh * t.noh) * t.mask;
+    (void)dFsum;
+    // V = V1(nol) V1(nov);  V1(u) = 1 / (u + sqrt(a2 + (1 - a2) u^2) + eps)
+    const float dV1l = dV * t.V1v, dV1v = dV * t.V1l;
+    const float om = 1.f - t.a2;
+    dnol += dV1l * (-t.V1l * t.V1l) * (1.f + om * t.nol / t.sl);
+    const float dnov = dV1v * (-t.V1v * t.V1v) * (1.f + om * t.nov / t.sv_);
+    ga2 += dV1l * (-t.V1l * t.V1l) * (1.f - t.nol * t.nol) / (2.f * t.sl) + dV1v * (-t.V1v * t.V1v) * (1.f - t.nov * t.nov) / (2.f * t.sv_);
+    // clamped dots -> normal (clamp(min) passes the gradient where raw >= eps)
+    const float cl = (t.rnol >= eps_dot) ? dnol : 0.f, cv = (t.rnov >= eps_dot) ? dnov : 0.f, ch = (t.rnoh >= eps_dot) ? dnoh : 0.f;
+    gn[0] += cl * lx + cv * vx + ch * t.hx;
+    gn[1] += cl * ly + cv * vy + ch * t.hy;
+    gn[2] += cl * lz + cv * vz + ch * t.hz;
+  }
+  for (int k = 0; k < 3; ++k) {
+    const float s = sh_block_sum(gn[k], red);
+    if (threadIdx.x == 0) g_normal[r * 3 + k] = s;
+  }
+  for (int k = 0; k < 3; ++k) {
+    const float s = sh_block_sum(gsc[k], red);
+    if (threadIdx.x == 0) g_spec[r * 3 + k] = s;
+  }
+  {
+    const float s = sh_block_sum(ga2, red);
+    if (threadIdx.x == 0) g_rough[r] = s * 2.f * ro;      // a2 = roughness^2
+  }
+}
+
+}  // namespace ndjir
+
+extern "C" int ndjir_render_diffuse_light(int R, int M, int C, const float* normal, const float* light_dir, const float* soft_vis,
+                                          const float* env, float eps_dot, float* out, hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  if (M < 1 || C < 1 || C > 3) return NDJIR_ERR_UNSUPPORTED;
+  if (!normal || !light_dir || !soft_vis || !env || !out) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_diffuse_light, dim3(R), dim3(SH_THREADS), 0, stream, M, C, normal, light_dir, soft_vis, env, eps_dot, out);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_diffuse_light_backward(int R, int M, int C, const float* normal, const float* light_dir,
+                                                   const float* soft_vis, const float* env, float eps_dot, const float* g,
+                                                   float* g_normal, float* g_soft_vis, float* g_env, hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  if (M < 1 || C < 1 || C > 3) return NDJIR_ERR_UNSUPPORTED;
+  if (!normal || !light_dir || !soft_vis || !env || !g || !g_normal || !g_soft_vis || !g_env) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_diffuse_light_bwd, dim3(R), dim3(SH_THREADS), 0, stream, M, C, normal, light_dir, soft_vis, env, eps_dot, g,
+                     g_normal, g_soft_vis, g_env);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_specular_light_filament(int R, int M, int C, const float* normal, const float* view_dir,
+                                                    const float* light_dir, const float* roughness, const float* specular_color,
+                                                    const float* soft_vis, const float* env, float eps_dot, float weight,
+                                                    float* out, hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  if (M < 1 || (C != 1 && C != 3)) return NDJIR_ERR_UNSUPPORTED;
+  if (!normal || !view_dir || !light_dir || !roughness || !specular_color || !soft_vis || !env || !out) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_specular_light, dim3(R), dim3(SH_THREADS), 0, stream, M, C, normal, view_dir, light_dir, roughness,
+                     specular_color, soft_vis, env, eps_dot, weight, out);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_specular_light_filament_backward(int R, int M, int C, const float* normal, const float* view_dir,
+                                                             const float* light_dir, const float* roughness,
+                                                             const float* specular_color, const float* soft_vis, const float* env,
+                                                             float eps_dot, float weight, const float* g, float* g_normal,
+                                                             float* g_roughness, float* g_specular_color, float* g_soft_vis,
+                                                             float* g_env, hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  if (M < 1 || (C != 1 && C != 3)) return NDJIR_ERR_UNSUPPORTED;
+  if (!normal || !view_dir || !light_dir || !roughness || !specular_color || !soft_vis || !env || !g || !g_normal ||
+      !g_roughness || !g_specular_color || !g_soft_vis || !g_env)
+    return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_specular_light_bwd, dim3(R), dim3(SH_THREADS), 0, stream, M, C, normal, view_dir, light_dir, roughness,
+                     specular_color, soft_vis, env, eps_dot, weight, g, g_normal, g_roughness, g_specular_color, g_soft_vis, g_env);
+  return ndjir_check_launch();
+}

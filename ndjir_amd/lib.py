@@ -45,6 +45,10 @@ SIGS = {
     "render_alpha_weights": "iii" + "p" * 11,
     "render_alpha_weights_backward": "iii" + "p" * 16,
     "render_integrate": "iiipipp",
+    "render_diffuse_light": "iiippppfp",
+    "render_diffuse_light_backward": "iiippppfpppp",
+    "render_specular_light_filament": "iii" + "p" * 7 + "ffp",
+    "render_specular_light_filament_backward": "iii" + "p" * 7 + "ff" + "p" * 6,
     "render_integrate_backward": "iiipippppi",
     "sampler_importance_round": "iiifpppppqqp",
     "ray_aabb_intersection": "ipppppiiFF",

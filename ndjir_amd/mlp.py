@@ -230,12 +230,18 @@ class FusedMLP(Function):
                 wide = torch.empty((P, A[j].shape[1]), device=x2.device, dtype=torch.float32)
                 side_out[bwd_skip] = wide
                 deltas[skip_layer] = wide[:, :split]
+            ldg = K0
             if need_x:
-                gx = torch.zeros((P, K0), device=x2.device, dtype=torch.float32) if bwd_skip >= 0 else \
-                    torch.empty((P, K0), device=x2.device, dtype=torch.float32)
+                if bwd_skip >= 0:
+                    gx = torch.zeros((P, K0), device=x2.device, dtype=torch.float32)
+                else:
+                    # rows padded to 16 bytes: the output layer then stores float4 (K0 = 259, 262, 301 ...)
+                    ldg = (K0 + 3) // 4 * 4
+                    gx = torch.empty((P, ldg), device=x2.device, dtype=torch.float32)[:, :K0]
             flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
             _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
-                     side_in, side_out, ld_side, bg, gx, K0, 1 if bwd_skip >= 0 else 0, 1 if need_x else 0,
+                     side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
+                     1 if bwd_skip >= 0 else 0, 1 if need_x else 0,
                      float(beta), int(bwd_skip), float(skip_scale), int(split),
                      gx if bwd_skip >= 0 else None, K0, chain_workspace(x2.device, bg),
                      shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)))
@@ -247,7 +253,7 @@ class FusedMLP(Function):
                     gW[j] = wgrad(A[j], deltas[j])
                 if ctx.needs_input_grad[4 + L + j]:
                     gb[j] = bgrads[j] if j < L - 1 else colsum(gy2)
-        return (gx.view(xshape) if gx is not None else None, None, None, None, *gW, *gb)
+        return (gx.reshape(xshape) if gx is not None else None, None, None, None, *gW, *gb)
 
 
 def fused_mlp(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0):

@@ -21,7 +21,7 @@ from .network import (background_network, base_color_network, environment_light_
                       soft_visibility_light_network, specular_reflectance_network)
 from .sampler import sample_importance_directions, sample_points, sample_uniform_directions
 from .specular_brdf import dot, specular_brdf_model
-from .volume import alpha_weights, integrate
+from .volume import alpha_weights, diffuse_light, integrate, specular_light_filament
 
 
 def make_rand(B, R, conf, device, n_fg=None, include_samples=True):
@@ -98,8 +98,8 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     implicit_pixel = VR(implicit)
 
     # Diffuse colour (renderer.py:117-120)
-    cos = dot(normal_bc, uniform_light_dir)
-    env_pixel = (soft_vis * env * cos).mean(dim=2)
+    # mean_m soft_vis * env * clamp(n.l): one fused launch (csrc/render.hip) instead of dot/clamp/mul/mean
+    env_pixel = diffuse_light(normal_pixel, uniform_light_dir, soft_vis, env, conf.renderer.eps_dot)
     diffuse_light_pixel = env_pixel + implicit_pixel
     base_color = base_color_network(x_fg, feature_x_fg, grad_x_fg, conf)
 
@@ -115,17 +115,24 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
                                                roughness_pixel)
     else:
         imp_dir = sample_uniform_directions(normal_pixel, rand["specular_cdf_the"], rand["specular_cdf_phi"])
-    sBRDF, cos = specular_brdf_model(normal_pixel, view_dir, imp_dir, roughness_pixel, spec_refl_pixel, conf)
     env = environment_light_network(imp_dir, conf)
     soft_vis = soft_visibility_light_network(x_fg_pixel, imp_dir, feature_pixel, normal_bc, conf)
-    if conf.specular_brdf.use_split_sum:
-        spec_pixel = (soft_vis * env).mean(dim=2) * (sBRDF * cos).mean(dim=2)
-    else:
-        spec_pixel = (sBRDF * soft_vis * env * cos).mean(dim=2)
     ii = conf.implicit_illumination_network
-    if ii.use_me and ii.use_me_on_specular:
-        spec_pixel = spec_pixel + (sBRDF * implicit_pixel[:, :, :, None]).mean(dim=2)
-    spec_pixel = conf.specular_brdf.weight * spec_pixel
+    sb = conf.specular_brdf
+    if (sb.model == "filament" and sb.sampling == "importance" and not sb.use_split_sum
+            and not (ii.use_me and ii.use_me_on_specular) and env.shape[-1] in (1, 3) and spec_refl_pixel.shape[-1] == 3):
+        # the default configuration: BRDF algebra and the light integral fused (csrc/render.hip)
+        spec_pixel = specular_light_filament(normal_pixel, view_dir.reshape(B, R, 3), imp_dir, roughness_pixel,
+                                             spec_refl_pixel, soft_vis, env, conf.renderer.eps_dot, sb.weight)
+    else:
+        sBRDF, cos = specular_brdf_model(normal_pixel, view_dir, imp_dir, roughness_pixel, spec_refl_pixel, conf)
+        if sb.use_split_sum:
+            spec_pixel = (soft_vis * env).mean(dim=2) * (sBRDF * cos).mean(dim=2)
+        else:
+            spec_pixel = (sBRDF * soft_vis * env * cos).mean(dim=2)
+        if ii.use_me and ii.use_me_on_specular:
+            spec_pixel = spec_pixel + (sBRDF * implicit_pixel[:, :, :, None]).mean(dim=2)
+        spec_pixel = sb.weight * spec_pixel
 
     # Diffuse + specular composition (renderer.py:163-176)
     if conf.photogrammetric_light_network.use_me:

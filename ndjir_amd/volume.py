@@ -92,3 +92,65 @@ class Integrate(Function):
 
 def integrate(weights, x, off=0):
     return Integrate.apply(weights, off, x)
+
+
+class DiffuseLight(Function):
+    """renderer.py:117-118: mean over the M light directions of soft_vis * env * clamp(n.l, eps).
+    normal (B,R,3), light_dir (B,R,M,3) [no grad], soft_vis (B,R,M,1), env (B,R,M,C) -> (B,R,C)."""
+
+    @staticmethod
+    def forward(ctx, normal, light_dir, soft_vis, env, eps_dot):
+        B, R, M, C = env.shape
+        args = [_c(normal), _c(light_dir), _c(soft_vis), _c(env)]
+        out = torch.empty((B, R, C), device=env.device, dtype=torch.float32)
+        lib.call("render_diffuse_light", B * R, M, C, *args, float(eps_dot), out)
+        ctx.save_for_backward(*args)
+        ctx.cfg = (B, R, M, C, float(eps_dot))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        B, R, M, C, eps = ctx.cfg
+        normal, light, sv, env = ctx.saved_tensors
+        gn = torch.empty_like(normal)
+        gsv = torch.empty_like(sv)
+        genv = torch.empty_like(env)
+        lib.call("render_diffuse_light_backward", B * R, M, C, normal, light, sv, env, eps, g.contiguous(), gn, gsv, genv)
+        return gn, None, gsv, genv, None
+
+
+def diffuse_light(normal, light_dir, soft_vis, env, eps_dot):
+    return DiffuseLight.apply(normal, light_dir, soft_vis, env, eps_dot)
+
+
+class SpecularLightFilament(Function):
+    """renderer.py:136-161 for model=filament, sampling=importance, use_split_sum=false:
+    weight * mean_m( sBRDF * soft_vis * env * clamp(n.l, eps) ), BRDF per specular_brdf.py:40-118.
+    normal, view_dir (B,R,3); light_dir (B,R,M,3); roughness (B,R,1); specular_color (B,R,3);
+    soft_vis (B,R,M,1); env (B,R,M,C) with C = 1 or 3 -> (B,R,3)."""
+
+    @staticmethod
+    def forward(ctx, normal, view_dir, light_dir, roughness, specular_color, soft_vis, env, eps_dot, weight):
+        B, R, M, C = env.shape
+        args = [_c(normal), _c(view_dir), _c(light_dir), _c(roughness), _c(specular_color), _c(soft_vis), _c(env)]
+        out = torch.empty((B, R, 3), device=env.device, dtype=torch.float32)
+        lib.call("render_specular_light_filament", B * R, M, C, *args, float(eps_dot), float(weight), out)
+        ctx.save_for_backward(*args)
+        ctx.cfg = (B, R, M, C, float(eps_dot), float(weight))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        B, R, M, C, eps, weight = ctx.cfg
+        normal, view, light, rough, spec, sv, env = ctx.saved_tensors
+        gn, gr, gs = torch.empty_like(normal), torch.empty_like(rough), torch.empty_like(spec)
+        gsv, genv = torch.empty_like(sv), torch.empty_like(env)
+        lib.call("render_specular_light_filament_backward", B * R, M, C, normal, view, light, rough, spec, sv, env, eps, weight,
+                 g.contiguous(), gn, gr, gs, gsv, genv)
+        return gn, None, None, gr, gs, gsv, genv, None, None
+
+
+def specular_light_filament(normal, view_dir, light_dir, roughness, specular_color, soft_vis, env, eps_dot, weight):
+    return SpecularLightFilament.apply(normal, view_dir, light_dir, roughness, specular_color, soft_vis, env, eps_dot, weight)

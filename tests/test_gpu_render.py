@@ -89,3 +89,70 @@ def test_integrate_matches_composite(gpu, R, S_all, off, S, C):
     gw32, gx32 = torch.autograd.grad(out, [w32, x32], g.float())
     assert float((gx32.double() - gx64).abs().max()) < 1e-5 * max(1.0, float(gx64.abs().max()))
     assert float((gw32.double() - gw64).abs().max()) < 1e-5 * max(1.0, float(gw64.abs().max()))
+
+
+def _light_inputs(B, R, M, C, seed, gpu):
+    rng = np.random.RandomState(seed)
+    f = lambda *s: torch.tensor(rng.randn(*s), dtype=torch.float64, device=gpu)
+    unit = lambda t: t / t.norm(dim=-1, keepdim=True)
+    normal = unit(f(B, R, 3))
+    view = unit(f(B, R, 3) + 1.5 * normal)          # mostly in the upper hemisphere, some grazing / below
+    light = unit(f(B, R, M, 3) + 1.0 * normal[:, :, None, :])
+    rough = torch.tensor(rng.rand(B, R, 1) * 0.9 + 0.05, dtype=torch.float64, device=gpu)
+    spec = torch.tensor(rng.rand(B, R, 3) * 0.16, dtype=torch.float64, device=gpu)
+    sv = torch.tensor(rng.rand(B, R, M, 1), dtype=torch.float64, device=gpu)
+    env = torch.tensor(rng.rand(B, R, M, C) * 2.0, dtype=torch.float64, device=gpu)
+    return normal, view, light, rough, spec, sv, env
+
+
+@pytest.mark.parametrize("B,R,M,C", [(1, 40, 128, 1), (2, 7, 32, 3), (1, 3, 200, 1)])
+def test_diffuse_light_matches_composite(gpu, B, R, M, C):
+    from ndjir_amd.specular_brdf import dot
+    from ndjir_amd.volume import diffuse_light
+    normal, _, light, _, _, sv, env = _light_inputs(B, R, M, C, 5 + M, gpu)
+    eps = 1e-8
+    a64 = [normal.clone().requires_grad_(True), light, sv.clone().requires_grad_(True), env.clone().requires_grad_(True)]
+    a32 = [t.detach().float().requires_grad_(t.requires_grad) for t in a64]
+    ref = (a64[2] * a64[3] * dot(a64[0][:, :, None, :].expand(B, R, M, 3), light, False, eps)).mean(dim=2)
+    out = diffuse_light(a32[0], a32[1], a32[2], a32[3], eps)
+    assert float((out.detach().double() - ref.detach()).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+    g = torch.tensor(np.random.RandomState(1).randn(B, R, C), dtype=torch.float64, device=gpu)
+    gref = torch.autograd.grad(ref, [a64[0], a64[2], a64[3]], g)
+    gout = torch.autograd.grad(out, [a32[0], a32[2], a32[3]], g.float())
+    for name, go, gr in zip(("normal", "soft_vis", "env"), gout, gref):
+        assert float((go.double() - gr).abs().max()) < 2e-5 * max(1.0, float(gr.abs().max())), name
+
+
+@pytest.mark.parametrize("B,R,M,C", [(1, 40, 128, 1), (2, 7, 32, 3), (1, 3, 200, 1)])
+def test_specular_light_matches_composite(gpu, B, R, M, C):
+    """fused filament specular integral vs specular_brdf.filament_specular_brdf + renderer.py:155 under autograd (fp64)."""
+    from types import SimpleNamespace as NS
+    from ndjir_amd.specular_brdf import filament_specular_brdf
+    from ndjir_amd.volume import specular_light_filament
+    normal, view, light, rough, spec, sv, env = _light_inputs(B, R, M, C, 9 + M, gpu)
+    eps, weight = 1e-8, 0.7
+    conf = NS(renderer=NS(eps_dot=eps), specular_brdf=NS(sampling="importance"))
+    req = (0, 3, 4, 5, 6)
+    a64 = [t.clone().requires_grad_(i in req) for i, t in enumerate((normal, view, light, rough, spec, sv, env))]
+    a32 = [t.detach().float().requires_grad_(i in req) for i, t in enumerate(a64)]
+
+    def composite(n, v, l, r, s, sv_, e):
+        sB, cos = filament_specular_brdf(n, v.reshape(B, R, 1, 3), l, r, s, conf)
+        return weight * (sB * sv_ * e * cos).mean(dim=2)
+
+    ref = composite(*a64)
+    out = specular_light_filament(*a32, eps, weight)
+    stock = composite(*[t.detach().float() for t in a64])
+    err = float((out.detach().double() - ref.detach()).abs().max())
+    err_stock = float((stock.double() - ref.detach()).abs().max())
+    assert err < max(4.0 * err_stock, 1e-6 * max(1.0, float(ref.abs().max()))), (err, err_stock)
+    g = torch.tensor(np.random.RandomState(2).randn(B, R, 3), dtype=torch.float64, device=gpu)
+    gref = torch.autograd.grad(ref, [a64[i] for i in req], g)
+    gout = torch.autograd.grad(out, [a32[i] for i in req], g.float())
+    a32s = [t.detach().float().requires_grad_(i in req) for i, t in enumerate(a64)]
+    gstock = torch.autograd.grad(composite(*a32s), [a32s[i] for i in req], g.float())
+    for name, go, gr, gs in zip(("normal", "roughness", "specular_color", "soft_vis", "env"), gout, gref, gstock):
+        scale = max(float(gr.abs().max()), 1e-6)
+        e1 = float((go.double() - gr).abs().max()) / scale
+        e2 = float((gs.double() - gr).abs().max()) / scale
+        assert e1 < max(4.0 * e2, 2e-5), (name, e1, e2)
