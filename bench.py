@@ -15,7 +15,11 @@ sum of the algorithmic FLOPs (2*in*out per affine per point) of its l
 their durations, measured live with HIP events recorded on the launching stream around every launch
 inside the timed region.  In the default bf16x6 arithmetic one algorithmic FLOP costs six bf16 MFMA
 FLOPs, so the peak it is priced against is the dense bf16 MFMA peak / 6.
-`hip_graph` (single GPU) re-measures the same step replayed from one captured HIP graph.
+Execution: on one GPU the step is captured once into a HIP graph and the timed region replays it
+(`--exec graph`, default; no host-side launch work in the timed region); HIP events cannot be
+recorded inside a captured graph, so `roofline` / `kernels` come from the same K steps issued eagerly
+right after (`eager` reports their wall time).  `--exec eager` (default for N > 1) times ordinary
+stream launches with the events inside the timed region.
 """
 import argparse
 import json
@@ -46,7 +50,10 @@ def parse():
     ap.add_argument("--config", default="default")
     ap.add_argument("--override", action="append", default=[])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="skip the extra HIP-graph replay measurement (single GPU)")
+    ap.add_argument("--exec", dest="exec_mode", choices=["graph", "eager"], default=None,
+                    help="how the timed steps are issued: 'graph' = the step is captured once into a HIP graph and the "
+                         "timed region replays it (default on 1 GPU); 'eager' = ordinary stream launches (default on N > 1, "
+                         "where the gradient exchange runs over RCCL between steps)")
     ap.add_argument("--cpu-rays", type=int, default=32)
     return ap.parse_args()
 
@@ -155,10 +162,9 @@ def cpu_baseline(conf, step, n_rays):
                        f"{cores} of {os.cpu_count()} host cores, {el:.1f} s")
 
 
-def graph_replay(step, steps):
-    """The same step captured once into a HIP graph (torch.cuda.CUDAGraph: forward, backward and every
-    custom launch are stream-ordered and allocation-stable) and replayed `steps` times: what the step
-    costs without host-side launch overhead.  Informational; `value` is the eager number."""
+def capture_step(step):
+    """Capture one whole step (sampling, forward, loss, backward to every parameter gradient -- all
+    custom launches are stream-ordered and allocation-stable) into a HIP graph."""
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -170,13 +176,7 @@ def graph_replay(step, steps):
         loss = step.forward_backward()
     g.replay()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        g.replay()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    return {"ms_per_step": 1e3 * el / steps, "rays_per_s": step.R * steps / el, "loss": float(loss),
-            "note": "same step, one hipGraphLaunch per step"}
+    return g, loss
 
 
 def kernel_report(profile):
@@ -232,16 +232,39 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    exec_mode = a.exec_mode or ("graph" if world == 1 else "eager")
+    if exec_mode == "graph" and world > 1:
+        raise SystemExit("--exec graph is single-GPU only (the RCCL gradient exchange is issued between steps)")
     for _ in range(a.warmup):
         step.forward_backward()
-    barrier()
-    mlp.PROFILE = [] if rank == 0 else None
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step.forward_backward()
-    barrier()
-    el = time.perf_counter() - t0
-    profile, mlp.PROFILE = mlp.PROFILE, None
+    eager = None
+    if exec_mode == "graph":
+        graph, loss = capture_step(step)              # untimed, like the warm-up
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            graph.replay()
+        barrier()
+        el = time.perf_counter() - t0
+        # HIP events cannot be recorded inside a captured graph: the same K steps are issued once more as
+        # ordinary stream launches, with events around every engine launch, for `roofline` / `kernels`
+        mlp.PROFILE = []
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step.forward_backward()
+        barrier()
+        eager = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / a.steps,
+                 "note": "same K steps as ordinary stream launches (with the HIP-event instrumentation)"}
+        profile, mlp.PROFILE = mlp.PROFILE, None
+    else:
+        barrier()
+        mlp.PROFILE = [] if rank == 0 else None
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = step.forward_backward()
+        barrier()
+        el = time.perf_counter() - t0
+        profile, mlp.PROFILE = mlp.PROFILE, None
     if world > 1:
         t = torch.tensor([el], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -280,18 +303,20 @@ def main():
                          "kernel": kname, "peak_note": peak_note,
                          "launches_per_step": dom["launches"] / max(a.steps, 1), "avg_launch_us": dom["avg_us"],
                          "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
-                         "method": "HIP events on the launching stream around every launch in the timed region"},
+                         "method": ("HIP events on the launching stream around every launch of the same K steps issued "
+                                    "eagerly right after the timed graph replays (events cannot be recorded inside a "
+                                    "captured graph)") if exec_mode == "graph" else
+                                   "HIP events on the launching stream around every launch in the timed region"},
             "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kr.items()},
             "step_roofline": {"achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
                               "frac": step_tflops / peak,
                               "scope": "whole step: 2168.9 MFLOP/ray fwd+bwd (SURVEY 8d) / step time"},
             "loss": float(loss),
         }
-        if world == 1 and not a.no_graph:
-            try:
-                out["hip_graph"] = graph_replay(step, a.steps)
-            except Exception as e:      # informational only
-                out["hip_graph"] = {"error": f"{type(e).__name__}: {e}"}
+        out["execution"] = ("one captured HIP graph per step (torch.cuda.CUDAGraph), K replays timed" if exec_mode == "graph"
+                            else "eager stream launches")
+        if eager is not None:
+            out["eager"] = eager
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(conf, step, a.cpu_rays)
