@@ -255,6 +255,12 @@ int ndjir_render_specular_light_filament_backward(int R, int M, int C, const flo
                                                   const float* g, float* g_normal, float* g_roughness, float* g_specular_color,
                                                   float* g_soft_vis, float* g_env, hipStream_t stream);
 
+/* Positional encoding (python/network.py:96-117): out (P, [C +] 2 C M) = [x, cos(x_i 2^k), sin(x_i 2^k)],
+ * band index k fastest; backward gx (P,C) from g (P, [C +] 2 C M). */
+int ndjir_positional_encoding(long long P, int C, int M, int include_input, const float* x, float* out, hipStream_t stream);
+int ndjir_positional_encoding_backward(long long P, int C, int M, int include_input, const float* x, const float* g,
+                                       float* gx, hipStream_t stream);
+
 /* ---- fused MLP engine ------------------------------------------------------------------------------
  * Replaces the reference's per-layer nnabla launches (PF.affine -> cuBLAS GEMM, F.softplus(beta=100),
  * python/network.py:88-93,165 and every network function :154-561) by ONE launch per net and

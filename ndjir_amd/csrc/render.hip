@@ -530,3 +530,70 @@ extern "C" int ndjir_render_specular_light_filament_backward(int R, int M, int C
                      specular_color, soft_vis, env, eps_dot, weight, g, g_normal, g_roughness, g_specular_color, g_soft_vis, g_env);
   return ndjir_check_launch();
 }
+
+// ---- positional encoding (python/network.py:96-117) ----------------------------------------------------
+// out[p] = [x (C), cos(x_i 2^k) (C*M, band fastest), sin(x_i 2^k) (C*M)]; the reference builds it from
+// a broadcast multiply, cos, sin and a concatenate.  One thread per output element.
+namespace ndjir {
+
+__global__ void __launch_bounds__(256) k_posenc(long long P, int C, int M, int include_input, const float* __restrict__ x,
+                                                float* __restrict__ out) {
+  const int CM = C * M, W = (include_input ? C : 0) + 2 * CM;
+  const long long total = P * W;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long p = t / W;
+    int c = (int)(t - p * W);
+    float v;
+    if (include_input && c < C) v = x[p * C + c];
+    else {
+      c -= include_input ? C : 0;
+      const bool is_sin = c >= CM;
+      if (is_sin) c -= CM;
+      const float b = x[p * C + c / M] * (float)(1 << (c % M));
+      v = is_sin ? sinf(b) : cosf(b);
+    }
+    out[t] = v;
+  }
+}
+
+// gx[p][i] = g_x[p][i] + sum_k 2^k ( -sin(b) g_cos + cos(b) g_sin )
+__global__ void __launch_bounds__(256) k_posenc_bwd(long long P, int C, int M, int include_input, const float* __restrict__ x,
+                                                    const float* __restrict__ g, float* __restrict__ gx) {
+  const int CM = C * M, W = (include_input ? C : 0) + 2 * CM, off = include_input ? C : 0;
+  const long long total = P * C;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long p = t / C;
+    const int i = (int)(t - p * C);
+    const float xv = x[t];
+    const float* gp = g + p * W;
+    float acc = include_input ? gp[i] : 0.f;
+    for (int k = 0; k < M; ++k) {
+      const float s = (float)(1 << k), b = xv * s;
+      acc += s * (-sinf(b) * gp[off + i * M + k] + cosf(b) * gp[off + CM + i * M + k]);
+    }
+    gx[t] = acc;
+  }
+}
+
+}  // namespace ndjir
+
+extern "C" int ndjir_positional_encoding(long long P, int C, int M, int include_input, const float* x, float* out,
+                                         hipStream_t stream) {
+  if (P <= 0 || C <= 0) return NDJIR_OK;
+  if (M < 0 || M > 30 || !x || !out) return NDJIR_ERR_ARG;
+  const long long total = P * ((include_input ? C : 0) + 2LL * C * M);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_posenc, dim3((unsigned)blocks), dim3(256), 0, stream, P, C, M, include_input, x, out);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_positional_encoding_backward(long long P, int C, int M, int include_input, const float* x, const float* g,
+                                                  float* gx, hipStream_t stream) {
+  if (P <= 0 || C <= 0) return NDJIR_OK;
+  if (M < 0 || M > 30 || !x || !g || !gx) return NDJIR_ERR_ARG;
+  long long blocks = (P * C + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_posenc_bwd, dim3((unsigned)blocks), dim3(256), 0, stream, P, C, M, include_input, x, g, gx);
+  return ndjir_check_launch();
+}

@@ -45,6 +45,8 @@ SIGS = {
     "render_alpha_weights": "iii" + "p" * 11,
     "render_alpha_weights_backward": "iii" + "p" * 16,
     "render_integrate": "iiipipp",
+    "positional_encoding": "liiipp",
+    "positional_encoding_backward": "liiippp",
     "render_diffuse_light": "iiippppfp",
     "render_diffuse_light_backward": "iiippppfpppp",
     "render_specular_light_filament": "iii" + "p" * 7 + "ffp",

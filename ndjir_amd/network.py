@@ -16,6 +16,7 @@ import numpy as np
 import torch
 import torch.nn.functional as TF
 
+from . import lib
 from . import parameter as P
 from . import parametric_functions as PF
 # these imports attach the ops to the F / PF namespaces (network.py:25-33)
@@ -97,8 +98,34 @@ def _act(name):
     return {"relu": torch.relu, "softplus": softplus}[name]
 
 
+class _PosEnc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, M, include_input):
+        C = x.shape[-1]
+        xc = x.detach().contiguous()
+        P_ = xc.numel() // C
+        out = torch.empty(x.shape[:-1] + ((C if include_input else 0) + 2 * C * M,), device=x.device, dtype=torch.float32)
+        lib.call("positional_encoding", P_, C, M, int(include_input), xc, out)
+        ctx.save_for_backward(xc)
+        ctx.cfg = (P_, C, M, int(include_input))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        P_, C, M, inc = ctx.cfg
+        gx = torch.empty_like(xc)
+        lib.call("positional_encoding_backward", P_, C, M, inc, xc, g.contiguous(), gx)
+        return gx, None, None
+
+
 def positional_encoding(x, M=6, include_input=True):
-    """network.py:96-117: [x, cos(x_i 2^k), sin(x_i 2^k)] with the band index fastest."""
+    """network.py:96-117: [x, cos(x_i 2^k), sin(x_i 2^k)] with the band index fastest (one HIP launch)."""
+    # inputs that carry a gradient stay on the stock-op composite: the geometric network differentiates
+    # THROUGH this function twice (nn.grad, renderer.py:52), the kernel's backward is first-order only
+    if x.is_cuda and x.dtype == torch.float32 and not x.requires_grad:
+        return _PosEnc.apply(x, int(M), bool(include_input))
     bands = 2.0 ** torch.arange(0, M, dtype=x.dtype, device=x.device)
     b = (bands.reshape((1,) * x.dim() + (M,)) * x.unsqueeze(-1)).reshape(x.shape[:-1] + (-1,))
     g = [x, torch.cos(b), torch.sin(b)] if include_input else [torch.cos(b), torch.sin(b)]

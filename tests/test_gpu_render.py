@@ -156,3 +156,23 @@ def test_specular_light_matches_composite(gpu, B, R, M, C):
         e1 = float((go.double() - gr).abs().max()) / scale
         e2 = float((gs.double() - gr).abs().max()) / scale
         assert e1 < max(4.0 * e2, 2e-5), (name, e1, e2)
+
+
+@pytest.mark.parametrize("shape,M,inc", [((1, 50, 128, 3), 6, True), ((7, 3), 4, True), ((2, 9, 5, 4), 6, False), ((11, 3), 0, True)])
+def test_positional_encoding_kernel(gpu, shape, M, inc):
+    """fused PE vs the stock-op composite of network.py:96-117 (value and input gradient)."""
+    from ndjir_amd.network import positional_encoding
+    rng = np.random.RandomState(4)
+    x64 = torch.tensor(rng.randn(*shape), dtype=torch.float64, device=gpu, requires_grad=True)
+    x32 = x64.detach().float().requires_grad_(True)
+    from ndjir_amd.network import _PosEnc
+    ref = positional_encoding(x64, M, inc)           # fp64 -> stock ops
+    out = _PosEnc.apply(x32, M, inc)                 # the HIP kernel (used by the product for inputs without gradient)
+    assert torch.equal(positional_encoding(x32.detach(), M, inc), out.detach())
+    assert out.shape == ref.shape
+    # |x 2^k| up to ~100: fp32 argument rounding limits cos/sin to ~1e-5
+    assert float((out.double() - ref).abs().max()) < 2e-5
+    g = torch.tensor(rng.randn(*ref.shape), dtype=torch.float64, device=gpu)
+    (gr,) = torch.autograd.grad(ref, x64, g)
+    (go,) = torch.autograd.grad(out, x32, g.float())
+    assert float((go.double() - gr).abs().max()) < 1e-3 * max(1.0, float(gr.abs().max()))
