@@ -81,6 +81,7 @@ class Step:
         self.car = torch.ones(1, device=device)
         self.P = P
         self.grid_bufs = {}
+        self.touched = None      # query points whose cells hold gradient from the previous step
         self.mlp_names = None
         self.forward_backward()          # creates the parameters (untimed)
         for name, p in P.get_parameters().items():
@@ -94,10 +95,25 @@ class Step:
         self.grid_params = [p for k, p in P.get_parameters().items() if k.endswith("feature/F")]
         self.flat_grad = torch.zeros(sum(p.numel() for p in self.mlp_params), device=device)
 
+    def rearm_grid_buffers(self):
+        """Zero the accumulate-in-place grid gradient buffers.  Linear dense voxel grid: only the cells the
+        previous step's query points touched (512^3 x 4 floats = 2 GiB would otherwise be rewritten every
+        step); anything else: dense."""
+        import math
+        from ndjir_amd.grid_feature import zero_touched
+        v = self.conf.geometric_network.voxel
+        for name, buf in self.grid_bufs.items():
+            if v.type == "voxel" and self.touched is not None:
+                x_fg = self.touched
+                r = self.conf.renderer.bounding_sphere_radius
+                zero_touched(buf, x_fg)
+                zero_touched(buf, x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size))
+            else:
+                buf.zero_()
+
     def forward_backward(self):
         from ndjir_amd.loss import total_loss
-        for buf in self.grid_bufs.values():
-            buf.zero_()
+        self.rearm_grid_buffers()
         out = total_loss(self.camloc, self.raydir, self.color_gt, None, self.car, self.conf, self.rand,
                          ray_shards=self.world)
         loss = out["loss"]
@@ -106,6 +122,12 @@ class Step:
             torch.autograd.grad(loss, params, allow_unused=True)
             return loss.detach()
         grads = torch.autograd.grad(loss, self.mlp_params + self.grid_params, allow_unused=True)
+        if self.grid_bufs:
+            # a persistent buffer (not the step's own tensor): a captured graph must find it at the same address
+            if self.touched is None:
+                self.touched = out["samples"]["x_fg"].detach().clone()
+            else:
+                self.touched.copy_(out["samples"]["x_fg"].detach())
         self.grads = grads               # the step's product: every parameter gradient, materialised
         if self.world == 1:
             return loss.detach()

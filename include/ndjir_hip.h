@@ -68,6 +68,11 @@ long long ndjir_hash_num_params(int G0, float growth_factor, int T0, int L, int 
                                           const float* min, const float* max, int boundary_check, int accum,               \
                                           hipStream_t stream);
 NDJIR_DECL_VOXEL_FAMILY(voxel_feature)
+/* No reference counterpart (nnabla zero-fills gradients densely): zero only the cells that the N query
+ * points (N x 3) touch in an accumulate-in-place gradient buffer of the linear dense voxel grid -- the
+ * 8 corners, which also cover the TV backward's cells -- instead of rewriting the whole buffer. */
+int ndjir_voxel_feature_zero_touched(int N, float* grad_feature, const float* query, const int* grid_sizes, int D,
+                                     const float* min, const float* max, hipStream_t stream);
 NDJIR_DECL_VOXEL_FAMILY(cosine_voxel_feature)
 NDJIR_DECL_VOXEL_FAMILY(lanczos_voxel_feature)
 

@@ -139,6 +139,15 @@ extern "C" int ndjir_voxel_feature_grad_query_grad_query(int N, float* gq, const
   CHECK_PTRS(gq, ggq, go, query, feature);
   return launch_voxel_gq_gq(voxel_desc(gs, D, mn, mx), N / D, gq, ggq, go, query, feature, st);
 }
+// No reference counterpart (the reference zero-fills gradients densely): zero only the cells the N query
+// points touch in an accumulate-in-place gradient buffer of the linear dense voxel grid.
+extern "C" int ndjir_voxel_feature_zero_touched(int N, float* gf, const float* query, const int* gs, int D, const float* mn,
+                                                const float* mx, hipStream_t st) {
+  if (N <= 0) return NDJIR_OK;
+  CHECK_PTRS(gf, query);
+  return launch_zero_touched(LINEAR, voxel_desc(gs, D, mn, mx), N, gf, query, st);
+}
+
 extern "C" int ndjir_voxel_feature_grad_feature_grad_grad_output(int N, float* ggo, const float* ggf, const float* query,
     const int* gs, int D, const float* mn, const float* mx, int bc, int accum, hipStream_t st) {
   (void)bc;

@@ -346,6 +346,26 @@ __global__ void __launch_bounds__(256) k_scatter(long long P, float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// zero the cells a set of queries touches (every tap of the stencil): re-arms an accumulate-in-place
+// gradient buffer after use without rewriting all of it (2 GiB for the default 512^3 x 4 grid).
+// Covers grad_feature, grad_query_grad_feature and the TV backward (its cells are a subset of the taps).
+// ------------------------------------------------------------------------------------------------
+template <int TOPO, int I, int VW>
+__global__ void __launch_bounds__(256) k_zero_touched(long long P, float* __restrict__ gf, const float* __restrict__ query,
+                                                      GridDesc g) {
+  constexpr int ND = NDims<TOPO>::v, NT = NTaps<I>::v;
+  NDJIR_GRID_THREAD_PROLOGUE
+  for (int d0 = 0; d0 < g.D; d0 += VW) {
+    NDJIR_FOR_TAPS(ND, NT) {
+      float* p = gf + cell_offset(st, i, j, k) + d0;
+#pragma unroll
+      for (int v = 0; v < VW; ++v) p[v] = 0.f;
+    }
+  }
+  NDJIR_GRID_THREAD_EPILOGUE
+}
+
+// ------------------------------------------------------------------------------------------------
 // grad_query_grad_query, linear dense voxel only (voxel_feature_cuda.cu:440-520). Accumulates.
 // ------------------------------------------------------------------------------------------------
 template <int VW>
@@ -532,6 +552,15 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
   NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
     if (mode == 0) hipLaunchKernelGGL((k_scatter<TOPO, I, VW, 0>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
     else hipLaunchKernelGGL((k_scatter<TOPO, I, VW, 1>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
+  }))
+  return ndjir_check_launch();
+}
+
+int launch_zero_touched(int interp, const GridDesc& g, long long P, float* gf, const float* query, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  int blocks = grid_blocks(P * g.S);
+  NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
+    hipLaunchKernelGGL((k_zero_touched<TOPO, I, VW>), dim3(blocks), dim3(256), 0, stream, P, gf, query, g);
   }))
   return ndjir_check_launch();
 }

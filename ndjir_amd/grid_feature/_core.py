@@ -62,6 +62,14 @@ def set_grad_buffer(feature, buf):
         _GRAD_BUFFERS[feature.data_ptr()] = buf
 
 
+def zero_touched(buf, query, min_=(-1, -1, -1), max_=(1, 1, 1)):
+    """Re-arm the accumulate-in-place gradient buffer `buf` (G0, G1, G2, D) of a linear dense voxel
+    grid: zero only the cells the `query` points (..., 3) touched (grad_feature,
+    grad_query_grad_feature and TV backward all stay inside the 8 corners) instead of the whole buffer."""
+    q = query.detach().reshape(-1, 3).contiguous()
+    lib.call("voxel_feature_zero_touched", q.shape[0], buf, q, list(buf.shape[:3]), buf.shape[3], list(min_), list(max_))
+
+
 def get_grad_buffer(feature):
     return _GRAD_BUFFERS.get(feature.data_ptr())
 

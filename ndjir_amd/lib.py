@@ -59,6 +59,7 @@ SIGS = {
     "inverse_transform_sample_importance_directions": "ipppppiiiif",
     "squareplus_forward": "ippf",
     "squareplus_backward": "ipppfi",
+    "voxel_feature_zero_touched": "ippIiFF",
     "voxel_feature_grad_query_grad_query": "ippppp" + _VOX_TAIL + "i",
     "voxel_feature_grad_feature_grad_grad_output": "ippp" + _VOX_TAIL + "i",
     "voxel_feature_grad_feature_grad_query": "ipppp" + _VOX_TAIL + "i",

@@ -251,3 +251,27 @@ def test_squareplus(gpu):
     np.testing.assert_allclose(y.detach().cpu().numpy(), 0.5 * (x + torch.sqrt(x * x + 4)).detach().cpu().numpy(), atol=1e-6)
     y.sum().backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), (0.5 * (1 + x / torch.sqrt(x * x + 4))).detach().cpu().numpy(), atol=1e-6)
+
+
+def test_zero_touched_rearms_the_grad_buffer(gpu):
+    """Everything the voxel backward kernels scatter (grad_feature, the second-order
+    grad_query_grad_feature, TV backward incl. sym_backward) lies inside the cells zero_touched clears."""
+    from ndjir_amd.grid_feature import _core, set_grad_buffer, zero_touched
+    rng = np.random.RandomState(7)
+    P, G, D = 3000, 16, 4
+    q = T((rng.rand(P, 3) * 2.4 - 1.2).astype(np.float32), gpu)          # incl. out-of-range queries
+    f = T((rng.randn(G, G, G, D) * 0.01).astype(np.float32), gpu).requires_grad_(True)
+    w = T(rng.randn(P, D).astype(np.float32), gpu)
+    buf = torch.zeros_like(f)
+    set_grad_buffer(f, buf)
+    try:
+        qg = q.clone().requires_grad_(True)
+        out = _core.query("voxel", qg, f)
+        (gq,) = _core.grad([out], [qg], [w])                             # differentiable d out / d query
+        loss = (out * w).sum() + (gq ** 2).sum() + _core.tv_loss("voxel", q, f, sym_backward=True).sum()
+        loss.backward()
+        assert int((buf != 0).sum()) > 0
+        zero_touched(buf, q)
+        assert int((buf != 0).sum()) == 0
+    finally:
+        set_grad_buffer(f, None)
