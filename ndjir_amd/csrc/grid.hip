@@ -13,6 +13,7 @@
 // Arithmetic definitions follow the reference kernels (file:line cited at each piece).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "grid.h"
@@ -346,6 +347,79 @@ __global__ void __launch_bounds__(256) k_scatter(long long P, float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same scatters for the linear stencils with D = 4, pre-aggregated per workgroup.  The fp32 atomics
+// of a scatter resolve in the memory-side cache (the 8 XCD L2s are not coherent) at a rate that bounds
+// the kernel; consecutive lanes are consecutive samples of a ray, which revisit cells (runs inside a
+// cell, and 4 of 8 corners shared with the next cell).  Each workgroup therefore accumulates its 256
+// points x 8 corners in an LDS hash table (cell -> float4, LDS atomics) and issues one global atomic
+// per distinct cell and channel.
+// ------------------------------------------------------------------------------------------------
+constexpr int AGG_HT = 4096;      // slots; at most 256 x 8 = 2048 insertions per pass
+
+template <int TOPO, int MODE>
+__global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restrict__ gf, const float* __restrict__ gg_query,
+                                                     const float* __restrict__ grad_output, const float* __restrict__ query,
+                                                     GridDesc g) {
+  constexpr int I = LINEAR, ND = NDims<TOPO>::v, NT = NTaps<I>::v;
+  __shared__ int keys[AGG_HT];
+  __shared__ float vals[AGG_HT * 4];
+  const long long total = P * g.S;
+  const long long per_pass = (long long)gridDim.x * 256;
+  for (long long base = (long long)blockIdx.x * 256; base < total; base += per_pass) {   // uniform per workgroup
+    for (int t = threadIdx.x; t < AGG_HT; t += 256) {
+      keys[t] = -1;
+      *reinterpret_cast<float4*>(vals + 4 * t) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const long long tid = base + threadIdx.x;
+    if (tid < total) {
+      const int s = (int)(tid / P);
+      const long long b = tid - (long long)s * P;
+      float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
+      Stencil<TOPO, I> st;
+      make_stencil<TOPO, I>(st, g, s, q);
+      float ggs[ND];
+      if constexpr (MODE == 1) {
+#pragma unroll
+        for (int a = 0; a < ND; ++a) ggs[a] = gg_query[b * 3 + st.axis[a]] * st.scale[a] * st.ax[a].gm;
+      }
+      float og[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) og[v] = grad_output[out_index<TOPO>(g, P, b, s, v)];
+      NDJIR_FOR_TAPS(ND, NT) {
+        float w;
+        if constexpr (MODE == 0) {
+          w = tap_w(st, i, j, k);
+        } else {
+          w = 0.f;
+#pragma unroll
+          for (int a = 0; a < ND; ++a) w += ggs[a] * tap_dw(st, a, i, j, k);
+        }
+        const int key = (int)(cell_offset(st, i, j, k) >> 2);       // cell index (D = 4 floats per cell)
+        unsigned slot = ((unsigned)key * 2654435761u) >> 20;        // 12 bits
+        while (true) {
+          const int old = atomicCAS(&keys[slot], -1, key);
+          if (old == -1 || old == key) break;
+          slot = (slot + 1) & (AGG_HT - 1);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) atomicAdd(&vals[4 * slot + v], og[v] * w);
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < AGG_HT; t += 256) {
+      const int key = keys[t];
+      if (key >= 0) {
+        float* p = gf + ((long long)key << 2);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) atomicAdd(p + v, vals[4 * t + v]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // zero the cells a set of queries touches (every tap of the stencil): re-arms an accumulate-in-place
 // gradient buffer after use without rewriting all of it (2 GiB for the default 512^3 x 4 grid).
 // Covers grad_feature, grad_query_grad_feature and the TV backward (its cells are a subset of the taps).
@@ -549,6 +623,18 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
                    const float* grad_output, const float* query, hipStream_t stream) {
   if (P <= 0) return NDJIR_OK;
   int blocks = grid_blocks(P * g.S);
+  static const bool no_agg = getenv("NDJIR_SCATTER_NO_AGG") != nullptr;      // A/B switch
+  if (interp == LINEAR && g.D == 4 && g.topo != HASH && !no_agg) {
+    // workgroup-aggregated path (dense cell index must fit 31 bits: 2^33 floats)
+#define NDJIR_AGG_CASE(T)                                                                                                  \
+    { if (mode == 0) hipLaunchKernelGGL((k_scatter_agg<T, 0>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g); \
+      else hipLaunchKernelGGL((k_scatter_agg<T, 1>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g); }
+    if (g.topo == VOXEL) NDJIR_AGG_CASE(VOXEL)
+    else if (g.topo == TRIPLANE) NDJIR_AGG_CASE(TRIPLANE)
+    else NDJIR_AGG_CASE(TRILINE)
+#undef NDJIR_AGG_CASE
+    return ndjir_check_launch();
+  }
   NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
     if (mode == 0) hipLaunchKernelGGL((k_scatter<TOPO, I, VW, 0>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
     else hipLaunchKernelGGL((k_scatter<TOPO, I, VW, 1>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
