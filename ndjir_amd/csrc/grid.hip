@@ -523,6 +523,78 @@ __global__ void __launch_bounds__(256) k_tv(long long P, float* __restrict__ dst
   NDJIR_GRID_THREAD_EPILOGUE
 }
 
+// TV backward with the workgroup-level LDS aggregation of k_scatter_agg (dense topologies, D = 4)
+template <int TOPO>
+__global__ void __launch_bounds__(256) k_tv_bwd_agg(long long P, float* __restrict__ dst, const float* __restrict__ grad_output,
+                                                    const float* __restrict__ query, const float* __restrict__ feature,
+                                                    GridDesc g, int sym_backward) {
+  constexpr int I = LINEAR, ND = NDims<TOPO>::v;
+  __shared__ int keys[AGG_HT];
+  __shared__ float vals[AGG_HT * 4];
+  const long long total = P * g.S;
+  const long long per_pass = (long long)gridDim.x * 256;
+  auto add = [&](long long off, const float* v4) {
+    const int key = (int)(off >> 2);
+    unsigned slot = ((unsigned)key * 2654435761u) >> 20;
+    while (true) {
+      const int old = atomicCAS(&keys[slot], -1, key);
+      if (old == -1 || old == key) break;
+      slot = (slot + 1) & (AGG_HT - 1);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) atomicAdd(&vals[4 * slot + v], v4[v]);
+  };
+  for (long long base = (long long)blockIdx.x * 256; base < total; base += per_pass) {
+    for (int t = threadIdx.x; t < AGG_HT; t += 256) {
+      keys[t] = -1;
+      *reinterpret_cast<float4*>(vals + 4 * t) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const long long tid = base + threadIdx.x;
+    if (tid < total) {
+      const int s = (int)(tid / P);
+      const long long b = tid - (long long)s * P;
+      float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
+      Stencil<TOPO, I> st;
+      make_stencil<TOPO, I>(st, g, s, q);
+      const long long o0 = cell_offset(st, 0, 0, 0);
+      long long oa[ND];
+      oa[0] = cell_offset(st, 1, 0, 0);
+      if constexpr (ND > 1) oa[1] = cell_offset(st, 0, 1, 0);
+      if constexpr (ND > 2) oa[2] = cell_offset(st, 0, 0, 1);
+      float f0[4], fa[ND][4], ga[ND][4], g0[4];
+      vload<4>(f0, feature + o0);
+#pragma unroll
+      for (int a = 0; a < ND; ++a) vload<4>(fa[a], feature + oa[a]);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        float del[ND], s2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) { del[a] = fa[a][v] - f0[v]; s2 += del[a] * del[a]; }
+        // total_variation_loss_cuda.cu:158-170: rsqrt(.. + 1e-12) evaluated in double
+        const double common = (double)grad_output[out_index<TOPO>(g, P, b, s, v)] * (1.0 / sqrt((double)s2 + 1e-12));
+        double gsum = 0.0;
+#pragma unroll
+        for (int a = 0; a < ND; ++a) { const double t = common * (double)del[a]; gsum += t; ga[a][v] = (float)t; }
+        g0[v] = (float)(-gsum);
+      }
+#pragma unroll
+      for (int a = 0; a < ND; ++a) add(oa[a], ga[a]);
+      if (sym_backward) add(o0, g0);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < AGG_HT; t += 256) {
+      const int key = keys[t];
+      if (key >= 0) {
+        float* p = dst + ((long long)key << 2);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) atomicAdd(p + v, vals[4 * t + v]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // hash_index (voxel_hash_feature_cuda.cu:54-100): 8 hashed corner indices as floats
 __global__ void __launch_bounds__(256) k_hash_index(long long P, float* __restrict__ out, const float* __restrict__ query,
                                                     GridDesc g) {
@@ -665,6 +737,13 @@ int launch_tv(const GridDesc& g, long long P, bool bwd, float* dst, const float*
               const float* feature, int sym_backward, hipStream_t stream) {
   if (P <= 0) return NDJIR_OK;
   int blocks = grid_blocks(P * g.S);
+  static const bool no_agg = getenv("NDJIR_SCATTER_NO_AGG") != nullptr;
+  if (bwd && g.D == 4 && g.topo != HASH && !no_agg) {
+    if (g.topo == VOXEL) hipLaunchKernelGGL((k_tv_bwd_agg<VOXEL>), dim3(blocks), dim3(256), 0, stream, P, dst, grad_output, query, feature, g, sym_backward);
+    else if (g.topo == TRIPLANE) hipLaunchKernelGGL((k_tv_bwd_agg<TRIPLANE>), dim3(blocks), dim3(256), 0, stream, P, dst, grad_output, query, feature, g, sym_backward);
+    else hipLaunchKernelGGL((k_tv_bwd_agg<TRILINE>), dim3(blocks), dim3(256), 0, stream, P, dst, grad_output, query, feature, g, sym_backward);
+    return ndjir_check_launch();
+  }
 #define NDJIR_TV_CASE(T)                                                                                         \
   NDJIR_DISPATCH_VW(pick_vw(g.D), {                                                                              \
     if (bwd) hipLaunchKernelGGL((k_tv<T, VW, true>), dim3(blocks), dim3(256), 0, stream, P, dst, grad_output, query, feature, g, sym_backward); \
