@@ -103,7 +103,8 @@ class Step:
         from ndjir_amd.grid_feature import zero_touched
         v = self.conf.geometric_network.voxel
         for name, buf in self.grid_bufs.items():
-            if v.type == "voxel" and self.touched is not None:
+            # (multi-GPU: the sparse exchange also deposits OTHER ranks' rows in this buffer -> dense zero)
+            if v.type == "voxel" and self.touched is not None and self.world == 1:
                 x_fg = self.touched
                 r = self.conf.renderer.bounding_sphere_radius
                 zero_touched(buf, x_fg)
