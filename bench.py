@@ -261,8 +261,15 @@ def main():
     for _ in range(a.warmup):
         step.forward_backward()
     eager = None
+    graph_error = None
     if exec_mode == "graph":
-        graph, loss = capture_step(step)              # untimed, like the warm-up
+        try:
+            graph, loss = capture_step(step)          # untimed, like the warm-up
+        except Exception as e:                        # capture is an optimisation: never lose the measurement to it
+            graph_error = f"{type(e).__name__}: {e}"
+            exec_mode = "eager"
+            torch.cuda.synchronize()
+    if exec_mode == "graph":
         barrier()
         t0 = time.perf_counter()
         for _ in range(a.steps):
@@ -340,6 +347,8 @@ def main():
                             else "eager stream launches")
         if eager is not None:
             out["eager"] = eager
+        if graph_error is not None:
+            out["graph_capture_error"] = graph_error
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(conf, step, a.cpu_rays)

@@ -347,11 +347,14 @@ static inline WgradPlan wgrad_plan(int K, int N) {
   return p;
 }
 
-// number of point-axis splits: ~1 workgroup (4 waves) of main-tile work per CU keeps every SIMD's matrix pipe busy
-static inline int pick_splits(int K, int N, long long P) {
+// number of point-axis splits.  fp32 engine: ~1 workgroup (4 waves) of main-tile work per CU keeps every
+// SIMD's matrix pipe busy (its LDS is double-buffered).  bf16x6 engine: 2 per CU -- its load/convert/store
+// phase is not overlapped inside a workgroup, a second resident workgroup fills it (measured 87 -> 72 us
+// at 256 x 256 x 65536).
+static inline int pick_splits(int K, int N, long long P, int target_blocks) {
   const WgradPlan pl = wgrad_plan(K, N);
   int T16 = pl.units < 16 ? 16 : pl.units;
-  int S = (256 * 16 + T16 - 1) / T16;
+  int S = (target_blocks * 16 + T16 - 1) / T16;
   long long max_s = (P + WG_C - 1) / WG_C;
   if (S > max_s) S = (int)max_s;
   if (S < 1) S = 1;
@@ -520,7 +523,7 @@ int launch_colsum(const float* X, int ldx, int N, long long P, float* out, int a
 }
 
 long long wgrad_workspace(int K, int N, long long P) {
-  long long splits = pick_splits(K, N, P);
+  long long splits = pick_splits(K, N, P, 512);      // the larger of the two engines' plans
   if (N <= SW_NMAX) {                                  // narrow path: one partial per SW_ROWS rows
     const long long nb = (P + SW_ROWS - 1) / SW_ROWS;
     if (nb > splits) splits = nb;
@@ -553,7 +556,7 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
     return launch_split_reduce(workspace, out, (long long)K * N, (int)blocks, accum, stream);
   }
   const WgradPlan pl = wgrad_plan(K, N);
-  const int S = pick_splits(K, N, P);
+  const int S = pick_splits(K, N, P, bf16x6 ? 512 : 256);
   long long rows = (P + S - 1) / S;
   rows = (rows + WG_C - 1) / WG_C * WG_C;
   if (bf16x6) {

@@ -7,7 +7,7 @@ name=$1; shift
 out=../_lib/variants; mkdir -p $out/obj_$name
 for f in *.hip; do
   o=$out/obj_$name/${f%.hip}.o
-  if [ "$f" = "mlp.hip" ] || [ "$f" = "mlp6.hip" ] || [ ! -f ../_lib/obj/${f%.hip}.o ]; then
+  if [ "$f" = "mlp.hip" ] || [ "$f" = "mlp6.hip" ] || [ "$f" = "wgrad.hip" ] || [ ! -f ../_lib/obj/${f%.hip}.o ]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -fno-slp-vectorize "$@" -c $f -o $o
   else
     cp ../_lib/obj/${f%.hip}.o $o
