@@ -260,6 +260,30 @@ int ndjir_render_specular_light_filament_backward(int R, int M, int C, const flo
                                                   const float* g, float* g_normal, float* g_roughness, float* g_specular_color,
                                                   float* g_soft_vis, float* g_env, hipStream_t stream);
 
+/* Material head: the output activations of the per-sample nets and the integrands of the prior terms in one
+ * launch each way (python/network.py:262, 335, 423, 456-463, 498-508; python/loss.py:117-166).
+ * Inputs are the nets' raw outputs for the R x N foreground samples: base colour (P,3), base colour of the
+ * perturbed pass (P,3), implicit illumination (P), photogrammetric light (P) with its 1-element gain,
+ * roughness (P,2) = [value, std], specular reflectance (P,6) = [value x3, std x3].
+ * Outputs: V (P,9) = [implicit, roughness, specular x3, photo, base colour (x photo when entangle) x3], the
+ * integrands of ONE VR integral; aux (P,10) = [base x3, base_ptb x3, std_roughness, std_specular x3];
+ * prior (R,5) = per-ray sums over the samples of |base - base_ptb| (3 ch), |r - prior_r| / std_r,
+ * clamp(log std_r, 1e-5, 1e5), sum_c |s_c - prior_s| / std_s_c, sum_c clamp(log std_s_c, 1e-5, 1e5).
+ * remap: roughness^2 / 0.16 s^2 (filament, python/network.py:459, 502) else specular_scale * s.
+ * Backward: gV (P,9), g_prior (R,5, may be null) -> gradients of the six raw inputs (aux carries none). */
+int ndjir_render_material_head(int R, int N, const float* raw_base_color, const float* raw_base_color_ptb,
+                               const float* raw_implicit, const float* raw_photo, const float* photo_gain,
+                               const float* raw_roughness, const float* raw_specular, int remap, int entangle,
+                               int sym_backward, float roughness_lower_bound, float specular_scale, float roughness_prior,
+                               float specular_prior, float* V, float* aux, float* prior, hipStream_t stream);
+int ndjir_render_material_head_backward(int R, int N, const float* raw_base_color, const float* raw_base_color_ptb,
+                                        const float* raw_implicit, const float* raw_photo, const float* photo_gain,
+                                        const float* raw_roughness, const float* raw_specular, int remap, int entangle,
+                                        int sym_backward, float roughness_lower_bound, float specular_scale,
+                                        float roughness_prior, float specular_prior, const float* gV, const float* g_prior,
+                                        float* g_base_color, float* g_base_color_ptb, float* g_implicit, float* g_photo,
+                                        float* g_roughness, float* g_specular, hipStream_t stream);
+
 /* Positional encoding (python/network.py:96-117): out (P, [C +] 2 C M) = [x, cos(x_i 2^k), sin(x_i 2^k)],
  * band index k fastest; backward gx (P,C) from g (P, [C +] 2 C M). */
 int ndjir_positional_encoding(long long P, int C, int M, int include_input, const float* x, float* out, hipStream_t stream);

@@ -597,3 +597,169 @@ extern "C" int ndjir_positional_encoding_backward(long long P, int C, int M, int
   hipLaunchKernelGGL(k_posenc_bwd, dim3((unsigned)blocks), dim3(256), 0, stream, P, C, M, include_input, x, g, gx);
   return ndjir_check_launch();
 }
+
+// ---- material head: output activations of the per-sample nets + the prior terms ------------------------
+// python/network.py:262 (base colour: sigmoid), :335 (implicit illumination: sigmoid), :423 (photogrammetric
+// light: sigmoid(gain h)), :456-463 (roughness: sigmoid [^2] clamp, std = softplus), :498-508 (specular
+// reflectance: sigmoid -> 0.16 s^2 | scale s, std = softplus) and the prior / regulariser integrands of
+// python/loss.py:117-166, which the reference evaluates as ~60 nnabla functions (+ backward) on (B,R,N,*)
+// tensors.  One thread per sample, one workgroup per ray (N <= 1024):
+//   V      (P,9)  = [implicit, roughness, spec x3, photo, base (* photo if entangle) x3]  -> ONE VR integral
+//   aux    (P,10) = [base x3, base_ptb x3, std_rough, std_spec x3]
+//   prior  (R,5)  = per-ray sums of |base - base_ptb| (3 ch), |r - p_r| / std_r, clamp(log std_r),
+//                   sum_c |s_c - p_s| / std_s_c, sum_c clamp(log std_s_c)      (clamp to [1e-5, 1e5])
+namespace ndjir {
+
+struct HeadCfg {
+  int remap, entangle, sym;
+  float rough_lb, spec_scale, prior_r, prior_s;
+};
+
+__device__ __forceinline__ float mh_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float mh_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // torch: beta 1, threshold 20
+__device__ __forceinline__ float mh_sign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+__global__ void __launch_bounds__(128) k_material_head(int N, const float* __restrict__ raw_bc, const float* __restrict__ raw_ptb,
+                                                       const float* __restrict__ raw_imp, const float* __restrict__ raw_photo,
+                                                       const float* __restrict__ photo_gain, const float* __restrict__ raw_rough,
+                                                       const float* __restrict__ raw_spec, HeadCfg c, float* __restrict__ V,
+                                                       float* __restrict__ aux, float* __restrict__ prior) {
+  __shared__ float red[2];
+  const long long r = blockIdx.x;
+  const float pg = photo_gain[0];
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < N; i += 128) {
+    const long long p = r * N + i;
+    float bc[3], pt[3];
+    for (int k = 0; k < 3; ++k) { bc[k] = mh_sigmoid(raw_bc[p * 3 + k]); pt[k] = mh_sigmoid(raw_ptb[p * 3 + k]); }
+    const float imp = mh_sigmoid(raw_imp[p]);
+    const float photo = mh_sigmoid(pg * raw_photo[p]);
+    const float r0 = mh_sigmoid(raw_rough[p * 2]);
+    const float r1 = c.remap ? r0 * r0 : r0;
+    const float ro = fminf(fmaxf(r1, c.rough_lb), 1.f);
+    const float sr = mh_softplus(raw_rough[p * 2 + 1]);
+    float sp[3], ss[3];
+    for (int k = 0; k < 3; ++k) {
+      const float s0 = mh_sigmoid(raw_spec[p * 6 + k]);
+      sp[k] = c.remap ? 0.16f * (s0 * s0) : c.spec_scale * s0;
+      ss[k] = mh_softplus(raw_spec[p * 6 + 3 + k]);
+    }
+    float* v = V + p * 9;
+    v[0] = imp; v[1] = ro; v[2] = sp[0]; v[3] = sp[1]; v[4] = sp[2]; v[5] = photo;
+    for (int k = 0; k < 3; ++k) v[6 + k] = c.entangle ? bc[k] * photo : bc[k];
+    float* a = aux + p * 10;
+    for (int k = 0; k < 3; ++k) { a[k] = bc[k]; a[3 + k] = pt[k]; a[7 + k] = ss[k]; }
+    a[6] = sr;
+    for (int k = 0; k < 3; ++k) acc[0] += fabsf(bc[k] - pt[k]);
+    acc[1] += fabsf(ro - c.prior_r) / sr;
+    acc[2] += fminf(fmaxf(logf(sr), 1e-5f), 1e5f);
+    for (int k = 0; k < 3; ++k) {
+      acc[3] += fabsf(sp[k] - c.prior_s) / ss[k];
+      acc[4] += fminf(fmaxf(logf(ss[k]), 1e-5f), 1e5f);
+    }
+  }
+  for (int k = 0; k < 5; ++k) {
+    float v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) prior[r * 5 + k] = red[0] + red[1];
+  }
+}
+
+// gV (P,9), g_prior (R,5) -> gradients of the raw net outputs
+__global__ void __launch_bounds__(128) k_material_head_bwd(int N, const float* __restrict__ raw_bc, const float* __restrict__ raw_ptb,
+                                                           const float* __restrict__ raw_imp, const float* __restrict__ raw_photo,
+                                                           const float* __restrict__ photo_gain, const float* __restrict__ raw_rough,
+                                                           const float* __restrict__ raw_spec, HeadCfg c,
+                                                           const float* __restrict__ gV, const float* __restrict__ g_prior,
+                                                           float* __restrict__ g_bc, float* __restrict__ g_ptb,
+                                                           float* __restrict__ g_imp, float* __restrict__ g_photo,
+                                                           float* __restrict__ g_rough, float* __restrict__ g_spec) {
+  const long long r = blockIdx.x;
+  const float pg = photo_gain[0];
+  float gp[5];
+  for (int k = 0; k < 5; ++k) gp[k] = g_prior ? g_prior[r * 5 + k] : 0.f;
+  for (int i = threadIdx.x; i < N; i += 128) {
+    const long long p = r * N + i;
+    const float* gv = gV + p * 9;
+    const float photo = mh_sigmoid(pg * raw_photo[p]);
+    float dphoto = gv[5];
+    for (int k = 0; k < 3; ++k) {
+      const float bc = mh_sigmoid(raw_bc[p * 3 + k]), pt = mh_sigmoid(raw_ptb[p * 3 + k]);
+      const float sg = mh_sign(bc - pt);
+      float dbc = gv[6 + k] * (c.entangle ? photo : 1.f) + (c.sym ? gp[0] * sg : 0.f);
+      if (c.entangle) dphoto += gv[6 + k] * bc;
+      g_bc[p * 3 + k] = dbc * bc * (1.f - bc);
+      g_ptb[p * 3 + k] = -gp[0] * sg * pt * (1.f - pt);
+    }
+    const float imp = mh_sigmoid(raw_imp[p]);
+    g_imp[p] = gv[0] * imp * (1.f - imp);
+    g_photo[p] = dphoto * photo * (1.f - photo) * pg;
+    {
+      const float h1 = raw_rough[p * 2 + 1];
+      const float r0 = mh_sigmoid(raw_rough[p * 2]);
+      const float r1 = c.remap ? r0 * r0 : r0;
+      const float ro = fminf(fmaxf(r1, c.rough_lb), 1.f);
+      const float sr = mh_softplus(h1);
+      const float dr = gv[1] + gp[1] * mh_sign(ro - c.prior_r) / sr;
+      const float dr1 = (r1 >= c.rough_lb && r1 <= 1.f) ? dr : 0.f;
+      const float dr0 = c.remap ? dr1 * 2.f * r0 : dr1;
+      g_rough[p * 2] = dr0 * r0 * (1.f - r0);
+      const float ls = logf(sr);
+      const float dsr = gp[1] * (-fabsf(ro - c.prior_r) / (sr * sr)) + ((ls >= 1e-5f && ls <= 1e5f) ? gp[2] / sr : 0.f);
+      g_rough[p * 2 + 1] = dsr * (h1 > 20.f ? 1.f : mh_sigmoid(h1));
+    }
+    for (int k = 0; k < 3; ++k) {
+      const float h1 = raw_spec[p * 6 + 3 + k];
+      const float s0 = mh_sigmoid(raw_spec[p * 6 + k]);
+      const float sp = c.remap ? 0.16f * (s0 * s0) : c.spec_scale * s0;
+      const float ss = mh_softplus(h1);
+      const float ds = gv[2 + k] + gp[3] * mh_sign(sp - c.prior_s) / ss;
+      const float ds0 = c.remap ? ds * 0.32f * s0 : ds * c.spec_scale;
+      g_spec[p * 6 + k] = ds0 * s0 * (1.f - s0);
+      const float ls = logf(ss);
+      const float dss = gp[3] * (-fabsf(sp - c.prior_s) / (ss * ss)) + ((ls >= 1e-5f && ls <= 1e5f) ? gp[4] / ss : 0.f);
+      g_spec[p * 6 + 3 + k] = dss * (h1 > 20.f ? 1.f : mh_sigmoid(h1));
+    }
+  }
+}
+
+}  // namespace ndjir
+
+extern "C" int ndjir_render_material_head(int R, int N, const float* raw_base_color, const float* raw_base_color_ptb,
+                                          const float* raw_implicit, const float* raw_photo, const float* photo_gain,
+                                          const float* raw_roughness, const float* raw_specular, int remap, int entangle,
+                                          int sym_backward, float roughness_lower_bound, float specular_scale,
+                                          float roughness_prior, float specular_prior, float* V, float* aux, float* prior,
+                                          hipStream_t stream) {
+  if (R <= 0 || N <= 0) return NDJIR_OK;
+  if (!raw_base_color || !raw_base_color_ptb || !raw_implicit || !raw_photo || !photo_gain || !raw_roughness || !raw_specular ||
+      !V || !aux || !prior)
+    return NDJIR_ERR_ARG;
+  HeadCfg c{remap, entangle, sym_backward, roughness_lower_bound, specular_scale, roughness_prior, specular_prior};
+  hipLaunchKernelGGL(k_material_head, dim3(R), dim3(128), 0, stream, N, raw_base_color, raw_base_color_ptb, raw_implicit,
+                     raw_photo, photo_gain, raw_roughness, raw_specular, c, V, aux, prior);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_material_head_backward(int R, int N, const float* raw_base_color, const float* raw_base_color_ptb,
+                                                   const float* raw_implicit, const float* raw_photo, const float* photo_gain,
+                                                   const float* raw_roughness, const float* raw_specular, int remap,
+                                                   int entangle, int sym_backward, float roughness_lower_bound,
+                                                   float specular_scale, float roughness_prior, float specular_prior,
+                                                   const float* gV, const float* g_prior, float* g_base_color,
+                                                   float* g_base_color_ptb, float* g_implicit, float* g_photo,
+                                                   float* g_roughness, float* g_specular, hipStream_t stream) {
+  if (R <= 0 || N <= 0) return NDJIR_OK;
+  if (!raw_base_color || !raw_base_color_ptb || !raw_implicit || !raw_photo || !photo_gain || !raw_roughness || !raw_specular ||
+      !gV || !g_base_color || !g_base_color_ptb || !g_implicit || !g_photo || !g_roughness || !g_specular)
+    return NDJIR_ERR_ARG;
+  HeadCfg c{remap, entangle, sym_backward, roughness_lower_bound, specular_scale, roughness_prior, specular_prior};
+  hipLaunchKernelGGL(k_material_head_bwd, dim3(R), dim3(128), 0, stream, N, raw_base_color, raw_base_color_ptb, raw_implicit,
+                     raw_photo, photo_gain, raw_roughness, raw_specular, c, gV, g_prior, g_base_color, g_base_color_ptb, g_implicit,
+                     g_photo, g_roughness, g_specular);
+  return ndjir_check_launch();
+}

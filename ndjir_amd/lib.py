@@ -45,6 +45,8 @@ SIGS = {
     "render_alpha_weights": "iii" + "p" * 11,
     "render_alpha_weights_backward": "iii" + "p" * 16,
     "render_integrate": "iiipipp",
+    "render_material_head": "ii" + "p" * 7 + "iiiffff" + "ppp",
+    "render_material_head_backward": "ii" + "p" * 7 + "iiiffff" + "pp" + "p" * 6,
     "positional_encoding": "liiipp",
     "positional_encoding_backward": "liiippp",
     "render_diffuse_light": "iiippppfp",

@@ -75,19 +75,32 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
         loss_mask = bce.sum() / (mask_sum + 1e-5)
 
     # Priors (loss.py:117-166)
+    pp = res.get("prior_partials")
+    if pp is not None:
+        # per-ray sums of the five integrands from the fused material head (volume.material_head)
+        pm = (pp * mask.reshape(B, R, 1)).sum(dim=(0, 1)) / denorm
     prior_base_color = zero
-    if tr.base_color_prior_weight > 0.0:
+    if pp is not None:
+        if tr.base_color_prior_weight > 0.0:
+            prior_base_color = pm[0]
+    elif tr.base_color_prior_weight > 0.0:
         bc = res["base_color"] if tr.base_color_prior_sym_backward else res["base_color"].detach()
         prior_base_color = ((bc - res["base_color_ptb"]).abs() * mask).sum() / denorm
 
     prior_roughness = reg_std_roughness = zero
-    if tr.roughness_prior_weight > 0.0:
+    if pp is not None:
+        if tr.roughness_prior_weight > 0.0:
+            prior_roughness, reg_std_roughness = pm[1], pm[2]
+    elif tr.roughness_prior_weight > 0.0:
         pr = (res["roughness"] - conf.roughness_network.prior_value).abs() / res["std_roughness"]
         prior_roughness = (pr * mask).sum() / denorm
         reg_std_roughness = (torch.log(res["std_roughness"]).clamp(1e-5, 1e5) * mask).sum() / denorm
 
     prior_spec = reg_std_spec = zero
-    if tr.specular_reflectance_prior_weight > 0.0:
+    if pp is not None:
+        if tr.specular_reflectance_prior_weight > 0.0:
+            prior_spec, reg_std_spec = pm[3], pm[4]
+    elif tr.specular_reflectance_prior_weight > 0.0:
         ps = (res["specular_reflectance"] - conf.specular_reflectance_network.prior_value).abs() \
             / res["std_specular_reflectance"]
         prior_spec = (ps * mask).sum() / denorm

@@ -315,12 +315,12 @@ def _cat_inputs(x, feature, normal, c):
     return torch.cat(inputs, dim=-1) if len(inputs) > 1 else x
 
 
-def base_color_network(x, feature, normal, conf):
-    """network.py:235-263."""
+def base_color_network(x, feature, normal, conf, raw=False):
+    """network.py:235-263.  raw=True: the net's output before the sigmoid (for volume.material_head)."""
     with P.parameter_scope("base-color-network"):
         c = conf.base_color_network
         h = _mlp(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, 3, _act(c.act), conf.use_wn)
-        return torch.sigmoid(h)
+        return h if raw else torch.sigmoid(h)
 
 
 def environment_light_network(light_dirs, conf):
@@ -335,14 +335,14 @@ def environment_light_network(light_dirs, conf):
         return out
 
 
-def implicit_illumination_network(x, feature, normal, conf):
+def implicit_illumination_network(x, feature, normal, conf, raw=False):
     """network.py:300-336."""
     with P.parameter_scope("implicit-illumination-network"):
         c = conf.implicit_illumination_network
         if not c.use_me:
             return torch.zeros(x.shape[:-1] + (1,), dtype=x.dtype, device=x.device)
         h = _mlp(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, c.channels, _act(c.act), conf.use_wn)
-        return _last_act(c.act_last, c.inverse_black_degree)(h)
+        return h if raw else _last_act(c.act_last, c.inverse_black_degree)(h)
 
 
 def soft_visibility_light_network(x, light_dirs, feature, normal, conf):
@@ -355,7 +355,7 @@ def soft_visibility_light_network(x, light_dirs, feature, normal, conf):
         return _last_act(c.act_last, c.inverse_black_degree)(h)
 
 
-def photogrammetric_light_network(x, camloc, view, feature, normal, conf):
+def photogrammetric_light_network(x, camloc, view, feature, normal, conf, raw=False):
     """network.py:380-424."""
     with P.parameter_scope("photogrammetric-light-network"):
         c = conf.photogrammetric_light_network
@@ -369,14 +369,18 @@ def photogrammetric_light_network(x, camloc, view, feature, normal, conf):
             inputs.append(1.0 / (dist2 + 1e-5))
         h = _mlp(torch.cat(inputs, dim=-1), c.feature_size, c.layers, c.channels, _act(c.act), conf.use_wn)
         gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain_lv_start]), False)
+        if raw:
+            return h, gain
         return torch.sigmoid(gain.reshape((1,) * h.dim()) * h)
 
 
-def roughness_network(x, feature, normal, conf):
+def roughness_network(x, feature, normal, conf, raw=False):
     """network.py:427-464 (hidden layers are named affine--1, affine-00, affine-01; :450-454)."""
     with P.parameter_scope("roughness-network"):
         c = conf.roughness_network
         h = _mlp(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, 2, _act(c.act), conf.use_wn, shift=1)
+        if raw:
+            return h
         h0, h1 = h[..., 0:1], h[..., 1:2]
         std = TF.softplus(h1)
         r = torch.sigmoid(h0)
@@ -385,7 +389,7 @@ def roughness_network(x, feature, normal, conf):
         return r.clamp(c.lower_bound, 1.0), std
 
 
-def specular_reflectance_network(x, feature, normal, conf):
+def specular_reflectance_network(x, feature, normal, conf, raw=False):
     """network.py:467-509."""
     with P.parameter_scope("specular-reflectance-network"):
         c = conf.specular_reflectance_network
@@ -393,6 +397,8 @@ def specular_reflectance_network(x, feature, normal, conf):
         if c.fixme:
             return torch.full(x.shape[:-1] + (Do,), 0.04, dtype=x.dtype, device=x.device), None
         h = _mlp(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, Do * 2, _act(c.act), conf.use_wn, shift=1)
+        if raw:
+            return h
         h0, h1 = h[..., :-Do], h[..., Do:]
         std = TF.softplus(h1)
         s = torch.sigmoid(h0)

@@ -21,7 +21,7 @@ from .network import (background_network, base_color_network, environment_light_
                       soft_visibility_light_network, specular_reflectance_network)
 from .sampler import sample_importance_directions, sample_points, sample_uniform_directions
 from .specular_brdf import dot, specular_brdf_model
-from .volume import alpha_weights, diffuse_light, integrate, specular_light_filament
+from .volume import alpha_weights, diffuse_light, integrate, material_head, specular_light_filament
 
 
 def make_rand(B, R, conf, device, n_fg=None, include_samples=True):
@@ -93,21 +93,52 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     env = environment_light_network(uniform_light_dir, conf)
     soft_vis = soft_visibility_light_network(x_fg_pixel, uniform_light_dir, feature_pixel, normal_bc, conf)
 
-    # Implicit light (renderer.py:113-114)
-    implicit = implicit_illumination_network(x_fg, feature_x_fg, grad_x_fg, conf)
-    implicit_pixel = VR(implicit)
+    # Material nets of the foreground samples (renderer.py:113-128, 164, 186-193).  Default configuration:
+    # their output activations, the products feeding the VR integrals and the prior integrands of
+    # loss.py:117-166 are ONE fused launch (volume.material_head) followed by ONE VR integral.
+    ii = conf.implicit_illumination_network
+    pl = conf.photogrammetric_light_network
+    sr = conf.specular_reflectance_network
+    use_head = (ii.use_me and ii.channels == 1 and ii.act_last == "sigmoid" and pl.use_me and pl.channels == 1
+                and not sr.fixme and sr.channels == 3)
+    G = conf.geometric_network.voxel.grid_size
+    rad = conf.renderer.bounding_sphere_radius
+    x_fg_ptb = x_fg + rand["noise"] * (math.sqrt(3) * 2 * rad / G)
+    prior_partials = None
+    if use_head:
+        raw_imp = implicit_illumination_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
+        raw_bc = base_color_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
+        raw_rough = roughness_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
+        raw_spec = specular_reflectance_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
+        raw_photo, photo_gain = photogrammetric_light_network(x_fg, camloc, view_dir, feature_x_fg, grad_x_fg, conf, raw=True)
+        _, feature_ptb, _ = geometric_network(x_fg_ptb, conf, first_order_only=True)
+        raw_ptb = base_color_network(x_fg_ptb, feature_ptb, None, conf, raw=True)
+        remap = conf.specular_brdf.model == "filament" and conf.specular_brdf.remap
+        V, aux, prior_partials = material_head(
+            raw_bc, raw_ptb, raw_imp, raw_photo, photo_gain, raw_rough, raw_spec, remap, conf.diffuse_brdf.entangle,
+            conf.train.base_color_prior_sym_backward, conf.roughness_network.lower_bound, sr.upper_bound_scale,
+            conf.roughness_network.prior_value, sr.prior_value)
+        pix = VR(V)
+        implicit_pixel, roughness_pixel, spec_refl_pixel = pix[..., 0:1], pix[..., 1:2], pix[..., 2:5]
+        photo_pixel, base_term_pixel = pix[..., 5:6], pix[..., 6:9]
+        base_color, base_color_ptb = aux[..., 0:3], aux[..., 3:6]
+        roughness, spec_refl = V[..., 1:2], V[..., 2:5]
+        std_roughness, std_spec_refl = aux[..., 6:7], aux[..., 7:10]
+    else:
+        # Implicit light (renderer.py:113-114)
+        implicit = implicit_illumination_network(x_fg, feature_x_fg, grad_x_fg, conf)
+        implicit_pixel = VR(implicit)
+        base_color = base_color_network(x_fg, feature_x_fg, grad_x_fg, conf)
+        # Roughness / specular reflectance (renderer.py:123-128)
+        roughness, std_roughness = roughness_network(x_fg, feature_x_fg, grad_x_fg, conf)
+        roughness_pixel = VR(roughness)
+        spec_refl, std_spec_refl = specular_reflectance_network(x_fg, feature_x_fg, grad_x_fg, conf)
+        spec_refl_pixel = VR(spec_refl)
 
     # Diffuse colour (renderer.py:117-120)
     # mean_m soft_vis * env * clamp(n.l): one fused launch (csrc/render.hip) instead of dot/clamp/mul/mean
     env_pixel = diffuse_light(normal_pixel, uniform_light_dir, soft_vis, env, conf.renderer.eps_dot)
     diffuse_light_pixel = env_pixel + implicit_pixel
-    base_color = base_color_network(x_fg, feature_x_fg, grad_x_fg, conf)
-
-    # Roughness / specular reflectance (renderer.py:123-128)
-    roughness, std_roughness = roughness_network(x_fg, feature_x_fg, grad_x_fg, conf)
-    roughness_pixel = VR(roughness)
-    spec_refl, std_spec_refl = specular_reflectance_network(x_fg, feature_x_fg, grad_x_fg, conf)
-    spec_refl_pixel = VR(spec_refl)
 
     # Specular colour (renderer.py:131-161)
     if conf.specular_brdf.sampling == "importance":
@@ -117,7 +148,6 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
         imp_dir = sample_uniform_directions(normal_pixel, rand["specular_cdf_the"], rand["specular_cdf_phi"])
     env = environment_light_network(imp_dir, conf)
     soft_vis = soft_visibility_light_network(x_fg_pixel, imp_dir, feature_pixel, normal_bc, conf)
-    ii = conf.implicit_illumination_network
     sb = conf.specular_brdf
     if (sb.model == "filament" and sb.sampling == "importance" and not sb.use_split_sum
             and not (ii.use_me and ii.use_me_on_specular) and env.shape[-1] in (1, 3) and spec_refl_pixel.shape[-1] == 3):
@@ -135,7 +165,12 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
         spec_pixel = sb.weight * spec_pixel
 
     # Diffuse + specular composition (renderer.py:163-176)
-    if conf.photogrammetric_light_network.use_me:
+    if use_head:
+        if conf.diffuse_brdf.entangle:
+            color_fg_pixel = base_term_pixel * diffuse_light_pixel + photo_pixel * spec_pixel
+        else:
+            color_fg_pixel = photo_pixel * (base_term_pixel * diffuse_light_pixel + spec_pixel)
+    elif conf.photogrammetric_light_network.use_me:
         photo = photogrammetric_light_network(x_fg, camloc, view_dir, feature_x_fg, grad_x_fg, conf)
         photo_pixel = VR(photo)
         if conf.diffuse_brdf.entangle:
@@ -152,13 +187,11 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
         obj_mask_pred = (alpha_fg * trans_fg).sum(dim=2)
 
     # Base-colour perturbation (renderer.py:186-193)
-    G = conf.geometric_network.voxel.grid_size
-    r = conf.renderer.bounding_sphere_radius
-    x_fg_ptb = x_fg + rand["noise"] * (math.sqrt(3) * 2 * r / G)
-    _, feature_ptb, _ = geometric_network(x_fg_ptb, conf, first_order_only=True)
-    base_color_ptb = base_color_network(x_fg_ptb, feature_ptb, None, conf)
+    if not use_head:
+        _, feature_ptb, _ = geometric_network(x_fg_ptb, conf, first_order_only=True)
+        base_color_ptb = base_color_network(x_fg_ptb, feature_ptb, None, conf)
 
-    return dict(color_pixel=color_pixel, sdf_x_fg=sdf_x_fg, grad_x_fg=grad_x_fg, alpha_fg=alpha_fg,
+    return dict(prior_partials=prior_partials, color_pixel=color_pixel, sdf_x_fg=sdf_x_fg, grad_x_fg=grad_x_fg, alpha_fg=alpha_fg,
                 trans_fg=trans_fg, obj_mask_pred=obj_mask_pred, base_color=base_color,
                 base_color_ptb=base_color_ptb, roughness=roughness, specular_reflectance=spec_refl,
                 std_roughness=std_roughness, std_specular_reflectance=std_spec_refl)

@@ -154,3 +154,44 @@ class SpecularLightFilament(Function):
 
 def specular_light_filament(normal, view_dir, light_dir, roughness, specular_color, soft_vis, env, eps_dot, weight):
     return SpecularLightFilament.apply(normal, view_dir, light_dir, roughness, specular_color, soft_vis, env, eps_dot, weight)
+
+
+class MaterialHead(Function):
+    """Output activations of the per-sample material nets and the prior integrands in one launch
+    (csrc/render.hip; network.py:262, 335, 423, 456-463, 498-508 and loss.py:117-166).
+    Raw net outputs -> V (B,R,N,9) = [implicit, roughness, specular x3, photo, base colour (x photo)],
+    aux (B,R,N,10) = [base x3, base_ptb x3, std_roughness, std_specular x3] (no gradient),
+    prior (B,R,5) per-ray sums of the five prior / regulariser integrands."""
+
+    @staticmethod
+    def forward(ctx, raw_bc, raw_ptb, raw_imp, raw_photo, photo_gain, raw_rough, raw_spec, cfg):
+        B, R, N, _ = raw_bc.shape
+        args = [_c(raw_bc), _c(raw_ptb), _c(raw_imp), _c(raw_photo), _c(photo_gain).reshape(-1), _c(raw_rough), _c(raw_spec)]
+        dev = raw_bc.device
+        V = torch.empty((B, R, N, 9), device=dev, dtype=torch.float32)
+        aux = torch.empty((B, R, N, 10), device=dev, dtype=torch.float32)
+        prior = torch.empty((B, R, 5), device=dev, dtype=torch.float32)
+        lib.call("render_material_head", B * R, N, *args, *cfg, V, aux, prior)
+        ctx.save_for_backward(*args)
+        ctx.cfg = (B, R, N, cfg)
+        ctx.mark_non_differentiable(aux)
+        return V, aux, prior
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gV, _g_aux, g_prior):
+        B, R, N, cfg = ctx.cfg
+        raw_bc, raw_ptb, raw_imp, raw_photo, gain, raw_rough, raw_spec = ctx.saved_tensors
+        outs = [torch.empty_like(t) for t in (raw_bc, raw_ptb, raw_imp, raw_photo, raw_rough, raw_spec)]
+        if gV is None:
+            gV = torch.zeros((B, R, N, 9), device=raw_bc.device, dtype=torch.float32)
+        lib.call("render_material_head_backward", B * R, N, raw_bc, raw_ptb, raw_imp, raw_photo, gain, raw_rough, raw_spec, *cfg,
+                 gV.contiguous(), None if g_prior is None else g_prior.contiguous(), *outs)
+        return outs[0], outs[1], outs[2], outs[3], None, outs[4], outs[5], None
+
+
+def material_head(raw_bc, raw_ptb, raw_imp, raw_photo, photo_gain, raw_rough, raw_spec, remap, entangle, sym_backward,
+                  roughness_lower_bound, specular_scale, roughness_prior, specular_prior):
+    cfg = (int(bool(remap)), int(bool(entangle)), int(bool(sym_backward)), float(roughness_lower_bound), float(specular_scale),
+           float(roughness_prior), float(specular_prior))
+    return MaterialHead.apply(raw_bc, raw_ptb, raw_imp, raw_photo, photo_gain, raw_rough, raw_spec, cfg)

@@ -176,3 +176,52 @@ def test_positional_encoding_kernel(gpu, shape, M, inc):
     (gr,) = torch.autograd.grad(ref, x64, g)
     (go,) = torch.autograd.grad(out, x32, g.float())
     assert float((go.double() - gr).abs().max()) < 1e-3 * max(1.0, float(gr.abs().max()))
+
+
+@pytest.mark.parametrize("remap,entangle,sym", [(True, True, True), (False, False, False), (True, False, True)])
+def test_material_head_matches_composite(gpu, remap, entangle, sym):
+    """fused output activations + prior integrands vs the stock-op formulas of network.py / loss.py (fp64 autograd)."""
+    import torch.nn.functional as TF
+    from ndjir_amd.volume import material_head
+    B, R, N = 1, 23, 128
+    rng = np.random.RandomState(17)
+    f = lambda *s: torch.tensor(rng.randn(*s) * 1.5, dtype=torch.float64, device=gpu)
+    raws64 = [f(B, R, N, 3), f(B, R, N, 3), f(B, R, N, 1), f(B, R, N, 1), f(B, R, N, 2), f(B, R, N, 6)]
+    gain = torch.tensor([1.3], dtype=torch.float64, device=gpu)
+    lb, scale, pr, ps = 0.089, 0.16, 0.5, 0.04
+
+    def composite(bc_r, pt_r, imp_r, ph_r, ro_r, sp_r):
+        bc, pt = torch.sigmoid(bc_r), torch.sigmoid(pt_r)
+        imp, photo = torch.sigmoid(imp_r), torch.sigmoid(gain * ph_r)
+        r = torch.sigmoid(ro_r[..., 0:1])
+        r = (r ** 2 if remap else r).clamp(lb, 1.0)
+        std_r = TF.softplus(ro_r[..., 1:2])
+        s = torch.sigmoid(sp_r[..., :3])
+        s = 0.16 * s ** 2 if remap else scale * s
+        std_s = TF.softplus(sp_r[..., 3:])
+        V = torch.cat([imp, r, s, photo, bc * photo if entangle else bc], dim=-1)
+        bcp = bc if sym else bc.detach()
+        prior = torch.stack([
+            (bcp - pt).abs().sum(-1).sum(-1),
+            ((r - pr).abs() / std_r).sum(-1).sum(-1),
+            torch.log(std_r).clamp(1e-5, 1e5).sum(-1).sum(-1),
+            ((s - ps).abs() / std_s).sum(-1).sum(-1),
+            torch.log(std_s).clamp(1e-5, 1e5).sum(-1).sum(-1)], dim=-1)
+        aux = torch.cat([bc, pt, std_r, std_s], dim=-1)
+        return V, aux, prior
+
+    a64 = [t.clone().requires_grad_(True) for t in raws64]
+    a32 = [t.float().requires_grad_(True) for t in raws64]
+    V64, aux64, pr64 = composite(*a64)
+    V32, aux32, pr32 = material_head(a32[0], a32[1], a32[2], a32[3], gain.float(), a32[4], a32[5], remap, entangle, sym,
+                                     lb, scale, pr, ps)
+    assert float((V32.double() - V64).abs().max()) < 2e-6
+    assert float((aux32.double() - aux64).abs().max()) < 1e-5 * max(1.0, float(aux64.abs().max()))
+    assert float(((pr32.double() - pr64).abs() / pr64.abs().clamp(min=1.0)).max()) < 2e-5
+    gV = torch.tensor(rng.randn(*V64.shape), dtype=torch.float64, device=gpu)
+    gp = torch.tensor(rng.randn(*pr64.shape), dtype=torch.float64, device=gpu)
+    gref = torch.autograd.grad([V64, pr64], a64, [gV, gp])
+    gout = torch.autograd.grad([V32, pr32], a32, [gV.float(), gp.float()])
+    for name, go, gr in zip(("base", "ptb", "implicit", "photo", "roughness", "specular"), gout, gref):
+        scale_ = max(float(gr.abs().max()), 1e-6)
+        assert float((go.double() - gr).abs().max()) / scale_ < 5e-5, name
