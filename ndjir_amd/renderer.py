@@ -13,6 +13,7 @@ import math
 import numpy as np
 import torch
 
+from . import parameter as P
 from .grid_feature import grad as nn_grad
 from .helper import generate_all_pixels, generate_raydir_camloc
 from .network import (background_network, base_color_network, environment_light_network, geometric_network,
@@ -84,14 +85,19 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     n_thetas = conf.renderer.n_thetas
     M = n_thetas * 2 * n_thetas
     D = feature_x_fg.shape[-1]
-    x_fg_pixel = VR(x_fg).reshape(B, R, 1, 3).expand(B, R, M, 3)
-    feature_pixel = VR(feature_x_fg).reshape(B, R, 1, D).expand(B, R, M, D)
-    normal_bc = normal_pixel[:, :, None, :].expand(B, R, M, 3)
+    x_fg_pixel = VR(x_fg).reshape(B, R, 1, 3)
+    feature_pixel = VR(feature_x_fg).reshape(B, R, 1, D)
+    normal_bc = normal_pixel[:, :, None, :]
 
     # Direct light + visibility (renderer.py:103-110)
     uniform_light_dir = sample_uniform_directions(normal_pixel, rand["diffuse_cdf_the"], rand["diffuse_cdf_phi"])
-    env = environment_light_network(uniform_light_dir, conf)
-    soft_vis = soft_visibility_light_network(x_fg_pixel, uniform_light_dir, feature_pixel, normal_bc, conf)
+    if not any(k.startswith("environment-light-network/") for k in P.get_parameters()):
+        # first call only: create the two light nets' parameters HERE, i.e. in the reference's creation order
+        # (renderer.py:105-110), so that seeded initialisation does not depend on the batching further down
+        with torch.no_grad():
+            environment_light_network(uniform_light_dir[:, :1, :1], conf)
+            soft_visibility_light_network(x_fg_pixel[:, :1], uniform_light_dir[:, :1, :1], feature_pixel[:, :1],
+                                          normal_bc[:, :1], conf)
 
     # Material nets of the foreground samples (renderer.py:113-128, 164, 186-193).  Default configuration:
     # their output activations, the products feeding the VR integrals and the prior integrands of
@@ -135,19 +141,29 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
         spec_refl, std_spec_refl = specular_reflectance_network(x_fg, feature_x_fg, grad_x_fg, conf)
         spec_refl_pixel = VR(spec_refl)
 
-    # Diffuse colour (renderer.py:117-120)
-    # mean_m soft_vis * env * clamp(n.l): one fused launch (csrc/render.hip) instead of dot/clamp/mul/mean
-    env_pixel = diffuse_light(normal_pixel, uniform_light_dir, soft_vis, env, conf.renderer.eps_dot)
-    diffuse_light_pixel = env_pixel + implicit_pixel
-
-    # Specular colour (renderer.py:131-161)
+    # Light directions of the specular term (renderer.py:131-140)
     if conf.specular_brdf.sampling == "importance":
         imp_dir = sample_importance_directions(normal_pixel, rand["specular_cdf_the"], rand["specular_cdf_phi"],
                                                roughness_pixel)
     else:
         imp_dir = sample_uniform_directions(normal_pixel, rand["specular_cdf_the"], rand["specular_cdf_phi"])
-    env = environment_light_network(imp_dir, conf)
-    soft_vis = soft_visibility_light_network(x_fg_pixel, imp_dir, feature_pixel, normal_bc, conf)
+
+    # Environment light and soft visibility (renderer.py:105-110 and :143-150): the reference evaluates both nets
+    # once for the diffuse and once for the specular directions; the 2 M directions go through them in one pass
+    # here (row-independent nets: same values; their weight gradients come from one reduction over 2 M lights)
+    dirs_all = torch.cat([uniform_light_dir, imp_dir], dim=2)
+    env_all = environment_light_network(dirs_all, conf)
+    soft_vis_all = soft_visibility_light_network(x_fg_pixel.expand(B, R, 2 * M, 3), dirs_all,
+                                                 feature_pixel.expand(B, R, 2 * M, D), normal_bc.expand(B, R, 2 * M, 3), conf)
+    env_d, env = env_all[:, :, :M], env_all[:, :, M:]
+    soft_vis_d, soft_vis = soft_vis_all[:, :, :M], soft_vis_all[:, :, M:]
+
+    # Diffuse colour (renderer.py:117-120)
+    # mean_m soft_vis * env * clamp(n.l): one fused launch (csrc/render.hip) instead of dot/clamp/mul/mean
+    env_pixel = diffuse_light(normal_pixel, uniform_light_dir, soft_vis_d, env_d, conf.renderer.eps_dot)
+    diffuse_light_pixel = env_pixel + implicit_pixel
+
+    # Specular colour (renderer.py:141-161)
     sb = conf.specular_brdf
     if (sb.model == "filament" and sb.sampling == "importance" and not sb.use_split_sum
             and not (ii.use_me and ii.use_me_on_specular) and env.shape[-1] in (1, 3) and spec_refl_pixel.shape[-1] == 3):
