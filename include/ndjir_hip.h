@@ -340,7 +340,13 @@ int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx, int K0, i
                        float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                        int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                        const float* const* side_in2, const float* const* side_add, float* const* side_out2,
-                       float* workspace, hipStream_t stream);
+                       const float* row_bias, int row_bias_div, float* workspace, hipStream_t stream);
+/* row_bias (mode 0, may be null): (P / row_bias_div, N_0) term added to the first layer's pre-activation of every
+ * group of row_bias_div consecutive rows -- the part of x W_0 that is constant over a group (e.g. the per-ray inputs
+ * of the soft-visibility net, python/network.py:339-377, whose other inputs vary per light direction): it is
+ * computed once per group instead of once per row, and the broadcast inputs are never materialised.  Its gradient
+ * is the group-wise column sum of the first layer's delta: */
+int ndjir_mlp_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, hipStream_t stream);
 /* Weight gradient of one layer: out (K x N) (+)= A^T B with A (P x K, row stride lda) the layer's
  * input activations and B (P x N, row stride ldb) its deltas (ndjir_amd/csrc/wgrad.hip; the
  * reference gets this from nnabla's affine backward, a cuBLAS GEMM).  `workspace` needs

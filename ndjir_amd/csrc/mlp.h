@@ -39,6 +39,8 @@ struct ChainArgs {
   int tile_rows;        // 64 (default) or 32 points per workgroup
   float skip_scale;
   float beta;
+  const float* row_bias;  // forward: (P / row_bias_div, N_0) term added to the first layer's pre-activation of each row group
+  int row_bias_div;
   float* bg_partial;    // bias gradients: per-workgroup partial sums [grid][bg_total] (workspace)
   int bg_total, bg_lds; // filled by launch_chain: accumulator floats / its offset in LDS
   long long* timeline;  // diagnostics (tools/chain_timeline.py): per-layer phase stamps of workgroup 0, else null
@@ -59,6 +61,7 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
                  float* workspace, int bf16x6, hipStream_t stream);
 
 long long colsum_workspace(int N, long long P);
+int launch_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, hipStream_t stream);
 int launch_colsum(const float* X, int ldx, int N, long long P, float* out, int accum, float* workspace,
                   hipStream_t stream);
 

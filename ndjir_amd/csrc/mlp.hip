@@ -156,6 +156,9 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
       // the LDS queue (lgkmcnt is shared).
       const gptr<const float> p_wp = pin(ly.Wp);
       const gptr<const float> p_bias = pin(ly.bias);
+      // forward, first layer only: per-row-group additive term (the part of x W_0 that is constant over a group)
+      const gptr<const float> p_rowbias = pin((MODE == 0 && li == 0) ? a.row_bias : nullptr);
+      const int rb_div = pin(a.row_bias_div > 0 ? a.row_bias_div : 1);
       const gptr<const float> p_side_in = pin(ly.side_in);
       const gptr<const float> p_side_in2 = pin(ly.side_in2);
       const gptr<const float> p_side_add = pin(ly.side_add);
@@ -230,7 +233,7 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
         const int n4 = nb * 32 + g * 4;           // first of the 4 columns
         // fast epilogue (wave-uniform): a hidden layer's full 32-column block of a full tile with
         // 16-byte aligned side rows -> no masks, no per-lane branches, vector loads/stores only
-        const bool fast = !last && (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && rows == TM;
+        const bool fast = !last && (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && rows == TM && (!p_rowbias || (l_N & 3) == 0);
         const long long off0 = (row0 + mbase) * l_ld + n4;    // this lane's first element in the side arrays
 
         // backward / tangent: the unit's stored activations are fetched from inside the k-loop (below)
@@ -329,9 +332,11 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
             f32x4 z = *reinterpret_cast<f32x4*>(lp + it * 32);
             f32x4 v;
             if (MODE == 0) {
+              f32x4 rb = {0.f, 0.f, 0.f, 0.f};
+              if (p_rowbias) rb = *((gptr<const f32x4>)(p_rowbias + ((row0 + mbase + 8 * it) / rb_div) * (long long)l_N + n4));
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                float t = z[q] + bias4[q];
+                float t = z[q] + bias4[q] + rb[q];
                 float u = b2 * t;
                 float sp = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(u)) * ib2;
                 v[q] = (u > 20.f * LOG2E ? t : sp) * sc;
@@ -399,6 +404,7 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 float t = z[q] + bias4[q];
+                if (p_rowbias && mrow && n4 + q < l_N) t += p_rowbias[(grow / rb_div) * (long long)l_N + n4 + q];
                 float u = b2 * t;
                 float sp = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(u)) * ib2;
                 v[q] = (u > 20.f * LOG2E ? t : sp) * (sc * cm[q] * rm);

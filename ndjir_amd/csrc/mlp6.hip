@@ -182,6 +182,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
       stamp(li, 0);
       const gptr<const bf16x8> p_wp = (gptr<const bf16x8>)pin(ly.Wp);
       const gptr<const float> p_bias = pin(ly.bias);
+      // forward, first layer only: per-row-group additive term (the part of x W_0 that is constant over a group)
+      const gptr<const float> p_rowbias = pin((MODE == 0 && li == 0) ? a.row_bias : nullptr);
+      const int rb_div = pin(a.row_bias_div > 0 ? a.row_bias_div : 1);
       const gptr<const float> p_side_in = pin(ly.side_in);
       const gptr<const float> p_side_in2 = pin(ly.side_in2);
       const gptr<const float> p_side_add = pin(ly.side_add);
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
         const int n4 = nb * 32 + g * 4;
         const int mbase = rb0 * 32 + (lane >> 3);
         const long long off0 = (row0 + mbase) * l_ld + n4;
-        const bool fast = !last && (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && rows == TM;
+        const bool fast = !last && (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && rows == TM && (!p_rowbias || (l_N & 3) == 0);
         f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
         const float* lp = stage + g * GPS + (lane >> 3) * 4;
         if (fast) {
@@ -373,9 +376,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
             const f32x4 z = *reinterpret_cast<const f32x4*>(lp + it * 32);
             f32x4 v;
             if (MODE == 0) {
+              f32x4 rb = {0.f, 0.f, 0.f, 0.f};
+              if (p_rowbias) rb = *((gptr<const f32x4>)(p_rowbias + ((row0 + mbase + 8 * it) / rb_div) * (long long)l_N + n4));
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const float t = z[q] + bias4[q];
+                const float t = z[q] + bias4[q] + rb[q];
                 const float u = b2 * t;
                 const float sp = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(u)) * ib2;
                 v[q] = (u > 20.f * LOG2E ? t : sp) * sc;
@@ -439,7 +444,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
             if (MODE == 0) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const float t = z[q] + bias4[q];
+                float t = z[q] + bias4[q];
+                if (p_rowbias && mrow && n4 + q < l_N) t += p_rowbias[(grow / rb_div) * (long long)l_N + n4 + q];
                 const float u = b2 * t;
                 const float sp = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(u)) * ib2;
                 v[q] = (u > 20.f * LOG2E ? t : sp) * (sc * cm[q] * rm);

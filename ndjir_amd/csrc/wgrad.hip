@@ -522,6 +522,36 @@ int launch_colsum(const float* X, int ldx, int N, long long P, float* out, int a
   return launch_split_reduce(workspace, out, N, blocks, accum, stream);
 }
 
+// out[g][n] = sum over the `div` consecutive rows of group g of X[row][n]  (gradient of a per-group additive term)
+__global__ void __launch_bounds__(256) k_group_colsum(const float* __restrict__ X, int ldx, int N, int div, float* __restrict__ out) {
+  __shared__ float red[256];
+  const long long gidx = blockIdx.x;
+  const int TX = pow2_at_least(N), TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const float* Xg = X + gidx * (long long)div * ldx;
+  for (int n0 = 0; n0 < N; n0 += TX) {
+    const int n = n0 + tx;
+    float acc = 0.f;
+    if (n < N) {
+#pragma unroll 8
+      for (int r = ty; r < div; r += TY) acc += Xg[(long long)r * ldx + n];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = TY / 2; s > 0; s >>= 1) {
+      if (ty < s) red[threadIdx.x] += red[threadIdx.x + s * TX];
+      __syncthreads();
+    }
+    if (ty == 0 && n < N) out[gidx * N + n] = red[tx];
+    __syncthreads();
+  }
+}
+
+int launch_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_group_colsum, dim3((unsigned)G), dim3(256), 0, stream, X, ldx, N, div, out);
+  return ndjir_check_launch();
+}
+
 long long wgrad_workspace(int K, int N, long long P) {
   long long splits = pick_splits(K, N, P, 512);      // the larger of the two engines' plans
   if (N <= SW_NMAX) {                                  // narrow path: one partial per SW_ROWS rows

@@ -196,7 +196,7 @@ class GeometricMain(Function):
             _launch("chain_tan", _flops(P, Ks[:T], Ns[:T]), "mlp_chain_ex", 2, P, gb0, K0, K0, T,
                     [_packed(w, False) for w in W[:T]], [None] * T, Ks[:T], Ns[:T], side_in, side_out, ld, bg,
                     None, 0, 0, 0, beta, skip_at, scale, 0, None, 0, side_in2, [None] * T, side_out2,
-                    chain_workspace(dev, bg), shape=f"{P}:tan {K0}-" + "-".join(map(str, Ns[:T])))
+                    None, 0, chain_workspace(dev, bg), shape=f"{P}:tan {K0}-" + "-".join(map(str, Ns[:T])))
 
         # ---- backward chain with the extra adjoints ----
         need_x = has_grid
@@ -227,7 +227,7 @@ class GeometricMain(Function):
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain_ex", 1, P, gy, Ns[-1], Ns[-1], steps, Wp, [None] * steps, bK, bN,
                 side_in, side_out, ld, bg, gx, K0, 1 if (bskip >= 0 and need_x) else 0, 1 if need_x else 0, beta,
                 bskip, scale, split, gx if (bskip >= 0 and need_x) else None, K0, [None] * steps, side_add, [None] * steps,
-                chain_workspace(dev, bg), shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
+                None, 0, chain_workspace(dev, bg), shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
 
         if has_grid:
             lib.call("voxel_feature_grad_feature", P * D0, grid_grad, gx[:, npe:].contiguous(), xf, gs_shape, D0,

@@ -85,9 +85,11 @@ def chain_workspace(device, bgrads):
     return _workspace(device, lib.load().ndjir_mlp_chain_workspace(total)) if total else None
 
 
-def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, keep_hidden=False):
+def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, keep_hidden=False, row_bias=None,
+                  row_bias_div=1):
     """x (P, K0) contiguous.  Returns y (P, N_last) and the list of stored activations
-    A_1..A_{L-1} (inputs of layers 1..L-1) when keep_hidden."""
+    A_1..A_{L-1} (inputs of layers 1..L-1) when keep_hidden.  row_bias (P / row_bias_div, N_0): added to
+    the first layer's pre-activation of each group of row_bias_div consecutive rows."""
     P, K0 = x.shape
     L = len(weights)
     Ks, Ns, Wp, hidden = [], [], [], []
@@ -104,9 +106,18 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
     side_out = (hidden + [None]) if keep_hidden else [None] * L
     ld_side = [h.shape[1] if h is not None else 0 for h in side_out]
     flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
-    _launch("chain_fwd", flops, "mlp_chain", 0, P, x, x.shape[1], K0, L, Wp, [b.detach() if b is not None else None for b in biases],
-             Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
-             int(skip_layer), float(skip_scale), 0, None, 0, None, shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
+    bl = [b.detach() if b is not None else None for b in biases]
+    if row_bias is None:
+        _launch("chain_fwd", flops, "mlp_chain", 0, P, x, x.shape[1], K0, L, Wp, bl,
+                Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
+                int(skip_layer), float(skip_scale), 0, None, 0, None, shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
+    else:
+        assert P % row_bias_div == 0 and tuple(row_bias.shape) == (P // row_bias_div, Ns[0])
+        _launch("chain_fwd", flops, "mlp_chain_ex", 0, P, x, x.shape[1], K0, L, Wp, bl,
+                Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
+                int(skip_layer), float(skip_scale), 0, None, 0, [None] * L, [None] * L, [None] * L,
+                row_bias.detach().contiguous(), int(row_bias_div), None,
+                shape=f"{P}:{K0}(+rows/{row_bias_div})-" + "-".join(map(str, Ns)))
     return y, hidden
 
 
@@ -167,16 +178,18 @@ class _Strided:
 
 class FusedMLP(Function):
     @staticmethod
-    def forward(ctx, x, beta, skip_layer, skip_scale, *params):
+    def forward(ctx, x, row_bias, row_bias_div, beta, skip_layer, skip_scale, *params):
         L = len(params) // 2
         weights, biases = list(params[:L]), list(params[L:])
         x2 = x.detach().reshape(-1, x.shape[-1]).contiguous()
         train = any(ctx.needs_input_grad)
+        rb = None if row_bias is None else row_bias.detach().reshape(-1, row_bias.shape[-1])
         y, hidden = chain_forward(x2, weights, biases, beta, skip_layer, skip_scale,
-                                  keep_hidden=train)
+                                  keep_hidden=train, row_bias=rb, row_bias_div=row_bias_div)
         if train:
             ctx.save_for_backward(x2, *hidden, *weights)
             ctx.cfg = (beta, skip_layer, skip_scale, L, tuple(x.shape))
+            ctx.rb = (None if row_bias is None else tuple(row_bias.shape), int(row_bias_div))
         return y.view(x.shape[:-1] + (y.shape[-1],))
 
     @staticmethod
@@ -189,7 +202,7 @@ class FusedMLP(Function):
         W = list(saved[L:2 * L])
         P, K0 = x2.shape
         need_x = ctx.needs_input_grad[0]
-        need_w = any(ctx.needs_input_grad[4:4 + L])
+        need_w = any(ctx.needs_input_grad[6:6 + L])
         gy2 = gy.reshape(P, -1).contiguous()
         # backward chain: step i applies W_{L-1-i}^T
         steps = L if need_x else L - 1
@@ -249,15 +262,25 @@ class FusedMLP(Function):
         gb = [None] * L
         if need_w:
             for j in range(L):
-                if ctx.needs_input_grad[4 + j]:
+                if ctx.needs_input_grad[6 + j]:
                     gW[j] = wgrad(A[j], deltas[j])
-                if ctx.needs_input_grad[4 + L + j]:
+                if ctx.needs_input_grad[6 + L + j]:
                     gb[j] = bgrads[j] if j < L - 1 else colsum(gy2)
-        return (gx.reshape(xshape) if gx is not None else None, None, None, None, *gW, *gb)
+        g_rb = None
+        rb_shape, rb_div = ctx.rb
+        if rb_shape is not None and ctx.needs_input_grad[1]:
+            # d/d(row term) = group-wise column sums of the first layer's delta
+            d0 = deltas[0]
+            G = P // rb_div
+            g_rb = torch.empty((G, d0.shape[1]), device=d0.device, dtype=torch.float32)
+            lib.call("mlp_group_colsum", _Strided(d0), d0.stride(0), d0.shape[1], G, rb_div, g_rb)
+            g_rb = g_rb.view(rb_shape)
+        return (gx.reshape(xshape) if gx is not None else None, g_rb, None, None, None, None, *gW, *gb)
 
 
-def fused_mlp(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0):
-    """x (..., K0); weights[j] (K_j, N_j); biases[j] (N_j,).  softplus(beta) hidden activations,
+def fused_mlp(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, row_bias=None, row_bias_div=1):
+    """x (..., K0); weights[j] (K_j, N_j); biases[j] (N_j,) or None.  softplus(beta) hidden activations,
     linear output; optional IDR-style skip: output of `skip_layer` is scaled by `skip_scale` and the
-    scaled input is appended (python/network.py:221-224)."""
-    return FusedMLP.apply(x, beta, skip_layer, skip_scale, *weights, *biases)
+    scaled input is appended (python/network.py:221-224).  row_bias (..., N_0): term added to the first
+    layer's pre-activation, constant over each group of `row_bias_div` consecutive rows of x."""
+    return FusedMLP.apply(x, row_bias, row_bias_div, beta, skip_layer, skip_scale, *weights, *biases)

@@ -297,16 +297,20 @@ def _last_act(name, beta):
     return {"softplus": lambda v: TF.softplus(v, beta=beta), "relu": torch.relu, "sigmoid": torch.sigmoid}[name]
 
 
-def _mlp(h, D, L, Dout, act, use_wn, shift=0):
-    """L-1 hidden layers of width D named affine-{l-shift:02d} + output layer affine-{L-1:02d}."""
+def _mlp_params(Din, D, L, Dout, use_wn, shift=0):
+    """Parameters of an MLP: L-1 hidden layers of width D named affine-{l-shift:02d} + output layer affine-{L-1:02d}."""
     Ws, bs = [], []
-    Din = h.shape[-1]
     for l in range(L - 1):
         W, b = affine_params(Din, D, use_wn, name=f"affine-{l - shift:02d}")
         Ws.append(W); bs.append(b)
         Din = D
     W, b = affine_params(Din, Dout, use_wn, name=f"affine-{L - 1:02d}")
     Ws.append(W); bs.append(b)
+    return Ws, bs
+
+
+def _mlp(h, D, L, Dout, act, use_wn, shift=0):
+    Ws, bs = _mlp_params(h.shape[-1], D, L, Dout, use_wn, shift)
     return _run_mlp(h, Ws, bs, act)
 
 
@@ -350,8 +354,26 @@ def soft_visibility_light_network(x, light_dirs, feature, normal, conf):
     with P.parameter_scope("soft-visibility-light-network"):
         c = conf.soft_visibility_light_network
         pe = positional_encoding(light_dirs, c.pe_bands) if c.pe_bands > 0 else light_dirs
-        inputs = [x, pe] + ([feature] if c.use_geometric_feature else []) + ([normal] if c.use_normal else [])
-        h = _mlp(torch.cat(inputs, dim=-1), c.feature_size, c.layers, c.channels, _act(c.act), conf.use_wn)
+        per_ray = [x] + ([feature] if c.use_geometric_feature else []) + ([normal] if c.use_normal else [])
+        act = _act(c.act)
+        if (USE_FUSED and act is softplus and c.layers >= 2 and pe.dim() == 4
+                and all(t.dim() == 4 and t.stride(2) == 0 for t in per_ray)):
+            # All inputs but the light direction are per-ray constants broadcast over the M lights.  The first
+            # affine is linear: their share  [x, feature, normal] W_0[rows] + b_0  is computed once per RAY and
+            # enters the fused chain as a per-row-group term; the (B,R,M,301) concatenation is never built and
+            # the first layer multiplies 39 instead of 301 columns per light.
+            B, R, M, _ = pe.shape
+            nx, npe = x.shape[-1], pe.shape[-1]
+            Ws, bs = _mlp_params(nx + npe + sum(t.shape[-1] for t in per_ray[1:]), c.feature_size, c.layers, c.channels,
+                                 conf.use_wn)
+            ray_in = torch.cat([t[:, :, 0, :] for t in per_ray], dim=-1)
+            W0_ray = torch.cat([Ws[0][:nx], Ws[0][nx + npe:]], dim=0)
+            row_term = torch.addmm(bs[0], ray_in.reshape(B * R, -1), W0_ray).view(B, R, -1)
+            from .mlp import fused_mlp
+            h = fused_mlp(pe, [Ws[0][nx:nx + npe]] + Ws[1:], [None] + bs[1:], 100.0, row_bias=row_term, row_bias_div=M)
+        else:
+            inputs = [x, pe] + per_ray[1:]
+            h = _mlp(torch.cat(inputs, dim=-1), c.feature_size, c.layers, c.channels, act, conf.use_wn)
         return _last_act(c.act_last, c.inverse_black_degree)(h)
 
 
