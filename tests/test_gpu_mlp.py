@@ -217,3 +217,38 @@ def test_geometric_main_double_backward(gpu, grid):
     names = [f"W{j}" for j in range(8)] + [f"b{j}" for j in range(8)] + (["F"] if grid else [])
     for nm, a, b in zip(names, grads, g64):
         assert rel(a, b) < 1e-3, (nm, rel(a, b))   # fp32 vs fp64 through beta=100 second-order terms
+
+
+def _rel(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).norm() / max(float(b.detach().cpu().double().norm()), 1e-30))
+
+
+@pytest.mark.parametrize("P,div,K0,Dh,No", [(4096, 128, 39, 128, 1), (640, 64, 39, 128, 1), (300, 100, 7, 64, 3)])
+def test_fused_mlp_row_bias(gpu, P, div, K0, Dh, No):
+    """per-row-group first-layer term: y = MLP(x; z_0 += row_term[row // div]) vs fp64 autograd, all gradients
+    (incl. the group-wise column sum that is the row term's gradient)."""
+    from ndjir_amd.mlp import fused_mlp
+    rng = np.random.RandomState(P + div)
+    dims = [K0, Dh, Dh, No]
+    Ws = [torch.tensor(rng.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i]), dtype=torch.float64, device=gpu) for i in range(3)]
+    bs = [None] + [torch.tensor(rng.randn(dims[i + 1]) * 0.1, dtype=torch.float64, device=gpu) for i in (1, 2)]
+    x = torch.tensor(rng.randn(P, K0), dtype=torch.float64, device=gpu)
+    rt = torch.tensor(rng.randn(P // div, Dh) * 0.3, dtype=torch.float64, device=gpu)
+
+    def ref(x, rt, Ws, bs):
+        h = x @ Ws[0] + rt.repeat_interleave(div, dim=0)
+        h = TF.softplus(h, beta=100)
+        h = TF.softplus(h @ Ws[1] + bs[1], beta=100)
+        return h @ Ws[2] + bs[2]
+
+    a64 = [x.clone().requires_grad_(True), rt.clone().requires_grad_(True)] + [w.clone().requires_grad_(True) for w in Ws] \
+        + [b.clone().requires_grad_(True) for b in bs[1:]]
+    y64 = ref(a64[0], a64[1], a64[2:5], [None] + a64[5:7])
+    a32 = [t.detach().float().requires_grad_(True) for t in a64]
+    y32 = fused_mlp(a32[0], a32[2:5], [None] + a32[5:7], 100.0, row_bias=a32[1], row_bias_div=div)
+    assert _rel(y32, y64.detach().cpu()) < 2e-6
+    g = torch.tensor(rng.randn(*y64.shape), dtype=torch.float64, device=gpu)
+    g64 = torch.autograd.grad(y64, a64, g)
+    g32 = torch.autograd.grad(y32, a32, g.float())
+    for i, (a, b) in enumerate(zip(g32, g64)):
+        assert _rel(a, b.cpu()) < 2e-5, i
