@@ -81,3 +81,27 @@ def test_render_image_tiles(gpu):
     K = np.array([[[20.0, 0, 8], [0, 20.0, 6], [0, 0, 1]]])
     img = render_image(pose, K, (16, 12), conf, device=gpu)
     assert img.shape == (1, 3, 12, 16) and np.isfinite(img).all() and img.min() >= 0 and img.max() <= 1
+
+
+def test_bench_step_graph_replay_matches_eager(gpu):
+    """bench.py times the step replayed from one captured HIP graph: the replayed step must produce the
+    eager step's loss and gradients (incl. the sparse re-zeroing of the grid gradient buffer between steps)."""
+    import bench
+    from ndjir_amd import config as cfg
+    conf = cfg.load("default", ["geometric_network.voxel.grid_size=64"])
+    step = bench.Step(conf, 64, gpu, 0, 1)
+    for _ in range(2):
+        loss_e = step.forward_backward()
+    eager = [g.clone() if g is not None else None for g in step.grads]
+    grid_e = {k: v.clone() for k, v in step.grid_bufs.items()}
+    graph, loss_g = bench.capture_step(step)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert abs(float(loss_g) - float(loss_e)) <= 1e-6 * abs(float(loss_e))
+    for a, b in zip(step.grads, eager):
+        if b is None:
+            continue
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-12)
+    for k, v in step.grid_bufs.items():
+        assert float((v - grid_e[k]).abs().max()) <= 1e-5 * max(float(grid_e[k].abs().max()), 1e-12), k
