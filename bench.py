@@ -82,6 +82,7 @@ class Step:
         self.P = P
         self.grid_bufs = {}
         self.touched = None      # query points whose cells hold gradient from the previous step
+        self.remote_rows = {}    # multi-GPU: grid rows received from the other ranks in the previous exchange
         self.mlp_names = None
         self.forward_backward()          # creates the parameters (untimed)
         for name, p in P.get_parameters().items():
@@ -103,12 +104,13 @@ class Step:
         from ndjir_amd.grid_feature import zero_touched
         v = self.conf.geometric_network.voxel
         for name, buf in self.grid_bufs.items():
-            # (multi-GPU: the sparse exchange also deposits OTHER ranks' rows in this buffer -> dense zero)
-            if v.type == "voxel" and self.touched is not None and self.world == 1:
+            if v.type == "voxel" and self.touched is not None and (self.world == 1 or name in self.remote_rows):
                 x_fg = self.touched
                 r = self.conf.renderer.bounding_sphere_radius
                 zero_touched(buf, x_fg)
                 zero_touched(buf, x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size))
+                if self.world > 1:      # rows the sparse exchange deposited on behalf of the other ranks
+                    buf.view(-1, buf.shape[-1]).index_fill_(0, self.remote_rows[name], 0.0)
             else:
                 buf.zero_()
 
@@ -153,7 +155,7 @@ class Step:
                 r = self.conf.renderer.bounding_sphere_radius
                 x_ptb = x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size)
                 queries["geometric-network/voxel_feature/F"] = ([x_fg, x_ptb], [v.grid_size] * 3)
-            allreduce_step_gradients(self.flat_grad, self.grid_bufs, queries)
+            self.remote_rows = allreduce_step_gradients(self.flat_grad, self.grid_bufs, queries)
         return loss.detach()
 
 

@@ -34,14 +34,16 @@ def voxel_cell_ids(query, grid_sizes, min_=(-1.0, -1.0, -1.0), max_=(1.0, 1.0, 1
     return torch.stack(ids, dim=1).reshape(-1)
 
 
-def allreduce_sparse_rows(buf, cell_ids, group=None):
+def allreduce_sparse_rows(buf, cell_ids, group=None, return_remote=False):
     """Sum `buf` (cells, D) over the ranks, given that rank-local non-zeros live in rows `cell_ids`.
+    return_remote: also return the row ids received from the other ranks (rows this rank now holds gradient
+    in although its own queries never touched them -- needed to re-arm the buffer sparsely).
 
     Every rank ends with buf_total = sum_r buf_r restricted to the union of touched rows; rows
     nobody touched stay as they are (zero).  Exchange volume: U_r x (8 + 4 D) bytes per rank."""
     world = dist.get_world_size(group)
     if world == 1:
-        return buf
+        return (buf, torch.empty((0,), device=buf.device, dtype=torch.int64)) if return_remote else buf
     rank = dist.get_rank(group)
     uniq = torch.unique(cell_ids)
     vals = buf.index_select(0, uniq)
@@ -58,17 +60,23 @@ def allreduce_sparse_rows(buf, cell_ids, group=None):
     all_val = [torch.empty_like(pad_val) for _ in range(world)]
     dist.all_gather(all_idx, pad_idx, group=group)
     dist.all_gather(all_val, pad_val, group=group)
+    remote = []
     for r in range(world):
         if r != rank and counts[r] > 0:
             buf.index_add_(0, all_idx[r][:counts[r]], all_val[r][:counts[r]])
+            remote.append(all_idx[r][:counts[r]])
+    if return_remote:
+        return buf, (torch.cat(remote) if remote else torch.empty((0,), device=buf.device, dtype=torch.int64))
     return buf
 
 
 def allreduce_step_gradients(flat_mlp_grad, grid_bufs, grid_queries, group=None):
     """One gradient exchange per step.  `grid_bufs`: {name: dense gradient buffer};
     `grid_queries`: {name: (list of query tensors, grid_sizes)} for dense voxel grids; buffers
-    without an entry (tri-plane / tri-line, a few hundred MB at most) are all-reduced densely."""
+    without an entry (tri-plane / tri-line, a few hundred MB at most) are all-reduced densely.
+    Returns {name: row ids received from other ranks} for the sparsely exchanged buffers."""
     dist.all_reduce(flat_mlp_grad, group=group)
+    remote_rows = {}
     for name, buf in grid_bufs.items():
         q = grid_queries.get(name)
         if q is None:
@@ -76,4 +84,5 @@ def allreduce_step_gradients(flat_mlp_grad, grid_bufs, grid_queries, group=None)
             continue
         queries, grid_sizes = q
         ids = torch.cat([voxel_cell_ids(x, grid_sizes) for x in queries])
-        allreduce_sparse_rows(buf.view(-1, buf.shape[-1]), ids, group=group)
+        _, remote_rows[name] = allreduce_sparse_rows(buf.view(-1, buf.shape[-1]), ids, group=group, return_remote=True)
+    return remote_rows

@@ -107,8 +107,13 @@ def _sparse_exchange(rank, world, port, q):
     flat_ref = flat.clone()
     dist.all_reduce(dense)
     dist.all_reduce(flat_ref)
-    allreduce_step_gradients(flat, {"g": buf}, {"g": ([x], [G, G, G])})
+    remote = allreduce_step_gradients(flat, {"g": buf}, {"g": ([x], [G, G, G])})
     ok = torch.allclose(buf, dense, atol=1e-6) and torch.allclose(flat, flat_ref)
+    # sparse re-arming (bench.Step.rearm_grid_buffers): own touched cells + the rows received from the other
+    # ranks must cover every non-zero of the exchanged buffer
+    buf.view(-1, D)[ids.unique()] = 0.0
+    buf.view(-1, D).index_fill_(0, remote["g"], 0.0)
+    ok = ok and int((buf != 0).sum()) == 0
     q.put((rank, bool(ok), float((buf - dense).abs().max())))
     dist.destroy_process_group()
 
