@@ -8,6 +8,8 @@
 // Workgroup -> (split, tile) mapping keeps the tiles that share a P-range on one XCD (shared L2).
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "mlp.h"
 
@@ -553,7 +555,7 @@ int launch_group_colsum(const float* X, int ldx, int N, long long G, int div, fl
 }
 
 long long wgrad_workspace(int K, int N, long long P) {
-  long long splits = pick_splits(K, N, P, 512);      // the larger of the two engines' plans
+  long long splits = pick_splits(K, N, P, 1024);     // upper bound over both engines' plans (and NDJIR_WGRAD_BLOCKS)
   if (N <= SW_NMAX) {                                  // narrow path: one partial per SW_ROWS rows
     const long long nb = (P + SW_ROWS - 1) / SW_ROWS;
     if (nb > splits) splits = nb;
@@ -586,7 +588,8 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
     return launch_split_reduce(workspace, out, (long long)K * N, (int)blocks, accum, stream);
   }
   const WgradPlan pl = wgrad_plan(K, N);
-  const int S = pick_splits(K, N, P, bf16x6 ? 512 : 256);
+  static const int x6_blocks = [] { const char* e = getenv("NDJIR_WGRAD_BLOCKS"); int v = e ? atoi(e) : 512; return (v >= 64 && v <= 1024) ? v : 512; }();
+  const int S = pick_splits(K, N, P, bf16x6 ? x6_blocks : 256);
   long long rows = (P + S - 1) / S;
   rows = (rows + WG_C - 1) / WG_C * WG_C;
   if (bf16x6) {
