@@ -357,7 +357,7 @@ def soft_visibility_light_network(x, light_dirs, feature, normal, conf):
         per_ray = [x] + ([feature] if c.use_geometric_feature else []) + ([normal] if c.use_normal else [])
         act = _act(c.act)
         if (USE_FUSED and act is softplus and c.layers >= 2 and pe.dim() == 4
-                and all(t.dim() == 4 and t.stride(2) == 0 for t in per_ray)):
+                and all(t.dim() == 4 and (t.shape[2] == 1 or t.stride(2) == 0) for t in per_ray)):
             # All inputs but the light direction are per-ray constants broadcast over the M lights.  The first
             # affine is linear: their share  [x, feature, normal] W_0[rows] + b_0  is computed once per RAY and
             # enters the fused chain as a per-row-group term; the (B,R,M,301) concatenation is never built and
@@ -372,7 +372,8 @@ def soft_visibility_light_network(x, light_dirs, feature, normal, conf):
             from .mlp import fused_mlp
             h = fused_mlp(pe, [Ws[0][nx:nx + npe]] + Ws[1:], [None] + bs[1:], 100.0, row_bias=row_term, row_bias_div=M)
         else:
-            inputs = [x, pe] + per_ray[1:]
+            per_ray = [t.expand(t.shape[0], t.shape[1], pe.shape[2], t.shape[3]) for t in per_ray]
+            inputs = [per_ray[0], pe] + per_ray[1:]
             h = _mlp(torch.cat(inputs, dim=-1), c.feature_size, c.layers, c.channels, act, conf.use_wn)
         return _last_act(c.act_last, c.inverse_black_degree)(h)
 

@@ -153,8 +153,8 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     # here (row-independent nets: same values; their weight gradients come from one reduction over 2 M lights)
     dirs_all = torch.cat([uniform_light_dir, imp_dir], dim=2)
     env_all = environment_light_network(dirs_all, conf)
-    soft_vis_all = soft_visibility_light_network(x_fg_pixel.expand(B, R, 2 * M, 3), dirs_all,
-                                                 feature_pixel.expand(B, R, 2 * M, D), normal_bc.expand(B, R, 2 * M, 3), conf)
+    # (per-ray inputs are passed un-broadcast, (B,R,1,*): the net folds them into a per-ray first-layer term)
+    soft_vis_all = soft_visibility_light_network(x_fg_pixel, dirs_all, feature_pixel, normal_bc, conf)
     env_d, env = env_all[:, :, :M], env_all[:, :, M:]
     soft_vis_d, soft_vis = soft_vis_all[:, :, :M], soft_vis_all[:, :, M:]
 
