@@ -233,9 +233,11 @@ int ndjir_render_alpha_weights_backward(int R, int N, int Nb, const float* sdf, 
                                         float* g_sdf, float* g_n, float* g_gain_ray, float* g_alpha_bg,
                                         hipStream_t stream);
 /* VR integral (renderer.py:84-87): out (R,C) = sum_i w[r][i] x[r][i][c], w rows of stride ldw >= S,
- * x (R,S,C).  Backward: gx (R,S,C) = w g, gw[r][i] (row stride ldgw) = sum_c x g; either may be null. */
-int ndjir_render_integrate(int R, int S, int C, const float* w, int ldw, const float* x, float* out, hipStream_t stream);
-int ndjir_render_integrate_backward(int R, int S, int C, const float* w, int ldw, const float* x, const float* g,
+ * x (R*S rows of C values, row stride ldx >= C).  Backward: gx (R,S,C) = w g, gw[r][i] (row stride ldgw) =
+ * sum_c x g; either may be null. */
+int ndjir_render_integrate(int R, int S, int C, const float* w, int ldw, const float* x, int ldx, float* out,
+                           hipStream_t stream);
+int ndjir_render_integrate_backward(int R, int S, int C, const float* w, int ldw, const float* x, int ldx, const float* g,
                                     float* gx, float* gw, int ldgw, hipStream_t stream);
 
 /* Direct-light integrals over the M sampled light directions of each ray, one launch each way.

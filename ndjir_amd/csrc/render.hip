@@ -160,19 +160,19 @@ __device__ __forceinline__ int rd_pow2(int v) {
 }
 
 __global__ void __launch_bounds__(256) k_integrate(int S, int C, const float* __restrict__ w, int ldw,
-                                                   const float* __restrict__ x, float* __restrict__ out) {
+                                                   const float* __restrict__ x, int ldx, float* __restrict__ out) {
   __shared__ float red[256];
   const long long r = blockIdx.x;
   const int TX = rd_pow2(C), TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const float* wr = w + r * ldw;
-  const float* xr = x + r * (long long)S * C;
+  const float* xr = x + r * (long long)S * ldx;
   for (int c0 = 0; c0 < C; c0 += TX) {
     const int c = c0 + tx;
     float acc = 0.f;
     if (c < C) {
 #pragma unroll 4
-      for (int i = ty; i < S; i += TY) acc += wr[i] * xr[(long long)i * C + c];
+      for (int i = ty; i < S; i += TY) acc += wr[i] * xr[(long long)i * ldx + c];
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256) k_integrate(int S, int C, const float* __
 // gx[r][i][c] = w[r][i] g[r][c];  gw[r][i] = sum_c x[r][i][c] g[r][c].  One workgroup per ray, a wave
 // per sample (lanes over channels, shuffle reduction).  gx / gw may be null.
 __global__ void __launch_bounds__(256) k_integrate_bwd(int S, int C, const float* __restrict__ w, int ldw,
-                                                       const float* __restrict__ x, const float* __restrict__ g,
+                                                       const float* __restrict__ x, int ldx, const float* __restrict__ g,
                                                        float* __restrict__ gx, float* __restrict__ gw, int ldgw) {
   const long long r = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256) k_integrate_bwd(int S, int C, const float
       float acc = 0.f;
       for (int c = 0; c < C; ++c) {
         const long long e = (r * S + i) * C + c;
-        if (gw) acc += x[e] * gr[c];
+        if (gw) acc += x[(r * S + i) * ldx + c] * gr[c];
         if (gx) gx[e] = wi * gr[c];
       }
       if (gw) gw[r * ldgw + i] = acc;
@@ -210,11 +210,11 @@ __global__ void __launch_bounds__(256) k_integrate_bwd(int S, int C, const float
   }
   for (int i = wave; i < S; i += 4) {
     const float wi = wr[i];
-    const long long base = (r * S + i) * C;
+    const long long base = (r * S + i) * C, xbase = (r * S + i) * ldx;
     float acc = 0.f;
     for (int c = lane; c < C; c += 64) {
       const float gc = gr[c];
-      if (gw) acc += x[base + c] * gc;
+      if (gw) acc += x[xbase + c] * gc;
       if (gx) gx[base + c] = wi * gc;
     }
     if (gw) {
@@ -259,19 +259,19 @@ extern "C" int ndjir_render_alpha_weights_backward(int R, int N, int Nb, const f
   return ndjir_check_launch();
 }
 
-extern "C" int ndjir_render_integrate(int R, int S, int C, const float* w, int ldw, const float* x, float* out,
+extern "C" int ndjir_render_integrate(int R, int S, int C, const float* w, int ldw, const float* x, int ldx, float* out,
                                       hipStream_t stream) {
   if (R <= 0 || C <= 0) return NDJIR_OK;
-  if (S < 0 || ldw < S || !w || !x || !out) return NDJIR_ERR_ARG;
-  hipLaunchKernelGGL(k_integrate, dim3(R), dim3(256), 0, stream, S, C, w, ldw, x, out);
+  if (S < 0 || ldw < S || ldx < C || !w || !x || !out) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_integrate, dim3(R), dim3(256), 0, stream, S, C, w, ldw, x, ldx, out);
   return ndjir_check_launch();
 }
 
-extern "C" int ndjir_render_integrate_backward(int R, int S, int C, const float* w, int ldw, const float* x, const float* g,
-                                               float* gx, float* gw, int ldgw, hipStream_t stream) {
+extern "C" int ndjir_render_integrate_backward(int R, int S, int C, const float* w, int ldw, const float* x, int ldx,
+                                               const float* g, float* gx, float* gw, int ldgw, hipStream_t stream) {
   if (R <= 0 || C <= 0 || S <= 0) return NDJIR_OK;
-  if (ldw < S || !w || !x || !g || (gw && ldgw < S)) return NDJIR_ERR_ARG;
-  hipLaunchKernelGGL(k_integrate_bwd, dim3(R), dim3(256), 0, stream, S, C, w, ldw, x, g, gx, gw, ldgw);
+  if (ldw < S || ldx < C || !w || !x || !g || (gw && ldgw < S)) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_integrate_bwd, dim3(R), dim3(256), 0, stream, S, C, w, ldw, x, ldx, g, gx, gw, ldgw);
   return ndjir_check_launch();
 }
 

@@ -45,7 +45,7 @@ SIGS = {
     "mlp_colsum": "piilpip",
     "render_alpha_weights": "iii" + "p" * 11,
     "render_alpha_weights_backward": "iii" + "p" * 16,
-    "render_integrate": "iiipipp",
+    "render_integrate": "iiipipip",
     "render_material_head": "ii" + "p" * 7 + "iiiffff" + "ppp",
     "render_material_head_backward": "ii" + "p" * 7 + "iiiffff" + "pp" + "p" * 6,
     "positional_encoding": "liiipp",
@@ -54,7 +54,7 @@ SIGS = {
     "render_diffuse_light_backward": "iiippppfpppp",
     "render_specular_light_filament": "iii" + "p" * 7 + "ffp",
     "render_specular_light_filament_backward": "iii" + "p" * 7 + "ff" + "p" * 6,
-    "render_integrate_backward": "iiipippppi",
+    "render_integrate_backward": "iiipipipppi",
     "sampler_importance_round": "iiifpppppqqp",
     "ray_aabb_intersection": "ipppppiiFF",
     "ray_sphere_intersection": "ipppppiif",

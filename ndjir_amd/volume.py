@@ -66,11 +66,15 @@ class Integrate(Function):
         B, R, S, C = x.shape
         S_all = weights.shape[2]
         w = _c(weights)
-        xc = _c(x)
+        xc = x.detach()
+        ld = xc.stride(2)
+        if not (xc.stride(3) == 1 and ld >= C and xc.stride(1) == S * ld and xc.stride(0) == R * S * ld):
+            xc = xc.contiguous()      # anything but a column slice of a row-major (B,R,S,ld) array
+            ld = C
         out = torch.empty((B, R, C), device=x.device, dtype=torch.float32)
-        lib.call("render_integrate", B * R, S, C, _Strided(w.view(B * R, S_all)[:, off:]), S_all, xc, out)
+        lib.call("render_integrate", B * R, S, C, _Strided(w.view(B * R, S_all)[:, off:]), S_all, _Strided(xc), ld, out)
         ctx.save_for_backward(w, xc)
-        ctx.off = off
+        ctx.off, ctx.ldx = off, ld
         return out
 
     @staticmethod
@@ -81,11 +85,12 @@ class Integrate(Function):
         S_all = w.shape[2]
         off = ctx.off
         need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
-        gx = torch.empty_like(x) if need_x else None
+        gx = torch.empty((B, R, S, C), device=x.device, dtype=torch.float32) if need_x else None
         gw = None
         if need_w:
             gw = torch.zeros_like(w) if S != S_all else torch.empty_like(w)
-        lib.call("render_integrate_backward", B * R, S, C, _Strided(w.view(B * R, S_all)[:, off:]), S_all, x, g.contiguous(),
+        lib.call("render_integrate_backward", B * R, S, C, _Strided(w.view(B * R, S_all)[:, off:]), S_all, _Strided(x), ctx.ldx,
+                 g.contiguous(),
                  gx, _Strided(gw.view(B * R, S_all)[:, off:]) if need_w else None, S_all)
         return gw, None, gx
 
