@@ -308,7 +308,9 @@ int ndjir_positional_encoding_backward(long long P, int C, int M, int include_in
  *                 (P x N), bgrad[i] (N) its column sums = the bias gradient (overwritten; summed per
  *                 workgroup in LDS, then across workgroups from `workspace`, which must hold
  *                 ndjir_mlp_chain_workspace(sum of the N_i that have a bgrad) floats -- may be null
- *                 when no bgrad is requested); with has_output the last step writes dL/dX to Y.
+ *                 when no bgrad is requested); in_bgrad (K0 floats, may be null) receives the column sums of
+ *                 the chain input dL/dY itself = the bias gradient of the net's output layer (its N counts
+ *                 towards the workspace size); with has_output the last step writes dL/dX to Y.
  *                 Weight gradients are plain GEMMs H^T delta (ndjir_mlp_wgrad).
  * Per-layer arrays are HOST arrays of length L; Ks/Ns are each step's logical input/output width.
  * skip_layer (-1 = none): forward, the output of that layer is scaled by skip_scale and the scaled
@@ -326,7 +328,7 @@ int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L
                     const float* const* side_in, float* const* side_out, const int* ld_side,
                     float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                     int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
-                    float* workspace, hipStream_t stream);
+                    float* in_bgrad, float* workspace, hipStream_t stream);
 long long ndjir_mlp_chain_workspace(int bgrad_total);   /* floats */
 /* Extended chain used by the geometric network, whose output gradient d(sdf)/dx itself enters the
  * loss (nn.grad, python/renderer.py:52; eikonal term python/loss.py:68-76):
@@ -342,7 +344,7 @@ int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx, int K0, i
                        float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                        int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                        const float* const* side_in2, const float* const* side_add, float* const* side_out2,
-                       const float* row_bias, int row_bias_div, float* workspace, hipStream_t stream);
+                       const float* row_bias, int row_bias_div, float* in_bgrad, float* workspace, hipStream_t stream);
 /* row_bias (mode 0, may be null): (P / row_bias_div, N_0) term added to the first layer's pre-activation of every
  * group of row_bias_div consecutive rows -- the part of x W_0 that is constant over a group (e.g. the per-ray inputs
  * of the soft-visibility net, python/network.py:339-377, whose other inputs vary per light direction): it is

@@ -44,8 +44,11 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
                                float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                                int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                                const float* const* side_in2, const float* const* side_add, float* const* side_out2,
-                               const float* row_bias, int row_bias_div, float* workspace, hipStream_t stream) {
+                               const float* row_bias, int row_bias_div, float* in_bgrad, float* workspace,
+                               hipStream_t stream) {
   if (P <= 0) {
+    if (bwd != 0 && in_bgrad && K0 > 0 && hipMemsetAsync(in_bgrad, 0, (size_t)K0 * sizeof(float), stream) != hipSuccess)
+      return NDJIR_ERR_LAUNCH;
     // nothing to process: bias gradients of an empty batch are zero
     if (bwd != 0 && bgrad && Ns && L >= 1 && L <= MAX_CHAIN_LAYERS)
       for (int i = 0; i < L; ++i)
@@ -63,6 +66,7 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
   a.bg_partial = workspace;
   if (row_bias && (bwd != 0 || L < 2 || row_bias_div < 1)) return NDJIR_ERR_ARG;
   a.row_bias = row_bias; a.row_bias_div = row_bias_div;
+  a.in_bgrad = (bwd != 0) ? in_bgrad : nullptr;
   a.P = P; a.X = X; a.ldx = ldx; a.K0 = K0; a.K0p = round_up(K0, 8); a.L = L;
   a.Y = Y; a.ldy = ldy; a.accum_y = accum_y; a.has_output = has_output; a.beta = beta;
   a.skip_layer = skip_layer; a.skip_scale = skip_scale; a.skip_split = skip_split; a.Xskip = Xskip; a.ld_xskip = ld_xskip;
@@ -99,11 +103,11 @@ extern "C" int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, in
                                const float* const* side_in, float* const* side_out, const int* ld_side,
                                float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                                int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
-                               float* workspace, hipStream_t stream) {
+                               float* in_bgrad, float* workspace, hipStream_t stream) {
   if (bwd != 0 && bwd != 1) return NDJIR_ERR_ARG;
   return chain_impl(bwd, P, X, ldx, K0, L, Wp, bias, Ks, Ns, side_in, side_out, ld_side, bgrad, Y, ldy, accum_y,
                     has_output, beta, skip_layer, skip_scale, skip_split, Xskip, ld_xskip, nullptr, nullptr, nullptr, nullptr, 0,
-                    workspace, stream);
+                    in_bgrad, workspace, stream);
 }
 
 // Extended form used by the geometric network's double backward (python/renderer.py:52 nn.grad):
@@ -114,11 +118,12 @@ extern "C" int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx
                                   float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                                   int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                                   const float* const* side_in2, const float* const* side_add, float* const* side_out2,
-                                  const float* row_bias, int row_bias_div, float* workspace, hipStream_t stream) {
+                                  const float* row_bias, int row_bias_div, float* in_bgrad, float* workspace,
+                                  hipStream_t stream) {
   if (mode < 0 || mode > 2) return NDJIR_ERR_ARG;
   return chain_impl(mode, P, X, ldx, K0, L, Wp, bias, Ks, Ns, side_in, side_out, ld_side, bgrad, Y, ldy, accum_y,
                     has_output, beta, skip_layer, skip_scale, skip_split, Xskip, ld_xskip, side_in2, side_add, side_out2,
-                    row_bias, row_bias_div, workspace, stream);
+                    row_bias, row_bias_div, in_bgrad, workspace, stream);
 }
 
 extern "C" long long ndjir_mlp_chain_workspace(int bgrad_total) { return chain_workspace(bgrad_total); }

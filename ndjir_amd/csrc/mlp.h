@@ -41,6 +41,8 @@ struct ChainArgs {
   float beta;
   const float* row_bias;  // forward: (P / row_bias_div, N_0) term added to the first layer's pre-activation of each row group
   int row_bias_div;
+  float* in_bgrad;        // backward: column sums of the chain INPUT (= bias gradient of the net's output layer), K0 floats
+  int in_bg_off;          // filled by launch_chain
   float* bg_partial;    // bias gradients: per-workgroup partial sums [grid][bg_total] (workspace)
   int bg_total, bg_lds; // filled by launch_chain: accumulator floats / its offset in LDS
   long long* timeline;  // diagnostics (tools/chain_timeline.py): per-layer phase stamps of workgroup 0, else null

@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
   // from every tile serialise in the memory-side cache: measured 4x on the 128-wide nets)
   float* bsum = lds + a.bg_lds;
   if (MODE != 0) for (int i = tid; i < a.bg_total; i += NTHREADS) bsum[i] = 0.f;
+  if (MODE != 0 && a.in_bgrad) __syncthreads();    // the first tile's input load already accumulates into bsum
 
   for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long row0 = tile * TM;
@@ -132,12 +133,17 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
             else { for (int q = 0; q < 4; ++q) if (k + q < K0) v[q] = X[(long long)m * a.ldx + k + q]; }
           }
           *reinterpret_cast<f32x4*>(bufA + g * GP + m * 4) = v;
+          if (MODE != 0 && a.in_bgrad && m < rows) {    // bias gradient of the output layer: column sums of the input
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (g * 4 + q < K0) atomicAdd(bsum + a.in_bg_off + g * 4 + q, v[q]);
+          }
         }
       } else {
         for (int t = tid; t < K0p * TM; t += NTHREADS) {
           int k = t % K0p, m = t / K0p;
           float v = (m < rows && k < K0) ? X[(long long)m * a.ldx + k] : 0.f;
           bufA[(k >> 2) * GP + m * 4 + (k & 3)] = v;
+          if (MODE != 0 && a.in_bgrad && m < rows && k < K0) atomicAdd(bsum + a.in_bg_off + k, v);
         }
       }
     }
@@ -503,8 +509,8 @@ __global__ void __launch_bounds__(NTHREADS, ((TM == 64 || MODE != 0) ? 2 : 4)) k
 
 // bias gradients: out_l[n] = sum over workgroups of partial[g][off_l + n]
 struct BgOut {
-  float* ptr[MAX_CHAIN_LAYERS];
-  int off[MAX_CHAIN_LAYERS + 1];
+  float* ptr[MAX_CHAIN_LAYERS + 1];
+  int off[MAX_CHAIN_LAYERS + 2];
   int n;
 };
 __global__ void __launch_bounds__(256) k_bgrad_reduce(const float* __restrict__ partial, int S, int total, BgOut o) {
@@ -582,6 +588,14 @@ int launch_chain(const ChainArgs& a, int mode, hipStream_t stream) {
       ++bg.n;
       bg_total += a.layers[i].N;
     } else b.layers[i].bgrad = nullptr;
+    bg.off[bg.n] = bg_total;
+  }
+  if (mode != 0 && a.in_bgrad) {
+    b.in_bg_off = bg_total;
+    bg.ptr[bg.n] = a.in_bgrad;
+    bg.off[bg.n] = bg_total;
+    ++bg.n;
+    bg_total += a.K0;
     bg.off[bg.n] = bg_total;
   }
   b.bg_total = bg_total;

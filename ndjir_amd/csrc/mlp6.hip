@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
   };
 
   if (MODE != 0) for (int i = tid; i < a.bg_total; i += NTHREADS) bsum[i] = 0.f;
+  if (MODE != 0 && a.in_bgrad) __syncthreads();    // the first tile's input load already accumulates into bsum
 
   for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long row0 = tile * TM;
@@ -170,6 +171,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
           }
         }
         put4(k, m, v);
+        if (MODE != 0 && a.in_bgrad && m < rows) {      // bias gradient of the output layer: column sums of the input
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (k + q < K0) atomicAdd(bsum + a.in_bg_off + k + q, v[q]);
+        }
       }
     }
     __syncthreads();
@@ -578,8 +583,8 @@ int launch_chain6(const ChainArgs& a, int mode, hipStream_t stream) {
   if (stage_bytes < partials) stage_bytes = partials;
   lds_bytes += stage_bytes;
   b.n_tiles = (a.P + TM - 1) / TM;
-  float* bg_ptr[MAX_CHAIN_LAYERS];
-  int bg_off[MAX_CHAIN_LAYERS];
+  float* bg_ptr[MAX_CHAIN_LAYERS + 1];
+  int bg_off[MAX_CHAIN_LAYERS + 1];
   int bg_n = 0, bg_total = 0;
   if (mode != 0) {
     for (int i = 0; i < a.L; ++i) if (a.layers[i].bgrad && !(a.has_output && i == a.L - 1)) {
@@ -589,6 +594,13 @@ int launch_chain6(const ChainArgs& a, int mode, hipStream_t stream) {
       ++bg_n;
       bg_total += a.layers[i].N;
     } else b.layers[i].bgrad = nullptr;
+  }
+  if (mode != 0 && a.in_bgrad) {
+    b.in_bg_off = bg_total;
+    bg_ptr[bg_n] = a.in_bgrad;
+    bg_off[bg_n] = bg_total;
+    ++bg_n;
+    bg_total += a.K0;
   }
   b.bg_total = bg_total;
   b.bg_lds = (int)(lds_bytes / 4);

@@ -79,7 +79,7 @@ class GeometricMain(Function):
         y = torch.empty((P, Ns[-1]), device=dev, dtype=torch.float32)
         _launch("chain_fwd", _flops(P, Ks, Ns), "mlp_chain", 0, P, e, K0, K0, L, [_packed(w, False) for w in W],
                 [t.detach() for t in b], Ks, Ns, [None] * L, A[1:] + [None], [a.shape[1] for a in A[1:]] + [0],
-                [None] * L, y, Ns[-1], 0, 1, beta, skip_at, scale, 0, None, 0, None,
+                [None] * L, y, Ns[-1], 0, 1, beta, skip_at, scale, 0, None, 0, None, None,
                 shape=f"{P}:geo {K0}-" + "-".join(map(str, Ns)))
 
         # ---- sdf chain: backward chain seeded with d(sdf) = 1, first step = column 0 of the last layer ----
@@ -111,7 +111,7 @@ class GeometricMain(Function):
         g0 = torch.zeros((P, K0), device=dev, dtype=torch.float32)
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain", 1, P, ones, 1, 1, L, Wp, [None] * L, bK, bN, side_in,
                 side_out, ld, [None] * L, g0, K0, 1 if bskip >= 0 else 0, 1, beta, bskip, scale, split,
-                g0 if bskip >= 0 else None, K0, None, shape=f"{P}:sdf 1-" + "-".join(map(str, bN)))
+                g0 if bskip >= 0 else None, K0, None, None, shape=f"{P}:sdf 1-" + "-".join(map(str, bN)))
 
         # ---- n = J_e(x)^T g_0 ----
         gc = g0[:, 3:3 + 3 * M].reshape(P, 3, M)
@@ -196,7 +196,7 @@ class GeometricMain(Function):
             _launch("chain_tan", _flops(P, Ks[:T], Ns[:T]), "mlp_chain_ex", 2, P, gb0, K0, K0, T,
                     [_packed(w, False) for w in W[:T]], [None] * T, Ks[:T], Ns[:T], side_in, side_out, ld, bg,
                     None, 0, 0, 0, beta, skip_at, scale, 0, None, 0, side_in2, [None] * T, side_out2,
-                    None, 0, chain_workspace(dev, bg), shape=f"{P}:tan {K0}-" + "-".join(map(str, Ns[:T])))
+                    None, 0, None, chain_workspace(dev, bg), shape=f"{P}:tan {K0}-" + "-".join(map(str, Ns[:T])))
 
         # ---- backward chain with the extra adjoints ----
         need_x = has_grid
@@ -224,10 +224,11 @@ class GeometricMain(Function):
             else:
                 side_in.append(None); side_out.append(None); side_add.append(None); ld.append(0); bg.append(None)
         gx = torch.zeros((P, K0), device=dev, dtype=torch.float32) if need_x else None
+        gb_last = torch.empty((Ns[-1],), device=dev, dtype=torch.float32)     # bias gradient of the output layer
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain_ex", 1, P, gy, Ns[-1], Ns[-1], steps, Wp, [None] * steps, bK, bN,
                 side_in, side_out, ld, bg, gx, K0, 1 if (bskip >= 0 and need_x) else 0, 1 if need_x else 0, beta,
                 bskip, scale, split, gx if (bskip >= 0 and need_x) else None, K0, [None] * steps, side_add, [None] * steps,
-                None, 0, chain_workspace(dev, bg), shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
+                None, 0, gb_last, chain_workspace(dev, bg + [gb_last]), shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
 
         if has_grid:
             lib.call("voxel_feature_grad_feature", P * D0, grid_grad, gx[:, npe:].contiguous(), xf, gs_shape, D0,
@@ -243,7 +244,7 @@ class GeometricMain(Function):
                 if nbar is not None and j == L - 1:
                     gW[j][:, 0] += col_last
             if ctx.needs_input_grad[3 + L + j]:
-                gb[j] = bgrads[j] if j < L - 1 else colsum(gy)
+                gb[j] = bgrads[j] if j < L - 1 else gb_last
         g_feature = None
         if has_grid and ctx.needs_input_grad[1] and buf is None:
             g_feature = grid_grad

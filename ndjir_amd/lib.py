@@ -38,8 +38,8 @@ SIGS = {
     "zero": "pl",
     "mlp_pack": "ppiii",
     # bwd P X ldx K0 L Wp bias Ks Ns side_in side_out ld_side bgrad Y ldy accum has_out beta skip scale split Xskip ld
-    "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi" + "p",
-    "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP" + "pi" + "p",
+    "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi" + "pp",
+    "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP" + "pi" + "pp",
     "mlp_group_colsum": "piilip",
     "mlp_wgrad": "pipiiilpip",
     "mlp_colsum": "piilpip",

@@ -110,13 +110,13 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
     if row_bias is None:
         _launch("chain_fwd", flops, "mlp_chain", 0, P, x, x.shape[1], K0, L, Wp, bl,
                 Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
-                int(skip_layer), float(skip_scale), 0, None, 0, None, shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
+                int(skip_layer), float(skip_scale), 0, None, 0, None, None, shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
     else:
         assert P % row_bias_div == 0 and tuple(row_bias.shape) == (P // row_bias_div, Ns[0])
         _launch("chain_fwd", flops, "mlp_chain_ex", 0, P, x, x.shape[1], K0, L, Wp, bl,
                 Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
                 int(skip_layer), float(skip_scale), 0, None, 0, [None] * L, [None] * L, [None] * L,
-                row_bias.detach().contiguous(), int(row_bias_div), None,
+                row_bias.detach().contiguous(), int(row_bias_div), None, None,
                 shape=f"{P}:{K0}(+rows/{row_bias_div})-" + "-".join(map(str, Ns)))
     return y, hidden
 
@@ -210,6 +210,7 @@ class FusedMLP(Function):
         deltas[L - 1] = gy2
         bgrads = [None] * L
         gx = None
+        gb_last = None
         if steps > 0:
             Wp, Ks, Ns, side_in, side_out, ld_side, bg = [], [], [], [], [], [], []
             bwd_skip, split = -1, 0
@@ -252,11 +253,14 @@ class FusedMLP(Function):
                     ldg = (K0 + 3) // 4 * 4
                     gx = torch.empty((P, ldg), device=x2.device, dtype=torch.float32)[:, :K0]
             flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
+            if need_w and ctx.needs_input_grad[6 + 2 * L - 1]:
+                # bias gradient of the output layer = column sums of dL/dY: accumulated by the chain's input load
+                gb_last = torch.empty((gy2.shape[1],), device=x2.device, dtype=torch.float32)
             _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
                      side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
                      1 if bwd_skip >= 0 else 0, 1 if need_x else 0,
                      float(beta), int(bwd_skip), float(skip_scale), int(split),
-                     gx if bwd_skip >= 0 else None, K0, chain_workspace(x2.device, bg),
+                     gx if bwd_skip >= 0 else None, K0, gb_last, chain_workspace(x2.device, bg + [gb_last]),
                      shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)))
         gW = [None] * L
         gb = [None] * L
@@ -265,7 +269,7 @@ class FusedMLP(Function):
                 if ctx.needs_input_grad[6 + j]:
                     gW[j] = wgrad(A[j], deltas[j])
                 if ctx.needs_input_grad[6 + L + j]:
-                    gb[j] = bgrads[j] if j < L - 1 else colsum(gy2)
+                    gb[j] = bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))
         g_rb = None
         rb_shape, rb_div = ctx.rb
         if rb_shape is not None and ctx.needs_input_grad[1]:
