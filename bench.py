@@ -264,6 +264,7 @@ def main():
         step.forward_backward()
     eager = None
     graph_error = None
+    profile_steps = a.steps
     if exec_mode == "graph":
         try:
             graph, loss = capture_step(step)          # untimed, like the warm-up
@@ -288,9 +289,24 @@ def main():
         eager = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / a.steps,
                  "note": "same K steps as ordinary stream launches (with the HIP-event instrumentation)"}
         profile, mlp.PROFILE = mlp.PROFILE, None
+    elif world > 1:
+        # N > 1: the event instrumentation costs rank 0 host time every step, which the other ranks then wait
+        # for.  `roofline` / `kernels` come from two extra untimed steps (all ranks run them: the step contains
+        # collectives); the timed region is clean.
+        mlp.PROFILE = [] if rank == 0 else None
+        for _ in range(2):
+            step.forward_backward()
+        profile, mlp.PROFILE = mlp.PROFILE, None
+        profile_steps = 2
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = step.forward_backward()
+        barrier()
+        el = time.perf_counter() - t0
     else:
         barrier()
-        mlp.PROFILE = [] if rank == 0 else None
+        mlp.PROFILE = []
         t0 = time.perf_counter()
         for _ in range(a.steps):
             loss = step.forward_backward()
@@ -309,7 +325,7 @@ def main():
         ms = 1e3 * el / a.steps
         kr = kernel_report(profile)
         if os.environ.get("NDJIR_BENCH_DETAIL"):
-            kernel_detail(profile, a.steps)
+            kernel_detail(profile, profile_steps)
         dom = kr.get("chain_fwd", dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0))
         step_tflops = MFLOP_PER_RAY_FWD_BWD * 1e6 * R / (ms * 1e-3) / 1e12      # per GPU
         tile = os.environ.get("NDJIR_MLP_TILE", "64")
@@ -333,11 +349,13 @@ def main():
             "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": dom["tflops"] / peak, "traffic": None,
                          "kernel": kname, "peak_note": peak_note,
-                         "launches_per_step": dom["launches"] / max(a.steps, 1), "avg_launch_us": dom["avg_us"],
+                         "launches_per_step": dom["launches"] / max(profile_steps, 1), "avg_launch_us": dom["avg_us"],
                          "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
                          "method": ("HIP events on the launching stream around every launch of the same K steps issued "
                                     "eagerly right after the timed graph replays (events cannot be recorded inside a "
                                     "captured graph)") if exec_mode == "graph" else
+                                   ("HIP events on the launching stream around every launch of two untimed steps before "
+                                    "the timed region (N > 1)") if world > 1 else
                                    "HIP events on the launching stream around every launch in the timed region"},
             "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kr.items()},
             "step_roofline": {"achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
