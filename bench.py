@@ -238,9 +238,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("NDJIR_BENCH_SAME_DEVICE"):
+        local_rank = 0      # debugging aid: several ranks on ONE GPU over gloo, to exercise the N > 1 code path
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("NDJIR_BENCH_SAME_DEVICE"):
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
