@@ -15,11 +15,12 @@ sum of the algorithmic FLOPs (2*in*out per affine per point) of its l
 their durations, measured live with HIP events recorded on the launching stream around every launch
 inside the timed region.  In the default bf16x6 arithmetic one algorithmic FLOP costs six bf16 MFMA
 FLOPs, so the peak it is priced against is the dense bf16 MFMA peak / 6.
-Execution: on one GPU the step is captured once into a HIP graph and the timed region replays it
-(`--exec graph`, default; no host-side launch work in the timed region); HIP events cannot be
-recorded inside a captured graph, so `roofline` / `kernels` come from the same K steps issued eagerly
-right after (`eager` reports their wall time).  `--exec eager` (default for N > 1) times ordinary
-stream launches with the events inside the timed region.
+Execution: on one GPU the compute part of the step (no collective inside) is captured once into a HIP
+graph and the timed region replays it (`--exec graph`; no host-side launch work in the timed region);
+HIP events cannot be recorded inside a captured graph, so `roofline` / `kernels` come from the same K
+steps issued eagerly right after (`eager` reports their wall time).  `--exec eager` (default for N > 1)
+times ordinary stream launches.  If the capture fails, or replaying is not faster than eager launches
+in a short untimed trial, the run falls back to eager.
 """
 import argparse
 import json
@@ -51,9 +52,10 @@ def parse():
     ap.add_argument("--override", action="append", default=[])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exec", dest="exec_mode", choices=["graph", "eager"], default=None,
-                    help="how the timed steps are issued: 'graph' = the step is captured once into a HIP graph and the "
-                         "timed region replays it (default on 1 GPU); 'eager' = ordinary stream launches (default on N > 1, "
-                         "where the gradient exchange runs over RCCL between steps)")
+                    help="how the timed steps are issued: 'graph' (default on 1 GPU) = the compute part of the step is captured "
+                         "once into a HIP graph and the timed region replays it (N > 1: the gradient exchange is issued "
+                         "eagerly between replays); 'eager' (default on N > 1) = ordinary stream launches.  Falls back to "
+                         "eager if the capture fails on any rank or replaying is not faster.")
     ap.add_argument("--cpu-rays", type=int, default=32)
     return ap.parse_args()
 
@@ -83,6 +85,8 @@ class Step:
         self.grid_bufs = {}
         self.touched = None      # query points whose cells hold gradient from the previous step
         self.remote_rows = {}    # multi-GPU: grid rows received from the other ranks in the previous exchange
+        self.mask_sum = torch.zeros((), device=device)   # multi-GPU: all-reduced sum of the ray masks
+        self.x_fg = None
         self.mlp_names = None
         self.forward_backward()          # creates the parameters (untimed)
         for name, p in P.get_parameters().items():
@@ -99,7 +103,7 @@ class Step:
     def rearm_grid_buffers(self):
         """Zero the accumulate-in-place grid gradient buffers.  Linear dense voxel grid: only the cells the
         previous step's query points touched (512^3 x 4 floats = 2 GiB would otherwise be rewritten every
-        step); anything else: dense."""
+        step); anything else: dense.  (Rows deposited by other ranks are cleared in `pre_exchange`.)"""
         import math
         from ndjir_amd.grid_feature import zero_touched
         v = self.conf.geometric_network.voxel
@@ -109,54 +113,79 @@ class Step:
                 r = self.conf.renderer.bounding_sphere_radius
                 zero_touched(buf, x_fg)
                 zero_touched(buf, x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size))
-                if self.world > 1:      # rows the sparse exchange deposited on behalf of the other ranks
-                    buf.view(-1, buf.shape[-1]).index_fill_(0, self.remote_rows[name], 0.0)
             else:
                 buf.zero_()
 
-    def forward_backward(self):
+    # One step = pre_exchange (N > 1 only) -> compute -> exchange (N > 1 only).  `compute` holds no collective
+    # and no data-dependent shapes: it is what bench.py captures into a HIP graph.
+    def pre_exchange(self):
+        """N > 1: global sum of the ray masks (a scalar all-reduce; the mask depends on the rays only) and the
+        clearing of the grid rows that the previous exchange deposited on behalf of the other ranks."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        from ndjir_amd.sampler import SamplePoints
+        for name, rows in self.remote_rows.items():
+            buf = self.grid_bufs[name]
+            buf.view(-1, buf.shape[-1]).index_fill_(0, rows, 0.0)
+        with torch.no_grad():
+            _, _, mask = SamplePoints(self.conf).t_near_far(self.camloc, self.raydir)
+            ms = mask.sum().reshape(())
+        dist.all_reduce(ms)
+        self.mask_sum.copy_(ms)
+
+    def compute(self):
         from ndjir_amd.loss import total_loss
         self.rearm_grid_buffers()
         out = total_loss(self.camloc, self.raydir, self.color_gt, None, self.car, self.conf, self.rand,
-                         ray_shards=self.world)
+                         ray_shards=self.world, mask_sum_global=self.mask_sum if self.world > 1 else None)
         loss = out["loss"]
         if self.mlp_names is None:
             params = [p for p in self.P.get_parameters(grad_only=True).values()]
             torch.autograd.grad(loss, params, allow_unused=True)
             return loss.detach()
         grads = torch.autograd.grad(loss, self.mlp_params + self.grid_params, allow_unused=True)
+        self.x_fg = out["samples"]["x_fg"].detach()
         if self.grid_bufs:
             # a persistent buffer (not the step's own tensor): a captured graph must find it at the same address
             if self.touched is None:
-                self.touched = out["samples"]["x_fg"].detach().clone()
+                self.touched = self.x_fg.clone()
             else:
-                self.touched.copy_(out["samples"]["x_fg"].detach())
+                self.touched.copy_(self.x_fg)
         self.grads = grads               # the step's product: every parameter gradient, materialised
-        if self.world == 1:
-            return loss.detach()
-        # multi-GPU: pack the MLP gradients into one flat bucket for the all-reduce
-        off = 0
-        for p, g in zip(self.mlp_params, grads):
-            n = p.numel()
-            if g is not None:
-                self.flat_grad[off:off + n].copy_(g.reshape(-1))
-            else:
-                self.flat_grad[off:off + n].zero_()
-            off += n
-        if True:
-            import math
-            from ndjir_amd.distributed import allreduce_step_gradients
-            # total_loss already normalised by the GLOBAL ray / mask counts: gradients just add up.
-            # MLP: one flat 5.9 MB bucket; voxel grid: touched cells only (ndjir_amd/distributed.py)
-            x_fg = out["samples"]["x_fg"].detach()
-            v = self.conf.geometric_network.voxel
-            queries = {}
-            if v.type.endswith("voxel"):
-                r = self.conf.renderer.bounding_sphere_radius
-                x_ptb = x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size)
-                queries["geometric-network/voxel_feature/F"] = ([x_fg, x_ptb], [v.grid_size] * 3)
-            self.remote_rows = allreduce_step_gradients(self.flat_grad, self.grid_bufs, queries)
+        if self.world > 1:
+            # pack the MLP gradients into one flat bucket for the all-reduce
+            off = 0
+            for p, g in zip(self.mlp_params, grads):
+                n = p.numel()
+                if g is not None:
+                    self.flat_grad[off:off + n].copy_(g.reshape(-1))
+                else:
+                    self.flat_grad[off:off + n].zero_()
+                off += n
         return loss.detach()
+
+    def exchange(self):
+        """N > 1: one gradient exchange.  total_loss already normalised by the GLOBAL ray / mask counts, so the
+        per-rank gradients just add up: MLP = one flat 5.9 MB bucket; voxel grid = touched cells only."""
+        if self.world == 1 or self.mlp_names is None:
+            return
+        import math
+        from ndjir_amd.distributed import allreduce_step_gradients
+        x_fg = self.x_fg
+        v = self.conf.geometric_network.voxel
+        queries = {}
+        if v.type.endswith("voxel"):
+            r = self.conf.renderer.bounding_sphere_radius
+            x_ptb = x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size)
+            queries["geometric-network/voxel_feature/F"] = ([x_fg, x_ptb], [v.grid_size] * 3)
+        self.remote_rows = allreduce_step_gradients(self.flat_grad, self.grid_bufs, queries)
+
+    def forward_backward(self):
+        self.pre_exchange()
+        loss = self.compute()
+        self.exchange()
+        return loss
 
 
 def cpu_baseline(conf, step, n_rays):
@@ -187,21 +216,64 @@ def cpu_baseline(conf, step, n_rays):
                        f"{cores} of {os.cpu_count()} host cores, {el:.1f} s")
 
 
+def _all_ranks_ok(step, ok):
+    """Logical AND of a per-rank flag (every rank must take the same branch: the step holds collectives)."""
+    if step.world == 1:
+        return ok
+    t = torch.tensor([1.0 if ok else 0.0], device=step.device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+    return float(t.item()) > 0.5
+
+
 def capture_step(step):
-    """Capture one whole step (sampling, forward, loss, backward to every parameter gradient -- all
-    custom launches are stream-ordered and allocation-stable) into a HIP graph."""
+    """Capture the compute part of one step (sampling, forward, loss, backward to every parameter gradient,
+    gradient packing -- all custom launches are stream-ordered and allocation-stable, no collective inside)
+    into a HIP graph.  Returns (graph, loss tensor of the captured step) or raises; on N > 1 every rank
+    raises if any rank failed, after completing the same sequence of collectives."""
+    multi = step.world > 1
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        step.forward_backward()
+        ref = step.forward_backward()
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
-    with torch.cuda.graph(g):
-        loss = step.forward_backward()
+    step.pre_exchange()
+    # N > 1: other threads of the process (the collective library's watchdog) keep issuing runtime calls
+    kw = dict(capture_error_mode="thread_local") if multi else {}
+    err, loss = None, None
+    try:
+        with torch.cuda.graph(g, **kw):
+            loss = step.compute()
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    if not _all_ranks_ok(step, err is None):
+        torch.cuda.synchronize()
+        step.compute()                 # finish the step that pre_exchange started, identically on all ranks
+        step.exchange()
+        raise RuntimeError(err or "graph capture failed on another rank")
     g.replay()
+    step.exchange()
     torch.cuda.synchronize()
+    same = abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    if not _all_ranks_ok(step, same):
+        raise RuntimeError(f"graph replay loss {float(loss)} != eager loss {float(ref)} (on some rank)")
     return g, loss
+
+
+def replay_step(step, graph):
+    if os.environ.get("NDJIR_BENCH_TRACE"):
+        def T(fn):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0)
+        a, b, c = T(step.pre_exchange), T(graph.replay), T(step.exchange)
+        print(f"[rank {step.rank}] pre {a:.1f} ms, graph {b:.1f} ms, exchange {c:.1f} ms", file=sys.stderr, flush=True)
+        return
+    step.pre_exchange()
+    graph.replay()
+    if step.world > 1:
+        torch.cuda.current_stream().synchronize()   # the exchange consumes the replayed step's results
+    step.exchange()
 
 
 def kernel_report(profile):
@@ -262,9 +334,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    exec_mode = a.exec_mode or ("graph" if world == 1 else "eager")
-    if exec_mode == "graph" and world > 1:
-        raise SystemExit("--exec graph is single-GPU only (the RCCL gradient exchange is issued between steps)")
+    # default: graph replay on one GPU; eager launches on N > 1 (graph replay between RCCL collectives works in the
+    # single-device gloo harness only with explicit synchronisation and could not be validated on a multi-GPU node:
+    # opt in with --exec graph)
+    exec_mode = a.exec_mode or os.environ.get("NDJIR_BENCH_EXEC") or ("graph" if world == 1 else "eager")
     for _ in range(a.warmup):
         step.forward_backward()
     eager = None
@@ -277,16 +350,30 @@ def main():
             graph_error = f"{type(e).__name__}: {e}"
             exec_mode = "eager"
             torch.cuda.synchronize()
+        if exec_mode == "graph":
+            # ... and never a pessimisation: two untimed steps each way, keep replaying only if it is not slower
+            def timed(fn, n=2):
+                barrier()
+                t = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                barrier()
+                return time.perf_counter() - t
+            t_graph = timed(lambda: replay_step(step, graph))
+            t_eager = timed(step.forward_backward)
+            if not _all_ranks_ok(step, t_graph <= 1.05 * t_eager):
+                graph_error = f"replay not faster than eager launches ({1e3 * t_graph / 2:.1f} vs {1e3 * t_eager / 2:.1f} ms/step)"
+                exec_mode = "eager"
     if exec_mode == "graph":
         barrier()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            graph.replay()
+            replay_step(step, graph)
         barrier()
         el = time.perf_counter() - t0
         # HIP events cannot be recorded inside a captured graph: the same K steps are issued once more as
         # ordinary stream launches, with events around every engine launch, for `roofline` / `kernels`
-        mlp.PROFILE = []
+        mlp.PROFILE = [] if rank == 0 else None
         t1 = time.perf_counter()
         for _ in range(a.steps):
             step.forward_backward()
@@ -368,8 +455,9 @@ def main():
                               "scope": "whole step: 2168.9 MFLOP/ray fwd+bwd (SURVEY 8d) / step time"},
             "loss": float(loss),
         }
-        out["execution"] = ("one captured HIP graph per step (torch.cuda.CUDAGraph), K replays timed" if exec_mode == "graph"
-                            else "eager stream launches")
+        out["execution"] = (("one captured HIP graph per step (torch.cuda.CUDAGraph), K replays timed"
+                             + ("; the RCCL gradient exchange is issued eagerly between replays" if world > 1 else ""))
+                            if exec_mode == "graph" else "eager stream launches")
         if eager is not None:
             out["eager"] = eager
         if graph_error is not None:

@@ -14,13 +14,15 @@ from .renderer import pb_render
 from .sampler import sample_points
 
 
-def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand, record=None, ray_shards=1):
+def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand, record=None, ray_shards=1,
+               mask_sum_global=None):
     """camloc (B,3), raydir (B,R,3), color_gt (B,R,3), obj_mask (B,R,1) or None, cos_anneal_ratio (1,).
 
     `ray_shards` > 1: this process holds one of `ray_shards` equal slices of the ray batch
     (torch.distributed initialised).  The loss normalisers -- B*R and sum(mask) -- are then taken
     over ALL shards (one scalar all-reduce before backward), so the sum over ranks of the returned
-    losses, and of their gradients, equals the single-process loss / gradient of the whole batch."""
+    losses, and of their gradients, equals the single-process loss / gradient of the whole batch.
+    `mask_sum_global`: that all-reduced sum(mask), if the caller has it already (0-d tensor)."""
     B, R, _ = color_gt.shape
     tr = conf.train
 
@@ -42,7 +44,11 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
         loss_rgb = err.sum() / (B * R * ray_shards)
 
     mask_sum = mask.sum()
-    if ray_shards > 1:
+    if mask_sum_global is not None:
+        # the caller already summed the ray masks over all shards (keeps this function free of collectives, so
+        # that a whole step can be captured into a HIP graph; the mask depends on the rays only)
+        mask_sum = mask_sum_global.reshape(()).to(mask_sum.dtype)
+    elif ray_shards > 1:
         import torch.distributed as dist
         mask_sum = mask_sum.clone()
         dist.all_reduce(mask_sum)
