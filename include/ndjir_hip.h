@@ -73,6 +73,10 @@ NDJIR_DECL_VOXEL_FAMILY(voxel_feature)
  * 8 corners, which also cover the TV backward's cells -- instead of rewriting the whole buffer. */
 int ndjir_voxel_feature_zero_touched(int N, float* grad_feature, const float* query, const int* grid_sizes, int D,
                                      const float* min, const float* max, hipStream_t stream);
+/* *flag |= 1 (device int) when one of those cells holds an inf or nan: the grid half of
+ * `check_inf_or_nan_grad` (python/solver.py:67-69) without reading the 2 GiB buffer. */
+int ndjir_voxel_feature_check_touched(int N, const float* grad_feature, const float* query, const int* grid_sizes, int D,
+                                      const float* min, const float* max, int* flag, hipStream_t stream);
 NDJIR_DECL_VOXEL_FAMILY(cosine_voxel_feature)
 NDJIR_DECL_VOXEL_FAMILY(lanczos_voxel_feature)
 
@@ -367,6 +371,37 @@ int ndjir_mlp_colsum(const float* X, int ldx, int N, long long P, float* out, in
  * chain launches record shader-clock stamps of workgroup 0, [layer][phase][wave], phases = layer
  * start / k-loop done / accumulators staged / epilogue done / barrier passed.  Null switches it off. */
 int ndjir_mlp_debug_timeline(long long* buf);
+
+
+/* ---- optimizer step ------------------------------------------------------------------------------
+ * Replaces nnabla's `S.Adam` update + `weight_decay` + `zero_grad` + `check_inf_or_nan_grad` as the reference
+ * calls them (python/solver.py:29-30, 48-50, 60-69; python/train.py:136-148).  nnabla 1.29.0's update rule:
+ *   m <- beta1 m + (1-beta1) g;  v <- beta2 v + (1-beta2) g^2;  w <- w - alpha_t m / (sqrt(v) + eps),
+ *   alpha_t = alpha sqrt(1-beta2^t) / (1-beta1^t)  (formed by the caller from its step counter t),
+ * with g = dL/dw + decay * w (the reference adds decay * w to the zeroed buffer before backward accumulates).
+ * ndjir_solver_adam: one dense parameter of n floats (16-byte aligned); zero_grad != 0 clears g in the same pass.
+ * ndjir_adam_state (device memory, 16 bytes): keeps the learning rate, nnabla's step counter t, the step size of
+ * the current step and the guard's verdict on the device, so that a captured HIP graph replays the step under a
+ * changing learning rate and a vetoed update (python/train.py:141-143) costs no host round trip.
+ * ndjir_solver_adam_begin: skipped = flag_a && flag_b (the reference combines the two solvers' guards with `and`,
+ * python/solver.py:67-69; one flag given: that flag; none: never); if not skipped t += 1 and alpha_t is formed.
+ * The update functions take `state` (may be null): non-null = use state->alpha_t instead of the argument and, when
+ * state->skipped, leave w, m, v untouched (g is still cleared if zero_grad). */
+typedef struct ndjir_adam_state { float alpha; int t; float alpha_t; int skipped; } ndjir_adam_state;
+int ndjir_solver_adam_begin(void* state, float beta1, float beta2, const int* flag_a, const int* flag_b,
+                            hipStream_t stream);
+int ndjir_solver_adam(long long n, float* w, float* g, float* m, float* v, float alpha_t, float beta1, float beta2,
+                      float eps, float decay, int zero_grad, const void* state, hipStream_t stream);
+/* the same over `count` small tensors given as host arrays of device pointers; g[k] null = zero gradient */
+int ndjir_solver_adam_multi(int count, float* const* w, const float* const* g, float* const* m, float* const* v,
+                            const long long* numel, float alpha_t, float beta1, float beta2, float eps, float decay,
+                            const void* state, hipStream_t stream);
+/* *flag |= 1 when g holds an inf or nan (flag zeroed by the caller) */
+int ndjir_solver_check_inf_or_nan(long long n, const float* g, int* flag, hipStream_t stream);
+int ndjir_solver_check_inf_or_nan_multi(int count, const float* const* g, const long long* numel, int* flag,
+                                        hipStream_t stream);
+/* *out += sum x^2 (device double): the norm of `clip_grad_by_norm` (python/solver.py:53-58) */
+int ndjir_solver_sum_squares(long long n, const float* x, double* out, hipStream_t stream);
 
 #ifdef __cplusplus
 }

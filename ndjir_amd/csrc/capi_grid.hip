@@ -145,7 +145,15 @@ extern "C" int ndjir_voxel_feature_zero_touched(int N, float* gf, const float* q
                                                 const float* mx, hipStream_t st) {
   if (N <= 0) return NDJIR_OK;
   CHECK_PTRS(gf, query);
-  return launch_zero_touched(LINEAR, voxel_desc(gs, D, mn, mx), N, gf, query, st);
+  return launch_zero_touched(LINEAR, voxel_desc(gs, D, mn, mx), N, gf, query, nullptr, st);
+}
+
+// *flag |= 1 when a cell of grad_feature that the N query points touch holds an inf or nan.
+extern "C" int ndjir_voxel_feature_check_touched(int N, const float* gf, const float* query, const int* gs, int D,
+                                                 const float* mn, const float* mx, int* flag, hipStream_t st) {
+  if (N <= 0) return NDJIR_OK;
+  CHECK_PTRS(gf, query, flag);
+  return launch_zero_touched(LINEAR, voxel_desc(gs, D, mn, mx), N, const_cast<float*>(gf), query, flag, st);
 }
 
 extern "C" int ndjir_voxel_feature_grad_feature_grad_grad_output(int N, float* ggo, const float* ggf, const float* query,

@@ -424,19 +424,30 @@ __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restr
 // gradient buffer after use without rewriting all of it (2 GiB for the default 512^3 x 4 grid).
 // Covers grad_feature, grad_query_grad_feature and the TV backward (its cells are a subset of the taps).
 // ------------------------------------------------------------------------------------------------
-template <int TOPO, int I, int VW>
+// CHECK: instead of clearing, raise *flag when a touched cell holds an inf or nan (the finite-gradient guard of
+// python/solver.py:67-69 restricted to the cells that can hold a gradient at all).
+template <int TOPO, int I, int VW, bool CHECK>
 __global__ void __launch_bounds__(256) k_zero_touched(long long P, float* __restrict__ gf, const float* __restrict__ query,
-                                                      GridDesc g) {
+                                                      GridDesc g, int* __restrict__ flag) {
   constexpr int ND = NDims<TOPO>::v, NT = NTaps<I>::v;
+  bool bad = false;
   NDJIR_GRID_THREAD_PROLOGUE
   for (int d0 = 0; d0 < g.D; d0 += VW) {
     NDJIR_FOR_TAPS(ND, NT) {
       float* p = gf + cell_offset(st, i, j, k) + d0;
+      if (CHECK) {
+        float x[VW];
+        vload<VW>(x, p);
 #pragma unroll
-      for (int v = 0; v < VW; ++v) p[v] = 0.f;
+        for (int v = 0; v < VW; ++v) bad |= !isfinite(x[v]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VW; ++v) p[v] = 0.f;
+      }
     }
   }
   NDJIR_GRID_THREAD_EPILOGUE
+  if (CHECK && bad) atomicOr(flag, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -714,12 +725,19 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
   return ndjir_check_launch();
 }
 
-int launch_zero_touched(int interp, const GridDesc& g, long long P, float* gf, const float* query, hipStream_t stream) {
+int launch_zero_touched(int interp, const GridDesc& g, long long P, float* gf, const float* query, int* nonfinite_flag,
+                        hipStream_t stream) {
   if (P <= 0) return NDJIR_OK;
   int blocks = grid_blocks(P * g.S);
-  NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
-    hipLaunchKernelGGL((k_zero_touched<TOPO, I, VW>), dim3(blocks), dim3(256), 0, stream, P, gf, query, g);
-  }))
+  if (nonfinite_flag) {
+    NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
+      hipLaunchKernelGGL((k_zero_touched<TOPO, I, VW, true>), dim3(blocks), dim3(256), 0, stream, P, gf, query, g, nonfinite_flag);
+    }))
+  } else {
+    NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
+      hipLaunchKernelGGL((k_zero_touched<TOPO, I, VW, false>), dim3(blocks), dim3(256), 0, stream, P, gf, query, g, nonfinite_flag);
+    }))
+  }
   return ndjir_check_launch();
 }
 

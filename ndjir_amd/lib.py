@@ -17,10 +17,11 @@ SO_PATH = os.environ.get("NDJIR_HIP_LIB") or os.path.join(_HERE, "_lib", "libndj
 _vp = ctypes.c_void_p
 _CT = {"i": ctypes.c_int, "f": ctypes.c_float, "p": _vp, "q": _vp, "F": ctypes.POINTER(ctypes.c_float),
        "I": ctypes.POINTER(ctypes.c_int), "l": ctypes.c_longlong, "P": ctypes.POINTER(_vp),
-       "A": ctypes.POINTER(ctypes.c_int)}
+       "A": ctypes.POINTER(ctypes.c_int), "L": ctypes.POINTER(ctypes.c_longlong), "x": _vp}
 
 # signature strings (without the trailing stream): i=int f=float l=long long p=device pointer
-# F=float[3] host  I=int[3] host
+# F=float[3] host  I=int[3] host  q=int32 device pointer (nullable)  x=device pointer of any dtype
+# P=host array of device pointers  A=host int array  L=host long long array
 _VOX_TAIL, _PLN_TAIL, _HSH_TAIL = "IiFFi", "iiFFi", "ifiiiFFi"
 
 
@@ -63,6 +64,14 @@ SIGS = {
     "squareplus_forward": "ippf",
     "squareplus_backward": "ipppfi",
     "voxel_feature_zero_touched": "ippIiFF",
+    "voxel_feature_check_touched": "ippIiFFq",
+    "solver_adam_begin": "xffqq",
+    # n w g m v alpha_t beta1 beta2 eps decay zero_grad state
+    "solver_adam": "lppppfffffix",
+    "solver_adam_multi": "iPPPPLfffffx",
+    "solver_check_inf_or_nan": "lpq",
+    "solver_check_inf_or_nan_multi": "iPLq",
+    "solver_sum_squares": "lpx",
     "voxel_feature_grad_query_grad_query": "ippppp" + _VOX_TAIL + "i",
     "voxel_feature_grad_feature_grad_grad_output": "ippp" + _VOX_TAIL + "i",
     "voxel_feature_grad_feature_grad_query": "ipppp" + _VOX_TAIL + "i",
@@ -175,6 +184,15 @@ def call(name, *args):
             cargs.append(arr)
         elif c == "A":     # host int array
             cargs.append((ctypes.c_int * len(v))(*[int(x) for x in v]))
+        elif c == "L":     # host long long array
+            cargs.append((ctypes.c_longlong * len(v))(*[int(x) for x in v]))
+        elif c == "x":     # device pointer of any dtype (None = null)
+            if v is None:
+                cargs.append(None)
+                continue
+            if not (v.is_cuda and v.is_contiguous()):
+                raise NdjirHipError(f"ndjir_{name}: expected a contiguous GPU tensor")
+            cargs.append(v.data_ptr())
         elif c == "F":
             cargs.append(_f3(v))
         elif c == "I":
