@@ -57,6 +57,9 @@ def parse():
                          "eagerly between replays); 'eager' (default on N > 1) = ordinary stream launches.  Falls back to "
                          "eager if the capture fails on any rank or replaying is not faster.")
     ap.add_argument("--cpu-rays", type=int, default=32)
+    ap.add_argument("--train-steps", type=int, default=10,
+                    help="after the fwd+bwd measurement: time this many full training iterations (fwd+bwd + the two Adam "
+                         "solvers with weight decay, python/train.py:136-148) and report them as `train_step`; 0 = skip")
     return ap.parse_args()
 
 
@@ -134,9 +137,10 @@ class Step:
         dist.all_reduce(ms)
         self.mask_sum.copy_(ms)
 
-    def compute(self):
+    def compute(self, rearm=True):
         from ndjir_amd.loss import total_loss
-        self.rearm_grid_buffers()
+        if rearm:
+            self.rearm_grid_buffers()
         out = total_loss(self.camloc, self.raydir, self.color_gt, None, self.car, self.conf, self.rand,
                          ray_shards=self.world, mask_sum_global=self.mask_sum if self.world > 1 else None)
         loss = out["loss"]
@@ -185,6 +189,65 @@ class Step:
         self.pre_exchange()
         loss = self.compute()
         self.exchange()
+        return loss
+
+    # ---- the reference's training iteration (python/train.py:136-148): forward_backward + the optimizer step ----------
+    def enable_training(self, epoch_index=None):
+        """Two Adam solvers over the step's parameters (ndjir_amd.solver.Solvers = python/solver.py).  From here on the
+        grid gradient buffers are re-armed by the update kernel itself."""
+        import copy
+        from ndjir_amd.solver import Solvers
+        conf = copy.deepcopy(self.conf)
+        conf.train.batch_size, conf.train.n_rays = 1, self.R * self.world      # learning rates scale with B R / 512
+        self.solvers = Solvers(conf)
+        self.solvers.set_parameters()
+        t = conf.train
+        self.solvers.update_learning_rate(int(t.epoch * t.warmup_term_ratio) if epoch_index is None else epoch_index)
+        self.rearm_grid_buffers()
+        for name, rows in self.remote_rows.items():
+            buf = self.grid_bufs[name]
+            buf.view(-1, buf.shape[-1]).index_fill_(0, rows, 0.0)
+        self.remote_rows = {}
+
+    def train_compute(self):
+        """Everything of a training iteration that holds no collective (one GPU: the whole iteration)."""
+        s = self.solvers
+        s.zero_grad()
+        s.weight_decay()
+        s.clip_grad_by_norm()
+        loss = self.compute(rearm=False)
+        if self.world == 1:
+            self.optimizer_step()
+        return loss
+
+    def optimizer_step(self):
+        import math
+        s = self.solvers
+        if self.world > 1:       # the exchange left the summed MLP gradients in the flat bucket
+            grads, off = {}, 0
+            for name, p in zip(self.mlp_names, self.mlp_params):
+                grads[name] = self.flat_grad[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            touched = None       # rows of other ranks' rays are not covered by this rank's samples: dense guard
+        else:
+            grads = dict(zip(self.mlp_names, self.grads))
+            v = self.conf.geometric_network.voxel
+            touched = None
+            if v.type == "voxel" and self.x_fg is not None:
+                r = self.conf.renderer.bounding_sphere_radius
+                touched = {"geometric-network/voxel_feature/F":
+                           [self.x_fg, self.x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size)]}
+        s.set_gradients(grads, touched)
+        s.guarded_update()
+
+    def train_step(self):
+        if self.world > 1:
+            rows, self.remote_rows = self.remote_rows, {}      # the update kernel cleared them with the rest of the buffer
+            self.pre_exchange()
+        loss = self.train_compute()
+        if self.world > 1:
+            self.exchange()
+            self.optimizer_step()
         return loss
 
 
@@ -274,6 +337,68 @@ def replay_step(step, graph):
     if step.world > 1:
         torch.cuda.current_stream().synchronize()   # the exchange consumes the replayed step's results
     step.exchange()
+
+
+def train_leg(step, steps, barrier, use_graph):
+    """Full training iterations (fwd+bwd + optimizer), timed like the main region.  Reported next to the headline
+    metric, never as it: the metric is fwd+bwd (BASELINE.json)."""
+    from ndjir_amd import mlp
+    step.enable_training()
+    for _ in range(2):
+        step.train_step()
+    torch.cuda.synchronize()
+    mode, err, graph = "eager stream launches", None, None
+    if use_graph and step.world == 1:
+        try:
+            mlp._PACK_CACHE.clear()          # the weights change every step: their re-packing must be part of the graph
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = step.train_compute()
+            g.replay()
+            torch.cuda.synchronize()
+            graph, mode = g, "one captured HIP graph per training iteration"
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
+            torch.cuda.synchronize()
+            mlp._PACK_CACHE.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            loss = step.train_step()
+    barrier()
+    el = time.perf_counter() - t0
+    # the optimizer alone (HIP events on the launching stream, ordinary launches)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    step.solvers.zero_grad()
+    step.solvers.weight_decay()
+    step.solvers.set_gradients(dict(zip(step.mlp_names, step.grads)) if step.world == 1 else
+                               {n: None for n in step.mlp_names})
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        step.solvers.solver_weight._check()
+        step.solvers.solver_weight.update()
+    e1.record()
+    for _ in range(reps):
+        step.solvers.solver_feat.update()
+    e2.record()
+    torch.cuda.synchronize()
+    n_grid = sum(p.numel() for p in step.grid_params)
+    grid_ms = e1.elapsed_time(e2) / reps
+    out = {"ms_per_step": 1e3 * el / steps, "steps": steps, "execution": mode,
+           "loss_after": float(loss),
+           "optimizer": {"mlp_ms": e0.elapsed_time(e1) / reps, "grid_ms": grid_ms,
+                         "grid_params": n_grid,
+                         "grid_bytes_per_launch": 32 * n_grid,
+                         "grid_GBps": 32 * n_grid / (grid_ms * 1e-3) / 1e9 if grid_ms > 0 else None,
+                         "note": "ndjir::k_adam: per float 4 reads (w, g, m, v) + 4 writes (w, m, v, g = 0) = 32 B; "
+                                 "HBM peak 8000 GB/s"}}
+    if err is not None:
+        out["graph_capture_error"] = err
+    return out
 
 
 def kernel_report(profile):
@@ -468,6 +593,18 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
+    if a.train_steps > 0:
+        tl = train_leg(step, a.train_steps, barrier, use_graph=(a.exec_mode or os.environ.get("NDJIR_BENCH_EXEC") or "graph") == "graph")
+        if world > 1:
+            t = torch.tensor([tl["ms_per_step"]], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            tl["ms_per_step"] = float(t.item())
+        if rank == 0:
+            tl["rays_per_s"] = world * R / (tl["ms_per_step"] * 1e-3)
+            tl["scope"] = ("fwd+bwd + weight decay + finite-gradient guard + Adam update of every parameter "
+                           "(python/train.py:136-148); reported beside the headline metric, not as it")
+            out["train_step"] = tl
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
