@@ -21,7 +21,7 @@
 
 #include "common.h"
 
-// fixed expression order, no fused multiply-add: bit-comparable with oracle/solver.py
+// fixed expression order, no fused multiply-add: bit-comparable with the CPU restatement used by the parity tests
 #pragma clang fp contract(off)
 
 namespace ndjir {
