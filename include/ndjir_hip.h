@@ -373,6 +373,15 @@ int ndjir_mlp_colsum(const float* X, int ldx, int N, long long P, float* out, in
 int ndjir_mlp_debug_timeline(long long* buf);
 
 
+/* ---- camera rays -----------------------------------------------------------------------------------
+ * Replaces the per-iteration host computation `generate_raydir_camloc` (python/helper.py:44-73, called at
+ * python/train.py:131-133 and python/renderer.py:238) and its two host->device copies: x_w = R_c2w K^-1 (x, y, 1)^T,
+ * normalised; camloc = pose[:3, 3].  pose (B,4,4) and intrinsic (B,3,3) are double (the reference keeps them in float64
+ * numpy), arithmetic in double, outputs fp32.  Pixels: flat indices pixel_index (B,R) int32 into a W-wide image
+ * (python/dataset.py:96-101) or coordinates xy (B,R,2) fp32 -- exactly one of the two non-null. */
+int ndjir_generate_raydir_camloc(int B, int R, const double* pose, const double* intrinsic, const int* pixel_index,
+                                 const float* xy, int W, float* raydir, float* camloc, hipStream_t stream);
+
 /* ---- optimizer step ------------------------------------------------------------------------------
  * Replaces nnabla's `S.Adam` update + `weight_decay` + `zero_grad` + `check_inf_or_nan_grad` as the reference
  * calls them (python/solver.py:29-30, 48-50, 60-69; python/train.py:136-148).  nnabla 1.29.0's update rule:

@@ -65,6 +65,7 @@ SIGS = {
     "squareplus_backward": "ipppfi",
     "voxel_feature_zero_touched": "ippIiFF",
     "voxel_feature_check_touched": "ippIiFFq",
+    "generate_raydir_camloc": "iixxqpipp",
     "solver_adam_begin": "xffqq",
     # n w g m v alpha_t beta1 beta2 eps decay zero_grad state
     "solver_adam": "lppppfffffix",

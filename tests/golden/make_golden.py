@@ -16,6 +16,8 @@ Sources:
   python/intersection/test/test_ray_sphere_intersection.py:24-75, 78-113
   python/intersection/ray_sphere_intersection.py:115-131 (sample_inside_sphere, test input sampler)
   python/sampler/test_sampler.py:23-70, 72-111
+  python/helper.py:44-81 (generate_raydir_camloc, generate_all_pixels: pure numpy, no reference test -- inputs made here)
+  python/solver.py:82-98 (Solvers.compute_learning_rate: pure numpy method), config/default.yaml:125-135 (its inputs)
 """
 import ast
 import os
@@ -35,6 +37,69 @@ def extract(path, names):
     ns = {"np": np}
     exec(compile(mod, path, "exec"), ns)
     return [ns[n] for n in names]
+
+
+def extract_methods(path, cls, names):
+    """Named methods of class `cls`, compiled as plain functions (first argument = self)."""
+    tree = ast.parse(open(path).read())
+    (c,) = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls]
+    body = [n for n in c.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(body) == len(names), (path, cls, names)
+    ns = {"np": np}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def golden_rays():
+    """python/helper.py:44-81 on synthetic cameras (DTU-like intrinsics, look-at poses)."""
+    gen, pixels = extract(f"{REF}/helper.py", ["generate_raydir_camloc", "generate_all_pixels"])
+    rng = np.random.RandomState(412)
+    B, W, H, R = 3, 40, 30, 64
+    pose = np.zeros((B, 4, 4))
+    for b in range(B):
+        c = rng.randn(3)
+        c = 2.5 * c / np.linalg.norm(c)
+        fwd = -c / np.linalg.norm(c)
+        up = rng.randn(3)
+        right = np.cross(fwd, up)
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        pose[b, :3, 0], pose[b, :3, 1], pose[b, :3, 2], pose[b, :3, 3] = right, down, fwd, c
+        pose[b, 3, 3] = 1.0
+    intrinsic = np.zeros((B, 3, 3))
+    for b in range(B):
+        f = 2892.33 * (0.9 + 0.2 * rng.rand())
+        intrinsic[b] = [[f, 0.3 * rng.randn(), 823.2 + rng.randn()], [0, f * (1 + 0.01 * rng.randn()), 619.07 + rng.randn()],
+                        [0, 0, 1]]
+    all_xy = pixels(W, H)
+    idx = rng.randint(0, W * H, (B, R))
+    xy = all_xy[idx]                                       # (B, R, 2) integer pixel coordinates
+    raydir, camloc = gen(pose, intrinsic, xy)
+    np.savez(os.path.join(OUT, "generate_raydir_camloc.npz"), pose=pose, intrinsic=intrinsic, xy=xy.astype(np.int64),
+             raydir=raydir, camloc=camloc, all_pixels=all_xy.astype(np.int64), W=np.int64(W), H=np.int64(H))
+
+
+def golden_schedule():
+    """python/solver.py:82-98 with the train section of config/default.yaml and two variants."""
+    (clr,) = extract_methods(f"{REF}/solver.py", "Solvers", ["compute_learning_rate"])
+
+    class NS:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+    out = {}
+    cases = [dict(epoch=1500, warmup_term_ratio=0.015, learning_rate_end_ratio=0.01),       # default.yaml
+             dict(epoch=1000, warmup_term_ratio=0.0, learning_rate_end_ratio=0.1),
+             dict(epoch=40, warmup_term_ratio=0.1, learning_rate_end_ratio=0.01)]
+    for k, c in enumerate(cases):
+        me = NS(conf=NS(train=NS(**c)))
+        idx = np.unique(np.concatenate([np.arange(0, min(c["epoch"], 60)), np.arange(0, c["epoch"] + 1, 37), [c["epoch"]]]))
+        lr0 = 0.0005 * (k + 1)
+        out[f"c{k}_epoch"], out[f"c{k}_warmup_term_ratio"] = np.int64(c["epoch"]), np.float64(c["warmup_term_ratio"])
+        out[f"c{k}_learning_rate_end_ratio"], out[f"c{k}_lr0"] = np.float64(c["learning_rate_end_ratio"]), np.float64(lr0)
+        out[f"c{k}_i"] = idx.astype(np.int64)
+        out[f"c{k}_lr"] = np.asarray([clr(me, int(i), lr0) for i in idx], np.float64)
+    out["n_cases"] = np.int64(len(cases))
+    np.savez(os.path.join(OUT, "solver_schedule.npz"), **out)
 
 
 def golden_aabb():
@@ -121,6 +186,8 @@ if __name__ == "__main__":
     golden_aabb()
     golden_sphere()
     golden_directions()
+    golden_rays()
+    golden_schedule()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

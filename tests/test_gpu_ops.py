@@ -275,3 +275,24 @@ def test_zero_touched_rearms_the_grad_buffer(gpu):
         assert int((buf != 0).sum()) == 0
     finally:
         set_grad_buffer(f, None)
+
+
+@pytest.mark.parametrize("mode", ["xy", "pixel_index"])
+def test_generate_raydir_camloc_device(gpu, mode):
+    """Device ray generation vs the golden outputs of the reference's python/helper.py:44-73 (float64 numpy, which
+    the reference then assigns to fp32 variables): equal after the same rounding to fp32, up to one ulp."""
+    from ndjir_amd.helper import generate_raydir_camloc_device
+    g = np.load(os.path.join(GOLD, "generate_raydir_camloc.npz"))
+    pose, K = T(g["pose"], gpu), T(g["intrinsic"], gpu)
+    if mode == "xy":
+        rd, cl = generate_raydir_camloc_device(pose, K, xy=T(g["xy"].astype(np.float32), gpu))
+    else:
+        W = int(g["W"])
+        idx = (g["xy"][..., 1] * W + g["xy"][..., 0]).astype(np.int32)
+        rd, cl = generate_raydir_camloc_device(pose, K, pixel_index=T(idx, gpu), width=W)
+    want = g["raydir"].astype(np.float32)
+    got = rd.cpu().numpy()
+    assert np.abs(got - want).max() <= 1.2e-7
+    assert (got != want).mean() < 0.01            # only double-rounding ties may differ
+    np.testing.assert_array_equal(cl.cpu().numpy(), g["camloc"].astype(np.float32))
+    np.testing.assert_allclose(np.linalg.norm(got, axis=-1), 1.0, atol=2e-7)

@@ -2,6 +2,8 @@
 (ndjir_amd/solver.py).  The reference holds no solver test (parity unpinned); the Adam recurrences and the bias
 correction are pinned independently against torch.optim.Adam in the regime where the two rules coincide (eps = 0:
 nnabla keeps eps outside the bias correction, torch inside)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -86,3 +88,28 @@ def test_schedules_product_vs_oracle(B, R):
     assert OS.cos_anneal_ratio(tr, 0) == 1.0 and OS.cos_anneal_ratio(tr, 224) == pytest.approx(0.0, abs=1e-4)
     assert OS.cos_anneal_ratio(tr, 225) == 1.0          # sic: jumps back to 1 once the anneal term is over (x >= 1)
     assert OS.light_visibility_gain(tr, 0) == 1.0 and OS.light_visibility_gain(tr, 1500) == 1.0
+
+
+def test_learning_rate_schedule_against_reference_golden():
+    """tests/golden/solver_schedule.npz: outputs of the reference's own Solvers.compute_learning_rate
+    (python/solver.py:82-98, extracted by tests/golden/make_golden.py) -- pins the oracle and the product's schedule."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "solver_schedule.npz"))
+    for k in range(int(g["n_cases"])):
+        tr = dict(epoch=int(g[f"c{k}_epoch"]), warmup_term_ratio=float(g[f"c{k}_warmup_term_ratio"]),
+                  learning_rate_end_ratio=float(g[f"c{k}_learning_rate_end_ratio"]))
+        conf = config.load("default", [f"train.{a}={b}" for a, b in tr.items()])
+        s = Solvers(conf)
+        lr0 = float(g[f"c{k}_lr0"])
+        for i, want in zip(g[f"c{k}_i"], g[f"c{k}_lr"]):
+            assert OS.compute_learning_rate(tr, int(i), lr0) == pytest.approx(want, rel=1e-13, abs=1e-300)
+            assert s.compute_learning_rate(int(i), lr0) == pytest.approx(want, rel=1e-13, abs=1e-300)
+
+
+def test_host_ray_generation_against_reference_golden():
+    """tests/golden/generate_raydir_camloc.npz: outputs of the reference's python/helper.py:44-81."""
+    from ndjir_amd.helper import generate_all_pixels, generate_raydir_camloc
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "generate_raydir_camloc.npz"))
+    raydir, camloc = generate_raydir_camloc(g["pose"], g["intrinsic"], g["xy"])
+    np.testing.assert_allclose(raydir, g["raydir"], rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(camloc, g["camloc"])
+    np.testing.assert_array_equal(generate_all_pixels(int(g["W"]), int(g["H"])), g["all_pixels"])
