@@ -639,3 +639,25 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, rand, param
                 prior_roughness=prior_roughness, prior_specular_reflectance=prior_spec,
                 reg_std_roughness=reg_std_roughness, reg_std_specular_reflectance=reg_std_spec,
                 render=res, x_fg=x_fg, t_fg=t_fg, x_bg=x_bg, t_bg=t_bg, mask=mask)
+
+
+# ----------------------------------------------------------------------------------------------
+# extract_by_mc.py
+# ----------------------------------------------------------------------------------------------
+def compute_pts_vol(mins, maxs, grid_size, params, conf, batch_size=50000):
+    """extract_by_mc.py:46-74, step by step: meshgrid (default 'xy' indexing), batches through
+    geometric_network(...)[0], reshape to (y, x, z), transpose to (x, y, z)."""
+    import numpy as np
+    x = np.linspace(mins[0], maxs[0], grid_size).astype(np.float32)
+    y = np.linspace(mins[1], maxs[1], grid_size).astype(np.float32)
+    z = np.linspace(mins[2], maxs[2], grid_size).astype(np.float32)
+    X, Y, Z = np.meshgrid(x, y, z)
+    pts = np.stack((X.reshape(-1), Y.reshape(-1), Z.reshape(-1)), axis=1)
+    dtype = next(iter(params.values())).dtype
+    vol = []
+    with torch.no_grad():
+        for b in range(0, pts.shape[0], batch_size):
+            p = torch.from_numpy(pts[b:b + batch_size]).to(dtype)
+            vol.append(geometric_network(p, params, conf)[0].reshape(-1).numpy())
+    vol = np.concatenate(vol).reshape((y.size, x.size, z.size)).transpose((1, 0, 2))
+    return pts, vol
