@@ -104,14 +104,19 @@ class Step:
         self.flat_grad = torch.zeros(sum(p.numel() for p in self.mlp_params), device=device)
 
     def rearm_grid_buffers(self):
-        """Zero the accumulate-in-place grid gradient buffers.  Linear dense voxel grid: only the cells the
-        previous step's query points touched (512^3 x 4 floats = 2 GiB would otherwise be rewritten every
-        step); anything else: dense.  (Rows deposited by other ranks are cleared in `pre_exchange`.)"""
+        """Zero the accumulate-in-place grid gradient buffers.  Linear dense voxel grid: only the cells that hold
+        gradient (512^3 x 4 floats = 2 GiB would otherwise be rewritten every step) -- one GPU: the cells the previous
+        step's query points touched; N > 1: the rows the previous exchange listed (own and received).  Anything
+        else: dense."""
         import math
+        from ndjir_amd.distributed import SparseRows
         from ndjir_amd.grid_feature import zero_touched
         v = self.conf.geometric_network.voxel
         for name, buf in self.grid_bufs.items():
-            if v.type == "voxel" and self.touched is not None and (self.world == 1 or name in self.remote_rows):
+            handle = self.remote_rows.get(name)
+            if isinstance(handle, SparseRows):
+                handle.zero(buf)
+            elif v.type == "voxel" and self.touched is not None and (self.world == 1 or handle is not None):
                 x_fg = self.touched
                 r = self.conf.renderer.bounding_sphere_radius
                 zero_touched(buf, x_fg)
@@ -129,8 +134,9 @@ class Step:
         import torch.distributed as dist
         from ndjir_amd.sampler import SamplePoints
         for name, rows in self.remote_rows.items():
-            buf = self.grid_bufs[name]
-            buf.view(-1, buf.shape[-1]).index_fill_(0, rows, 0.0)
+            if torch.is_tensor(rows):          # generic torch path of the exchange (the HIP path re-arms in `compute`)
+                buf = self.grid_bufs[name]
+                buf.view(-1, buf.shape[-1]).index_fill_(0, rows, 0.0)
         with torch.no_grad():
             _, _, mask = SamplePoints(self.conf).t_near_far(self.camloc, self.raydir)
             ms = mask.sum().reshape(())
@@ -205,8 +211,9 @@ class Step:
         self.solvers.update_learning_rate(int(t.epoch * t.warmup_term_ratio) if epoch_index is None else epoch_index)
         self.rearm_grid_buffers()
         for name, rows in self.remote_rows.items():
-            buf = self.grid_bufs[name]
-            buf.view(-1, buf.shape[-1]).index_fill_(0, rows, 0.0)
+            if torch.is_tensor(rows):
+                buf = self.grid_bufs[name]
+                buf.view(-1, buf.shape[-1]).index_fill_(0, rows, 0.0)
         self.remote_rows = {}
 
     def train_compute(self):

@@ -77,6 +77,22 @@ int ndjir_voxel_feature_zero_touched(int N, float* grad_feature, const float* qu
  * `check_inf_or_nan_grad` (python/solver.py:67-69) without reading the 2 GiB buffer. */
 int ndjir_voxel_feature_check_touched(int N, const float* grad_feature, const float* query, const int* grid_sizes, int D,
                                       const float* min, const float* max, int* flag, hipStream_t stream);
+/* ---- sparse exchange of the dense voxel gradient between ranks (no reference counterpart: the reference is single-GPU).
+ * A rank touches < 1 % of the 512^3 cells per step.  pack_rows appends the NON-ZERO rows (D = 4: one float4 per cell) of
+ * the cells the N query points touch to a packed list -- ids (capacity) int32, rows (capacity, 4) -- each cell once
+ * (bitmap: 1 bit per cell, all zero before the first call, cleared again by ndjir_sparse_rows_clear_bitmap); *count
+ * (device int) keeps counting past capacity so that the caller can detect an overflow.  After an all-gather with a
+ * common capacity -- ids (world, capacity), rows (world, capacity, 4), counts (world), all device memory --
+ * ndjir_sparse_rows_apply adds every other rank's rows into the local buffer and ndjir_sparse_rows_zero clears all
+ * listed rows (re-arming the accumulate-in-place buffer for the next step without touching 2 GiB). */
+int ndjir_voxel_feature_pack_rows(int N, const float* grad_feature, const float* query, const int* grid_sizes, int D,
+                                  const float* min, const float* max, unsigned* bitmap, int* ids, float* rows, int* count,
+                                  int capacity, hipStream_t stream);
+int ndjir_sparse_rows_clear_bitmap(const int* ids, const int* count, int capacity, unsigned* bitmap, hipStream_t stream);
+int ndjir_sparse_rows_apply(const int* ids, const float* rows, const int* counts, int world, int capacity, int skip_rank,
+                            float* grad_feature, int D, hipStream_t stream);
+int ndjir_sparse_rows_zero(const int* ids, const int* counts, int world, int capacity, float* grad_feature, int D,
+                           hipStream_t stream);
 NDJIR_DECL_VOXEL_FAMILY(cosine_voxel_feature)
 NDJIR_DECL_VOXEL_FAMILY(lanczos_voxel_feature)
 

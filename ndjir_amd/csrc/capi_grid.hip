@@ -148,6 +148,15 @@ extern "C" int ndjir_voxel_feature_zero_touched(int N, float* gf, const float* q
   return launch_zero_touched(LINEAR, voxel_desc(gs, D, mn, mx), N, gf, query, nullptr, st);
 }
 
+// Sparse gradient exchange: append the non-zero rows of the cells the N query points touch (each cell once).
+extern "C" int ndjir_voxel_feature_pack_rows(int N, const float* gf, const float* query, const int* gs, int D, const float* mn,
+                                             const float* mx, unsigned* bitmap, int* ids, float* rows, int* count, int capacity,
+                                             hipStream_t st) {
+  if (N <= 0) return NDJIR_OK;
+  CHECK_PTRS(gf, query, bitmap, ids, rows, count);
+  return launch_pack_rows(voxel_desc(gs, D, mn, mx), N, gf, query, bitmap, ids, rows, count, capacity, st);
+}
+
 // *flag |= 1 when a cell of grad_feature that the N query points touch holds an inf or nan.
 extern "C" int ndjir_voxel_feature_check_touched(int N, const float* gf, const float* query, const int* gs, int D,
                                                  const float* mn, const float* mx, int* flag, hipStream_t st) {

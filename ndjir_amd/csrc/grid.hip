@@ -451,6 +451,34 @@ __global__ void __launch_bounds__(256) k_zero_touched(long long P, float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sparse gradient exchange (multi-GPU, no reference counterpart): append the NON-ZERO rows of the cells that the query
+// points touch in an accumulate-in-place gradient buffer (D = 4: one float4 per cell) to a packed list (cell id, row),
+// each cell once -- a persistent bitmap (1 bit per cell) marks the cells already listed.  `count` keeps counting past
+// `capacity` (the caller sees the overflow and repeats with a larger list).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_rows(long long P, const float* __restrict__ gf, const float* __restrict__ query,
+                                                   GridDesc g, unsigned* __restrict__ bitmap, int* __restrict__ ids,
+                                                   float4* __restrict__ rows, int* __restrict__ count, int capacity) {
+  constexpr int TOPO = VOXEL, I = LINEAR;
+  constexpr int ND = 3, NT = 2;
+  NDJIR_GRID_THREAD_PROLOGUE
+  NDJIR_FOR_TAPS(ND, NT) {
+    const long long off = cell_offset(st, i, j, k);
+    const float4 v = *reinterpret_cast<const float4*>(gf + off);
+    if (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f) {
+      const unsigned cell = (unsigned)(off >> 2);
+      const unsigned bit = 1u << (cell & 31);
+      const unsigned old = atomicOr(bitmap + (cell >> 5), bit);
+      if (!(old & bit)) {
+        const int slot = atomicAdd(count, 1);
+        if (slot < capacity) { ids[slot] = (int)cell; rows[slot] = v; }
+      }
+    }
+  }
+  NDJIR_GRID_THREAD_EPILOGUE
+}
+
+// ------------------------------------------------------------------------------------------------
 // grad_query_grad_query, linear dense voxel only (voxel_feature_cuda.cu:440-520). Accumulates.
 // ------------------------------------------------------------------------------------------------
 template <int VW>
@@ -722,6 +750,15 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
     if (mode == 0) hipLaunchKernelGGL((k_scatter<TOPO, I, VW, 0>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
     else hipLaunchKernelGGL((k_scatter<TOPO, I, VW, 1>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
   }))
+  return ndjir_check_launch();
+}
+
+int launch_pack_rows(const GridDesc& g, long long P, const float* gf, const float* query, unsigned* bitmap, int* ids, float* rows,
+                     int* count, int capacity, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  if (g.topo != VOXEL || g.D != 4) return NDJIR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_pack_rows, dim3(grid_blocks(P * g.S)), dim3(256), 0, stream, P, gf, query, g, bitmap, ids,
+                     reinterpret_cast<float4*>(rows), count, capacity);
   return ndjir_check_launch();
 }
 

@@ -70,11 +70,78 @@ def allreduce_sparse_rows(buf, cell_ids, group=None, return_remote=False):
     return buf
 
 
+class SparseRows:
+    """What one HIP-path exchange leaves behind for a buffer: every rank's packed cell ids (world, cap) and counts
+    (world) -- the rows that now hold gradient in the local dense buffer.  `zero(buf)` clears exactly those."""
+
+    def __init__(self, ids, counts, world, cap):
+        self.ids, self.counts, self.world, self.cap = ids, counts, world, cap
+
+    def zero(self, buf):
+        from . import lib
+        lib.call("sparse_rows_zero", self.ids, self.counts, self.world, self.cap, buf, buf.shape[-1])
+
+
+_STATE = {}
+
+
+def _state(buf, capacity):
+    st = _STATE.get(buf.data_ptr())
+    cells = buf.numel() // buf.shape[-1]
+    if st is None or st["cells"] != cells:
+        st = dict(cells=cells, bitmap=torch.zeros((cells + 31) // 32, dtype=torch.int32, device=buf.device), cap=0,
+                  count=torch.zeros(1, dtype=torch.int32, device=buf.device))
+        _STATE[buf.data_ptr()] = st
+    if st["cap"] < capacity:
+        st["cap"] = capacity
+        st["ids"] = torch.empty(capacity, dtype=torch.int32, device=buf.device)
+        st["rows"] = torch.empty((capacity, buf.shape[-1]), dtype=torch.float32, device=buf.device)
+    return st
+
+
+def allreduce_voxel_rows_hip(buf, queries, min_=(-1.0, -1.0, -1.0), max_=(1.0, 1.0, 1.0), group=None):
+    """HIP path of the sparse exchange for a dense D = 4 voxel gradient buffer on the GPU (csrc/grid.hip
+    `k_pack_rows`, csrc/sparse_rows.hip): the non-zero rows of the cells this rank's query points touched are packed
+    once each on the device (bitmap dedup), all-gathered with the common size max_r(count_r) -- the one host
+    synchronisation of the exchange is reading those counts -- and the other ranks' rows are added in place.
+    Returns a `SparseRows` handle (for re-arming the buffer before the next step)."""
+    from . import lib
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    G, D = list(buf.shape[:3]), buf.shape[-1]
+    need = sum(q.numel() // 3 for q in queries) * 8          # upper bound: every corner of every point distinct
+    st = _state(buf, min(need, 1 << 18))
+    while True:
+        st["count"].zero_()
+        for q in queries:
+            q = q.detach().reshape(-1, 3).contiguous()
+            lib.call("voxel_feature_pack_rows", q.shape[0], buf, q, G, D, list(min_), list(max_), st["bitmap"], st["ids"],
+                     st["rows"], st["count"], st["cap"])
+        lib.call("sparse_rows_clear_bitmap", st["ids"], st["count"], st["cap"], st["bitmap"])
+        counts = torch.empty(world, dtype=torch.int32, device=buf.device)
+        dist.all_gather(list(counts.unbind(0)), st["count"].reshape(()), group=group)
+        host = counts.tolist()                                # the exchange's one host synchronisation
+        if max(host) <= st["cap"]:
+            break
+        # some rank's list overflowed (every rank sees it): grow everywhere and pack again (the dedup bitmap of a
+        # rank that overflowed still holds the unlisted cells -> clear it densely; rare)
+        st["bitmap"].zero_()
+        st = _state(buf, min(need, 2 * max(host)))
+    m = max(4096, -(-max(host) // 4096) * 4096)
+    m = min(m, st["cap"])
+    ids = torch.empty((world, m), dtype=torch.int32, device=buf.device)
+    rows = torch.empty((world, m, D), dtype=torch.float32, device=buf.device)
+    dist.all_gather(list(ids.unbind(0)), st["ids"][:m], group=group)
+    dist.all_gather(list(rows.unbind(0)), st["rows"][:m], group=group)
+    lib.call("sparse_rows_apply", ids, rows, counts, world, m, rank, buf, D)
+    return SparseRows(ids, counts, world, m)
+
+
 def allreduce_step_gradients(flat_mlp_grad, grid_bufs, grid_queries, group=None):
     """One gradient exchange per step.  `grid_bufs`: {name: dense gradient buffer};
     `grid_queries`: {name: (list of query tensors, grid_sizes)} for dense voxel grids; buffers
     without an entry (tri-plane / tri-line, a few hundred MB at most) are all-reduced densely.
-    Returns {name: row ids received from other ranks} for the sparsely exchanged buffers."""
+    Returns, for the sparsely exchanged buffers, {name: SparseRows handle} (HIP path: GPU buffer with D = 4) or
+    {name: row ids received from other ranks} (generic torch path)."""
     dist.all_reduce(flat_mlp_grad, group=group)
     remote_rows = {}
     for name, buf in grid_bufs.items():
@@ -83,6 +150,9 @@ def allreduce_step_gradients(flat_mlp_grad, grid_bufs, grid_queries, group=None)
             dist.all_reduce(buf, group=group)
             continue
         queries, grid_sizes = q
+        if buf.is_cuda and buf.dim() == 4 and buf.shape[-1] == 4:
+            remote_rows[name] = allreduce_voxel_rows_hip(buf, queries, group=group)
+            continue
         ids = torch.cat([voxel_cell_ids(x, grid_sizes) for x in queries])
         _, remote_rows[name] = allreduce_sparse_rows(buf.view(-1, buf.shape[-1]), ids, group=group, return_remote=True)
     return remote_rows

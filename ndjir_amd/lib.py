@@ -65,6 +65,10 @@ SIGS = {
     "squareplus_backward": "ipppfi",
     "voxel_feature_zero_touched": "ippIiFF",
     "voxel_feature_check_touched": "ippIiFFq",
+    "voxel_feature_pack_rows": "ippIiFFqqpqi",
+    "sparse_rows_clear_bitmap": "qqiq",
+    "sparse_rows_apply": "qpqiiipi",
+    "sparse_rows_zero": "qqiipi",
     "generate_raydir_camloc": "iixxqpipp",
     "solver_adam_begin": "xffqq",
     # n w g m v alpha_t beta1 beta2 eps decay zero_grad state

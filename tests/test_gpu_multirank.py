@@ -1,0 +1,48 @@
+"""The N > 1 step on the GPU: two ranks (sharing GPU 0 over gloo) run the ray-sharded step with the HIP sparse grid
+exchange; the summed loss, the all-reduced MLP gradient bucket and the exchanged grid gradient must equal the
+single-process step over the union of the rays -- for two consecutive steps (the second one exercises the re-arming of
+the rows received from the other rank)."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_equal_one_process(gpu):
+    import bench
+    from ndjir_amd import config as cfg, parameter as P
+    from ndjir_amd.grid_feature import set_grad_buffer
+    R, G, steps = 64, 64, 2
+    with tempfile.TemporaryDirectory() as out:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29533", os.path.join(ROOT, "tests", "multi_rank_worker.py"), out, str(R), str(G), str(steps)]
+        res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+        assert res.returncode == 0, res.stderr[-3000:]
+        ranks = [torch.load(os.path.join(out, f"rank{r}.pt")) for r in range(2)]
+    assert ranks[0]["handle"] == {"geometric-network/voxel_feature/F": "SparseRows"}       # the HIP path ran
+    conf = cfg.load("default", [f"geometric_network.voxel.grid_size={G}"])
+    step = bench.Step(conf, 2 * R, gpu, 0, 1)
+    try:
+        for _ in range(steps):
+            loss = float(step.forward_backward())
+        assert ranks[0]["losses"][-1] + ranks[1]["losses"][-1] == pytest.approx(loss, rel=5e-6)
+        flat = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for p, g in zip(step.mlp_params, step.grads)]).cpu()
+        for r in range(2):      # both ranks hold the same sums
+            d = (ranks[r]["flat"] - flat).abs().max()
+            assert float(d) <= 2e-4 * float(flat.abs().max()), r
+            for k, v in step.grid_bufs.items():
+                ref = v.cpu()
+                assert float((ranks[r]["grid"][k] - ref).abs().max()) <= 2e-4 * float(ref.abs().max()), (r, k)
+                assert int(((ranks[r]["grid"][k] != 0).any(-1) != (ref != 0).any(-1)).sum()) <= 0.001 * int((ref != 0).any(-1).sum()) + 2
+    finally:
+        for p in step.grid_params:
+            set_grad_buffer(p, None)
+        P.clear_parameters()

@@ -296,3 +296,60 @@ def test_generate_raydir_camloc_device(gpu, mode):
     assert (got != want).mean() < 0.01            # only double-rounding ties may differ
     np.testing.assert_array_equal(cl.cpu().numpy(), g["camloc"].astype(np.float32))
     np.testing.assert_allclose(np.linalg.norm(got, axis=-1), 1.0, atol=2e-7)
+
+
+def test_sparse_row_exchange_kernels(gpu):
+    """pack_rows / clear_bitmap / apply / zero (csrc/grid.hip, csrc/sparse_rows.hip) on two simulated ranks: after the
+    exchange both buffers equal the dense sum; the packed lists hold every non-zero touched cell exactly once; zeroing the
+    listed rows re-arms the buffers completely; an undersized list reports its overflow through the count."""
+    from ndjir_amd import lib
+    from ndjir_amd.distributed import voxel_cell_ids
+    G, D, P = 48, 4, 3000
+    gen = torch.Generator(device=gpu).manual_seed(5)
+    bufs, qs, packed = [], [], []
+    for rank in range(2):
+        q = [(torch.rand(P, 3, device=gpu, generator=gen) * 1.9 - 0.95), (torch.rand(P // 2, 3, device=gpu, generator=gen) * 1.9 - 0.95)]
+        buf = torch.zeros(G, G, G, D, device=gpu)
+        for x in q:      # a gradient as the scatter kernels leave it: only touched cells, some of them exactly zero
+            go = torch.randn(x.shape[0], D, device=gpu, generator=gen) * (torch.rand(x.shape[0], 1, device=gpu, generator=gen) > 0.3)
+            lib.call("voxel_feature_grad_feature", x.shape[0] * D, buf, go.contiguous(), x.contiguous(), [G] * 3, D, [-1] * 3, [1] * 3, 0, 1)
+        bufs.append(buf)
+        qs.append(q)
+    dense = bufs[0] + bufs[1]
+    cap = 1 << 16
+    ids = torch.full((2, cap), -1, dtype=torch.int32, device=gpu)
+    rows = torch.zeros(2, cap, D, device=gpu)
+    counts = torch.zeros(2, dtype=torch.int32, device=gpu)
+    bitmap = torch.zeros((G ** 3 + 31) // 32, dtype=torch.int32, device=gpu)
+    for rank in range(2):
+        cnt = torch.zeros(1, dtype=torch.int32, device=gpu)
+        for x in qs[rank]:
+            lib.call("voxel_feature_pack_rows", x.shape[0], bufs[rank], x.contiguous(), [G] * 3, D, [-1] * 3, [1] * 3, bitmap, ids[rank],
+                     rows[rank], cnt, cap)
+        lib.call("sparse_rows_clear_bitmap", ids[rank], cnt, cap, bitmap)
+        assert int(bitmap.abs().sum()) == 0
+        counts[rank] = cnt[0]
+        n = int(cnt)
+        got = ids[rank, :n].long()
+        flat = bufs[rank].view(-1, D)
+        nonzero = torch.nonzero((flat != 0).any(dim=1)).reshape(-1)
+        assert n == nonzero.numel() and torch.equal(torch.sort(got).values, nonzero)          # each non-zero row once
+        touched = torch.unique(torch.cat([voxel_cell_ids(x, [G] * 3) for x in qs[rank]]))
+        assert bool(torch.isin(got, touched).all())
+        assert torch.equal(rows[rank, :n], flat[got])
+    for rank in range(2):
+        lib.call("sparse_rows_apply", ids, rows, counts, 2, cap, rank, bufs[rank], D)
+        scale = float(dense.abs().max())
+        assert float((bufs[rank] - dense).abs().max()) <= 1e-6 * scale
+    for rank in range(2):
+        lib.call("sparse_rows_zero", ids, counts, 2, cap, bufs[rank], D)
+        assert float(bufs[rank].abs().max()) == 0.0
+    # overflow: the count runs past the capacity, nothing is written beyond it
+    buf = dense.clone()
+    small = 100
+    ids2 = torch.full((small + 8,), -7, dtype=torch.int32, device=gpu)
+    rows2 = torch.zeros(small + 8, D, device=gpu)
+    cnt = torch.zeros(1, dtype=torch.int32, device=gpu)
+    x = qs[0][0].contiguous()
+    lib.call("voxel_feature_pack_rows", x.shape[0], buf, x, [G] * 3, D, [-1] * 3, [1] * 3, bitmap, ids2, rows2, cnt, small)
+    assert int(cnt) > small and bool((ids2[small:] == -7).all()) and bool((ids2[:small] >= 0).all())
