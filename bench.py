@@ -91,6 +91,7 @@ class Step:
         self.mask_sum = torch.zeros((), device=device)   # multi-GPU: all-reduced sum of the ray masks
         self.x_fg = None
         self.mlp_names = None
+        self._zeros = None
         self.forward_backward()          # creates the parameters (untimed)
         for name, p in P.get_parameters().items():
             if name.endswith("feature/F"):
@@ -164,15 +165,10 @@ class Step:
                 self.touched.copy_(self.x_fg)
         self.grads = grads               # the step's product: every parameter gradient, materialised
         if self.world > 1:
-            # pack the MLP gradients into one flat bucket for the all-reduce
-            off = 0
-            for p, g in zip(self.mlp_params, grads):
-                n = p.numel()
-                if g is not None:
-                    self.flat_grad[off:off + n].copy_(g.reshape(-1))
-                else:
-                    self.flat_grad[off:off + n].zero_()
-                off += n
+            # pack the MLP gradients into one flat bucket for the all-reduce (one batched copy, not one launch per tensor)
+            if self._zeros is None:
+                self._zeros = [torch.zeros(p.numel(), device=self.device) for p in self.mlp_params]
+            torch.cat([g.reshape(-1) if g is not None else z for g, z in zip(grads, self._zeros)], out=self.flat_grad)
         return loss.detach()
 
     def exchange(self):
