@@ -354,7 +354,8 @@ __global__ void __launch_bounds__(256) k_scatter(long long P, float* __restrict_
 // points x 8 corners in an LDS hash table (cell -> float4, LDS atomics) and issues one global atomic
 // per distinct cell and channel.
 // ------------------------------------------------------------------------------------------------
-constexpr int AGG_HT = 4096;      // slots; at most 256 x 8 = 2048 insertions per pass
+constexpr int AGG_HT = 4096;      // slots; at most 2048 insertions per pass: 256 lanes x taps x D / 4 (voxel D = 4: 8 taps;
+                                  // tri-plane D <= 8: 4 taps x 2; tri-line D <= 8: 2 taps x 2)
 
 template <int TOPO, int MODE>
 __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restrict__ gf, const float* __restrict__ gg_query,
@@ -383,27 +384,29 @@ __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restr
 #pragma unroll
         for (int a = 0; a < ND; ++a) ggs[a] = gg_query[b * 3 + st.axis[a]] * st.scale[a] * st.ax[a].gm;
       }
-      float og[4];
+      for (int d0 = 0; d0 < g.D; d0 += 4) {       // a cell of D floats = D / 4 float4 entries of the table
+        float og[4];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) og[v] = grad_output[out_index<TOPO>(g, P, b, s, v)];
-      NDJIR_FOR_TAPS(ND, NT) {
-        float w;
-        if constexpr (MODE == 0) {
-          w = tap_w(st, i, j, k);
-        } else {
-          w = 0.f;
+        for (int v = 0; v < 4; ++v) og[v] = grad_output[out_index<TOPO>(g, P, b, s, d0 + v)];
+        NDJIR_FOR_TAPS(ND, NT) {
+          float w;
+          if constexpr (MODE == 0) {
+            w = tap_w(st, i, j, k);
+          } else {
+            w = 0.f;
 #pragma unroll
-          for (int a = 0; a < ND; ++a) w += ggs[a] * tap_dw(st, a, i, j, k);
+            for (int a = 0; a < ND; ++a) w += ggs[a] * tap_dw(st, a, i, j, k);
+          }
+          const int key = (int)((cell_offset(st, i, j, k) + d0) >> 2);     // float4 index
+          unsigned slot = ((unsigned)key * 2654435761u) >> 20;             // 12 bits
+          while (true) {
+            const int old = atomicCAS(&keys[slot], -1, key);
+            if (old == -1 || old == key) break;
+            slot = (slot + 1) & (AGG_HT - 1);
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) atomicAdd(&vals[4 * slot + v], og[v] * w);
         }
-        const int key = (int)(cell_offset(st, i, j, k) >> 2);       // cell index (D = 4 floats per cell)
-        unsigned slot = ((unsigned)key * 2654435761u) >> 20;        // 12 bits
-        while (true) {
-          const int old = atomicCAS(&keys[slot], -1, key);
-          if (old == -1 || old == key) break;
-          slot = (slot + 1) & (AGG_HT - 1);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) atomicAdd(&vals[4 * slot + v], og[v] * w);
       }
     }
     __syncthreads();
@@ -601,25 +604,27 @@ __global__ void __launch_bounds__(256) k_tv_bwd_agg(long long P, float* __restri
       oa[0] = cell_offset(st, 1, 0, 0);
       if constexpr (ND > 1) oa[1] = cell_offset(st, 0, 1, 0);
       if constexpr (ND > 2) oa[2] = cell_offset(st, 0, 0, 1);
-      float f0[4], fa[ND][4], ga[ND][4], g0[4];
-      vload<4>(f0, feature + o0);
+      for (int d0 = 0; d0 < g.D; d0 += 4) {
+        float f0[4], fa[ND][4], ga[ND][4], g0[4];
+        vload<4>(f0, feature + o0 + d0);
 #pragma unroll
-      for (int a = 0; a < ND; ++a) vload<4>(fa[a], feature + oa[a]);
+        for (int a = 0; a < ND; ++a) vload<4>(fa[a], feature + oa[a] + d0);
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        float del[ND], s2 = 0.f;
+        for (int v = 0; v < 4; ++v) {
+          float del[ND], s2 = 0.f;
 #pragma unroll
-        for (int a = 0; a < ND; ++a) { del[a] = fa[a][v] - f0[v]; s2 += del[a] * del[a]; }
-        // total_variation_loss_cuda.cu:158-170: rsqrt(.. + 1e-12) evaluated in double
-        const double common = (double)grad_output[out_index<TOPO>(g, P, b, s, v)] * (1.0 / sqrt((double)s2 + 1e-12));
-        double gsum = 0.0;
+          for (int a = 0; a < ND; ++a) { del[a] = fa[a][v] - f0[v]; s2 += del[a] * del[a]; }
+          // total_variation_loss_cuda.cu:158-170: rsqrt(.. + 1e-12) evaluated in double
+          const double common = (double)grad_output[out_index<TOPO>(g, P, b, s, d0 + v)] * (1.0 / sqrt((double)s2 + 1e-12));
+          double gsum = 0.0;
 #pragma unroll
-        for (int a = 0; a < ND; ++a) { const double t = common * (double)del[a]; gsum += t; ga[a][v] = (float)t; }
-        g0[v] = (float)(-gsum);
+          for (int a = 0; a < ND; ++a) { const double t = common * (double)del[a]; gsum += t; ga[a][v] = (float)t; }
+          g0[v] = (float)(-gsum);
+        }
+#pragma unroll
+        for (int a = 0; a < ND; ++a) add(oa[a] + d0, ga[a]);
+        if (sym_backward) add(o0 + d0, g0);
       }
-#pragma unroll
-      for (int a = 0; a < ND; ++a) add(oa[a], ga[a]);
-      if (sym_backward) add(o0, g0);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < AGG_HT; t += 256) {
@@ -735,7 +740,8 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
   if (P <= 0) return NDJIR_OK;
   int blocks = grid_blocks(P * g.S);
   static const bool no_agg = getenv("NDJIR_SCATTER_NO_AGG") != nullptr;      // A/B switch
-  if (interp == LINEAR && g.D == 4 && g.topo != HASH && !no_agg) {
+  const bool agg_fits = (g.D == 4) || (g.topo != VOXEL && g.D == 8);          // table capacity, see AGG_HT
+  if (interp == LINEAR && agg_fits && g.topo != HASH && !no_agg) {
     // workgroup-aggregated path (dense cell index must fit 31 bits: 2^33 floats)
 #define NDJIR_AGG_CASE(T)                                                                                                  \
     { if (mode == 0) hipLaunchKernelGGL((k_scatter_agg<T, 0>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g); \
@@ -793,7 +799,7 @@ int launch_tv(const GridDesc& g, long long P, bool bwd, float* dst, const float*
   if (P <= 0) return NDJIR_OK;
   int blocks = grid_blocks(P * g.S);
   static const bool no_agg = getenv("NDJIR_SCATTER_NO_AGG") != nullptr;
-  if (bwd && g.D == 4 && g.topo != HASH && !no_agg) {
+  if (bwd && (g.D == 4 || (g.topo != VOXEL && g.D == 8)) && g.topo != HASH && !no_agg) {
     if (g.topo == VOXEL) hipLaunchKernelGGL((k_tv_bwd_agg<VOXEL>), dim3(blocks), dim3(256), 0, stream, P, dst, grad_output, query, feature, g, sym_backward);
     else if (g.topo == TRIPLANE) hipLaunchKernelGGL((k_tv_bwd_agg<TRIPLANE>), dim3(blocks), dim3(256), 0, stream, P, dst, grad_output, query, feature, g, sym_backward);
     else hipLaunchKernelGGL((k_tv_bwd_agg<TRILINE>), dim3(blocks), dim3(256), 0, stream, P, dst, grad_output, query, feature, g, sym_backward);

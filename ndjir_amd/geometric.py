@@ -17,6 +17,11 @@ backward graph; here they are derived by hand and mapped onto three kinds of fus
   backward     delta_j = (delta_{j+1} W_{j+1}^T) * softplus'(z_j) + extra_j
   weights      dW_j = A_j^T delta_j + g-bar_j^T s_j ;  dW_last[:, 0] += colsum(g-bar_last) ;  db_j = colsum(delta_j)
   grid         dF = grad_feature(dX[:, 39:43]) + grad_query_grad_feature(n-bar, g_0[:, 39:43])
+
+The grid encoding may be any concatenation of grid-feature families (dense voxel: 4 columns; `triplaneline`:
+tri-plane 24 + tri-line 24 columns, python/network.py:124-127); each contributes its slice of e, of g_0 and of dX
+through its own five entry points (query, grad_query, grad_query_grad_grad_output, grad_query_grad_feature,
+grad_feature).
 """
 import math
 
@@ -27,7 +32,11 @@ from . import lib
 from .grid_feature import _core
 from .mlp import _launch, _packed, chain_workspace, colsum, wgrad
 
-_VOX = _core.FAMILIES["voxel"]
+
+
+def _enc_call(fam, name, P, C, *args):
+    """entry point `name` of grid family `fam` (N = P * channels for the dense families)"""
+    lib.call(f"{fam.prefix}_{name}", P * C, *args)
 
 
 def _bands(M, device):
@@ -44,11 +53,15 @@ def _sdf_col(W):
 
 
 class GeometricMain(Function):
-    """(x, feature|None, *W, *b) -> sdf (..,1), feature (..,D), n (..,3).  `cfg` = (M, skip_at, scale, min, max)."""
+    """(x, cfg, *grids, *W, *b) -> sdf (..,1), feature (..,D), n (..,3).
+    `cfg` = (M, skip_at, scale, min, max, families): one grid-feature family name per grid tensor."""
 
     @staticmethod
-    def forward(ctx, x, feature, cfg, *params):
-        M, skip_at, scale, min_, max_ = cfg
+    def forward(ctx, x, cfg, *tensors):
+        M, skip_at, scale, min_, max_, fam_names = cfg
+        NG = len(fam_names)
+        grids, params = list(tensors[:NG]), tensors[NG:]
+        fams = [_core.FAMILIES[f] for f in fam_names]
         L = len(params) // 2
         W, b = list(params[:L]), list(params[L:])
         beta = 100.0
@@ -59,13 +72,18 @@ class GeometricMain(Function):
         xb = xf.unsqueeze(-1) * bands                      # (P, 3, M), band fastest (network.py:108-115)
         cosb, sinb = torch.cos(xb), torch.sin(xb)
         parts = [xf, cosb.reshape(P, -1), sinb.reshape(P, -1)]
-        has_grid = feature is not None
-        if has_grid:
-            fd = feature.detach().contiguous()
-            D0 = fd.shape[-1]
-            vf = torch.empty((P, D0), device=dev, dtype=torch.float32)
-            lib.call("voxel_feature_query_on_voxel", P * D0, vf, xf, fd, list(fd.shape[:3]), D0, min_, max_, 0)
+        has_grid = NG > 0
+        enc = []                                           # (family, feature, shape args, channels, first column in e)
+        col = 3 + 6 * M
+        for fam, feat in zip(fams, grids):
+            fd = feat.detach().contiguous()
+            C = fam.channels(fd.shape, None)
+            sa = fam.shape_args(fd.shape, None)
+            vf = torch.empty((P, C), device=dev, dtype=torch.float32)
+            _enc_call(fam, fam.fwd, P, C, vf, xf, fd, *sa, min_, max_, 0)
             parts.append(vf)
+            enc.append((fam, fd, sa, C, col))
+            col += C
         e = torch.cat(parts, dim=-1).contiguous()          # A_0 (P, K0)
         K0 = e.shape[1]
         npe = 3 + 6 * M
@@ -117,26 +135,28 @@ class GeometricMain(Function):
         gc = g0[:, 3:3 + 3 * M].reshape(P, 3, M)
         gs = g0[:, 3 + 3 * M:npe].reshape(P, 3, M)
         n = g0[:, :3] + ((gs * cosb - gc * sinb) * bands).sum(-1)
-        if has_grid:
-            go = g0[:, npe:].contiguous()
+        for fam, fd, sa, C, c0 in enc:
+            go = g0[:, c0:c0 + C].contiguous()
             gq = torch.empty((P, 3), device=dev, dtype=torch.float32)
-            lib.call("voxel_feature_grad_query", P * D0, gq, go, xf, fd, list(fd.shape[:3]), D0, min_, max_, 0, 0)
+            _enc_call(fam, "grad_query", P, C, gq, go, xf, fd, *sa, min_, max_, 0, 0)
             n = n + gq
 
-        ctx.cfg = (M, skip_at, scale, min_, max_, L, tuple(x.shape), has_grid, bskip, split)
+        ctx.cfg = (M, skip_at, scale, min_, max_, L, tuple(x.shape), fam_names, bskip, split)
         ctx.A, ctx.s_store, ctx.s = A, s_store, s
         ctx.aux = (xf, cosb, sinb, g0)
-        ctx.save_for_backward(*W, *([feature] if has_grid else []))
+        ctx.save_for_backward(*W, *grids)
         lead = x.shape[:-1]
         return y[:, 0:1].reshape(lead + (1,)), y[:, 1:].reshape(lead + (Ns[-1] - 1,)), n.reshape(lead + (3,))
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_sdf, g_feat, g_n):
-        M, skip_at, scale, min_, max_, L, xshape, has_grid, bskip, split = ctx.cfg
+        M, skip_at, scale, min_, max_, L, xshape, fam_names, bskip, split = ctx.cfg
         saved = ctx.saved_tensors
         W = list(saved[:L])
-        feature = saved[L] if has_grid else None
+        grids = list(saved[L:])
+        NG = len(grids)
+        has_grid = NG > 0
         A, s_store, s = ctx.A, ctx.s_store, ctx.s
         xf, cosb, sinb, g0 = ctx.aux
         beta = 100.0
@@ -153,13 +173,16 @@ class GeometricMain(Function):
         gy[:, 1:] = g_feat.reshape(P, -1) if g_feat is not None else 0.0
         nbar = g_n.reshape(P, 3).contiguous() if g_n is not None else None
 
-        grid_grad = None
-        buf = _core.get_grad_buffer(feature) if has_grid else None
-        if has_grid:
-            fd = feature.detach().contiguous()
-            D0 = fd.shape[-1]
-            gs_shape = list(fd.shape[:3])
-            grid_grad = buf if buf is not None else torch.zeros_like(fd)
+        enc = []          # (family, feature, shape args, channels, first column, gradient destination, is caller's buffer)
+        col = npe
+        for fname, feat in zip(fam_names, grids):
+            fam = _core.FAMILIES[fname]
+            fd = feat.detach().contiguous()
+            C = fam.channels(fd.shape, None)
+            buf = _core.get_grad_buffer(feat)
+            enc.append((fam, fd, fam.shape_args(fd.shape, None), C, col, buf if buf is not None else torch.zeros_like(fd),
+                        buf is not None))
+            col += C
 
         extras = [None] * L
         gbar = [None] * L                 # gbar[j] = adjoint of g_j = d sdf / d A_j  (P, width of A_j)
@@ -171,13 +194,13 @@ class GeometricMain(Function):
             nb = nbar.unsqueeze(-1) * bands                                   # (P, 3, M)
             gb0[:, 3:3 + 3 * M] = (-sinb * nb).reshape(P, -1)
             gb0[:, 3 + 3 * M:npe] = (cosb * nb).reshape(P, -1)
-            if has_grid:
-                ggo = torch.empty((P, D0), device=dev, dtype=torch.float32)
-                lib.call("voxel_feature_grad_query_grad_grad_output", P * D0, ggo, nbar, xf, fd, gs_shape, D0, min_, max_, 0, 0)
-                gb0[:, npe:] = ggo
+            for fam, fd, sa, C, c0, gdst, _ in enc:
+                ggo = torch.empty((P, C), device=dev, dtype=torch.float32)
+                _enc_call(fam, "grad_query_grad_grad_output", P, C, ggo, nbar, xf, fd, *sa, min_, max_, 0, 0)
+                gb0[:, c0:c0 + C] = ggo
                 # n depends on the grid directly through the interpolation derivative
-                lib.call("voxel_feature_grad_query_grad_feature", P * D0, grid_grad, nbar, g0[:, npe:].contiguous(), xf,
-                         gs_shape, D0, min_, max_, 0, 1)
+                _enc_call(fam, "grad_query_grad_feature", P, C, gdst, nbar, g0[:, c0:c0 + C].contiguous(), xf, *sa,
+                          min_, max_, 0, 1)
             gbar[0] = gb0
             # ---- tangent chain over layers 0..L-2 ----
             T = L - 1
@@ -230,28 +253,32 @@ class GeometricMain(Function):
                 bskip, scale, split, gx if (bskip >= 0 and need_x) else None, K0, [None] * steps, side_add, [None] * steps,
                 None, 0, gb_last, chain_workspace(dev, bg + [gb_last]), shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
 
-        if has_grid:
-            lib.call("voxel_feature_grad_feature", P * D0, grid_grad, gx[:, npe:].contiguous(), xf, gs_shape, D0,
-                     min_, max_, 0, 1)
+        for fam, fd, sa, C, c0, gdst, _ in enc:
+            _enc_call(fam, "grad_feature", P, C, gdst, gx[:, c0:c0 + C].contiguous(), xf, *sa, min_, max_, 0, 1)
 
         # ---- weight / bias gradients ----
         gW, gb = [None] * L, [None] * L
         for j in range(L):
-            if ctx.needs_input_grad[3 + j]:
+            if ctx.needs_input_grad[2 + NG + j]:
                 gW[j] = wgrad(A[j], deltas[j])
                 if nbar is not None and j < L - 1:
                     wgrad(gbar[j], s[j], out=gW[j], accum=True)
                 if nbar is not None and j == L - 1:
                     gW[j][:, 0] += col_last
-            if ctx.needs_input_grad[3 + L + j]:
+            if ctx.needs_input_grad[2 + NG + L + j]:
                 gb[j] = bgrads[j] if j < L - 1 else gb_last
-        g_feature = None
-        if has_grid and ctx.needs_input_grad[1] and buf is None:
-            g_feature = grid_grad
+        g_grids = [gdst if (ctx.needs_input_grad[2 + k] and not own) else None
+                   for k, (_, _, _, _, _, gdst, own) in enumerate(enc)]
         ctx.A = ctx.s_store = ctx.s = ctx.aux = None
-        return (None, g_feature, None, *gW, *gb)
+        return (None, None, *g_grids, *gW, *gb)
 
 
-def geometric_main(x, feature, weights, biases, M, skip_at, scale, min_=(-1, -1, -1), max_=(1, 1, 1)):
-    cfg = (int(M), int(skip_at), float(scale), tuple(min_), tuple(max_))
-    return GeometricMain.apply(x, feature, cfg, *weights, *biases)
+def geometric_main(x, grids, weights, biases, M, skip_at, scale, min_=(-1, -1, -1), max_=(1, 1, 1)):
+    """grids: None, one dense-voxel feature tensor, or a list of (family name, feature tensor) in the order their
+    outputs are concatenated behind the positional encoding."""
+    if grids is None:
+        grids = []
+    elif torch.is_tensor(grids):
+        grids = [("voxel", grids)]
+    cfg = (int(M), int(skip_at), float(scale), tuple(min_), tuple(max_), tuple(f for f, _ in grids))
+    return GeometricMain.apply(x, cfg, *[t for _, t in grids], *weights, *biases)

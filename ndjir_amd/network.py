@@ -164,12 +164,15 @@ def geometric_network_with_grad(x, conf):
     (ndjir_amd/geometric.py); other configurations run layer by layer through autograd."""
     g = conf.geometric_network
     v = g.voxel
-    if USE_FUSED and g.geometric_init and g.act == "softplus" and v.type in ("voxel", "none") and not v.use_ste:
+    fused_grids = {"none": [], "voxel": ["voxel"], "triplane": ["triplane"], "triline": ["triline"],
+                   "triplaneline": ["triplane", "triline"]}
+    if USE_FUSED and g.geometric_init and g.act == "softplus" and v.type in fused_grids and not v.use_ste:
         from .geometric import geometric_main
         _ensure_geometric_params(x, conf)
         Ws, bs, skip_at, scale = _geometric_param_lists(conf)
-        feature = P.get_parameters().get("geometric-network/voxel_feature/F") if v.type == "voxel" else None
-        sdf, feat, grad_x = geometric_main(x, feature, Ws, bs, g.pe_bands, skip_at, scale)
+        params = P.get_parameters()
+        grids = [(f, params[f"geometric-network/{f}_feature/F"]) for f in fused_grids[v.type]]
+        sdf, feat, grad_x = geometric_main(x, grids, Ws, bs, g.pe_bands, skip_at, scale)
         with P.parameter_scope("geometric-network"):
             gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain]), True)
         return sdf, feat, torch.exp(gain * 10).clamp(1e-6, 5e4), grad_x

@@ -97,11 +97,21 @@ def _hip_family(family):
 @pytest.mark.parametrize("family,P,G,hash_cfg", CASES + [("voxel", 4097, 33, None), ("triplane", 1000, 64, None),
                                                          ("voxel_hash", 777, None, (16, 1.5, 2 ** 15, 16, 2))])
 def test_grid_family_vs_oracle(gpu, family, P, G, hash_cfg):
+    _family_check(gpu, family, P, G, hash_cfg)
+
+
+@pytest.mark.parametrize("family,P,G", [("triplane", 3000, 64), ("triline", 3000, 64), ("voxel", 3000, 16), ("lanczos_triplane", 200, 16)])
+def test_grid_family_eight_channels(gpu, family, P, G):
+    """feature_size = 8 (config/triplaneline.yaml): two float4 chunks per cell on the LDS-aggregated scatter path
+    (tri-plane / tri-line), the plain atomic path for the dense voxel and the Lanczos families."""
+    _family_check(gpu, family, P, G, None, D=8)
+
+
+def _family_check(gpu, family, P, G, hash_cfg, D=4):
     from ndjir_amd.grid_feature import _core
     rng = np.random.RandomState(412)
     o = K.GridOracle(family, hash=hash_cfg)
-    D = 4 if hash_cfg is None else hash_cfg[4]
-    fs = feature_shape(o, G, 4, hash_cfg)
+    fs = feature_shape(o, G, D, hash_cfg)
     # larger dense cases include out-of-box queries (extrapolation, clamped cells); fine hash levels
     # would extrapolate with coefficients ~1e2 there (ill-conditioned), so those stay inside the box
     lo, hi = (-1.0, 1.0) if (P <= 16 or hash_cfg is not None) else (-1.2, 1.2)
@@ -194,12 +204,13 @@ def test_voxel_second_order_extras(gpu):
     np.testing.assert_allclose(out.cpu().numpy(), ref, atol=2e-5 * max(1.0, np.abs(ref).max()))
 
 
-@pytest.mark.parametrize("topo", ["voxel", "triplane", "triline", "voxel_hash"])
+@pytest.mark.parametrize("topo,D", [("voxel", 4), ("triplane", 4), ("triline", 4), ("voxel_hash", 4), ("voxel", 8), ("triplane", 8),
+                                    ("triline", 8)])
 @pytest.mark.parametrize("sym", [False, True])
-def test_tv_loss(gpu, topo, sym):
+def test_tv_loss(gpu, topo, sym, D):
     from ndjir_amd.grid_feature import _core
     rng = np.random.RandomState(412)
-    P, G, D = 500, 8, 4
+    P, G = 500, 8
     hc = (4, 1.5, 2 ** 10, 4, 2)
     q = (rng.rand(P, 3) * 2.4 - 1.2).astype(np.float32)
     if topo == "voxel":
