@@ -157,6 +157,17 @@ def query_on_grid(x, G, D, use_ste, type):
     return getattr(PF, f"{pre}query_on_{topo}")(x, G, D, use_ste=use_ste, f_init=f_init)
 
 
+_FUSED_GRIDS = {"none": [], "voxel": ["voxel"], "triplane": ["triplane"], "triline": ["triline"],
+                "triplaneline": ["triplane", "triline"]}
+
+
+def uses_fused_geometric(conf):
+    """True when `geometric_network_with_grad` runs as fused chains that produce d(sdf)/dx themselves (no autograd
+    graph needed for a forward-only render)."""
+    g = conf.geometric_network
+    return bool(USE_FUSED and g.geometric_init and g.act == "softplus" and g.voxel.type in _FUSED_GRIDS and not g.voxel.use_ste)
+
+
 def geometric_network_with_grad(x, conf):
     """`sdf, feature, gain = geometric_network(x, conf); grad_x = nn.grad([sdf], [x])[0]`
     (python/renderer.py:51-52) as one operator.  Dense-voxel / no-grid configurations with the
@@ -164,9 +175,8 @@ def geometric_network_with_grad(x, conf):
     (ndjir_amd/geometric.py); other configurations run layer by layer through autograd."""
     g = conf.geometric_network
     v = g.voxel
-    fused_grids = {"none": [], "voxel": ["voxel"], "triplane": ["triplane"], "triline": ["triline"],
-                   "triplaneline": ["triplane", "triline"]}
-    if USE_FUSED and g.geometric_init and g.act == "softplus" and v.type in fused_grids and not v.use_ste:
+    fused_grids = _FUSED_GRIDS
+    if uses_fused_geometric(conf):
         from .geometric import geometric_main
         _ensure_geometric_params(x, conf)
         Ws, bs, skip_at, scale = _geometric_param_lists(conf)

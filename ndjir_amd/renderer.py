@@ -48,7 +48,7 @@ def make_rand(B, R, conf, device, n_fg=None, include_samples=True):
     return out
 
 
-def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, conf, rand):
+def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, conf, rand, render_only=False):
     """renderer.py:32-209.
       x_fg (B,R,N,3) requires grad; t_fg (B,R,N+1,1); x_bg (B,R,Nb,4); t_bg (B,R,Nb+1,1);
       camloc (B,3); raydir (B,R,3); mask (B,R,1,1); cos_anneal_ratio (1,)."""
@@ -117,8 +117,13 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
         raw_rough = roughness_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
         raw_spec = specular_reflectance_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
         raw_photo, photo_gain = photogrammetric_light_network(x_fg, camloc, view_dir, feature_x_fg, grad_x_fg, conf, raw=True)
-        _, feature_ptb, _ = geometric_network(x_fg_ptb, conf, first_order_only=True)
-        raw_ptb = base_color_network(x_fg_ptb, feature_ptb, None, conf, raw=True)
+        if render_only:
+            # `render_image` evaluates `color_pixel` only: the reference's graph executor never runs the base-colour
+            # perturbation branch there (it feeds the prior term of the loss, python/loss.py:108-115)
+            raw_ptb = raw_bc
+        else:
+            _, feature_ptb, _ = geometric_network(x_fg_ptb, conf, first_order_only=True)
+            raw_ptb = base_color_network(x_fg_ptb, feature_ptb, None, conf, raw=True)
         remap = conf.specular_brdf.model == "filament" and conf.specular_brdf.remap
         V, aux, prior_partials = material_head(
             raw_bc, raw_ptb, raw_imp, raw_photo, photo_gain, raw_rough, raw_spec, remap, conf.diffuse_brdf.entangle,
@@ -204,8 +209,11 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
 
     # Base-colour perturbation (renderer.py:186-193)
     if not use_head:
-        _, feature_ptb, _ = geometric_network(x_fg_ptb, conf, first_order_only=True)
-        base_color_ptb = base_color_network(x_fg_ptb, feature_ptb, None, conf)
+        if render_only:
+            base_color_ptb = base_color
+        else:
+            _, feature_ptb, _ = geometric_network(x_fg_ptb, conf, first_order_only=True)
+            base_color_ptb = base_color_network(x_fg_ptb, feature_ptb, None, conf)
 
     return dict(prior_partials=prior_partials, color_pixel=color_pixel, sdf_x_fg=sdf_x_fg, grad_x_fg=grad_x_fg, alpha_fg=alpha_fg,
                 trans_fg=trans_fg, obj_mask_pred=obj_mask_pred, base_color=base_color,
@@ -213,9 +221,11 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
                 std_roughness=std_roughness, std_specular_reflectance=std_spec_refl)
 
 
-def render_image(pose, intrinsic, resolution, conf, device=None, progress=None):
+def render_image(pose, intrinsic, resolution, conf, device=None, progress=None, rank=0, world=1, reduce=True):
     """renderer.py:212-272: tiled forward render of one view.
-    pose (1,4,4), intrinsic (1,3,3) numpy; resolution (W, H).  Returns (1,3,H,W) in [0,1]."""
+    pose (1,4,4), intrinsic (1,3,3) numpy; resolution (W, H).  Returns (1,3,H,W) in [0,1].
+    world > 1: tiles go round-robin to the ranks (no data-path collective while rendering); `reduce` sums the
+    partial images over the ranks at the end (torch.distributed), otherwise the rank's partial image is returned."""
     device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     scale = 1.0 / 2 ** conf.valid.n_down_samples
     W, H = resolution
@@ -224,27 +234,38 @@ def render_image(pose, intrinsic, resolution, conf, device=None, progress=None):
     intrinsic = intrinsic.copy()
     for (i, j) in ((0, 0), (1, 1), (0, 2), (1, 2), (0, 1)):
         intrinsic[:, i, j] = intrinsic[:, i, j] * scale
-    xy = generate_all_pixels(W, H).reshape((1, H * W, 2))
     _, m = divmod(W * H, P)
     P = P - m   # renderer.py:237-241 (sic: makes P a divisor only in the reference's use cases)
 
+    # The reference builds every tile's rays on the host and copies each tile's colours back; here the camera lives on
+    # the device (float64 like the reference's numpy), rays come from the pixel index (ndjir_generate_raydir_camloc),
+    # the image is assembled on the device and copied once.  With the fused geometric pass the normals come out of
+    # the forward chains themselves, so no autograd graph is recorded.
+    import contextlib
+    from .helper import generate_raydir_camloc_device
+    from .network import uses_fused_geometric
     rand = make_rand(1, P, conf, device)
     cos_anneal_ratio = torch.ones(1, device=device)
-    rimage = np.zeros([1, H * W, 3])
-    for p in range(0, H * W, P):
-        xy_b = xy[:, p:p + P, :]
-        n = xy_b.shape[1]
-        if n < P:  # last partial tile: pad (the reference assumes divisibility)
-            xy_b = np.concatenate([xy_b, np.repeat(xy_b[:, -1:, :], P - n, axis=1)], axis=1)
-        raydir_np, camloc_np = generate_raydir_camloc(pose, intrinsic, xy_b)
-        raydir = torch.from_numpy(raydir_np.astype(np.float32)).to(device)
-        camloc = torch.from_numpy(camloc_np.astype(np.float32)).to(device)
-        x_fg, t_fg, x_bg, t_bg, mask = sample_points(camloc, raydir, rand["stratified_sample"],
-                                                     rand["background_sample"], conf)
-        x_fg = x_fg.requires_grad_(True)
-        res = pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, conf, rand)
-        rimage[0, p:p + n, :] = res["color_pixel"].detach().reshape(P, 3)[:n].cpu().numpy()
+    pose_d = torch.from_numpy(np.ascontiguousarray(pose, dtype=np.float64)).to(device)
+    K_d = torch.from_numpy(np.ascontiguousarray(intrinsic, dtype=np.float64)).to(device)
+    image = torch.zeros((H * W, 3), device=device)
+    guard = torch.no_grad() if uses_fused_geometric(conf) else contextlib.nullcontext()
+    for p in range(rank * P, H * W, world * P):
+        n = min(P, H * W - p)
+        idx = torch.arange(p, p + P, device=device, dtype=torch.int32).clamp_(max=H * W - 1).reshape(1, P)   # last tile: padded
+        raydir, camloc = generate_raydir_camloc_device(pose_d, K_d, pixel_index=idx, width=W)
+        with guard:
+            x_fg, t_fg, x_bg, t_bg, mask = sample_points(camloc, raydir, rand["stratified_sample"],
+                                                         rand["background_sample"], conf)
+            if not isinstance(guard, torch.no_grad):
+                x_fg = x_fg.requires_grad_(True)
+            res = pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, conf, rand, render_only=True)
+        image[p:p + n] = res["color_pixel"].detach().reshape(P, 3)[:n]
         if progress is not None:
             progress(p, H * W)
+    if world > 1 and reduce:
+        import torch.distributed as dist
+        dist.all_reduce(image)
+    rimage = image.cpu().numpy().astype(np.float64).reshape((1, H * W, 3))
     rimage = rimage.reshape((1, H, W, 3)).transpose((0, 3, 1, 2))
     return np.clip(rimage, 0.0, 1.0)

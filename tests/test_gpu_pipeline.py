@@ -81,6 +81,9 @@ def test_render_image_tiles(gpu):
     K = np.array([[[20.0, 0, 8], [0, 20.0, 6], [0, 0, 1]]])
     img = render_image(pose, K, (16, 12), conf, device=gpu)
     assert img.shape == (1, 3, 12, 16) and np.isfinite(img).all() and img.min() >= 0 and img.max() <= 1
+    # tiles shard round-robin over ranks: the partial images of a 3-way shard add up to the frame
+    parts = [render_image(pose, K, (16, 12), conf, device=gpu, rank=r, world=3, reduce=False) for r in range(3)]
+    np.testing.assert_array_equal(parts[0] + parts[1] + parts[2], img)
 
 
 def test_bench_step_graph_replay_matches_eager(gpu):
