@@ -417,6 +417,13 @@ int ndjir_solver_adam_begin(void* state, float beta1, float beta2, const int* fl
                             hipStream_t stream);
 int ndjir_solver_adam(long long n, float* w, float* g, float* m, float* v, float alpha_t, float beta1, float beta2,
                       float eps, float decay, int zero_grad, const void* state, hipStream_t stream);
+/* Sparse-gradient variant for the voxel grid (zero_grad implied): `touched` holds one bit per float4 of g, set where g
+ * may be non-zero (ndjir_voxel_feature_mark_touched with the step's query points); g is read and cleared only there
+ * (24 instead of 32 bytes per parameter) and the bitmap comes back all zero.  n % 128 == 0. */
+int ndjir_solver_adam_touched(long long n, float* w, float* g, float* m, float* v, float alpha_t, float beta1, float beta2,
+                              float eps, float decay, unsigned* touched, const void* state, hipStream_t stream);
+int ndjir_voxel_feature_mark_touched(int N, const float* query, const int* grid_sizes, int D, const float* min,
+                                     const float* max, unsigned* bitmap, hipStream_t stream);
 /* the same over `count` small tensors given as host arrays of device pointers; g[k] null = zero gradient */
 int ndjir_solver_adam_multi(int count, float* const* w, const float* const* g, float* const* m, float* const* v,
                             const long long* numel, float alpha_t, float beta1, float beta2, float eps, float decay,

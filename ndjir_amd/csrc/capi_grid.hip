@@ -148,6 +148,14 @@ extern "C" int ndjir_voxel_feature_zero_touched(int N, float* gf, const float* q
   return launch_zero_touched(LINEAR, voxel_desc(gs, D, mn, mx), N, gf, query, nullptr, st);
 }
 
+// bitmap |= the cells (one bit per cell, D = 4) the N query points touch -- input of ndjir_solver_adam_touched
+extern "C" int ndjir_voxel_feature_mark_touched(int N, const float* query, const int* gs, int D, const float* mn, const float* mx,
+                                                unsigned* bitmap, hipStream_t st) {
+  if (N <= 0) return NDJIR_OK;
+  CHECK_PTRS(query, bitmap);
+  return launch_mark_touched(voxel_desc(gs, D, mn, mx), N, query, bitmap, st);
+}
+
 // Sparse gradient exchange: append the non-zero rows of the cells the N query points touch (each cell once).
 extern "C" int ndjir_voxel_feature_pack_rows(int N, const float* gf, const float* query, const int* gs, int D, const float* mn,
                                              const float* mx, unsigned* bitmap, int* ids, float* rows, int* count, int capacity,

@@ -459,6 +459,20 @@ __global__ void __launch_bounds__(256) k_zero_touched(long long P, float* __rest
 // each cell once -- a persistent bitmap (1 bit per cell) marks the cells already listed.  `count` keeps counting past
 // `capacity` (the caller sees the overflow and repeats with a larger list).
 // ------------------------------------------------------------------------------------------------
+// one bit per cell (D = 4: per float4 of the gradient buffer) for every cell the query points touch
+__global__ void __launch_bounds__(256) k_mark_touched(long long P, const float* __restrict__ query, GridDesc g,
+                                                      unsigned* __restrict__ bitmap) {
+  constexpr int TOPO = VOXEL, I = LINEAR;
+  constexpr int ND = 3, NT = 2;
+  NDJIR_GRID_THREAD_PROLOGUE
+  NDJIR_FOR_TAPS(ND, NT) {
+    const unsigned cell = (unsigned)(cell_offset(st, i, j, k) >> 2);
+    const unsigned bit = 1u << (cell & 31);
+    if (!(bitmap[cell >> 5] & bit)) atomicOr(bitmap + (cell >> 5), bit);
+  }
+  NDJIR_GRID_THREAD_EPILOGUE
+}
+
 __global__ void __launch_bounds__(256) k_pack_rows(long long P, const float* __restrict__ gf, const float* __restrict__ query,
                                                    GridDesc g, unsigned* __restrict__ bitmap, int* __restrict__ ids,
                                                    float4* __restrict__ rows, int* __restrict__ count, int capacity) {
@@ -756,6 +770,13 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
     if (mode == 0) hipLaunchKernelGGL((k_scatter<TOPO, I, VW, 0>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
     else hipLaunchKernelGGL((k_scatter<TOPO, I, VW, 1>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
   }))
+  return ndjir_check_launch();
+}
+
+int launch_mark_touched(const GridDesc& g, long long P, const float* query, unsigned* bitmap, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  if (g.topo != VOXEL || g.D != 4) return NDJIR_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_mark_touched, dim3(grid_blocks(P * g.S)), dim3(256), 0, stream, P, query, g, bitmap);
   return ndjir_check_launch();
 }
 

@@ -66,17 +66,33 @@ __global__ void k_adam_begin(AdamState* __restrict__ st, float beta1, float beta
   st->alpha_t = (float)a;
 }
 
-template <int UNROLL, bool ZERO>
+// BM: `touched` holds one bit per float4 of g (set for every float4 that may be non-zero): g is read -- and, with ZERO,
+// cleared -- only there (the loss gradient of a voxel grid lives in < 1 % of the cells; everywhere else the step is the
+// decay-only update), and the words consumed are cleared for the next step: 24 instead of 32 bytes per parameter.
+// The 32 float4s of a bitmap word belong to 32 consecutive lanes of one wave, which all read the word before lane 0
+// of the group clears it.
+template <int UNROLL, bool ZERO, bool BM>
 __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ w, f4* __restrict__ g, f4* __restrict__ m,
-                                              f4* __restrict__ v, AdamHyper h, const AdamState* __restrict__ st) {
+                                              f4* __restrict__ v, AdamHyper h, const AdamState* __restrict__ st,
+                                              unsigned* __restrict__ touched) {
   long long base = ((long long)blockIdx.x * UNROLL) * 256 + threadIdx.x;
+  unsigned bits[UNROLL];
+  if (BM) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      long long i = base + (long long)u * 256;
+      bits[u] = (i < n4) ? touched[i >> 5] : 0u;
+    }
+  }
+  auto hit = [&](int u, long long i) { return !BM || ((bits[u] >> (i & 31)) & 1u); };
   if (st) {
     if (st->skipped) {            // vetoed step: parameters and moments stay, the gradient buffer is still re-armed
-      if (ZERO) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-          long long i = base + (long long)u * 256;
-          if (i < n4) __builtin_nontemporal_store(f4{0.f, 0.f, 0.f, 0.f}, g + i);
+      for (int u = 0; u < UNROLL; ++u) {
+        long long i = base + (long long)u * 256;
+        if (i < n4) {
+          if (ZERO && hit(u, i)) __builtin_nontemporal_store(f4{0.f, 0.f, 0.f, 0.f}, g + i);
+          if (BM && (i & 31) == 0 && bits[u]) touched[i >> 5] = 0u;
         }
       }
       return;
@@ -89,7 +105,7 @@ __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ w, 
     long long i = base + (long long)u * 256;
     if (i < n4) {
       W[u] = __builtin_nontemporal_load(w + i);
-      G[u] = __builtin_nontemporal_load(g + i);
+      G[u] = hit(u, i) ? __builtin_nontemporal_load(g + i) : f4{0.f, 0.f, 0.f, 0.f};
       M[u] = __builtin_nontemporal_load(m + i);
       V[u] = __builtin_nontemporal_load(v + i);
     }
@@ -107,7 +123,8 @@ __global__ void __launch_bounds__(256) k_adam(long long n4, f4* __restrict__ w, 
       __builtin_nontemporal_store(W[u], w + i);
       __builtin_nontemporal_store(M[u], m + i);
       __builtin_nontemporal_store(V[u], v + i);
-      if (ZERO) __builtin_nontemporal_store(f4{0.f, 0.f, 0.f, 0.f}, g + i);
+      if (ZERO && hit(u, i)) __builtin_nontemporal_store(f4{0.f, 0.f, 0.f, 0.f}, g + i);
+      if (BM && (i & 31) == 0 && bits[u]) touched[i >> 5] = 0u;
     }
   }
 }
@@ -264,14 +281,32 @@ extern "C" int ndjir_solver_adam(long long n, float* w, float* g, float* m, floa
     long long blocks = (n4 + 256 * U - 1) / (256 * U);
     if (blocks > 0x7fffffffLL) return NDJIR_ERR_ARG;
     if (zero_grad)
-      hipLaunchKernelGGL((k_adam<U, true>), dim3((unsigned)blocks), dim3(256), 0, stream, n4, (f4*)w, (f4*)g, (f4*)m, (f4*)v, h, st);
+      hipLaunchKernelGGL((k_adam<U, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, n4, (f4*)w, (f4*)g, (f4*)m, (f4*)v, h, st, nullptr);
     else
-      hipLaunchKernelGGL((k_adam<U, false>), dim3((unsigned)blocks), dim3(256), 0, stream, n4, (f4*)w, (f4*)g, (f4*)m, (f4*)v, h, st);
+      hipLaunchKernelGGL((k_adam<U, false, false>), dim3((unsigned)blocks), dim3(256), 0, stream, n4, (f4*)w, (f4*)g, (f4*)m, (f4*)v, h, st, nullptr);
   }
   if (n4 * 4 < n) {
     if (zero_grad) hipLaunchKernelGGL((k_adam_tail<true>), dim3(1), dim3(256), 0, stream, n4 * 4, n, w, g, m, v, h, st);
     else hipLaunchKernelGGL((k_adam_tail<false>), dim3(1), dim3(256), 0, stream, n4 * 4, n, w, g, m, v, h, st);
   }
+  return ndjir_check_launch();
+}
+
+// As ndjir_solver_adam with zero_grad = 1, for a gradient that is non-zero only where `touched` (1 bit per float4 of g, n / 4
+// bits rounded up to whole 32-bit words; n % 128 == 0) says so: g is read and cleared only there and the bitmap comes back zero.
+extern "C" int ndjir_solver_adam_touched(long long n, float* w, float* g, float* m, float* v, float alpha_t, float beta1,
+                                         float beta2, float eps, float decay, unsigned* touched, const void* state,
+                                         hipStream_t stream) {
+  if (n <= 0) return NDJIR_OK;
+  if (!w || !g || !m || !v || !touched || (n & 127)) return NDJIR_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+       reinterpret_cast<uintptr_t>(v)) & 15) return NDJIR_ERR_ARG;
+  AdamHyper h = hyper(alpha_t, beta1, beta2, eps, decay);
+  constexpr int U = 4;
+  long long n4 = n / 4, blocks = (n4 + 256 * U - 1) / (256 * U);
+  if (blocks > 0x7fffffffLL) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL((k_adam<U, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, n4, (f4*)w, (f4*)g, (f4*)m, (f4*)v, h,
+                     (const AdamState*)state, touched);
   return ndjir_check_launch();
 }
 

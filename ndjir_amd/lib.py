@@ -74,6 +74,8 @@ SIGS = {
     # n w g m v alpha_t beta1 beta2 eps decay zero_grad state
     "solver_adam": "lppppfffffix",
     "solver_adam_multi": "iPPPPLfffffx",
+    "solver_adam_touched": "lppppfffffqx",
+    "voxel_feature_mark_touched": "ipIiFFq",
     "solver_check_inf_or_nan": "lpq",
     "solver_check_inf_or_nan_multi": "iPLq",
     "solver_sum_squares": "lpx",

@@ -39,6 +39,7 @@ class Adam:
         self.flag = None             # device int: the guard found an inf / nan
         self._decay = 0.0
         self._touched = {}           # name -> list of query tensors whose cells hold this step's grid gradient
+        self._bitmaps = {}           # name -> touched-cell bitmap of a voxel grid (all zero between updates)
         self._grads = None
 
     # -- nnabla API ------------------------------------------------------------------------------------------------
@@ -140,7 +141,18 @@ class Adam:
         for i, (k, p) in enumerate(zip(self.names, self.params)):
             g, is_buf = self._grad_of(k, p)
             decay = self._decay * (scales[i] if scales else 1.0)
-            if g is not None and (is_buf or p.numel() >= (1 << 20)) and p.numel() % 4 == 0:
+            if g is not None and is_buf and k in self._touched and p.dim() == 4 and p.shape[-1] == 4 and p.numel() % 128 == 0:
+                # voxel grid whose gradient lives in the cells this step's samples touched: mark them, then the update
+                # reads / clears g only there
+                bm = self._bitmaps.get(k)
+                if bm is None:
+                    bm = self._bitmaps[k] = torch.zeros(p.numel() // 128, dtype=torch.int32, device=p.device)
+                for q in self._touched[k]:
+                    q = q.detach().reshape(-1, 3).contiguous()
+                    lib.call("voxel_feature_mark_touched", q.shape[0], q, list(p.shape[:3]), 4, [-1, -1, -1], [1, 1, 1], bm)
+                lib.call("solver_adam_touched", p.numel(), p.detach(), g, self.m[i], self.v[i], 0.0, self.beta1, self.beta2,
+                         self.eps, decay, bm, self.state)
+            elif g is not None and (is_buf or p.numel() >= (1 << 20)) and p.numel() % 4 == 0:
                 lib.call("solver_adam", p.numel(), p.detach(), g, self.m[i], self.v[i], 0.0, self.beta1, self.beta2,
                          self.eps, decay, 1 if is_buf else 0, self.state)
             else:

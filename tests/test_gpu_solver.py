@@ -221,3 +221,38 @@ def test_solvers_against_oracle(gpu):
     finally:
         set_grad_buffer(F, None)
         P.clear_parameters()
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_adam_touched_bitmap_equals_dense(gpu, skip):
+    """ndjir_solver_adam_touched + ndjir_voxel_feature_mark_touched: reading g only in the marked cells gives the dense
+    kernel's result bit for bit (the gradient is zero elsewhere), g and the bitmap come back zero; a vetoed step leaves w, m, v."""
+    G, D, P = 32, 4, 2000
+    gen = torch.Generator(device=gpu).manual_seed(9)
+    q = (torch.rand(P, 3, device=gpu, generator=gen) * 2.2 - 1.1).contiguous()          # some points outside the box
+    go = torch.randn(P, D, device=gpu, generator=gen)
+    g = torch.zeros(G, G, G, D, device=gpu)
+    lib.call("voxel_feature_grad_feature", P * D, g, go, q, [G] * 3, D, [-1] * 3, [1] * 3, 0, 1)
+    w0 = torch.randn(G, G, G, D, device=gpu, generator=gen) * 1e-3
+    m0, v0 = torch.rand_like(w0) * 1e-3, torch.rand_like(w0) * 1e-6
+    n = w0.numel()
+    flag = torch.tensor([1 if skip else 0], dtype=torch.int32, device=gpu)
+    res = []
+    for mode in ("dense", "touched"):
+        w, gg, m, v = w0.clone(), g.clone(), m0.clone(), v0.clone()
+        st = _state(gpu, 5e-4)
+        lib.call("solver_adam_begin", st, 0.9, 0.999, flag, None)
+        if mode == "dense":
+            lib.call("solver_adam", n, w, gg, m, v, 0.0, 0.9, 0.999, 1e-8, 1e-3, 1, st)
+        else:
+            bm = torch.zeros(n // 128, dtype=torch.int32, device=gpu)
+            lib.call("voxel_feature_mark_touched", P, q, [G] * 3, D, [-1] * 3, [1] * 3, bm)
+            marked = int(sum(bin(x & 0xffffffff).count("1") for x in bm.cpu().tolist()))
+            assert marked >= int((g != 0).any(-1).sum()) > 0
+            lib.call("solver_adam_touched", n, w, gg, m, v, 0.0, 0.9, 0.999, 1e-8, 1e-3, bm, st)
+            assert int(bm.abs().sum()) == 0
+        assert float(gg.abs().max()) == 0.0
+        res.append((w, m, v))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][0], w0) == skip
