@@ -118,7 +118,7 @@ def allreduce_voxel_rows_hip(buf, queries, min_=(-1.0, -1.0, -1.0), max_=(1.0, 1
                      st["rows"], st["count"], st["cap"])
         lib.call("sparse_rows_clear_bitmap", st["ids"], st["count"], st["cap"], st["bitmap"])
         counts = torch.empty(world, dtype=torch.int32, device=buf.device)
-        dist.all_gather(list(counts.unbind(0)), st["count"].reshape(()), group=group)
+        dist.all_gather(list(counts.view(world, 1).unbind(0)), st["count"], group=group)
         host = counts.tolist()                                # the exchange's one host synchronisation
         if max(host) <= st["cap"]:
             break
