@@ -62,8 +62,14 @@ def apply_overrides(conf, overrides):
 
 
 def load(name="default", overrides=None):
-    with open(os.path.join(_HERE, "default.yaml")) as f:
-        conf = _wrap(yaml.safe_load(f))
+    from .defaults import DEFAULTS
+    conf = Conf()
+    for key, val in DEFAULTS.items():
+        node = conf
+        parts = key.split(".")
+        for p in parts[:-1]:
+            node = node.setdefault(p, Conf())
+        node[parts[-1]] = copy.deepcopy(val)
     apply_overrides(conf, _VARIANTS[name])
     apply_overrides(conf, overrides)
     return conf
