@@ -73,6 +73,9 @@ class Step:
         from ndjir_amd.synthetic import make_rays
 
         self.conf, self.device, self.rank, self.world = conf, device, rank, world
+        # distributed code path: N > 1, or forced on one rank (NDJIR_BENCH_FORCE_DIST: a 1-rank RCCL group, to exercise
+        # graph capture / replay around real RCCL calls on a single-GPU box)
+        self.multi = world > 1 or bool(os.environ.get("NDJIR_BENCH_FORCE_DIST"))
         self.R = R
         P.clear_parameters()
         P.set_device(device)
@@ -117,7 +120,7 @@ class Step:
             handle = self.remote_rows.get(name)
             if isinstance(handle, SparseRows):
                 handle.zero(buf)
-            elif v.type == "voxel" and self.touched is not None and (self.world == 1 or handle is not None):
+            elif v.type == "voxel" and self.touched is not None and (not self.multi or handle is not None):
                 x_fg = self.touched
                 r = self.conf.renderer.bounding_sphere_radius
                 zero_touched(buf, x_fg)
@@ -130,7 +133,7 @@ class Step:
     def pre_exchange(self):
         """N > 1: global sum of the ray masks (a scalar all-reduce; the mask depends on the rays only) and the
         clearing of the grid rows that the previous exchange deposited on behalf of the other ranks."""
-        if self.world == 1:
+        if not self.multi:
             return
         import torch.distributed as dist
         from ndjir_amd.sampler import SamplePoints
@@ -149,7 +152,7 @@ class Step:
         if rearm:
             self.rearm_grid_buffers()
         out = total_loss(self.camloc, self.raydir, self.color_gt, None, self.car, self.conf, self.rand,
-                         ray_shards=self.world, mask_sum_global=self.mask_sum if self.world > 1 else None)
+                         ray_shards=self.world, mask_sum_global=self.mask_sum if self.multi else None)
         loss = out["loss"]
         if self.mlp_names is None:
             params = [p for p in self.P.get_parameters(grad_only=True).values()]
@@ -164,7 +167,7 @@ class Step:
             else:
                 self.touched.copy_(self.x_fg)
         self.grads = grads               # the step's product: every parameter gradient, materialised
-        if self.world > 1:
+        if self.multi:
             # pack the MLP gradients into one flat bucket for the all-reduce (one batched copy, not one launch per tensor)
             if self._zeros is None:
                 self._zeros = [torch.zeros(p.numel(), device=self.device) for p in self.mlp_params]
@@ -174,7 +177,7 @@ class Step:
     def exchange(self):
         """N > 1: one gradient exchange.  total_loss already normalised by the GLOBAL ray / mask counts, so the
         per-rank gradients just add up: MLP = one flat 5.9 MB bucket; voxel grid = touched cells only."""
-        if self.world == 1 or self.mlp_names is None:
+        if not self.multi or self.mlp_names is None:
             return
         import math
         from ndjir_amd.distributed import allreduce_step_gradients
@@ -219,7 +222,7 @@ class Step:
         s.weight_decay()
         s.clip_grad_by_norm()
         loss = self.compute(rearm=False)
-        if self.world == 1:
+        if not self.multi:
             self.optimizer_step()
         return loss
 
@@ -230,7 +233,7 @@ class Step:
     def set_solver_gradients(self):
         import math
         s = self.solvers
-        if self.world > 1:       # the exchange left the summed MLP gradients in the flat bucket
+        if self.multi:       # the exchange left the summed MLP gradients in the flat bucket
             grads, off = {}, 0
             for name, p in zip(self.mlp_names, self.mlp_params):
                 grads[name] = self.flat_grad[off:off + p.numel()].view(p.shape)
@@ -247,11 +250,11 @@ class Step:
         s.set_gradients(grads, touched)
 
     def train_step(self):
-        if self.world > 1:
+        if self.multi:
             rows, self.remote_rows = self.remote_rows, {}      # the update kernel cleared them with the rest of the buffer
             self.pre_exchange()
         loss = self.train_compute()
-        if self.world > 1:
+        if self.multi:
             self.exchange()
             self.optimizer_step()
         return loss
@@ -287,7 +290,7 @@ def cpu_baseline(conf, step, n_rays):
 
 def _all_ranks_ok(step, ok):
     """Logical AND of a per-rank flag (every rank must take the same branch: the step holds collectives)."""
-    if step.world == 1:
+    if not step.multi:
         return ok
     t = torch.tensor([1.0 if ok else 0.0], device=step.device)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
@@ -299,7 +302,7 @@ def capture_step(step):
     gradient packing -- all custom launches are stream-ordered and allocation-stable, no collective inside)
     into a HIP graph.  Returns (graph, loss tensor of the captured step) or raises; on N > 1 every rank
     raises if any rank failed, after completing the same sequence of collectives."""
-    multi = step.world > 1
+    multi = step.multi
     g = torch.cuda.CUDAGraph()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -340,8 +343,8 @@ def replay_step(step, graph):
         return
     step.pre_exchange()
     graph.replay()
-    if step.world > 1:
-        torch.cuda.current_stream().synchronize()   # the exchange consumes the replayed step's results
+    if step.multi and torch.distributed.get_backend() != "nccl":
+        torch.cuda.current_stream().synchronize()   # gloo stages through the host: it must see the replayed step's results
     step.exchange()
 
 
@@ -354,7 +357,7 @@ def train_leg(step, steps, barrier, use_graph):
         step.train_step()
     torch.cuda.synchronize()
     mode, err, graph = "eager stream launches", None, None
-    if use_graph and step.world == 1:
+    if use_graph and not step.multi:
         try:
             mlp._PACK_CACHE.clear()          # the weights change every step: their re-packing must be part of the graph
             g = torch.cuda.CUDAGraph()
@@ -381,7 +384,7 @@ def train_leg(step, steps, barrier, use_graph):
     step.solvers.zero_grad()
     step.solvers.weight_decay()
     step.set_solver_gradients()
-    sparse = step.world == 1 and step.conf.geometric_network.voxel.type == "voxel"
+    sparse = not step.multi and step.conf.geometric_network.voxel.type == "voxel"
     reps = 5
     e0.record()
     for _ in range(reps):
@@ -445,9 +448,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("NDJIR_BENCH_SAME_DEVICE"):
         local_rank = 0      # debugging aid: several ranks on ONE GPU over gloo, to exercise the N > 1 code path
-    if world > 1:
+    force_dist = world == 1 and bool(os.environ.get("NDJIR_BENCH_FORCE_DIST"))
+    if world > 1 or force_dist:
         import torch.distributed as dist
-        if os.environ.get("NDJIR_BENCH_SAME_DEVICE"):
+        if force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29555")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        elif os.environ.get("NDJIR_BENCH_SAME_DEVICE"):
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -467,15 +475,28 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # default: graph replay on one GPU; eager launches on N > 1 (graph replay between RCCL collectives works in the
-    # single-device gloo harness only with explicit synchronisation and could not be validated on a multi-GPU node:
-    # opt in with --exec graph)
-    exec_mode = a.exec_mode or os.environ.get("NDJIR_BENCH_EXEC") or ("graph" if world == 1 else "eager")
+    # default: graph replay of the compute part; on N > 1 the collectives are issued eagerly around every replay
+    # (validated against RCCL with a 1-rank group, NDJIR_BENCH_FORCE_DIST=1: 12.9 ms/step vs 15.9 ms eager -- the
+    # exchange's host synchronisation serialises the eager step's launch time with the GPU's).  Safety nets below:
+    # capture failure, loss mismatch or a replay that is not faster than eager launches all fall back to eager.
+    exec_mode = a.exec_mode or os.environ.get("NDJIR_BENCH_EXEC") or "graph"
+    if step.multi and os.environ.get("NDJIR_BENCH_SAME_DEVICE") and not (a.exec_mode or os.environ.get("NDJIR_BENCH_EXEC")):
+        exec_mode = "eager"          # several processes replaying graphs on ONE GPU time-slice badly (debug harness only)
     for _ in range(a.warmup):
         step.forward_backward()
     eager = None
     graph_error = None
     profile_steps = a.steps
+
+    def timed(fn, n=2):
+        barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        return time.perf_counter() - t
+    # eager reference time taken BEFORE anything is captured (N > 1: what the replay has to beat)
+    t_eager_pre = timed(step.forward_backward) if (exec_mode == "graph" and step.multi) else None
     if exec_mode == "graph":
         try:
             graph, loss = capture_step(step)          # untimed, like the warm-up
@@ -485,15 +506,8 @@ def main():
             torch.cuda.synchronize()
         if exec_mode == "graph":
             # ... and never a pessimisation: two untimed steps each way, keep replaying only if it is not slower
-            def timed(fn, n=2):
-                barrier()
-                t = time.perf_counter()
-                for _ in range(n):
-                    fn()
-                barrier()
-                return time.perf_counter() - t
             t_graph = timed(lambda: replay_step(step, graph))
-            t_eager = timed(step.forward_backward)
+            t_eager = t_eager_pre if t_eager_pre is not None else timed(step.forward_backward)
             if not _all_ranks_ok(step, t_graph <= 1.05 * t_eager):
                 graph_error = f"replay not faster than eager launches ({1e3 * t_graph / 2:.1f} vs {1e3 * t_eager / 2:.1f} ms/step)"
                 exec_mode = "eager"
@@ -612,10 +626,18 @@ def main():
             tl["scope"] = ("fwd+bwd + weight decay + finite-gradient guard + Adam update of every parameter "
                            "(python/train.py:136-148); reported beside the headline metric, not as it")
             out["train_step"] = tl
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would otherwise land
+        # after this line at exit: flush it first so that the JSON line is the last thing on stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
