@@ -7,6 +7,7 @@ import subprocess
 import sys
 import tempfile
 
+import numpy as np
 import pytest
 import torch
 
@@ -46,3 +47,26 @@ def test_two_ranks_equal_one_process(gpu):
         for p in step.grid_params:
             set_grad_buffer(p, None)
         P.clear_parameters()
+
+
+@pytest.mark.timeout(1800)          # a cold box pages torch and librccl in once per process: minutes, not seconds
+def test_bench_graph_replay_around_rccl_calls(gpu):
+    """bench.py's N > 1 execution scheme against the real collective library: a 1-rank RCCL group forces the distributed
+    code path (mask all-reduce, gradient bucket, sparse grid exchange) with the compute part replayed from a HIP graph.
+    The JSON line must be the last line on stdout (RCCL's banner goes through C stdio) and report graph execution."""
+    import json
+    env = dict(os.environ, NDJIR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rays", "64", "--override", "geometric_network.voxel.grid_size=64",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--train-steps", "2"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    assert d["execution"].startswith("one captured HIP graph"), (d["execution"], d.get("graph_capture_error"))
+    assert d["n_gpus"] == 1 and np.isfinite(d["loss"]) and d["value"] > 0
+    assert np.isfinite(d["train_step"]["loss_after"])
+    # the same step without the process group gives the same loss
+    res2 = subprocess.run(cmd, env={k: v for k, v in env.items() if k != "NDJIR_BENCH_FORCE_DIST"}, cwd=ROOT, capture_output=True,
+                          text=True, timeout=800)
+    assert res2.returncode == 0, res2.stderr[-3000:]
+    d2 = json.loads(res2.stdout.strip().splitlines()[-1])
+    assert d["loss"] == pytest.approx(d2["loss"], rel=1e-6)
