@@ -412,6 +412,26 @@ def train_leg(step, steps, barrier, use_graph):
     return out
 
 
+def committed_pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_hbm_bench.txt: FETCH_SIZE and WRITE_SIZE in KB per launch, collected in separate runs as
+    MI355X_MICROARCH.md prescribes; FETCH doubled per its gfx950 note).  Not a live measurement: None if the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_bench.txt")
+    try:
+        vals, section = {}, None
+        lines = open(path).read().splitlines()
+        for i, line in enumerate(lines):
+            if line.startswith("## "):
+                section = line[3:].strip()
+            elif section and line.startswith(kernel + "  launches=") and i + 1 < len(lines):
+                vals[section] = float(lines[i + 1].split()[-1])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        pass
+    return None
+
+
 def kernel_report(profile):
     """Aggregate the live HIP-event records of the MLP engine (ndjir_amd.mlp.PROFILE)."""
     agg = {}
@@ -586,7 +606,11 @@ def main():
                                    f"total_loss fwd+bwd to all parameter gradients",
                        "rays_per_gpu": R, "samples_per_ray": N, "parallelism": f"ray-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": dom["tflops"] / peak, "traffic": None,
+                         "frac": dom["tflops"] / peak,
+                         "traffic": committed_pmc_traffic(f"ndjir::x6::k_chain6<0, {tile}>") if x6 else None,
+                         "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes "
+                                         "of this command, profiles/r01_pmc_hbm_bench.txt -- mostly the stored activations; the kernel is "
+                                         "MFMA-bound, its algorithmic measure is FLOPs",
                          "kernel": kname, "peak_note": peak_note,
                          "launches_per_step": dom["launches"] / max(profile_steps, 1), "avg_launch_us": dom["avg_us"],
                          "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
