@@ -80,3 +80,41 @@ def set_parameters(d):
 
 def clear_parameters():
     _params.clear()
+
+
+def save_parameters(path):
+    """`nn.save_parameters` counterpart (python/train.py:101): every registered parameter under its nnabla scope name,
+    with its `need_grad` flag.  Container: numpy `.npz` (the reference writes HDF5 through nnabla/h5py, neither of which
+    exists here; the names and array layouts are nnabla's, so a one-line h5py loop converts either way)."""
+    if not str(path).endswith(".npz"):
+        raise ValueError("parameters are stored as .npz here (HDF5 needs h5py, which this environment lacks)")
+    arrays = {}
+    for k, v in _params.items():
+        arrays[k] = v.detach().cpu().numpy()
+        arrays["__need_grad__/" + k] = np.asarray(bool(v.requires_grad))
+    np.savez(path, **arrays)
+
+
+def load_parameters(path, device=None):
+    """`nn.load_parameters` counterpart (python/render_image.py:43, python/extract_by_mc.py:300): installs the stored
+    tensors in the registry (existing entries are overwritten in place when shapes agree, so optimizer state and
+    gradient buffers keyed by the tensor stay valid)."""
+    if not str(path).endswith(".npz"):
+        raise ValueError("parameters are stored as .npz here (HDF5 needs h5py, which this environment lacks)")
+    dev = torch.device(device) if device is not None else get_device()
+    with np.load(path) as z:
+        for k in z.files:
+            if k.startswith("__need_grad__/"):
+                continue
+            a = np.ascontiguousarray(z[k], dtype=np.float32)
+            need = bool(z["__need_grad__/" + k]) if ("__need_grad__/" + k) in z.files else True
+            cur = _params.get(k)
+            if cur is not None and tuple(cur.shape) == a.shape:
+                with torch.no_grad():
+                    cur.copy_(torch.from_numpy(a))
+                torch.autograd.graph.increment_version(cur) if cur.is_cuda else None
+                cur.requires_grad_(need)
+            else:
+                t = torch.from_numpy(a).to(dev)
+                t.requires_grad_(need)
+                _params[k] = t

@@ -113,3 +113,35 @@ def test_host_ray_generation_against_reference_golden():
     np.testing.assert_allclose(raydir, g["raydir"], rtol=0, atol=1e-15)
     np.testing.assert_array_equal(camloc, g["camloc"])
     np.testing.assert_array_equal(generate_all_pixels(int(g["W"]), int(g["H"])), g["all_pixels"])
+
+
+def test_parameter_file_round_trip(tmp_path):
+    """save_parameters / load_parameters (python/train.py:101, python/render_image.py:43): names, values, need_grad."""
+    from ndjir_amd import parameter as P
+    P.clear_parameters()
+    P.set_device("cpu")
+    rng = np.random.RandomState(0)
+    with P.parameter_scope("geometric-network"):
+        with P.parameter_scope("affine-00"), P.parameter_scope("affine"):
+            w = P.get_parameter_or_create("W", (5, 7), rng.randn(5, 7))
+        g = P.get_parameter_or_create("gain", (1,), np.asarray([0.3]), True)
+    fixed = P.get_parameter_or_create("cos_anneal_ratio", (1,), np.asarray([0.25]), False)
+    path = str(tmp_path / "model_00010.npz")
+    P.save_parameters(path)
+    want = {k: v.detach().clone() for k, v in P.get_parameters().items()}
+    need = {k: v.requires_grad for k, v in P.get_parameters().items()}
+    with torch.no_grad():
+        w.zero_()
+    P.load_parameters(path)                       # in place: the same tensor objects come back filled
+    assert P.get_parameters()["geometric-network/affine-00/affine/W"] is w and torch.equal(w, want["geometric-network/affine-00/affine/W"])
+    P.clear_parameters()
+    P.load_parameters(path, device="cpu")
+    got = P.get_parameters()
+    assert list(got) == list(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]) and got[k].requires_grad == need[k], k
+    assert not got["cos_anneal_ratio"].requires_grad
+    with pytest.raises(ValueError):
+        P.save_parameters(str(tmp_path / "model.h5"))
+    P.clear_parameters()
+    P.set_device(None)
