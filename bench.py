@@ -15,12 +15,12 @@ sum of the algorithmic FLOPs (2*in*out per affine per point) of its l
 their durations, measured live with HIP events recorded on the launching stream around every launch
 inside the timed region.  In the default bf16x6 arithmetic one algorithmic FLOP costs six bf16 MFMA
 FLOPs, so the peak it is priced against is the dense bf16 MFMA peak / 6.
-Execution: on one GPU the compute part of the step (no collective inside) is captured once into a HIP
-graph and the timed region replays it (`--exec graph`; no host-side launch work in the timed region);
-HIP events cannot be recorded inside a captured graph, so `roofline` / `kernels` come from the same K
-steps issued eagerly right after (`eager` reports their wall time).  `--exec eager` (default for N > 1)
-times ordinary stream launches.  If the capture fails, or replaying is not faster than eager launches
-in a short untimed trial, the run falls back to eager.
+Execution: the compute part of the step (ndjir_amd/step.py `Step.compute`: no collective inside) is captured once
+into a HIP graph and the timed region replays it (`--exec graph`, default; no host-side launch work in the timed
+region; N > 1: the scalar mask all-reduce and the gradient exchange are issued eagerly around every replay).  HIP events
+cannot be recorded inside a captured graph, so `roofline` / `kernels` come from the same K steps issued eagerly right
+after (`eager` reports their wall time).  `--exec eager` times ordinary stream launches.  If the capture fails on any
+rank, or replaying is not faster than eager launches in a short untimed trial, the run falls back to eager.
 """
 import argparse
 import json
@@ -52,9 +52,9 @@ def parse():
     ap.add_argument("--override", action="append", default=[])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exec", dest="exec_mode", choices=["graph", "eager"], default=None,
-                    help="how the timed steps are issued: 'graph' (default on 1 GPU) = the compute part of the step is captured "
-                         "once into a HIP graph and the timed region replays it (N > 1: the gradient exchange is issued "
-                         "eagerly between replays); 'eager' (default on N > 1) = ordinary stream launches.  Falls back to "
+                    help="how the timed steps are issued: 'graph' (default) = the compute part of the step is captured "
+                         "once into a HIP graph and the timed region replays it (N > 1: the collectives are issued "
+                         "eagerly around every replay); 'eager' = ordinary stream launches.  Falls back to "
                          "eager if the capture fails on any rank or replaying is not faster.")
     ap.add_argument("--cpu-rays", type=int, default=32)
     ap.add_argument("--train-steps", type=int, default=10,
@@ -63,201 +63,7 @@ def parse():
     return ap.parse_args()
 
 
-class Step:
-    """Owns parameters, gradient buffers and the synthetic inputs of one rank."""
-
-    def __init__(self, conf, R, device, rank, world):
-        from ndjir_amd import network, parameter as P
-        from ndjir_amd.grid_feature import set_grad_buffer
-        from ndjir_amd.renderer import make_rand
-        from ndjir_amd.synthetic import make_rays
-
-        self.conf, self.device, self.rank, self.world = conf, device, rank, world
-        # distributed code path: N > 1, or forced on one rank (NDJIR_BENCH_FORCE_DIST: a 1-rank RCCL group, to exercise
-        # graph capture / replay around real RCCL calls on a single-GPU box)
-        self.multi = world > 1 or bool(os.environ.get("NDJIR_BENCH_FORCE_DIST"))
-        self.R = R
-        P.clear_parameters()
-        P.set_device(device)
-        network.seed(313)
-        B = 1
-        # every rank draws the full (world*R)-ray set and keeps its contiguous slice
-        self.camloc, self.raydir, self.color_gt = make_rays(B, R, seed=412, device=device, ray_offset=rank * R,
-                                                            total_rays=world * R)
-        full = make_rand(B, world * R, conf, "cpu")
-        self.rand = {k: v[:, rank * R:(rank + 1) * R].contiguous().to(device) for k, v in full.items()}
-        self.car = torch.ones(1, device=device)
-        self.P = P
-        self.grid_bufs = {}
-        self.touched = None      # query points whose cells hold gradient from the previous step
-        self.remote_rows = {}    # multi-GPU: grid rows received from the other ranks in the previous exchange
-        self.mask_sum = torch.zeros((), device=device)   # multi-GPU: all-reduced sum of the ray masks
-        self.x_fg = None
-        self.mlp_names = None
-        self._zeros = None
-        self.forward_backward()          # creates the parameters (untimed)
-        for name, p in P.get_parameters().items():
-            if name.endswith("feature/F"):
-                buf = torch.zeros_like(p)
-                set_grad_buffer(p, buf)
-                self.grid_bufs[name] = buf
-        params = P.get_parameters(grad_only=True)
-        self.mlp_names = [k for k in params if not k.endswith("feature/F")]
-        self.mlp_params = [params[k] for k in self.mlp_names]
-        self.grid_params = [p for k, p in P.get_parameters().items() if k.endswith("feature/F")]
-        self.flat_grad = torch.zeros(sum(p.numel() for p in self.mlp_params), device=device)
-
-    def rearm_grid_buffers(self):
-        """Zero the accumulate-in-place grid gradient buffers.  Linear dense voxel grid: only the cells that hold
-        gradient (512^3 x 4 floats = 2 GiB would otherwise be rewritten every step) -- one GPU: the cells the previous
-        step's query points touched; N > 1: the rows the previous exchange listed (own and received).  Anything
-        else: dense."""
-        import math
-        from ndjir_amd.distributed import SparseRows
-        from ndjir_amd.grid_feature import zero_touched
-        v = self.conf.geometric_network.voxel
-        for name, buf in self.grid_bufs.items():
-            handle = self.remote_rows.get(name)
-            if isinstance(handle, SparseRows):
-                handle.zero(buf)
-            elif v.type == "voxel" and self.touched is not None and (not self.multi or handle is not None):
-                x_fg = self.touched
-                r = self.conf.renderer.bounding_sphere_radius
-                zero_touched(buf, x_fg)
-                zero_touched(buf, x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size))
-            else:
-                buf.zero_()
-
-    # One step = pre_exchange (N > 1 only) -> compute -> exchange (N > 1 only).  `compute` holds no collective
-    # and no data-dependent shapes: it is what bench.py captures into a HIP graph.
-    def pre_exchange(self):
-        """N > 1: global sum of the ray masks (a scalar all-reduce; the mask depends on the rays only) and the
-        clearing of the grid rows that the previous exchange deposited on behalf of the other ranks."""
-        if not self.multi:
-            return
-        import torch.distributed as dist
-        from ndjir_amd.sampler import SamplePoints
-        for name, rows in self.remote_rows.items():
-            if torch.is_tensor(rows):          # generic torch path of the exchange (the HIP path re-arms in `compute`)
-                buf = self.grid_bufs[name]
-                buf.view(-1, buf.shape[-1]).index_fill_(0, rows, 0.0)
-        with torch.no_grad():
-            _, _, mask = SamplePoints(self.conf).t_near_far(self.camloc, self.raydir)
-            ms = mask.sum().reshape(())
-        dist.all_reduce(ms)
-        self.mask_sum.copy_(ms)
-
-    def compute(self, rearm=True):
-        from ndjir_amd.loss import total_loss
-        if rearm:
-            self.rearm_grid_buffers()
-        out = total_loss(self.camloc, self.raydir, self.color_gt, None, self.car, self.conf, self.rand,
-                         ray_shards=self.world, mask_sum_global=self.mask_sum if self.multi else None)
-        loss = out["loss"]
-        if self.mlp_names is None:
-            params = [p for p in self.P.get_parameters(grad_only=True).values()]
-            torch.autograd.grad(loss, params, allow_unused=True)
-            return loss.detach()
-        grads = torch.autograd.grad(loss, self.mlp_params + self.grid_params, allow_unused=True)
-        self.x_fg = out["samples"]["x_fg"].detach()
-        if self.grid_bufs:
-            # a persistent buffer (not the step's own tensor): a captured graph must find it at the same address
-            if self.touched is None:
-                self.touched = self.x_fg.clone()
-            else:
-                self.touched.copy_(self.x_fg)
-        self.grads = grads               # the step's product: every parameter gradient, materialised
-        if self.multi:
-            # pack the MLP gradients into one flat bucket for the all-reduce (one batched copy, not one launch per tensor)
-            if self._zeros is None:
-                self._zeros = [torch.zeros(p.numel(), device=self.device) for p in self.mlp_params]
-            torch.cat([g.reshape(-1) if g is not None else z for g, z in zip(grads, self._zeros)], out=self.flat_grad)
-        return loss.detach()
-
-    def exchange(self):
-        """N > 1: one gradient exchange.  total_loss already normalised by the GLOBAL ray / mask counts, so the
-        per-rank gradients just add up: MLP = one flat 5.9 MB bucket; voxel grid = touched cells only."""
-        if not self.multi or self.mlp_names is None:
-            return
-        import math
-        from ndjir_amd.distributed import allreduce_step_gradients
-        x_fg = self.x_fg
-        v = self.conf.geometric_network.voxel
-        queries = {}
-        if v.type.endswith("voxel"):
-            r = self.conf.renderer.bounding_sphere_radius
-            x_ptb = x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size)
-            queries["geometric-network/voxel_feature/F"] = ([x_fg, x_ptb], [v.grid_size] * 3)
-        self.remote_rows = allreduce_step_gradients(self.flat_grad, self.grid_bufs, queries)
-
-    def forward_backward(self):
-        self.pre_exchange()
-        loss = self.compute()
-        self.exchange()
-        return loss
-
-    # ---- the reference's training iteration (python/train.py:136-148): forward_backward + the optimizer step ----------
-    def enable_training(self, epoch_index=None):
-        """Two Adam solvers over the step's parameters (ndjir_amd.solver.Solvers = python/solver.py).  From here on the
-        grid gradient buffers are re-armed by the update kernel itself."""
-        import copy
-        from ndjir_amd.solver import Solvers
-        conf = copy.deepcopy(self.conf)
-        conf.train.batch_size, conf.train.n_rays = 1, self.R * self.world      # learning rates scale with B R / 512
-        self.solvers = Solvers(conf)
-        self.solvers.set_parameters()
-        t = conf.train
-        self.solvers.update_learning_rate(int(t.epoch * t.warmup_term_ratio) if epoch_index is None else epoch_index)
-        self.rearm_grid_buffers()
-        for name, rows in self.remote_rows.items():
-            if torch.is_tensor(rows):
-                buf = self.grid_bufs[name]
-                buf.view(-1, buf.shape[-1]).index_fill_(0, rows, 0.0)
-        self.remote_rows = {}
-
-    def train_compute(self):
-        """Everything of a training iteration that holds no collective (one GPU: the whole iteration)."""
-        s = self.solvers
-        s.zero_grad()
-        s.weight_decay()
-        s.clip_grad_by_norm()
-        loss = self.compute(rearm=False)
-        if not self.multi:
-            self.optimizer_step()
-        return loss
-
-    def optimizer_step(self):
-        self.set_solver_gradients()
-        self.solvers.guarded_update()
-
-    def set_solver_gradients(self):
-        import math
-        s = self.solvers
-        if self.multi:       # the exchange left the summed MLP gradients in the flat bucket
-            grads, off = {}, 0
-            for name, p in zip(self.mlp_names, self.mlp_params):
-                grads[name] = self.flat_grad[off:off + p.numel()].view(p.shape)
-                off += p.numel()
-            touched = None       # rows of other ranks' rays are not covered by this rank's samples: dense guard
-        else:
-            grads = dict(zip(self.mlp_names, self.grads))
-            v = self.conf.geometric_network.voxel
-            touched = None
-            if v.type == "voxel" and self.x_fg is not None:
-                r = self.conf.renderer.bounding_sphere_radius
-                touched = {"geometric-network/voxel_feature/F":
-                           [self.x_fg, self.x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size)]}
-        s.set_gradients(grads, touched)
-
-    def train_step(self):
-        if self.multi:
-            rows, self.remote_rows = self.remote_rows, {}      # the update kernel cleared them with the rest of the buffer
-            self.pre_exchange()
-        loss = self.train_compute()
-        if self.multi:
-            self.exchange()
-            self.optimizer_step()
-        return loss
+from ndjir_amd.step import Step  # noqa: E402,F401  (the step itself lives in the package; bench.py only times it)
 
 
 def cpu_baseline(conf, step, n_rays):
