@@ -71,8 +71,10 @@ def allreduce_sparse_rows(buf, cell_ids, group=None, return_remote=False):
 
 
 class SparseRows:
-    """What one HIP-path exchange leaves behind for a buffer: every rank's packed cell ids (world, cap) and counts
-    (world) -- the rows that now hold gradient in the local dense buffer.  `zero(buf)` clears exactly those."""
+    """What the HIP-path exchange keeps for a buffer: every rank's packed cell ids (world, cap) and counts (world) --
+    the rows that hold gradient in the local dense buffer after the exchange.  `zero(buf)` clears exactly those.
+    The tensors are allocated once per buffer (worst-case capacity) and rewritten by every exchange, so a HIP graph
+    that captured `zero` keeps reading the current lists."""
 
     def __init__(self, ids, counts, world, cap):
         self.ids, self.counts, self.world, self.cap = ids, counts, world, cap
@@ -85,17 +87,21 @@ class SparseRows:
 _STATE = {}
 
 
-def _state(buf, capacity):
+def _state(buf, capacity, world):
     st = _STATE.get(buf.data_ptr())
     cells = buf.numel() // buf.shape[-1]
-    if st is None or st["cells"] != cells:
-        st = dict(cells=cells, bitmap=torch.zeros((cells + 31) // 32, dtype=torch.int32, device=buf.device), cap=0,
-                  count=torch.zeros(1, dtype=torch.int32, device=buf.device))
+    if st is None or st["cells"] != cells or st["cap"] < capacity or st["world"] != world:
+        dev, D = buf.device, buf.shape[-1]
+        st = dict(cells=cells, cap=capacity, world=world,
+                  bitmap=torch.zeros((cells + 31) // 32, dtype=torch.int32, device=dev),
+                  count=torch.zeros(1, dtype=torch.int32, device=dev),
+                  ids=torch.empty(capacity, dtype=torch.int32, device=dev),
+                  rows=torch.empty((capacity, D), dtype=torch.float32, device=dev),
+                  ids_all=torch.zeros((world, capacity), dtype=torch.int32, device=dev),
+                  rows_all=torch.empty((world, capacity, D), dtype=torch.float32, device=dev),
+                  counts_all=torch.zeros(world, dtype=torch.int32, device=dev))
+        st["handle"] = SparseRows(st["ids_all"], st["counts_all"], world, capacity)
         _STATE[buf.data_ptr()] = st
-    if st["cap"] < capacity:
-        st["cap"] = capacity
-        st["ids"] = torch.empty(capacity, dtype=torch.int32, device=buf.device)
-        st["rows"] = torch.empty((capacity, buf.shape[-1]), dtype=torch.float32, device=buf.device)
     return st
 
 
@@ -104,36 +110,30 @@ def allreduce_voxel_rows_hip(buf, queries, min_=(-1.0, -1.0, -1.0), max_=(1.0, 1
     `k_pack_rows`, csrc/sparse_rows.hip): the non-zero rows of the cells this rank's query points touched are packed
     once each on the device (bitmap dedup), all-gathered with the common size max_r(count_r) -- the one host
     synchronisation of the exchange is reading those counts -- and the other ranks' rows are added in place.
-    Returns a `SparseRows` handle (for re-arming the buffer before the next step)."""
+    List capacity = the worst case (8 corners of every point distinct): lists never grow, their addresses never change.
+    Returns the buffer's `SparseRows` handle (for re-arming the buffer before the next step)."""
     from . import lib
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     G, D = list(buf.shape[:3]), buf.shape[-1]
-    need = sum(q.numel() // 3 for q in queries) * 8          # upper bound: every corner of every point distinct
-    st = _state(buf, min(need, 1 << 18))
-    while True:
-        st["count"].zero_()
-        for q in queries:
-            q = q.detach().reshape(-1, 3).contiguous()
-            lib.call("voxel_feature_pack_rows", q.shape[0], buf, q, G, D, list(min_), list(max_), st["bitmap"], st["ids"],
-                     st["rows"], st["count"], st["cap"])
-        lib.call("sparse_rows_clear_bitmap", st["ids"], st["count"], st["cap"], st["bitmap"])
-        counts = torch.empty(world, dtype=torch.int32, device=buf.device)
-        dist.all_gather(list(counts.view(world, 1).unbind(0)), st["count"], group=group)
-        host = counts.tolist()                                # the exchange's one host synchronisation
-        if max(host) <= st["cap"]:
-            break
-        # some rank's list overflowed (every rank sees it): grow everywhere and pack again (the dedup bitmap of a
-        # rank that overflowed still holds the unlisted cells -> clear it densely; rare)
-        st["bitmap"].zero_()
-        st = _state(buf, min(need, 2 * max(host)))
-    m = max(4096, -(-max(host) // 4096) * 4096)
-    m = min(m, st["cap"])
-    ids = torch.empty((world, m), dtype=torch.int32, device=buf.device)
-    rows = torch.empty((world, m, D), dtype=torch.float32, device=buf.device)
-    dist.all_gather(list(ids.unbind(0)), st["ids"][:m], group=group)
-    dist.all_gather(list(rows.unbind(0)), st["rows"][:m], group=group)
-    lib.call("sparse_rows_apply", ids, rows, counts, world, m, rank, buf, D)
-    return SparseRows(ids, counts, world, m)
+    cap = sum(q.numel() // 3 for q in queries) * 8
+    st = _state(buf, cap, world)
+    cap = st["cap"]
+    st["count"].zero_()
+    for q in queries:
+        q = q.detach().reshape(-1, 3).contiguous()
+        lib.call("voxel_feature_pack_rows", q.shape[0], buf, q, G, D, list(min_), list(max_), st["bitmap"], st["ids"],
+                 st["rows"], st["count"], cap)
+    lib.call("sparse_rows_clear_bitmap", st["ids"], st["count"], cap, st["bitmap"])
+    counts = st["counts_all"]
+    dist.all_gather(list(counts.view(world, 1).unbind(0)), st["count"], group=group)
+    host = counts.tolist()                                # the exchange's one host synchronisation
+    assert max(host) <= cap, "more distinct cells than point corners"
+    m = min(cap, max(4096, -(-max(host) // 4096) * 4096))  # rows actually communicated (same on every rank)
+    ids, rows = st["ids_all"], st["rows_all"]
+    dist.all_gather([ids[r, :m] for r in range(world)], st["ids"][:m], group=group)
+    dist.all_gather([rows[r, :m] for r in range(world)], st["rows"][:m], group=group)
+    lib.call("sparse_rows_apply", ids, rows, counts, world, cap, rank, buf, D)
+    return st["handle"]
 
 
 def allreduce_step_gradients(flat_mlp_grad, grid_bufs, grid_queries, group=None):

@@ -1,6 +1,8 @@
 """Worker of tests/test_gpu_multirank.py: one rank of a ray-sharded step (all ranks share GPU 0 over gloo -- the only
 multi-rank set-up a single-GPU box offers; the product path under test is the same one RCCL drives on a real node).
-usage (under torch.distributed.run): python tests/multi_rank_worker.py <outdir> <rays_per_rank> <grid> <steps>"""
+usage (under torch.distributed.run): python tests/multi_rank_worker.py <outdir> <rays_per_rank> <grid> <steps> [graph]
+`graph`: after the eager steps, capture the compute part into a HIP graph (bench.capture_step) and replay it `steps` more times
+with the collectives issued eagerly around each replay -- the execution scheme bench.py uses."""
 import os
 import sys
 
@@ -22,6 +24,12 @@ def main():
     losses = []
     for _ in range(steps):
         losses.append(float(step.forward_backward()))
+    if len(sys.argv) > 5 and sys.argv[5] == "graph":
+        graph, loss_t = bench.capture_step(step)
+        for _ in range(steps):
+            bench.replay_step(step, graph)
+        torch.cuda.synchronize()
+        losses.append(float(loss_t))
     torch.cuda.synchronize()
     torch.save(dict(losses=losses, flat=step.flat_grad.cpu(), grid={k: v.cpu() for k, v in step.grid_bufs.items()},
                     handle={k: type(v).__name__ for k, v in step.remote_rows.items()}), os.path.join(out, f"rank{rank}.pt"))

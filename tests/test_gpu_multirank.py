@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_equal_one_process(gpu):
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_two_ranks_equal_one_process(gpu, mode):
     import bench
     from ndjir_amd import config as cfg, parameter as P
     from ndjir_amd.grid_feature import set_grad_buffer
@@ -24,7 +25,8 @@ def test_two_ranks_equal_one_process(gpu):
     with tempfile.TemporaryDirectory() as out:
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", "29533", os.path.join(ROOT, "tests", "multi_rank_worker.py"), out, str(R), str(G), str(steps)]
+               "--master-port", "29533", os.path.join(ROOT, "tests", "multi_rank_worker.py"), out, str(R), str(G), str(steps)] + \
+            (["graph"] if mode == "graph" else [])
         res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
         assert res.returncode == 0, res.stderr[-3000:]
         ranks = [torch.load(os.path.join(out, f"rank{r}.pt")) for r in range(2)]
