@@ -418,6 +418,9 @@ def main():
                                          "of this command, profiles/r01_pmc_hbm_bench.txt -- mostly the stored activations; the kernel is "
                                          "MFMA-bound, its algorithmic measure is FLOPs",
                          "kernel": kname, "peak_note": peak_note,
+                         # the same algorithmic fp32 FLOP/s against the fp32-input MFMA peak (what an fp32 GEMM engine could
+                         # reach at best on this chip): the bf16x6 engine exists to get past it
+                         "frac_of_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
                          "launches_per_step": dom["launches"] / max(profile_steps, 1), "avg_launch_us": dom["avg_us"],
                          "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
                          "method": ("HIP events on the launching stream around every launch of the same K steps issued "
