@@ -430,9 +430,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain6(ChainArgs a) {
             if (last) {
               if (mrow) {
                 float* y = a.Y + grow * a.ldy + n4;
-                if (vec_ok && (a.ldy & 3) == 0 && !a.accum_y) {
+                if (vec_ok && (a.ldy & 3) == 0 && ((uintptr_t)a.Y & 15) == 0) {
                   f32x4 t = z;
                   if (MODE == 0) t += bias4;
+                  if (a.accum_y) t += *reinterpret_cast<const f32x4*>(y);
                   *reinterpret_cast<f32x4*>(y) = t;
                 } else {
 #pragma unroll

@@ -288,3 +288,95 @@ def fused_mlp(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, row
     scaled input is appended (python/network.py:221-224).  row_bias (..., N_0): term added to the first
     layer's pre-activation, constant over each group of `row_bias_div` consecutive rows of x."""
     return FusedMLP.apply(x, row_bias, row_bias_div, beta, skip_layer, skip_scale, *weights, *biases)
+
+
+class MultiMLP(Function):
+    """Several softplus-MLPs on ONE shared input (no skip connection): forward = one chain per net on the same x;
+    backward = one chain per net ACCUMULATING into a single dL/dx, so autograd sees one consumer of x instead of one
+    per net (no per-net input concatenation, no gradient additions).  The per-sample material nets of the reference
+    all take cat(x, feature, normal) (python/network.py:235-263, 300-336, 427-509).
+    apply(x, beta, layer_counts, *W_net0, *b_net0, *W_net1, *b_net1, ...) -> one output per net."""
+
+    @staticmethod
+    def forward(ctx, x, beta, layer_counts, *params):
+        x2 = x.detach().reshape(-1, x.shape[-1]).contiguous()
+        train = any(ctx.needs_input_grad)
+        nets, off = [], 0
+        for L in layer_counts:
+            nets.append((list(params[off:off + L]), list(params[off + L:off + 2 * L])))
+            off += 2 * L
+        ys, saved = [], [x2]
+        for W, b in nets:
+            y, hidden = chain_forward(x2, W, b, beta, -1, 1.0, keep_hidden=train)
+            ys.append(y.view(x.shape[:-1] + (y.shape[-1],)))
+            if train:
+                saved += hidden + W
+        if train:
+            ctx.save_for_backward(*saved)
+            ctx.cfg = (float(beta), tuple(layer_counts), tuple(x.shape))
+        return tuple(ys)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gys):
+        beta, layer_counts, xshape = ctx.cfg
+        saved = ctx.saved_tensors
+        x2 = saved[0]
+        P, K0 = x2.shape
+        dev = x2.device
+        need_x = ctx.needs_input_grad[0]
+        ldg = (K0 + 3) // 4 * 4
+        gx = torch.empty((P, ldg), device=dev, dtype=torch.float32)[:, :K0] if need_x else None
+        grads, pos, poff, first = [], 1, 3, True
+        for n, L in enumerate(layer_counts):
+            A = [x2] + list(saved[pos:pos + L - 1])
+            W = list(saved[pos + L - 1:pos + 2 * L - 1])
+            pos += 2 * L - 1
+            gy = gys[n]
+            nW = ctx.needs_input_grad[poff:poff + L]
+            nb = ctx.needs_input_grad[poff + L:poff + 2 * L]
+            poff += 2 * L
+            if gy is None:
+                grads += [None] * (2 * L)
+                continue
+            gy2 = gy.reshape(P, -1).contiguous()
+            steps = L if need_x else L - 1
+            deltas, bgrads = [None] * L, [None] * L
+            deltas[L - 1] = gy2
+            gb_last = None
+            if steps > 0:
+                Wp, Ks, Ns, side_in, side_out, ld_side, bg = [], [], [], [], [], [], []
+                for i in range(steps):
+                    j = L - 1 - i
+                    Wp.append(_packed(W[j], True))
+                    Ks.append(W[j].shape[1])
+                    Ns.append(W[j].shape[0])
+                    if i < L - 1:
+                        width = W[j - 1].shape[1]
+                        deltas[j - 1] = torch.empty((P, width), device=dev, dtype=torch.float32)
+                        bgrads[j - 1] = torch.empty((width,), device=dev, dtype=torch.float32)
+                        side_in.append(A[j]); side_out.append(deltas[j - 1]); ld_side.append(A[j].shape[1]); bg.append(bgrads[j - 1])
+                    else:
+                        side_in.append(None); side_out.append(None); ld_side.append(0); bg.append(None)
+                if any(nW) and nb[L - 1]:
+                    gb_last = torch.empty((gy2.shape[1],), device=dev, dtype=torch.float32)
+                flops = 2.0 * P * sum(k * m for k, m in zip(Ks, Ns))
+                _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
+                        side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
+                        0 if first else 1, 1 if need_x else 0, float(beta), -1, 1.0, 0, None, K0, gb_last,
+                        chain_workspace(dev, bg + [gb_last]), shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)) + ("" if first else " (+=)"))
+                first = False
+            gW = [wgrad(A[j], deltas[j]) if nW[j] else None for j in range(L)]
+            gb = [(bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))) if nb[j] else None for j in range(L)]
+            grads += gW + gb
+        if need_x and first:
+            gx = None
+        return (gx.reshape(xshape) if gx is not None else None, None, None, *grads)
+
+
+def multi_mlp(x, nets, beta=100.0):
+    """nets: list of (weights, biases).  Returns one output per net (see MultiMLP)."""
+    flat = []
+    for W, b in nets:
+        flat += list(W) + list(b)
+    return MultiMLP.apply(x, float(beta), tuple(len(W) for W, _ in nets), *flat)

@@ -12,6 +12,8 @@ device GEMMs (see DESIGN.md for the hand-written MFMA path that replaces them).
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as TF
@@ -330,6 +332,30 @@ def _mlp(h, D, L, Dout, act, use_wn, shift=0):
 def _cat_inputs(x, feature, normal, c):
     inputs = [x] + ([feature] if c.use_geometric_feature else []) + ([normal] if c.use_normal else [])
     return torch.cat(inputs, dim=-1) if len(inputs) > 1 else x
+
+
+def material_nets_raw(x, feature, normal, conf):
+    """The four per-sample material nets that share the input cat(x, feature, normal) -- implicit illumination
+    (network.py:300-336), base colour (:235-263), roughness (:427-464), specular reflectance (:467-509) -- evaluated
+    as one operator on one concatenation (ndjir_amd.mlp.MultiMLP): their raw (pre-activation) outputs, in that order.
+    Returns None when the configuration does not allow it (different inputs, activations or weight normalisation);
+    parameters are created in the order the separate calls create them."""
+    cs = [conf.implicit_illumination_network, conf.base_color_network, conf.roughness_network, conf.specular_reflectance_network]
+    same = all(c.use_geometric_feature == cs[0].use_geometric_feature and c.use_normal == cs[0].use_normal and c.act == "softplus"
+               for c in cs)
+    if not (USE_FUSED and same and not conf.use_wn and cs[0].use_me and not cs[3].fixme) or os.environ.get("NDJIR_NO_MULTI_MLP"):
+        return None
+    from .mlp import multi_mlp
+    inp = _cat_inputs(x, feature, normal, cs[0])
+    Din = inp.shape[-1]
+    nets = []
+    for scope, c, Dout, shift in (("implicit-illumination-network", cs[0], cs[0].channels, 0),
+                                  ("base-color-network", cs[1], 3, 0),
+                                  ("roughness-network", cs[2], 2, 1),
+                                  ("specular-reflectance-network", cs[3], cs[3].channels * 2, 1)):
+        with P.parameter_scope(scope):
+            nets.append(_mlp_params(Din, c.feature_size, c.layers, Dout, conf.use_wn, shift))
+    return multi_mlp(inp, nets)
 
 
 def base_color_network(x, feature, normal, conf, raw=False):

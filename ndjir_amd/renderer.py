@@ -16,7 +16,7 @@ import torch
 from . import parameter as P
 from .grid_feature import grad as nn_grad
 from .helper import generate_all_pixels, generate_raydir_camloc
-from .network import (background_network, base_color_network, environment_light_network, geometric_network,
+from .network import (background_network, base_color_network, material_nets_raw, environment_light_network, geometric_network,
                       geometric_network_with_grad,
                       implicit_illumination_network, photogrammetric_light_network, roughness_network,
                       soft_visibility_light_network, specular_reflectance_network)
@@ -112,10 +112,14 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     x_fg_ptb = x_fg + rand["noise"] * (math.sqrt(3) * 2 * rad / G)
     prior_partials = None
     if use_head:
-        raw_imp = implicit_illumination_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
-        raw_bc = base_color_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
-        raw_rough = roughness_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
-        raw_spec = specular_reflectance_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
+        raws = material_nets_raw(x_fg, feature_x_fg, grad_x_fg, conf)
+        if raws is not None:
+            raw_imp, raw_bc, raw_rough, raw_spec = raws
+        else:
+            raw_imp = implicit_illumination_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
+            raw_bc = base_color_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
+            raw_rough = roughness_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
+            raw_spec = specular_reflectance_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
         raw_photo, photo_gain = photogrammetric_light_network(x_fg, camloc, view_dir, feature_x_fg, grad_x_fg, conf, raw=True)
         if render_only:
             # `render_image` evaluates `color_pixel` only: the reference's graph executor never runs the base-colour
