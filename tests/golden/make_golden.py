@@ -18,6 +18,8 @@ Sources:
   python/sampler/test_sampler.py:23-70, 72-111
   python/helper.py:44-81 (generate_raydir_camloc, generate_all_pixels: pure numpy, no reference test -- inputs made here)
   python/solver.py:82-98 (Solvers.compute_learning_rate: pure numpy method), config/default.yaml:125-135 (its inputs)
+  python/dataset.py:33-108 (IDRDataSource._get_data, _generate_patch_rays, _generate_mask_rays: pure numpy methods; the
+      three pixel-sampling modes of the training feed) on a synthetic image set
 """
 import ast
 import os
@@ -100,6 +102,41 @@ def golden_schedule():
         out[f"c{k}_lr"] = np.asarray([clr(me, int(i), lr0) for i in idx], np.float64)
     out["n_cases"] = np.int64(len(cases))
     np.savez(os.path.join(OUT, "solver_schedule.npz"), **out)
+
+
+def golden_pixel_sampling():
+    """python/dataset.py:33-108: which pixels a training batch reads, in the three modes (uniform, patch, mask ratio)."""
+    get_data, patch, maskr = extract_methods(f"{REF}/dataset.py", "IDRDataSource",
+                                             ["_get_data", "_generate_patch_rays", "_generate_mask_rays"])
+
+    class NS:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+    M, H, W, R = 3, 24, 40, 64
+    rng0 = np.random.RandomState(7)
+    images = rng0.rand(M, H, W, 3).astype(np.float32)
+    masks = (rng0.rand(M, H, W, 1) > 0.6) * 1.0
+    intr = rng0.rand(M, 3, 3)
+    poses = rng0.rand(M, 4, 4).astype(np.float32)
+    xx, yy = np.meshgrid(np.arange(W), np.arange(H))
+    xy_all = np.asarray([xx.flatten(), yy.flatten()]).T
+    out = dict(images=images, masks=masks, M=np.int64(M), H=np.int64(H), W=np.int64(W), R=np.int64(R))
+    for mode, tr in (("uniform", dict(patch_ray_sampling=False, mask_ray_sample_ratio=0)),
+                     ("patch", dict(patch_ray_sampling=True, mask_ray_sample_ratio=0)),
+                     ("mask", dict(patch_ray_sampling=False, mask_ray_sample_ratio=0.25))):
+        me = NS(conf=NS(train=NS(n_rays=R, **tr)), rng=np.random.RandomState(313), _images=images, _masks=masks,
+                _intrinsics=intr, _intrinsics_inv=np.linalg.inv(intr), _poses=poses, _xy=xy_all, _H=H, _W=W,
+                _img_indices=np.arange(M))
+        me._generate_patch_rays = lambda im, mk, me=me: patch(me, im, mk)
+        me._generate_mask_rays = lambda im, mk, me=me: maskr(me, im, mk)
+        # reset() (:180-189): pixel indices of the epoch for every image, drawn first
+        me._pixel_idx = me.rng.randint(0, H * W, (M, R))
+        for pos in range(M):
+            color_p, mask_p, K, pose, xy = get_data(me, pos)
+            out[f"{mode}_{pos}_color"] = np.asarray(color_p, np.float32)
+            out[f"{mode}_{pos}_mask"] = np.asarray(mask_p, np.float64)
+            out[f"{mode}_{pos}_xy"] = np.asarray(xy, np.int64)
+    np.savez_compressed(os.path.join(OUT, "pixel_sampling.npz"), **out)
 
 
 def golden_aabb():
@@ -188,6 +225,7 @@ if __name__ == "__main__":
     golden_directions()
     golden_rays()
     golden_schedule()
+    golden_pixel_sampling()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")

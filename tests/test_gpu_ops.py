@@ -364,3 +364,31 @@ def test_sparse_row_exchange_kernels(gpu):
     x = qs[0][0].contiguous()
     lib.call("voxel_feature_pack_rows", x.shape[0], buf, x, [G] * 3, D, [-1] * 3, [1] * 3, bitmap, ids2, rows2, cnt, small)
     assert int(cnt) > small and bool((ids2[small:] == -7).all()) and bool((ids2[:small] >= 0).all())
+
+
+@pytest.mark.parametrize("mode", ["uniform", "patch", "mask"])
+def test_device_data_feed(gpu, mode):
+    """ndjir_amd.dataset.IDRRaySource on the GPU (scene resident on the device, rays generated there) delivers the golden
+    colours / masks of the reference's data source and rays equal to the reference's host computation."""
+    from ndjir_amd import config
+    from ndjir_amd.dataset import IDRRaySource
+    from ndjir_amd.helper import generate_raydir_camloc
+    g = np.load(os.path.join(GOLD, "pixel_sampling.npz"))
+    M, W, R = int(g["M"]), int(g["W"]), int(g["R"])
+    ov = {"uniform": [], "patch": ["train.patch_ray_sampling=true"], "mask": ["train.mask_ray_sample_ratio=0.25"]}[mode]
+    conf = config.load("default", [f"train.n_rays={R}", "train.patch_ray_sampling=false", "train.mask_ray_sample_ratio=0"] + ov)
+    gr = np.load(os.path.join(GOLD, "generate_raydir_camloc.npz"))
+    K, poses = gr["intrinsic"][:M], gr["pose"][:M]
+    src = IDRRaySource(g["images"], g["masks"], K, poses, conf, rng=np.random.RandomState(313), device=gpu)
+    color, mask, raydir, camloc = src.next_batch(M)
+    assert color.is_cuda and raydir.is_cuda
+    for pos in range(M):
+        np.testing.assert_array_equal(color[pos].cpu().numpy(), g[f"{mode}_{pos}_color"])
+        np.testing.assert_array_equal(mask[pos].cpu().numpy(), g[f"{mode}_{pos}_mask"].astype(np.float32))
+    xy = np.stack([g[f"{mode}_{pos}_xy"] for pos in range(M)])
+    rd, cl = generate_raydir_camloc(poses, K, xy)
+    assert np.abs(raydir.cpu().numpy() - rd.astype(np.float32)).max() <= 1.2e-7
+    np.testing.assert_array_equal(camloc.cpu().numpy(), cl.astype(np.float32))
+    # the epoch wraps: M more positions come from a fresh reset()
+    c2 = src.next_batch(M)[0]
+    assert c2.shape == color.shape
