@@ -61,6 +61,13 @@ class Step:
         self.grid_params = [p for k, p in P.get_parameters().items() if k.endswith("feature/F")]
         self.flat_grad = torch.zeros(sum(p.numel() for p in self.mlp_params), device=device)
 
+    def set_rays(self, camloc, raydir, color_gt):
+        """Feed the next iteration's rays (python/train.py:124-133: `raydir.d = ...`, `camloc.d = ...`, `color_gt.d = ...`)
+        into the step's persistent input tensors -- in place, so that a captured graph keeps reading them."""
+        self.camloc.copy_(camloc.reshape(self.camloc.shape))
+        self.raydir.copy_(raydir.reshape(self.raydir.shape))
+        self.color_gt.copy_(color_gt.reshape(self.color_gt.shape))
+
     def rearm_grid_buffers(self):
         """Zero the accumulate-in-place grid gradient buffers.  Linear dense voxel grid: only the cells that hold
         gradient (512^3 x 4 floats = 2 GiB would otherwise be rewritten every step) -- one GPU: the cells the previous

@@ -153,3 +153,50 @@ def test_step_edge_cases(gpu, case):
             continue
         assert a is not None and bool(torch.isfinite(a).all()), k
         assert rel_err(a, b) <= 5e-3, (k, rel_err(a, b))
+
+
+def test_training_iterations_on_the_device_data_feed(gpu):
+    """The pieces of the reference's training loop (python/train.py:124-148) end to end on the GPU: IDRRaySource batches
+    -> Step.set_rays -> forward + backward -> weight decay, guard and the two Adam solvers.  A uniformly coloured scene is
+    fitted: the RGB loss must fall and nothing may turn non-finite."""
+    from ndjir_amd import config as cfg, parameter as P
+    from ndjir_amd.dataset import IDRRaySource
+    from ndjir_amd.grid_feature import set_grad_buffer
+    from ndjir_amd.step import Step
+    R = 64
+    conf = cfg.load("default", ["geometric_network.voxel.grid_size=32", f"train.n_rays={R}", "train.batch_size=1"])
+    M, H, W = 4, 24, 32
+    rng = np.random.RandomState(3)
+    images = np.broadcast_to(np.array([0.8, 0.3, 0.1], np.float32), (M, H, W, 3)).copy()
+    masks = np.ones((M, H, W, 1))
+    poses = np.zeros((M, 4, 4))
+    Ks = np.zeros((M, 3, 3))
+    for m in range(M):
+        c = rng.randn(3)
+        c = 2.5 * c / np.linalg.norm(c)
+        fwd = -c / np.linalg.norm(c)
+        right = np.cross(fwd, rng.randn(3))
+        right /= np.linalg.norm(right)
+        poses[m, :3, 0], poses[m, :3, 1], poses[m, :3, 2], poses[m, :3, 3] = right, np.cross(fwd, right), fwd, c
+        poses[m, 3, 3] = 1
+        Ks[m] = [[1.5 * W, 0, W / 2], [0, 1.5 * W, H / 2], [0, 0, 1]]
+    src = IDRRaySource(images, masks, Ks, poses, conf, rng=np.random.RandomState(313), device=gpu)
+    step = Step(conf, R, gpu, 0, 1)
+    try:
+        step.enable_training()
+        first = last = None
+        for it in range(40):
+            color, mask, raydir, camloc = src.next_batch(1)
+            step.set_rays(camloc, raydir, color)
+            loss = float(step.train_step())
+            assert np.isfinite(loss), it
+            first = loss if first is None else first
+            last = loss
+        assert step.solvers.solver_feat.step_count() == 40 and not step.solvers.solver_feat.skipped()
+        assert last < 0.7 * first, (first, last)
+        for k, p in P.get_parameters().items():
+            assert bool(torch.isfinite(p).all()), k
+    finally:
+        for p in step.grid_params:
+            set_grad_buffer(p, None)
+        P.clear_parameters()
