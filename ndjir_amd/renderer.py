@@ -48,6 +48,20 @@ def make_rand(B, R, conf, device, n_fg=None, include_samples=True):
     return out
 
 
+def redraw_rand(rand, generator=None):
+    """Next iteration's random tensors, drawn in place on the device (the reference's `F.rand` / `F.randn` nodes produce
+    new numbers at every forward: python/loss.py:40-41, python/renderer.py:97-98, 131-132, 191).  In place, so that a
+    captured graph keeps reading the same tensors; call it between replays."""
+    for k, t in rand.items():
+        if k == "noise":
+            t.normal_(generator=generator)
+        elif k == "background_sample":
+            t.uniform_(1e-5, 1.0, generator=generator)
+        else:
+            t.uniform_(0.0, 1.0, generator=generator)
+    return rand
+
+
 def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, conf, rand, render_only=False):
     """renderer.py:32-209.
       x_fg (B,R,N,3) requires grad; t_fg (B,R,N+1,1); x_bg (B,R,Nb,4); t_bg (B,R,Nb+1,1);

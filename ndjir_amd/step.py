@@ -68,6 +68,11 @@ class Step:
         self.raydir.copy_(raydir.reshape(self.raydir.shape))
         self.color_gt.copy_(color_gt.reshape(self.color_gt.shape))
 
+    def redraw_rand(self, generator=None):
+        """New stratified / background / light-direction / perturbation samples for the next iteration (in place)."""
+        from .renderer import redraw_rand
+        redraw_rand(self.rand, generator)
+
     def rearm_grid_buffers(self):
         """Zero the accumulate-in-place grid gradient buffers.  Linear dense voxel grid: only the cells that hold
         gradient (512^3 x 4 floats = 2 GiB would otherwise be rewritten every step) -- one GPU: the cells the previous

@@ -188,6 +188,7 @@ def test_training_iterations_on_the_device_data_feed(gpu):
         for it in range(40):
             color, mask, raydir, camloc = src.next_batch(1)
             step.set_rays(camloc, raydir, color)
+            step.redraw_rand()
             loss = float(step.train_step())
             assert np.isfinite(loss), it
             first = loss if first is None else first
