@@ -38,6 +38,7 @@ class Adam:
         self.state = None            # device ndjir_adam_state {alpha, t, alpha_t, skipped} as 4 x int32/float32
         self.flag = None             # device int: the guard found an inf / nan
         self._decay = 0.0
+        self._decay_scales = None    # per-parameter factors from clip_grad_by_norm (None: no clipping)
         self._touched = {}           # name -> list of query tensors whose cells hold this step's grid gradient
         self._bitmaps = {}           # name -> touched-cell bitmap of a voxel grid (all zero between updates)
         self._grads = None
@@ -136,7 +137,7 @@ class Adam:
         are raised (python/solver.py:67-69); None = unconditional, as nnabla's `update()`."""
         fa, fb = guard_flags if guard_flags is not None else (None, None)
         lib.call("solver_adam_begin", self.state, self.beta1, self.beta2, fa, fb)
-        scales = getattr(self, "_decay_scales", None)
+        scales = self._decay_scales
         small = []
         for i, (k, p) in enumerate(zip(self.names, self.params)):
             g, is_buf = self._grad_of(k, p)
