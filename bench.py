@@ -423,6 +423,10 @@ def main():
                          "frac_of_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
                          "launches_per_step": dom["launches"] / max(profile_steps, 1), "avg_launch_us": dom["avg_us"],
                          "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
+                         "note": "64-point-tile launches only (small launches use the 32-point-tile instantiation, listed as "
+                                 "chain_fwd_t32 under `kernels`); an event interval spans the launch gap of the host-bound eager pass "
+                                 "as well as the kernel, ~5-7 % more than rocprofv3's kernel-only average in "
+                                 "profiles/r01_bench_kernel_summary.txt",
                          "method": ("HIP events on the launching stream around every launch of the same K steps issued "
                                     "eagerly right after the timed graph replays (events cannot be recorded inside a "
                                     "captured graph)") if exec_mode == "graph" else

@@ -9,7 +9,9 @@ keep nnabla's layout, W (in, out) and y = x W + b.
 Backward: one fused chain launch for the data path (delta of every layer + bias gradients + input
 gradient); weight gradients H^T delta by the split-P MFMA kernel of csrc/wgrad.hip.
 """
+import os
 import weakref
+
 
 import torch
 from torch.autograd import Function
@@ -48,6 +50,8 @@ def _launch(kind, flops, name, *args, shape=""):
     if PROFILE is None:
         lib.call(name, *args)
         return
+    if kind.startswith("chain") and not os.environ.get("NDJIR_MLP_TILE") and (int(args[1]) + 63) // 64 < 256:
+        kind += "_t32"            # small launch: the library picks 32-point tiles (a different kernel instantiation)
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
