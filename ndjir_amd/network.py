@@ -159,8 +159,14 @@ def query_on_grid(x, G, D, use_ste, type):
     return getattr(PF, f"{pre}query_on_{topo}")(x, G, D, use_ste=use_ste, f_init=f_init)
 
 
-_FUSED_GRIDS = {"none": [], "voxel": ["voxel"], "triplane": ["triplane"], "triline": ["triline"],
-                "triplaneline": ["triplane", "triline"]}
+# grid type -> [(grid-feature family, parameter scope)] in concatenation order (python/network.py:120-151; the cosine /
+# Lanczos variants keep the linear ones' parameter scopes)
+_FUSED_GRIDS = {"none": []}
+for _pre in ("", "cosine_", "lanczos_"):
+    _FUSED_GRIDS[_pre + "voxel"] = [(_pre + "voxel", "voxel_feature")]
+    _FUSED_GRIDS[_pre + "triplane"] = [(_pre + "triplane", "triplane_feature")]
+    _FUSED_GRIDS[_pre + "triline"] = [(_pre + "triline", "triline_feature")]
+    _FUSED_GRIDS[_pre + "triplaneline"] = [(_pre + "triplane", "triplane_feature"), (_pre + "triline", "triline_feature")]
 
 
 def uses_fused_geometric(conf):
@@ -183,7 +189,7 @@ def geometric_network_with_grad(x, conf):
         _ensure_geometric_params(x, conf)
         Ws, bs, skip_at, scale = _geometric_param_lists(conf)
         params = P.get_parameters()
-        grids = [(f, params[f"geometric-network/{f}_feature/F"]) for f in fused_grids[v.type]]
+        grids = [(f, params[f"geometric-network/{scope}/F"]) for f, scope in fused_grids[v.type]]
         sdf, feat, grad_x = geometric_main(x, grids, Ws, bs, g.pe_bands, skip_at, scale)
         with P.parameter_scope("geometric-network"):
             gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain]), True)
