@@ -357,23 +357,27 @@ __global__ void __launch_bounds__(256) k_scatter(long long P, float* __restrict_
 constexpr int AGG_HT = 4096;      // slots; at most 2048 insertions per pass: 256 lanes x taps x D / 4 (voxel D = 4: 8 taps;
                                   // tri-plane D <= 8: 4 taps x 2; tri-line D <= 8: 2 taps x 2)
 
-template <int TOPO, int MODE>
+// Points per pass and workgroup: as many as keep the table at most half full in the worst case (every tap of every
+// point a distinct cell): 2048 / (taps x float4 chunks per cell).  Linear: 256 (voxel, 8 taps) ; Lanczos voxel (64 taps): 32
+// -- its 4 x 4 x 4 neighbourhoods of consecutive ray samples overlap almost completely, which is exactly what the
+// table removes (3.4 ms -> see DESIGN 3.3).
+template <int TOPO, int I, int MODE>
 __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restrict__ gf, const float* __restrict__ gg_query,
                                                      const float* __restrict__ grad_output, const float* __restrict__ query,
-                                                     GridDesc g) {
-  constexpr int I = LINEAR, ND = NDims<TOPO>::v, NT = NTaps<I>::v;
+                                                     GridDesc g, int ppp) {
+  constexpr int ND = NDims<TOPO>::v, NT = NTaps<I>::v;
   __shared__ int keys[AGG_HT];
   __shared__ float vals[AGG_HT * 4];
   const long long total = P * g.S;
-  const long long per_pass = (long long)gridDim.x * 256;
-  for (long long base = (long long)blockIdx.x * 256; base < total; base += per_pass) {   // uniform per workgroup
+  const long long per_pass = (long long)gridDim.x * ppp;
+  for (long long base = (long long)blockIdx.x * ppp; base < total; base += per_pass) {   // uniform per workgroup
     for (int t = threadIdx.x; t < AGG_HT; t += 256) {
       keys[t] = -1;
       *reinterpret_cast<float4*>(vals + 4 * t) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     const long long tid = base + threadIdx.x;
-    if (tid < total) {
+    if ((int)threadIdx.x < ppp && tid < total) {
       const int s = (int)(tid / P);
       const long long b = tid - (long long)s * P;
       float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
@@ -754,15 +758,27 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
   if (P <= 0) return NDJIR_OK;
   int blocks = grid_blocks(P * g.S);
   static const bool no_agg = getenv("NDJIR_SCATTER_NO_AGG") != nullptr;      // A/B switch
-  const bool agg_fits = (g.D == 4) || (g.topo != VOXEL && g.D == 8);          // table capacity, see AGG_HT
-  if (interp == LINEAR && agg_fits && g.topo != HASH && !no_agg) {
-    // workgroup-aggregated path (dense cell index must fit 31 bits: 2^33 floats)
-#define NDJIR_AGG_CASE(T)                                                                                                  \
-    { if (mode == 0) hipLaunchKernelGGL((k_scatter_agg<T, 0>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g); \
-      else hipLaunchKernelGGL((k_scatter_agg<T, 1>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g); }
-    if (g.topo == VOXEL) NDJIR_AGG_CASE(VOXEL)
-    else if (g.topo == TRIPLANE) NDJIR_AGG_CASE(TRIPLANE)
-    else NDJIR_AGG_CASE(TRILINE)
+  // workgroup-aggregated path (dense cell index must fit 31 bits: 2^33 floats); insertions per point = taps x D / 4
+  const int nd = g.topo == VOXEL ? 3 : (g.topo == TRIPLANE ? 2 : 1), nt = interp == LANCZOS ? 4 : 2;
+  int taps = 1;
+  for (int a = 0; a < nd; ++a) taps *= nt;
+  const int per_point = taps * (g.D / 4);
+  if (g.topo != HASH && (g.D & 3) == 0 && per_point <= 128 && !no_agg) {
+    int ppp = 2048 / per_point;
+    if (ppp > 256) ppp = 256;
+    const long long want = (P * g.S + ppp - 1) / ppp;
+    const int ablocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+#define NDJIR_AGG_CASE(T, IV)                                                                                              \
+    { if (mode == 0) hipLaunchKernelGGL((k_scatter_agg<T, IV, 0>), dim3(ablocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g, ppp); \
+      else hipLaunchKernelGGL((k_scatter_agg<T, IV, 1>), dim3(ablocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g, ppp); }
+#define NDJIR_AGG_TOPO(IV)                                   \
+    { if (g.topo == VOXEL) NDJIR_AGG_CASE(VOXEL, IV)          \
+      else if (g.topo == TRIPLANE) NDJIR_AGG_CASE(TRIPLANE, IV) \
+      else NDJIR_AGG_CASE(TRILINE, IV) }
+    if (interp == LINEAR) NDJIR_AGG_TOPO(LINEAR)
+    else if (interp == COSINE) NDJIR_AGG_TOPO(COSINE)
+    else NDJIR_AGG_TOPO(LANCZOS)
+#undef NDJIR_AGG_TOPO
 #undef NDJIR_AGG_CASE
     return ndjir_check_launch();
   }
