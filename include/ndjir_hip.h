@@ -73,6 +73,9 @@ NDJIR_DECL_VOXEL_FAMILY(voxel_feature)
  * 8 corners, which also cover the TV backward's cells -- instead of rewriting the whole buffer. */
 int ndjir_voxel_feature_zero_touched(int N, float* grad_feature, const float* query, const int* grid_sizes, int D,
                                      const float* min, const float* max, hipStream_t stream);
+/* ... for any interpolation of the dense voxel family: interp 0 linear (8 corners), 1 cosine, 2 Lanczos (4 x 4 x 4 taps) */
+int ndjir_voxel_feature_zero_touched_interp(int N, float* grad_feature, const float* query, const int* grid_sizes, int D,
+                                            const float* min, const float* max, int interp, hipStream_t stream);
 /* *flag |= 1 (device int) when one of those cells holds an inf or nan: the grid half of
  * `check_inf_or_nan_grad` (python/solver.py:67-69) without reading the 2 GiB buffer. */
 int ndjir_voxel_feature_check_touched(int N, const float* grad_feature, const float* query, const int* grid_sizes, int D,

@@ -165,6 +165,15 @@ extern "C" int ndjir_voxel_feature_pack_rows(int N, const float* gf, const float
   return launch_pack_rows(voxel_desc(gs, D, mn, mx), N, gf, query, bitmap, ids, rows, count, capacity, st);
 }
 
+// the same for the cosine (interp = 1) and Lanczos (interp = 2: 4 x 4 x 4 taps) dense voxel families
+extern "C" int ndjir_voxel_feature_zero_touched_interp(int N, float* gf, const float* query, const int* gs, int D, const float* mn,
+                                                       const float* mx, int interp, hipStream_t st) {
+  if (N <= 0) return NDJIR_OK;
+  CHECK_PTRS(gf, query);
+  if (interp != LINEAR && interp != COSINE && interp != LANCZOS) return NDJIR_ERR_ARG;
+  return launch_zero_touched(interp, voxel_desc(gs, D, mn, mx), N, gf, query, nullptr, st);
+}
+
 // *flag |= 1 when a cell of grad_feature that the N query points touch holds an inf or nan.
 extern "C" int ndjir_voxel_feature_check_touched(int N, const float* gf, const float* query, const int* gs, int D,
                                                  const float* mn, const float* mx, int* flag, hipStream_t st) {

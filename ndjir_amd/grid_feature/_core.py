@@ -62,12 +62,17 @@ def set_grad_buffer(feature, buf):
         _GRAD_BUFFERS[feature.data_ptr()] = buf
 
 
-def zero_touched(buf, query, min_=(-1, -1, -1), max_=(1, 1, 1)):
-    """Re-arm the accumulate-in-place gradient buffer `buf` (G0, G1, G2, D) of a linear dense voxel
-    grid: zero only the cells the `query` points (..., 3) touched (grad_feature,
-    grad_query_grad_feature and TV backward all stay inside the 8 corners) instead of the whole buffer."""
+def zero_touched(buf, query, min_=(-1, -1, -1), max_=(1, 1, 1), interp="linear"):
+    """Re-arm the accumulate-in-place gradient buffer `buf` (G0, G1, G2, D) of a dense voxel grid: zero only the
+    cells the `query` points (..., 3) touched -- every tap of the family's stencil (linear / cosine: the 8 corners,
+    which also hold the TV backward's cells; Lanczos: 4 x 4 x 4) -- instead of the whole buffer."""
     q = query.detach().reshape(-1, 3).contiguous()
-    lib.call("voxel_feature_zero_touched", q.shape[0], buf, q, list(buf.shape[:3]), buf.shape[3], list(min_), list(max_))
+    code = {"linear": 0, "cosine": 1, "lanczos": 2}[interp]
+    if code == 0:
+        lib.call("voxel_feature_zero_touched", q.shape[0], buf, q, list(buf.shape[:3]), buf.shape[3], list(min_), list(max_))
+    else:
+        lib.call("voxel_feature_zero_touched_interp", q.shape[0], buf, q, list(buf.shape[:3]), buf.shape[3], list(min_),
+                 list(max_), code)
 
 
 def get_grad_buffer(feature):

@@ -86,11 +86,12 @@ class Step:
             handle = self.remote_rows.get(name)
             if isinstance(handle, SparseRows):
                 handle.zero(buf)
-            elif v.type == "voxel" and self.touched is not None and (not self.multi or handle is not None):
+            elif v.type.endswith("voxel") and self.touched is not None and (not self.multi or handle is not None):
                 x_fg = self.touched
                 r = self.conf.renderer.bounding_sphere_radius
-                zero_touched(buf, x_fg)
-                zero_touched(buf, x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size))
+                interp = v.type[:-len("voxel")].rstrip("_") or "linear"
+                zero_touched(buf, x_fg, interp=interp)
+                zero_touched(buf, x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size), interp=interp)
             else:
                 buf.zero_()
 

@@ -264,7 +264,8 @@ def test_squareplus(gpu):
     np.testing.assert_allclose(x.grad.cpu().numpy(), (0.5 * (1 + x / torch.sqrt(x * x + 4))).detach().cpu().numpy(), atol=1e-6)
 
 
-def test_zero_touched_rearms_the_grad_buffer(gpu):
+@pytest.mark.parametrize("family,interp", [("voxel", "linear"), ("cosine_voxel", "cosine"), ("lanczos_voxel", "lanczos")])
+def test_zero_touched_rearms_the_grad_buffer(gpu, family, interp):
     """Everything the voxel backward kernels scatter (grad_feature, the second-order
     grad_query_grad_feature, TV backward incl. sym_backward) lies inside the cells zero_touched clears."""
     from ndjir_amd.grid_feature import _core, set_grad_buffer, zero_touched
@@ -277,12 +278,12 @@ def test_zero_touched_rearms_the_grad_buffer(gpu):
     set_grad_buffer(f, buf)
     try:
         qg = q.clone().requires_grad_(True)
-        out = _core.query("voxel", qg, f)
+        out = _core.query(family, qg, f)
         (gq,) = _core.grad([out], [qg], [w])                             # differentiable d out / d query
         loss = (out * w).sum() + (gq ** 2).sum() + _core.tv_loss("voxel", q, f, sym_backward=True).sum()
         loss.backward()
         assert int((buf != 0).sum()) > 0
-        zero_touched(buf, q)
+        zero_touched(buf, q, interp=interp)
         assert int((buf != 0).sum()) == 0
     finally:
         set_grad_buffer(f, None)
