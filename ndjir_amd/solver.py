@@ -97,7 +97,9 @@ class Adam:
     def set_gradients(self, grads, touched=None):
         """grads: {name: tensor or None} for dense parameters (what backward produced); grid parameters use
         their accumulate-in-place buffer (`grid_feature.set_grad_buffer`).  touched: {name: [query tensors]} -- the
-        points whose cells can hold gradient (restricts the guard to them; absent = dense check)."""
+        points whose cells can hold gradient (restricts the guard and the gradient read of the update to the 8 corner
+        cells of each point: LINEAR dense voxel grids only -- a cosine / Lanczos grid scatters into more cells and must
+        be passed without `touched`; absent = dense check and dense update)."""
         self._grads = grads
         self._touched = touched or {}
 
