@@ -86,7 +86,7 @@ class Step:
             handle = self.remote_rows.get(name)
             if isinstance(handle, SparseRows):
                 handle.zero(buf)
-            elif v.type.endswith("voxel") and self.touched is not None and (not self.multi or handle is not None):
+            elif v.type.endswith("voxel") and self.touched is not None and not self.multi:
                 x_fg = self.touched
                 r = self.conf.renderer.bounding_sphere_radius
                 interp = v.type[:-len("voxel")].rstrip("_") or "linear"
@@ -151,7 +151,8 @@ class Step:
         x_fg = self.x_fg
         v = self.conf.geometric_network.voxel
         queries = {}
-        if v.type.endswith("voxel"):
+        if v.type == "voxel":       # sparse exchange: the 8 corner cells of the LINEAR voxel stencil; the cosine / Lanczos
+            # families scatter into more cells and go through the dense all-reduce
             r = self.conf.renderer.bounding_sphere_radius
             x_ptb = x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size)
             queries["geometric-network/voxel_feature/F"] = ([x_fg, x_ptb], [v.grid_size] * 3)
