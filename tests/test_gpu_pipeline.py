@@ -211,3 +211,30 @@ def test_training_iterations_on_the_device_data_feed(gpu):
         for p in step.grid_params:
             set_grad_buffer(p, None)
         P.clear_parameters()
+
+
+@pytest.mark.parametrize("gtype,G,D", [("cosine_voxel", 16, 4), ("lanczos_triplaneline", 32, 4), ("cosine_triplaneline", 32, 8),
+                                       ("triplane", 32, 8)])
+def test_step_parity_other_grid_types(gpu, gtype, G, D):
+    """The remaining values of geometric_network.voxel.type (python/network.py:120-151) through the fused geometric pass:
+    loss, pixels and every gradient against the oracle."""
+    conf = small_conf(grid_size=G, n_rays=8, overrides=[f"geometric_network.voxel.type={gtype}",
+                                                        f"geometric_network.voxel.feature_size={D}"])
+    prod = run_product_step(conf, B=1, R=8, device=gpu)
+    s = prod["samples"]
+    ref = run_oracle_step(conf, prod["params_cpu"], prod["inputs_cpu"], samples=(s["x_fg"], s["t_fg"], s["x_bg"], s["t_bg"], s["mask"]))
+    assert abs(float(prod["loss"]) - float(ref["loss"])) <= LOSS_RTOL * abs(float(ref["loss"]))
+    assert float((prod["color_pixel"].cpu() - ref["color_pixel"]).abs().max()) <= PIXEL_TOL
+    ref64 = None
+    for k, g in ref["grads"].items():
+        gp = prod["grads"][k]
+        assert (g is None) == (gp is None), k
+        if g is None:
+            continue
+        e = rel_err(gp, g)
+        if e >= GRAD_RTOL:
+            if ref64 is None:
+                ref64 = run_oracle_step(conf, prod["params_cpu"], prod["inputs_cpu"], dtype=torch.float64,
+                                        samples=(s["x_fg"], s["t_fg"], s["x_bg"], s["t_bg"], s["mask"]))
+            e64, o64 = rel_err(gp, ref64["grads"][k]), rel_err(g, ref64["grads"][k])
+            assert e64 <= 3 * o64, (k, e, e64, o64)
