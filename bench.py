@@ -185,6 +185,10 @@ def train_leg(step, steps, barrier, use_graph):
             loss = step.train_step()
     barrier()
     el = time.perf_counter() - t0
+    # a replayed optimizer graph rewrites the weights without bumping tensor._version (increment_version ran at capture
+    # only), and the packed-weight cache keys on (data_ptr, _version): drop it, or an eager forward after the replays
+    # would run on weights packed before the last update
+    mlp._PACK_CACHE.clear()
     # the optimizer alone (HIP events on the launching stream, ordinary launches)
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     step.solvers.zero_grad()

@@ -435,6 +435,9 @@ int ndjir_solver_adam_multi(int count, float* const* w, const float* const* g, f
 int ndjir_solver_check_inf_or_nan(long long n, const float* g, int* flag, hipStream_t stream);
 int ndjir_solver_check_inf_or_nan_multi(int count, const float* const* g, const long long* numel, int* flag,
                                         hipStream_t stream);
+/* python/train.py:144-146 (`if np.any(np.isnan(loss.d)): continue`): raises both guard flags when x (n floats, the
+ * loss) holds a NaN, so that the `and` in ndjir_solver_adam_begin skips the update */
+int ndjir_solver_veto_if_nan(int n, const float* x, int* flag_a, int* flag_b, hipStream_t stream);
 /* *out += sum x^2 (device double): the norm of `clip_grad_by_norm` (python/solver.py:53-58) */
 int ndjir_solver_sum_squares(long long n, const float* x, double* out, hipStream_t stream);
 

@@ -7,15 +7,18 @@
  *
  * Also the scan / reduction ORDERS of the hierarchical sampler (python/sampler.py:199-222): the
  * reference leaves them to nnabla's CUDA scan kernels (unspecified association); here they are fixed
- * as Kogge-Stone inclusive scans and an xor-butterfly sum over 128 slots, which a 64-lane wave and a
- * plain C loop evaluate identically.
+ * as Kogge-Stone inclusive scans over the slots and a sum that first adds the slots of one residue
+ * class mod 64, s_l = (w[l] + w[l+64]) + (w[l+128] + w[l+192]), then combines the 64 classes with an
+ * xor butterfly (masks 32, 16, ..., 1) -- which a 64-lane wave and a plain C loop evaluate identically.
+ * Slots beyond the ray's samples hold the identity (1 for the product scan, 0 for the sums), so the
+ * results do not depend on how many slots an implementation carries (128 or 256).
  */
 #ifndef NDJIR_MATH_H
 #define NDJIR_MATH_H
 
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NDJIR_HD __host__ __device__ static inline
 #else
 #define NDJIR_HD static inline
@@ -40,6 +43,6 @@ NDJIR_HD float ndjir_expf(float x) {
 
 NDJIR_HD float ndjir_sigmoidf(float x) { return 1.0f / (1.0f + ndjir_expf(-x)); }
 
-#define NDJIR_SAMPLER_SLOTS 128   /* max samples per ray the sampler kernels handle */
+#define NDJIR_SAMPLER_SLOTS 256   /* max samples per ray the sampler kernels handle */
 
 #endif /* NDJIR_MATH_H */

@@ -14,7 +14,7 @@
 
 namespace ndjir {
 
-constexpr int RD_SLOTS = 256;   // samples per ray (foreground + background) handled by one wave
+constexpr int RD_SLOTS = 512;   // samples per ray (foreground + background) handled by one wave (cfg5: 256 + 32)
 
 __device__ __forceinline__ float rd_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 

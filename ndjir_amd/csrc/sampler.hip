@@ -1,7 +1,8 @@
 // sampler.hip -- one up-sampling round of the hierarchical SDF-guided importance sampler
 // (python/sampler.py:194-240: robust slope, sigmoid CDF, alpha, transmittance weights, inverse-
 // transform sampling with deterministic u, clip, merge-sort) as ONE kernel: one wave per ray, lane l
-// owns slots l and l+64 of the ray's <= 128 samples; all intermediates live in LDS.
+// owns slots l, l+64, ... of the ray's <= 64*H samples (H = 2 up to 128 slots, the training shapes;
+// H = 4 up to 256 slots, render_image at renderer.n_samples0 = 128); all intermediates live in LDS.
 // The reference runs ~40 small nnabla launches per round.  Arithmetic and scan orders are the
 // definitions of include/ndjir_math.h, shared bit-for-bit with the CPU oracle.
 #include <hip/hip_runtime.h>
@@ -13,13 +14,17 @@
 
 namespace ndjir {
 
-constexpr int SLOTS = NDJIR_SAMPLER_SLOTS;
 constexpr int RAYS_PER_BLOCK = 4;
 
+// The scan / sum orders of ndjir_math.h do not depend on H: a Kogge-Stone prefix at slot i only
+// involves slots <= i, and the lane sum (W[l] + W[l+64]) + (W[l+128] + W[l+192]) adds exact zeros
+// when the upper slots are empty, so H = 2 and H = 4 give the same bits wherever both apply.
+template <int H>
 __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK) k_importance_round(
     int R, int N, int M, float gain, float udenom, const float* __restrict__ t_in, const float* __restrict__ sdf_in,
     const float* __restrict__ t_near, const float* __restrict__ t_far, float* __restrict__ t_out, int* __restrict__ idx_out,
     int* __restrict__ src_out, float* __restrict__ tnew_out) {
+  constexpr int SLOTS = 64 * H;
   __shared__ float s_t[RAYS_PER_BLOCK][SLOTS], s_a[RAYS_PER_BLOCK][SLOTS], s_b[RAYS_PER_BLOCK][SLOTS],
       s_w[RAYS_PER_BLOCK][SLOTS], s_c[RAYS_PER_BLOCK][SLOTS], s_new[RAYS_PER_BLOCK][32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -31,7 +36,7 @@ __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK) k_importance_round(
 
   // load samples; A = sdf
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < H; ++h) {
     int i = lane + 64 * h;
     T[i] = (live && i < N) ? t_in[(long long)ray * N + i] : 0.f;
     A[i] = (live && i < N) ? sdf_in[(long long)ray * N + i] : 0.f;
@@ -39,7 +44,7 @@ __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK) k_importance_round(
   __syncthreads();
   // cos1 of every interval -> B
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < H; ++h) {
     int i = lane + 64 * h;
     float v = 0.f;
     if (i < NI) v = (A[i + 1] - A[i]) / (T[i + 1] - T[i] + 1e-5f);
@@ -48,7 +53,7 @@ __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK) k_importance_round(
   __syncthreads();
   // alpha -> W ; q = 1 - alpha -> C (scan input)
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < H; ++h) {
     int i = lane + 64 * h;
     float alpha = 0.f;
     if (i < NI) {
@@ -71,37 +76,38 @@ __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK) k_importance_round(
   __syncthreads();
   // inclusive cumprod of q, Kogge-Stone
   for (int d = 1; d < SLOTS; d <<= 1) {
-    float v[2];
+    float v[H];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) { int i = lane + 64 * h; v[h] = (i >= d) ? C[i - d] * C[i] : C[i]; }
+    for (int h = 0; h < H; ++h) { int i = lane + 64 * h; v[h] = (i >= d) ? C[i - d] * C[i] : C[i]; }
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) C[lane + 64 * h] = v[h];
+    for (int h = 0; h < H; ++h) C[lane + 64 * h] = v[h];
     __syncthreads();
   }
   // weights = alpha * exclusive cumprod -> W
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < H; ++h) {
     int i = lane + 64 * h;
     float ex = (i == 0) ? 1.f : C[i - 1];
     W[i] = (i < NI) ? W[i] * ex : 0.f;
   }
   __syncthreads();
-  // butterfly sum over 128 slots
+  // lane sums in the order of ndjir_math.h, then the xor butterfly over the 64 lanes
   float s = W[lane] + W[lane + 64];
+  if (H == 4) s = s + (W[lane + 128] + W[lane + 192]);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) s = s + __shfl_xor(s, m);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) { int i = lane + 64 * h; W[i] = W[i] / s; C[i] = W[i]; }
+  for (int h = 0; h < H; ++h) { int i = lane + 64 * h; W[i] = W[i] / s; C[i] = W[i]; }
   __syncthreads();
   // inclusive cumsum, Kogge-Stone
   for (int d = 1; d < SLOTS; d <<= 1) {
-    float v[2];
+    float v[H];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) { int i = lane + 64 * h; v[h] = (i >= d) ? C[i - d] + C[i] : C[i]; }
+    for (int h = 0; h < H; ++h) { int i = lane + 64 * h; v[h] = (i >= d) ? C[i - d] + C[i] : C[i]; }
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) C[lane + 64 * h] = v[h];
+    for (int h = 0; h < H; ++h) C[lane + 64 * h] = v[h];
     __syncthreads();
   }
   // inverse transform sampling: lane m < M
@@ -127,7 +133,7 @@ __global__ void __launch_bounds__(64 * RAYS_PER_BLOCK) k_importance_round(
     float* out = t_out + (long long)ray * (N + M);
     int* src = src_out ? src_out + (long long)ray * (N + M) : nullptr;   // merged position -> source slot
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < H; ++h) {
       int i = lane + 64 * h;
       if (i < N) {
         float v = T[i];
@@ -151,11 +157,15 @@ int launch_importance_round(int R, int N, int M, float gain, const float* t, con
                             const float* t_far, float* t_out, int* idx_out, int* src_out, float* tnew_out,
                             hipStream_t stream) {
   if (R <= 0) return NDJIR_OK;
-  if (N < 2 || M < 1 || M > 32 || N + M > SLOTS) return NDJIR_ERR_UNSUPPORTED;
+  if (N < 2 || M < 1 || M > 32 || N + M > NDJIR_SAMPLER_SLOTS) return NDJIR_ERR_UNSUPPORTED;
   float udenom = (float)(M - 1 + 1.0 / M);
   int blocks = (R + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK;
-  hipLaunchKernelGGL(k_importance_round, dim3(blocks), dim3(64 * RAYS_PER_BLOCK), 0, stream, R, N, M, gain, udenom, t, sdf,
-                     t_near, t_far, t_out, idx_out, src_out, tnew_out);
+  if (N + M <= 128)
+    hipLaunchKernelGGL(k_importance_round<2>, dim3(blocks), dim3(64 * RAYS_PER_BLOCK), 0, stream, R, N, M, gain, udenom, t,
+                       sdf, t_near, t_far, t_out, idx_out, src_out, tnew_out);
+  else
+    hipLaunchKernelGGL(k_importance_round<4>, dim3(blocks), dim3(64 * RAYS_PER_BLOCK), 0, stream, R, N, M, gain, udenom, t,
+                       sdf, t_near, t_far, t_out, idx_out, src_out, tnew_out);
   return ndjir_check_launch();
 }
 

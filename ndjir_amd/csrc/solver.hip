@@ -354,6 +354,21 @@ extern "C" int ndjir_solver_check_inf_or_nan_multi(int count, const float* const
   return ndjir_check_launch();
 }
 
+// python/train.py:144-146: `if np.any(np.isnan(loss.d)): continue`.  Raises BOTH guard flags when x holds a NaN, so that
+// the `and` of ndjir_solver_adam_begin vetoes the update whatever the gradient checks found.  n is tiny (the loss).
+__global__ void k_veto_if_nan(int n, const float* __restrict__ x, int* __restrict__ flag_a, int* __restrict__ flag_b) {
+  bool bad = false;
+  for (int i = threadIdx.x; i < n; i += 64) bad |= (x[i] != x[i]);
+  if (__any(bad) && threadIdx.x == 0) { *flag_a = 1; *flag_b = 1; }
+}
+
+extern "C" int ndjir_solver_veto_if_nan(int n, const float* x, int* flag_a, int* flag_b, hipStream_t stream) {
+  if (n <= 0) return NDJIR_OK;
+  if (!x || !flag_a || !flag_b) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_veto_if_nan, dim3(1), dim3(64), 0, stream, n, x, flag_a, flag_b);
+  return ndjir_check_launch();
+}
+
 // *out += sum(x^2) (device double, zeroed by the caller): the norm `clip_grad_by_norm` needs
 // (python/solver.py:53-58; called on the decay-only gradient d*w, python/train.py:138-139).
 extern "C" int ndjir_solver_sum_squares(long long n, const float* x, double* out, hipStream_t stream) {

@@ -34,9 +34,10 @@ def compute_num_params(G0, growth_factor, T0, D, levels):
 
 
 def compute_params_boundary(G0, growth_factor, T0, D, level):
+    """[n0, n1) of level `level` in the 1-D parameter vector, alignment padding included (:52-62)."""
     n0 = compute_num_params(G0, growth_factor, T0, D, level)
     T = compute_table_size(compute_grid_size(G0, growth_factor, T0, level), T0)
-    return n0, n0 + T * D
+    return n0, n0 + force_align(T * D)
 
 
 def query_on_voxel_hash(query, feature, G0=16, growth_factor=1.5, T0=2 ** 15, L=16, D=2,

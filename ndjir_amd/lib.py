@@ -78,6 +78,7 @@ SIGS = {
     "solver_adam_touched": "lppppfffffqx",
     "voxel_feature_mark_touched": "ipIiFFq",
     "solver_check_inf_or_nan": "lpq",
+    "solver_veto_if_nan": "ipqq",
     "solver_check_inf_or_nan_multi": "iPLq",
     "solver_sum_squares": "lpx",
     "voxel_feature_grad_query_grad_query": "ippppp" + _VOX_TAIL + "i",

@@ -15,14 +15,15 @@ from .sampler import sample_points
 
 
 def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand, record=None, ray_shards=1,
-               mask_sum_global=None):
+               mask_sum_global=None, obj_mask_sum_global=None):
     """camloc (B,3), raydir (B,R,3), color_gt (B,R,3), obj_mask (B,R,1) or None, cos_anneal_ratio (1,).
 
     `ray_shards` > 1: this process holds one of `ray_shards` equal slices of the ray batch
     (torch.distributed initialised).  The loss normalisers -- B*R and sum(mask) -- are then taken
     over ALL shards (one scalar all-reduce before backward), so the sum over ranks of the returned
     losses, and of their gradients, equals the single-process loss / gradient of the whole batch.
-    `mask_sum_global`: that all-reduced sum(mask), if the caller has it already (0-d tensor)."""
+    `mask_sum_global` / `obj_mask_sum_global`: the all-reduced sum(mask) / sum(obj_mask), if the caller has them
+    already (0-d tensors)."""
     B, R, _ = color_gt.shape
     tr = conf.train
 
@@ -39,7 +40,16 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
     color = res["color_pixel"]
     err = (color - color_gt).abs() if tr.rgb_loss == "l1" else (color - color_gt) ** 2
     if tr.mask_weight > 0.0:
-        loss_rgb = (err * obj_mask).sum() / (obj_mask.sum() + 1e-5)
+        if obj_mask is None:
+            raise ValueError("train.mask_weight > 0 needs obj_mask (python/loss.py:62)")
+        obj_sum = obj_mask.sum()
+        if obj_mask_sum_global is not None:
+            obj_sum = obj_mask_sum_global.reshape(()).to(obj_sum.dtype)
+        elif ray_shards > 1:       # normalise by the GLOBAL count, like every other term, so that per-rank gradients add
+            import torch.distributed as dist
+            obj_sum = obj_sum.clone()
+            dist.all_reduce(obj_sum)
+        loss_rgb = (err * obj_mask).sum() / (obj_sum + 1e-5)
     else:
         loss_rgb = err.sum() / (B * R * ray_shards)
 

@@ -211,11 +211,14 @@ class Solvers:
         self.solver_weight.update()
         self.solver_feat.update()
 
-    def guarded_update(self):
-        """`if check_inf_or_nan_grad(): continue` + `update()` (python/train.py:141-148) without leaving the stream."""
+    def guarded_update(self, loss=None):
+        """`if check_inf_or_nan_grad(): continue`, `if isnan(loss): continue`, `update()` (python/train.py:141-148)
+        without leaving the stream.  loss: the step's loss as a 1-element device tensor (None: gradient guard only)."""
         self.solver_weight._check()
         self.solver_feat._check()
         flags = (self.solver_weight.flag, self.solver_feat.flag)
+        if loss is not None:        # a NaN loss vetoes the step whatever the gradients look like: raise both flags
+            lib.call("solver_veto_if_nan", 1, loss.detach().reshape(1), flags[0], flags[1])
         self.solver_weight.update(flags)
         self.solver_feat.update(flags)
 

@@ -40,10 +40,19 @@ class Step:
                                                             total_rays=world * R)
         full = make_rand(B, world * R, conf, "cpu")
         self.rand = {k: v[:, rank * R:(rank + 1) * R].contiguous().to(device) for k, v in full.items()}
-        self.car = torch.ones(1, device=device)
+        # python/train.py:75-78: the registry parameter "cos_anneal_ratio" (created at 0.0; Solvers.update_cos_anneal_ratio
+        # rewrites it in place every epoch, so a captured graph keeps reading the current value).  The synthetic bench /
+        # parity steps run at ratio 1 until a schedule says otherwise.
+        import numpy as np
+        self.car = P.get_parameter_or_create("cos_anneal_ratio", (1,), np.asarray([0.0]), False)
+        self.car.fill_(1.0)
+        # object mask of the rays (python/train.py:126-127), read by the loss only when train.mask_weight > 0
+        self.obj_mask = torch.ones(B, R, 1, device=device)
+        self.obj_mask_sum = torch.zeros((), device=device)   # multi-GPU: all-reduced sum of the object masks
         self.P = P
         self.grid_bufs = {}
-        self.touched = None      # query points whose cells hold gradient from the previous step
+        self.touched = None      # query points whose cells hold gradient from the previous step ...
+        self.touched_ptb = None  # ... and their perturbed twins (x_fg + the noise of THAT step: redraw_rand may follow)
         self.remote_rows = {}    # multi-GPU: grid rows received from the other ranks in the previous exchange
         self.mask_sum = torch.zeros((), device=device)   # multi-GPU: all-reduced sum of the ray masks
         self.x_fg = None
@@ -61,12 +70,21 @@ class Step:
         self.grid_params = [p for k, p in P.get_parameters().items() if k.endswith("feature/F")]
         self.flat_grad = torch.zeros(sum(p.numel() for p in self.mlp_params), device=device)
 
-    def set_rays(self, camloc, raydir, color_gt):
-        """Feed the next iteration's rays (python/train.py:124-133: `raydir.d = ...`, `camloc.d = ...`, `color_gt.d = ...`)
-        into the step's persistent input tensors -- in place, so that a captured graph keeps reading them."""
+    def set_rays(self, camloc, raydir, color_gt, obj_mask=None):
+        """Feed the next iteration's rays (python/train.py:124-133: `raydir.d = ...`, `camloc.d = ...`, `color_gt.d = ...`,
+        `obj_mask.d = ...`) into the step's persistent input tensors -- in place, so that a captured graph keeps reading
+        them."""
         self.camloc.copy_(camloc.reshape(self.camloc.shape))
         self.raydir.copy_(raydir.reshape(self.raydir.shape))
         self.color_gt.copy_(color_gt.reshape(self.color_gt.shape))
+        if obj_mask is not None:
+            self.obj_mask.copy_(obj_mask.reshape(self.obj_mask.shape))
+        elif self.conf.train.mask_weight > 0.0:
+            raise ValueError("train.mask_weight > 0 needs the rays' object mask (python/train.py:127)")
+
+    def _ptb_scale(self):
+        import math
+        return math.sqrt(3) * 2 * self.conf.renderer.bounding_sphere_radius / self.conf.geometric_network.voxel.grid_size
 
     def redraw_rand(self, generator=None):
         """New stratified / background / light-direction / perturbation samples for the next iteration (in place)."""
@@ -78,7 +96,6 @@ class Step:
         gradient (512^3 x 4 floats = 2 GiB would otherwise be rewritten every step) -- one GPU: the cells the previous
         step's query points touched; N > 1: the rows the previous exchange listed (own and received).  Anything
         else: dense."""
-        import math
         from ndjir_amd.distributed import SparseRows
         from ndjir_amd.grid_feature import zero_touched
         v = self.conf.geometric_network.voxel
@@ -87,11 +104,9 @@ class Step:
             if isinstance(handle, SparseRows):
                 handle.zero(buf)
             elif v.type.endswith("voxel") and self.touched is not None and not self.multi:
-                x_fg = self.touched
-                r = self.conf.renderer.bounding_sphere_radius
                 interp = v.type[:-len("voxel")].rstrip("_") or "linear"
-                zero_touched(buf, x_fg, interp=interp)
-                zero_touched(buf, x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size), interp=interp)
+                zero_touched(buf, self.touched, interp=interp)
+                zero_touched(buf, self.touched_ptb, interp=interp)
             else:
                 buf.zero_()
 
@@ -113,13 +128,19 @@ class Step:
             ms = mask.sum().reshape(())
         dist.all_reduce(ms)
         self.mask_sum.copy_(ms)
+        if self.conf.train.mask_weight > 0.0:      # the RGB term divides by the GLOBAL object-mask count (loss.py:62)
+            oms = self.obj_mask.sum().reshape(())
+            dist.all_reduce(oms)
+            self.obj_mask_sum.copy_(oms)
 
     def compute(self, rearm=True):
         from ndjir_amd.loss import total_loss
         if rearm:
             self.rearm_grid_buffers()
-        out = total_loss(self.camloc, self.raydir, self.color_gt, None, self.car, self.conf, self.rand,
-                         ray_shards=self.world, mask_sum_global=self.mask_sum if self.multi else None)
+        use_mask = self.conf.train.mask_weight > 0.0
+        out = total_loss(self.camloc, self.raydir, self.color_gt, self.obj_mask if use_mask else None, self.car, self.conf,
+                         self.rand, ray_shards=self.world, mask_sum_global=self.mask_sum if self.multi else None,
+                         obj_mask_sum_global=self.obj_mask_sum if (self.multi and use_mask) else None)
         loss = out["loss"]
         if self.mlp_names is None:
             params = [p for p in self.P.get_parameters(grad_only=True).values()]
@@ -128,12 +149,17 @@ class Step:
         grads = torch.autograd.grad(loss, self.mlp_params + self.grid_params, allow_unused=True)
         self.x_fg = out["samples"]["x_fg"].detach()
         if self.grid_bufs:
-            # a persistent buffer (not the step's own tensor): a captured graph must find it at the same address
+            # persistent buffers (not the step's own tensors): a captured graph must find them at the same address.  The
+            # perturbed points are stored with the noise of THIS step -- the re-arm of the next step must clear the cells
+            # this step wrote even if redraw_rand() replaced the noise in between
             if self.touched is None:
                 self.touched = self.x_fg.clone()
+                self.touched_ptb = torch.empty_like(self.x_fg)
             else:
                 self.touched.copy_(self.x_fg)
+            torch.add(self.x_fg, self.rand["noise"], alpha=self._ptb_scale(), out=self.touched_ptb)
         self.grads = grads               # the step's product: every parameter gradient, materialised
+        self.loss = loss.detach().reshape(1)
         if self.multi:
             # pack the MLP gradients into one flat bucket for the all-reduce (one batched copy, not one launch per tensor)
             if self._zeros is None:
@@ -146,16 +172,12 @@ class Step:
         per-rank gradients just add up: MLP = one flat 5.9 MB bucket; voxel grid = touched cells only."""
         if not self.multi or self.mlp_names is None:
             return
-        import math
         from ndjir_amd.distributed import allreduce_step_gradients
-        x_fg = self.x_fg
         v = self.conf.geometric_network.voxel
         queries = {}
         if v.type == "voxel":       # sparse exchange: the 8 corner cells of the LINEAR voxel stencil; the cosine / Lanczos
             # families scatter into more cells and go through the dense all-reduce
-            r = self.conf.renderer.bounding_sphere_radius
-            x_ptb = x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size)
-            queries["geometric-network/voxel_feature/F"] = ([x_fg, x_ptb], [v.grid_size] * 3)
+            queries["geometric-network/voxel_feature/F"] = ([self.touched, self.touched_ptb], [v.grid_size] * 3)
         self.remote_rows = allreduce_step_gradients(self.flat_grad, self.grid_bufs, queries)
 
     def forward_backward(self):
@@ -196,10 +218,9 @@ class Step:
 
     def optimizer_step(self):
         self.set_solver_gradients()
-        self.solvers.guarded_update()
+        self.solvers.guarded_update(self.loss)     # python/train.py:141-146: non-finite gradients or a NaN loss skip the update
 
     def set_solver_gradients(self):
-        import math
         s = self.solvers
         if self.multi:       # the exchange left the summed MLP gradients in the flat bucket
             grads, off = {}, 0
@@ -211,10 +232,8 @@ class Step:
             grads = dict(zip(self.mlp_names, self.grads))
             v = self.conf.geometric_network.voxel
             touched = None
-            if v.type == "voxel" and self.x_fg is not None:
-                r = self.conf.renderer.bounding_sphere_radius
-                touched = {"geometric-network/voxel_feature/F":
-                           [self.x_fg, self.x_fg + self.rand["noise"] * (math.sqrt(3) * 2 * r / v.grid_size)]}
+            if v.type == "voxel" and self.touched is not None:
+                touched = {"geometric-network/voxel_feature/F": [self.touched, self.touched_ptb]}
         s.set_gradients(grads, touched)
 
     def train_step(self):

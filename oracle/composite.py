@@ -186,12 +186,12 @@ def compute_table_size(G, T0):           # voxel_hash_feature.py:35-38
     return int(min(int(min(Gf * Gf * Gf, np.float32(T0))), int(T0)))
 
 
-def compute_params_boundary(G0, growth_factor, T0, D, level):
+def compute_params_boundary(G0, growth_factor, T0, D, level):   # voxel_hash_feature.py:52-62: padding included
     n = 0
     for l in range(level):
         n += force_align(compute_table_size(compute_grid_size(G0, growth_factor, l), T0) * D)
     T = compute_table_size(compute_grid_size(G0, growth_factor, level), T0)
-    return n, n + T * D
+    return n, n + force_align(T * D)
 
 
 def compute_num_params(G0, growth_factor, T0, D, L):
@@ -216,7 +216,7 @@ def query_on_voxel_hash(query, feature, G0, growth_factor, T0, L, D, min_=-1.0, 
         G = compute_grid_size(G0, growth_factor, l)
         T = compute_table_size(G, T0)
         n0, n1 = compute_params_boundary(G0, growth_factor, T0, D, l)
-        fl = feature[n0:n1].reshape(T, D)
+        fl = feature[n0:n0 + T * D].reshape(T, D)
         if kind == "linear":
             pf, p0, p1 = _cells(query, G, min_, max_, True)
             c0, c1 = _coeffs(pf, p0, p1, "linear")
@@ -316,7 +316,7 @@ def tv_loss_on_voxel_hash(query, feature, G0, growth_factor, T0, L, D, min_=-1.0
         G = compute_grid_size(G0, growth_factor, l)
         T = compute_table_size(G, T0)
         n0, n1 = compute_params_boundary(G0, growth_factor, T0, D, l)
-        fl = feature[n0:n1].reshape(T, D)
+        fl = feature[n0:n0 + T * D].reshape(T, D)
         pf, p0, p1 = _cells(query, G, min_, max_, True)
         i0, i1 = p0.long(), p1.long()
         f000 = fl[_hash(i0[:, 0], i0[:, 1], i0[:, 2], T)]

@@ -661,3 +661,64 @@ def compute_pts_vol(mins, maxs, grid_size, params, conf, batch_size=50000):
             vol.append(geometric_network(p, params, conf)[0].reshape(-1).numpy())
     vol = np.concatenate(vol).reshape((y.size, x.size, z.size)).transpose((1, 0, 2))
     return pts, vol
+
+
+# ----------------------------------------------------------------------------------------------
+# helper.py ray generation + renderer.py render_image
+# ----------------------------------------------------------------------------------------------
+def generate_all_pixels(W, H):
+    """helper.py:75-81: (H*W, 2) pixel coordinates (x, y), y-major."""
+    import numpy as np
+    xx, yy = np.meshgrid(np.arange(0, W), np.arange(0, H))
+    return np.asarray([xx.flatten(), yy.flatten()]).T
+
+
+def generate_raydir_camloc(pose, intrinsic, xy):
+    """helper.py:44-73 in numpy float64: x_w = R_c2w K^-1 (x, y, 1)^T, normalised."""
+    import numpy as np
+    B, R, _ = xy.shape
+    R_c2w = pose[:, np.newaxis, :3, :3]
+    camloc = pose[:, np.newaxis, :3, 3:4]
+    K_inv = np.linalg.inv(intrinsic[:, np.newaxis, :, :])
+    pix = np.concatenate([xy, np.ones([B, R, 1])], axis=-1)[:, :, :, np.newaxis]
+    world = np.matmul(R_c2w, np.matmul(K_inv, pix)).reshape((B, R, 3))
+    return world / np.sqrt(np.sum(world ** 2, axis=-1, keepdims=True)), camloc.reshape((B, 3))
+
+
+def render_image(pose, intrinsic, resolution, rand, params, conf):
+    """renderer.py:212-272: intrinsics scaled by 2^-n_down_samples, all pixels y-major, tile size
+    P = valid.n_rays - mod(W*H, valid.n_rays), per tile {host rays in float64 -> fp32, sample_points,
+    pb_render with cos_anneal_ratio = 1, color_pixel}, reshape to NCHW, clip to [0,1].
+    `rand`: the P-ray random tensors of one tile, reused for every tile (explicit inputs; the reference's
+    F.rand nodes are graph constants of the one graph it forwards per tile).  Where the reference's
+    `xy[:, p:p+P].reshape((1, P, 2))` would raise on a short last tile, the tile is padded with the last
+    pixel and the padding dropped."""
+    import numpy as np
+    scale = 1.0 / 2 ** conf.valid.n_down_samples
+    W, H = resolution
+    W, H = int(W * scale), int(H * scale)
+    P = conf.valid.n_rays
+    intrinsic = intrinsic.copy()
+    for (i, j) in ((0, 0), (1, 1), (0, 2), (1, 2), (0, 1)):
+        intrinsic[:, i, j] = intrinsic[:, i, j] * scale
+    xy = generate_all_pixels(W, H).reshape((1, H * W, 2))
+    _, m = divmod(W * H, P)
+    P = P - m
+    dtype = next(iter(params.values())).dtype
+    car = torch.ones(1, dtype=dtype)
+    rimage = np.zeros([1, H * W, 3])
+    for p in range(0, H * W, P):
+        xy_b = xy[:, p:p + P, :]
+        n = xy_b.shape[1]
+        if n < P:
+            xy_b = np.concatenate([xy_b, np.repeat(xy_b[:, -1:, :], P - n, axis=1)], axis=1)
+        raydir, camloc = generate_raydir_camloc(pose, intrinsic, xy_b)
+        raydir = torch.from_numpy(raydir.astype(np.float32)).to(dtype)
+        camloc = torch.from_numpy(camloc.astype(np.float32)).to(dtype)
+        x_fg, t_fg, x_bg, t_bg, mask = sample_points(camloc, raydir, rand["stratified_sample"],
+                                                     rand["background_sample"], params, conf)
+        x_fg = x_fg.detach().requires_grad_(True)
+        res = pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, car, rand, params, conf)
+        rimage[0, p:p + n, :] = res["color_pixel"].detach().reshape(P, 3)[:n].double().numpy()
+    rimage = rimage.reshape((1, H, W, 3)).transpose((0, 3, 1, 2))
+    return np.clip(rimage, 0.0, 1.0)

@@ -30,12 +30,18 @@ def _case(R, N, seed, kind):
     return t, sdf.astype(np.float32), tn, tf
 
 
-@pytest.mark.parametrize("N,u", [(64, 0), (80, 1), (96, 2), (112, 3), (5, 0)])
+# default.yaml's training rounds (64/80/96/112 + 16), a tiny ragged one, and render_image at
+# renderer.n_samples0=128, n_samples1=32 (BASELINE config 5: 128/160/192/224 + 32 -> 256 samples, the
+# 4-slots-per-lane instantiation of the kernel) plus the exact capacity edges 96+32 = 128 and 240+16 = 256
+ROUNDS = [(64, 0, 16), (80, 1, 16), (96, 2, 16), (112, 3, 16), (5, 0, 16),
+          (128, 0, 32), (160, 1, 32), (192, 2, 32), (224, 3, 32), (96, 1, 32), (240, 2, 16), (113, 3, 16)]
+
+
+@pytest.mark.parametrize("N,u,M", ROUNDS)
 @pytest.mark.parametrize("kind", ["sphere", "flat", "steep", "miss"])
 @pytest.mark.parametrize("R", [1, 7, 512])
-def test_importance_round_bit_exact(gpu, N, u, kind, R):
+def test_importance_round_bit_exact(gpu, N, u, M, kind, R):
     from ndjir_amd import lib
-    M = 16
     gain = 64.0 * 2 ** u
     t, sdf, tn, tf = _case(R, N, 100 + N + R, kind)
     t_ref = np.zeros((R, N + M), np.float32)
@@ -101,3 +107,13 @@ def test_sampler_end_to_end_indices(gpu):
         tot += b.numel()
         mis += int((a.cpu() != b).sum())
     assert mis <= 2e-3 * tot, (mis, tot)
+
+
+def test_importance_round_capacity(gpu):
+    """More than NDJIR_SAMPLER_SLOTS = 256 merged samples is refused loudly, not truncated."""
+    from ndjir_amd import lib
+    R, N, M = 4, 240, 32
+    z = lambda *s: torch.zeros(s, device=gpu)
+    with pytest.raises(RuntimeError):
+        lib.call("sampler_importance_round", R, N, M, 64.0, z(R, N), z(R, N), z(R), z(R), z(R, N + M),
+                 torch.zeros((R, M), device=gpu, dtype=torch.int32), None, None)

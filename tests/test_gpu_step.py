@@ -1,0 +1,113 @@
+"""The training step object (ndjir_amd/step.py = python/train.py:75-78, 124-148) on the GPU: sparse re-arming of the grid
+gradient buffer across redraws of the random tensors, the cos-anneal-ratio registry parameter, the object-mask loss
+path and the NaN-loss veto of the optimizer step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(gpu, overrides=(), R=32, G=32):
+    from ndjir_amd import config as cfg
+    from ndjir_amd.step import Step
+    conf = cfg.load("default", [f"geometric_network.voxel.grid_size={G}"] + list(overrides))
+    return Step(conf, R, gpu, 0, 1)
+
+
+def test_rearm_after_redraw_clears_the_previous_steps_cells(gpu):
+    """forward_backward, redraw_rand, forward_backward: the second step's grid gradient equals a run that zeroes the
+    whole buffer (the perturbed points of step 1 were formed with the noise of step 1, not the redrawn one)."""
+    step = _step(gpu)
+    gen = torch.Generator(device=gpu)
+    gen.manual_seed(5)
+    step.forward_backward()
+    step.redraw_rand(gen)
+    step.forward_backward()
+    sparse = {k: v.clone() for k, v in step.grid_bufs.items()}
+    # dense reference: same inputs (the rand tensors now hold the redrawn values), buffer fully zeroed first
+    for v in step.grid_bufs.values():
+        v.zero_()
+    step.compute(rearm=False)
+    for k, v in step.grid_bufs.items():
+        assert float(v.abs().max()) > 0
+        assert float((v - sparse[k]).abs().max()) <= 1e-6 * float(v.abs().max()), k
+    # and a third step after another redraw leaves no stale rows either
+    step.redraw_rand(gen)
+    step.forward_backward()
+    third = {k: v.clone() for k, v in step.grid_bufs.items()}
+    for v in step.grid_bufs.values():
+        v.zero_()
+    step.compute(rearm=False)
+    for k, v in step.grid_bufs.items():
+        assert float((v - third[k]).abs().max()) <= 1e-6 * float(v.abs().max()), k
+
+
+def test_step_reads_the_cos_anneal_ratio_parameter(gpu):
+    """python/train.py:75-78: the loss graph reads the registry parameter "cos_anneal_ratio", which
+    Solvers.update_cos_anneal_ratio rewrites in place (python/solver.py:100-108)."""
+    from ndjir_amd import parameter as P
+    from ndjir_amd.solver import Solvers
+    step = _step(gpu)
+    car = P.get_parameters()["cos_anneal_ratio"]
+    assert car.data_ptr() == step.car.data_ptr() and not car.requires_grad
+    l1 = float(step.forward_backward())
+    s = Solvers(step.conf)
+    s.update_cos_anneal_ratio(100)          # 0.5 cos(pi 100 / 225) + 0.5
+    want = 0.5 * np.cos(np.pi * 100 / (1500 * 0.15)) + 0.5
+    assert float(step.car) == pytest.approx(want, rel=1e-6)
+    l2 = float(step.forward_backward())
+    assert l1 != l2
+    # same value through the explicit-argument API
+    from ndjir_amd.loss import total_loss
+    out = total_loss(step.camloc, step.raydir, step.color_gt, None, torch.tensor([want], device=gpu, dtype=torch.float32),
+                     step.conf, step.rand)
+    assert float(out["loss"]) == pytest.approx(l2, rel=1e-6)
+
+
+def test_object_mask_path(gpu):
+    """train.mask_weight > 0 (python/loss.py:59-66, 107-115): Step feeds the rays' object mask; parity with the oracle."""
+    from oracle import graph as G
+    step = _step(gpu, ["train.mask_weight=0.5"], R=16)
+    rng = np.random.RandomState(3)
+    om = torch.from_numpy((rng.rand(1, 16, 1) > 0.4).astype(np.float32)).to(gpu)
+    with pytest.raises(ValueError):
+        step.set_rays(step.camloc.clone(), step.raydir.clone(), step.color_gt.clone())
+    step.set_rays(step.camloc.clone(), step.raydir.clone(), step.color_gt.clone(), om)
+    loss = float(step.forward_backward())
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in step.P.get_parameters().items()}
+    rand = {k: v.cpu() for k, v in step.rand.items()}
+    ref = G.total_loss(step.camloc.cpu(), step.raydir.cpu(), step.color_gt.cpu(), om.cpu(), step.car.detach().cpu(), rand,
+                       params, step.conf)
+    assert float(ref["loss_mask"]) > 0
+    assert loss == pytest.approx(float(ref["loss"]), rel=2e-4)
+
+
+@pytest.mark.parametrize("bad", [False, True])
+def test_nan_loss_vetoes_the_update(gpu, bad):
+    """python/train.py:144-146: a NaN loss skips the update even when at most one solver's gradients are non-finite."""
+    from ndjir_amd import lib
+    fa = torch.zeros(1, dtype=torch.int32, device=gpu)
+    fb = torch.zeros(1, dtype=torch.int32, device=gpu)
+    loss = torch.tensor([float("nan") if bad else 1.5], device=gpu)
+    lib.call("solver_veto_if_nan", 1, loss, fa, fb)
+    assert int(fa) == int(fb) == (1 if bad else 0)
+    lib.call("solver_veto_if_nan", 1, torch.tensor([float("inf")], device=gpu), fa, fb)      # inf is not NaN (np.isnan)
+    assert int(fa) == int(fb) == (1 if bad else 0)
+    # end to end through Solvers.guarded_update
+    step = _step(gpu, R=16, G=16)
+    step.enable_training()
+    step.train_step()
+    w = step.mlp_params[0].detach().clone()
+    t0 = step.solvers.solver_weight.step_count()
+    step.train_compute.__func__     # (exists)
+    s = step.solvers
+    s.zero_grad(); s.weight_decay(); s.clip_grad_by_norm()
+    step.compute(rearm=False)
+    if bad:
+        step.loss.fill_(float("nan"))
+    step.optimizer_step()
+    moved = float((step.mlp_params[0].detach() - w).abs().max()) > 0
+    assert moved == (not bad)
+    assert step.solvers.solver_weight.step_count() == t0 + (0 if bad else 1)
+    assert step.solvers.solver_weight.skipped() == bad

@@ -76,3 +76,25 @@ def test_empty_rays_miss_box():
     assert mask.flatten().tolist() == [0.0, 1.0]
     assert torch.isfinite(x_fg).all() and torch.isfinite(x_bg).all()
     np.testing.assert_allclose(x_fg[0, 0], camloc.expand(x_fg.shape[2], 3))
+
+
+@pytest.mark.parametrize("N,M", [(64, 16), (112, 16), (128, 32), (224, 32), (240, 16)])
+def test_importance_round_c_vs_torch(N, M):
+    """The C round (fixed Kogge-Stone / butterfly orders of include/ndjir_math.h, up to 256 slots) against the stock-op
+    restatement of python/sampler.py:194-240: same bins except where a CDF value sits within round-off of u."""
+    rng = np.random.RandomState(N + M)
+    R = 64
+    tn = (1.0 + rng.rand(1, R, 1, 1)).astype(np.float32)
+    tf = (tn + 1.0 + rng.rand(1, R, 1, 1)).astype(np.float32)
+    frac = ((np.arange(N)[None, :] + rng.rand(R, N)) / N).reshape(1, R, N, 1)
+    t = (tn + (tf - tn) * frac).astype(np.float32)
+    sdf = (np.abs(t - (tn + tf) / 2) - 0.35 + 0.01 * rng.randn(1, R, N, 1)).astype(np.float32)
+    a = [torch.from_numpy(x) for x in (t, sdf, tn, tf)]
+    t_c, i_c = G._importance_round_c(*a, 64.0, M)
+    t_t, i_t = G.importance_round_torch(*a, 64.0, M)
+    assert i_c.shape == i_t.shape == (1, R, M) and t_c.shape == (1, R, N + M, 1)
+    mism = float((i_c != i_t).float().mean())
+    assert mism <= 5e-3, mism
+    assert bool((t_c[:, :, 1:] >= t_c[:, :, :-1]).all())
+    same = (i_c == i_t).all(dim=2)
+    np.testing.assert_allclose(t_c[same].numpy(), t_t[same].numpy(), atol=2e-5)
