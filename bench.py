@@ -89,9 +89,30 @@ def cpu_baseline(conf, step, n_rays):
         el = time.perf_counter() - t0
         if el > 15.0 or reps >= 5:
             break
-    return dict(value=n_rays * reps / el, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{reps} x fwd+bwd of {n_rays} rays (B=1) of the same workload, oracle/graph.py torch-CPU fp32, "
-                       f"{cores} of {os.cpu_count()} host cores, {el:.1f} s")
+    out = dict(value=n_rays * reps / el, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+               sample=f"{reps} x fwd+bwd of {n_rays} rays (B=1) of the same workload, oracle/graph.py torch-CPU fp32, "
+                      f"{cores} of {os.cpu_count()} host cores, {el:.1f} s")
+    # BASELINE.json config 1 (SURVEY 8d "CPU baseline": the reference's own CPU-runnable shape, 512 rays x 64 samples =
+    # renderer.n_upsamples 0), same rays and parameters, bounded to a few seconds
+    try:
+        import copy
+        conf1 = copy.deepcopy(conf)
+        conf1.renderer.n_upsamples = 0
+        n1 = conf1.renderer.n_samples0
+        in1 = dict(inputs, rand=dict(inputs["rand"], noise=inputs["rand"]["noise"][:, :, :n1].contiguous()))
+        t0 = time.perf_counter()
+        reps1 = 0
+        while True:
+            run_oracle_step(conf1, params_cpu, in1)
+            reps1 += 1
+            el1 = time.perf_counter() - t0
+            if el1 > 6.0 or reps1 >= 4:
+                break
+        out["cfg1"] = dict(value=n_rays * reps1 / el1, unit="rays/s",
+                           sample=f"{reps1} x fwd+bwd of {n_rays} rays x {n1} samples (n_upsamples=0), {el1:.1f} s")
+    except Exception as e:
+        out["cfg1"] = dict(value=None, sample=f"failed: {type(e).__name__}: {e}")
+    return out
 
 
 def _all_ranks_ok(step, ok):

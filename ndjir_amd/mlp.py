@@ -378,6 +378,82 @@ class MultiMLP(Function):
         return (gx.reshape(xshape) if gx is not None else None, None, None, *grads)
 
 
+# ---- single dense layer, differentiable any number of times -------------------------------------------------------------
+# y = x W (+ b) is what nnabla's PF.affine computes (python/network.py:88-93).  Wherever a net is evaluated layer by layer
+# (non-softplus activations, the geometric network of configurations the fused double-backward node does not cover, the
+# per-ray term of the soft-visibility net) it goes through these three operators, which are closed under differentiation
+# and run on the same hand-written kernels as the fused chain -- no library GEMM anywhere on the path:
+#   MatMul(x, W, t)   y = x W^T if t else x W      one-layer chain launch on the packed (transposed) weights
+#   WGradOp(a, b)     Z = a^T b                    the weight-gradient kernel (reduction over the points)
+#   ColSumOp(g)       column sums                  the bias gradient
+def _mm(x2, W, transpose, bias=None):
+    P_, K = x2.shape
+    N = W.shape[0] if transpose else W.shape[1]
+    assert (W.shape[1] if transpose else W.shape[0]) == K, (tuple(x2.shape), tuple(W.shape), transpose)
+    y = torch.empty((P_, N), device=x2.device, dtype=torch.float32)
+    if P_ == 0:
+        return y
+    _launch("chain_fwd", 2.0 * P_ * K * N, "mlp_chain", 0, P_, x2, x2.shape[1], K, 1, [_packed(W, bool(transpose))],
+            [bias.detach() if bias is not None else None], [K], [N], [None], [None], [0], [None], y, N, 0, 1, 100.0, -1, 1.0, 0,
+            None, 0, None, None, shape=f"{P_}:{K}-{N}")
+    return y
+
+
+class MatMul(Function):
+    @staticmethod
+    def forward(ctx, x, W, transpose, bias):
+        ctx.save_for_backward(x, W)
+        ctx.t = bool(transpose)
+        ctx.has_bias = bias is not None
+        x2 = x.detach().reshape(-1, x.shape[-1]).contiguous()
+        y = _mm(x2, W.detach(), ctx.t, bias)
+        return y.view(x.shape[:-1] + (y.shape[-1],))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W = ctx.saved_tensors
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = MatMul.apply(gy, W, not ctx.t, None)
+        if ctx.needs_input_grad[1]:
+            x2, g2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
+            gW = WGradOp.apply(g2, x2) if ctx.t else WGradOp.apply(x2, g2)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gb = ColSumOp.apply(gy.reshape(-1, gy.shape[-1]))
+        return gx, gW, None, gb
+
+
+class WGradOp(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return wgrad(a.detach().contiguous(), b.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, gz):
+        a, b = ctx.saved_tensors
+        ga = MatMul.apply(b, gz, True, None) if ctx.needs_input_grad[0] else None      # b gz^T
+        gb = MatMul.apply(a, gz, False, None) if ctx.needs_input_grad[1] else None     # a gz
+        return ga, gb
+
+
+class ColSumOp(Function):
+    @staticmethod
+    def forward(ctx, g):
+        ctx.rows = g.shape[0]
+        return colsum(g.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, gz):
+        return gz.reshape(1, -1).expand(ctx.rows, -1)
+
+
+def linear(x, W, b=None):
+    """x (..., K) @ W (K, N) + b: PF.affine on the last axis, on the chain / wgrad / colsum kernels, differentiable to
+    any order (the layer-by-layer geometric network is differentiated twice, python/renderer.py:52)."""
+    return MatMul.apply(x, W, False, b)
+
+
 def multi_mlp(x, nets, beta=100.0):
     """nets: list of (weights, biases).  Returns one output per net (see MultiMLP)."""
     flat = []

@@ -57,8 +57,10 @@ def _glorot_uniform(shape):
 
 # Dense layers run through the fused MFMA chain kernel (ndjir_amd/mlp.py) wherever only
 # first-order gradients are needed; the geometric network's main pass (differentiated twice through
-# nn.grad) still runs layer by layer.  `USE_FUSED = False` forces the layer-by-layer GPU path
-# everywhere (debugging / A-B timing only; both paths run on the GPU).
+# nn.grad) is one fused operator (ndjir_amd/geometric.py) for every shipped configuration and runs layer by
+# layer otherwise (use_ste, relu, no geometric init).  `USE_FUSED = False` forces the layer-by-layer path
+# everywhere (debugging / A-B timing only).  Both paths run on this package's own kernels: a single layer is
+# `mlp.linear` (one-layer chain launch; weight-gradient and column-sum kernels in backward), never a library GEMM.
 USE_FUSED = True
 
 
@@ -75,7 +77,8 @@ def affine(h, D, use_wn=False, w_init=None, b_init=None, name=None):
     """network.py:88-93: PF.affine on the last axis inside parameter scope `name`/affine."""
     Din = h.shape[-1]
     W, b = affine_params(Din, D, use_wn, w_init, b_init, name)
-    return torch.addmm(b, h.reshape(-1, Din), W).view(h.shape[:-1] + (D,))
+    from .mlp import linear
+    return linear(h, W, b)
 
 
 def _run_mlp(h, Ws, bs, act, skip_layer=-1, skip_scale=1.0, inputs=None):
@@ -83,8 +86,9 @@ def _run_mlp(h, Ws, bs, act, skip_layer=-1, skip_scale=1.0, inputs=None):
     if USE_FUSED and act is softplus:
         from .mlp import fused_mlp
         return fused_mlp(h, Ws, bs, 100.0, skip_layer, skip_scale)
+    from .mlp import linear
     for j, (W, b) in enumerate(zip(Ws, bs)):
-        h = torch.addmm(b, h.reshape(-1, h.shape[-1]), W).view(h.shape[:-1] + (W.shape[1],))
+        h = linear(h, W, b)          # own one-layer kernels (no library GEMM), see ndjir_amd/mlp.py
         if j < len(Ws) - 1:
             h = act(h)
             if j == skip_layer:
@@ -285,8 +289,9 @@ def geometric_network(x, conf, first_order_only=False, sdf_only=False):
             if first_order_only and USE_FUSED and act is softplus:
                 h = _run_mlp(inputs, Ws, bs, act, skip_at, scale)
             else:
+                from .mlp import linear
                 for l in range(L):
-                    h = torch.addmm(bs[l], h.reshape(-1, h.shape[-1]), Ws[l]).view(h.shape[:-1] + (Ws[l].shape[1],))
+                    h = linear(h, Ws[l], bs[l])
                     if l < L - 1:
                         h = act(h)
                         if l == skip_at:
@@ -413,8 +418,8 @@ def soft_visibility_light_network(x, light_dirs, feature, normal, conf):
                                  conf.use_wn)
             ray_in = torch.cat([t[:, :, 0, :] for t in per_ray], dim=-1)
             W0_ray = torch.cat([Ws[0][:nx], Ws[0][nx + npe:]], dim=0)
-            row_term = torch.addmm(bs[0], ray_in.reshape(B * R, -1), W0_ray).view(B, R, -1)
-            from .mlp import fused_mlp
+            from .mlp import fused_mlp, linear
+            row_term = linear(ray_in.reshape(B * R, -1), W0_ray, bs[0]).view(B, R, -1)
             h = fused_mlp(pe, [Ws[0][nx:nx + npe]] + Ws[1:], [None] + bs[1:], 100.0, row_bias=row_term, row_bias_div=M)
         else:
             per_ray = [t.expand(t.shape[0], t.shape[1], pe.shape[2], t.shape[3]) for t in per_ray]

@@ -252,3 +252,30 @@ def test_fused_mlp_row_bias(gpu, P, div, K0, Dh, No):
     g32 = torch.autograd.grad(y32, a32, g.float())
     for i, (a, b) in enumerate(zip(g32, g64)):
         assert _rel(a, b.cpu()) < 2e-5, i
+
+
+@pytest.mark.parametrize("P,K,N", [(512, 262, 128), (100, 43, 256), (7, 3, 5), (4096, 256, 257)])
+def test_linear_is_twice_differentiable(gpu, P, K, N):
+    """mlp.linear (PF.affine, python/network.py:88-93) on the chain / wgrad / colsum kernels: value, first derivatives and
+    the derivative of a gradient-dependent scalar (the nn.grad pattern of python/renderer.py:52) against fp64 autograd."""
+    from ndjir_amd.mlp import linear
+    from tests.parity_utils import rel_err
+    g = torch.Generator(device="cpu").manual_seed(P + K)
+    x64 = torch.randn(P, K, generator=g, dtype=torch.float64).requires_grad_(True)
+    W64 = (torch.randn(K, N, generator=g, dtype=torch.float64) / K ** 0.5).requires_grad_(True)
+    b64 = torch.randn(N, generator=g, dtype=torch.float64).requires_grad_(True)
+    c64 = torch.randn(P, N, generator=g, dtype=torch.float64)
+
+    def run(x, W, b, c, lin):
+        y = torch.tanh(lin(x, W, b))
+        (gx,) = torch.autograd.grad((y * c).sum(), x, create_graph=True)      # first-order graph, kept differentiable
+        loss = (gx * gx).sum() + (y * y).sum()
+        return y, gx, torch.autograd.grad(loss, [x, W, b])
+    y64, gx64, gg64 = run(x64, W64, b64, c64, lambda x, W, b: x @ W + b)
+    x = x64.detach().float().to(gpu).requires_grad_(True)
+    W = W64.detach().float().to(gpu).requires_grad_(True)
+    b = b64.detach().float().to(gpu).requires_grad_(True)
+    y, gx, gg = run(x, W, b, c64.float().to(gpu), linear)
+    assert rel_err(y, y64) < 2e-6 and rel_err(gx, gx64) < 5e-6
+    for a, r, name in zip(gg, gg64, "xWb"):
+        assert rel_err(a, r) < 2e-5, (name, rel_err(a, r))
