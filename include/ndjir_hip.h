@@ -341,7 +341,10 @@ int ndjir_positional_encoding_backward(long long P, int C, int M, int include_in
  * gradient of that concatenation: columns >= skip_split go (scaled) to Xskip. */
 #define NDJIR_MATH_FP32 0     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 vector rate */
 #define NDJIR_MATH_BF16X6 1   /* x = hi + mid + lo in bf16 (exact), six bf16 MFMA partial products accumulated in
-                                 fp32: ~2^-24 relative error like an fp32 FMA chain, 6/16 of the matrix time (default) */
+                                 fp32: ~2^-24 relative error like an fp32 FMA chain, 6/16 of the matrix time */
+#define NDJIR_MATH_F16X3 2    /* x s = hi + lo 2^-11 in f16 (s: power of two per scaling group), three f16 MFMA partial
+                                 products in two fp32 accumulators: 22 significant bits per operand, error below an fp32
+                                 FMA chain's, 3/16 of the matrix time (default) */
 int ndjir_mlp_set_math(int math);   /* selects the arithmetic of pack / chain; packed weights are mode specific */
 int ndjir_mlp_get_math(void);
 long long ndjir_mlp_packed_size(int K, int N, int transpose);
@@ -351,7 +354,11 @@ int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L
                     const float* const* side_in, float* const* side_out, const int* ld_side,
                     float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                     int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
-                    float* in_bgrad, float* workspace, hipStream_t stream);
+                    float* in_bgrad, float* workspace, unsigned* const* side_amax, unsigned* x_amax, hipStream_t stream);
+/* side_amax (host array of L device pointers, or null; entries may be null) / x_amax (device pointer or null): slots
+ * that receive, by atomic max, the bit pattern of the largest finite |value| written to side_out[i] / read from X.
+ * The caller zeroes them.  NDJIR_MATH_F16X3 only (ignored otherwise): ndjir_mlp_wgrad takes them as the scales of its
+ * operands, which saves it a pass over the tensors. */
 long long ndjir_mlp_chain_workspace(int bgrad_total);   /* floats */
 /* Extended chain used by the geometric network, whose output gradient d(sdf)/dx itself enters the
  * loss (nn.grad, python/renderer.py:52; eikonal term python/loss.py:68-76):
@@ -367,7 +374,8 @@ int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx, int K0, i
                        float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                        int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                        const float* const* side_in2, const float* const* side_add, float* const* side_out2,
-                       const float* row_bias, int row_bias_div, float* in_bgrad, float* workspace, hipStream_t stream);
+                       const float* row_bias, int row_bias_div, float* in_bgrad, float* workspace,
+                       unsigned* const* side_amax, unsigned* x_amax, hipStream_t stream);
 /* row_bias (mode 0, may be null): (P / row_bias_div, N_0) term added to the first layer's pre-activation of every
  * group of row_bias_div consecutive rows -- the part of x W_0 that is constant over a group (e.g. the per-ray inputs
  * of the soft-visibility net, python/network.py:339-377, whose other inputs vary per light direction): it is
@@ -377,10 +385,12 @@ int ndjir_mlp_group_colsum(const float* X, int ldx, int N, long long G, int div,
 /* Weight gradient of one layer: out (K x N) (+)= A^T B with A (P x K, row stride lda) the layer's
  * input activations and B (P x N, row stride ldb) its deltas (ndjir_amd/csrc/wgrad.hip; the
  * reference gets this from nnabla's affine backward, a cuBLAS GEMM).  `workspace` needs
- * ndjir_mlp_wgrad_workspace(K, N, P) floats (split-P partial sums). */
+ * ndjir_mlp_wgrad_workspace(K, N, P) floats (split-P partial sums).  amax_a / amax_b (device, may be null):
+ * recorded maxima of A / B (see ndjir_mlp_chain; any upper bound of the largest finite magnitude will do) -- the
+ * operand scales of NDJIR_MATH_F16X3; null = found by one extra pass over the tensor. */
 long long ndjir_mlp_wgrad_workspace(int K, int N, long long P);
 int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out,
-                    int accum, float* workspace, hipStream_t stream);
+                    int accum, float* workspace, const unsigned* amax_a, const unsigned* amax_b, hipStream_t stream);
 /* Bias gradient of a layer: out (N) (+)= column sums of its deltas X (P x N, row stride ldx); the
  * reference gets it from nnabla's affine backward (a reduction kernel per layer). */
 long long ndjir_mlp_colsum_workspace(int N, long long P);   /* floats */

@@ -11,13 +11,14 @@ using namespace ndjir;
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // Matrix arithmetic of the chain engine: NDJIR_MATH_FP32 = v_mfma_f32_32x32x2_f32 (mlp.hip),
-// NDJIR_MATH_BF16X6 = three-way bf16 split, six v_mfma_f32_32x32x16_bf16 partial products (mlp6.hip):
-// the same ~2^-24 accuracy at 6/16 of the matrix time.  Packed weights are specific to the mode that
-// was active when they were packed.
-static int g_math = NDJIR_MATH_BF16X6;
+// NDJIR_MATH_BF16X6 = three-way bf16 split, six v_mfma_f32_32x32x16_bf16 partial products (mlp6.hip),
+// NDJIR_MATH_F16X3 = scaled two-way f16 split, three v_mfma_f32_32x32x16_f16 partial products (mlp3.hip; default):
+// all at fp32-FMA-chain accuracy or better, at 16/16, 6/16 and 3/16 of the fp32 matrix time.  Packed weights are
+// specific to the mode that was active when they were packed.
+static int g_math = NDJIR_MATH_F16X3;
 
 extern "C" int ndjir_mlp_set_math(int math) {
-  if (math != NDJIR_MATH_FP32 && math != NDJIR_MATH_BF16X6) return NDJIR_ERR_ARG;
+  if (math != NDJIR_MATH_FP32 && math != NDJIR_MATH_BF16X6 && math != NDJIR_MATH_F16X3) return NDJIR_ERR_ARG;
   g_math = math;
   return NDJIR_OK;
 }
@@ -26,6 +27,7 @@ extern "C" int ndjir_mlp_get_math(void) { return g_math; }
 
 extern "C" long long ndjir_mlp_packed_size(int K, int N, int transpose) {
   if (g_math == NDJIR_MATH_BF16X6) return packed_size6(K, N, transpose);
+  if (g_math == NDJIR_MATH_F16X3) return packed_size3(K, N, transpose);
   int Kp = round_up(transpose ? N : K, 8), Np = round_up(transpose ? K : N, 32);
   return (long long)Kp * Np;
 }
@@ -33,6 +35,7 @@ extern "C" long long ndjir_mlp_packed_size(int K, int N, int transpose) {
 extern "C" int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream) {
   if (!W || !dst || K <= 0 || N <= 0) return NDJIR_ERR_ARG;
   if (g_math == NDJIR_MATH_BF16X6) return launch_pack6(W, dst, K, N, transpose, stream);
+  if (g_math == NDJIR_MATH_F16X3) return launch_pack3(W, dst, K, N, transpose, stream);
   return launch_pack(W, dst, K, N, transpose, stream);
 }
 
@@ -45,7 +48,7 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
                                int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                                const float* const* side_in2, const float* const* side_add, float* const* side_out2,
                                const float* row_bias, int row_bias_div, float* in_bgrad, float* workspace,
-                               hipStream_t stream) {
+                               unsigned* const* side_amax, unsigned* x_amax, hipStream_t stream) {
   if (P <= 0) {
     if (bwd != 0 && in_bgrad && K0 > 0 && hipMemsetAsync(in_bgrad, 0, (size_t)K0 * sizeof(float), stream) != hipSuccess)
       return NDJIR_ERR_LAUNCH;
@@ -67,6 +70,7 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
   if (row_bias && (bwd != 0 || L < 2 || row_bias_div < 1)) return NDJIR_ERR_ARG;
   a.row_bias = row_bias; a.row_bias_div = row_bias_div;
   a.in_bgrad = (bwd != 0) ? in_bgrad : nullptr;
+  a.x_amax = x_amax;
   a.P = P; a.X = X; a.ldx = ldx; a.K0 = K0; a.K0p = round_up(K0, 8); a.L = L;
   a.Y = Y; a.ldy = ldy; a.accum_y = accum_y; a.has_output = has_output; a.beta = beta;
   a.skip_layer = skip_layer; a.skip_scale = skip_scale; a.skip_split = skip_split; a.Xskip = Xskip; a.ld_xskip = ld_xskip;
@@ -82,6 +86,7 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
     ly.side_in2 = side_in2 ? side_in2[i] : nullptr;
     ly.side_add = side_add ? side_add[i] : nullptr;
     ly.side_out2 = side_out2 ? side_out2[i] : nullptr;
+    ly.side_amax = side_amax ? side_amax[i] : nullptr;
     ly.K = Ks[i]; ly.N = Ns[i]; ly.Kp = round_up(Ks[i], 8); ly.Np = round_up(Ns[i], 32);
     ly.ld_side = ld_side ? ld_side[i] : Ns[i];
     const bool last = has_output && (i == L - 1);
@@ -94,6 +99,7 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
     if (bwd != 1 && i == skip_layer) kin = ly.N + K0;
     if (bwd == 1 && i == skip_layer) kin = skip_split;
   }
+  if (g_math == NDJIR_MATH_F16X3) return launch_chain3(a, bwd, stream);
   if (g_math == NDJIR_MATH_BF16X6) return launch_chain6(a, bwd, stream);
   return launch_chain(a, bwd, stream);
 }
@@ -103,11 +109,12 @@ extern "C" int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, in
                                const float* const* side_in, float* const* side_out, const int* ld_side,
                                float* const* bgrad, float* Y, int ldy, int accum_y, int has_output, float beta,
                                int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
-                               float* in_bgrad, float* workspace, hipStream_t stream) {
+                               float* in_bgrad, float* workspace, unsigned* const* side_amax, unsigned* x_amax,
+                               hipStream_t stream) {
   if (bwd != 0 && bwd != 1) return NDJIR_ERR_ARG;
   return chain_impl(bwd, P, X, ldx, K0, L, Wp, bias, Ks, Ns, side_in, side_out, ld_side, bgrad, Y, ldy, accum_y,
                     has_output, beta, skip_layer, skip_scale, skip_split, Xskip, ld_xskip, nullptr, nullptr, nullptr, nullptr, 0,
-                    in_bgrad, workspace, stream);
+                    in_bgrad, workspace, side_amax, x_amax, stream);
 }
 
 // Extended form used by the geometric network's double backward (python/renderer.py:52 nn.grad):
@@ -119,11 +126,11 @@ extern "C" int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx
                                   int skip_layer, float skip_scale, int skip_split, float* Xskip, int ld_xskip,
                                   const float* const* side_in2, const float* const* side_add, float* const* side_out2,
                                   const float* row_bias, int row_bias_div, float* in_bgrad, float* workspace,
-                                  hipStream_t stream) {
+                                  unsigned* const* side_amax, unsigned* x_amax, hipStream_t stream) {
   if (mode < 0 || mode > 2) return NDJIR_ERR_ARG;
   return chain_impl(mode, P, X, ldx, K0, L, Wp, bias, Ks, Ns, side_in, side_out, ld_side, bgrad, Y, ldy, accum_y,
                     has_output, beta, skip_layer, skip_scale, skip_split, Xskip, ld_xskip, side_in2, side_add, side_out2,
-                    row_bias, row_bias_div, in_bgrad, workspace, stream);
+                    row_bias, row_bias_div, in_bgrad, workspace, side_amax, x_amax, stream);
 }
 
 extern "C" long long ndjir_mlp_chain_workspace(int bgrad_total) { return chain_workspace(bgrad_total); }
@@ -131,10 +138,11 @@ extern "C" long long ndjir_mlp_chain_workspace(int bgrad_total) { return chain_w
 extern "C" long long ndjir_mlp_wgrad_workspace(int K, int N, long long P) { return wgrad_workspace(K, N, P); }
 
 extern "C" int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out,
-                               int accum, float* workspace, hipStream_t stream) {
+                               int accum, float* workspace, const unsigned* amax_a, const unsigned* amax_b,
+                               hipStream_t stream) {
   if (P <= 0) return NDJIR_OK;
   if (!A || !B || !out || !workspace || lda < K || ldb < N) return NDJIR_ERR_ARG;
-  return launch_wgrad(A, lda, B, ldb, K, N, P, out, accum, workspace, g_math == NDJIR_MATH_BF16X6, stream);
+  return launch_wgrad(A, lda, B, ldb, K, N, P, out, accum, workspace, g_math, amax_a, amax_b, stream);
 }
 
 extern "C" long long ndjir_mlp_colsum_workspace(int N, long long P) { return colsum_workspace(N, P); }

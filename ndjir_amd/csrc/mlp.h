@@ -15,6 +15,7 @@ struct ChainLayer {
   float* side_out2;     // tangent: extra adjoint beta * z * s * exp(-beta h)
   float* side_out;      // forward: activation store (P x N); backward: delta store (P x N)
   float* bgrad;         // backward: bias gradient (N): column sums of this layer's delta (overwritten)
+  unsigned* side_amax;  // f16x3 engine: atomicMax of the largest finite |side_out| (bit pattern; caller zeroes), may be null
   int bg_off;           // filled by launch_chain: offset of this layer in the workgroup's LDS accumulator
   int K, N;             // logical dims of this GEMM (input width, output width)
   int Kp, Np;           // padded: Kp % 8 == 0, Np % 32 == 0
@@ -45,6 +46,7 @@ struct ChainArgs {
   int in_bg_off;          // filled by launch_chain
   float* bg_partial;    // bias gradients: per-workgroup partial sums [grid][bg_total] (workspace)
   int bg_total, bg_lds; // filled by launch_chain: accumulator floats / its offset in LDS
+  unsigned* x_amax;     // f16x3 engine: atomicMax of the largest finite |X| (bit pattern; caller zeroes), may be null
   long long* timeline;  // diagnostics (tools/chain_timeline.py): per-layer phase stamps of workgroup 0, else null
   ChainLayer layers[MAX_CHAIN_LAYERS];
 };
@@ -56,11 +58,16 @@ int launch_bgrad_reduce(const float* partial, int S, int total, float* const* pt
 long long packed_size6(int K, int N, int transpose);   // in floats (for allocation through the same API)
 int launch_pack6(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
 int launch_chain6(const ChainArgs& a, int mode, hipStream_t stream);
+// f16 2-way-split engine (mlp3.hip): same ChainArgs, weights packed by launch_pack3 (per-column-block scales inside)
+long long packed_size3(int K, int N, int transpose);
+int launch_pack3(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
+int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream);
 constexpr int CHAIN_MAX_GRID_BG = 512;   // workgroups of a chain launch that produces bias gradients
 inline long long chain_workspace(int bg_total) { return (long long)CHAIN_MAX_GRID_BG * bg_total; }
 long long wgrad_workspace(int K, int N, long long P);
+// math: 0 fp32 MFMA, 1 bf16x6, 2 f16x3 (amax_a / amax_b: recorded maxima of A / B, null = computed by a pre-pass)
 int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out, int accum,
-                 float* workspace, int bf16x6, hipStream_t stream);
+                 float* workspace, int math, const unsigned* amax_a, const unsigned* amax_b, hipStream_t stream);
 
 long long colsum_workspace(int N, long long P);
 int launch_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, hipStream_t stream);

@@ -1,0 +1,774 @@
+// mlp3.hip -- the fused MLP chain on the f16 matrix cores: two-way split operands, three partial products.
+//
+// gfx950 runs fp32-input MFMA at the fp32 VECTOR rate; 16-bit MFMA is 16x faster.  mlp6.hip splits every
+// fp32 operand exactly into three bf16 planes (8 + 8 + 8 bits) and pays six partial products.  Here each
+// operand is scaled by a power of two (exact) into the fp16 range and split into TWO fp16 planes
+//     x s = hi + lo 2^-11,   hi = fp16(x s),   lo = fp16((x s - hi) 2^11)          (11 + 11 significant bits)
+// and a product is formed from THREE partial products in two fp32 accumulators
+//     acc0 += hi hi'            acc1 += hi lo' + lo hi'            z = (acc0 + acc1 2^-11) / (s s')
+// (lo lo' ~ 2^-22 of the product is dropped; each partial product is an exact fp16 x fp16 product accumulated
+// in fp32 by v_mfma_f32_32x32x16_f16).  Keeping lo pre-scaled by 2^11 puts it in hi's exponent range, so every
+// element within 2^-28 of the largest one of its scaling group keeps all 22 bits; smaller ones degrade
+// gracefully (absolute error <= 2^-39 of the group maximum).  Scaling groups: a 32-column block of a packed
+// weight matrix (scale fixed at pack time, stored behind the planes), and one tile of points x all features
+// for the activations (the tile maximum is reduced in LDS between the activation math and the split).
+// Accuracy (tests/test_gpu_mlp.py, vs fp64): below a plain fp32 FMA chain's, at 3/16 of the fp32 MFMA time
+// and half of mlp6's -- operand rounding 2^-23 sits under the fp32 accumulation error that every fp32 GEMM has.
+//
+// Structure per tile of TM points, 8 waves (as mlp6.hip, with the epilogue cut in two at the tile maximum):
+//   for every layer:  k-loops of all column blocks (accumulator pairs stay in registers)
+//                     phase A per 32x32 block: acc0 + acc1 2^-11 -> per-wave fp32 staging tile in LDS -> row-major
+//                       pass (bias + softplus / softplus' product, coalesced float4 side stores and loads,
+//                       bias-gradient column sums); results parked in registers; running maximum
+//                     tile maximum -> LDS; barrier (every wave has also finished reading the planes)
+//                     phase B: scale from the maximum, 2-way split, planes updated in place
+//                     barrier
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "mlp.h"
+
+namespace ndjir {
+namespace x3 {
+
+constexpr int NWAVES = 8;
+constexpr int NTHREADS = NWAVES * 64;
+constexpr int MAXNB = 16;        // widest layer: 512 columns (2 column blocks per wave)
+constexpr int GPS = 32 * 4 + 4;  // staging tile: dwords per group of 4 columns (32 rows + pad)
+constexpr int STG = 8 * GPS;     // staging dwords per wave (32 x 32 tile)
+constexpr int IN_CACHE = 10;     // float4 groups of the chain input a thread keeps between the max pass and the split
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+__device__ __forceinline__ int pin(int v) {
+  v = __builtin_amdgcn_readfirstlane(v);
+  asm volatile("" : "+s"(v));
+  return v;
+}
+__device__ __forceinline__ float pin(float v) { return __int_as_float(pin(__float_as_int(v))); }
+template <class T>
+using gptr = T __attribute__((address_space(1)))*;
+template <class T>
+__device__ __forceinline__ gptr<T> pin(T* p) {
+  asm volatile("" : "+s"(p));
+  return (gptr<T>)p;
+}
+
+// Power-of-two scale that puts a group whose largest finite magnitude has bit pattern `mbits` at [2^14, 2^15);
+// inv = 1 / s exactly.  An all-zero group gets a large harmless scale.
+__host__ __device__ __forceinline__ void scale_from_max(unsigned mbits, float& s, float& inv) {
+  int E = (int)(mbits >> 23);
+  if (E < 1) E = 1;
+  int se = 268 - E;                  // biased exponent of s: max * s = 1.x * 2^14
+  if (se > 253) se = 253;
+  if (se < 1) se = 1;
+  union { int i; float f; } a, b;
+  a.i = se << 23;
+  b.i = (254 - se) << 23;
+  s = a.f;
+  inv = b.f;
+}
+
+// |v| as ordered bits, Inf / NaN ignored (they stay confined to their own rows; the group's scale is taken from
+// the finite values)
+__device__ __forceinline__ unsigned finite_abs_bits(float v) {
+  const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+  return b < 0x7f800000u ? b : 0u;
+}
+
+__device__ __forceinline__ float wave_max(float m) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  return m;
+}
+
+// ---- weight packing -----------------------------------------------------------------------------
+// dst (16-byte units): [Np/32][Kp/16][plane 0..1][lane 0..63], lane (c = lane & 31, h = lane >> 5) holds
+// W[16 ks + 8 h + j][32 nb + c] * s_nb, j = 0..7, of plane p (0 = hi, 1 = lo * 2^11); behind the planes, at float
+// offset Kp * Np: 1 / s_nb for every column block.  One workgroup per column block: slab maximum, then the split.
+// transpose packs W^T.
+__global__ void __launch_bounds__(256) k_pack3(const float* __restrict__ W, _Float16* __restrict__ dst, float* __restrict__ inv_out,
+                                               int K, int N, int transpose, int Kp, int Np) {
+  __shared__ unsigned red[256];
+  const int nb = blockIdx.x;
+  const int KS = Kp >> 4;
+  const int total = Kp * 32;
+  auto value = [&](int t) -> float {
+    int k, c;
+    if (!transpose) { c = t & 31; k = t >> 5; } else { k = t % Kp; c = t / Kp; }     // contiguous axis fastest
+    const int n = nb * 32 + c;
+    float v = 0.f;
+    if (!transpose) { if (k < K && n < N) v = W[(long long)k * N + n]; }
+    else { if (k < N && n < K) v = W[(long long)n * N + k]; }
+    return v;
+  };
+  unsigned m = 0;
+  for (int t = threadIdx.x; t < total; t += 256) { const unsigned b = finite_abs_bits(value(t)); m = b > m ? b : m; }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { const unsigned o = red[threadIdx.x + s]; if (o > red[threadIdx.x]) red[threadIdx.x] = o; }
+    __syncthreads();
+  }
+  float sc, inv;
+  scale_from_max(red[0], sc, inv);
+  if (threadIdx.x == 0) inv_out[nb] = inv;
+  for (int t = threadIdx.x; t < total; t += 256) {
+    int k, c;
+    if (!transpose) { c = t & 31; k = t >> 5; } else { k = t % Kp; c = t / Kp; }
+    const float xs = value(t) * sc;
+    const _Float16 hi = (_Float16)xs;
+    const _Float16 lo = (_Float16)((xs - (float)hi) * LO_SCALE);
+    const int ks = k >> 4, lane = c + 32 * ((k & 15) >> 3), j = k & 7;
+    const long long base = (((long long)nb * KS + ks) * 2) * 64 * 8 + lane * 8 + j;
+    dst[base] = hi;
+    dst[base + 64 * 8] = lo;
+  }
+}
+
+// ---- the chain kernel ---------------------------------------------------------------------------
+template <int MODE, int TM>
+__global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
+  constexpr bool BWD = (MODE == 1);
+  constexpr int RB = TM / 32;
+  constexpr int TMP = TM + 4;          // rows per k-group incl. pad: (TMP * 16) % 256 == 64 -> conflict-free plane writes
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ unsigned s_tmax[4];       // [0], [1]: tile maximum of the layer outputs (ping-pong); [2]: of the chain input
+  const int PLANE = a.lds_split;       // 16-byte units per plane ( = k-groups * TMP )
+  f16x8* act = reinterpret_cast<f16x8*>(lds);
+  char* actb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  float* stage_all = lds + (size_t)2 * PLANE * 4;
+  float* stage = stage_all + wave * STG;
+  float* bsum = lds + a.bg_lds;
+  const float beta = a.beta;
+  auto stamp = [&](int li, int phase) {
+    if (a.timeline && blockIdx.x == 0 && lane == 0) a.timeline[(li * 5 + phase) * NWAVES + wave] = (long long)__builtin_amdgcn_s_memtime();
+  };
+  // write 4 consecutive features k..k+3 (k % 4 == 0) of row m, scaled by s, into the two planes
+  auto put4 = [&](int k, int m, f32x4 v, float s) {
+    const f32x4 xs = v * s;
+    const f16x4 ph = __builtin_convertvector(xs, f16x4);
+    const f32x4 res = (xs - __builtin_convertvector(ph, f32x4)) * LO_SCALE;
+    const f16x4 pl = __builtin_convertvector(res, f16x4);
+    char* p = actb + ((size_t)((k >> 3) * TMP + m) * 16 + (k & 7) * 2);
+    *reinterpret_cast<f16x4*>(p) = ph;
+    *reinterpret_cast<f16x4*>(p + (size_t)PLANE * 16) = pl;
+  };
+  auto put1 = [&](int k, int m, float v, float s) {
+    const float xs = v * s;
+    const _Float16 ph = (_Float16)xs;
+    const _Float16 pl = (_Float16)((xs - (float)ph) * LO_SCALE);
+    char* p = actb + ((size_t)((k >> 3) * TMP + m) * 16 + (k & 7) * 2);
+    *reinterpret_cast<_Float16*>(p) = ph;
+    *reinterpret_cast<_Float16*>(p + (size_t)PLANE * 16) = pl;
+  };
+
+  if (MODE != 0) for (int i = tid; i < a.bg_total; i += NTHREADS) bsum[i] = 0.f;
+  if (tid < 4) s_tmax[tid] = 0u;
+  __syncthreads();
+
+  for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const long long row0 = tile * TM;
+    const int rows = (int)((a.P - row0) < TM ? (a.P - row0) : TM);
+    float a_inv;                 // 1 / scale of the planes the next k-loop reads
+    float x_max;                 // largest finite |x| of the chain input tile
+
+    // ---- chain input tile -> planes (zero padded to a multiple of 16 features) ----
+    {
+      const int K0p = a.K0p, K0 = a.K0;
+      const float* X = a.X + row0 * a.ldx;
+      int groups = K0p >> 2;
+      // (opaque to the optimiser: the per-thread addresses below are tile-invariant, and hoisted out of the tile loop
+      // they would sit in -- spilled -- registers for the whole kernel)
+      asm volatile("" : "+s"(groups));
+      const int total = groups * TM;
+      const bool vec = (a.ldx & 3) == 0 && ((uintptr_t)a.X & 15) == 0;
+      auto load = [&](int t) -> f32x4 {
+        const int g = t % groups, m = t / groups;
+        const int k = g * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < rows) {
+          if (vec && k + 3 < K0) v = *reinterpret_cast<const f32x4*>(X + (long long)m * a.ldx + k);
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (k + q < K0) v[q] = X[(long long)m * a.ldx + k + q];
+          }
+        }
+        return v;
+      };
+      f32x4 cache[IN_CACHE];
+      unsigned mb = 0;
+#pragma unroll
+      for (int i = 0; i < IN_CACHE; ++i) {
+        const int t = tid + i * NTHREADS;
+        cache[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < total) cache[i] = load(t);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const unsigned b = finite_abs_bits(cache[i][q]); mb = b > mb ? b : mb; }
+      }
+      for (int t = tid + IN_CACHE * NTHREADS; t < total; t += NTHREADS) {
+        const f32x4 v = load(t);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const unsigned b = finite_abs_bits(v[q]); mb = b > mb ? b : mb; }
+      }
+      const float wm = wave_max(__uint_as_float(mb));
+      if (lane == 0) atomicMax(&s_tmax[2], __float_as_uint(wm));
+      __syncthreads();
+      const unsigned mbits = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tmax[2]);
+      x_max = __uint_as_float(mbits);
+      float s_in;
+      scale_from_max(mbits, s_in, a_inv);
+      if (tid == 0 && a.x_amax) atomicMax(a.x_amax, mbits);
+      auto emit = [&](int t, f32x4 v) {
+        const int g = t % groups, m = t / groups;
+        const int k = g * 4;
+        put4(k, m, v, s_in);
+        if (MODE != 0 && a.in_bgrad && m < rows) {      // bias gradient of the output layer: column sums of the input
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (k + q < K0) atomicAdd(bsum + a.in_bg_off + k + q, v[q]);
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < IN_CACHE; ++i) {
+        const int t = tid + i * NTHREADS;
+        if (t < total) emit(t, cache[i]);
+      }
+      for (int t = tid + IN_CACHE * NTHREADS; t < total; t += NTHREADS) emit(t, load(t));
+    }
+    __syncthreads();
+    if (tid == 0) s_tmax[2] = 0u;        // next use: the next tile's input stage, many barriers away
+
+    int cur = 0;                         // ping-pong slot of the layer's tile maximum
+    for (int li = 0; li < a.L; ++li) {
+      const ChainLayer& ly = a.layers[li];
+      const int KS = (ly.Kp + 15) >> 4;          // k-steps of 16 (planes are zero beyond Kp)
+      const int NB = ly.Np >> 5;
+      const bool last = a.has_output && (li == a.L - 1);
+      stamp(li, 0);
+      const gptr<const f16x8> p_wp = (gptr<const f16x8>)pin(ly.Wp);
+      const gptr<const float> p_winv = pin(ly.Wp + (long long)KS * 16 * ly.Np);   // [NB] behind the planes
+      const gptr<const float> p_bias = pin(ly.bias);
+      // forward, first layer only: per-row-group additive term (the part of x W_0 that is constant over a group)
+      const gptr<const float> p_rowbias = pin((MODE == 0 && li == 0) ? a.row_bias : nullptr);
+      const int rb_div = pin(a.row_bias_div > 0 ? a.row_bias_div : 1);
+      const gptr<const float> p_side_in = pin(ly.side_in);
+      const gptr<const float> p_side_in2 = pin(ly.side_in2);
+      const gptr<const float> p_side_add = pin(ly.side_add);
+      const gptr<float> p_side_out = pin(ly.side_out);
+      const gptr<float> p_side_out2 = pin(ly.side_out2);
+      float* const p_bgrad = (MODE != 0 && ly.bgrad) ? bsum + pin(ly.bg_off) : nullptr;
+      const int l_N = pin(ly.N);
+      const int l_ld = pin(ly.ld_side);
+      const bool is_skip = (li == a.skip_layer);
+      const float sc = pin(is_skip ? a.skip_scale : 1.f);
+      const int nlim = pin((BWD && is_skip) ? a.skip_split : l_N);
+      const float ainv = pin(a_inv);
+
+      // one k-loop: RBU row blocks of column block nb, accumulator pairs acc0/acc1[SLOT .. SLOT + RBU)
+      // Two accumulator-pair slots; a wave's (at most 4) output blocks are processed in rounds of two: k-loops, then
+      // phase A, which parks the results -- 128 accumulator registers for four blocks would not leave room for them.
+      f32x16 acc0[2], acc1[2];   // static indices only (an accumulator array indexed under run-time branches goes to scratch)
+      auto kloop = [&](auto rbu_tag, auto slot_tag, const int nb, const int rb0, const int ks0, const int ks1) {
+        constexpr int RBU = decltype(rbu_tag)::value;
+        constexpr int SLOT = decltype(slot_tag)::value;
+#pragma unroll
+        for (int q = 0; q < RBU; ++q) { acc0[SLOT + q] = f32x16{0}; acc1[SLOT + q] = f32x16{0}; }
+        const gptr<const f16x8> Bp = p_wp + ((long long)nb * KS) * 2 * 64 + lane;
+        const f16x8* A0 = act + h * TMP + rb0 * 32 + r;
+        // Software pipeline (static register slots, unrolled by 3): weight fragments 3 steps ahead, activation
+        // fragments one step ahead (double buffered).
+        f16x8 b[3][2];                 // [slot][plane]
+        f16x8 af[2][2][RBU];           // [buffer][plane][row block]
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) b[s][p] = Bp[(long long)((ks0 + s < ks1 ? ks0 + s : ks0) * 2 + p) * 64];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+          const f16x8* An = A0 + 2 * ks0 * TMP;
+#pragma unroll
+          for (int q = 0; q < RBU; ++q) { af[0][0][q] = An[q * 32]; af[0][1][q] = An[PLANE + q * 32]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto kstep = [&](auto stag, auto btag, auto gtag, const int ks) {
+          constexpr int S = decltype(stag)::value;       // weight slot
+          constexpr int C = decltype(btag)::value;       // activation buffer
+          constexpr bool GUARD = decltype(gtag)::value;
+          const bool nxt = !GUARD || ks + 1 < ks1;
+          const f16x8* An = A0 + 2 * (ks + 1) * TMP;
+          if (nxt) {
+#pragma unroll
+            for (int q = 0; q < RBU; ++q) { af[C ^ 1][0][q] = An[q * 32]; af[C ^ 1][1][q] = An[PLANE + q * 32]; }
+          }
+          // three partial products: lo*hi', hi*lo' -> acc1; hi*hi' -> acc0 (dependent MFMAs kept apart)
+#pragma unroll
+          for (int q = 0; q < RBU; ++q) acc1[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[C][1][q], b[S][0], acc1[SLOT + q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < RBU; ++q) acc0[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[C][0][q], b[S][0], acc0[SLOT + q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < RBU; ++q) acc1[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[C][0][q], b[S][1], acc1[SLOT + q], 0, 0, 0);
+          if (!GUARD || ks + 3 < ks1) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) b[S][p] = Bp[(long long)((ks + 3) * 2 + p) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        {
+          using T = std::true_type;
+          using F = std::false_type;
+          using S0 = std::integral_constant<int, 0>;
+          using S1 = std::integral_constant<int, 1>;
+          using S2 = std::integral_constant<int, 2>;
+          int ks = ks0;
+          // the weight slots rotate with period 3, the activation buffers with period 2: unroll by 6
+          for (; ks + 9 <= ks1; ks += 6) {
+            kstep(S0{}, S0{}, F{}, ks); kstep(S1{}, S1{}, F{}, ks + 1); kstep(S2{}, S0{}, F{}, ks + 2);
+            kstep(S0{}, S1{}, F{}, ks + 3); kstep(S1{}, S0{}, F{}, ks + 4); kstep(S2{}, S1{}, F{}, ks + 5);
+          }
+          for (; ks < ks1; ks += 6) {
+            kstep(S0{}, S0{}, T{}, ks);
+            if (ks + 1 < ks1) kstep(S1{}, S1{}, T{}, ks + 1);
+            if (ks + 2 < ks1) kstep(S2{}, S0{}, T{}, ks + 2);
+            if (ks + 3 < ks1) kstep(S0{}, S1{}, T{}, ks + 3);
+            if (ks + 4 < ks1) kstep(S1{}, S0{}, T{}, ks + 4);
+            if (ks + 5 < ks1) kstep(S2{}, S1{}, T{}, ks + 5);
+          }
+        }
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      using I3 = std::integral_constant<int, 3>;
+      using IRB = std::integral_constant<int, RB>;
+
+      if (NB == 1) {
+        // ---- narrow output (N <= 32): K split over 4 wave groups, partial sums through the staging area ----
+        constexpr int KSPLIT = 4;
+        const int rb = wave % RB, kq = wave / RB;
+        const int k0 = kq < KSPLIT ? (KS * kq) / KSPLIT : 0, k1 = kq < KSPLIT ? (KS * (kq + 1)) / KSPLIT : 0;
+        kloop(I1{}, I0{}, 0, rb, k0, k1);
+        float* part = stage_all;                 // [kq][m][n]: KSPLIT x TM x 32 floats
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (kq < KSPLIT) part[(kq * TM + rb * 32 + acc_row(i, h)) * 32 + r] = fmaf(acc1[0][i], LO_INV, acc0[0][i]);
+        __syncthreads();
+        const float winv = p_winv[0];
+        for (int t = tid; t < TM * 32; t += NTHREADS) {
+          const int n = t & 31, m = t >> 5;
+          float z = 0.f;
+#pragma unroll
+          for (int q = 0; q < KSPLIT; ++q) z += part[q * TM * 32 + t];
+          z = z * ainv * winv;
+          if (n < l_N && m < rows) {
+            if (MODE == 0) {
+              z += p_bias ? p_bias[n] : 0.f;
+              if (!last) { const float bz = beta * z; z = bz > 20.f ? z : log1pf(__expf(bz)) / beta; }
+            }
+            if (last) {
+              float* y = a.Y + (row0 + m) * a.ldy + n;
+              *y = a.accum_y ? *y + z : z;
+            }
+          }
+        }
+        __syncthreads();
+        continue;
+      }
+
+      // ---- general layer: this wave's 32 x 32 output blocks ("jobs"), at most 4 ----
+      // Column blocks that fill whole rounds of 8 waves go to one wave with all row blocks (the weight
+      // fragments are fetched once per tile); the NB % 8 remainder blocks are split by row block.
+      const int rem = (RB == 1) ? 0 : (NB % NWAVES);
+      const int full = NB - rem;
+      unsigned jobs = 0;    // job j in bits 8j..8j+7: column block | row block << 5
+      int njobs = 0;
+      unsigned pairs = 0;   // bit r: round r is one k-loop over both row blocks of a column block (RB == 2)
+      auto job = [&](int j, int nb, int rb) { jobs |= (unsigned)(nb | (rb << 5)) << (8 * j); };
+      if (RB == 2) {
+        if (wave < full) { job(0, wave, 0); job(1, wave, 1); njobs = 2; pairs |= 1u; }
+        if (wave + NWAVES < full) { job(2, wave + NWAVES, 0); job(3, wave + NWAVES, 1); njobs = 4; pairs |= 2u; }
+        if (wave < rem * RB) { job(njobs, full + wave / RB, wave % RB); ++njobs; }
+        if (wave + NWAVES < rem * RB) { job(njobs, full + (wave + NWAVES) / RB, (wave + NWAVES) % RB); ++njobs; }
+      } else {
+        if (wave < NB) { job(0, wave, 0); njobs = 1; }
+        if (wave + NWAVES < NB) { job(1, wave + NWAVES, 0); njobs = 2; }
+      }
+
+      // ================= phase A: activation math on the accumulators; results parked in registers =================
+      constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+      const float b2 = beta * LOG2E, ib2sc = LN2 / beta * sc;
+      const float hsc = (MODE != 0 && is_skip) ? 1.f / sc : 1.f;
+      const float nb2 = -b2 * hsc;
+      const int g = lane & 7;
+      f32x4 vp[4][4];                 // [job][row step]: this lane's outputs, 4 consecutive columns x 4 rows per job
+      float vmax = 0.f;               // running max |v| (NaN ignored by v_max; Inf handled after the reduction)
+      auto phaseA = [&](auto jtag, auto stag) {
+        constexpr int J = decltype(jtag)::value;        // job: index of the parked results
+        constexpr int SL = decltype(stag)::value;       // accumulator slot holding it
+        const int nb = (jobs >> (8 * J)) & 31, rb0 = (jobs >> (8 * J + 5)) & 7;
+        const float winv = p_winv[nb];
+        // pass 1: acc0 + acc1 2^-11 -> staging tile (conflict-free: column groups GPS apart, rows 4 dwords apart)
+        {
+          float* dst = stage + (r >> 2) * GPS + (r & 3);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dst[acc_row(i, h) * 4] = fmaf(acc1[SL][i], LO_INV, acc0[SL][i]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // pass 2: 4 steps of 8 rows; lane = (column group g of 4 columns, row)
+        const int n4 = nb * 32 + g * 4;
+        const int mbase = rb0 * 32 + (lane >> 3);
+        const long long off0 = (row0 + mbase) * l_ld + n4;
+        const bool fast = !last && (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && rows == TM && (!p_rowbias || (l_N & 3) == 0);
+        f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+        const float* lp = stage + g * GPS + (lane >> 3) * 4;
+        if (fast) {
+          f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+          if (MODE == 0 && p_bias) bias4 = *((gptr<const f32x4>)(p_bias + n4)) * b2;
+          const float wb2 = winv * b2;
+          f32x4 hs[4];
+          if (MODE != 0) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) hs[it] = *((gptr<const f32x4>)(p_side_in + off0 + (long long)it * 8 * l_ld));
+          }
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const long long off = off0 + (long long)it * 8 * l_ld;
+            const f32x4 z = *reinterpret_cast<const f32x4*>(lp + it * 32) * ainv;
+            f32x4 v;
+            if (MODE == 0) {
+              f32x4 rb = {0.f, 0.f, 0.f, 0.f};
+              if (p_rowbias) rb = *((gptr<const f32x4>)(p_rowbias + ((row0 + mbase + 8 * it) / rb_div) * (long long)l_N + n4));
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float u = fmaf(z[q], wb2, bias4[q]);                 // b2 * (pre-activation)
+                if (p_rowbias) u = fmaf(rb[q], b2, u);
+                // softplus_beta(t) = (max(u, 0) + log2(1 + 2^-|u|)) ln2 / beta,  u = beta log2(e) t
+                const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-fabsf(u)));
+                v[q] = (fmaxf(u, 0.f) + l2) * ib2sc;
+              }
+              if (p_side_out) *((gptr<f32x4>)(p_side_out + off)) = v;
+            } else {
+              f32x4 ex = {0.f, 0.f, 0.f, 0.f}, x2;
+              if (MODE == 1 && p_side_add) ex = *((gptr<const f32x4>)(p_side_add + off));
+              if (MODE == 2 && p_side_in2) ex = *((gptr<const f32x4>)(p_side_in2 + off));
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float zz = z[q] * winv;
+                const float e = __builtin_amdgcn_exp2f(nb2 * hs[it][q]);
+                const float sp = (1.f - e) * sc;
+                if (MODE == 1) v[q] = zz * sp + ex[q];
+                else { v[q] = zz * sp; x2[q] = beta * zz * ex[q] * e; }
+              }
+              if (p_side_out) *((gptr<f32x4>)(p_side_out + off)) = v;
+              if (MODE == 2 && p_side_out2) *((gptr<f32x4>)(p_side_out2 + off)) = x2;
+              colsum += v;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vmax = fmaxf(vmax, fabsf(v[q]));
+            vp[J][it] = v;
+          }
+        } else {
+          const bool vec_ok = (n4 + 3 < nlim);
+          const bool vec_side = vec_ok && (l_ld & 3) == 0;
+          f32x4 cm, bias4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cm[q] = (n4 + q < nlim) ? 1.f : 0.f;
+          if (MODE == 0 && p_bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (n4 + q < l_N) bias4[q] = p_bias[n4 + q];
+          }
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int m = mbase + 8 * it;
+            const bool mrow = m < rows;
+            const float rm = mrow ? 1.f : 0.f;
+            const long long grow = row0 + m;
+            const long long off = off0 + (long long)it * 8 * l_ld;
+            const f32x4 z = *reinterpret_cast<const f32x4*>(lp + it * 32) * ainv * winv;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            vp[J][it] = v;
+            if (last) {
+              if (mrow) {
+                float* y = a.Y + grow * a.ldy + n4;
+                if (vec_ok && (a.ldy & 3) == 0 && ((uintptr_t)a.Y & 15) == 0) {
+                  f32x4 t = z;
+                  if (MODE == 0) t += bias4;
+                  if (a.accum_y) t += *reinterpret_cast<const f32x4*>(y);
+                  *reinterpret_cast<f32x4*>(y) = t;
+                } else {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    if (n4 + q < l_N) {
+                      const float t = z[q] + (MODE == 0 ? bias4[q] : 0.f);
+                      y[q] = a.accum_y ? y[q] + t : t;
+                    }
+                  }
+                }
+              }
+              continue;
+            }
+            if (MODE == 0) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float t = z[q] + bias4[q];
+                if (p_rowbias && mrow && n4 + q < l_N) t += p_rowbias[(grow / rb_div) * (long long)l_N + n4 + q];
+                const float u = b2 * t;
+                const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-fabsf(u)));
+                v[q] = (fmaxf(u, 0.f) + l2) * (ib2sc * cm[q] * rm);
+              }
+              if (mrow && p_side_out) {
+                if (vec_side) *((gptr<f32x4>)(p_side_out + off)) = v;
+                else {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) if (n4 + q < l_N) p_side_out[off + q] = v[q];
+                }
+              }
+            } else {
+              f32x4 hs = {0.f, 0.f, 0.f, 0.f}, ex = {0.f, 0.f, 0.f, 0.f}, x2 = {0.f, 0.f, 0.f, 0.f};
+              if (mrow) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (n4 + q < nlim) {
+                  hs[q] = p_side_in[off + q];
+                  if (MODE == 1 && p_side_add) ex[q] = p_side_add[off + q];
+                  if (MODE == 2 && p_side_in2) ex[q] = p_side_in2[off + q];
+                }
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float e = __builtin_amdgcn_exp2f(nb2 * hs[q]);
+                const float sp = (1.f - e) * sc;
+                const float mk = cm[q] * rm;
+                if (MODE == 1) v[q] = (z[q] * sp + ex[q]) * mk;
+                else { v[q] = z[q] * sp * mk; x2[q] = beta * z[q] * ex[q] * e * mk; }
+              }
+              if (MODE == 1 && is_skip && mrow && a.Xskip) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int n = n4 + q;
+                  if (n >= a.skip_split && n < l_N) a.Xskip[grow * a.ld_xskip + (n - a.skip_split)] = z[q] * sc;
+                }
+              }
+              if (mrow) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (n4 + q < nlim) {
+                  if (p_side_out) p_side_out[off + q] = v[q];
+                  if (MODE == 2 && p_side_out2) p_side_out2[off + q] = x2[q];
+                }
+              }
+              colsum += v;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vmax = fmaxf(vmax, fabsf(v[q]));
+            vp[J][it] = v;
+          }
+        }
+        if (MODE != 0 && !last && p_bgrad) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float c = colsum[q];
+            c += __shfl_xor(c, 8);
+            c += __shfl_xor(c, 16);
+            c += __shfl_xor(c, 32);
+            if (lane < 8 && n4 + q < nlim) atomicAdd(p_bgrad + n4 + q, c);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();   // staging tile is reused by the next job
+      };
+      // round 0: jobs 0, 1; round 1: jobs 2, 3
+      {
+        const int nbA = jobs & 31, rbA = (jobs >> 5) & 7, nbB = (jobs >> 8) & 31, rbB = (jobs >> 13) & 7;
+        if (RB == 2 && (pairs & 1u)) kloop(IRB{}, I0{}, nbA, 0, 0, KS);
+        else {
+          if (njobs > 0) kloop(I1{}, I0{}, nbA, rbA, 0, KS);
+          if (njobs > 1) kloop(I1{}, I1{}, nbB, rbB, 0, KS);
+        }
+        stamp(li, 1);
+        if (njobs > 0) phaseA(I0{}, I0{});
+        if (njobs > 1) phaseA(I1{}, I1{});
+      }
+      if (RB == 2 && njobs > 2) {
+        const int nbA = (jobs >> 16) & 31, rbA = (jobs >> 21) & 7, nbB = (jobs >> 24) & 31, rbB = (jobs >> 29) & 7;
+        if (pairs & 2u) kloop(IRB{}, I0{}, nbA, 0, 0, KS);
+        else {
+          kloop(I1{}, I0{}, nbA, rbA, 0, KS);
+          if (njobs > 3) kloop(I1{}, I1{}, nbB, rbB, 0, KS);
+        }
+        phaseA(I2{}, I0{});
+        if (njobs > 3) phaseA(I3{}, I1{});
+      }
+      stamp(li, 2);
+
+      if (last) {              // the output layer leaves nothing in the planes: no maximum, no split
+        __syncthreads();
+        stamp(li, 4);
+        continue;
+      }
+
+      // ---- tile maximum of this layer's outputs (what the next k-loop reads, incl. the skip concatenation) ----
+      {
+        float wm = wave_max(vmax);
+        if (!(wm < 3.0e38f)) {
+          // an Inf among the outputs: take the maximum of the finite values from the parked registers (rare path)
+          unsigned mb = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (j < njobs) { const unsigned b = finite_abs_bits(vp[j][it][q]); mb = b > mb ? b : mb; }
+          wm = wave_max(__uint_as_float(mb));
+        }
+        if (MODE != 1 && is_skip) wm = fmaxf(wm, x_max * fabsf(a.skip_scale));
+        if (lane == 0) atomicMax(&s_tmax[cur], __float_as_uint(wm));
+      }
+      __syncthreads();          // every wave has read the planes and contributed its maximum
+      stamp(li, 3);
+
+      // ================= phase B: scale, 2-way split, planes updated in place =================
+      float s_out;
+      {
+        const unsigned mbits = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tmax[cur]);
+        scale_from_max(mbits, s_out, a_inv);
+        if (tid == 0 && ly.side_amax) atomicMax(ly.side_amax, mbits);
+      }
+      auto phaseB = [&](auto jtag) {
+        constexpr int J = decltype(jtag)::value;
+        const int nb = (jobs >> (8 * J)) & 31, rb0 = (jobs >> (8 * J + 5)) & 7;
+        const int n4 = nb * 32 + g * 4;
+        const int mbase = rb0 * 32 + (lane >> 3);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) put4(n4, mbase + 8 * it, vp[J][it], s_out);
+      };
+      if (njobs > 0) phaseB(I0{});
+      if (njobs > 1) phaseB(I1{});
+      if (njobs > 2) phaseB(I2{});
+      if (njobs > 3) phaseB(I3{});
+
+      // the planes beyond this layer's padded width must read as zero for the next layer's k-loop:
+      // column blocks are written whole (32 columns), the k-loop reads multiples of 16 <= Np
+      // ---- forward skip connection: append the (scaled) chain input after the skip layer's output ----
+      if (MODE != 1 && is_skip) {
+        __syncthreads();
+        const int K0 = a.K0, base = l_N;
+        const float* X = a.X + row0 * a.ldx;
+        for (int t = tid; t < K0 * TM; t += NTHREADS) {
+          const int k = t % K0, m = t / K0;
+          const float v = (m < rows) ? X[(long long)m * a.ldx + k] * a.skip_scale : 0.f;
+          const int kk = base + k;
+          put1(kk, m, v, s_out);
+          if (m < rows && ly.side_out) ly.side_out[(row0 + m) * ly.ld_side + kk] = v;
+        }
+        // zero the tail up to the next multiple of 16
+        const int wcat = base + K0, wpad = (wcat + 15) & ~15;
+        for (int t = tid; t < (wpad - wcat) * TM; t += NTHREADS) put1(wcat + t % (wpad - wcat), t / (wpad - wcat), 0.f, 1.f);
+      }
+      __syncthreads();
+      if (tid == 0) s_tmax[cur] = 0u;      // next use: two layers on, two barriers away
+      cur ^= 1;
+      stamp(li, 4);
+    }
+  }
+  if (MODE != 0 && a.bg_total > 0) {
+    __syncthreads();
+    float* part = a.bg_partial + (long long)blockIdx.x * a.bg_total;
+    for (int i = tid; i < a.bg_total; i += NTHREADS) part[i] = bsum[i];
+  }
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace x3
+
+long long packed_size3(int K, int N, int transpose) {
+  const int Kp = x3::round_up(transpose ? N : K, 16), Np = x3::round_up(transpose ? K : N, 32);
+  return (long long)Kp * Np + x3::round_up(Np / 32, 4);       // two f16 planes + 1/scale per column block, in floats
+}
+
+int launch_pack3(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream) {
+  const int Kp = x3::round_up(transpose ? N : K, 16), Np = x3::round_up(transpose ? K : N, 32);
+  hipLaunchKernelGGL(x3::k_pack3, dim3(Np / 32), dim3(256), 0, stream, W, reinterpret_cast<_Float16*>(dst),
+                     dst + (long long)Kp * Np, K, N, transpose, Kp, Np);
+  return ndjir_check_launch();
+}
+
+int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream) {
+  using namespace x3;
+  if (a.P <= 0) return NDJIR_OK;
+  const int TM = a.tile_rows == 32 ? 32 : 64;
+  const int TMP = TM + 4;
+  // widest activation the planes have to hold: chain input, every hidden output (+ skip concat)
+  int wmax = round_up(a.K0, 16);
+  for (int i = 0; i < a.L; ++i) {
+    const bool last = a.has_output && i == a.L - 1;
+    if (a.layers[i].Np > MAXNB * 32) return NDJIR_ERR_UNSUPPORTED;
+    if (!last && a.layers[i].Np > 32) { if (a.layers[i].Np > wmax) wmax = a.layers[i].Np; }
+  }
+  if (a.skip_layer >= 0 && mode != 1) { int w = round_up(a.layers[a.skip_layer].N + a.K0, 16); if (w > wmax) wmax = w; }
+  ChainArgs b = a;
+  b.K0p = round_up(a.K0, 16);
+  b.lds_split = (wmax / 8) * TMP;                          // 16-byte units per plane
+  size_t lds_bytes = (size_t)2 * b.lds_split * 16;
+  size_t stage_bytes = (size_t)NWAVES * STG * 4;
+  const size_t partials = (size_t)4 * TM * 32 * 4;
+  if (stage_bytes < partials) stage_bytes = partials;
+  lds_bytes += stage_bytes;
+  b.n_tiles = (a.P + TM - 1) / TM;
+  float* bg_ptr[MAX_CHAIN_LAYERS + 1];
+  int bg_off[MAX_CHAIN_LAYERS + 1];
+  int bg_n = 0, bg_total = 0;
+  if (mode != 0) {
+    for (int i = 0; i < a.L; ++i) if (a.layers[i].bgrad && !(a.has_output && i == a.L - 1)) {
+      b.layers[i].bg_off = bg_total;
+      bg_ptr[bg_n] = a.layers[i].bgrad;
+      bg_off[bg_n] = bg_total;
+      ++bg_n;
+      bg_total += a.layers[i].N;
+    } else b.layers[i].bgrad = nullptr;
+  }
+  if (mode != 0 && a.in_bgrad) {
+    b.in_bg_off = bg_total;
+    bg_ptr[bg_n] = a.in_bgrad;
+    bg_off[bg_n] = bg_total;
+    ++bg_n;
+    bg_total += a.K0;
+  }
+  b.bg_total = bg_total;
+  b.bg_lds = (int)(lds_bytes / 4);
+  lds_bytes += (size_t)bg_total * 4;
+  if (bg_total > 0 && !a.bg_partial) return NDJIR_ERR_ARG;
+  if (lds_bytes > 160 * 1024 - 64) return NDJIR_ERR_UNSUPPORTED;
+  long long blocks = b.n_tiles;
+  if (blocks > 256LL * 8) blocks = 256LL * 8;
+  if (bg_total > 0 && blocks > CHAIN_MAX_GRID_BG) blocks = CHAIN_MAX_GRID_BG;
+  static bool attr_set = false;
+  if (!attr_set) {
+#define NDJIR_SET(M, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain3<M, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)
+    NDJIR_SET(0, 64); NDJIR_SET(1, 64); NDJIR_SET(2, 64); NDJIR_SET(0, 32); NDJIR_SET(1, 32); NDJIR_SET(2, 32);
+#undef NDJIR_SET
+    attr_set = true;
+  }
+#define NDJIR_GO(M, T) hipLaunchKernelGGL((k_chain3<M, T>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b)
+  if (TM == 64) { if (mode == 0) NDJIR_GO(0, 64); else if (mode == 1) NDJIR_GO(1, 64); else NDJIR_GO(2, 64); }
+  else { if (mode == 0) NDJIR_GO(0, 32); else if (mode == 1) NDJIR_GO(1, 32); else NDJIR_GO(2, 32); }
+#undef NDJIR_GO
+  int rc = ndjir_check_launch();
+  if (rc != NDJIR_OK) return rc;
+  if (bg_total > 0) return launch_bgrad_reduce(a.bg_partial, (int)blocks, bg_total, bg_ptr, bg_off, bg_n, stream);
+  return NDJIR_OK;
+}
+
+}  // namespace ndjir

@@ -292,6 +292,192 @@ static inline void wgrad6_go(int blocks, hipStream_t stream, const float* A, int
                      tn, rows, k_off, n_off, k_end, n_end);
 }
 
+// ---- the same tiles on the f16 matrix cores: two-way split, three partial products (see mlp3.hip) ----
+// A and B are scaled by per-tensor powers of two taken from their largest finite magnitudes (amax_a / amax_b: bit
+// patterns of max |.|, produced by the chain kernels that wrote the tensors, or by k_absmax2 below) and split into
+// hi = f16(x s), lo = f16((x s - hi) 2^11); acc0 += hi hi', acc1 += hi lo' + lo hi', dW = (acc0 + acc1 2^-11) / (s s').
+// LDS planes [plane][feature][point] as in k_wgrad6, two planes instead of three.
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wg_f16x4 __attribute__((ext_vector_type(4)));
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ __forceinline__ void wg_scale_from_max(unsigned mbits, float& s, float& inv) {
+  int E = (int)(mbits >> 23);
+  if (E < 1) E = 1;
+  int se = 268 - E;
+  if (se > 253) se = 253;
+  if (se < 1) se = 1;
+  union { int i; float f; } a, b;
+  a.i = se << 23;
+  b.i = (254 - se) << 23;
+  s = a.f;
+  inv = b.f;
+}
+
+template <int WK, int WN, int BK, int BN>
+__global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad3(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                          int ldb, int K, int N, long long P, float* __restrict__ partial,
+                                                          int S, int tiles_k, int tiles_n, long long rows_per_split,
+                                                          int k_off, int n_off, int k_end, int n_end,
+                                                          const unsigned* __restrict__ amax_a, const unsigned* __restrict__ amax_b) {
+  static_assert(WK * WN == 4, "4 waves");
+  constexpr int TK = WK * BK * 32, TN = WN * BN * 32;
+  constexpr int PA = TK / 8, PB = TN / 8;          // points per thread and chunk (multiples of 4)
+  extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
+  _Float16* As = reinterpret_cast<_Float16*>(wg_lds);      // [2][TK][WG_CP]
+  _Float16* Bs = As + 2 * TK * WG_CP;                      // [2][TN][WG_CP]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wk = wave / WN, wn = wave % WN;
+  const int T = tiles_k * tiles_n;
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  int vid = (nblk & 7) == 0 ? xcd * (nblk >> 3) + local : blockIdx.x;
+  const int split = vid / T, tile = vid - split * T;
+  const int tk = tile / tiles_n, tn = tile - tk * tiles_n;
+  const int k0 = k_off + tk * TK, n0 = n_off + tn * TN;
+  const long long p_begin = (long long)split * rows_per_split;
+  long long p_end = p_begin + rows_per_split;
+  if (p_end > P) p_end = P;
+  float sa, ia, sb, ib;
+  wg_scale_from_max(*amax_a, sa, ia);
+  wg_scale_from_max(*amax_b, sb, ib);
+
+  f32x16 acc0[BK][BN] = {}, acc1[BK][BN] = {};
+  float ra[PA], rb[PB];
+  const int fa = tid % TK, ga = tid / TK, fb = tid % TN, gb = tid / TN;   // feature column, point group
+  const bool acol = (k0 + fa) < k_end, bcol = (n0 + fb) < n_end;
+  const float* Ap = A + (long long)(ga * PA) * lda + k0 + fa;
+  const float* Bp = B + (long long)(gb * PB) * ldb + n0 + fb;
+  auto load_chunk = [&](long long p0) {
+    const float* ap = Ap + p0 * lda;
+    const float* bp = Bp + p0 * ldb;
+    if (p0 + WG_C <= p_end) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = acol ? ap[(long long)i * lda] : 0.f;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) rb[i] = bcol ? bp[(long long)i * ldb] : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = (acol && p0 + ga * PA + i < p_end) ? ap[(long long)i * lda] : 0.f;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) rb[i] = (bcol && p0 + gb * PB + i < p_end) ? bp[(long long)i * ldb] : 0.f;
+    }
+  };
+  auto split4 = [&](const float* v, float s, _Float16* d, int plane_stride) {
+    wg_f32x4 xs = {v[0] * s, v[1] * s, v[2] * s, v[3] * s};
+    const wg_f16x4 ph = __builtin_convertvector(xs, wg_f16x4);
+    const wg_f32x4 res = (xs - __builtin_convertvector(ph, wg_f32x4)) * 2048.f;
+    const wg_f16x4 pl = __builtin_convertvector(res, wg_f16x4);
+    *reinterpret_cast<wg_f16x4*>(d) = ph;
+    *reinterpret_cast<wg_f16x4*>(d + plane_stride) = pl;
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int g4 = 0; g4 < PA / 4; ++g4) split4(ra + 4 * g4, sa, As + fa * WG_CP + ga * PA + 4 * g4, TK * WG_CP);
+#pragma unroll
+    for (int g4 = 0; g4 < PB / 4; ++g4) split4(rb + 4 * g4, sb, Bs + fb * WG_CP + gb * PB + 4 * g4, TN * WG_CP);
+  };
+
+  if (p_begin < p_end) {
+    load_chunk(p_begin);
+    store_chunk();
+    __syncthreads();
+    for (long long p0 = p_begin; p0 < p_end; p0 += WG_C) {
+      const bool more = p0 + WG_C < p_end;
+      if (more) load_chunk(p0 + WG_C);
+#pragma unroll
+      for (int s = 0; s < WG_C / 16; ++s) {
+        wg_f16x8 av[BK][2], bv[BN][2];
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            av[i][p] = *reinterpret_cast<const wg_f16x8*>(As + p * TK * WG_CP + ((wk * BK + i) * 32 + r) * WG_CP + 16 * s + 8 * h);
+#pragma unroll
+        for (int j = 0; j < BN; ++j)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            bv[j][p] = *reinterpret_cast<const wg_f16x8*>(Bs + p * TN * WG_CP + ((wn * BN + j) * 32 + r) * WG_CP + 16 * s + 8 * h);
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int j = 0; j < BN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][1], bv[j][0], acc1[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int j = 0; j < BN; ++j) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][0], bv[j][0], acc0[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BK; ++i)
+#pragma unroll
+          for (int j = 0; j < BN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][0], bv[j][1], acc1[i][j], 0, 0, 0);
+      }
+      __syncthreads();                 // every wave is done with this chunk's planes
+      if (more) store_chunk();
+      __syncthreads();
+    }
+  }
+
+  float* out = partial + (long long)split * K * N;
+#pragma unroll
+  for (int bi = 0; bi < BK; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < BN; ++bj) {
+      const int n = n0 + (wn * BN + bj) * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = k0 + (wk * BK + bi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (k < k_end && n < n_end) out[(long long)k * N + n] = fmaf(acc1[bi][bj][i], 1.f / 2048.f, acc0[bi][bj][i]) * ia * ib;
+      }
+    }
+}
+
+template <int WK, int WN, int BK, int BN>
+static inline void wgrad3_go(int blocks, hipStream_t stream, const float* A, int lda, const float* B, int ldb, int K, int N,
+                             long long P, float* ws, int S, int tk, int tn, long long rows, int k_off, int n_off, int k_end,
+                             int n_end, const unsigned* amax_a, const unsigned* amax_b) {
+  constexpr int TK = WK * BK * 32, TN = WN * BN * 32;
+  const size_t lds = (size_t)2 * (TK + TN) * WG_CP * sizeof(unsigned short);
+  hipLaunchKernelGGL((k_wgrad3<WK, WN, BK, BN>), dim3(blocks), dim3(WG_THREADS), lds, stream, A, lda, B, ldb, K, N, P, ws, S, tk,
+                     tn, rows, k_off, n_off, k_end, n_end, amax_a, amax_b);
+}
+
+// largest finite |.| of two row-strided matrices -> out[0], out[1] (bit patterns; zeroed by the caller): the scales
+// of k_wgrad3 when the producer of a tensor did not record its maximum
+__global__ void __launch_bounds__(256) k_absmax2(const float* __restrict__ A, int lda, int K, const float* __restrict__ B, int ldb,
+                                                 int N, long long P, unsigned* __restrict__ out, int need_a, int need_b) {
+  __shared__ unsigned red[2][256];
+  unsigned ma = 0, mb = 0;
+  const long long rows_per = (P + gridDim.x - 1) / gridDim.x;
+  const long long p0 = (long long)blockIdx.x * rows_per;
+  const long long p1 = p0 + rows_per < P ? p0 + rows_per : P;
+  for (long long p = p0; p < p1; ++p) {
+    if (need_a) for (int k = threadIdx.x; k < K; k += 256) {
+      const unsigned b = __float_as_uint(A[p * lda + k]) & 0x7fffffffu;
+      if (b < 0x7f800000u && b > ma) ma = b;
+    }
+    if (need_b) for (int n = threadIdx.x; n < N; n += 256) {
+      const unsigned b = __float_as_uint(B[p * ldb + n]) & 0x7fffffffu;
+      if (b < 0x7f800000u && b > mb) mb = b;
+    }
+  }
+  red[0][threadIdx.x] = ma;
+  red[1][threadIdx.x] = mb;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      if (red[0][threadIdx.x + s] > red[0][threadIdx.x]) red[0][threadIdx.x] = red[0][threadIdx.x + s];
+      if (red[1][threadIdx.x + s] > red[1][threadIdx.x]) red[1][threadIdx.x] = red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (need_a) atomicMax(out, red[0][0]);
+    if (need_b) atomicMax(out + 1, red[1][0]);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ out,
                                                       long long KN, int S, int accum) {
   // one float4 of the output per thread; 8 independent loads in flight per thread
@@ -560,7 +746,7 @@ long long wgrad_workspace(int K, int N, long long P) {
     const long long nb = (P + SW_ROWS - 1) / SW_ROWS;
     if (nb > splits) splits = nb;
   }
-  return splits * K * N;
+  return splits * K * N + 4;        // + two maxima (k_absmax2) behind the partial sums
 }
 
 static int launch_split_reduce(const float* ws, float* out, long long KN, int S, int accum, hipStream_t stream) {
@@ -576,7 +762,9 @@ static int launch_split_reduce(const float* ws, float* out, long long KN, int S,
 }
 
 int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out, int accum,
-                 float* workspace, int bf16x6, hipStream_t stream) {
+                 float* workspace, int math, const unsigned* amax_a, const unsigned* amax_b, hipStream_t stream) {
+  const int bf16x6 = (math == 1);
+  const int f16x3 = (math == 2);
   if (K <= 0 || N <= 0) return NDJIR_OK;
   if (N <= SW_NMAX && (K & 3) == 0 && (lda & 3) == 0 && ((uintptr_t)A & 15) == 0) {
     if (P <= 0) {
@@ -589,9 +777,40 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
   }
   const WgradPlan pl = wgrad_plan(K, N);
   static const int x6_blocks = [] { const char* e = getenv("NDJIR_WGRAD_BLOCKS"); int v = e ? atoi(e) : 512; return (v >= 64 && v <= 1024) ? v : 512; }();
-  const int S = pick_splits(K, N, P, bf16x6 ? x6_blocks : 256);
+  const int S = pick_splits(K, N, P, (bf16x6 || f16x3) ? x6_blocks : 256);
   long long rows = (P + S - 1) / S;
   rows = (rows + WG_C - 1) / WG_C * WG_C;
+  if (f16x3) {
+    static bool attr3 = false;
+    if (!attr3) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3<2, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr3 = true;
+    }
+    if (!amax_a || !amax_b) {
+      // a tensor whose producer did not record its maximum: one streaming pass over it (the slots live behind the
+      // partial sums; pick_splits' upper bound sized the workspace)
+      unsigned* slots = reinterpret_cast<unsigned*>(workspace + wgrad_workspace(K, N, P) - 4);
+      if (hipMemsetAsync(slots, 0, 2 * sizeof(unsigned), stream) != hipSuccess) return NDJIR_ERR_LAUNCH;
+      long long nb = (P + 63) / 64;
+      if (nb > 1024) nb = 1024;
+      hipLaunchKernelGGL(k_absmax2, dim3((unsigned)nb), dim3(256), 0, stream, A, lda, K, B, ldb, N, P, slots, amax_a ? 0 : 1,
+                         amax_b ? 0 : 1);
+      if (!amax_a) amax_a = slots;
+      if (!amax_b) amax_b = slots + 1;
+    }
+    if (pl.tk > 0 && pl.tn > 0)
+      wgrad3_go<2, 2, 2, 2>(S * pl.tk * pl.tn, stream, A, lda, B, ldb, K, N, P, workspace, S, pl.tk, pl.tn, rows, 0, 0,
+                            pl.Km < K ? pl.Km : K, pl.Nm < N ? pl.Nm : N, amax_a, amax_b);
+    if (pl.sk > 0) {
+      const int tn_all = (N + WG_T - 1) / WG_T;
+      wgrad3_go<1, 4, 1, 1>(S * pl.sk * tn_all, stream, A, lda, B, ldb, K, N, P, workspace, S, pl.sk, tn_all, rows, pl.Km, 0, K, N,
+                            amax_a, amax_b);
+    }
+    if (pl.sn > 0 && pl.tk > 0)
+      wgrad3_go<4, 1, 1, 1>(S * pl.tk * pl.sn, stream, A, lda, B, ldb, K, N, P, workspace, S, pl.tk, pl.sn, rows, 0, pl.Nm, pl.Km, N,
+                            amax_a, amax_b);
+    return launch_split_reduce(workspace, out, (long long)K * N, S, accum, stream);
+  }
   if (bf16x6) {
     static bool attr = false;
     if (!attr) {

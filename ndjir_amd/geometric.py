@@ -30,7 +30,7 @@ from torch.autograd import Function
 
 from . import lib
 from .grid_feature import _core
-from .mlp import _launch, _packed, chain_workspace, colsum, wgrad
+from .mlp import _launch, _packed, amax_slots, chain_workspace, colsum, wgrad
 
 
 
@@ -95,16 +95,19 @@ class GeometricMain(Function):
         for j in range(L - 1):
             A.append(torch.empty((P, Ns[j] + (K0 if j == skip_at else 0)), device=dev, dtype=torch.float32))
         y = torch.empty((P, Ns[-1]), device=dev, dtype=torch.float32)
+        # recorded maxima (operand scales of the f16x3 weight-gradient kernel): am[j] <-> A[j]; sm[j] <-> s_store[j]
+        am, sm = amax_slots(dev, L), amax_slots(dev, L)
         _launch("chain_fwd", _flops(P, Ks, Ns), "mlp_chain", 0, P, e, K0, K0, L, [_packed(w, False) for w in W],
                 [t.detach() for t in b], Ks, Ns, [None] * L, A[1:] + [None], [a.shape[1] for a in A[1:]] + [0],
                 [None] * L, y, Ns[-1], 0, 1, beta, skip_at, scale, 0, None, 0, None, None,
+                [am[j + 1:j + 2] for j in range(L - 1)] + [None], am[0:1],
                 shape=f"{P}:geo {K0}-" + "-".join(map(str, Ns)))
 
         # ---- sdf chain: backward chain seeded with d(sdf) = 1, first step = column 0 of the last layer ----
         ones = torch.ones((P, 1), device=dev, dtype=torch.float32)
         s = [None] * L                                     # s[j] = d sdf / d z_j, j < L-1
         s_store = [None] * L
-        Wp, bK, bN, side_in, side_out, ld = [], [], [], [], [], []
+        Wp, bK, bN, side_in, side_out, ld, side_am = [], [], [], [], [], [], []
         bskip, split = -1, 0
         for i in range(L):
             j = L - 1 - i
@@ -119,17 +122,19 @@ class GeometricMain(Function):
                 s[below] = buf[:, :Ns[below]]
                 side_in.append(A[j])
                 side_out.append(buf)
+                side_am.append(sm[below:below + 1])
                 ld.append(A[j].shape[1])
                 if below == skip_at:
                     bskip, split = i, Ns[below]
             else:
                 side_in.append(None)
                 side_out.append(None)
+                side_am.append(None)
                 ld.append(0)
         g0 = torch.zeros((P, K0), device=dev, dtype=torch.float32)
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain", 1, P, ones, 1, 1, L, Wp, [None] * L, bK, bN, side_in,
                 side_out, ld, [None] * L, g0, K0, 1 if bskip >= 0 else 0, 1, beta, bskip, scale, split,
-                g0 if bskip >= 0 else None, K0, None, None, shape=f"{P}:sdf 1-" + "-".join(map(str, bN)))
+                g0 if bskip >= 0 else None, K0, None, None, side_am, None, shape=f"{P}:sdf 1-" + "-".join(map(str, bN)))
 
         # ---- n = J_e(x)^T g_0 ----
         gc = g0[:, 3:3 + 3 * M].reshape(P, 3, M)
@@ -143,6 +148,7 @@ class GeometricMain(Function):
 
         ctx.cfg = (M, skip_at, scale, min_, max_, L, tuple(x.shape), fam_names, bskip, split)
         ctx.A, ctx.s_store, ctx.s = A, s_store, s
+        ctx.am, ctx.sm = am, sm
         ctx.aux = (xf, cosb, sinb, g0)
         ctx.save_for_backward(*W, *grids)
         lead = x.shape[:-1]
@@ -158,7 +164,9 @@ class GeometricMain(Function):
         NG = len(grids)
         has_grid = NG > 0
         A, s_store, s = ctx.A, ctx.s_store, ctx.s
+        am, sm = ctx.am, ctx.sm
         xf, cosb, sinb, g0 = ctx.aux
+        gm, dm = amax_slots(xf.device, L), amax_slots(xf.device, L)      # recorded maxima of gbar[j] / deltas[j]
         beta = 100.0
         P = xf.shape[0]
         dev = xf.device
@@ -204,7 +212,7 @@ class GeometricMain(Function):
             gbar[0] = gb0
             # ---- tangent chain over layers 0..L-2 ----
             T = L - 1
-            side_in, side_in2, side_out, side_out2, ld, bg = [], [], [], [], [], [None] * T
+            side_in, side_in2, side_out, side_out2, ld, bg, side_am = [], [], [], [], [], [None] * T, []
             for l in range(T):
                 wide = A[l + 1].shape[1]
                 gbar[l + 1] = torch.empty((P, wide), device=dev, dtype=torch.float32)
@@ -213,13 +221,14 @@ class GeometricMain(Function):
                 side_in2.append(s_store[l])
                 side_out.append(gbar[l + 1])
                 side_out2.append(extras[l])
+                side_am.append(gm[l + 1:l + 2])
                 ld.append(wide)
             col_last = torch.empty((Ns[L - 2],), device=dev, dtype=torch.float32)
             bg[T - 1] = col_last
             _launch("chain_tan", _flops(P, Ks[:T], Ns[:T]), "mlp_chain_ex", 2, P, gb0, K0, K0, T,
                     [_packed(w, False) for w in W[:T]], [None] * T, Ks[:T], Ns[:T], side_in, side_out, ld, bg,
                     None, 0, 0, 0, beta, skip_at, scale, 0, None, 0, side_in2, [None] * T, side_out2,
-                    None, 0, None, chain_workspace(dev, bg), shape=f"{P}:tan {K0}-" + "-".join(map(str, Ns[:T])))
+                    None, 0, None, chain_workspace(dev, bg), side_am, gm[0:1], shape=f"{P}:tan {K0}-" + "-".join(map(str, Ns[:T])))
 
         # ---- backward chain with the extra adjoints ----
         need_x = has_grid
@@ -227,7 +236,7 @@ class GeometricMain(Function):
         deltas = [None] * L
         deltas[L - 1] = gy
         bgrads = [None] * L
-        Wp, bK, bN, side_in, side_out, side_add, ld, bg = [], [], [], [], [], [], [], []
+        Wp, bK, bN, side_in, side_out, side_add, ld, bg, side_am = [], [], [], [], [], [], [], [], []
         for i in range(steps):
             j = L - 1 - i
             Wp.append(_packed(W[j], True))
@@ -242,16 +251,18 @@ class GeometricMain(Function):
                 side_in.append(A[j])
                 side_out.append(dbuf)
                 side_add.append(extras[below])
+                side_am.append(dm[below:below + 1])
                 ld.append(wide)
                 bg.append(bgrads[below])
             else:
                 side_in.append(None); side_out.append(None); side_add.append(None); ld.append(0); bg.append(None)
+                side_am.append(None)
         gx = torch.zeros((P, K0), device=dev, dtype=torch.float32) if need_x else None
         gb_last = torch.empty((Ns[-1],), device=dev, dtype=torch.float32)     # bias gradient of the output layer
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain_ex", 1, P, gy, Ns[-1], Ns[-1], steps, Wp, [None] * steps, bK, bN,
                 side_in, side_out, ld, bg, gx, K0, 1 if (bskip >= 0 and need_x) else 0, 1 if need_x else 0, beta,
                 bskip, scale, split, gx if (bskip >= 0 and need_x) else None, K0, [None] * steps, side_add, [None] * steps,
-                None, 0, gb_last, chain_workspace(dev, bg + [gb_last]), shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
+                None, 0, gb_last, chain_workspace(dev, bg + [gb_last]), side_am, dm[L - 1:L], shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
 
         for fam, fd, sa, C, c0, gdst, _ in enc:
             _enc_call(fam, "grad_feature", P, C, gdst, gx[:, c0:c0 + C].contiguous(), xf, *sa, min_, max_, 0, 1)
@@ -260,16 +271,16 @@ class GeometricMain(Function):
         gW, gb = [None] * L, [None] * L
         for j in range(L):
             if ctx.needs_input_grad[2 + NG + j]:
-                gW[j] = wgrad(A[j], deltas[j])
+                gW[j] = wgrad(A[j], deltas[j], amax_a=am[j:j + 1], amax_b=dm[j:j + 1])
                 if nbar is not None and j < L - 1:
-                    wgrad(gbar[j], s[j], out=gW[j], accum=True)
+                    wgrad(gbar[j], s[j], out=gW[j], accum=True, amax_a=gm[j:j + 1], amax_b=sm[j:j + 1])
                 if nbar is not None and j == L - 1:
                     gW[j][:, 0] += col_last
             if ctx.needs_input_grad[2 + NG + L + j]:
                 gb[j] = bgrads[j] if j < L - 1 else gb_last
         g_grids = [gdst if (ctx.needs_input_grad[2 + k] and not own) else None
                    for k, (_, _, _, _, _, gdst, own) in enumerate(enc)]
-        ctx.A = ctx.s_store = ctx.s = ctx.aux = None
+        ctx.A = ctx.s_store = ctx.s = ctx.aux = ctx.am = ctx.sm = None
         return (None, None, *g_grids, *gW, *gb)
 
 

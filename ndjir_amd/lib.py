@@ -39,10 +39,11 @@ SIGS = {
     "zero": "pl",
     "mlp_pack": "ppiii",
     # bwd P X ldx K0 L Wp bias Ks Ns side_in side_out ld_side bgrad Y ldy accum has_out beta skip scale split Xskip ld
-    "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi" + "pp",
-    "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP" + "pi" + "pp",
+    # ... in_bgrad workspace side_amax x_amax
+    "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi" + "pp" + "Pp",
+    "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP" + "pi" + "pp" + "Pp",
     "mlp_group_colsum": "piilip",
-    "mlp_wgrad": "pipiiilpip",
+    "mlp_wgrad": "pipiiilpippp",
     "mlp_colsum": "piilpip",
     "render_alpha_weights": "iii" + "p" * 11,
     "render_alpha_weights_backward": "iii" + "p" * 16,
@@ -183,7 +184,10 @@ def call(name, *args):
             if not (v.is_cuda and v.dtype == torch.int32 and v.is_contiguous()):
                 raise NdjirHipError(f"ndjir_{name}: expected a contiguous int32 GPU tensor")
             cargs.append(v.data_ptr())
-        elif c == "P":     # host array of device pointers (list of tensors / None)
+        elif c == "P":     # host array of device pointers (list of tensors / None); None = null array
+            if v is None:
+                cargs.append(None)
+                continue
             arr = (_vp * len(v))()
             for i, t in enumerate(v):
                 if t is not None:

@@ -20,12 +20,13 @@ from . import lib
 
 _PACK_CACHE = {}
 
-MATH_FP32, MATH_BF16X6 = 0, 1
+MATH_FP32, MATH_BF16X6, MATH_F16X3 = 0, 1, 2
 
 
 def set_math(math):
-    """Arithmetic of the chain engine: MATH_BF16X6 (default; exact three-way bf16 split, six MFMA
-    partial products, fp32-equivalent accuracy) or MATH_FP32 (fp32-input MFMA).  NDJIR_MLP_MATH=fp32|bf16x6."""
+    """Arithmetic of the chain engine: MATH_F16X3 (default; scaled two-way f16 split, three MFMA partial products in
+    two fp32 accumulators, error below a plain fp32 FMA chain's), MATH_BF16X6 (exact three-way bf16 split, six partial
+    products) or MATH_FP32 (fp32-input MFMA).  NDJIR_MLP_MATH=fp32|bf16x6|f16x3."""
     if lib.load().ndjir_mlp_set_math(int(math)) != 0:
         raise lib.NdjirHipError(f"unknown math mode {math}")
     _PACK_CACHE.clear()
@@ -39,7 +40,7 @@ def _init_math():
     import os
     env = os.environ.get("NDJIR_MLP_MATH")
     if env:
-        set_math({"fp32": MATH_FP32, "bf16x6": MATH_BF16X6}[env.lower()])
+        set_math({"fp32": MATH_FP32, "bf16x6": MATH_BF16X6, "f16x3": MATH_F16X3}[env.lower()])
 
 # Optional live timing of the engine's launches with HIP events on the launching stream
 # (bench.py sets PROFILE = [] around its timed region): entries (kind, algorithmic_flops, e0, e1, shape).
@@ -83,6 +84,16 @@ def _packed(W, transpose):
     return dst
 
 
+def amax_slots(device, n):
+    """n zeroed slots for the largest finite |value| of tensors written / read by a chain launch (bit patterns, updated
+    by atomic max): the f16x3 weight-gradient kernel scales its operands by them (ndjir_mlp_chain / ndjir_mlp_wgrad)."""
+    return torch.zeros(n, device=device, dtype=torch.float32)
+
+
+def _slot(am, i):
+    return am[i:i + 1] if am is not None else None
+
+
 def chain_workspace(device, bgrads):
     """Workspace of a chain launch that produces the bias gradients `bgrads` (list, None entries ok)."""
     total = sum(b.numel() for b in bgrads if b is not None)
@@ -91,9 +102,10 @@ def chain_workspace(device, bgrads):
 
 def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, keep_hidden=False, row_bias=None,
                   row_bias_div=1):
-    """x (P, K0) contiguous.  Returns y (P, N_last) and the list of stored activations
-    A_1..A_{L-1} (inputs of layers 1..L-1) when keep_hidden.  row_bias (P / row_bias_div, N_0): added to
-    the first layer's pre-activation of each group of row_bias_div consecutive rows."""
+    """x (P, K0) contiguous.  Returns y (P, N_last), the list of stored activations A_1..A_{L-1} (inputs of layers
+    1..L-1) when keep_hidden, and their recorded maxima (slot j <-> A_j, slot 0 = x; None unless keep_hidden).
+    row_bias (P / row_bias_div, N_0): added to the first layer's pre-activation of each group of row_bias_div
+    consecutive rows."""
     P, K0 = x.shape
     L = len(weights)
     Ks, Ns, Wp, hidden = [], [], [], []
@@ -111,18 +123,21 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
     ld_side = [h.shape[1] if h is not None else 0 for h in side_out]
     flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
     bl = [b.detach() if b is not None else None for b in biases]
+    am = amax_slots(x.device, L) if keep_hidden else None
+    side_am = [_slot(am, j + 1) if (keep_hidden and j < L - 1) else None for j in range(L)]
     if row_bias is None:
         _launch("chain_fwd", flops, "mlp_chain", 0, P, x, x.shape[1], K0, L, Wp, bl,
                 Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
-                int(skip_layer), float(skip_scale), 0, None, 0, None, None, shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
+                int(skip_layer), float(skip_scale), 0, None, 0, None, None, side_am, _slot(am, 0),
+                shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
     else:
         assert P % row_bias_div == 0 and tuple(row_bias.shape) == (P // row_bias_div, Ns[0])
         _launch("chain_fwd", flops, "mlp_chain_ex", 0, P, x, x.shape[1], K0, L, Wp, bl,
                 Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
                 int(skip_layer), float(skip_scale), 0, None, 0, [None] * L, [None] * L, [None] * L,
-                row_bias.detach().contiguous(), int(row_bias_div), None, None,
+                row_bias.detach().contiguous(), int(row_bias_div), None, None, side_am, _slot(am, 0),
                 shape=f"{P}:{K0}(+rows/{row_bias_div})-" + "-".join(map(str, Ns)))
-    return y, hidden
+    return y, hidden, am
 
 
 _WORKSPACE = {}
@@ -136,10 +151,12 @@ def _workspace(device, need):
     return ws
 
 
-def wgrad(A, B, out=None, accum=False):
+def wgrad(A, B, out=None, accum=False, amax_a=None, amax_b=None):
     """dW = A^T B with A (P, K) and B (P, N) row-major views (column stride 1): the weight gradient
     of one layer, reduction over the P points (ndjir_amd/csrc/wgrad.hip).  `out` (K, N) with
-    `accum=True` adds to an existing gradient."""
+    `accum=True` adds to an existing gradient.  amax_a / amax_b: 1-element slots holding (an upper bound of) the
+    largest finite magnitude of A / B as recorded by the chain launch that produced them (f16x3 operand scales);
+    None = the kernel finds it with one extra pass over the tensor."""
     P, K = A.shape
     N = B.shape[1]
     assert A.stride(1) == 1 and B.stride(1) == 1 and B.shape[0] == P
@@ -148,7 +165,7 @@ def wgrad(A, B, out=None, accum=False):
         out = torch.empty((K, N), device=A.device, dtype=torch.float32)
         accum = False
     _launch("wgrad", 2.0 * P * K * N, "mlp_wgrad", _Strided(A), A.stride(0), _Strided(B), B.stride(0), K, N, P, out,
-            1 if accum else 0, ws, shape=f"{P}:{K}x{N}")
+            1 if accum else 0, ws, amax_a, amax_b, shape=f"{P}:{K}x{N}")
     return out
 
 
@@ -188,10 +205,10 @@ class FusedMLP(Function):
         x2 = x.detach().reshape(-1, x.shape[-1]).contiguous()
         train = any(ctx.needs_input_grad)
         rb = None if row_bias is None else row_bias.detach().reshape(-1, row_bias.shape[-1])
-        y, hidden = chain_forward(x2, weights, biases, beta, skip_layer, skip_scale,
-                                  keep_hidden=train, row_bias=rb, row_bias_div=row_bias_div)
+        y, hidden, am = chain_forward(x2, weights, biases, beta, skip_layer, skip_scale,
+                                      keep_hidden=train, row_bias=rb, row_bias_div=row_bias_div)
         if train:
-            ctx.save_for_backward(x2, *hidden, *weights)
+            ctx.save_for_backward(x2, *hidden, *weights, am)
             ctx.cfg = (beta, skip_layer, skip_scale, L, tuple(x.shape))
             ctx.rb = (None if row_bias is None else tuple(row_bias.shape), int(row_bias_div))
         return y.view(x.shape[:-1] + (y.shape[-1],))
@@ -204,6 +221,7 @@ class FusedMLP(Function):
         x2 = saved[0]
         A = [x2] + list(saved[1:L])          # A[j] = input activation of layer j
         W = list(saved[L:2 * L])
+        am = saved[2 * L]                    # recorded maxima of A[j]
         P, K0 = x2.shape
         need_x = ctx.needs_input_grad[0]
         need_w = any(ctx.needs_input_grad[6:6 + L])
@@ -215,8 +233,10 @@ class FusedMLP(Function):
         bgrads = [None] * L
         gx = None
         gb_last = None
+        dm = amax_slots(x2.device, L)        # recorded maxima of deltas[j]; slot L-1 = the chain input gy2
+        have_dm = steps > 0
         if steps > 0:
-            Wp, Ks, Ns, side_in, side_out, ld_side, bg = [], [], [], [], [], [], []
+            Wp, Ks, Ns, side_in, side_out, ld_side, bg, side_am = [], [], [], [], [], [], [], []
             bwd_skip, split = -1, 0
             for i in range(steps):
                 j = L - 1 - i
@@ -230,6 +250,7 @@ class FusedMLP(Function):
                     bgrads[below] = torch.empty((width,), device=x2.device, dtype=torch.float32)
                     side_in.append(A[j])
                     side_out.append(deltas[below])
+                    side_am.append(_slot(dm, below))
                     ld_side.append(A[j].shape[1])
                     bg.append(bgrads[below])
                     if below == skip_layer:
@@ -239,6 +260,7 @@ class FusedMLP(Function):
                 else:
                     side_in.append(None)
                     side_out.append(None)
+                    side_am.append(None)
                     ld_side.append(0)
                     bg.append(None)
             if bwd_skip >= 0:
@@ -265,13 +287,13 @@ class FusedMLP(Function):
                      1 if bwd_skip >= 0 else 0, 1 if need_x else 0,
                      float(beta), int(bwd_skip), float(skip_scale), int(split),
                      gx if bwd_skip >= 0 else None, K0, gb_last, chain_workspace(x2.device, bg + [gb_last]),
-                     shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)))
+                     side_am, _slot(dm, L - 1), shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)))
         gW = [None] * L
         gb = [None] * L
         if need_w:
             for j in range(L):
                 if ctx.needs_input_grad[6 + j]:
-                    gW[j] = wgrad(A[j], deltas[j])
+                    gW[j] = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
                 if ctx.needs_input_grad[6 + L + j]:
                     gb[j] = bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))
         g_rb = None
@@ -311,10 +333,10 @@ class MultiMLP(Function):
             off += 2 * L
         ys, saved = [], [x2]
         for W, b in nets:
-            y, hidden = chain_forward(x2, W, b, beta, -1, 1.0, keep_hidden=train)
+            y, hidden, am = chain_forward(x2, W, b, beta, -1, 1.0, keep_hidden=train)
             ys.append(y.view(x.shape[:-1] + (y.shape[-1],)))
             if train:
-                saved += hidden + W
+                saved += hidden + W + [am]
         if train:
             ctx.save_for_backward(*saved)
             ctx.cfg = (float(beta), tuple(layer_counts), tuple(x.shape))
@@ -335,7 +357,8 @@ class MultiMLP(Function):
         for n, L in enumerate(layer_counts):
             A = [x2] + list(saved[pos:pos + L - 1])
             W = list(saved[pos + L - 1:pos + 2 * L - 1])
-            pos += 2 * L - 1
+            am = saved[pos + 2 * L - 1]
+            pos += 2 * L
             gy = gys[n]
             nW = ctx.needs_input_grad[poff:poff + L]
             nb = ctx.needs_input_grad[poff + L:poff + 2 * L]
@@ -348,8 +371,9 @@ class MultiMLP(Function):
             deltas, bgrads = [None] * L, [None] * L
             deltas[L - 1] = gy2
             gb_last = None
+            dm = amax_slots(dev, L) if steps > 0 else None
             if steps > 0:
-                Wp, Ks, Ns, side_in, side_out, ld_side, bg = [], [], [], [], [], [], []
+                Wp, Ks, Ns, side_in, side_out, ld_side, bg, side_am = [], [], [], [], [], [], [], []
                 for i in range(steps):
                     j = L - 1 - i
                     Wp.append(_packed(W[j], True))
@@ -360,17 +384,18 @@ class MultiMLP(Function):
                         deltas[j - 1] = torch.empty((P, width), device=dev, dtype=torch.float32)
                         bgrads[j - 1] = torch.empty((width,), device=dev, dtype=torch.float32)
                         side_in.append(A[j]); side_out.append(deltas[j - 1]); ld_side.append(A[j].shape[1]); bg.append(bgrads[j - 1])
+                        side_am.append(_slot(dm, j - 1))
                     else:
-                        side_in.append(None); side_out.append(None); ld_side.append(0); bg.append(None)
+                        side_in.append(None); side_out.append(None); ld_side.append(0); bg.append(None); side_am.append(None)
                 if any(nW) and nb[L - 1]:
                     gb_last = torch.empty((gy2.shape[1],), device=dev, dtype=torch.float32)
                 flops = 2.0 * P * sum(k * m for k, m in zip(Ks, Ns))
                 _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
                         side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
                         0 if first else 1, 1 if need_x else 0, float(beta), -1, 1.0, 0, None, K0, gb_last,
-                        chain_workspace(dev, bg + [gb_last]), shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)) + ("" if first else " (+=)"))
+                        chain_workspace(dev, bg + [gb_last]), side_am, _slot(dm, L - 1), shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)) + ("" if first else " (+=)"))
                 first = False
-            gW = [wgrad(A[j], deltas[j]) if nW[j] else None for j in range(L)]
+            gW = [wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j)) if nW[j] else None for j in range(L)]
             gb = [(bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))) if nb[j] else None for j in range(L)]
             grads += gW + gb
         if need_x and first:
@@ -395,7 +420,7 @@ def _mm(x2, W, transpose, bias=None):
         return y
     _launch("chain_fwd", 2.0 * P_ * K * N, "mlp_chain", 0, P_, x2, x2.shape[1], K, 1, [_packed(W, bool(transpose))],
             [bias.detach() if bias is not None else None], [K], [N], [None], [None], [0], [None], y, N, 0, 1, 100.0, -1, 1.0, 0,
-            None, 0, None, None, shape=f"{P_}:{K}-{N}")
+            None, 0, None, None, None, None, shape=f"{P_}:{K}-{N}")
     return y
 
 

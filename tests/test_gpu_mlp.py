@@ -279,3 +279,106 @@ def test_linear_is_twice_differentiable(gpu, P, K, N):
     assert rel_err(y, y64) < 2e-6 and rel_err(gx, gx64) < 5e-6
     for a, r, name in zip(gg, gg64, "xWb"):
         assert rel_err(a, r) < 2e-5, (name, rel_err(a, r))
+
+
+# ---- arithmetic of the three engines ------------------------------------------------------------------------------------
+def _geo_net_error(gpu, math_mode, P=4096, seed=3):
+    """Relative error (vs fp64) of the 8-layer geometric net's forward value and input gradient under `math_mode`."""
+    from ndjir_amd import mlp
+    dims = (43, 256, 256, 256, 213, 256, 256, 256, 257)
+    Ws, bs = make(dims, seed, 3)
+    rng = np.random.RandomState(seed)
+    x = torch.tensor(rng.randn(P, 43) * 0.5, dtype=torch.float32)
+    gy = torch.tensor(rng.randn(P, 257), dtype=torch.float32)
+    x64 = x.double().requires_grad_(True)
+    W64 = [w.double().requires_grad_(True) for w in Ws]
+    y64 = ref_mlp(x64, W64, [b.double() for b in bs], 100.0, 3, 0.7071067811865476)
+    g64 = torch.autograd.grad(y64, [x64, W64[0], W64[4]], gy.double())
+    old = mlp.get_math()
+    mlp.set_math(math_mode)
+    try:
+        xd = x.to(gpu).requires_grad_(True)
+        Wd = [w.to(gpu).requires_grad_(True) for w in Ws]
+        y = mlp.fused_mlp(xd, Wd, [b.to(gpu) for b in bs], 100.0, 3, 0.7071067811865476)
+        g = torch.autograd.grad(y, [xd, Wd[0], Wd[4]], gy.to(gpu))
+    finally:
+        mlp.set_math(old)
+    rel = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm())
+    return rel(y, y64), [rel(a, b) for a, b in zip(g, g64)]
+
+
+def test_f16x3_is_at_least_as_accurate_as_an_fp32_fma_chain(gpu):
+    """The default engine (two-way f16 split, three MFMA partial products) against the fp32-input MFMA engine, which is
+    bitwise an fp32 FMA chain (MI355X_MICROARCH.md): its error vs fp64 must not exceed the fp32 chain's -- the claim
+    behind calling the arithmetic fp32-equivalent.  The exact bf16x6 engine is printed beside them."""
+    from ndjir_amd import mlp
+    e32, g32 = _geo_net_error(gpu, mlp.MATH_FP32)
+    e6, g6 = _geo_net_error(gpu, mlp.MATH_BF16X6)
+    e3, g3 = _geo_net_error(gpu, mlp.MATH_F16X3)
+    print(f"\nforward error vs fp64: fp32 chain {e32:.2e}  bf16x6 {e6:.2e}  f16x3 {e3:.2e}")
+    print(f"gradient errors (x, W0, W4): fp32 {g32}  bf16x6 {g6}  f16x3 {g3}")
+    assert e3 <= 1.05 * e32, (e3, e32)
+    for a, b in zip(g3, g32):
+        assert a <= 1.25 * b, (g3, g32)
+    assert e3 < 2e-6
+
+
+@pytest.mark.parametrize("spread", [1e-6, 1e6])
+def test_f16x3_scaling_groups(gpu, spread):
+    """Rows of very different magnitude in one tile (the activations of a tile share one power-of-two scale) and weight
+    columns of very different magnitude: every output row / column keeps fp32-class relative accuracy as long as it is
+    within 2^-28 of its group's maximum; magnitudes far outside fp16's own range (1e-12 .. 1e9) are handled by the scales."""
+    from ndjir_amd.mlp import fused_mlp
+    rng = np.random.RandomState(11)
+    P, K, H, N = 256, 64, 128, 96
+    row_scale = np.exp(rng.uniform(0, np.log(1e5), size=(P, 1))) * spread          # rows spread over 5 decades
+    col_scale = np.exp(rng.uniform(0, np.log(1e3), size=(1, N)))
+    x = torch.tensor(rng.randn(P, K) * row_scale, dtype=torch.float32)
+    W0 = torch.tensor(rng.randn(K, H) / np.sqrt(K) / spread, dtype=torch.float32)      # pre-activations stay O(1..1e5)
+    b0 = torch.tensor(rng.randn(H) * 0.1, dtype=torch.float32)
+    W1 = torch.tensor(rng.randn(H, N) / np.sqrt(H) * col_scale, dtype=torch.float32)
+    b1 = torch.zeros(N)
+    y = fused_mlp(x.to(gpu), [W0.to(gpu), W1.to(gpu)], [b0.to(gpu), b1.to(gpu)], 100.0).cpu().double()
+    ref = ref_mlp(x.double(), [W0.double(), W1.double()], [b0.double(), b1.double()], 100.0)
+    # per-row and per-column relative errors, not just the norm of the whole matrix
+    row_err = (y - ref).norm(dim=1) / ref.norm(dim=1)
+    col_err = (y - ref).norm(dim=0) / ref.norm(dim=0)
+    assert float(row_err.max()) < 3e-6, float(row_err.max())
+    assert float(col_err.max()) < 3e-6, float(col_err.max())
+
+
+def test_f16x3_nonfinite_rows_stay_confined(gpu):
+    """An Inf / NaN in one row of a tile must not leak into the other rows of the tile through the shared scale."""
+    from ndjir_amd.mlp import fused_mlp
+    rng = np.random.RandomState(2)
+    P, K, H, N = 128, 40, 128, 33
+    x = torch.tensor(rng.randn(P, K), dtype=torch.float32)
+    Ws = [torch.tensor(rng.randn(K, H) / np.sqrt(K), dtype=torch.float32), torch.tensor(rng.randn(H, N) / np.sqrt(H), dtype=torch.float32)]
+    bs = [torch.zeros(H), torch.zeros(N)]
+    ref = ref_mlp(x.double(), [w.double() for w in Ws], [b.double() for b in bs], 100.0)
+    xb = x.clone()
+    xb[5, 3] = float("nan")
+    xb[70, 0] = float("inf")
+    y = fused_mlp(xb.to(gpu), [w.to(gpu) for w in Ws], [b.to(gpu) for b in bs], 100.0).cpu()
+    bad = torch.zeros(P, dtype=torch.bool)
+    bad[5] = bad[70] = True
+    assert not torch.isfinite(y[5]).any() and not torch.isfinite(y[70]).all()
+    assert torch.isfinite(y[~bad]).all()
+    assert float((y[~bad].double() - ref[~bad]).norm() / ref[~bad].norm()) < 2e-6
+
+
+@pytest.mark.parametrize("scale_a,scale_b", [(1.0, 1.0), (1e-7, 1e4), (3e5, 1e-9)])
+def test_wgrad_operand_scales(gpu, scale_a, scale_b):
+    """Weight-gradient kernel with and without recorded maxima (the kernel's own pre-pass), operands far from O(1)."""
+    from ndjir_amd.mlp import wgrad
+    rng = np.random.RandomState(7)
+    P, K, N = 5000, 200, 130
+    A = torch.tensor(rng.randn(P, K) * scale_a, dtype=torch.float32)
+    B = torch.tensor(rng.randn(P, N) * scale_b, dtype=torch.float32)
+    ref = A.double().t() @ B.double()
+    out = wgrad(A.to(gpu), B.to(gpu))
+    assert float((out.cpu().double() - ref).norm() / ref.norm()) < 2e-6
+    am = (A.abs().max() * 3.0).reshape(1).to(gpu)           # any upper bound will do
+    bm = B.abs().max().reshape(1).to(gpu)
+    out2 = wgrad(A.to(gpu), B.to(gpu), amax_a=am, amax_b=bm)
+    assert float((out2.cpu().double() - ref).norm() / ref.norm()) < 2e-6
