@@ -19,9 +19,9 @@
 //   for every layer:  k-loops of all column blocks (accumulator pairs stay in registers)
 //                     phase A per 32x32 block: acc0 + acc1 2^-11 -> per-wave fp32 staging tile in LDS -> row-major
 //                       pass (bias + softplus / softplus' product, coalesced float4 side stores and loads,
-//                       bias-gradient column sums); results parked in registers; running maximum
+//                       bias-gradient column sums); results written back to the staging tile; running maximum
 //                     tile maximum -> LDS; barrier (every wave has also finished reading the planes)
-//                     phase B: scale from the maximum, 2-way split, planes updated in place
+//                     phase B: scale from the maximum, staging tile -> 2-way split, planes updated in place
 //                     barrier
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -96,9 +96,10 @@ __device__ __forceinline__ float wave_max(float m) {
 // W[16 ks + 8 h + j][32 nb + c] * s_nb, j = 0..7, of plane p (0 = hi, 1 = lo * 2^11); behind the planes, at float
 // offset Kp * Np: 1 / s_nb for every column block.  One workgroup per column block: slab maximum, then the split.
 // transpose packs W^T.
-__global__ void __launch_bounds__(256) k_pack3(const float* __restrict__ W, _Float16* __restrict__ dst, float* __restrict__ inv_out,
+constexpr int PACK_T = 1024;
+__global__ void __launch_bounds__(PACK_T) k_pack3(const float* __restrict__ W, _Float16* __restrict__ dst, float* __restrict__ inv_out,
                                                int K, int N, int transpose, int Kp, int Np) {
-  __shared__ unsigned red[256];
+  __shared__ unsigned red[PACK_T];
   const int nb = blockIdx.x;
   const int KS = Kp >> 4;
   const int total = Kp * 32;
@@ -112,17 +113,17 @@ __global__ void __launch_bounds__(256) k_pack3(const float* __restrict__ W, _Flo
     return v;
   };
   unsigned m = 0;
-  for (int t = threadIdx.x; t < total; t += 256) { const unsigned b = finite_abs_bits(value(t)); m = b > m ? b : m; }
+  for (int t = threadIdx.x; t < total; t += PACK_T) { const unsigned b = finite_abs_bits(value(t)); m = b > m ? b : m; }
   red[threadIdx.x] = m;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = PACK_T / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) { const unsigned o = red[threadIdx.x + s]; if (o > red[threadIdx.x]) red[threadIdx.x] = o; }
     __syncthreads();
   }
   float sc, inv;
   scale_from_max(red[0], sc, inv);
   if (threadIdx.x == 0) inv_out[nb] = inv;
-  for (int t = threadIdx.x; t < total; t += 256) {
+  for (int t = threadIdx.x; t < total; t += PACK_T) {
     int k, c;
     if (!transpose) { c = t & 31; k = t >> 5; } else { k = t % Kp; c = t / Kp; }
     const float xs = value(t) * sc;
@@ -151,7 +152,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   float* stage_all = lds + (size_t)2 * PLANE * 4;
-  float* stage = stage_all + wave * STG;
+  float* stage = stage_all + wave * 2 * STG;      // two 32 x 32 tiles per wave: one per output block of a layer
   float* bsum = lds + a.bg_lds;
   const float beta = a.beta;
   auto stamp = [&](int li, int phase) {
@@ -176,6 +177,18 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
     *reinterpret_cast<_Float16*>(p + (size_t)PLANE * 16) = pl;
   };
 
+  stamp(MAX_CHAIN_LAYERS - 1, 0);                  // (diagnostics: kernel start / first input stage done / first tile done)
+  auto stamp_rt = [&](int phase) {                 // constant-rate (100 MHz) clock beside the shader clock: effective frequency
+    if (a.timeline && blockIdx.x == 0 && lane == 0) a.timeline[((MAX_CHAIN_LAYERS - 2) * 5 + phase) * NWAVES + wave] = (long long)__builtin_amdgcn_s_memrealtime();
+  };
+  stamp_rt(0);
+  // diagnostics: slot [9][4][7] of the timeline buffer = number of per-workgroup records behind it (start / end on the
+  // 100 MHz clock, hardware id): lets tools/chain_timeline.py see how the grid packs onto the CUs
+  const bool rec = a.timeline && tid == 0 && (long long)blockIdx.x < a.timeline[399];
+  if (rec) {
+    a.timeline[400 + 3 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+    a.timeline[400 + 3 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+  }
   if (MODE != 0) for (int i = tid; i < a.bg_total; i += NTHREADS) bsum[i] = 0.f;
   if (tid < 4) s_tmax[tid] = 0u;
   __syncthreads();
@@ -250,6 +263,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
     }
     __syncthreads();
     if (tid == 0) s_tmax[2] = 0u;        // next use: the next tile's input stage, many barriers away
+    if (tile == blockIdx.x) stamp(MAX_CHAIN_LAYERS - 1, 1);
 
     int cur = 0;                         // ping-pong slot of the layer's tile maximum
     for (int li = 0; li < a.L; ++li) {
@@ -278,8 +292,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
       const float ainv = pin(a_inv);
 
       // one k-loop: RBU row blocks of column block nb, accumulator pairs acc0/acc1[SLOT .. SLOT + RBU)
-      // Two accumulator-pair slots; a wave's (at most 4) output blocks are processed in rounds of two: k-loops, then
-      // phase A, which parks the results -- 128 accumulator registers for four blocks would not leave room for them.
+      // Two accumulator-pair slots: a wave works on at most two 32 x 32 output blocks at a time.
       f32x16 acc0[2], acc1[2];   // static indices only (an accumulator array indexed under run-time branches goes to scratch)
       auto kloop = [&](auto rbu_tag, auto slot_tag, const int nb, const int rb0, const int ks0, const int ks1) {
         constexpr int RBU = decltype(rbu_tag)::value;
@@ -388,43 +401,54 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         continue;
       }
 
-      // ---- general layer: this wave's 32 x 32 output blocks ("jobs"), at most 4 ----
-      // Column blocks that fill whole rounds of 8 waves go to one wave with all row blocks (the weight
-      // fragments are fetched once per tile); the NB % 8 remainder blocks are split by row block.
-      const int rem = (RB == 1) ? 0 : (NB % NWAVES);
-      const int full = NB - rem;
-      unsigned jobs = 0;    // job j in bits 8j..8j+7: column block | row block << 5
-      int njobs = 0;
-      unsigned pairs = 0;   // bit r: round r is one k-loop over both row blocks of a column block (RB == 2)
-      auto job = [&](int j, int nb, int rb) { jobs |= (unsigned)(nb | (rb << 5)) << (8 * j); };
-      if (RB == 2) {
-        if (wave < full) { job(0, wave, 0); job(1, wave, 1); njobs = 2; pairs |= 1u; }
-        if (wave + NWAVES < full) { job(2, wave + NWAVES, 0); job(3, wave + NWAVES, 1); njobs = 4; pairs |= 2u; }
-        if (wave < rem * RB) { job(njobs, full + wave / RB, wave % RB); ++njobs; }
-        if (wave + NWAVES < rem * RB) { job(njobs, full + (wave + NWAVES) / RB, (wave + NWAVES) % RB); ++njobs; }
-      } else {
-        if (wave < NB) { job(0, wave, 0); njobs = 1; }
-        if (wave + NWAVES < NB) { job(1, wave + NWAVES, 0); njobs = 2; }
-      }
-
-      // ================= phase A: activation math on the accumulators; results parked in registers =================
+      // ---- general layer: this wave's 32 x 32 output blocks ("jobs"), two per round ----
+      // TM = 64 and a multiple of 8 column blocks: a column block goes to one wave with both row blocks (the weight
+      // fragments are fetched once per tile); otherwise the NB * RB blocks are dealt round-robin.  Hidden layers fit one
+      // round (the launcher picks 32-point tiles for hidden layers wider than 256: their results are parked in the
+      // wave's two staging tiles); an output layer, which parks nothing, may take several.
+      const bool pair_mode = (RB == 2) && (NB % NWAVES == 0);
+      const int nblk = NB * RB;
+      const int nrounds = pair_mode ? NB / NWAVES : (nblk + 2 * NWAVES - 1) / (2 * NWAVES);
       constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
       const float b2 = beta * LOG2E, ib2sc = LN2 / beta * sc;
       const float hsc = (MODE != 0 && is_skip) ? 1.f / sc : 1.f;
       const float nb2 = -b2 * hsc;
       const int g = lane & 7;
-      f32x4 vp[4][4];                 // [job][row step]: this lane's outputs, 4 consecutive columns x 4 rows per job
       float vmax = 0.f;               // running max |v| (NaN ignored by v_max; Inf handled after the reduction)
-      auto phaseA = [&](auto jtag, auto stag) {
-        constexpr int J = decltype(jtag)::value;        // job: index of the parked results
-        constexpr int SL = decltype(stag)::value;       // accumulator slot holding it
-        const int nb = (jobs >> (8 * J)) & 31, rb0 = (jobs >> (8 * J + 5)) & 7;
+      unsigned jobs = 0;    // job j in bits 8j..8j+7: column block | row block << 5
+      int njobs = 0;
+#pragma unroll 1
+      for (int round = 0; round < nrounds; ++round) {
+      jobs = 0; njobs = 0;
+      auto job = [&](int j, int nb, int rb) { jobs |= (unsigned)(nb | (rb << 5)) << (8 * j); };
+      if (pair_mode) {
+        const int nb = wave + NWAVES * round;
+        job(0, nb, 0); job(1, nb, 1); njobs = 2;
+        kloop(IRB{}, I0{}, nb, 0, 0, KS);
+      } else {
+        const int b0 = wave + 2 * NWAVES * round, b1 = b0 + NWAVES;
+        if (b0 < nblk) { job(0, b0 / RB, b0 % RB); njobs = 1; kloop(I1{}, I0{}, b0 / RB, b0 % RB, 0, KS); }
+        if (b1 < nblk) { job(1, b1 / RB, b1 % RB); njobs = 2; kloop(I1{}, I1{}, b1 / RB, b1 % RB, 0, KS); }
+      }
+      if (round == 0) stamp(li, 1);
+      __builtin_amdgcn_wave_barrier();     // (a later round reuses the staging tiles)
+
+      // ================= phase A: activation math on the accumulators; results back into the staging tile =================
+#pragma unroll 1
+      for (int j = 0; j < njobs; ++j) {
+        const int nb = (jobs >> (8 * j)) & 31, rb0 = (jobs >> (8 * j + 5)) & 7;
         const float winv = p_winv[nb];
+        float* const stj = stage + j * STG;
         // pass 1: acc0 + acc1 2^-11 -> staging tile (conflict-free: column groups GPS apart, rows 4 dwords apart)
         {
-          float* dst = stage + (r >> 2) * GPS + (r & 3);
+          float* dst = stj + (r >> 2) * GPS + (r & 3);
+          if (j == 0) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) dst[acc_row(i, h) * 4] = fmaf(acc1[SL][i], LO_INV, acc0[SL][i]);
+            for (int i = 0; i < 16; ++i) dst[acc_row(i, h) * 4] = fmaf(acc1[0][i], LO_INV, acc0[0][i]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[acc_row(i, h) * 4] = fmaf(acc1[1][i], LO_INV, acc0[1][i]);
+          }
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -434,7 +458,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         const long long off0 = (row0 + mbase) * l_ld + n4;
         const bool fast = !last && (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && rows == TM && (!p_rowbias || (l_N & 3) == 0);
         f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
-        const float* lp = stage + g * GPS + (lane >> 3) * 4;
+        float* lp = stj + g * GPS + (lane >> 3) * 4;
         if (fast) {
           f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
           if (MODE == 0 && p_bias) bias4 = *((gptr<const f32x4>)(p_bias + n4)) * b2;
@@ -479,7 +503,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) vmax = fmaxf(vmax, fabsf(v[q]));
-            vp[J][it] = v;
+            *reinterpret_cast<f32x4*>(lp + it * 32) = v;       // parked for phase B (same lane reads it back)
           }
         } else {
           const bool vec_ok = (n4 + 3 < nlim);
@@ -500,7 +524,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
             const long long off = off0 + (long long)it * 8 * l_ld;
             const f32x4 z = *reinterpret_cast<const f32x4*>(lp + it * 32) * ainv * winv;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            vp[J][it] = v;
             if (last) {
               if (mrow) {
                 float* y = a.Y + grow * a.ldy + n4;
@@ -573,7 +596,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) vmax = fmaxf(vmax, fabsf(v[q]));
-            vp[J][it] = v;
+            *reinterpret_cast<f32x4*>(lp + it * 32) = v;
           }
         }
         if (MODE != 0 && !last && p_bgrad) {
@@ -586,30 +609,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
             if (lane < 8 && n4 + q < nlim) atomicAdd(p_bgrad + n4 + q, c);
           }
         }
-        __builtin_amdgcn_wave_barrier();   // staging tile is reused by the next job
-      };
-      // round 0: jobs 0, 1; round 1: jobs 2, 3
-      {
-        const int nbA = jobs & 31, rbA = (jobs >> 5) & 7, nbB = (jobs >> 8) & 31, rbB = (jobs >> 13) & 7;
-        if (RB == 2 && (pairs & 1u)) kloop(IRB{}, I0{}, nbA, 0, 0, KS);
-        else {
-          if (njobs > 0) kloop(I1{}, I0{}, nbA, rbA, 0, KS);
-          if (njobs > 1) kloop(I1{}, I1{}, nbB, rbB, 0, KS);
-        }
-        stamp(li, 1);
-        if (njobs > 0) phaseA(I0{}, I0{});
-        if (njobs > 1) phaseA(I1{}, I1{});
       }
-      if (RB == 2 && njobs > 2) {
-        const int nbA = (jobs >> 16) & 31, rbA = (jobs >> 21) & 7, nbB = (jobs >> 24) & 31, rbB = (jobs >> 29) & 7;
-        if (pairs & 2u) kloop(IRB{}, I0{}, nbA, 0, 0, KS);
-        else {
-          kloop(I1{}, I0{}, nbA, rbA, 0, KS);
-          if (njobs > 3) kloop(I1{}, I1{}, nbB, rbB, 0, KS);
-        }
-        phaseA(I2{}, I0{});
-        if (njobs > 3) phaseA(I3{}, I1{});
-      }
+      }   // rounds
       stamp(li, 2);
 
       if (last) {              // the output layer leaves nothing in the planes: no maximum, no split
@@ -624,12 +625,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         if (!(wm < 3.0e38f)) {
           // an Inf among the outputs: take the maximum of the finite values from the parked registers (rare path)
           unsigned mb = 0;
+          for (int j = 0; j < njobs; ++j)
+            for (int it = 0; it < 4; ++it) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(stage + j * STG + g * GPS + (lane >> 3) * 4 + it * 32);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int it = 0; it < 4; ++it)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) if (j < njobs) { const unsigned b = finite_abs_bits(vp[j][it][q]); mb = b > mb ? b : mb; }
+              for (int q = 0; q < 4; ++q) { const unsigned b = finite_abs_bits(v[q]); mb = b > mb ? b : mb; }
+            }
           wm = wave_max(__uint_as_float(mb));
         }
         if (MODE != 1 && is_skip) wm = fmaxf(wm, x_max * fabsf(a.skip_scale));
@@ -645,18 +646,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         scale_from_max(mbits, s_out, a_inv);
         if (tid == 0 && ly.side_amax) atomicMax(ly.side_amax, mbits);
       }
-      auto phaseB = [&](auto jtag) {
-        constexpr int J = decltype(jtag)::value;
-        const int nb = (jobs >> (8 * J)) & 31, rb0 = (jobs >> (8 * J + 5)) & 7;
+#pragma unroll 1
+      for (int j = 0; j < njobs; ++j) {
+        const int nb = (jobs >> (8 * j)) & 31, rb0 = (jobs >> (8 * j + 5)) & 7;
         const int n4 = nb * 32 + g * 4;
         const int mbase = rb0 * 32 + (lane >> 3);
+        const float* lp = stage + j * STG + g * GPS + (lane >> 3) * 4;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) put4(n4, mbase + 8 * it, vp[J][it], s_out);
-      };
-      if (njobs > 0) phaseB(I0{});
-      if (njobs > 1) phaseB(I1{});
-      if (njobs > 2) phaseB(I2{});
-      if (njobs > 3) phaseB(I3{});
+        for (int it = 0; it < 4; ++it) put4(n4, mbase + 8 * it, *reinterpret_cast<const f32x4*>(lp + it * 32), s_out);
+      }
 
       // the planes beyond this layer's padded width must read as zero for the next layer's k-loop:
       // column blocks are written whole (32 columns), the k-loop reads multiples of 16 <= Np
@@ -681,7 +679,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
       cur ^= 1;
       stamp(li, 4);
     }
+    if (tile == blockIdx.x) stamp(MAX_CHAIN_LAYERS - 1, 2);
   }
+  stamp(MAX_CHAIN_LAYERS - 1, 3);
+  stamp_rt(1);
+  if (rec) a.timeline[400 + 3 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
   if (MODE != 0 && a.bg_total > 0) {
     __syncthreads();
     float* part = a.bg_partial + (long long)blockIdx.x * a.bg_total;
@@ -700,7 +702,7 @@ long long packed_size3(int K, int N, int transpose) {
 
 int launch_pack3(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream) {
   const int Kp = x3::round_up(transpose ? N : K, 16), Np = x3::round_up(transpose ? K : N, 32);
-  hipLaunchKernelGGL(x3::k_pack3, dim3(Np / 32), dim3(256), 0, stream, W, reinterpret_cast<_Float16*>(dst),
+  hipLaunchKernelGGL(x3::k_pack3, dim3(Np / 32), dim3(x3::PACK_T), 0, stream, W, reinterpret_cast<_Float16*>(dst),
                      dst + (long long)Kp * Np, K, N, transpose, Kp, Np);
   return ndjir_check_launch();
 }
@@ -708,21 +710,22 @@ int launch_pack3(const float* W, float* dst, int K, int N, int transpose, hipStr
 int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream) {
   using namespace x3;
   if (a.P <= 0) return NDJIR_OK;
-  const int TM = a.tile_rows == 32 ? 32 : 64;
-  const int TMP = TM + 4;
+  int TM = a.tile_rows == 32 ? 32 : 64;
   // widest activation the planes have to hold: chain input, every hidden output (+ skip concat)
   int wmax = round_up(a.K0, 16);
   for (int i = 0; i < a.L; ++i) {
     const bool last = a.has_output && i == a.L - 1;
     if (a.layers[i].Np > MAXNB * 32) return NDJIR_ERR_UNSUPPORTED;
+    if (!last && a.layers[i].Np > NWAVES * 32) TM = 32;   // a hidden layer's results are parked in two staging tiles per wave
     if (!last && a.layers[i].Np > 32) { if (a.layers[i].Np > wmax) wmax = a.layers[i].Np; }
   }
+  const int TMP = TM + 4;
   if (a.skip_layer >= 0 && mode != 1) { int w = round_up(a.layers[a.skip_layer].N + a.K0, 16); if (w > wmax) wmax = w; }
   ChainArgs b = a;
   b.K0p = round_up(a.K0, 16);
   b.lds_split = (wmax / 8) * TMP;                          // 16-byte units per plane
   size_t lds_bytes = (size_t)2 * b.lds_split * 16;
-  size_t stage_bytes = (size_t)NWAVES * STG * 4;
+  size_t stage_bytes = (size_t)NWAVES * 2 * STG * 4;
   const size_t partials = (size_t)4 * TM * 32 * 4;
   if (stage_bytes < partials) stage_bytes = partials;
   lds_bytes += stage_bytes;

@@ -29,6 +29,16 @@ def show(buf, L, title):
               f"{(p1 - k)[act].mean():6.0f} | {(p2 - p1)[act].mean():6.0f} | {(b - p2).min():6d} {(b - p2).max():6d} | "
               f"{b.max() - s.min():6d}")
     print(f"total {t[L - 1, 4].max() - t0} cycles")
+    full = buf.cpu().numpy().reshape(10, 5, 8).astype(np.int64)[9]
+    if full[0].max() > 0:
+        k0 = full[0].min()
+        rt = buf.cpu().numpy().reshape(10, 5, 8).astype(np.int64)[8]
+        if rt[0].max() > 0:
+            ticks = rt[1].max() - rt[0].min()
+            print(f"workgroup 0 lifetime: {full[3].max() - k0} shader cycles in {ticks} ticks of the 100 MHz clock "
+                  f"-> {100e6 * (full[3].max() - k0) / max(ticks, 1) / 1e9:.2f} GHz effective shader clock")
+        print(f"workgroup 0: kernel start -> input stage done {full[1].max() - k0}, -> first tile done {full[2].max() - k0}, "
+              f"-> all its tiles done {full[3].max() - k0} cycles")
     if os.environ.get("TIMELINE_RAW"):
         li = int(os.environ["TIMELINE_RAW"])
         print(f"layer {li} per wave (relative to layer start): k-loop done, staged, epilogue done, barrier passed")
@@ -42,7 +52,9 @@ def main():
     dims = (43, 256, 256, 256, 213, 256, 256, 256, 257)
     Ws, bs = make(dims, 1, 3)
     x = torch.randn(P, 43, device="cuda")
-    buf = torch.zeros(10 * 5 * 8, dtype=torch.int64, device="cuda")
+    NREC = int(os.environ.get("TIMELINE_BLOCKS", "0"))
+    buf = torch.zeros(10 * 5 * 8 + 3 * NREC, dtype=torch.int64, device="cuda")
+    buf[399] = NREC
     so = lib.load()
     so.ndjir_mlp_debug_timeline.argtypes = [ctypes.c_void_p]
     if mode in ("fwd", "fwd_nostore"):
@@ -50,10 +62,32 @@ def main():
         chain_forward(x, Ws, bs, 100.0, 3, 0.7071, keep_hidden=keep)
         torch.cuda.synchronize()
         so.ndjir_mlp_debug_timeline(buf.data_ptr())
-        chain_forward(x, Ws, bs, 100.0, 3, 0.7071, keep_hidden=keep)
+        reps = int(os.environ.get("TIMELINE_REPS", "1"))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):      # > 1: stamps of the last of a back-to-back series
+            chain_forward(x, Ws, bs, 100.0, 3, 0.7071, keep_hidden=keep)
+        e1.record()
         torch.cuda.synchronize()
+        print(f"{reps} launches: {e0.elapsed_time(e1) * 1e3 / reps:.1f} us per launch by HIP events")
         so.ndjir_mlp_debug_timeline(None)
-        show(buf, 8, "geometric net forward chain (43-256-256-256-213|+43-256-256-256-257), tile of 64 points")
+        show(buf[:400], 8, "geometric net forward chain (43-256-256-256-213|+43-256-256-256-257), tile of 64 points")
+        if NREC:
+            rec = buf[400:].cpu().numpy().reshape(NREC, 3)
+            t0 = rec[:, 0].min()
+            st, en, hw = (rec[:, 0] - t0) / 100.0, (rec[:, 1] - t0) / 100.0, rec[:, 2]
+            print(f"{NREC} workgroups: start min/median/max {st.min():.1f}/{np.median(st):.1f}/{st.max():.1f} us, "
+                  f"duration min/median/max {(en - st).min():.1f}/{np.median(en - st):.1f}/{(en - st).max():.1f} us, last end {en.max():.1f} us")
+            order = np.argsort(st)
+            for q in (0, 255, 256, 511, 512, 767, 768, 1023):
+                if q < NREC:
+                    b = order[q]
+                    print(f"  {q}-th to start: block {b} start {st[b]:.1f} dur {en[b] - st[b]:.1f} hw_id 0x{int(hw[b]):x}")
+            ids = {}
+            for b in range(NREC):
+                ids.setdefault(int(hw[b]) & 0xfffffff0, []).append(b)     # drop the wave-slot bits
+            cnt = np.array([len(v) for v in ids.values()])
+            print(f"  distinct (se, sh, cu, simd...) ids {len(ids)}; workgroups per id min/max {cnt.min()}/{cnt.max()}")
     else:
         dims2 = (259, 256, 256, 256, 3) if mode == "bwd" else (39, 128, 128, 128, 1)
         W2, b2 = make(dims2, 2)
