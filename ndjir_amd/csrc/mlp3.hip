@@ -10,8 +10,9 @@
 // in fp32 by v_mfma_f32_32x32x16_f16).  Keeping lo pre-scaled by 2^11 puts it in hi's exponent range, so every
 // element within 2^-28 of the largest one of its scaling group keeps all 22 bits; smaller ones degrade
 // gracefully (absolute error <= 2^-39 of the group maximum).  Scaling groups: a 32-column block of a packed
-// weight matrix (scale fixed at pack time, stored behind the planes), and one tile of points x all features
-// for the activations (the tile maximum is reduced in LDS between the activation math and the split).
+// weight matrix (scale fixed at pack time, stored behind the planes), and ONE ROW (point) of the activations: the row
+// maxima are reduced in LDS between the activation math and the split.  Power-of-two scaling is exact, so a point's
+// result does not depend on which other points share its tile (batch invariance, as with the other engines).
 // Accuracy (tests/test_gpu_mlp.py, vs fp64): below a plain fp32 FMA chain's, at 3/16 of the fp32 MFMA time
 // and half of mlp6's -- operand rounding 2^-23 sits under the fp32 accumulation error that every fp32 GEMM has.
 //
@@ -20,8 +21,8 @@
 //                     phase A per 32x32 block: acc0 + acc1 2^-11 -> per-wave fp32 staging tile in LDS -> row-major
 //                       pass (bias + softplus / softplus' product, coalesced float4 side stores and loads,
 //                       bias-gradient column sums); results written back to the staging tile; running maximum
-//                     tile maximum -> LDS; barrier (every wave has also finished reading the planes)
-//                     phase B: scale from the maximum, staging tile -> 2-way split, planes updated in place
+//                     row maxima -> LDS; barrier (every wave has also finished reading the planes)
+//                     phase B: per-row scale from the maximum, staging tile -> 2-way split, planes updated in place
 //                     barrier
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -143,7 +144,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
   constexpr int RB = TM / 32;
   constexpr int TMP = TM + 4;          // rows per k-group incl. pad: (TMP * 16) % 256 == 64 -> conflict-free plane writes
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ unsigned s_tmax[4];       // [0], [1]: tile maximum of the layer outputs (ping-pong); [2]: of the chain input
+  __shared__ unsigned s_rmax[2][64];   // per row: largest finite |output| of the layer (bit pattern; ping-pong by layer)
+  __shared__ unsigned s_xmax[2][64];   // per row: largest finite |x| of the chain input tile (ping-pong by tile)
+  __shared__ float s_ainv[64];         // per row: 1 / scale of the planes the next k-loop reads
   const int PLANE = a.lds_split;       // 16-byte units per plane ( = k-groups * TMP )
   f16x8* act = reinterpret_cast<f16x8*>(lds);
   char* actb = reinterpret_cast<char*>(lds);
@@ -190,14 +193,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
     a.timeline[400 + 3 * blockIdx.x + 2] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
   }
   if (MODE != 0) for (int i = tid; i < a.bg_total; i += NTHREADS) bsum[i] = 0.f;
-  if (tid < 4) s_tmax[tid] = 0u;
+  if (tid < 128) { (&s_rmax[0][0])[tid] = 0u; (&s_xmax[0][0])[tid] = 0u; }
   __syncthreads();
+  int xpar = 0;                        // ping-pong slot of the input row maxima
 
   for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long row0 = tile * TM;
     const int rows = (int)((a.P - row0) < TM ? (a.P - row0) : TM);
-    float a_inv;                 // 1 / scale of the planes the next k-loop reads
-    float x_max;                 // largest finite |x| of the chain input tile
 
     // ---- chain input tile -> planes (zero padded to a multiple of 16 features) ----
     {
@@ -223,31 +225,35 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         return v;
       };
       f32x4 cache[IN_CACHE];
-      unsigned mb = 0;
+      auto rowmax = [&](int t, f32x4 v) {
+        unsigned mb = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const unsigned b = finite_abs_bits(v[q]); mb = b > mb ? b : mb; }
+        if (mb) atomicMax(&s_xmax[xpar][t / groups], mb);
+      };
 #pragma unroll
       for (int i = 0; i < IN_CACHE; ++i) {
         const int t = tid + i * NTHREADS;
         cache[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t < total) cache[i] = load(t);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const unsigned b = finite_abs_bits(cache[i][q]); mb = b > mb ? b : mb; }
+        if (t < total) { cache[i] = load(t); rowmax(t, cache[i]); }
       }
-      for (int t = tid + IN_CACHE * NTHREADS; t < total; t += NTHREADS) {
-        const f32x4 v = load(t);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const unsigned b = finite_abs_bits(v[q]); mb = b > mb ? b : mb; }
-      }
-      const float wm = wave_max(__uint_as_float(mb));
-      if (lane == 0) atomicMax(&s_tmax[2], __float_as_uint(wm));
+      for (int t = tid + IN_CACHE * NTHREADS; t < total; t += NTHREADS) rowmax(t, load(t));
       __syncthreads();
-      const unsigned mbits = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tmax[2]);
-      x_max = __uint_as_float(mbits);
-      float s_in;
-      scale_from_max(mbits, s_in, a_inv);
-      if (tid == 0 && a.x_amax) atomicMax(a.x_amax, mbits);
+      if (tid < TM) {
+        float s_row, inv_row;
+        scale_from_max(s_xmax[xpar][tid], s_row, inv_row);
+        s_ainv[tid] = inv_row;
+        s_xmax[xpar ^ 1][tid] = 0u;                    // the other slot: next tile's input stage, many barriers away
+      }
+      if (a.x_amax && tid < 64) {
+        const float wm = wave_max(__uint_as_float(tid < TM ? s_xmax[xpar][tid] : 0u));
+        if (tid == 0) atomicMax(a.x_amax, __float_as_uint(wm));
+      }
       auto emit = [&](int t, f32x4 v) {
         const int g = t % groups, m = t / groups;
         const int k = g * 4;
+        float s_in, inv_in;
+        scale_from_max(s_xmax[xpar][m], s_in, inv_in);
         put4(k, m, v, s_in);
         if (MODE != 0 && a.in_bgrad && m < rows) {      // bias gradient of the output layer: column sums of the input
 #pragma unroll
@@ -262,7 +268,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
       for (int t = tid + IN_CACHE * NTHREADS; t < total; t += NTHREADS) emit(t, load(t));
     }
     __syncthreads();
-    if (tid == 0) s_tmax[2] = 0u;        // next use: the next tile's input stage, many barriers away
     if (tile == blockIdx.x) stamp(MAX_CHAIN_LAYERS - 1, 1);
 
     int cur = 0;                         // ping-pong slot of the layer's tile maximum
@@ -289,7 +294,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
       const bool is_skip = (li == a.skip_layer);
       const float sc = pin(is_skip ? a.skip_scale : 1.f);
       const int nlim = pin((BWD && is_skip) ? a.skip_split : l_N);
-      const float ainv = pin(a_inv);
 
       // one k-loop: RBU row blocks of column block nb, accumulator pairs acc0/acc1[SLOT .. SLOT + RBU)
       // Two accumulator-pair slots: a wave works on at most two 32 x 32 output blocks at a time.
@@ -385,7 +389,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
           float z = 0.f;
 #pragma unroll
           for (int q = 0; q < KSPLIT; ++q) z += part[q * TM * 32 + t];
-          z = z * ainv * winv;
+          z = z * s_ainv[m] * winv;
           if (n < l_N && m < rows) {
             if (MODE == 0) {
               z += p_bias ? p_bias[n] : 0.f;
@@ -414,9 +418,23 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
       const float hsc = (MODE != 0 && is_skip) ? 1.f / sc : 1.f;
       const float nb2 = -b2 * hsc;
       const int g = lane & 7;
-      float vmax = 0.f;               // running max |v| (NaN ignored by v_max; Inf handled after the reduction)
       unsigned jobs = 0;    // job j in bits 8j..8j+7: column block | row block << 5
       int njobs = 0;
+      // running maximum of row `row` (8 lanes hold 4 columns each of it): max over the lane's 4 values, xor-butterfly over
+      // the 8 lanes, one LDS atomic.  v_max ignores NaN; an Inf sends the group through the bit-pattern filter.
+      auto row_max = [&](int row, f32x4 v) {
+        float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        if (!(m4 < 3.0e38f)) {
+          unsigned mb = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const unsigned b = finite_abs_bits(v[q]); mb = b > mb ? b : mb; }
+          m4 = __uint_as_float(mb);
+        }
+        m4 = fmaxf(m4, __shfl_xor(m4, 1));
+        m4 = fmaxf(m4, __shfl_xor(m4, 2));
+        m4 = fmaxf(m4, __shfl_xor(m4, 4));
+        if (g == 0) atomicMax(&s_rmax[cur][row], __float_as_uint(m4));
+      };
 #pragma unroll 1
       for (int round = 0; round < nrounds; ++round) {
       jobs = 0; njobs = 0;
@@ -471,7 +489,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const long long off = off0 + (long long)it * 8 * l_ld;
-            const f32x4 z = *reinterpret_cast<const f32x4*>(lp + it * 32) * ainv;
+            const int row = mbase + 8 * it;
+            const f32x4 z = *reinterpret_cast<const f32x4*>(lp + it * 32) * s_ainv[row];
             f32x4 v;
             if (MODE == 0) {
               f32x4 rb = {0.f, 0.f, 0.f, 0.f};
@@ -501,8 +520,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
               if (MODE == 2 && p_side_out2) *((gptr<f32x4>)(p_side_out2 + off)) = x2;
               colsum += v;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) vmax = fmaxf(vmax, fabsf(v[q]));
+            row_max(row, v);
             *reinterpret_cast<f32x4*>(lp + it * 32) = v;       // parked for phase B (same lane reads it back)
           }
         } else {
@@ -522,7 +540,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
             const float rm = mrow ? 1.f : 0.f;
             const long long grow = row0 + m;
             const long long off = off0 + (long long)it * 8 * l_ld;
-            const f32x4 z = *reinterpret_cast<const f32x4*>(lp + it * 32) * ainv * winv;
+            const f32x4 z = *reinterpret_cast<const f32x4*>(lp + it * 32) * s_ainv[m] * winv;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (last) {
               if (mrow) {
@@ -594,8 +612,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
               }
               colsum += v;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) vmax = fmaxf(vmax, fabsf(v[q]));
+            row_max(m, v);
             *reinterpret_cast<f32x4*>(lp + it * 32) = v;
           }
         }
@@ -619,33 +636,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         continue;
       }
 
-      // ---- tile maximum of this layer's outputs (what the next k-loop reads, incl. the skip concatenation) ----
-      {
-        float wm = wave_max(vmax);
-        if (!(wm < 3.0e38f)) {
-          // an Inf among the outputs: take the maximum of the finite values from the parked registers (rare path)
-          unsigned mb = 0;
-          for (int j = 0; j < njobs; ++j)
-            for (int it = 0; it < 4; ++it) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(stage + j * STG + g * GPS + (lane >> 3) * 4 + it * 32);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { const unsigned b = finite_abs_bits(v[q]); mb = b > mb ? b : mb; }
-            }
-          wm = wave_max(__uint_as_float(mb));
-        }
-        if (MODE != 1 && is_skip) wm = fmaxf(wm, x_max * fabsf(a.skip_scale));
-        if (lane == 0) atomicMax(&s_tmax[cur], __float_as_uint(wm));
+      // ---- row maxima of this layer's outputs are in s_rmax[cur] (incl. the skip concatenation's input part) ----
+      if (MODE != 1 && is_skip && tid < TM) {
+        const float xm = __uint_as_float(s_xmax[xpar][tid]) * fabsf(a.skip_scale);
+        atomicMax(&s_rmax[cur][tid], __float_as_uint(xm));
       }
-      __syncthreads();          // every wave has read the planes and contributed its maximum
+      __syncthreads();          // every wave has read the planes and contributed its maxima
       stamp(li, 3);
 
-      // ================= phase B: scale, 2-way split, planes updated in place =================
-      float s_out;
-      {
-        const unsigned mbits = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tmax[cur]);
-        scale_from_max(mbits, s_out, a_inv);
-        if (tid == 0 && ly.side_amax) atomicMax(ly.side_amax, mbits);
-      }
+      // ================= phase B: per-row scale, 2-way split, planes updated in place =================
 #pragma unroll 1
       for (int j = 0; j < njobs; ++j) {
         const int nb = (jobs >> (8 * j)) & 31, rb0 = (jobs >> (8 * j + 5)) & 7;
@@ -653,7 +652,20 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         const int mbase = rb0 * 32 + (lane >> 3);
         const float* lp = stage + j * STG + g * GPS + (lane >> 3) * 4;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) put4(n4, mbase + 8 * it, *reinterpret_cast<const f32x4*>(lp + it * 32), s_out);
+        for (int it = 0; it < 4; ++it) {
+          float s_row, inv_row;
+          scale_from_max(s_rmax[cur][mbase + 8 * it], s_row, inv_row);
+          put4(n4, mbase + 8 * it, *reinterpret_cast<const f32x4*>(lp + it * 32), s_row);
+        }
+      }
+      if (tid < TM) {
+        float s_row, inv_row;
+        scale_from_max(s_rmax[cur][tid], s_row, inv_row);
+        s_ainv[tid] = inv_row;           // read by the next layer's phase A, two barriers on
+      }
+      if (ly.side_amax && tid < 64) {
+        const float wm = wave_max(__uint_as_float(tid < TM ? s_rmax[cur][tid] : 0u));
+        if (tid == 0) atomicMax(ly.side_amax, __float_as_uint(wm));
       }
 
       // the planes beyond this layer's padded width must read as zero for the next layer's k-loop:
@@ -667,7 +679,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
           const int k = t % K0, m = t / K0;
           const float v = (m < rows) ? X[(long long)m * a.ldx + k] * a.skip_scale : 0.f;
           const int kk = base + k;
-          put1(kk, m, v, s_out);
+          float s_row, inv_row;
+          scale_from_max(s_rmax[cur][m], s_row, inv_row);
+          put1(kk, m, v, s_row);
           if (m < rows && ly.side_out) ly.side_out[(row0 + m) * ly.ld_side + kk] = v;
         }
         // zero the tail up to the next multiple of 16
@@ -675,11 +689,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         for (int t = tid; t < (wpad - wcat) * TM; t += NTHREADS) put1(wcat + t % (wpad - wcat), t / (wpad - wcat), 0.f, 1.f);
       }
       __syncthreads();
-      if (tid == 0) s_tmax[cur] = 0u;      // next use: two layers on, two barriers away
+      if (tid < TM) s_rmax[cur][tid] = 0u;      // next use: two layers on, two barriers away
       cur ^= 1;
       stamp(li, 4);
     }
     if (tile == blockIdx.x) stamp(MAX_CHAIN_LAYERS - 1, 2);
+    xpar ^= 1;
   }
   stamp(MAX_CHAIN_LAYERS - 1, 3);
   stamp_rt(1);
@@ -709,6 +724,7 @@ int launch_pack3(const float* W, float* dst, int K, int N, int transpose, hipStr
 
 int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream) {
   using namespace x3;
+  constexpr int LDS_DYN_MAX = 160 * 1024 - 2048;      // the kernel also holds 1.3 KB of static LDS (row maxima / scales)
   if (a.P <= 0) return NDJIR_OK;
   int TM = a.tile_rows == 32 ? 32 : 64;
   // widest activation the planes have to hold: chain input, every hidden output (+ skip concat)
@@ -753,13 +769,13 @@ int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream) {
   b.bg_lds = (int)(lds_bytes / 4);
   lds_bytes += (size_t)bg_total * 4;
   if (bg_total > 0 && !a.bg_partial) return NDJIR_ERR_ARG;
-  if (lds_bytes > 160 * 1024 - 64) return NDJIR_ERR_UNSUPPORTED;
+  if (lds_bytes > LDS_DYN_MAX) return NDJIR_ERR_UNSUPPORTED;
   long long blocks = b.n_tiles;
   if (blocks > 256LL * 8) blocks = 256LL * 8;
   if (bg_total > 0 && blocks > CHAIN_MAX_GRID_BG) blocks = CHAIN_MAX_GRID_BG;
   static bool attr_set = false;
   if (!attr_set) {
-#define NDJIR_SET(M, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain3<M, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)
+#define NDJIR_SET(M, T) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain3<M, T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX)
     NDJIR_SET(0, 64); NDJIR_SET(1, 64); NDJIR_SET(2, 64); NDJIR_SET(0, 32); NDJIR_SET(1, 32); NDJIR_SET(2, 32);
 #undef NDJIR_SET
     attr_set = true;
