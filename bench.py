@@ -10,11 +10,11 @@ samples, 128 lights), synthetic rays, reference-initialised weights.  Rays shard
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 
 `roofline` is for the dominant hand-written kernel, the fused MLP forward chain
-(`ndjir::x6::k_chain6<0, TM>`, or `ndjir::k_mlp_chain<0, TM>` with NDJIR_MLP_MATH=fp32): achieved =
-sum of the algorithmic FLOPs (2*in*out per affine per point) of its launches / sum of
+(`ndjir::x3::k_chain3<0, TM>`; `ndjir::x6::k_chain6` / `ndjir::k_mlp_chain` with NDJIR_MLP_MATH=bf16x6 / fp32):
+achieved = sum of the algorithmic FLOPs (2*in*out per affine per point) of its launches / sum of
 their durations, measured live with HIP events recorded on the launching stream around every launch
-inside the timed region.  In the default bf16x6 arithmetic one algorithmic FLOP costs six bf16 MFMA
-FLOPs, so the peak it is priced against is the dense bf16 MFMA peak / 6.
+inside the timed region.  In the default f16x3 arithmetic one algorithmic FLOP costs three f16 MFMA
+FLOPs, so the peak it is priced against is the dense 16-bit MFMA peak / 3 (bf16x6: / 6).
 Execution: the compute part of the step (ndjir_amd/step.py `Step.compute`: no collective inside) is captured once
 into a HIP graph and the timed region replays it (`--exec graph`, default; no host-side launch work in the timed
 region; N > 1: the scalar mask all-reduce and the gradient exchange are issued eagerly around every replay).  HIP events
@@ -38,8 +38,11 @@ if ROOT not in sys.path:
 MFLOP_PER_RAY_FWD_BWD = 2168.9
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
-# bf16x6 engine: every algorithmic fp32 FLOP is executed as 6 bf16 MFMA FLOPs (three-way operand split)
+# bf16x6 engine: every algorithmic fp32 FLOP is executed as 6 bf16 MFMA FLOPs (three-way operand split);
+# f16x3 engine: as 3 f16 MFMA FLOPs (scaled two-way split) -- f16 and bf16 MFMA run at the same rate
 PEAK_BF16X6_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_F16X3_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
+PROFILE_ROUND = "r02"
 
 
 def parse():
@@ -245,9 +248,9 @@ def train_leg(step, steps, barrier, use_graph):
 
 def committed_pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_hbm_bench.txt: FETCH_SIZE and WRITE_SIZE in KB per launch, collected in separate runs as
+    (profiles/<round>_pmc_hbm_bench.txt: FETCH_SIZE and WRITE_SIZE in KB per launch, collected in separate runs as
     MI355X_MICROARCH.md prescribes; FETCH doubled per its gfx950 note).  Not a live measurement: None if the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_bench.txt")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{PROFILE_ROUND}_pmc_hbm_bench.txt")
     try:
         vals, section = {}, None
         lines = open(path).read().splitlines()
@@ -419,18 +422,25 @@ def main():
         dom = kr.get("chain_fwd", dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0))
         step_tflops = MFLOP_PER_RAY_FWD_BWD * 1e6 * R / (ms * 1e-3) / 1e12      # per GPU
         tile = os.environ.get("NDJIR_MLP_TILE", "64")
-        x6 = mlp.get_math() == mlp.MATH_BF16X6
-        peak = PEAK_BF16X6_EFFECTIVE_TFLOPS if x6 else PEAK_FP32_MFMA_TFLOPS
-        kname = (f"ndjir::x6::k_chain6<0, {tile}> (fused MLP forward chain; fp32 operands split exactly into 3 bf16 planes, "
-                 f"6 v_mfma_f32_32x32x16_bf16 partial products per fp32 product, fp32 accumulate)") if x6 else \
-            f"ndjir::k_mlp_chain<0, {tile}> (fused MLP forward chain, fp32 MFMA 32x32x2)"
-        peak_note = ("dense bf16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 6 partial products per algorithmic FLOP"
-                     if x6 else "fp32-input MFMA peak (MI355X_MICROARCH.md)")
+        math = mlp.get_math()
+        x6, x3 = math == mlp.MATH_BF16X6, math == mlp.MATH_F16X3
+        peak = PEAK_F16X3_EFFECTIVE_TFLOPS if x3 else PEAK_BF16X6_EFFECTIVE_TFLOPS if x6 else PEAK_FP32_MFMA_TFLOPS
+        ksym = f"ndjir::x3::k_chain3<0, {tile}>" if x3 else f"ndjir::x6::k_chain6<0, {tile}>" if x6 else f"ndjir::k_mlp_chain<0, {tile}>"
+        kname = ksym + (" (fused MLP forward chain; fp32 operands scaled by powers of two and split into 2 f16 planes, "
+                        "3 v_mfma_f32_32x32x16_f16 partial products per fp32 product in two fp32 accumulators)" if x3 else
+                        " (fused MLP forward chain; fp32 operands split exactly into 3 bf16 planes, 6 v_mfma_f32_32x32x16_bf16 "
+                        "partial products per fp32 product, fp32 accumulate)" if x6 else
+                        " (fused MLP forward chain, fp32 MFMA 32x32x2)")
+        peak_note = ("dense 16-bit MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 3 partial products per algorithmic FLOP" if x3 else
+                     "dense bf16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 6 partial products per algorithmic FLOP" if x6 else
+                     "fp32-input MFMA peak (MI355X_MICROARCH.md)")
+        dtype = ("f32 (f16x2-split MFMA products, f32 accumulate; error vs fp64 below an fp32 FMA chain's)" if x3 else
+                 "f32 (bf16x3-split MFMA products, f32 accumulate)" if x6 else "f32")
         out = {
             "metric": "rays/sec (fwd+bwd) at 512 rays x 128 samples",
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (bf16x3-split MFMA products, f32 accumulate)" if x6 else "f32", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"config/{a.config}.yaml, B=1, R={R} rays/GPU x N={N} fg samples (+{r.n_bg_samples} bg, "
                                    f"{r.n_thetas * 2 * r.n_thetas} lights), voxel {conf.geometric_network.voxel.type} "
                                    f"{conf.geometric_network.voxel.grid_size}^3x{conf.geometric_network.voxel.feature_size}, "
@@ -438,20 +448,22 @@ def main():
                        "rays_per_gpu": R, "samples_per_ray": N, "parallelism": f"ray-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": dom["tflops"] / peak,
-                         "traffic": committed_pmc_traffic(f"ndjir::x6::k_chain6<0, {tile}>") if x6 else None,
+                         "traffic": committed_pmc_traffic(ksym),
                          "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes "
-                                         "of this command, profiles/r01_pmc_hbm_bench.txt -- mostly the stored activations; the kernel is "
-                                         "MFMA-bound, its algorithmic measure is FLOPs",
+                                         f"of this command, profiles/{PROFILE_ROUND}_pmc_hbm_bench.txt -- mostly the stored activations "
+                                         "(every hidden activation is written once for the backward pass); the kernel's algorithmic "
+                                         "measure is FLOPs",
                          "kernel": kname, "peak_note": peak_note,
                          # the same algorithmic fp32 FLOP/s against the fp32-input MFMA peak (what an fp32 GEMM engine could
-                         # reach at best on this chip): the bf16x6 engine exists to get past it
+                         # reach at best on this chip) and against the bf16x6 engine's effective peak (round 1's yardstick)
                          "frac_of_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
+                         "frac_of_bf16x6_peak": dom["tflops"] / PEAK_BF16X6_EFFECTIVE_TFLOPS,
                          "launches_per_step": dom["launches"] / max(profile_steps, 1), "avg_launch_us": dom["avg_us"],
                          "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
                          "note": "64-point-tile launches only (small launches use the 32-point-tile instantiation, listed as "
                                  "chain_fwd_t32 under `kernels`); an event interval spans the launch gap of the host-bound eager pass "
                                  "as well as the kernel, ~5-7 % more than rocprofv3's kernel-only average in "
-                                 "profiles/r01_bench_kernel_summary.txt",
+                                 f"profiles/{PROFILE_ROUND}_bench_kernel_summary.txt",
                          "method": ("HIP events on the launching stream around every launch of the same K steps issued "
                                     "eagerly right after the timed graph replays (events cannot be recorded inside a "
                                     "captured graph)") if exec_mode == "graph" else

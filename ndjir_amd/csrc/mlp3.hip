@@ -439,19 +439,22 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
       for (int round = 0; round < nrounds; ++round) {
       jobs = 0; njobs = 0;
       auto job = [&](int j, int nb, int rb) { jobs |= (unsigned)(nb | (rb << 5)) << (8 * j); };
+      int kl_nb0 = 0, kl_rb0 = 0, kl_nb1 = 0, kl_rb1 = 0;
       if (pair_mode) {
-        const int nb = wave + NWAVES * round;
-        job(0, nb, 0); job(1, nb, 1); njobs = 2;
-        kloop(IRB{}, I0{}, nb, 0, 0, KS);
+        kl_nb0 = wave + NWAVES * round;
+        job(0, kl_nb0, 0); job(1, kl_nb0, 1); njobs = 2;
       } else {
         const int b0 = wave + 2 * NWAVES * round, b1 = b0 + NWAVES;
-        if (b0 < nblk) { job(0, b0 / RB, b0 % RB); njobs = 1; kloop(I1{}, I0{}, b0 / RB, b0 % RB, 0, KS); }
-        if (b1 < nblk) { job(1, b1 / RB, b1 % RB); njobs = 2; kloop(I1{}, I1{}, b1 / RB, b1 % RB, 0, KS); }
+        if (b0 < nblk) { kl_nb0 = b0 / RB; kl_rb0 = b0 % RB; job(0, kl_nb0, kl_rb0); njobs = 1; }
+        if (b1 < nblk) { kl_nb1 = b1 / RB; kl_rb1 = b1 % RB; job(1, kl_nb1, kl_rb1); njobs = 2; }
+      }
+      if (pair_mode) kloop(IRB{}, I0{}, kl_nb0, 0, 0, KS);
+      else {
+        if (njobs > 0) kloop(I1{}, I0{}, kl_nb0, kl_rb0, 0, KS);
+        if (njobs > 1) kloop(I1{}, I1{}, kl_nb1, kl_rb1, 0, KS);
       }
       if (round == 0) stamp(li, 1);
       __builtin_amdgcn_wave_barrier();     // (a later round reuses the staging tiles)
-
-      // ================= phase A: activation math on the accumulators; results back into the staging tile =================
 #pragma unroll 1
       for (int j = 0; j < njobs; ++j) {
         const int nb = (jobs >> (8 * j)) & 31, rb0 = (jobs >> (8 * j + 5)) & 7;
@@ -481,6 +484,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
           f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
           if (MODE == 0 && p_bias) bias4 = *((gptr<const f32x4>)(p_bias + n4)) * b2;
           const float wb2 = winv * b2;
+          // (requesting these before the k-loops does not help: vmcnt retires in order, the k-loop's weight fragments
+          // would wait behind the HBM latency; requesting both jobs' at once measured the same)
           f32x4 hs[4];
           if (MODE != 0) {
 #pragma unroll
