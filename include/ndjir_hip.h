@@ -80,22 +80,31 @@ int ndjir_voxel_feature_zero_touched_interp(int N, float* grad_feature, const fl
  * `check_inf_or_nan_grad` (python/solver.py:67-69) without reading the 2 GiB buffer. */
 int ndjir_voxel_feature_check_touched(int N, const float* grad_feature, const float* query, const int* grid_sizes, int D,
                                       const float* min, const float* max, int* flag, hipStream_t stream);
-/* ---- sparse exchange of the dense voxel gradient between ranks (no reference counterpart: the reference is single-GPU).
- * A rank touches < 1 % of the 512^3 cells per step.  pack_rows appends the NON-ZERO rows (D = 4: one float4 per cell) of
- * the cells the N query points touch to a packed list -- ids (capacity) int32, rows (capacity, 4) -- each cell once
- * (bitmap: 1 bit per cell, all zero before the first call, cleared again by ndjir_sparse_rows_clear_bitmap); *count
- * (device int) keeps counting past capacity so that the caller can detect an overflow.  After an all-gather with a
- * common capacity -- ids (world, capacity), rows (world, capacity, 4), counts (world), all device memory --
- * ndjir_sparse_rows_apply adds every other rank's rows into the local buffer and ndjir_sparse_rows_zero clears all
- * listed rows (re-arming the accumulate-in-place buffer for the next step without touching 2 GiB). */
+/* ---- sparse exchange of a dense grid gradient between ranks (no reference counterpart: the reference is single-GPU).
+ * A rank touches < 1 % of the 512^3 cells per step.  pack_rows appends the NON-ZERO rows (the D = 4 or 8 floats of one
+ * cell) of the cells in the interpolation stencils of the N query points to a packed list -- ids (capacity) int32, rows
+ * (capacity, D) -- each cell once (bitmap: 1 bit per cell, all zero before the first call, cleared again by
+ * ndjir_sparse_rows_clear_bitmap); *count (device int) keeps counting past capacity.  After all-gathers of the counts
+ * and of the first `limit` rows of every rank -- ids (world, capacity), rows (world, capacity, D), counts (world), all
+ * device memory, only [r][0..limit) communicated -- ndjir_sparse_rows_apply adds every other rank's rows into the local
+ * buffer, ndjir_sparse_rows_overflow raises a device flag when some rank listed more than `limit` rows (the caller
+ * vetoes that optimizer step and grows `limit`; no host synchronisation per step), and ndjir_sparse_rows_zero clears
+ * all listed rows (own_ids / own_count non-null: this rank's own rows from its local list, which may exceed `limit`),
+ * re-arming the accumulate-in-place buffer for the next step without touching the whole tensor. */
 int ndjir_voxel_feature_pack_rows(int N, const float* grad_feature, const float* query, const int* grid_sizes, int D,
                                   const float* min, const float* max, unsigned* bitmap, int* ids, float* rows, int* count,
                                   int capacity, hipStream_t stream);
+/* topo 0 dense voxel (grid_sizes[3]) / 1 tri-plane / 2 tri-line (grid_sizes[0] = G); interp 0 linear / 1 cosine / 2 Lanczos */
+int ndjir_grid_pack_rows(int topo, int interp, int N, const float* grad_feature, const float* query, const int* grid_sizes, int D,
+                         const float* min, const float* max, unsigned* bitmap, int* ids, float* rows, int* count, int capacity,
+                         hipStream_t stream);
 int ndjir_sparse_rows_clear_bitmap(const int* ids, const int* count, int capacity, unsigned* bitmap, hipStream_t stream);
-int ndjir_sparse_rows_apply(const int* ids, const float* rows, const int* counts, int world, int capacity, int skip_rank,
-                            float* grad_feature, int D, hipStream_t stream);
-int ndjir_sparse_rows_zero(const int* ids, const int* counts, int world, int capacity, float* grad_feature, int D,
-                           hipStream_t stream);
+int ndjir_sparse_rows_apply(const int* ids, const float* rows, const int* counts, int world, int capacity, int limit,
+                            int skip_rank, float* grad_feature, int D, hipStream_t stream);
+int ndjir_sparse_rows_overflow(const int* counts, int world, int limit, int* flag, hipStream_t stream);
+/* (`limit`: device int here -- the call may be replayed from a captured HIP graph after the limit has grown) */
+int ndjir_sparse_rows_zero(const int* ids, const int* counts, int world, int capacity, const int* limit, int own_rank,
+                           const int* own_ids, const int* own_count, float* grad_feature, int D, hipStream_t stream);
 NDJIR_DECL_VOXEL_FAMILY(cosine_voxel_feature)
 NDJIR_DECL_VOXEL_FAMILY(lanczos_voxel_feature)
 

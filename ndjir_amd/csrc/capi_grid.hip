@@ -162,7 +162,19 @@ extern "C" int ndjir_voxel_feature_pack_rows(int N, const float* gf, const float
                                              hipStream_t st) {
   if (N <= 0) return NDJIR_OK;
   CHECK_PTRS(gf, query, bitmap, ids, rows, count);
-  return launch_pack_rows(voxel_desc(gs, D, mn, mx), N, gf, query, bitmap, ids, rows, count, capacity, st);
+  return launch_pack_rows(LINEAR, voxel_desc(gs, D, mn, mx), N, gf, query, bitmap, ids, rows, count, capacity, st);
+}
+
+// ... for any dense family: topo 0 voxel (grid_sizes[3]) / 1 tri-plane / 2 tri-line (grid_sizes[0] = G), interp 0 linear /
+// 1 cosine / 2 Lanczos, D = 4 or 8.  A row = the D floats of one cell; cell id = float offset / D.
+extern "C" int ndjir_grid_pack_rows(int topo, int interp, int N, const float* gf, const float* query, const int* gs, int D,
+                                    const float* mn, const float* mx, unsigned* bitmap, int* ids, float* rows, int* count,
+                                    int capacity, hipStream_t st) {
+  if (N <= 0) return NDJIR_OK;
+  CHECK_PTRS(gf, query, gs, mn, mx, bitmap, ids, rows, count);
+  if (topo < VOXEL || topo > TRILINE || interp < LINEAR || interp > LANCZOS) return NDJIR_ERR_ARG;
+  const GridDesc g = topo == VOXEL ? voxel_desc(gs, D, mn, mx) : plane_desc(topo, gs[0], D, mn, mx);
+  return launch_pack_rows(interp, g, N, gf, query, bitmap, ids, rows, count, capacity, st);
 }
 
 // the same for the cosine (interp = 1) and Lanczos (interp = 2: 4 x 4 x 4 taps) dense voxel families

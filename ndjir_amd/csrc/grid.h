@@ -23,8 +23,8 @@ struct GridDesc {
 int launch_query(int interp, const GridDesc& g, long long P, float* out, const float* query, const float* feature, bool accum, hipStream_t stream);
 int launch_dquery(int interp, const GridDesc& g, long long P, int mode, float* dst, const float* src, const float* query, const float* feature, bool accum, hipStream_t stream);
 int launch_mark_touched(const GridDesc& g, long long P, const float* query, unsigned* bitmap, hipStream_t stream);
-int launch_pack_rows(const GridDesc& g, long long P, const float* gf, const float* query, unsigned* bitmap, int* ids, float* rows,
-                     int* count, int capacity, hipStream_t stream);
+int launch_pack_rows(int interp, const GridDesc& g, long long P, const float* gf, const float* query, unsigned* bitmap, int* ids,
+                     float* rows, int* count, int capacity, hipStream_t stream);
 int launch_zero_touched(int interp, const GridDesc& g, long long P, float* gf, const float* query, int* nonfinite_flag,
                         hipStream_t stream);
 int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* gf, const float* gg_query, const float* grad_output, const float* query, hipStream_t stream);

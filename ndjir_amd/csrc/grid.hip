@@ -477,22 +477,32 @@ __global__ void __launch_bounds__(256) k_mark_touched(long long P, const float* 
   NDJIR_GRID_THREAD_EPILOGUE
 }
 
+template <int TOPO, int I, int D4>      // D4 = float4 chunks per row (D = 4 or 8)
 __global__ void __launch_bounds__(256) k_pack_rows(long long P, const float* __restrict__ gf, const float* __restrict__ query,
                                                    GridDesc g, unsigned* __restrict__ bitmap, int* __restrict__ ids,
                                                    float4* __restrict__ rows, int* __restrict__ count, int capacity) {
-  constexpr int TOPO = VOXEL, I = LINEAR;
-  constexpr int ND = 3, NT = 2;
+  constexpr int ND = NDims<TOPO>::v, NT = NTaps<I>::v;
   NDJIR_GRID_THREAD_PROLOGUE
   NDJIR_FOR_TAPS(ND, NT) {
     const long long off = cell_offset(st, i, j, k);
-    const float4 v = *reinterpret_cast<const float4*>(gf + off);
-    if (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f) {
-      const unsigned cell = (unsigned)(off >> 2);
+    float4 v[D4];
+    bool nz = false;
+#pragma unroll
+    for (int c = 0; c < D4; ++c) {
+      v[c] = *reinterpret_cast<const float4*>(gf + off + 4 * c);
+      nz |= (v[c].x != 0.f || v[c].y != 0.f || v[c].z != 0.f || v[c].w != 0.f);
+    }
+    if (nz) {
+      const unsigned cell = (unsigned)(off / (4 * D4));
       const unsigned bit = 1u << (cell & 31);
       const unsigned old = atomicOr(bitmap + (cell >> 5), bit);
       if (!(old & bit)) {
         const int slot = atomicAdd(count, 1);
-        if (slot < capacity) { ids[slot] = (int)cell; rows[slot] = v; }
+        if (slot < capacity) {
+          ids[slot] = (int)cell;
+#pragma unroll
+          for (int c = 0; c < D4; ++c) rows[(long long)slot * D4 + c] = v[c];
+        }
       }
     }
   }
@@ -796,12 +806,17 @@ int launch_mark_touched(const GridDesc& g, long long P, const float* query, unsi
   return ndjir_check_launch();
 }
 
-int launch_pack_rows(const GridDesc& g, long long P, const float* gf, const float* query, unsigned* bitmap, int* ids, float* rows,
-                     int* count, int capacity, hipStream_t stream) {
+int launch_pack_rows(int interp, const GridDesc& g, long long P, const float* gf, const float* query, unsigned* bitmap, int* ids,
+                     float* rows, int* count, int capacity, hipStream_t stream) {
   if (P <= 0) return NDJIR_OK;
-  if (g.topo != VOXEL || g.D != 4) return NDJIR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_pack_rows, dim3(grid_blocks(P * g.S)), dim3(256), 0, stream, P, gf, query, g, bitmap, ids,
-                     reinterpret_cast<float4*>(rows), count, capacity);
+  if (g.topo == HASH || (g.D != 4 && g.D != 8)) return NDJIR_ERR_UNSUPPORTED;
+  const int blocks = grid_blocks(P * g.S);
+  NDJIR_DISPATCH_TI(g.topo, interp, {
+    if (g.D == 4) hipLaunchKernelGGL((k_pack_rows<TOPO, I, 1>), dim3(blocks), dim3(256), 0, stream, P, gf, query, g, bitmap, ids,
+                                     reinterpret_cast<float4*>(rows), count, capacity);
+    else hipLaunchKernelGGL((k_pack_rows<TOPO, I, 2>), dim3(blocks), dim3(256), 0, stream, P, gf, query, g, bitmap, ids,
+                            reinterpret_cast<float4*>(rows), count, capacity);
+  })
   return ndjir_check_launch();
 }
 

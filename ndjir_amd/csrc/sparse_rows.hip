@@ -1,7 +1,9 @@
 // sparse_rows.hip -- the receiving side of the sparse grid-gradient exchange of the ray-sharded step (SURVEY.md §8 e).
-// The reference has no distributed code; the 2 GiB dense voxel gradient is exchanged as packed lists of
-// (cell id, float4 row) per rank (ndjir_voxel_feature_pack_rows), all-gathered with a common capacity:
-//   lists: ids (world, cap) int32, rows (world, cap, 4) fp32, counts (world) int32 -- all in device memory.
+// The reference has no distributed code; a dense grid gradient (2 GiB for the 512^3 x 4 voxel grid, 403 MB for the
+// 3 x 2048^2 x 8 tri-plane) is exchanged as packed lists of (cell id, row of D floats) per rank
+// (ndjir_grid_pack_rows), all-gathered with a common, fixed number of rows:
+//   lists: ids (world, cap) int32, rows (world, cap, D) fp32, counts (world) int32 -- all in device memory;
+//   `limit` = rows per rank that were actually communicated (a rank whose count exceeds it raised the overflow flag).
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -9,30 +11,51 @@
 namespace ndjir {
 
 // buf[cell] += row for every listed row of every rank but `skip_rank` (this rank's own rows are already in buf)
+template <int D4>
 __global__ void __launch_bounds__(256) k_rows_apply(const int* __restrict__ ids, const float4* __restrict__ rows,
-                                                    const int* __restrict__ counts, int world, int cap, int skip_rank,
+                                                    const int* __restrict__ counts, int world, int cap, int limit, int skip_rank,
                                                     float* __restrict__ buf) {
-  const long long total = (long long)world * cap;
+  const long long total = (long long)world * limit;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const int r = (int)(t / cap), i = (int)(t - (long long)r * cap);
+    const int r = (int)(t / limit), i = (int)(t - (long long)r * limit);
     if (r == skip_rank || i >= counts[r]) continue;
-    const float4 v = rows[t];
-    float* p = buf + (long long)ids[t] * 4;
-    if (v.x != 0.f) atomicAdd(p, v.x);
-    if (v.y != 0.f) atomicAdd(p + 1, v.y);
-    if (v.z != 0.f) atomicAdd(p + 2, v.z);
-    if (v.w != 0.f) atomicAdd(p + 3, v.w);
+    const long long e = (long long)r * cap + i;
+    float* p = buf + (long long)ids[e] * (4 * D4);
+#pragma unroll
+    for (int c = 0; c < D4; ++c) {
+      const float4 v = rows[e * D4 + c];
+      if (v.x != 0.f) atomicAdd(p + 4 * c, v.x);
+      if (v.y != 0.f) atomicAdd(p + 4 * c + 1, v.y);
+      if (v.z != 0.f) atomicAdd(p + 4 * c + 2, v.z);
+      if (v.w != 0.f) atomicAdd(p + 4 * c + 3, v.w);
+    }
   }
 }
 
-// buf[cell] = 0 for every listed row of every rank: re-arms the accumulate-in-place buffer for the next step
+// buf[cell] = 0 for every listed row: the other ranks' communicated rows and ALL of this rank's own rows (own_ids /
+// own_count: the local list, which may be longer than `limit`) -- re-arms the accumulate-in-place buffer
+// (`limit` is read from device memory: the call may be replayed from a captured HIP graph after the limit has grown)
+template <int D4>
 __global__ void __launch_bounds__(256) k_rows_zero(const int* __restrict__ ids, const int* __restrict__ counts, int world, int cap,
-                                                   float* __restrict__ buf) {
-  const long long total = (long long)world * cap;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const int r = (int)(t / cap), i = (int)(t - (long long)r * cap);
-    if (i >= counts[r]) continue;
-    *reinterpret_cast<float4*>(buf + (long long)ids[t] * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                                                   const int* __restrict__ limit_p, int own_rank, const int* __restrict__ own_ids,
+                                                   const int* __restrict__ own_count, float* __restrict__ buf) {
+  int limit = *limit_p;
+  if (limit > cap) limit = cap;
+  const long long remote = (long long)world * limit;
+  int own = own_ids ? *own_count : 0;
+  if (own > cap) own = cap;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < remote + own; t += (long long)gridDim.x * 256) {
+    int cell;
+    if (t < remote) {
+      const int r = (int)(t / limit), i = (int)(t - (long long)r * limit);
+      if ((own_ids && r == own_rank) || i >= counts[r]) continue;
+      cell = ids[(long long)r * cap + i];
+    } else {
+      cell = own_ids[t - remote];
+    }
+    float4* p = reinterpret_cast<float4*>(buf + (long long)cell * (4 * D4));
+#pragma unroll
+    for (int c = 0; c < D4; ++c) p[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -44,6 +67,14 @@ __global__ void __launch_bounds__(256) k_rows_clear_bitmap(const int* __restrict
   for (int t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) bitmap[(unsigned)ids[t] >> 5] = 0u;
 }
 
+// *flag |= 1 when a rank listed more rows than were communicated (the step's grid gradient is then incomplete: the
+// caller vetoes the optimizer step on the device and grows the communicated size)
+__global__ void k_rows_overflow(const int* __restrict__ counts, int world, int limit, int* __restrict__ flag) {
+  bool over = false;
+  for (int r = threadIdx.x; r < world; r += 64) over |= counts[r] > limit;
+  if (__any(over) && threadIdx.x == 0) *flag = 1;
+}
+
 static int blocks_for(long long n) {
   long long b = (n + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -53,22 +84,29 @@ static int blocks_for(long long n) {
 
 using namespace ndjir;
 
-extern "C" int ndjir_sparse_rows_apply(const int* ids, const float* rows, const int* counts, int world, int capacity,
+extern "C" int ndjir_sparse_rows_apply(const int* ids, const float* rows, const int* counts, int world, int capacity, int limit,
                                        int skip_rank, float* buf, int D, hipStream_t stream) {
-  if (world <= 0 || capacity <= 0) return NDJIR_OK;
-  if (!ids || !rows || !counts || !buf) return NDJIR_ERR_ARG;
-  if (D != 4) return NDJIR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_rows_apply, dim3(blocks_for((long long)world * capacity)), dim3(256), 0, stream, ids,
-                     reinterpret_cast<const float4*>(rows), counts, world, capacity, skip_rank, buf);
+  if (world <= 0 || capacity <= 0 || limit <= 0) return NDJIR_OK;
+  if (!ids || !rows || !counts || !buf || limit > capacity) return NDJIR_ERR_ARG;
+  if (D != 4 && D != 8) return NDJIR_ERR_UNSUPPORTED;
+  const int blocks = blocks_for((long long)world * limit);
+  if (D == 4) hipLaunchKernelGGL(k_rows_apply<1>, dim3(blocks), dim3(256), 0, stream, ids, reinterpret_cast<const float4*>(rows), counts,
+                                 world, capacity, limit, skip_rank, buf);
+  else hipLaunchKernelGGL(k_rows_apply<2>, dim3(blocks), dim3(256), 0, stream, ids, reinterpret_cast<const float4*>(rows), counts, world,
+                          capacity, limit, skip_rank, buf);
   return ndjir_check_launch();
 }
 
-extern "C" int ndjir_sparse_rows_zero(const int* ids, const int* counts, int world, int capacity, float* buf, int D,
-                                      hipStream_t stream) {
+extern "C" int ndjir_sparse_rows_zero(const int* ids, const int* counts, int world, int capacity, const int* limit, int own_rank,
+                                      const int* own_ids, const int* own_count, float* buf, int D, hipStream_t stream) {
   if (world <= 0 || capacity <= 0) return NDJIR_OK;
-  if (!ids || !counts || !buf) return NDJIR_ERR_ARG;
-  if (D != 4) return NDJIR_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_rows_zero, dim3(blocks_for((long long)world * capacity)), dim3(256), 0, stream, ids, counts, world, capacity, buf);
+  if (!ids || !counts || !buf || !limit || ((own_ids == nullptr) != (own_count == nullptr))) return NDJIR_ERR_ARG;
+  if (D != 4 && D != 8) return NDJIR_ERR_UNSUPPORTED;
+  const int blocks = blocks_for((long long)(world + 1) * capacity);      // grid-stride over world x *limit (+ own rows)
+  if (D == 4) hipLaunchKernelGGL(k_rows_zero<1>, dim3(blocks), dim3(256), 0, stream, ids, counts, world, capacity, limit, own_rank, own_ids,
+                                 own_count, buf);
+  else hipLaunchKernelGGL(k_rows_zero<2>, dim3(blocks), dim3(256), 0, stream, ids, counts, world, capacity, limit, own_rank, own_ids,
+                          own_count, buf);
   return ndjir_check_launch();
 }
 
@@ -76,5 +114,12 @@ extern "C" int ndjir_sparse_rows_clear_bitmap(const int* ids, const int* count, 
   if (capacity <= 0) return NDJIR_OK;
   if (!ids || !count || !bitmap) return NDJIR_ERR_ARG;
   hipLaunchKernelGGL(k_rows_clear_bitmap, dim3(blocks_for(capacity)), dim3(256), 0, stream, ids, count, capacity, bitmap);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_sparse_rows_overflow(const int* counts, int world, int limit, int* flag, hipStream_t stream) {
+  if (world <= 0) return NDJIR_OK;
+  if (!counts || !flag) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_rows_overflow, dim3(1), dim3(64), 0, stream, counts, world, limit, flag);
   return ndjir_check_launch();
 }

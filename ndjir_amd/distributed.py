@@ -71,88 +71,139 @@ def allreduce_sparse_rows(buf, cell_ids, group=None, return_remote=False):
 
 
 class SparseRows:
-    """What the HIP-path exchange keeps for a buffer: every rank's packed cell ids (world, cap) and counts (world) --
-    the rows that hold gradient in the local dense buffer after the exchange.  `zero(buf)` clears exactly those.
+    """What the HIP-path exchange keeps for a buffer: every rank's packed cell ids (world, cap), their counts (world),
+    the number of rows per rank that were communicated (`limit`) and this rank's own full list -- together the rows
+    that hold gradient in the local dense buffer after the exchange.  `zero(buf)` clears exactly those.
     The tensors are allocated once per buffer (worst-case capacity) and rewritten by every exchange, so a HIP graph
     that captured `zero` keeps reading the current lists."""
 
-    def __init__(self, ids, counts, world, cap):
-        self.ids, self.counts, self.world, self.cap = ids, counts, world, cap
+    def __init__(self, st, rank):
+        self.st, self.rank = st, rank
 
     def zero(self, buf):
         from . import lib
-        lib.call("sparse_rows_zero", self.ids, self.counts, self.world, self.cap, buf, buf.shape[-1])
+        st = self.st
+        lib.call("sparse_rows_zero", st["ids_all"], st["counts_all"], st["world"], st["cap"], st["limit_dev"], self.rank,
+                 st["ids"], st["count"], buf, buf.shape[-1])
 
 
 _STATE = {}
+_GRID_GROUP = {}
+CHECK_EVERY = 64          # exchanges between two (host-synchronising) looks at the row counts
+
+
+def grid_group(group=None):
+    """A second communicator for the sparse grid exchange, so that it progresses beside the MLP bucket's all-reduce
+    (collectives of ONE group execute in issue order on its stream).  Created lazily, once per parent group."""
+    key = id(group)
+    if key not in _GRID_GROUP:
+        ranks = list(range(dist.get_world_size(group))) if group is None else dist.get_process_group_ranks(group)
+        _GRID_GROUP[key] = dist.new_group(ranks=ranks)
+    return _GRID_GROUP[key]
 
 
 def _state(buf, capacity, world):
     st = _STATE.get(buf.data_ptr())
-    cells = buf.numel() // buf.shape[-1]
+    D = buf.shape[-1]
+    cells = buf.numel() // D
     if st is None or st["cells"] != cells or st["cap"] < capacity or st["world"] != world:
-        dev, D = buf.device, buf.shape[-1]
-        st = dict(cells=cells, cap=capacity, world=world,
+        dev = buf.device
+        st = dict(cells=cells, cap=capacity, world=world, limit=None, calls=0,
                   bitmap=torch.zeros((cells + 31) // 32, dtype=torch.int32, device=dev),
                   count=torch.zeros(1, dtype=torch.int32, device=dev),
+                  overflow=torch.zeros(1, dtype=torch.int32, device=dev),
+                  limit_dev=torch.zeros(1, dtype=torch.int32, device=dev),
                   ids=torch.empty(capacity, dtype=torch.int32, device=dev),
                   rows=torch.empty((capacity, D), dtype=torch.float32, device=dev),
                   ids_all=torch.zeros((world, capacity), dtype=torch.int32, device=dev),
                   rows_all=torch.empty((world, capacity, D), dtype=torch.float32, device=dev),
                   counts_all=torch.zeros(world, dtype=torch.int32, device=dev))
-        st["handle"] = SparseRows(st["ids_all"], st["counts_all"], world, capacity)
         _STATE[buf.data_ptr()] = st
     return st
 
 
-def allreduce_voxel_rows_hip(buf, queries, min_=(-1.0, -1.0, -1.0), max_=(1.0, 1.0, 1.0), group=None):
-    """HIP path of the sparse exchange for a dense D = 4 voxel gradient buffer on the GPU (csrc/grid.hip
-    `k_pack_rows`, csrc/sparse_rows.hip): the non-zero rows of the cells this rank's query points touched are packed
-    once each on the device (bitmap dedup), all-gathered with the common size max_r(count_r) -- the one host
-    synchronisation of the exchange is reading those counts -- and the other ranks' rows are added in place.
-    List capacity = the worst case (8 corners of every point distinct): lists never grow, their addresses never change.
-    Returns the buffer's `SparseRows` handle (for re-arming the buffer before the next step)."""
+_TOPO = {"voxel": 0, "triplane": 1, "triline": 2}
+_INTERP = {"": 0, "linear": 0, "cosine": 1, "lanczos": 2}
+_TAPS = {0: 2, 1: 2, 2: 4}
+
+
+def exchange_grid_rows_hip(buf, family, queries, min_=(-1.0, -1.0, -1.0), max_=(1.0, 1.0, 1.0), group=None):
+    """HIP path of the sparse exchange for the dense gradient buffer of any dense grid family on the GPU (D = 4 or 8;
+    csrc/grid.hip `k_pack_rows`, csrc/sparse_rows.hip).  `family`: voxel / triplane / triline with an optional cosine_ /
+    lanczos_ prefix.  The non-zero rows of the cells in the stencils of this rank's query points are packed once each
+    on the device (bitmap dedup), the counts and the first `limit` rows of every rank are all-gathered and the other
+    ranks' rows are added in place.
+
+    No host synchronisation per step: `limit` (rows per rank on the wire) is fixed -- measured on the first exchange
+    with 50 % head-room -- and a device flag (`st["overflow"]`, returned with the handle) is raised when some rank listed
+    more; the caller vetoes that optimizer step on the device (Step.optimizer_step) and `limit` grows at the next look
+    at the counts, every CHECK_EVERY exchanges.  List capacity = the worst case (every stencil cell distinct): lists
+    never grow, their addresses never change.  Returns the buffer's `SparseRows` handle."""
     from . import lib
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    G, D = list(buf.shape[:3]), buf.shape[-1]
-    cap = sum(q.numel() // 3 for q in queries) * 8
+    interp_name, _, topo_name = family.rpartition("_")
+    topo, interp = _TOPO[topo_name], _INTERP[interp_name]
+    D = buf.shape[-1]
+    if topo == 0:
+        gs, sub, nd = list(buf.shape[:3]), 1, 3
+    else:
+        gs, sub, nd = [buf.shape[1]] * 3, 3, (2 if topo == 1 else 1)
+    cells = buf.numel() // D
+    cap = min(cells, sum(q.numel() // 3 for q in queries) * sub * _TAPS[interp] ** nd)
     st = _state(buf, cap, world)
     cap = st["cap"]
     st["count"].zero_()
     for q in queries:
         q = q.detach().reshape(-1, 3).contiguous()
-        lib.call("voxel_feature_pack_rows", q.shape[0], buf, q, G, D, list(min_), list(max_), st["bitmap"], st["ids"],
+        lib.call("grid_pack_rows", topo, interp, q.shape[0], buf, q, gs, D, list(min_), list(max_), st["bitmap"], st["ids"],
                  st["rows"], st["count"], cap)
     lib.call("sparse_rows_clear_bitmap", st["ids"], st["count"], cap, st["bitmap"])
     counts = st["counts_all"]
-    dist.all_gather(list(counts.view(world, 1).unbind(0)), st["count"], group=group)
-    host = counts.tolist()                                # the exchange's one host synchronisation
-    assert max(host) <= cap, "more distinct cells than point corners"
-    m = min(cap, max(4096, -(-max(host) // 4096) * 4096))  # rows actually communicated (same on every rank)
+    gg = grid_group(group) if world > 1 else group
+    dist.all_gather(list(counts.view(world, 1).unbind(0)), st["count"], group=gg)
+    st["calls"] += 1
+    if st["limit"] is None or st["calls"] % CHECK_EVERY == 0:
+        most = int(counts.max().item())               # the only host synchronisation, once per CHECK_EVERY exchanges
+        assert most <= cap, "more distinct cells than stencil taps"
+        want = min(cap, max(4096, -(-int(most * 1.5) // 4096) * 4096))
+        if st["limit"] is None or want > st["limit"]:
+            st["limit"] = want
+            st["limit_dev"].fill_(want)
+    m = st["limit"]
     ids, rows = st["ids_all"], st["rows_all"]
-    dist.all_gather([ids[r, :m] for r in range(world)], st["ids"][:m], group=group)
-    dist.all_gather([rows[r, :m] for r in range(world)], st["rows"][:m], group=group)
-    lib.call("sparse_rows_apply", ids, rows, counts, world, cap, rank, buf, D)
-    return st["handle"]
+    dist.all_gather([ids[r, :m] for r in range(world)], st["ids"][:m], group=gg)
+    dist.all_gather([rows[r, :m] for r in range(world)], st["rows"][:m], group=gg)
+    lib.call("sparse_rows_overflow", counts, world, m, st["overflow"])
+    lib.call("sparse_rows_apply", ids, rows, counts, world, cap, m, rank, buf, D)
+    return SparseRows(st, rank)
+
+
+def allreduce_voxel_rows_hip(buf, queries, min_=(-1.0, -1.0, -1.0), max_=(1.0, 1.0, 1.0), group=None):
+    """Linear dense voxel grid (kept for callers of the round-1 name)."""
+    return exchange_grid_rows_hip(buf, "voxel", queries, min_, max_, group)
 
 
 def allreduce_step_gradients(flat_mlp_grad, grid_bufs, grid_queries, group=None):
     """One gradient exchange per step.  `grid_bufs`: {name: dense gradient buffer};
-    `grid_queries`: {name: (list of query tensors, grid_sizes)} for dense voxel grids; buffers
-    without an entry (tri-plane / tri-line, a few hundred MB at most) are all-reduced densely.
-    Returns, for the sparsely exchanged buffers, {name: SparseRows handle} (HIP path: GPU buffer with D = 4) or
-    {name: row ids received from other ranks} (generic torch path)."""
-    dist.all_reduce(flat_mlp_grad, group=group)
+    `grid_queries`: {name: (list of query tensors, grid_sizes or family name)}: the points whose stencil cells can hold
+    gradient.  GPU buffers of the dense families (D = 4 or 8) go through the HIP sparse exchange on a second
+    communicator while the MLP bucket's all-reduce is in flight; buffers without an entry are all-reduced densely.
+    Returns, for the sparsely exchanged buffers, {name: SparseRows handle} (HIP path) or {name: row ids received from
+    other ranks} (generic torch path: CPU tests, unusual layouts)."""
+    work = dist.all_reduce(flat_mlp_grad, group=group, async_op=True)
     remote_rows = {}
     for name, buf in grid_bufs.items():
         q = grid_queries.get(name)
         if q is None:
             dist.all_reduce(buf, group=group)
             continue
-        queries, grid_sizes = q
-        if buf.is_cuda and buf.dim() == 4 and buf.shape[-1] == 4:
-            remote_rows[name] = allreduce_voxel_rows_hip(buf, queries, group=group)
+        queries, spec = q
+        family = spec if isinstance(spec, str) else "voxel"
+        if buf.is_cuda and buf.shape[-1] in (4, 8):
+            remote_rows[name] = exchange_grid_rows_hip(buf, family, queries, group=group)
             continue
-        ids = torch.cat([voxel_cell_ids(x, grid_sizes) for x in queries])
+        assert family == "voxel", "the generic (torch) sparse exchange walks the 8 corners of the linear voxel stencil"
+        ids = torch.cat([voxel_cell_ids(x, spec) for x in queries])
         _, remote_rows[name] = allreduce_sparse_rows(buf.view(-1, buf.shape[-1]), ids, group=group, return_remote=True)
+    work.wait()
     return remote_rows

@@ -69,8 +69,10 @@ SIGS = {
     "voxel_feature_check_touched": "ippIiFFq",
     "voxel_feature_pack_rows": "ippIiFFqqpqi",
     "sparse_rows_clear_bitmap": "qqiq",
-    "sparse_rows_apply": "qpqiiipi",
-    "sparse_rows_zero": "qqiipi",
+    "grid_pack_rows": "iiippIiFFqqpqi",
+    "sparse_rows_apply": "qpqiiiipi",
+    "sparse_rows_overflow": "qiiq",
+    "sparse_rows_zero": "qqiiqiqqpi",
     "generate_raydir_camloc": "iixxqpipp",
     "solver_adam_begin": "xffqq",
     # n w g m v alpha_t beta1 beta2 eps decay zero_grad state

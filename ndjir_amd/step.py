@@ -172,13 +172,24 @@ class Step:
         per-rank gradients just add up: MLP = one flat 5.9 MB bucket; voxel grid = touched cells only."""
         if not self.multi or self.mlp_names is None:
             return
-        from ndjir_amd.distributed import allreduce_step_gradients
+        from ndjir_amd.distributed import SparseRows, allreduce_step_gradients
         v = self.conf.geometric_network.voxel
+        # every dense grid family is exchanged sparsely: the rows of the cells in the interpolation stencils (8 corners,
+        # 4 x 4 x 4 Lanczos taps, 3 x 4 plane texels ...) of this step's sample points and their perturbed twins
+        pre, _, topo = v.type.rpartition("_")
+        pre = pre + "_" if pre else ""
         queries = {}
-        if v.type == "voxel":       # sparse exchange: the 8 corner cells of the LINEAR voxel stencil; the cosine / Lanczos
-            # families scatter into more cells and go through the dense all-reduce
-            queries["geometric-network/voxel_feature/F"] = ([self.touched, self.touched_ptb], [v.grid_size] * 3)
+        pts = [self.touched, self.touched_ptb]
+        for name, buf in self.grid_bufs.items():
+            fam = name.split("/")[-2][:-len("_feature")]          # voxel / triplane / triline
+            on_gpu = buf.is_cuda and buf.shape[-1] in (4, 8)
+            if on_gpu:
+                queries[name] = (pts, pre + fam)
+            elif fam == "voxel" and pre == "":
+                queries[name] = (pts, [v.grid_size] * 3)           # generic torch path (CPU tests)
         self.remote_rows = allreduce_step_gradients(self.flat_grad, self.grid_bufs, queries)
+        # a rank that listed more rows than fit on the wire: this step's grid gradient is incomplete -> veto the update
+        self.exchange_overflow = [h.st["overflow"] for h in self.remote_rows.values() if isinstance(h, SparseRows)]
 
     def forward_backward(self):
         self.pre_exchange()
@@ -218,7 +229,12 @@ class Step:
 
     def optimizer_step(self):
         self.set_solver_gradients()
-        self.solvers.guarded_update(self.loss)     # python/train.py:141-146: non-finite gradients or a NaN loss skip the update
+        loss = self.loss
+        for flag in getattr(self, "exchange_overflow", []):
+            # (device-side: an overflowing sparse exchange turns the loss the guard sees into NaN, which skips the update)
+            loss = torch.where(flag > 0, torch.full_like(loss, float("nan")), loss)
+            flag.zero_()
+        self.solvers.guarded_update(loss)     # python/train.py:141-146: non-finite gradients or a NaN loss skip the update
 
     def set_solver_gradients(self):
         s = self.solvers

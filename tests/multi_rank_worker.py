@@ -19,7 +19,16 @@ def main():
     dev = torch.device("cuda", 0)
     import bench
     from ndjir_amd import config as cfg
-    conf = cfg.load("default", [f"geometric_network.voxel.grid_size={G}"])
+    variant = os.environ.get("NDJIR_TEST_VARIANT", "default")
+    conf = cfg.load(variant, [f"geometric_network.voxel.grid_size={G}"])
+    # record what goes through all_reduce: the grid gradients must never be among it
+    reduced = []
+    _all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        reduced.append(int(t.numel()))
+        return _all_reduce(t, *a, **k)
+    dist.all_reduce = counting_all_reduce
     step = bench.Step(conf, R, dev, rank, world)
     losses = []
     for _ in range(steps):
@@ -32,7 +41,10 @@ def main():
         losses.append(float(loss_t))
     torch.cuda.synchronize()
     torch.save(dict(losses=losses, flat=step.flat_grad.cpu(), grid={k: v.cpu() for k, v in step.grid_bufs.items()},
-                    handle={k: type(v).__name__ for k, v in step.remote_rows.items()}), os.path.join(out, f"rank{rank}.pt"))
+                    handle={k: type(v).__name__ for k, v in step.remote_rows.items()}, reduced=reduced,
+                    limits={k: v.st["limit"] for k, v in step.remote_rows.items() if hasattr(v, "st")},
+                    counts={k: v.st["counts_all"].cpu() for k, v in step.remote_rows.items() if hasattr(v, "st")}),
+               os.path.join(out, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -16,22 +16,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["eager", "graph"])
-def test_two_ranks_equal_one_process(gpu, mode):
+@pytest.mark.parametrize("mode,variant", [("eager", "default"), ("graph", "default"), ("eager", "custom"), ("eager", "triplaneline"),
+                                          ("graph", "triplaneline")])
+def test_two_ranks_equal_one_process(gpu, mode, variant):
+    """variant: default (linear voxel, D = 4), custom (Lanczos voxel: 4 x 4 x 4 taps), triplaneline (tri-plane + tri-line,
+    D = 8): every grid gradient goes through the sparse row exchange -- no all-reduce larger than the MLP bucket."""
     import bench
     from ndjir_amd import config as cfg, parameter as P
     from ndjir_amd.grid_feature import set_grad_buffer
     R, G, steps = 64, 64, 2
     with tempfile.TemporaryDirectory() as out:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", NDJIR_TEST_VARIANT=variant)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", "29533", os.path.join(ROOT, "tests", "multi_rank_worker.py"), out, str(R), str(G), str(steps)] + \
             (["graph"] if mode == "graph" else [])
         res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
         assert res.returncode == 0, res.stderr[-3000:]
         ranks = [torch.load(os.path.join(out, f"rank{r}.pt")) for r in range(2)]
-    assert ranks[0]["handle"] == {"geometric-network/voxel_feature/F": "SparseRows"}       # the HIP path ran
-    conf = cfg.load("default", [f"geometric_network.voxel.grid_size={G}"])
+    want = {"geometric-network/triplane_feature/F": "SparseRows", "geometric-network/triline_feature/F": "SparseRows"} \
+        if variant == "triplaneline" else {"geometric-network/voxel_feature/F": "SparseRows"}
+    assert ranks[0]["handle"] == want                                                      # the HIP path ran
+    n_mlp = int(ranks[0]["flat"].numel())
+    assert max(ranks[0]["reduced"]) <= n_mlp, ("a dense grid all-reduce was issued", max(ranks[0]["reduced"]), n_mlp)
+    for k, lim in ranks[0]["limits"].items():
+        assert int(ranks[0]["counts"][k].max()) <= lim, k                                  # nothing was cut off the wire
+    conf = cfg.load(variant, [f"geometric_network.voxel.grid_size={G}"])
     step = bench.Step(conf, 2 * R, gpu, 0, 1)
     try:
         for _ in range(steps):

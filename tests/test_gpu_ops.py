@@ -393,3 +393,64 @@ def test_device_data_feed(gpu, mode):
     # the epoch wraps: M more positions come from a fresh reset()
     c2 = src.next_batch(M)[0]
     assert c2.shape == color.shape
+
+
+@pytest.mark.parametrize("family,D", [("voxel", 4), ("cosine_voxel", 4), ("lanczos_voxel", 4), ("triplane", 8), ("lanczos_triplane", 4),
+                                      ("triline", 8), ("cosine_triline", 4)])
+def test_grid_pack_rows_lists_every_nonzero_row_once(gpu, family, D):
+    """Sparse exchange, sending side (no reference counterpart): after a grad_feature scatter, ndjir_grid_pack_rows lists
+    exactly the non-zero rows of the buffer (each once, with its values) when walked with the same query points -- for
+    every dense family and interpolation; applying the list to a zero buffer reproduces the gradient, and
+    ndjir_sparse_rows_zero (own rows from the local list) re-arms the buffer."""
+    from ndjir_amd import lib
+    from ndjir_amd.distributed import _INTERP, _TAPS, _TOPO
+    G, P = 24, 700
+    gen = torch.Generator(device=gpu).manual_seed(5)
+    q = (torch.rand(P, 3, device=gpu, generator=gen) * 2.4 - 1.2)            # some points outside the box (clamped stencils)
+    interp_name, _, topo_name = family.rpartition("_")
+    topo, interp = _TOPO[topo_name], _INTERP[interp_name]
+    shape = (G, G, G, D) if topo == 0 else (3, G, G, D) if topo == 1 else (3, G, D)
+    C = D if topo == 0 else 3 * D
+    go = torch.randn(P, C, device=gpu, generator=gen)
+    go[::7] = 0.0                                                             # points without gradient: their rows stay zero
+    gf = torch.zeros(shape, device=gpu)
+    gs = [G, G, G]
+    if topo == 0:
+        lib.call(f"{family}_feature_grad_feature", P * C, gf, go, q, gs, D, [-1] * 3, [1] * 3, 0, 1)
+    else:
+        lib.call(f"{family}_feature_grad_feature", P * C, gf, go, q, G, D, [-1] * 3, [1] * 3, 0, 1)
+    cells = gf.numel() // D
+    sub, nd = (1, 3) if topo == 0 else (3, 2 if topo == 1 else 1)
+    cap = min(cells, P * sub * _TAPS[interp] ** nd)
+    bitmap = torch.zeros((cells + 31) // 32, dtype=torch.int32, device=gpu)
+    ids = torch.full((cap,), -1, dtype=torch.int32, device=gpu)
+    rows = torch.zeros((cap, D), device=gpu)
+    count = torch.zeros(1, dtype=torch.int32, device=gpu)
+    lib.call("grid_pack_rows", topo, interp, P, gf, q, gs, D, [-1] * 3, [1] * 3, bitmap, ids, rows, count, cap)
+    n = int(count)
+    flat = gf.view(-1, D)
+    want = torch.nonzero((flat != 0).any(dim=1)).reshape(-1)
+    got = ids[:n].long().sort().values
+    assert torch.equal(got, want), (n, want.numel())
+    assert torch.equal(rows[:n], flat[ids[:n].long()])
+    lib.call("sparse_rows_clear_bitmap", ids, count, cap, bitmap)
+    assert int(bitmap.abs().sum()) == 0
+    # receiving side: a "world" of 2 whose other rank sent this list
+    ids_all = torch.stack([torch.zeros_like(ids), ids])
+    rows_all = torch.stack([torch.zeros_like(rows), rows])
+    counts = torch.tensor([0, n], dtype=torch.int32, device=gpu)
+    limit = max(1, min(cap, n))
+    recv = torch.zeros_like(gf)
+    lib.call("sparse_rows_apply", ids_all, rows_all, counts, 2, cap, limit, 0, recv, D)
+    assert torch.equal(recv, gf)
+    flag = torch.zeros(1, dtype=torch.int32, device=gpu)
+    lib.call("sparse_rows_overflow", counts, 2, limit, flag)
+    assert int(flag) == 0
+    if n > 1:
+        lib.call("sparse_rows_overflow", counts, 2, n - 1, flag)
+        assert int(flag) == 1
+    lim_dev = torch.tensor([limit], dtype=torch.int32, device=gpu)
+    lib.call("sparse_rows_zero", ids_all, counts, 2, cap, lim_dev, 0, None, None, recv, D)
+    assert float(recv.abs().max()) == 0.0
+    lib.call("sparse_rows_zero", ids_all, torch.zeros_like(counts), 2, cap, lim_dev, 0, ids, count, gf, D)      # own list only
+    assert float(gf.abs().max()) == 0.0
