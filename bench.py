@@ -358,20 +358,38 @@ def main():
             graph_error = f"{type(e).__name__}: {e}"
             exec_mode = "eager"
             torch.cuda.synchronize()
+        dbg = (lambda tag: print("DEBUG", tag, float(loss), file=sys.stderr)) if os.environ.get("NDJIR_BENCH_DEBUG") else (lambda tag: None)
         if exec_mode == "graph":
+            ref_loss = float(loss)       # the captured step's loss right after capture (= the eager step's, checked by capture_step)
+            dbg("after capture")
             # ... and never a pessimisation: two untimed steps each way, keep replaying only if it is not slower
             t_graph = timed(lambda: replay_step(step, graph))
+            dbg("after 2 replays")
             t_eager = t_eager_pre if t_eager_pre is not None else timed(step.forward_backward)
             if not _all_ranks_ok(step, t_graph <= 1.05 * t_eager):
                 graph_error = f"replay not faster than eager launches ({1e3 * t_graph / 2:.1f} vs {1e3 * t_eager / 2:.1f} ms/step)"
                 exec_mode = "eager"
     if exec_mode == "graph":
+        dbg("after eager trial")
         barrier()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             replay_step(step, graph)
         barrier()
         el = time.perf_counter() - t0
+        dbg("after timed replays")
+        # the inputs did not change: the timed replays must still produce the eager step's loss -- a replay that computed
+        # something else is not a measurement of the step (seen once: a 64-ray tri-plane debug configuration after eager
+        # steps had run between replays); fall back to timing ordinary launches
+        if not _all_ranks_ok(step, abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)):
+            graph_error = f"timed replays produced loss {float(loss)} instead of {ref_loss}: timed as eager launches instead"
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                loss = step.forward_backward()
+            barrier()
+            el = time.perf_counter() - t0
+            exec_mode = "eager (graph replay rejected)"
         # HIP events cannot be recorded inside a captured graph: the same K steps are issued once more as
         # ordinary stream launches, with events around every engine launch, for `roofline` / `kernels`
         mlp.PROFILE = [] if rank == 0 else None
