@@ -91,16 +91,19 @@ def amax_slots(device, n):
     """n zeroed slots for the largest finite |value| of tensors written / read by a chain launch (bit patterns, updated
     by atomic max): the f16x3 weight-gradient kernel scales its operands by them (ndjir_mlp_chain / ndjir_mlp_wgrad).
     Slots are handed out from a zero-filled arena (one fill launch per 4096 slots instead of one per chain launch); an
-    exhausted arena is simply replaced -- slices still in use keep the old storage alive.  Inside a graph capture every
-    call allocates its own zeros: a replay must find them zero again."""
-    if torch.cuda.is_current_stream_capturing():
-        return torch.zeros(n, device=device, dtype=torch.float32)
+    exhausted arena is simply replaced -- slices still in use keep the old storage alive.  `begin_step` starts a fresh
+    arena: called at the top of a step that may be captured into a HIP graph, so that the fill is part of the graph and
+    every replay finds its slots zero (a stale slot would still be a valid upper bound, just a needlessly large one)."""
     a = _AMAX_ARENA.get(device)
     if a is None or a[1] + n > a[0].numel():
         a = _AMAX_ARENA[device] = [torch.zeros(4096, device=device, dtype=torch.float32), 0]
     out = a[0][a[1]:a[1] + n]
     a[1] += n
     return out
+
+
+def begin_step(device):
+    _AMAX_ARENA[device] = [torch.zeros(4096, device=device, dtype=torch.float32), 0]
 
 
 def _slot(am, i):

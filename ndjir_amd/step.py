@@ -134,7 +134,9 @@ class Step:
             self.obj_mask_sum.copy_(oms)
 
     def compute(self, rearm=True):
+        from ndjir_amd import mlp
         from ndjir_amd.loss import total_loss
+        mlp.begin_step(self.device)          # fresh (zeroed) operand-maximum slots: part of the graph when captured
         if rearm:
             self.rearm_grid_buffers()
         use_mask = self.conf.train.mask_weight > 0.0
