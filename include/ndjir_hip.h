@@ -318,6 +318,31 @@ int ndjir_render_material_head_backward(int R, int N, const float* raw_base_colo
                                         float* g_base_color, float* g_base_color_ptb, float* g_implicit, float* g_photo,
                                         float* g_roughness, float* g_specular, hipStream_t stream);
 
+/* ---- the per-ray tail of the step (ndjir_amd/csrc/loss.hip) -------------------------------------------------------
+ * ndjir_render_pixel_compose: python/renderer.py:163-178 for the fused material head -- pix (R,9) = VR of
+ *   [implicit, roughness, specular x3, photo, base term x3], env (R,Ce) the diffuse light integral (Ce = 1 or 3), spec (R,3),
+ *   bg (R,3, may be null): diffuse = env + implicit; color = base * diffuse + photo * spec (entangle) or
+ *   photo * (base * diffuse + spec); color += bg.  The reference: ~6 nnabla functions, twice as many in backward.
+ * ndjir_loss_terms: python/loss.py:59-178 without the mask term (train.mask_weight = 0) -- RGB error (l1 / l2), eikonal
+ *   term, sampled TV term(s), the five prior / regulariser sums of the material head (prior (R,5), may be null) and the
+ *   weighted total, normalised by sum(mask) N + 1e-5 (mask_sum_global: device scalar holding the sum over all ray shards,
+ *   or null = this call's own sum).  weights5 (host) = eikonal, tv, base colour prior, roughness prior, specular prior.
+ *   workspace: ndjir_loss_terms_workspace(R) floats; terms (device, 12 floats): total, rgb, eikonal, tv, prior base colour,
+ *   prior roughness, reg std roughness, prior specular, reg std specular, 1 / denorm, sum(mask), 0.  Per-ray partial sums
+ *   and a fixed-order final reduction: the loss is bit-reproducible.  The backward takes the gradient of terms[0]. */
+int ndjir_render_pixel_compose(int R, int Ce, int entangle, const float* pix, const float* env, const float* spec, const float* bg,
+                               float* color, hipStream_t stream);
+int ndjir_render_pixel_compose_backward(int R, int Ce, int entangle, const float* pix, const float* env, const float* spec,
+                                        const float* g, float* g_pix, float* g_env, float* g_spec, float* g_bg, hipStream_t stream);
+int ndjir_loss_terms_workspace(int R);
+int ndjir_loss_terms(int R, int N, const float* color, const float* color_gt, const float* mask, const float* grad_x,
+                     const float* tv0, int D0, const float* tv1, int D1, const float* prior, const float* mask_sum_global,
+                     float inv_rays, const float* weights5, int l2, float* workspace, float* terms, hipStream_t stream);
+int ndjir_loss_terms_backward(int R, int N, const float* color, const float* color_gt, const float* mask, const float* grad_x,
+                              int D0, int D1, const float* terms, const float* g_loss, float inv_rays, const float* weights5,
+                              int l2, float* g_color, float* g_grad_x, float* g_tv0, float* g_tv1, float* g_prior,
+                              hipStream_t stream);
+
 /* Positional encoding (python/network.py:96-117): out (P, [C +] 2 C M) = [x, cos(x_i 2^k), sin(x_i 2^k)],
  * band index k fastest; backward gx (P,C) from g (P, [C +] 2 C M). */
 int ndjir_positional_encoding(long long P, int C, int M, int include_input, const float* x, float* out, hipStream_t stream);

@@ -17,7 +17,8 @@ SO_PATH = os.environ.get("NDJIR_HIP_LIB") or os.path.join(_HERE, "_lib", "libndj
 _vp = ctypes.c_void_p
 _CT = {"i": ctypes.c_int, "f": ctypes.c_float, "p": _vp, "q": _vp, "F": ctypes.POINTER(ctypes.c_float),
        "I": ctypes.POINTER(ctypes.c_int), "l": ctypes.c_longlong, "P": ctypes.POINTER(_vp),
-       "A": ctypes.POINTER(ctypes.c_int), "L": ctypes.POINTER(ctypes.c_longlong), "x": _vp}
+       "A": ctypes.POINTER(ctypes.c_int), "L": ctypes.POINTER(ctypes.c_longlong), "x": _vp,
+       "W": ctypes.POINTER(ctypes.c_float)}
 
 # signature strings (without the trailing stream): i=int f=float l=long long p=device pointer
 # F=float[3] host  I=int[3] host  q=int32 device pointer (nullable)  x=device pointer of any dtype
@@ -50,6 +51,11 @@ SIGS = {
     "render_integrate": "iiipipip",
     "render_material_head": "ii" + "p" * 7 + "iiiffff" + "ppp",
     "render_material_head_backward": "ii" + "p" * 7 + "iiiffff" + "pp" + "p" * 6,
+    "render_pixel_compose": "iiippppp",
+    "render_pixel_compose_backward": "iiippppppp" + "p",
+    # R N color gt mask grad_x tv0 D0 tv1 D1 prior mask_sum inv_rays weights[5] l2 workspace terms
+    "loss_terms": "iipppppipippfWipp",
+    "loss_terms_backward": "iippppiippfWippppp",
     "positional_encoding": "liiipp",
     "positional_encoding_backward": "liiippp",
     "render_diffuse_light": "iiippppfp",
@@ -208,6 +214,8 @@ def call(name, *args):
             if not (v.is_cuda and v.is_contiguous()):
                 raise NdjirHipError(f"ndjir_{name}: expected a contiguous GPU tensor")
             cargs.append(v.data_ptr())
+        elif c == "W":     # host float array
+            cargs.append((ctypes.c_float * len(v))(*[float(x) for x in v]))
         elif c == "F":
             cargs.append(_f3(v))
         elif c == "I":
@@ -228,7 +236,7 @@ def symbols():
                                             "ndjir_hash_table_size", "ndjir_hash_num_params",
                                             "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_colsum_workspace",
                                             "ndjir_mlp_chain_workspace", "ndjir_mlp_set_math", "ndjir_mlp_get_math",
-                                            "ndjir_mlp_debug_timeline"]
+                                            "ndjir_mlp_debug_timeline", "ndjir_loss_terms_workspace"]
 
 
 def hash_num_params(G0, growth_factor, T0, L, D):

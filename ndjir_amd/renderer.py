@@ -22,7 +22,7 @@ from .network import (background_network, base_color_network, material_nets_raw,
                       soft_visibility_light_network, specular_reflectance_network)
 from .sampler import sample_importance_directions, sample_points, sample_uniform_directions
 from .specular_brdf import dot, specular_brdf_model
-from .volume import alpha_weights, diffuse_light, integrate, material_head, specular_light_filament
+from .volume import alpha_weights, diffuse_light, integrate, material_head, pixel_compose, specular_light_filament
 
 
 def make_rand(B, R, conf, device, n_fg=None, include_samples=True):
@@ -184,7 +184,6 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     # Diffuse colour (renderer.py:117-120)
     # mean_m soft_vis * env * clamp(n.l): one fused launch (csrc/render.hip) instead of dot/clamp/mul/mean
     env_pixel = diffuse_light(normal_pixel, uniform_light_dir, soft_vis_d, env_d, conf.renderer.eps_dot)
-    diffuse_light_pixel = env_pixel + implicit_pixel
 
     # Specular colour (renderer.py:141-161)
     sb = conf.specular_brdf
@@ -204,12 +203,18 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
         spec_pixel = sb.weight * spec_pixel
 
     # Diffuse + specular composition (renderer.py:163-176)
-    if use_head:
+    color_pixel = None
+    if use_head and env_pixel.shape[-1] in (1, 3) and spec_pixel.shape[-1] == 3:
+        # one launch: diffuse = env + implicit, the entangled / disentangled product, + VR(color_bg)
+        color_pixel = pixel_compose(pix, env_pixel, spec_pixel, VR(color_bg, N), conf.diffuse_brdf.entangle)
+    elif use_head:
+        diffuse_light_pixel = env_pixel + implicit_pixel
         if conf.diffuse_brdf.entangle:
             color_fg_pixel = base_term_pixel * diffuse_light_pixel + photo_pixel * spec_pixel
         else:
             color_fg_pixel = photo_pixel * (base_term_pixel * diffuse_light_pixel + spec_pixel)
     elif conf.photogrammetric_light_network.use_me:
+        diffuse_light_pixel = env_pixel + implicit_pixel
         photo = photogrammetric_light_network(x_fg, camloc, view_dir, feature_x_fg, grad_x_fg, conf)
         photo_pixel = VR(photo)
         if conf.diffuse_brdf.entangle:
@@ -219,7 +224,8 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     else:
         color_fg_pixel = VR(base_color) + spec_pixel
 
-    color_pixel = color_fg_pixel + VR(color_bg, N)
+    if color_pixel is None:
+        color_pixel = color_fg_pixel + VR(color_bg, N)
 
     obj_mask_pred = torch.zeros((), dtype=x_fg.dtype, device=x_fg.device)
     if conf.train.mask_weight > 0.0:

@@ -200,3 +200,89 @@ def material_head(raw_bc, raw_ptb, raw_imp, raw_photo, photo_gain, raw_rough, ra
     cfg = (int(bool(remap)), int(bool(entangle)), int(bool(sym_backward)), float(roughness_lower_bound), float(specular_scale),
            float(roughness_prior), float(specular_prior))
     return MaterialHead.apply(raw_bc, raw_ptb, raw_imp, raw_photo, photo_gain, raw_rough, raw_spec, cfg)
+
+
+class PixelCompose(Function):
+    """renderer.py:163-178 for the fused material head: diffuse = env + implicit; color = base * diffuse + photo * spec
+    (entangle) or photo * (base * diffuse + spec); + background.  pix (B,R,9) = VR of the head's V, env (B,R,1|3),
+    spec (B,R,3), bg (B,R,3) -> color_pixel (B,R,3).  One launch each way (csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, pix, env, spec, bg, entangle):
+        B, R, _ = pix.shape
+        args = [_c(pix), _c(env), _c(spec)]
+        color = torch.empty((B, R, 3), device=pix.device, dtype=torch.float32)
+        lib.call("render_pixel_compose", B * R, env.shape[-1], int(entangle), *args, _c(bg), color)
+        ctx.save_for_backward(*args)
+        ctx.cfg = (B, R, env.shape[-1], int(entangle))
+        return color
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        B, R, Ce, entangle = ctx.cfg
+        pix, env, spec = ctx.saved_tensors
+        g_pix, g_env, g_spec = torch.empty_like(pix), torch.empty_like(env), torch.empty_like(spec)
+        g_bg = torch.empty((B, R, 3), device=pix.device, dtype=torch.float32) if ctx.needs_input_grad[3] else None
+        lib.call("render_pixel_compose_backward", B * R, Ce, entangle, pix, env, spec, g.contiguous(), g_pix, g_env, g_spec, g_bg)
+        return g_pix, g_env, g_spec, g_bg, None
+
+
+def pixel_compose(pix, env, spec, bg, entangle):
+    return PixelCompose.apply(pix, env, spec, bg, bool(entangle))
+
+
+LOSS_TERM_NAMES = ("loss", "loss_rgb", "loss_eikonal", "loss_tv", "prior_base_color", "prior_roughness", "reg_std_roughness",
+                   "prior_specular_reflectance", "reg_std_specular_reflectance")
+
+
+class LossTerms(Function):
+    """python/loss.py:59-178 without the mask term: RGB error, eikonal, sampled TV, the five prior / regulariser sums and
+    their weighted total in one pass over the rays plus a fixed-order final reduction (csrc/loss.hip).
+    color, color_gt (B,R,3); mask (B,R,1,1); grad_x (B,R,N,3) or None; prior (B,R,5) or None (per-ray sums of the material
+    head); mask_sum_global 0-d tensor or None; cfg = (N, inv_rays, (w_eikonal, w_tv, w_base_color, w_roughness,
+    w_specular), l2); tvs: up to two (B,R,N,D) sampled TV tensors.
+    -> terms (12,): see LOSS_TERM_NAMES for [0..8]; only terms[0] (the total) carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, color, color_gt, mask, grad_x, prior, mask_sum_global, cfg, *tvs):
+        N, inv_rays, weights, l2 = cfg
+        R = color.shape[0] * color.shape[1]
+        dev = color.device
+        assert len(tvs) <= 2
+        tv = [_c(t) for t in tvs] + [None] * (2 - len(tvs))
+        D = [t.shape[-1] if t is not None else 0 for t in tv]
+        args = [_c(color), _c(color_gt), _c(mask).reshape(-1), None if grad_x is None else _c(grad_x)]
+        ws = torch.empty(lib.load().ndjir_loss_terms_workspace(R), device=dev, dtype=torch.float32)
+        terms = torch.empty(12, device=dev, dtype=torch.float32)
+        lib.call("loss_terms", R, N, *args, tv[0], D[0], tv[1], D[1], None if prior is None else _c(prior),
+                 None if mask_sum_global is None else _c(mask_sum_global).reshape(1), float(inv_rays), [float(w) for w in weights],
+                 int(l2), ws, terms)
+        ctx.save_for_backward(args[0], args[1], args[2], *([args[3]] if args[3] is not None else []), terms)
+        ctx.cfg = (R, N, float(inv_rays), [float(w) for w in weights], int(l2), D, grad_x is not None, prior is not None,
+                   [t.shape if t is not None else None for t in tv], tuple(color.shape), None if grad_x is None else tuple(grad_x.shape))
+        return terms
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_terms):
+        R, N, inv_rays, weights, l2, D, has_gx, has_prior, tv_shapes, cshape, gxshape = ctx.cfg
+        saved = ctx.saved_tensors
+        color, gt, mask = saved[0], saved[1], saved[2]
+        grad_x = saved[3] if has_gx else None
+        terms = saved[-1]
+        dev = color.device
+        g_color = torch.empty(cshape, device=dev, dtype=torch.float32)
+        g_gx = torch.empty(gxshape, device=dev, dtype=torch.float32) if (has_gx and ctx.needs_input_grad[3]) else None
+        g_prior = torch.empty((cshape[0], cshape[1], 5), device=dev, dtype=torch.float32) if (has_prior and ctx.needs_input_grad[4]) else None
+        g_tv = [torch.empty(s, device=dev, dtype=torch.float32) if (s is not None and ctx.needs_input_grad[7 + i]) else None
+                for i, s in enumerate(tv_shapes)]
+        lib.call("loss_terms_backward", R, N, color, gt, mask, grad_x, D[0], D[1], terms, g_terms[0:1].contiguous(), inv_rays,
+                 weights, l2, g_color, g_gx, g_tv[0], g_tv[1], g_prior)
+        n_tv = sum(s is not None for s in tv_shapes)
+        return (g_color, None, None, g_gx, g_prior, None, None, *g_tv[:n_tv])
+
+
+def loss_terms(color, color_gt, mask, grad_x, prior, mask_sum_global, N, inv_rays, weights, l2, tvs):
+    return LossTerms.apply(color, color_gt, mask, grad_x, prior, mask_sum_global, (int(N), float(inv_rays), tuple(weights), bool(l2)),
+                           *tvs)
