@@ -14,6 +14,10 @@ from .renderer import pb_render
 from .sampler import sample_points
 
 
+import os
+_NO_FUSED_TAIL = bool(os.environ.get("NDJIR_NO_FUSED_TAIL"))       # A/B switch: the stock-op formulation of the loss terms
+
+
 def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand, record=None, ray_shards=1,
                mask_sum_global=None, obj_mask_sum_global=None):
     """camloc (B,3), raydir (B,R,3), color_gt (B,R,3), obj_mask (B,R,1) or None, cos_anneal_ratio (1,).
@@ -42,7 +46,7 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
     tv_feats = [(name, f) for name, f in P.get_parameters().items() if name.endswith("feature/F")] \
         if (conf.geometric_network.voxel.type != "none" and tr.tv_weight > 0.0) else []
     if (x_fg.is_cuda and tr.mask_weight == 0.0 and res.get("prior_partials") is not None and len(tv_feats) <= 2
-            and tr.rgb_loss in ("l1", "l2")):
+            and tr.rgb_loss in ("l1", "l2") and not _NO_FUSED_TAIL):
         from .volume import LOSS_TERM_NAMES, loss_terms
         tv_loss_map = dict(voxel_feature=F.tv_loss_on_voxel, voxel_hash_feature=F.tv_loss_on_voxel_hash,
                            triplane_feature=F.tv_loss_on_triplane, triline_feature=F.tv_loss_on_triline)

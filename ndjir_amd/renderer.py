@@ -9,6 +9,7 @@ diffuse_cdf_the, diffuse_cdf_phi, specular_cdf_the, specular_cdf_phi, noise) so 
 backend sees identical values; `make_rand` draws them with the configured seeds.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -204,7 +205,7 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
 
     # Diffuse + specular composition (renderer.py:163-176)
     color_pixel = None
-    if use_head and env_pixel.shape[-1] in (1, 3) and spec_pixel.shape[-1] == 3:
+    if use_head and env_pixel.shape[-1] in (1, 3) and spec_pixel.shape[-1] == 3 and not os.environ.get("NDJIR_NO_FUSED_TAIL"):
         # one launch: diffuse = env + implicit, the entangled / disentangled product, + VR(color_bg)
         color_pixel = pixel_compose(pix, env_pixel, spec_pixel, VR(color_bg, N), conf.diffuse_brdf.entangle)
     elif use_head:
