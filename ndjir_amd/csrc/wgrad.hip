@@ -449,19 +449,17 @@ __global__ void __launch_bounds__(256) k_absmax2(const float* __restrict__ A, in
                                                  int N, long long P, unsigned* __restrict__ out, int need_a, int need_b) {
   __shared__ unsigned red[2][256];
   unsigned ma = 0, mb = 0;
-  const long long rows_per = (P + gridDim.x - 1) / gridDim.x;
-  const long long p0 = (long long)blockIdx.x * rows_per;
-  const long long p1 = p0 + rows_per < P ? p0 + rows_per : P;
-  for (long long p = p0; p < p1; ++p) {
-    if (need_a) for (int k = threadIdx.x; k < K; k += 256) {
-      const unsigned b = __float_as_uint(A[p * lda + k]) & 0x7fffffffu;
+  const long long stride = (long long)gridDim.x * 256, t0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (need_a)
+    for (long long t = t0; t < P * K; t += stride) {          // flat over (row, column): every thread has loads in flight
+      const unsigned b = __float_as_uint(A[(t / K) * lda + (t % K)]) & 0x7fffffffu;
       if (b < 0x7f800000u && b > ma) ma = b;
     }
-    if (need_b) for (int n = threadIdx.x; n < N; n += 256) {
-      const unsigned b = __float_as_uint(B[p * ldb + n]) & 0x7fffffffu;
+  if (need_b)
+    for (long long t = t0; t < P * N; t += stride) {
+      const unsigned b = __float_as_uint(B[(t / N) * ldb + (t % N)]) & 0x7fffffffu;
       if (b < 0x7f800000u && b > mb) mb = b;
     }
-  }
   red[0][threadIdx.x] = ma;
   red[1][threadIdx.x] = mb;
   __syncthreads();
@@ -791,8 +789,9 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
       // partial sums; pick_splits' upper bound sized the workspace)
       unsigned* slots = reinterpret_cast<unsigned*>(workspace + wgrad_workspace(K, N, P) - 4);
       if (hipMemsetAsync(slots, 0, 2 * sizeof(unsigned), stream) != hipSuccess) return NDJIR_ERR_LAUNCH;
-      long long nb = (P + 63) / 64;
-      if (nb > 1024) nb = 1024;
+      long long nb = (P * (K > N ? K : N) + 256 * 16 - 1) / (256 * 16);     // ~16 elements per thread
+      if (nb > 2048) nb = 2048;
+      if (nb < 1) nb = 1;
       hipLaunchKernelGGL(k_absmax2, dim3((unsigned)nb), dim3(256), 0, stream, A, lda, K, B, ldb, N, P, slots, amax_a ? 0 : 1,
                          amax_b ? 0 : 1);
       if (!amax_a) amax_a = slots;
