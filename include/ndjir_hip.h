@@ -236,7 +236,7 @@ int ndjir_squareplus_backward(int size, float* dinput, const float* doutput, con
  * (python/sampler.py:194-240) given the SDF at the current samples: robust slope, sigmoid CDF,
  * alpha, transmittance weights, normalisation, inverse-transform sampling at the deterministic
  * u_m = m / (M - 1 + 1/M), clip to [t_near, t_far], merge-sort.  t, sdf: (R, N); t_near, t_far: (R);
- * t_out: (R, N + M) sorted; idx_out: (R, M) int32 bin indices.  N + M <= 128, M <= 32.
+ * t_out: (R, N + M) sorted; idx_out: (R, M) int32 bin indices.  N + M <= 256, M <= 32.
  * Optional (may be null): src_out (R, N + M) int32 = for every merged position the slot it came
  * from (i < N: old sample i; N + m: new sample m) and tnew_out (R, M) the new distances, so that a
  * caller can evaluate the SDF at the M new samples only and merge it into the values it already has.
@@ -245,6 +245,27 @@ int ndjir_squareplus_backward(int size, float* dinput, const float* doutput, con
 int ndjir_sampler_importance_round(int R, int N, int M, float gain, const float* t, const float* sdf,
                                    const float* t_near, const float* t_far, float* t_out, int* idx_out,
                                    int* src_out, float* tnew_out, hipStream_t stream);
+/* The rest of SamplePoints around that round as kernels instead of ~60 small launches (same arithmetic, expression by
+ * expression, as the stock-op formulation; floating-point contraction off):
+ * ndjir_sampler_begin (python/sampler.py:71-165, 265-273): mask = n_hits > 1 (n_hits null: 1), stratified distances
+ *   t_i = t_near + (t_far - t_near) / N0 (i + u_i) and their points x_i = c + t_i d.  camloc (B,3), rays_per_batch = R / B.
+ * ndjir_sampler_round_fused: ndjir_sampler_importance_round that also (a) gathers the SDF of the current samples from the
+ *   previous round's values sdf_prev (R, n_prev) and the values at the samples that round added, sdf_new (R, N - n_prev), by
+ *   its source map src_prev (R, N) -- sdf_new null: sdf_prev is the (R, N) array -- writing the result to sdf_out (may be
+ *   null), and (b) emits the new samples' points xnew_out (R, M, 3) = camloc + t_new raydir (null: skipped).
+ * ndjir_sampler_finish (python/sampler.py:275-299, 244-254): x_fg = c + t d, t_fg = [t, t_far]; background (x_bg null:
+ *   skipped): t_base = t_far mask + (|c| - radius)(1 - mask), t_bg = sort(t_base / background_sample) (Nb + 1 <= 64 values),
+ *   x_bg (R, Nb, 4) = inverted-sphere coordinates (x / |x|, 1 / |x|) of the first Nb. */
+int ndjir_sampler_begin(long long R, int N0, int rays_per_batch, const float* camloc, const float* raydir, const float* t_near,
+                        const float* t_far, const float* n_hits, const float* stratified_sample, float* mask, float* t0,
+                        float* x0, hipStream_t stream);
+int ndjir_sampler_round_fused(int R, int N, int M, float gain, const float* t, const float* sdf_prev, int n_prev,
+                              const float* sdf_new, const int* src_prev, float* sdf_out, const float* t_near, const float* t_far,
+                              const float* camloc, const float* raydir, int rays_per_batch, float* t_out, int* idx_out,
+                              int* src_out, float* tnew_out, float* xnew_out, hipStream_t stream);
+int ndjir_sampler_finish(long long R, int N, int Nb, int rays_per_batch, float radius, const float* camloc, const float* raydir,
+                         const float* t, const float* t_far, const float* mask, const float* background_sample, float* x_fg,
+                         float* t_fg, float* x_bg, float* t_bg, hipStream_t stream);
 
 /* ---- volume-rendering stage (ndjir_amd/csrc/render.hip) ----------------------------------------------
  * python/renderer.py:55-67 (foreground alpha from sdf, n = d sdf/dx and the ray direction, with the

@@ -64,6 +64,9 @@ SIGS = {
     "render_specular_light_filament_backward": "iii" + "p" * 7 + "ff" + "p" * 6,
     "render_integrate_backward": "iiipipipppi",
     "sampler_importance_round": "iiifpppppqqp",
+    "sampler_begin": "liippppppppp",
+    "sampler_round_fused": "iiifppipqpppppipqqpp",
+    "sampler_finish": "liiifpppppppppp",
     "ray_aabb_intersection": "ipppppiiFF",
     "ray_sphere_intersection": "ipppppiif",
     "inverse_transform_sample_uniform_directions": "ippppiiiif",

@@ -7,6 +7,8 @@ SampleDirections :317-408.  Neither op has a gradient (`backward_impl: pass`, :3
 Random tensors (`stratified_sample`, `background_sample`, cdf tables) are explicit inputs, exactly
 as in the reference.
 """
+import os
+
 import torch
 
 from . import lib
@@ -155,8 +157,71 @@ class SamplePoints:
         t, _ = torch.sort(t_base.reshape(B, R, 1, 1) / background_sample, dim=2)
         return t
 
+    def _fused_ok(self, raydir):
+        """The kernel formulation of the glue around the round kernel (csrc/sampler.hip): device tensors, the fused
+        geometric chain for the sdf-only passes, at most 64 background samples; a parity recorder wants the per-round
+        tensors of the step-by-step path."""
+        from .network import uses_fused_geometric
+        c = self.conf
+        return (raydir.is_cuda and self.record is None and uses_fused_geometric(c) and c.renderer.n_bg_samples + 1 <= 64
+                and c.renderer.n_samples1 <= 32
+                and c.renderer.n_samples0 + c.renderer.n_samples1 * c.renderer.n_upsamples <= 256
+                and not os.environ.get("NDJIR_NO_FUSED_SAMPLER"))
+
+    def _call_fused(self, camloc, raydir, stratified_sample, background_sample):
+        """SamplePoints._forward_impl (sampler.py:265-299) as: intersection, `sampler_begin`, per round {sdf-only chain on
+        the new points, `sampler_round_fused`}, `sampler_finish` -- the same arithmetic, expression by expression, as the
+        step-by-step path below (tests/test_gpu_sampler.py compares the two bit for bit)."""
+        conf = self.conf
+        r = conf.renderer
+        B, R, _ = raydir.shape
+        dev = raydir.device
+        N0, M, U, Nb = r.n_samples0, r.n_samples1, r.n_upsamples, r.n_bg_samples
+        method = r.t_near_far_method
+        if method == "intersect_with_r_sphere":
+            t_near, t_far, n_hits = ray_sphere_intersection(camloc, raydir, r.bounding_sphere_radius)
+        elif method == "intersect_with_aabb":
+            rad = r.bounding_sphere_radius
+            t_near, t_far, n_hits = ray_aabb_intersection(camloc, raydir, [-rad] * 3, [rad] * 3)
+        else:
+            t_near, t_far, _ = self.t_near_far(camloc, raydir)
+            t_near, t_far, n_hits = t_near.contiguous(), t_far.contiguous(), None
+        cl, rd = camloc.contiguous(), raydir.contiguous()
+        BR = B * R
+        f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+        mask, t, x = f(B, R, 1, 1), f(B, R, N0, 1), f(B, R, N0, 3)
+        lib.call("sampler_begin", BR, N0, R, cl, rd, t_near, t_far, n_hits, stratified_sample.contiguous(), mask, t, x)
+        sdf_prev, sdf_new, src, N = None, None, None, N0
+        for u in range(U):
+            s_new, _, _ = geometric_network(x, conf, first_order_only=True, sdf_only=True)     # (B,R,N0|M,1)
+            gain = r.sampling_sigmoid_gain * 2 ** u
+            t_out, idx = f(B, R, N + M, 1), torch.empty((B, R, M), device=dev, dtype=torch.int32)
+            src_out, t_new, x = torch.empty((B, R, N + M), device=dev, dtype=torch.int32), f(B, R, M, 1), f(B, R, M, 3)
+            if u == 0:
+                sdf_cur = s_new
+                lib.call("sampler_round_fused", BR, N, M, float(gain), t, sdf_cur, N, None, None, None, t_near, t_far, cl, rd, R,
+                         t_out, idx, src_out, t_new, x)
+            else:
+                sdf_cur = f(B, R, N, 1)
+                lib.call("sampler_round_fused", BR, N, M, float(gain), t, sdf_prev, N - M, s_new, src, sdf_cur, t_near, t_far, cl, rd,
+                         R, t_out, idx, src_out, t_new, x)
+            sdf_prev, src, t, N = sdf_cur, src_out, t_out, N + M
+        x_fg, t_fg = f(B, R, N, 3), f(B, R, N + 1, 1)
+        if conf.background_modeling:
+            x_bg, t_bg = f(B, R, Nb, 4), f(B, R, Nb + 1, 1)
+            lib.call("sampler_finish", BR, N, Nb, R, float(r.bounding_sphere_radius), cl, rd, t, t_far, mask,
+                     background_sample.contiguous(), x_fg, t_fg, x_bg, t_bg)
+        else:
+            lib.call("sampler_finish", BR, N, Nb, R, float(r.bounding_sphere_radius), cl, rd, t, t_far, None, None, x_fg, t_fg,
+                     None, None)
+            x_bg = torch.ones(B, R, Nb, 4, dtype=t.dtype, device=dev)
+            t_bg = torch.ones(B, R, Nb + 1, 1, dtype=t.dtype, device=dev)
+        return x_fg, t_fg, x_bg, t_bg, mask
+
     def __call__(self, camloc, raydir, stratified_sample, background_sample):
         with torch.no_grad():
+            if self._fused_ok(raydir):
+                return self._call_fused(camloc, raydir, stratified_sample, background_sample)
             conf = self.conf
             B, R, _ = raydir.shape
             t_near, t_far, mask = self.t_near_far(camloc, raydir)

@@ -117,3 +117,39 @@ def test_importance_round_capacity(gpu):
     with pytest.raises(RuntimeError):
         lib.call("sampler_importance_round", R, N, M, 64.0, z(R, N), z(R, N), z(R), z(R), z(R, N + M),
                  torch.zeros((R, M), device=gpu, dtype=torch.int32), None, None)
+
+
+@pytest.mark.parametrize("variant,ov,R", [("default", [], 96), ("default", ["renderer.n_samples0=128", "renderer.n_samples1=32"], 33),
+                                          ("default", ["renderer.n_upsamples=0"], 40),
+                                          ("default", ["renderer.t_near_far_method=intersect_with_r_sphere"], 64),
+                                          ("default", ["renderer.t_near_far_method=intersect_with_midpoint"], 20),
+                                          ("no_voxel", [], 50), ("default", ["background_modeling=False"], 17)])
+def test_fused_sampler_equals_step_by_step(gpu, monkeypatch, variant, ov, R):
+    """SamplePoints with the glue around the round kernel fused into kernels (sampler_begin / sampler_round_fused /
+    sampler_finish) against the step-by-step stock-op path: distances, points and mask bit for bit (the two evaluate the
+    same expressions in the same order); background coordinates to round-off (one 3-term sum may associate differently)."""
+    from ndjir_amd import network, parameter as P
+    from ndjir_amd.renderer import make_rand
+    from ndjir_amd.sampler import SamplePoints
+    from ndjir_amd.synthetic import make_rays
+    from tests.parity_utils import small_conf
+    conf = small_conf(grid_size=32, n_rays=R, variant=variant, overrides=ov)
+    P.clear_parameters(); P.set_device(gpu); network.seed(11)
+    B = 2
+    camloc, raydir, _ = make_rays(B, R, seed=5, device=gpu)
+    rand = make_rand(B, R, conf, gpu)
+    sp = SamplePoints(conf)
+    assert sp._fused_ok(raydir)
+    fused = sp(camloc, raydir, rand["stratified_sample"], rand["background_sample"])
+    monkeypatch.setenv("NDJIR_NO_FUSED_SAMPLER", "1")
+    assert not sp._fused_ok(raydir)
+    plain = sp(camloc, raydir, rand["stratified_sample"], rand["background_sample"])
+    names = ("x_fg", "t_fg", "x_bg", "t_bg", "mask")
+    for n, a, b in zip(names, fused, plain):
+        assert a.shape == b.shape, n
+        if n == "x_bg":
+            assert float((a - b).abs().max()) <= 2e-7, n
+        else:
+            assert torch.equal(a, b), (n, float((a - b).abs().max()))
+    N = conf.renderer.n_samples0 + conf.renderer.n_samples1 * conf.renderer.n_upsamples
+    assert fused[0].shape == (B, R, N, 3) and fused[1].shape == (B, R, N + 1, 1)
