@@ -83,11 +83,17 @@ def clear_parameters():
 
 
 def save_parameters(path):
-    """`nn.save_parameters` counterpart (python/train.py:101): every registered parameter under its nnabla scope name,
-    with its `need_grad` flag.  Container: numpy `.npz` (the reference writes HDF5 through nnabla/h5py, neither of which
-    exists here; the names and array layouts are nnabla's, so a one-line h5py loop converts either way)."""
-    if not str(path).endswith(".npz"):
-        raise ValueError("parameters are stored as .npz here (HDF5 needs h5py, which this environment lacks)")
+    """`nn.save_parameters` counterpart (python/train.py:100-101): every registered parameter under its nnabla scope
+    name with its `need_grad` flag, in registration order.  `.h5`: the HDF5 layout nnabla writes through h5py
+    (ndjir_amd/h5params.py: own writer, no h5py needed), so the reference's `render_image.py` / `extract_by_mc.py` load
+    the file as is.  `.npz`: the same arrays in a numpy archive."""
+    path = str(path)
+    if path.endswith(".h5"):
+        from .h5params import write_nnabla_h5
+        write_nnabla_h5(path, [(k, v, bool(v.requires_grad)) for k, v in _params.items()])
+        return
+    if not path.endswith(".npz"):
+        raise ValueError(f"{path}: parameters are stored as .h5 (nnabla's format) or .npz")
     arrays = {}
     for k, v in _params.items():
         arrays[k] = v.detach().cpu().numpy()
@@ -95,26 +101,37 @@ def save_parameters(path):
     np.savez(path, **arrays)
 
 
+def _install(k, a, need, dev):
+    cur = _params.get(k)
+    if cur is not None and tuple(cur.shape) == a.shape:
+        with torch.no_grad():
+            cur.copy_(torch.from_numpy(a))
+        torch.autograd.graph.increment_version(cur) if cur.is_cuda else None
+        cur.requires_grad_(need)
+    else:
+        t = torch.from_numpy(a).to(dev)
+        t.requires_grad_(need)
+        _params[k] = t
+
+
 def load_parameters(path, device=None):
     """`nn.load_parameters` counterpart (python/render_image.py:43, python/extract_by_mc.py:300): installs the stored
     tensors in the registry (existing entries are overwritten in place when shapes agree, so optimizer state and
-    gradient buffers keyed by the tensor stay valid)."""
-    if not str(path).endswith(".npz"):
-        raise ValueError("parameters are stored as .npz here (HDF5 needs h5py, which this environment lacks)")
+    gradient buffers keyed by the tensor stay valid).  `.h5` files -- the reference's own checkpoints included -- are
+    installed in nnabla's order, sorted by their `index` attribute."""
+    path = str(path)
     dev = torch.device(device) if device is not None else get_device()
+    if path.endswith(".h5"):
+        from .h5params import load_nnabla_h5
+        for k, a, need in load_nnabla_h5(path):
+            _install(k, a, need, dev)
+        return
+    if not path.endswith(".npz"):
+        raise ValueError(f"{path}: parameters are stored as .h5 (nnabla's format) or .npz")
     with np.load(path) as z:
         for k in z.files:
             if k.startswith("__need_grad__/"):
                 continue
             a = np.ascontiguousarray(z[k], dtype=np.float32)
             need = bool(z["__need_grad__/" + k]) if ("__need_grad__/" + k) in z.files else True
-            cur = _params.get(k)
-            if cur is not None and tuple(cur.shape) == a.shape:
-                with torch.no_grad():
-                    cur.copy_(torch.from_numpy(a))
-                torch.autograd.graph.increment_version(cur) if cur.is_cuda else None
-                cur.requires_grad_(need)
-            else:
-                t = torch.from_numpy(a).to(dev)
-                t.requires_grad_(need)
-                _params[k] = t
+            _install(k, a, need, dev)

@@ -162,6 +162,29 @@ def test_render_image_tiles(gpu):
     np.testing.assert_array_equal(parts[0] + parts[1] + parts[2], img)
 
 
+def test_checkpoint_h5_round_trip_renders_the_same_frame(gpu, tmp_path):
+    """python/train.py:100-101 -> python/render_image.py:43: parameters saved as nnabla `.h5` and loaded into an empty
+    registry render the identical frame (names, order, need_grad flags and every byte of every array survive)."""
+    from ndjir_amd import network, parameter as P
+    from ndjir_amd.renderer import render_image
+    conf = small_conf(grid_size=16, n_rays=16, overrides=["valid.n_rays=48", "valid.n_down_samples=0"])
+    P.clear_parameters()
+    P.set_device(gpu)
+    network.seed(313)
+    pose, K = _camera()
+    img = render_image(pose, K, (16, 12), conf, device=gpu)
+    before = {k: (v.detach().cpu().clone(), v.requires_grad) for k, v in P.get_parameters().items()}
+    path = str(tmp_path / "model_00001.h5")
+    P.save_parameters(path)
+    P.clear_parameters()
+    P.load_parameters(path, device=gpu)
+    after = P.get_parameters()
+    assert list(after) == list(before)
+    for k, (v, need) in before.items():
+        assert after[k].is_cuda and torch.equal(after[k].cpu(), v) and after[k].requires_grad == need, k
+    np.testing.assert_array_equal(render_image(pose, K, (16, 12), conf, device=gpu), img)
+
+
 def _camera():
     pose = np.eye(4, dtype=np.float64)[None]
     pose[0, :3, 3] = [0.1, -0.05, -2.5]

@@ -115,7 +115,8 @@ def test_host_ray_generation_against_reference_golden():
     np.testing.assert_array_equal(generate_all_pixels(int(g["W"]), int(g["H"])), g["all_pixels"])
 
 
-def test_parameter_file_round_trip(tmp_path):
+@pytest.mark.parametrize("ext", [".h5", ".npz"])
+def test_parameter_file_round_trip(tmp_path, ext):
     """save_parameters / load_parameters (python/train.py:101, python/render_image.py:43): names, values, need_grad."""
     from ndjir_amd import parameter as P
     P.clear_parameters()
@@ -126,7 +127,7 @@ def test_parameter_file_round_trip(tmp_path):
             w = P.get_parameter_or_create("W", (5, 7), rng.randn(5, 7))
         g = P.get_parameter_or_create("gain", (1,), np.asarray([0.3]), True)
     fixed = P.get_parameter_or_create("cos_anneal_ratio", (1,), np.asarray([0.25]), False)
-    path = str(tmp_path / "model_00010.npz")
+    path = str(tmp_path / ("model_00010" + ext))
     P.save_parameters(path)
     want = {k: v.detach().clone() for k, v in P.get_parameters().items()}
     need = {k: v.requires_grad for k, v in P.get_parameters().items()}
@@ -142,7 +143,7 @@ def test_parameter_file_round_trip(tmp_path):
         assert torch.equal(got[k], want[k]) and got[k].requires_grad == need[k], k
     assert not got["cos_anneal_ratio"].requires_grad
     with pytest.raises(ValueError):
-        P.save_parameters(str(tmp_path / "model.h5"))
+        P.save_parameters(str(tmp_path / "model.protobuf"))
     P.clear_parameters()
     P.set_device(None)
 
