@@ -370,6 +370,28 @@ int ndjir_positional_encoding(long long P, int C, int M, int include_input, cons
 int ndjir_positional_encoding_backward(long long P, int C, int M, int include_input, const float* x, const float* g,
                                        float* gx, hipStream_t stream);
 
+/* Element-wise stages around the geometric network's chains (ndjir_amd/csrc/geo.hip).  The reference spells them as
+ * nnabla functions inside `geometric_network` and `nn.grad([sdf], [x])` (python/network.py:96-117, 154-170,
+ * python/renderer.py:51-52); here each is one launch.
+ *   geo_encode            e (P, lde) = [x | cos(x_d 2^k) | sin(x_d 2^k) | seg_0 | seg_1 ...], seg_i (P, segC[i]) contiguous
+ *   geo_normal            n = g0[:, :3] + J_pe(x)^T g0[:, 3:3+6M] + sum_i gq_i   (cos / sin taken from e);
+ *                         with Z: sdf_out[p] = Z[p][2], then Z[p] = [x | feature (kept) | n | 0 ...]  (row stride ldz)
+ *   geo_backward_begin    gy (P, 1+D) = [g_sdf | g_feat + gZ[:, 3:3+D]], nbar (P, 3) = g_n + gZ[:, 3+D:6+D]; null = zero
+ *   geo_gbar0             gb0 (P, 3+6M+sum segC) = [nbar | -sin nbar_d 2^k | cos nbar_d 2^k | seg_0 | ...]
+ *   copy_columns          dst[p][0:C] = src[p][0:C] for row strides lds / ldd
+ *   inverse_squared_distance  out[p * ldo] = 1 / (|x_p - camloc_b|^2 + 1e-5)   (python/network.py:405-409) */
+int ndjir_geo_encode(long long P, int M, const float* x, int nseg, const float* const* seg, const int* segC, float* e, int lde,
+                     hipStream_t stream);
+int ndjir_geo_normal(long long P, int M, const float* e, int lde, const float* g0, int ldg, int nseg, const float* const* gq,
+                     float* n_out, float* Z, int ldz, int D, float* sdf_out, hipStream_t stream);
+int ndjir_geo_backward_begin(long long P, int D, const float* g_sdf, const float* g_feat, int ldf, const float* g_n,
+                             const float* gZ, int ldz, float* gy, float* nbar, hipStream_t stream);
+int ndjir_geo_gbar0(long long P, int M, const float* e, int lde, const float* nbar, int nseg, const float* const* seg,
+                    const int* segC, float* gb0, hipStream_t stream);
+int ndjir_copy_columns(long long P, int C, const float* src, int lds, float* dst, int ldd, hipStream_t stream);
+int ndjir_inverse_squared_distance(long long P, long long rows_per_batch, const float* x, int ldx, const float* camloc, float* out,
+                                   int ldo, hipStream_t stream);
+
 /* ---- fused MLP engine ------------------------------------------------------------------------------
  * Replaces the reference's per-layer nnabla launches (PF.affine -> cuBLAS GEMM, F.softplus(beta=100),
  * python/network.py:88-93,165 and every network function :154-561) by ONE launch per net and

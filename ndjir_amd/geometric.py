@@ -30,17 +30,13 @@ from torch.autograd import Function
 
 from . import lib
 from .grid_feature import _core
-from .mlp import _launch, _packed, amax_slots, chain_workspace, colsum, wgrad
+from .mlp import _launch, _packed, _Strided, amax_slots, chain_workspace, colsum, wgrad
 
 
 
 def _enc_call(fam, name, P, C, *args):
     """entry point `name` of grid family `fam` (N = P * channels for the dense families)"""
     lib.call(f"{fam.prefix}_{name}", P * C, *args)
-
-
-def _bands(M, device):
-    return 2.0 ** torch.arange(0, M, dtype=torch.float32, device=device)
 
 
 def _flops(P, Ks, Ns):
@@ -53,8 +49,11 @@ def _sdf_col(W):
 
 
 class GeometricMain(Function):
-    """(x, cfg, *grids, *W, *b) -> sdf (..,1), feature (..,D), n (..,3).
-    `cfg` = (M, skip_at, scale, min, max, families): one grid-feature family name per grid tensor."""
+    """(x, cfg, *grids, *W, *b) -> sdf (..,1), feature (..,D), n (..,3), Z (.., ldz).
+    `cfg` = (M, skip_at, scale, min, max, families): one grid-feature family name per grid tensor.
+    Z = [x | feature | n | spare columns] is the packed input of the per-sample material nets (cat(x, feature, normal),
+    python/network.py:235-263, 300-336, 380-509): `feature` is a view of its columns, and a gradient arriving for Z counts
+    for feature and n."""
 
     @staticmethod
     def forward(ctx, x, cfg, *tensors):
@@ -68,25 +67,22 @@ class GeometricMain(Function):
         xf = x.detach().reshape(-1, 3).contiguous()
         P = xf.shape[0]
         dev = xf.device
-        bands = _bands(M, dev)
-        xb = xf.unsqueeze(-1) * bands                      # (P, 3, M), band fastest (network.py:108-115)
-        cosb, sinb = torch.cos(xb), torch.sin(xb)
-        parts = [xf, cosb.reshape(P, -1), sinb.reshape(P, -1)]
         has_grid = NG > 0
         enc = []                                           # (family, feature, shape args, channels, first column in e)
-        col = 3 + 6 * M
+        col = npe = 3 + 6 * M
+        segs = []
         for fam, feat in zip(fams, grids):
             fd = feat.detach().contiguous()
             C = fam.channels(fd.shape, None)
             sa = fam.shape_args(fd.shape, None)
             vf = torch.empty((P, C), device=dev, dtype=torch.float32)
             _enc_call(fam, fam.fwd, P, C, vf, xf, fd, *sa, min_, max_, 0)
-            parts.append(vf)
+            segs.append(vf)
             enc.append((fam, fd, sa, C, col))
             col += C
-        e = torch.cat(parts, dim=-1).contiguous()          # A_0 (P, K0)
-        K0 = e.shape[1]
-        npe = 3 + 6 * M
+        K0 = col
+        e = torch.empty((P, K0), device=dev, dtype=torch.float32)          # A_0 = [x, cos, sin, grid features]
+        lib.call("geo_encode", P, M, xf, len(segs), segs, [t.shape[1] for t in segs], e, K0)
 
         # ---- forward chain ----
         Ks = [w.shape[0] for w in W]
@@ -94,12 +90,16 @@ class GeometricMain(Function):
         A = [e]
         for j in range(L - 1):
             A.append(torch.empty((P, Ns[j] + (K0 if j == skip_at else 0)), device=dev, dtype=torch.float32))
-        y = torch.empty((P, Ns[-1]), device=dev, dtype=torch.float32)
+        # the output y = [sdf | feature] is stored inside Z = [x | feature | n | spare] (csrc/geo.hip): y starts at Z + 2
+        D = Ns[-1] - 1
+        ldz = (3 + D + 3 + 1 + 3) // 4 * 4
+        Z = torch.empty((P, ldz), device=dev, dtype=torch.float32)
+        y = _Strided(Z.view(-1)[2:])
         # recorded maxima (operand scales of the f16x3 weight-gradient kernel): am[j] <-> A[j]; sm[j] <-> s_store[j]
         am, sm = amax_slots(dev, L), amax_slots(dev, L)
         _launch("chain_fwd", _flops(P, Ks, Ns), "mlp_chain", 0, P, e, K0, K0, L, [_packed(w, False) for w in W],
                 [t.detach() for t in b], Ks, Ns, [None] * L, A[1:] + [None], [a.shape[1] for a in A[1:]] + [0],
-                [None] * L, y, Ns[-1], 0, 1, beta, skip_at, scale, 0, None, 0, None, None,
+                [None] * L, y, ldz, 0, 1, beta, skip_at, scale, 0, None, 0, None, None,
                 [am[j + 1:j + 2] for j in range(L - 1)] + [None], am[0:1],
                 shape=f"{P}:geo {K0}-" + "-".join(map(str, Ns)))
 
@@ -136,27 +136,31 @@ class GeometricMain(Function):
                 side_out, ld, [None] * L, g0, K0, 1 if bskip >= 0 else 0, 1, beta, bskip, scale, split,
                 g0 if bskip >= 0 else None, K0, None, None, side_am, None, shape=f"{P}:sdf 1-" + "-".join(map(str, bN)))
 
-        # ---- n = J_e(x)^T g_0 ----
-        gc = g0[:, 3:3 + 3 * M].reshape(P, 3, M)
-        gs = g0[:, 3 + 3 * M:npe].reshape(P, 3, M)
-        n = g0[:, :3] + ((gs * cosb - gc * sinb) * bands).sum(-1)
+        # ---- n = J_e(x)^T g_0 (one launch; it also completes Z and moves the sdf out of it) ----
+        gqs, gos = [], []
         for fam, fd, sa, C, c0 in enc:
-            go = g0[:, c0:c0 + C].contiguous()
+            go = torch.empty((P, C), device=dev, dtype=torch.float32)
+            lib.call("copy_columns", P, C, _Strided(g0[:, c0:]), K0, go, C)
             gq = torch.empty((P, 3), device=dev, dtype=torch.float32)
             _enc_call(fam, "grad_query", P, C, gq, go, xf, fd, *sa, min_, max_, 0, 0)
-            n = n + gq
+            gqs.append(gq)
+            gos.append(go)
+        n = torch.empty((P, 3), device=dev, dtype=torch.float32)
+        sdf = torch.empty((P, 1), device=dev, dtype=torch.float32)
+        lib.call("geo_normal", P, M, e, K0, g0, K0, len(gqs), gqs, n, Z, ldz, D, sdf)
 
         ctx.cfg = (M, skip_at, scale, min_, max_, L, tuple(x.shape), fam_names, bskip, split)
         ctx.A, ctx.s_store, ctx.s = A, s_store, s
         ctx.am, ctx.sm = am, sm
-        ctx.aux = (xf, cosb, sinb, g0)
+        ctx.aux = (xf, gos, ldz)
         ctx.save_for_backward(*W, *grids)
         lead = x.shape[:-1]
-        return y[:, 0:1].reshape(lead + (1,)), y[:, 1:].reshape(lead + (Ns[-1] - 1,)), n.reshape(lead + (3,))
+        Zv = Z.view(lead + (ldz,))
+        return sdf.view(lead + (1,)), Zv[..., 3:3 + D], n.view(lead + (3,)), Zv
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g_sdf, g_feat, g_n):
+    def backward(ctx, g_sdf, g_feat, g_n, g_Z):
         M, skip_at, scale, min_, max_, L, xshape, fam_names, bskip, split = ctx.cfg
         saved = ctx.saved_tensors
         W = list(saved[:L])
@@ -165,7 +169,7 @@ class GeometricMain(Function):
         has_grid = NG > 0
         A, s_store, s = ctx.A, ctx.s_store, ctx.s
         am, sm = ctx.am, ctx.sm
-        xf, cosb, sinb, g0 = ctx.aux
+        xf, gos, ldz = ctx.aux
         gm, dm = amax_slots(xf.device, L), amax_slots(xf.device, L)      # recorded maxima of gbar[j] / deltas[j]
         beta = 100.0
         P = xf.shape[0]
@@ -174,12 +178,17 @@ class GeometricMain(Function):
         npe = 3 + 6 * M
         Ks = [w.shape[0] for w in W]
         Ns = [w.shape[1] for w in W]
-        bands = _bands(M, dev)
-
+        D = Ns[-1] - 1
+        e = A[0]
         gy = torch.empty((P, Ns[-1]), device=dev, dtype=torch.float32)
-        gy[:, 0:1] = g_sdf.reshape(P, 1) if g_sdf is not None else 0.0
-        gy[:, 1:] = g_feat.reshape(P, -1) if g_feat is not None else 0.0
-        nbar = g_n.reshape(P, 3).contiguous() if g_n is not None else None
+        nbar = torch.empty((P, 3), device=dev, dtype=torch.float32) if (g_n is not None or g_Z is not None) else None
+        gf = g_feat.reshape(P, -1) if g_feat is not None else None
+        if gf is not None and gf.stride(1) != 1:
+            gf = gf.contiguous()
+        lib.call("geo_backward_begin", P, D, g_sdf.reshape(P).contiguous() if g_sdf is not None else None,
+                 _Strided(gf) if gf is not None else None, gf.stride(0) if gf is not None else 0,
+                 g_n.reshape(P, 3).contiguous() if g_n is not None else None,
+                 g_Z.reshape(P, ldz).contiguous() if g_Z is not None else None, ldz, gy, nbar)
 
         enc = []          # (family, feature, shape args, channels, first column, gradient destination, is caller's buffer)
         col = npe
@@ -197,18 +206,15 @@ class GeometricMain(Function):
         col_last = None
         if nbar is not None:
             # ---- g-bar_0 = J_e(x) n-bar ----
-            gb0 = torch.empty((P, K0), device=dev, dtype=torch.float32)
-            gb0[:, :3] = nbar
-            nb = nbar.unsqueeze(-1) * bands                                   # (P, 3, M)
-            gb0[:, 3:3 + 3 * M] = (-sinb * nb).reshape(P, -1)
-            gb0[:, 3 + 3 * M:npe] = (cosb * nb).reshape(P, -1)
-            for fam, fd, sa, C, c0, gdst, _ in enc:
+            ggos = []
+            for (fam, fd, sa, C, c0, gdst, _), go in zip(enc, gos):
                 ggo = torch.empty((P, C), device=dev, dtype=torch.float32)
                 _enc_call(fam, "grad_query_grad_grad_output", P, C, ggo, nbar, xf, fd, *sa, min_, max_, 0, 0)
-                gb0[:, c0:c0 + C] = ggo
+                ggos.append(ggo)
                 # n depends on the grid directly through the interpolation derivative
-                _enc_call(fam, "grad_query_grad_feature", P, C, gdst, nbar, g0[:, c0:c0 + C].contiguous(), xf, *sa,
-                          min_, max_, 0, 1)
+                _enc_call(fam, "grad_query_grad_feature", P, C, gdst, nbar, go, xf, *sa, min_, max_, 0, 1)
+            gb0 = torch.empty((P, K0), device=dev, dtype=torch.float32)
+            lib.call("geo_gbar0", P, M, e, K0, nbar, len(ggos), ggos, [t.shape[1] for t in ggos], gb0)
             gbar[0] = gb0
             # ---- tangent chain over layers 0..L-2 ----
             T = L - 1
@@ -265,7 +271,9 @@ class GeometricMain(Function):
                 None, 0, gb_last, chain_workspace(dev, bg + [gb_last]), side_am, dm[L - 1:L], shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
 
         for fam, fd, sa, C, c0, gdst, _ in enc:
-            _enc_call(fam, "grad_feature", P, C, gdst, gx[:, c0:c0 + C].contiguous(), xf, *sa, min_, max_, 0, 1)
+            gxc = torch.empty((P, C), device=dev, dtype=torch.float32)
+            lib.call("copy_columns", P, C, _Strided(gx[:, c0:]), K0, gxc, C)
+            _enc_call(fam, "grad_feature", P, C, gdst, gxc, xf, *sa, min_, max_, 0, 1)
 
         # ---- weight / bias gradients ----
         gW, gb = [None] * L, [None] * L

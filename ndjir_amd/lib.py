@@ -56,6 +56,12 @@ SIGS = {
     # R N color gt mask grad_x tv0 D0 tv1 D1 prior mask_sum inv_rays weights[5] l2 workspace terms
     "loss_terms": "iipppppipippfWipp",
     "loss_terms_backward": "iippppiippfWippppp",
+    "geo_encode": "lipiPApi",
+    "geo_normal": "lipipiiPppiip",
+    "geo_backward_begin": "lippippipp",
+    "geo_gbar0": "lipipiPAp",
+    "copy_columns": "lipipi",
+    "inverse_squared_distance": "llpippi",
     "positional_encoding": "liiipp",
     "positional_encoding_backward": "liiippp",
     "render_diffuse_light": "iiippppfp",

@@ -117,12 +117,13 @@ def chain_workspace(device, bgrads):
 
 
 def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, keep_hidden=False, row_bias=None,
-                  row_bias_div=1):
-    """x (P, K0) contiguous.  Returns y (P, N_last), the list of stored activations A_1..A_{L-1} (inputs of layers
+                  row_bias_div=1, K0=None):
+    """x (P, ld) contiguous; the net reads its first K0 columns (default: all).  Returns y (P, N_last), the list of stored activations A_1..A_{L-1} (inputs of layers
     1..L-1) when keep_hidden, and their recorded maxima (slot j <-> A_j, slot 0 = x; None unless keep_hidden).
     row_bias (P / row_bias_div, N_0): added to the first layer's pre-activation of each group of row_bias_div
     consecutive rows."""
-    P, K0 = x.shape
+    P, ldx = x.shape
+    K0 = ldx if K0 is None else int(K0)
     L = len(weights)
     Ks, Ns, Wp, hidden = [], [], [], []
     kin = K0
@@ -142,13 +143,13 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
     am = amax_slots(x.device, L) if keep_hidden else None
     side_am = [_slot(am, j + 1) if (keep_hidden and j < L - 1) else None for j in range(L)]
     if row_bias is None:
-        _launch("chain_fwd", flops, "mlp_chain", 0, P, x, x.shape[1], K0, L, Wp, bl,
+        _launch("chain_fwd", flops, "mlp_chain", 0, P, x, ldx, K0, L, Wp, bl,
                 Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
                 int(skip_layer), float(skip_scale), 0, None, 0, None, None, side_am, _slot(am, 0),
                 shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
     else:
         assert P % row_bias_div == 0 and tuple(row_bias.shape) == (P // row_bias_div, Ns[0])
-        _launch("chain_fwd", flops, "mlp_chain_ex", 0, P, x, x.shape[1], K0, L, Wp, bl,
+        _launch("chain_fwd", flops, "mlp_chain_ex", 0, P, x, ldx, K0, L, Wp, bl,
                 Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
                 int(skip_layer), float(skip_scale), 0, None, 0, [None] * L, [None] * L, [None] * L,
                 row_bias.detach().contiguous(), int(row_bias_div), None, None, side_am, _slot(am, 0),
@@ -336,52 +337,75 @@ class MultiMLP(Function):
     """Several softplus-MLPs on ONE shared input (no skip connection): forward = one chain per net on the same x;
     backward = one chain per net ACCUMULATING into a single dL/dx, so autograd sees one consumer of x instead of one
     per net (no per-net input concatenation, no gradient additions).  The per-sample material nets of the reference
-    all take cat(x, feature, normal) (python/network.py:235-263, 300-336, 427-509).
-    apply(x, beta, layer_counts, *W_net0, *b_net0, *W_net1, *b_net1, ...) -> one output per net."""
+    all take cat(x, feature, normal) (python/network.py:235-263, 300-336, 427-509); the photogrammetric light net
+    (:380-424) takes the same columns plus per-ray ones, which enter as a row term.
+    apply(x, beta, net_cfg, lazy_pad, *params) -> one output per net.
+      x (..., ld): every net reads its first K0 <= ld columns (x may be wider than any net: packed sample inputs)
+      net_cfg[i] = (layers, K0, row_div): row_div > 0 -> the net's parameter list starts with a row term (G, N_0) added to
+                   the first layer's pre-activation of each group of row_div consecutive rows
+      lazy_pad   = True: the gradient of the columns no net reads is left undefined (the producer of x ignores them)
+      params     = for each net: [row term] + weights + biases (a bias may be None)"""
 
     @staticmethod
-    def forward(ctx, x, beta, layer_counts, *params):
-        x2 = x.detach().reshape(-1, x.shape[-1]).contiguous()
+    def forward(ctx, x, beta, net_cfg, lazy_pad, *params):
+        ld = x.shape[-1]
+        x2 = x.detach().reshape(-1, ld).contiguous()
         train = any(ctx.needs_input_grad)
-        nets, off = [], 0
-        for L in layer_counts:
-            nets.append((list(params[off:off + L]), list(params[off + L:off + 2 * L])))
+        ys, saved, off = [], [x2], 0
+        for L, K0, div in net_cfg:
+            rb = None
+            if div > 0:
+                rb = params[off].detach().reshape(-1, params[off].shape[-1])
+                off += 1
+            W, b = list(params[off:off + L]), list(params[off + L:off + 2 * L])
             off += 2 * L
-        ys, saved = [], [x2]
-        for W, b in nets:
-            y, hidden, am = chain_forward(x2, W, b, beta, -1, 1.0, keep_hidden=train)
+            y, hidden, am = chain_forward(x2, W, b, beta, -1, 1.0, keep_hidden=train, row_bias=rb, row_bias_div=max(div, 1), K0=K0)
             ys.append(y.view(x.shape[:-1] + (y.shape[-1],)))
             if train:
                 saved += hidden + W + [am]
         if train:
             ctx.save_for_backward(*saved)
-            ctx.cfg = (float(beta), tuple(layer_counts), tuple(x.shape))
+            ctx.cfg = (float(beta), tuple(net_cfg), tuple(x.shape), [tuple(p.shape) if torch.is_tensor(p) else None for p in params],
+                       bool(lazy_pad))
         return tuple(ys)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *gys):
-        beta, layer_counts, xshape = ctx.cfg
+        beta, net_cfg, xshape, pshapes, lazy_pad = ctx.cfg
         saved = ctx.saved_tensors
         x2 = saved[0]
-        P, K0 = x2.shape
+        P, ld = x2.shape
         dev = x2.device
         need_x = ctx.needs_input_grad[0]
-        ldg = (K0 + 3) // 4 * 4
-        gx = torch.empty((P, ldg), device=dev, dtype=torch.float32)[:, :K0] if need_x else None
-        grads, pos, poff, first = [], 1, 3, True
-        for n, L in enumerate(layer_counts):
-            A = [x2] + list(saved[pos:pos + L - 1])
+        ldg = (ld + 3) // 4 * 4
+        gx = torch.empty((P, ldg), device=dev, dtype=torch.float32)[:, :ld] if need_x else None
+        kmax = max(K0 for _, K0, _ in net_cfg)
+        if need_x and kmax < ld and not lazy_pad:
+            gx[:, kmax:].zero_()
+        # the widest net first: its chain assigns every column any net writes, the others accumulate
+        order = sorted(range(len(net_cfg)), key=lambda i: -net_cfg[i][1])
+        spos, ppos, sp, pp = [], [], 1, 4
+        for L, K0, div in net_cfg:
+            spos.append(sp)
+            ppos.append(pp)
+            sp += 2 * L
+            pp += 2 * L + (1 if div > 0 else 0)
+        out = [None] * (pp - 4)
+        first = True
+        for n in order:
+            L, K0, div = net_cfg[n]
+            gy = gys[n]
+            if gy is None:
+                continue
+            pos, poff = spos[n], ppos[n]
+            A = [x2[:, :K0]] + list(saved[pos:pos + L - 1])
             W = list(saved[pos + L - 1:pos + 2 * L - 1])
             am = saved[pos + 2 * L - 1]
-            pos += 2 * L
-            gy = gys[n]
-            nW = ctx.needs_input_grad[poff:poff + L]
-            nb = ctx.needs_input_grad[poff + L:poff + 2 * L]
-            poff += 2 * L
-            if gy is None:
-                grads += [None] * (2 * L)
-                continue
+            need_rb = div > 0 and ctx.needs_input_grad[poff]
+            wo = poff + (1 if div > 0 else 0)
+            nW = ctx.needs_input_grad[wo:wo + L]
+            nb = ctx.needs_input_grad[wo + L:wo + 2 * L]
             gy2 = gy.reshape(P, -1).contiguous()
             steps = L if need_x else L - 1
             deltas, bgrads = [None] * L, [None] * L
@@ -411,12 +435,20 @@ class MultiMLP(Function):
                         0 if first else 1, 1 if need_x else 0, float(beta), -1, 1.0, 0, None, K0, gb_last,
                         chain_workspace(dev, bg + [gb_last]), side_am, _slot(dm, L - 1), shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)) + ("" if first else " (+=)"))
                 first = False
-            gW = [wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j)) if nW[j] else None for j in range(L)]
-            gb = [(bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))) if nb[j] else None for j in range(L)]
-            grads += gW + gb
+            if need_rb:
+                d0 = deltas[0] if L > 1 else gy2
+                G = P // div
+                g_rb = torch.empty((G, d0.shape[1]), device=dev, dtype=torch.float32)
+                lib.call("mlp_group_colsum", _Strided(d0), d0.stride(0), d0.shape[1], G, div, g_rb)
+                out[poff - 4] = g_rb.view(pshapes[poff - 4])
+            for j in range(L):
+                if nW[j]:
+                    out[wo - 4 + j] = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j))
+                if nb[j]:
+                    out[wo - 4 + L + j] = bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))
         if need_x and first:
             gx = None
-        return (gx.reshape(xshape) if gx is not None else None, None, None, *grads)
+        return (gx.reshape(xshape) if gx is not None else None, None, None, None, *out)
 
 
 # ---- single dense layer, differentiable any number of times -------------------------------------------------------------
@@ -495,9 +527,14 @@ def linear(x, W, b=None):
     return MatMul.apply(x, W, False, b)
 
 
-def multi_mlp(x, nets, beta=100.0):
-    """nets: list of (weights, biases).  Returns one output per net (see MultiMLP)."""
-    flat = []
-    for W, b in nets:
+def multi_mlp(x, nets, beta=100.0, widths=None, row_terms=None, lazy_pad=False):
+    """nets: list of (weights, biases).  widths[i]: leading columns of x net i reads (default: all); row_terms[i]:
+    None or (tensor (..., N_0), div) -- see MultiMLP.  Returns one output per net."""
+    flat, cfg = [], []
+    for i, (W, b) in enumerate(nets):
+        rt = row_terms[i] if row_terms is not None else None
+        if rt is not None:
+            flat.append(rt[0])
         flat += list(W) + list(b)
-    return MultiMLP.apply(x, float(beta), tuple(len(W) for W, _ in nets), *flat)
+        cfg.append((len(W), int(widths[i]) if widths is not None else x.shape[-1], int(rt[1]) if rt is not None else 0))
+    return MultiMLP.apply(x, float(beta), tuple(cfg), bool(lazy_pad), *flat)

@@ -180,11 +180,13 @@ def uses_fused_geometric(conf):
     return bool(USE_FUSED and g.geometric_init and g.act == "softplus" and g.voxel.type in _FUSED_GRIDS and not g.voxel.use_ste)
 
 
-def geometric_network_with_grad(x, conf):
+def geometric_network_with_grad(x, conf, packed=False):
     """`sdf, feature, gain = geometric_network(x, conf); grad_x = nn.grad([sdf], [x])[0]`
     (python/renderer.py:51-52) as one operator.  Dense-voxel / no-grid configurations with the
     geometric initialisation run as fused MFMA chains with the hand-derived double backward
-    (ndjir_amd/geometric.py); other configurations run layer by layer through autograd."""
+    (ndjir_amd/geometric.py); other configurations run layer by layer through autograd.
+    packed=True: a fifth result, the packed sample inputs Z (..., ld) = [x | feature | grad_x | spare] of the fused path
+    (None otherwise) -- what `material_nets_raw` reads instead of a concatenation."""
     g = conf.geometric_network
     v = g.voxel
     fused_grids = _FUSED_GRIDS
@@ -194,13 +196,15 @@ def geometric_network_with_grad(x, conf):
         Ws, bs, skip_at, scale = _geometric_param_lists(conf)
         params = P.get_parameters()
         grids = [(f, params[f"geometric-network/{scope}/F"]) for f, scope in fused_grids[v.type]]
-        sdf, feat, grad_x = geometric_main(x, grids, Ws, bs, g.pe_bands, skip_at, scale)
+        sdf, feat, grad_x, Z = geometric_main(x, grids, Ws, bs, g.pe_bands, skip_at, scale)
         with P.parameter_scope("geometric-network"):
             gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain]), True)
-        return sdf, feat, torch.exp(gain * 10).clamp(1e-6, 5e4), grad_x
+        gain = torch.exp(gain * 10).clamp(1e-6, 5e4)
+        return (sdf, feat, gain, grad_x, Z) if packed else (sdf, feat, gain, grad_x)
     from .grid_feature import grad as nn_grad
     sdf, feat, gain = geometric_network(x, conf)
-    return sdf, feat, gain, nn_grad([sdf], [x])[0]
+    grad_x = nn_grad([sdf], [x])[0]
+    return (sdf, feat, gain, grad_x, None) if packed else (sdf, feat, gain, grad_x)
 
 
 def _ensure_geometric_params(x, conf):
@@ -345,28 +349,83 @@ def _cat_inputs(x, feature, normal, c):
     return torch.cat(inputs, dim=-1) if len(inputs) > 1 else x
 
 
-def material_nets_raw(x, feature, normal, conf):
+def material_nets_raw(x, feature, normal, conf, packed=None, photo=None):
     """The four per-sample material nets that share the input cat(x, feature, normal) -- implicit illumination
     (network.py:300-336), base colour (:235-263), roughness (:427-464), specular reflectance (:467-509) -- evaluated
-    as one operator on one concatenation (ndjir_amd.mlp.MultiMLP): their raw (pre-activation) outputs, in that order.
+    as one operator on one input (ndjir_amd.mlp.MultiMLP): their raw (pre-activation) outputs, in that order.
     Returns None when the configuration does not allow it (different inputs, activations or weight normalisation);
-    parameters are created in the order the separate calls create them."""
+    parameters are created in the order the separate calls create them.
+
+    packed: the geometric pass's Z = [x | feature | normal | spare] (geometric_network_with_grad(packed=True)); the nets
+    read its leading columns, no concatenation is built and one gradient flows back to the geometric node.
+    photo = (camloc, view): also evaluate the photogrammetric light net (:380-424) in the same operator -- its per-ray
+    inputs (the encoded view direction) enter as a row term, the inverse squared distance goes to Z's first spare
+    column; a fifth output (raw) and the net's gain are appended: (imp, bc, rough, spec, photo_raw, photo_gain)."""
     cs = [conf.implicit_illumination_network, conf.base_color_network, conf.roughness_network, conf.specular_reflectance_network]
-    same = all(c.use_geometric_feature == cs[0].use_geometric_feature and c.use_normal == cs[0].use_normal and c.act == "softplus"
-               for c in cs)
-    if not (USE_FUSED and same and not conf.use_wn and cs[0].use_me and not cs[3].fixme) or os.environ.get("NDJIR_NO_MULTI_MLP"):
+    if not (USE_FUSED and all(c.act == "softplus" for c in cs) and not conf.use_wn and cs[0].use_me and not cs[3].fixme) \
+            or os.environ.get("NDJIR_NO_MULTI_MLP"):
         return None
     from .mlp import multi_mlp
-    inp = _cat_inputs(x, feature, normal, cs[0])
-    Din = inp.shape[-1]
+    nx, nf, nn_ = x.shape[-1], feature.shape[-1], normal.shape[-1]
+    # with the packed input every net reads a prefix of [x | feature | normal]; a concatenation must be the same for all
+    prefix = all(c.use_geometric_feature or not c.use_normal for c in cs)
+    if packed is not None and (not prefix or os.environ.get("NDJIR_NO_PACKED_INPUT")):
+        packed = None
+    if packed is None and not all(c.use_geometric_feature == cs[0].use_geometric_feature and c.use_normal == cs[0].use_normal
+                                  for c in cs):
+        return None
+    inp = packed if packed is not None else _cat_inputs(x, feature, normal, cs[0])
+    Dins = [nx + (nf if c.use_geometric_feature else 0) + (nn_ if c.use_normal else 0) for c in cs]
+    Din = nx + nf + nn_                           # the packed columns [x | feature | normal]
     nets = []
-    for scope, c, Dout, shift in (("implicit-illumination-network", cs[0], cs[0].channels, 0),
-                                  ("base-color-network", cs[1], 3, 0),
-                                  ("roughness-network", cs[2], 2, 1),
-                                  ("specular-reflectance-network", cs[3], cs[3].channels * 2, 1)):
+    for scope, c, Dout, shift, Di in (("implicit-illumination-network", cs[0], cs[0].channels, 0, Dins[0]),
+                                      ("base-color-network", cs[1], 3, 0, Dins[1]),
+                                      ("roughness-network", cs[2], 2, 1, Dins[2]),
+                                      ("specular-reflectance-network", cs[3], cs[3].channels * 2, 1, Dins[3])):
         with P.parameter_scope(scope):
-            nets.append(_mlp_params(Din, c.feature_size, c.layers, Dout, conf.use_wn, shift))
-    return multi_mlp(inp, nets)
+            nets.append(_mlp_params(Di, c.feature_size, c.layers, Dout, conf.use_wn, shift))
+    widths, rows = list(Dins), [None] * 4
+    pc = conf.photogrammetric_light_network
+    with_photo = (photo is not None and packed is not None and pc.use_me and pc.act == "softplus" and pc.layers >= 2
+                  and Din + (1 if pc.use_inverse_distance else 0) <= packed.shape[-1])
+    if with_photo:
+        camloc, view = photo
+        B, R, N, _ = x.shape
+        with P.parameter_scope("photogrammetric-light-network"):
+            view_ray = view.reshape(B, R, 3)
+            pe_view = positional_encoding(view_ray, pc.pe_bands) if pc.pe_bands > 0 else view_ray
+            nx, npe = x.shape[-1], pe_view.shape[-1]
+            extra = 1 if pc.use_inverse_distance else 0
+            Ws, bs = _mlp_params(Din + npe + extra, pc.feature_size, pc.layers, pc.channels, conf.use_wn)
+            pgain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain_lv_start]), False)
+        from .mlp import linear
+        # reference input order [x, pe(view), feature, normal, 1/d^2]: the pe rows of the first layer act per ray
+        row_term = linear(pe_view.reshape(B * R, npe), Ws[0][nx:nx + npe], bs[0])
+        W0 = torch.cat([Ws[0][:nx], Ws[0][nx + npe:]], dim=0)
+        if extra:
+            Z2 = packed.detach().view(-1, packed.shape[-1])
+            lib.call("inverse_squared_distance", Z2.shape[0], R * N, Z2, Z2.shape[1], camloc.detach().reshape(B, 3).contiguous(),
+                     _ColumnView(Z2, Din), Z2.shape[1])
+        nets.append(([W0] + Ws[1:], [None] + bs[1:]))
+        widths.append(Din + extra)
+        rows.append((row_term, N))
+    outs = multi_mlp(inp, nets, widths=widths if packed is not None else None, row_terms=rows if with_photo else None,
+                     lazy_pad=packed is not None)
+    return tuple(outs) + ((pgain,) if with_photo else ())
+
+
+class _ColumnView:
+    """Raw pointer to column `c` of a row-major GPU matrix (for kernels that take a pointer and a row stride)."""
+    is_cuda, dtype = True, torch.float32
+
+    def __init__(self, t, c):
+        self.t, self.c = t, c
+
+    def is_contiguous(self):
+        return True
+
+    def data_ptr(self):
+        return self.t.data_ptr() + 4 * self.c
 
 
 def base_color_network(x, feature, normal, conf, raw=False):

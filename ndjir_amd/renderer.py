@@ -73,7 +73,7 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     eps_normal = conf.renderer.eps_normal
 
     # Geometric network and its spatial gradient (nn.grad, renderer.py:51-52)
-    sdf_x_fg, feature_x_fg, gain, grad_x_fg = geometric_network_with_grad(x_fg, conf)
+    sdf_x_fg, feature_x_fg, gain, grad_x_fg, packed_fg = geometric_network_with_grad(x_fg, conf, packed=True)
 
     # Background alpha (renderer.py:70-76)
     if conf.background_modeling:
@@ -127,15 +127,19 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     x_fg_ptb = x_fg + rand["noise"] * (math.sqrt(3) * 2 * rad / G)
     prior_partials = None
     if use_head:
-        raws = material_nets_raw(x_fg, feature_x_fg, grad_x_fg, conf)
-        if raws is not None:
+        raws = material_nets_raw(x_fg, feature_x_fg, grad_x_fg, conf, packed=packed_fg, photo=(camloc, view_dir))
+        raw_photo = None
+        if raws is not None and len(raws) == 6:
+            raw_imp, raw_bc, raw_rough, raw_spec, raw_photo, photo_gain = raws
+        elif raws is not None:
             raw_imp, raw_bc, raw_rough, raw_spec = raws
         else:
             raw_imp = implicit_illumination_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
             raw_bc = base_color_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
             raw_rough = roughness_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
             raw_spec = specular_reflectance_network(x_fg, feature_x_fg, grad_x_fg, conf, raw=True)
-        raw_photo, photo_gain = photogrammetric_light_network(x_fg, camloc, view_dir, feature_x_fg, grad_x_fg, conf, raw=True)
+        if raw_photo is None:
+            raw_photo, photo_gain = photogrammetric_light_network(x_fg, camloc, view_dir, feature_x_fg, grad_x_fg, conf, raw=True)
         if render_only:
             # `render_image` evaluates `color_pixel` only: the reference's graph executor never runs the base-colour
             # perturbation branch there (it feeds the prior term of the loss, python/loss.py:108-115)

@@ -189,9 +189,13 @@ def test_geometric_main_double_backward(gpu, grid):
     Fd = torch.tensor(F, device=gpu).requires_grad_(True) if grid else None
     Wd = [w.to(gpu).requires_grad_(True) for w in Ws]
     bd = [b.to(gpu).requires_grad_(True) for b in bs]
-    sdf, feat, n = geometric_main(xd, Fd, Wd, bd, M, 3, c)
+    sdf, feat, n, Z = geometric_main(xd, Fd, Wd, bd, M, 3, c)
+    # the packed sample inputs: [x | feature | n | zeros]; a gradient arriving through Z counts for feature and n
+    assert Z.shape == (P, (3 + Dh + 3 + 1 + 3) // 4 * 4) and feat.data_ptr() == Z.data_ptr() + 12
+    assert torch.equal(Z[:, :3], xd) and torch.equal(Z[:, 3 + Dh:6 + Dh], n) and float(Z[:, 6 + Dh:].abs().max()) == 0.0
+    w_Z = rng.randn(P, Z.shape[1]).astype(np.float32)
     loss = (sdf * torch.tensor(w_sdf, device=gpu)).sum() + (feat * torch.tensor(w_feat, device=gpu)).sum() \
-        + ((n * torch.tensor(w_n, device=gpu)).sum(-1) ** 2).sum()
+        + ((n * torch.tensor(w_n, device=gpu)).sum(-1) ** 2).sum() + (Z * torch.tensor(w_Z, device=gpu)).sum()
     params = Wd + bd + ([Fd] if grid else [])
     grads = torch.autograd.grad(loss, params)
 
@@ -206,7 +210,8 @@ def test_geometric_main_double_backward(gpu, grid):
     sdf64, feat64 = y[:, :1], y[:, 1:]
     n64, = torch.autograd.grad(sdf64.sum(), x64, create_graph=True)
     loss64 = (sdf64 * torch.tensor(w_sdf).double()).sum() + (feat64 * torch.tensor(w_feat).double()).sum() \
-        + ((n64 * torch.tensor(w_n).double()).sum(-1) ** 2).sum()
+        + ((n64 * torch.tensor(w_n).double()).sum(-1) ** 2).sum() \
+        + (feat64 * torch.tensor(w_Z[:, 3:3 + Dh]).double()).sum() + (n64 * torch.tensor(w_Z[:, 3 + Dh:6 + Dh]).double()).sum()
     g64 = torch.autograd.grad(loss64, W64 + b64 + ([F64] if grid else []))
 
     def rel(a, b):
@@ -251,6 +256,58 @@ def test_fused_mlp_row_bias(gpu, P, div, K0, Dh, No):
     g64 = torch.autograd.grad(y64, a64, g)
     g32 = torch.autograd.grad(y32, a32, g.float())
     for i, (a, b) in enumerate(zip(g32, g64)):
+        assert _rel(a, b.cpu()) < 2e-5, i
+
+
+def test_multi_mlp_on_packed_input_with_row_term(gpu):
+    """mlp.multi_mlp on a packed input (P, 24): two nets read its first 18 columns, a third reads 19 and takes a per-group
+    row term; outputs, the shared input gradient (accumulated in the kernels; undefined beyond the widest net) and every
+    parameter gradient against fp64 autograd of the separate nets."""
+    from ndjir_amd.mlp import multi_mlp
+    rng = np.random.RandomState(11)
+    P, ld, div, Dh = 768, 24, 64, 64
+
+    def net(K, No, seed):
+        r = np.random.RandomState(seed)
+        dims = [K, Dh, Dh, No]
+        return ([torch.tensor(r.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i]), dtype=torch.float64, device=gpu) for i in range(3)],
+                [torch.tensor(r.randn(dims[i + 1]) * 0.1, dtype=torch.float64, device=gpu) for i in range(3)])
+
+    nets64 = [net(18, 3, 1), net(18, 2, 2), net(19, 1, 3)]
+    x64 = torch.tensor(rng.randn(P, ld), dtype=torch.float64, device=gpu, requires_grad=True)
+    rt64 = torch.tensor(rng.randn(P // div, Dh) * 0.3, dtype=torch.float64, device=gpu, requires_grad=True)
+
+    def ref(x, W, b, K, rt=None):
+        h = x[:, :K] @ W[0] + (b[0] if rt is None else rt.repeat_interleave(div, dim=0))
+        h = TF.softplus(h, beta=100)
+        h = TF.softplus(h @ W[1] + b[1], beta=100)
+        return h @ W[2] + b[2]
+
+    leaves64 = [x64, rt64]
+    for W, b in nets64:
+        for t in W + b:
+            t.requires_grad_(True)
+        leaves64 += W + b
+    y64 = [ref(x64, *nets64[0], 18), ref(x64, *nets64[1], 18), ref(x64, *nets64[2], 19, rt64)]
+    gs = [torch.tensor(rng.randn(*y.shape), dtype=torch.float64, device=gpu) for y in y64]
+    g64 = torch.autograd.grad(y64, leaves64, gs, allow_unused=True)
+
+    x32 = x64.detach().float().requires_grad_(True)
+    rt32 = rt64.detach().float().requires_grad_(True)
+    nets32 = [([w.detach().float().requires_grad_(True) for w in W], [t.detach().float().requires_grad_(True) for t in b]) for W, b in nets64]
+    call = [(nets32[0][0], nets32[0][1]), (nets32[1][0], nets32[1][1]), (nets32[2][0], [None] + nets32[2][1][1:])]
+    y32 = multi_mlp(x32, call, widths=[18, 18, 19], row_terms=[None, None, (rt32, div)])
+    for a, b in zip(y32, y64):
+        assert _rel(a, b.detach().cpu()) < 2e-6
+    leaves32 = [x32, rt32]
+    for W, b in nets32:
+        leaves32 += W + b
+    g32 = torch.autograd.grad(list(y32), leaves32, [g.float() for g in gs], allow_unused=True)
+    assert _rel(g32[0][:, :19], g64[0][:, :19].cpu()) < 2e-5 and float(g32[0][:, 19:].abs().max()) == 0.0
+    for i, (a, b) in enumerate(zip(g32[1:], g64[1:]), 1):
+        if b is None or a is None:
+            assert i == len(leaves32) - 3 and a is None          # the third net's first bias lives in the row term: unused here
+            continue
         assert _rel(a, b.cpu()) < 2e-5, i
 
 

@@ -350,12 +350,31 @@ def test_sparse_row_exchange_kernels(gpu):
         assert bool(torch.isin(got, touched).all())
         assert torch.equal(rows[rank, :n], flat[got])
     for rank in range(2):
-        lib.call("sparse_rows_apply", ids, rows, counts, 2, cap, rank, bufs[rank], D)
+        lib.call("sparse_rows_apply", ids, rows, counts, 2, cap, cap, rank, bufs[rank], D)
         scale = float(dense.abs().max())
         assert float((bufs[rank] - dense).abs().max()) <= 1e-6 * scale
+    limit = torch.full((1,), cap, dtype=torch.int32, device=gpu)
     for rank in range(2):
-        lib.call("sparse_rows_zero", ids, counts, 2, cap, bufs[rank], D)
+        lib.call("sparse_rows_zero", ids, counts, 2, cap, limit, rank, None, None, bufs[rank], D)
         assert float(bufs[rank].abs().max()) == 0.0
+    # a communicated size below a rank's count: only the first `limit` rows of the other rank arrive, the flag is raised,
+    # and zeroing with the rank's own full list still clears everything it wrote
+    m = 4096
+    flag = torch.zeros(1, dtype=torch.int32, device=gpu)
+    lib.call("sparse_rows_overflow", counts, 2, cap, flag)
+    assert int(flag) == 0
+    lib.call("sparse_rows_overflow", counts, 2, m, flag)
+    assert int(flag) == 1
+    buf = torch.zeros(G, G, G, D, device=gpu)
+    lib.call("sparse_rows_apply", ids, rows, counts, 2, cap, m, 0, buf, D)
+    want = torch.zeros(G ** 3, D, device=gpu)
+    want[ids[1, :m].long()] = rows[1, :m]
+    assert torch.equal(buf.view(-1, D), want)
+    limit.fill_(m)
+    own_cnt = counts[0:1].clone()
+    buf.view(-1, D)[ids[0, :int(counts[0])].long()] = 1.0
+    lib.call("sparse_rows_zero", ids, counts, 2, cap, limit, 0, ids[0], own_cnt, buf, D)
+    assert float(buf.abs().max()) == 0.0
     # overflow: the count runs past the capacity, nothing is written beyond it
     buf = dense.clone()
     small = 100
