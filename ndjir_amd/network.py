@@ -246,9 +246,17 @@ def geometric_network(x, conf, first_order_only=False, sdf_only=False):
         skip_layers = list(g.skip_layers)
         v = g.voxel
 
-        pe_x = positional_encoding(x, M) if M > 0 else x
         vfeat = query_on_grid(x, v.grid_size, v.feature_size, v.use_ste, v.type)
-        inputs = torch.cat([pe_x, vfeat], dim=-1) if vfeat is not None else pe_x
+        if (vfeat is not None and x.is_cuda and x.dtype == torch.float32 and M > 0 and x.shape[-1] == 3 and g.geometric_init
+                and not vfeat.requires_grad and not x.requires_grad):
+            # nothing to differentiate (sampler rounds, mesh extraction): encoding and grid features side by side in one launch
+            Kin = 3 + 6 * M + vfeat.shape[-1]
+            inputs = torch.empty(x.shape[:-1] + (Kin,), device=x.device, dtype=torch.float32)
+            lib.call("geo_encode", inputs.numel() // Kin, M, x.contiguous(), 1, [vfeat.contiguous()], [vfeat.shape[-1]], inputs, Kin)
+            pe_x = None
+        else:
+            pe_x = positional_encoding(x, M) if M > 0 else x
+            inputs = torch.cat([pe_x, vfeat], dim=-1) if vfeat is not None else pe_x
         h = inputs
 
         if not g.geometric_init:
@@ -302,7 +310,8 @@ def geometric_network(x, conf, first_order_only=False, sdf_only=False):
                             h = torch.cat([h, inputs], dim=-1) * scale
         sdf, feature = h[..., 0:1], h[..., 1:]
         gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain]), True)
-        gain = torch.exp(gain * 10).clamp(1e-6, 5e4)
+        # (the sampler's and the perturbation pass's callers ignore the gain: three launches saved per call)
+        gain = None if (sdf_only or first_order_only) else torch.exp(gain * 10).clamp(1e-6, 5e4)
     return sdf, feature, gain
 
 
