@@ -339,6 +339,15 @@ int ndjir_render_material_head_backward(int R, int N, const float* raw_base_colo
                                         float* g_base_color, float* g_base_color_ptb, float* g_implicit, float* g_photo,
                                         float* g_roughness, float* g_specular, hipStream_t stream);
 
+/* Several VR integrals of the same weights (python/renderer.py:84-87 as called at :90-176) in one launch.  Segment k:
+ * x[k] (R, S[k], C[k]) with row stride ld[k], weighted by w[:, off[k] : off[k] + S[k]] of w (R, S_all); out[k] (R, C[k]).
+ * Backward: g[k] (R, C[k]) or null; gx[k] (R, S[k], C[k]) or null; gw (R, S_all) = the sum over all segments (or null). */
+int ndjir_render_integrate_many(int R, int S_all, const float* w, int nseg, const float* const* x, const int* ld, const int* C,
+                                const int* S, const int* off, float* const* out, hipStream_t stream);
+int ndjir_render_integrate_many_backward(int R, int S_all, const float* w, int nseg, const float* const* x, const int* ld,
+                                         const int* C, const int* S, const int* off, const float* const* g, float* const* gx,
+                                         float* gw, hipStream_t stream);
+
 /* ---- the per-ray tail of the step (ndjir_amd/csrc/loss.hip) -------------------------------------------------------
  * ndjir_render_pixel_compose: python/renderer.py:163-178 for the fused material head -- pix (R,9) = VR of
  *   [implicit, roughness, specular x3, photo, base term x3], env (R,Ce) the diffuse light integral (Ce = 1 or 3), spec (R,3),

@@ -225,6 +225,113 @@ __global__ void __launch_bounds__(256) k_integrate_bwd(int S, int C, const float
   }
 }
 
+// ---- several VR integrals of one ray's weights in one launch ----
+// python/renderer.py:84-87 is called for the normal, the position, the feature, the material products and the background
+// colour of every ray (:90-176); each call reads the same weights and -- backward -- adds to the same weight gradient.
+// Segment k: x_k (R, S_k, C_k) with row stride ld_k against weights[:, off_k : off_k + S_k].
+constexpr int IM_SEGS = 6;
+struct IntSegs {
+  const float* x[IM_SEGS];
+  const float* g[IM_SEGS];      // backward: (R, C_k) or null (segment without a gradient)
+  float* out[IM_SEGS];          // forward: (R, C_k); backward: gx (R, S_k, C_k) or null
+  int ld[IM_SEGS], C[IM_SEGS], S[IM_SEGS], off[IM_SEGS];
+  int n;
+};
+
+__global__ void __launch_bounds__(256) k_integrate_many(int S_all, const float* __restrict__ w, IntSegs sg) {
+  __shared__ float red[256];
+  const long long r = blockIdx.x;
+  const float* wrow = w + r * S_all;
+  for (int k = 0; k < sg.n; ++k) {
+    const int C = sg.C[k], S = sg.S[k], ldx = sg.ld[k];
+    const int TX = rd_pow2(C), TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const float* wr = wrow + sg.off[k];
+    const float* xr = sg.x[k] + r * (long long)S * ldx;
+    for (int c0 = 0; c0 < C; c0 += TX) {
+      const int c = c0 + tx;
+      float acc = 0.f;
+      if (c < C) {
+#pragma unroll 4
+        for (int i = ty; i < S; i += TY) acc += wr[i] * xr[(long long)i * ldx + c];
+      }
+      red[threadIdx.x] = acc;
+      __syncthreads();
+      for (int s = TY / 2; s > 0; s >>= 1) {
+        if (ty < s) red[threadIdx.x] += red[threadIdx.x + s * TX];
+        __syncthreads();
+      }
+      if (ty == 0 && c < C) sg.out[k][r * C + c] = red[tx];
+      __syncthreads();
+    }
+  }
+}
+
+// gx_k[r][i][c] = w[r][off_k + i] g_k[r][c];  gw[r][j] = sum over the segments covering j of sum_c x_k[r][j - off_k][c] g_k[r][c]
+// (segments in order, a barrier between them: the sum order is fixed)
+__global__ void __launch_bounds__(256) k_integrate_many_bwd(int S_all, const float* __restrict__ w, IntSegs sg,
+                                                            float* __restrict__ gw) {
+  __shared__ float gws[RD_SLOTS];
+  const long long r = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* wrow = w + r * S_all;
+  for (int i = threadIdx.x; i < S_all; i += 256) gws[i] = 0.f;
+  __syncthreads();
+  for (int k = 0; k < sg.n; ++k) {
+    const float* g = sg.g[k];
+    if (!g) continue;
+    const int C = sg.C[k], S = sg.S[k], ldx = sg.ld[k], off = sg.off[k];
+    const float* gr = g + r * C;
+    const float* x = sg.x[k] + r * (long long)S * ldx;
+    float* gx = sg.out[k] ? sg.out[k] + r * (long long)S * C : nullptr;
+    if (C <= 4) {
+      for (int i = threadIdx.x; i < S; i += 256) {
+        const float wi = wrow[off + i];
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+          if (gw) acc += x[(long long)i * ldx + c] * gr[c];
+          if (gx) gx[(long long)i * C + c] = wi * gr[c];
+        }
+        if (gw) gws[off + i] += acc;
+      }
+    } else {
+      for (int i = wave; i < S; i += 4) {
+        const float wi = wrow[off + i];
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) {
+          const float gc = gr[c];
+          if (gw) acc += x[(long long)i * ldx + c] * gc;
+          if (gx) gx[(long long)i * C + c] = wi * gc;
+        }
+        if (gw) {
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+          if (lane == 0) gws[off + i] += acc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (gw)
+    for (int i = threadIdx.x; i < S_all; i += 256) gw[r * S_all + i] = gws[i];
+}
+
+static int int_segs(IntSegs& sg, int S_all, int nseg, const float* const* x, const int* ld, const int* C, const int* S, const int* off) {
+  if (nseg < 1 || nseg > IM_SEGS || !x || !ld || !C || !S || !off) return NDJIR_ERR_ARG;
+  sg.n = nseg;
+  for (int k = 0; k < IM_SEGS; ++k) {
+    sg.x[k] = k < nseg ? x[k] : nullptr;
+    sg.g[k] = nullptr;
+    sg.out[k] = nullptr;
+    sg.ld[k] = k < nseg ? ld[k] : 0;
+    sg.C[k] = k < nseg ? C[k] : 0;
+    sg.S[k] = k < nseg ? S[k] : 0;
+    sg.off[k] = k < nseg ? off[k] : 0;
+    if (k < nseg && (!x[k] || C[k] < 1 || ld[k] < C[k] || S[k] < 0 || off[k] < 0 || off[k] + S[k] > S_all)) return NDJIR_ERR_ARG;
+  }
+  return NDJIR_OK;
+}
+
 }  // namespace ndjir
 
 using namespace ndjir;
@@ -272,6 +379,33 @@ extern "C" int ndjir_render_integrate_backward(int R, int S, int C, const float*
   if (R <= 0 || C <= 0 || S <= 0) return NDJIR_OK;
   if (ldw < S || ldx < C || !w || !x || !g || (gw && ldgw < S)) return NDJIR_ERR_ARG;
   hipLaunchKernelGGL(k_integrate_bwd, dim3(R), dim3(256), 0, stream, S, C, w, ldw, x, ldx, g, gx, gw, ldgw);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_integrate_many(int R, int S_all, const float* w, int nseg, const float* const* x, const int* ld,
+                                           const int* C, const int* S, const int* off, float* const* out, hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  IntSegs sg;
+  if (!w || !out || int_segs(sg, S_all, nseg, x, ld, C, S, off) != NDJIR_OK) return NDJIR_ERR_ARG;
+  for (int k = 0; k < nseg; ++k) {
+    if (!out[k]) return NDJIR_ERR_ARG;
+    sg.out[k] = out[k];
+  }
+  hipLaunchKernelGGL(k_integrate_many, dim3(R), dim3(256), 0, stream, S_all, w, sg);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_integrate_many_backward(int R, int S_all, const float* w, int nseg, const float* const* x, const int* ld,
+                                                    const int* C, const int* S, const int* off, const float* const* g,
+                                                    float* const* gx, float* gw, hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  IntSegs sg;
+  if (!w || !g || !gx || S_all > RD_SLOTS || int_segs(sg, S_all, nseg, x, ld, C, S, off) != NDJIR_OK) return NDJIR_ERR_ARG;
+  for (int k = 0; k < nseg; ++k) {
+    sg.g[k] = g[k];
+    sg.out[k] = gx[k];
+  }
+  hipLaunchKernelGGL(k_integrate_many_bwd, dim3(R), dim3(256), 0, stream, S_all, w, sg, gw);
   return ndjir_check_launch();
 }
 

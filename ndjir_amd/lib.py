@@ -49,6 +49,8 @@ SIGS = {
     "render_alpha_weights": "iii" + "p" * 11,
     "render_alpha_weights_backward": "iii" + "p" * 16,
     "render_integrate": "iiipipip",
+    "render_integrate_many": "iipiPAAAAP",
+    "render_integrate_many_backward": "iipiPAAAAPPp",
     "render_material_head": "ii" + "p" * 7 + "iiiffff" + "ppp",
     "render_material_head_backward": "ii" + "p" * 7 + "iiiffff" + "pp" + "p" * 6,
     "render_pixel_compose": "iiippppp",

@@ -23,7 +23,8 @@ from .network import (background_network, base_color_network, material_nets_raw,
                       soft_visibility_light_network, specular_reflectance_network)
 from .sampler import sample_importance_directions, sample_points, sample_uniform_directions
 from .specular_brdf import dot, specular_brdf_model
-from .volume import alpha_weights, diffuse_light, integrate, material_head, pixel_compose, specular_light_filament
+from .volume import (alpha_weights, diffuse_light, integrate, integrate_many, material_head, pixel_compose,
+                     specular_light_filament)
 
 
 def make_rand(B, R, conf, device, n_fg=None, include_samples=True):
@@ -93,26 +94,17 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
         """sum_i weights_i x_i over the foreground (off=0) or background (off=N) samples"""
         return integrate(weights, x, off)
 
-    # Normal (renderer.py:90-91)
-    grad_pixel = VR(grad_x_fg) + eps_normal
-    normal_pixel = grad_pixel / torch.sqrt((grad_pixel * grad_pixel).sum(-1, keepdim=True))
-
     n_thetas = conf.renderer.n_thetas
     M = n_thetas * 2 * n_thetas
     D = feature_x_fg.shape[-1]
-    x_fg_pixel = VR(x_fg).reshape(B, R, 1, 3)
-    feature_pixel = VR(feature_x_fg).reshape(B, R, 1, D)
-    normal_bc = normal_pixel[:, :, None, :]
-
-    # Direct light + visibility (renderer.py:103-110)
-    uniform_light_dir = sample_uniform_directions(normal_pixel, rand["diffuse_cdf_the"], rand["diffuse_cdf_phi"])
     if not any(k.startswith("environment-light-network/") for k in P.get_parameters()):
         # first call only: create the two light nets' parameters HERE, i.e. in the reference's creation order
-        # (renderer.py:105-110), so that seeded initialisation does not depend on the batching further down
+        # (renderer.py:105-110, before the material nets), so that seeded initialisation does not depend on the evaluation
+        # order further down; only the input widths matter
         with torch.no_grad():
-            environment_light_network(uniform_light_dir[:, :1, :1], conf)
-            soft_visibility_light_network(x_fg_pixel[:, :1], uniform_light_dir[:, :1, :1], feature_pixel[:, :1],
-                                          normal_bc[:, :1], conf)
+            z = torch.zeros((B, 1, 1, 3), dtype=x_fg.dtype, device=x_fg.device)
+            environment_light_network(z, conf)
+            soft_visibility_light_network(z, z, torch.zeros((B, 1, 1, D), dtype=x_fg.dtype, device=x_fg.device), z, conf)
 
     # Material nets of the foreground samples (renderer.py:113-128, 164, 186-193).  Default configuration:
     # their output activations, the products feeding the VR integrals and the prior integrands of
@@ -126,6 +118,7 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     rad = conf.renderer.bounding_sphere_radius
     x_fg_ptb = x_fg + rand["noise"] * (math.sqrt(3) * 2 * rad / G)
     prior_partials = None
+    bg_pixel = None
     if use_head:
         raws = material_nets_raw(x_fg, feature_x_fg, grad_x_fg, conf, packed=packed_fg, photo=(camloc, view_dir))
         raw_photo = None
@@ -152,13 +145,31 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
             raw_bc, raw_ptb, raw_imp, raw_photo, photo_gain, raw_rough, raw_spec, remap, conf.diffuse_brdf.entangle,
             conf.train.base_color_prior_sym_backward, conf.roughness_network.lower_bound, sr.upper_bound_scale,
             conf.roughness_network.prior_value, sr.prior_value)
-        pix = VR(V)
+        # every VR integral of the ray in one launch (normal, position, feature, material products, background colour)
+        if os.environ.get("NDJIR_NO_FUSED_VR"):
+            grad_vr, x_vr, feat_vr, pix = VR(grad_x_fg), VR(x_fg), VR(feature_x_fg), VR(V)
+        else:
+            grad_vr, x_vr, feat_vr, pix, bg_pixel = integrate_many(weights, [grad_x_fg, x_fg, feature_x_fg, V, color_bg],
+                                                                   [0, 0, 0, 0, N])
         implicit_pixel, roughness_pixel, spec_refl_pixel = pix[..., 0:1], pix[..., 1:2], pix[..., 2:5]
         photo_pixel, base_term_pixel = pix[..., 5:6], pix[..., 6:9]
         base_color, base_color_ptb = aux[..., 0:3], aux[..., 3:6]
         roughness, spec_refl = V[..., 1:2], V[..., 2:5]
         std_roughness, std_spec_refl = aux[..., 6:7], aux[..., 7:10]
     else:
+        grad_vr, x_vr, feat_vr = VR(grad_x_fg), VR(x_fg), VR(feature_x_fg)
+
+    # Normal (renderer.py:90-91)
+    grad_pixel = grad_vr + eps_normal
+    normal_pixel = grad_pixel / torch.sqrt((grad_pixel * grad_pixel).sum(-1, keepdim=True))
+    x_fg_pixel = x_vr.reshape(B, R, 1, 3)
+    feature_pixel = feat_vr.reshape(B, R, 1, D)
+    normal_bc = normal_pixel[:, :, None, :]
+
+    # Direct light + visibility (renderer.py:103-110)
+    uniform_light_dir = sample_uniform_directions(normal_pixel, rand["diffuse_cdf_the"], rand["diffuse_cdf_phi"])
+
+    if not use_head:
         # Implicit light (renderer.py:113-114)
         implicit = implicit_illumination_network(x_fg, feature_x_fg, grad_x_fg, conf)
         implicit_pixel = VR(implicit)
@@ -211,7 +222,8 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     color_pixel = None
     if use_head and env_pixel.shape[-1] in (1, 3) and spec_pixel.shape[-1] == 3 and not os.environ.get("NDJIR_NO_FUSED_TAIL"):
         # one launch: diffuse = env + implicit, the entangled / disentangled product, + VR(color_bg)
-        color_pixel = pixel_compose(pix, env_pixel, spec_pixel, VR(color_bg, N), conf.diffuse_brdf.entangle)
+        color_pixel = pixel_compose(pix, env_pixel, spec_pixel, bg_pixel if bg_pixel is not None else VR(color_bg, N),
+                                    conf.diffuse_brdf.entangle)
     elif use_head:
         diffuse_light_pixel = env_pixel + implicit_pixel
         if conf.diffuse_brdf.entangle:
@@ -230,7 +242,7 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
         color_fg_pixel = VR(base_color) + spec_pixel
 
     if color_pixel is None:
-        color_pixel = color_fg_pixel + VR(color_bg, N)
+        color_pixel = color_fg_pixel + (bg_pixel if bg_pixel is not None else VR(color_bg, N))
 
     obj_mask_pred = torch.zeros((), dtype=x_fg.dtype, device=x_fg.device)
     if conf.train.mask_weight > 0.0:

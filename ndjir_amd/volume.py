@@ -99,6 +99,53 @@ def integrate(weights, x, off=0):
     return Integrate.apply(weights, off, x)
 
 
+class IntegrateMany(Function):
+    """Several VR integrals (renderer.py:84-87) of the same weights in one launch each way: apply(weights, offs, *xs) with
+    xs[k] (B,R,S_k,C_k) against weights[:, :, offs[k]:offs[k]+S_k] -> one (B,R,C_k) per x.  The weight gradient is formed
+    once, inside the backward launch, instead of one tensor per integral summed by autograd."""
+
+    @staticmethod
+    def forward(ctx, weights, offs, *xs):
+        B, R, S_all, _ = weights.shape
+        w = _c(weights)
+        xcs, lds = [], []
+        for x in xs:
+            _, _, S, C = x.shape
+            xc = x.detach()
+            ld = xc.stride(2)
+            if not (xc.stride(3) == 1 and ld >= C and xc.stride(1) == S * ld and xc.stride(0) == R * S * ld):
+                xc = xc.contiguous()
+                ld = C
+            xcs.append(xc)
+            lds.append(ld)
+        outs = [torch.empty((B, R, x.shape[3]), device=w.device, dtype=torch.float32) for x in xs]
+        lib.call("render_integrate_many", B * R, S_all, w, len(xs), [_Strided(x) for x in xcs], lds, [x.shape[3] for x in xs],
+                 [x.shape[2] for x in xs], list(offs), outs)
+        ctx.save_for_backward(w, *xcs)
+        ctx.cfg = (tuple(offs), tuple(lds))
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        w, *xs = ctx.saved_tensors
+        offs, lds = ctx.cfg
+        B, R, S_all, _ = w.shape
+        need_w = ctx.needs_input_grad[0]
+        gxs = [torch.empty(x.shape, device=w.device, dtype=torch.float32) if (ctx.needs_input_grad[2 + k] and gs[k] is not None)
+               else None for k, x in enumerate(xs)]
+        gw = torch.empty_like(w) if need_w else None
+        lib.call("render_integrate_many_backward", B * R, S_all, w, len(xs), [_Strided(x) for x in xs], list(lds),
+                 [x.shape[3] for x in xs], [x.shape[2] for x in xs], list(offs),
+                 [g.contiguous() if g is not None else None for g in gs], gxs, gw)
+        return (gw, None, *gxs)
+
+
+def integrate_many(weights, xs, offs):
+    return IntegrateMany.apply(weights, tuple(int(o) for o in offs), *xs)
+
+
 class DiffuseLight(Function):
     """renderer.py:117-118: mean over the M light directions of soft_vis * env * clamp(n.l, eps).
     normal (B,R,3), light_dir (B,R,M,3) [no grad], soft_vis (B,R,M,1), env (B,R,M,C) -> (B,R,C)."""

@@ -91,6 +91,36 @@ def test_integrate_matches_composite(gpu, R, S_all, off, S, C):
     assert float((gw32.double() - gw64).abs().max()) < 1e-5 * max(1.0, float(gw64.abs().max()))
 
 
+@pytest.mark.parametrize("R,N,Nb", [(37, 128, 32), (5, 256, 32), (16, 64, 1)])
+def test_integrate_many_matches_composite(gpu, R, N, Nb):
+    """volume.integrate_many: the ray's VR integrals (3-, 3-, 20-, 9-wide over the foreground, a column slice of a wider
+    array among them, 3-wide over the background) in one launch each way; one of the outputs unused."""
+    from ndjir_amd.volume import integrate_many
+    rng = np.random.RandomState(R + N)
+    w64 = torch.tensor(rng.rand(1, R, N + Nb, 1), dtype=torch.float64, device=gpu, requires_grad=True)
+    wide = torch.tensor(rng.randn(1, R, N, 28), dtype=torch.float64, device=gpu, requires_grad=True)
+    xs64 = [torch.tensor(rng.randn(1, R, S, C), dtype=torch.float64, device=gpu, requires_grad=True)
+            for S, C in ((N, 3), (N, 3), (N, 9), (Nb, 3))]
+    offs = [0, 0, 0, 0, N]
+    ins64 = xs64[:2] + [wide[..., 3:23]] + xs64[2:]
+    ref = [(w64[:, :, o:o + x.shape[2], :] * x).sum(dim=2) for x, o in zip(ins64, offs)]
+    w32 = w64.detach().float().requires_grad_(True)
+    wide32 = wide.detach().float().requires_grad_(True)
+    xs32 = [x.detach().float().requires_grad_(True) for x in xs64]
+    out = integrate_many(w32, xs32[:2] + [wide32[..., 3:23]] + xs32[2:], offs)
+    for a, b in zip(out, ref):
+        assert float((a.double() - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max()))
+    gs = [torch.tensor(rng.randn(*r.shape), dtype=torch.float64, device=gpu) for r in ref]
+    use = [0, 2, 3, 4]                                    # the second integral's result is not used
+    g64 = torch.autograd.grad([ref[k] for k in use], [w64, wide] + xs64, [gs[k] for k in use], allow_unused=True)
+    g32 = torch.autograd.grad([out[k] for k in use], [w32, wide32] + xs32, [gs[k].float() for k in use], allow_unused=True)
+    for i, (a, b) in enumerate(zip(g32, g64)):
+        if b is None:
+            assert a is None, i
+            continue
+        assert float((a.double() - b).abs().max()) < 1e-5 * max(1.0, float(b.abs().max())), i
+
+
 def _light_inputs(B, R, M, C, seed, gpu):
     rng = np.random.RandomState(seed)
     f = lambda *s: torch.tensor(rng.randn(*s), dtype=torch.float64, device=gpu)
