@@ -427,6 +427,78 @@ __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Hash-grid scatters through a table image in LDS.  A level's table is small (T <= 2^15 ... 2^19 entries of D floats:
+// 256 KB at the reference bench's T0 = 2^15, D = 2) and EVERY point writes 8 (Lanczos: 64) pseudo-random entries of it:
+// nothing to merge inside a wave, and the device-wide fp32 atomic rate (~20 G/s, tools/ubench/atomics.hip) prices the
+// plain scatter at 256 atomics per point.  Here a workgroup owns one slice of one level's table (<= 32768 floats, 128 KB
+// of LDS), walks a share of the points, adds the taps that fall into its slice with LDS atomics and flushes the slice
+// once: global atomics drop from taps x D per (point, level) to (slice floats) per workgroup.
+//   grid = levels x slices per level x point shares ;  workgroup (s, c, k): level s, entries [c E, (c+1) E), points k, k+K, ...
+// Every workgroup evaluates all taps of its points and keeps those of its slice, so the hash arithmetic is repeated once
+// per slice of the level -- the launcher uses this path while a level has at most HASH_LDS_MAX_SLICES slices.
+// ------------------------------------------------------------------------------------------------
+constexpr int HASH_LDS_FLOATS = 32768;
+constexpr int HASH_LDS_MAX_SLICES = 8;
+
+template <int I, int MODE>
+__global__ void __launch_bounds__(256) k_scatter_hash_lds(long long P, float* __restrict__ gf, const float* __restrict__ gg_query,
+                                                          const float* __restrict__ grad_output, const float* __restrict__ query,
+                                                          GridDesc g, int slices, int shares, int entries_per_slice) {
+  constexpr int TOPO = HASH;
+  constexpr int ND = 3, NT = NTaps<I>::v;
+  extern __shared__ float hs_tab[];
+  const int share = blockIdx.x % shares;
+  const int c = (blockIdx.x / shares) % slices;
+  const int s = blockIdx.x / (shares * slices);
+  const int T = g.lvlT[s], D = g.D;
+  const int lo = c * entries_per_slice;
+  int n_ent = T - lo;
+  if (n_ent > entries_per_slice) n_ent = entries_per_slice;
+  if (n_ent <= 0) return;
+  const int n_fl = n_ent * D;
+  for (int t = threadIdx.x; t < n_fl; t += 256) hs_tab[t] = 0.f;
+  __syncthreads();
+  for (long long b = (long long)share * 256 + threadIdx.x; b < P; b += (long long)shares * 256) {
+    float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
+    Stencil<TOPO, I> st;
+    make_stencil<TOPO, I>(st, g, s, q);
+    float ggs[ND];
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int a = 0; a < ND; ++a) ggs[a] = gg_query[b * 3 + st.axis[a]] * st.scale[a] * st.ax[a].gm;
+    }
+    float og[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) og[d] = d < D ? grad_output[out_index<TOPO>(g, P, b, s, d)] : 0.f;
+    NDJIR_FOR_TAPS(ND, NT) {
+      const int e = (int)hash3(st.ax[0].idx[i], st.ax[1].idx[j], st.ax[2].idx[k], T) - lo;
+      if (e >= 0 && e < n_ent) {
+        float w;
+        if constexpr (MODE == 0) {
+          w = tap_w(st, i, j, k);
+        } else {
+          w = 0.f;
+#pragma unroll
+          for (int a = 0; a < ND; ++a) w += ggs[a] * tap_dw(st, a, i, j, k);
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) if (d < D) atomicAdd(&hs_tab[e * D + d], og[d] * w);
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = gf + g.lvlOff[s] + (long long)lo * D;
+  if (shares == 1) {
+    for (int t = threadIdx.x; t < n_fl; t += 256) dst[t] += hs_tab[t];          // sole owner of the slice
+  } else {
+    for (int t = threadIdx.x; t < n_fl; t += 256) {
+      const float v = hs_tab[t];
+      if (v != 0.f) atomicAdd(dst + t, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // zero the cells a set of queries touches (every tap of the stencil): re-arms an accumulate-in-place
 // gradient buffer after use without rewriting all of it (2 GiB for the default 512^3 x 4 grid).
 // Covers grad_feature, grad_query_grad_feature and the TV backward (its cells are a subset of the taps).
@@ -762,6 +834,8 @@ int launch_dquery(int interp, const GridDesc& g, long long P, int mode, float* d
   return ndjir_check_launch();
 }
 
+static inline long long NTapsOf(int interp) { return interp == LANCZOS ? 64 : 8; }
+
 // mode 0: grad_feature ; mode 1: grad_query_grad_feature.  The caller zero-fills when !accum.
 int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* gf, const float* gg_query,
                    const float* grad_output, const float* query, hipStream_t stream) {
@@ -791,6 +865,35 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
 #undef NDJIR_AGG_TOPO
 #undef NDJIR_AGG_CASE
     return ndjir_check_launch();
+  }
+  if (g.topo == HASH && (interp == LINEAR || interp == LANCZOS) && !no_agg) {
+    int Tmax = 0;
+    for (int l = 0; l < g.S; ++l) Tmax = g.lvlT[l] > Tmax ? g.lvlT[l] : Tmax;
+    const int per_slice = HASH_LDS_FLOATS / g.D;                   // entries
+    const int slices = (Tmax + per_slice - 1) / per_slice;
+    // enough points per workgroup that the slice flush (per_slice x D global atomics) stays small beside the taps it replaces
+    if (g.D <= 8 && slices <= HASH_LDS_MAX_SLICES && P * NTapsOf(interp) >= 8LL * per_slice) {
+      long long shares = 1024 / ((long long)g.S * slices);
+      const long long max_shares = (P + 2047) / 2048;              // at least 2048 points per workgroup
+      if (shares > max_shares) shares = max_shares;
+      if (shares < 1) shares = 1;
+      const int nblk = (int)(g.S * slices * shares);
+      const size_t lds = (size_t)HASH_LDS_FLOATS * sizeof(float);
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_hash_lds<LINEAR, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_hash_lds<LINEAR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_hash_lds<LANCZOS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_hash_lds<LANCZOS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+      }
+#define NDJIR_HASH_LDS(IV, MV) hipLaunchKernelGGL((k_scatter_hash_lds<IV, MV>), dim3(nblk), dim3(256), lds, stream, P, gf, gg_query, \
+                                                  grad_output, query, g, slices, (int)shares, per_slice)
+      if (interp == LINEAR) { if (mode == 0) NDJIR_HASH_LDS(LINEAR, 0); else NDJIR_HASH_LDS(LINEAR, 1); }
+      else { if (mode == 0) NDJIR_HASH_LDS(LANCZOS, 0); else NDJIR_HASH_LDS(LANCZOS, 1); }
+#undef NDJIR_HASH_LDS
+      return ndjir_check_launch();
+    }
   }
   NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
     if (mode == 0) hipLaunchKernelGGL((k_scatter<TOPO, I, VW, 0>), dim3(blocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);

@@ -89,6 +89,16 @@ def test_sample_directions_z_normal_is_nan_like_reference(gpu):
     assert torch.isnan(out).any()
 
 
+@pytest.mark.parametrize("family,P,hash_cfg", [("voxel_hash", 20000, (16, 1.5, 2 ** 15, 16, 2)),      # 2 table slices per level
+                                               ("voxel_hash", 40000, (16, 1.5, 2 ** 17, 6, 2)),       # up to 8 slices
+                                               ("voxel_hash", 9000, (16, 1.5, 2 ** 13, 8, 4)),        # one slice, 4 channels
+                                               ("lanczos_voxel_hash", 3000, (16, 1.5, 2 ** 15, 8, 2))])
+def test_hash_scatter_through_lds_table(gpu, family, P, hash_cfg):
+    """grad_feature / grad_query_grad_feature of the hash grids at point counts where the scatter runs through the LDS image of
+    a level's table (csrc/grid.hip k_scatter_hash_lds) instead of one global atomic per tap and channel."""
+    _family_check(gpu, family, P, None, hash_cfg, fine=True)
+
+
 def _hip_family(family):
     from ndjir_amd.grid_feature import _core
     return _core
@@ -107,7 +117,7 @@ def test_grid_family_eight_channels(gpu, family, P, G):
     _family_check(gpu, family, P, G, None, D=8)
 
 
-def _family_check(gpu, family, P, G, hash_cfg, D=4):
+def _family_check(gpu, family, P, G, hash_cfg, D=4, fine=None):
     from ndjir_amd.grid_feature import _core
     rng = np.random.RandomState(412)
     o = K.GridOracle(family, hash=hash_cfg)
@@ -124,7 +134,7 @@ def _family_check(gpu, family, P, G, hash_cfg, D=4):
     ref = o.query(q, f)
     # the finest hash levels (G ~ 7000) resolve the cell fraction to ~1e-4 in fp32: 1-2 ulp of the
     # continuous coordinate moves a coefficient by ~1e-3
-    fine = hash_cfg is not None and hash_cfg[3] > 8
+    fine = (hash_cfg is not None and hash_cfg[3] > 8) if fine is None else fine
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref, atol=2e-5 if fine else (2e-6 if lz else 1e-6))
     og = rng.randn(*ref.shape).astype(np.float32)
     ogd = T(og, gpu).requires_grad_(True)
