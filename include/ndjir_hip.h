@@ -348,6 +348,11 @@ int ndjir_render_integrate_many_backward(int R, int S_all, const float* w, int n
                                          const int* C, const int* S, const int* off, const float* const* g, float* const* gx,
                                          float* gw, hipStream_t stream);
 
+/* Pixel normal (python/renderer.py:90-91): normal = (grad_pixel + eps) / |grad_pixel + eps| per ray, and its backward. */
+int ndjir_render_pixel_normal(int R, float eps, const float* grad_pixel, float* normal, hipStream_t stream);
+int ndjir_render_pixel_normal_backward(int R, float eps, const float* grad_pixel, const float* g_normal, float* g_grad_pixel,
+                                       hipStream_t stream);
+
 /* ---- the per-ray tail of the step (ndjir_amd/csrc/loss.hip) -------------------------------------------------------
  * ndjir_render_pixel_compose: python/renderer.py:163-178 for the fused material head -- pix (R,9) = VR of
  *   [implicit, roughness, specular x3, photo, base term x3], env (R,Ce) the diffuse light integral (Ce = 1 or 3), spec (R,3),

@@ -11,6 +11,32 @@
 
 namespace ndjir {
 
+// ---- pixel normal, python/renderer.py:90-91: n = (VR(grad) + eps) / |VR(grad) + eps| ------------------------------------
+__global__ void __launch_bounds__(256) k_pixel_normal(int R, float eps, const float* __restrict__ g, float* __restrict__ n) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const float x = g[r * 3] + eps, y = g[r * 3 + 1] + eps, z = g[r * 3 + 2] + eps;
+  const float len = sqrtf(x * x + y * y + z * z);
+  n[r * 3] = x / len;
+  n[r * 3 + 1] = y / len;
+  n[r * 3 + 2] = z / len;
+}
+
+// d/dg of the above: (gn - n (n . gn)) / len
+__global__ void __launch_bounds__(256) k_pixel_normal_bwd(int R, float eps, const float* __restrict__ g, const float* __restrict__ gn,
+                                                          float* __restrict__ gg) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const float x = g[r * 3] + eps, y = g[r * 3 + 1] + eps, z = g[r * 3 + 2] + eps;
+  const float len = sqrtf(x * x + y * y + z * z);
+  const float nx = x / len, ny = y / len, nz = z / len;
+  const float a = gn[r * 3], b = gn[r * 3 + 1], c = gn[r * 3 + 2];
+  const float dot = nx * a + ny * b + nz * c;
+  gg[r * 3] = (a - nx * dot) / len;
+  gg[r * 3 + 1] = (b - ny * dot) / len;
+  gg[r * 3 + 2] = (c - nz * dot) / len;
+}
+
 // ---- pixel composition ----------------------------------------------------------------------------------------------
 // pix (R,9) = VR of [implicit, roughness, specular x3, photo, base term x3]; env (R,Ce) diffuse light integral, Ce = 1 or 3;
 // spec (R,3); bg (R,3).  diffuse = env + implicit;
@@ -197,6 +223,21 @@ __global__ void __launch_bounds__(256) k_loss_bwd(int R, int N, const float* __r
 }  // namespace ndjir
 
 using namespace ndjir;
+
+extern "C" int ndjir_render_pixel_normal(int R, float eps, const float* grad_pixel, float* normal, hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  if (!grad_pixel || !normal) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_pixel_normal, dim3((R + 255) / 256), dim3(256), 0, stream, R, eps, grad_pixel, normal);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_pixel_normal_backward(int R, float eps, const float* grad_pixel, const float* g_normal, float* g_grad_pixel,
+                                                  hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  if (!grad_pixel || !g_normal || !g_grad_pixel) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_pixel_normal_bwd, dim3((R + 255) / 256), dim3(256), 0, stream, R, eps, grad_pixel, g_normal, g_grad_pixel);
+  return ndjir_check_launch();
+}
 
 extern "C" int ndjir_render_pixel_compose(int R, int Ce, int entangle, const float* pix, const float* env, const float* spec,
                                           const float* bg, float* color, hipStream_t stream) {

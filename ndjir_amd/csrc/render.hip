@@ -244,11 +244,13 @@ __global__ void __launch_bounds__(256) k_integrate_many(int S_all, const float* 
   const float* wrow = w + r * S_all;
   for (int k = 0; k < sg.n; ++k) {
     const int C = sg.C[k], S = sg.S[k], ldx = sg.ld[k];
-    const int TX = rd_pow2(C), TY = 256 / TX;
+    int TX = rd_pow2(C);
+    if (TX > 64) TX = 64;                          // wide segments: 64-channel chunks dealt to the workgroups (r, y)
+    const int TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const float* wr = wrow + sg.off[k];
     const float* xr = sg.x[k] + r * (long long)S * ldx;
-    for (int c0 = 0; c0 < C; c0 += TX) {
+    for (int c0 = blockIdx.y * TX; c0 < C; c0 += gridDim.y * TX) {     // uniform per workgroup
       const int c = c0 + tx;
       float acc = 0.f;
       if (c < C) {
@@ -268,52 +270,38 @@ __global__ void __launch_bounds__(256) k_integrate_many(int S_all, const float* 
 }
 
 // gx_k[r][i][c] = w[r][off_k + i] g_k[r][c];  gw[r][j] = sum over the segments covering j of sum_c x_k[r][j - off_k][c] g_k[r][c]
-// (segments in order, a barrier between them: the sum order is fixed)
+// Workgroup (r, y) owns the weight positions j = y, y + gridDim.y, ... of ray r (a wave per position, lanes over channels):
+// the segments are visited in order, so each gw[r][j] is summed in a fixed order by one wave.
 __global__ void __launch_bounds__(256) k_integrate_many_bwd(int S_all, const float* __restrict__ w, IntSegs sg,
                                                             float* __restrict__ gw) {
-  __shared__ float gws[RD_SLOTS];
   const long long r = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* wrow = w + r * S_all;
-  for (int i = threadIdx.x; i < S_all; i += 256) gws[i] = 0.f;
-  __syncthreads();
-  for (int k = 0; k < sg.n; ++k) {
-    const float* g = sg.g[k];
-    if (!g) continue;
-    const int C = sg.C[k], S = sg.S[k], ldx = sg.ld[k], off = sg.off[k];
-    const float* gr = g + r * C;
-    const float* x = sg.x[k] + r * (long long)S * ldx;
-    float* gx = sg.out[k] ? sg.out[k] + r * (long long)S * C : nullptr;
-    if (C <= 4) {
-      for (int i = threadIdx.x; i < S; i += 256) {
-        const float wi = wrow[off + i];
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) {
-          if (gw) acc += x[(long long)i * ldx + c] * gr[c];
-          if (gx) gx[(long long)i * C + c] = wi * gr[c];
-        }
-        if (gw) gws[off + i] += acc;
+  for (int j = blockIdx.y * 4 + wave; j < S_all; j += gridDim.y * 4) {
+    const float wj = wrow[j];
+    float tot = 0.f;
+    for (int k = 0; k < sg.n; ++k) {
+      const float* g = sg.g[k];
+      const int i = j - sg.off[k];
+      if (!g || i < 0 || i >= sg.S[k]) continue;
+      const int C = sg.C[k], S = sg.S[k], ldx = sg.ld[k];
+      const float* gr = g + r * C;
+      const float* x = sg.x[k] + (r * (long long)S + i) * ldx;
+      float* gx = sg.out[k] ? sg.out[k] + (r * (long long)S + i) * C : nullptr;
+      float acc = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float gc = gr[c];
+        if (gw) acc += x[c] * gc;
+        if (gx) gx[c] = wj * gc;
       }
-    } else {
-      for (int i = wave; i < S; i += 4) {
-        const float wi = wrow[off + i];
-        float acc = 0.f;
-        for (int c = lane; c < C; c += 64) {
-          const float gc = gr[c];
-          if (gw) acc += x[(long long)i * ldx + c] * gc;
-          if (gx) gx[(long long)i * C + c] = wi * gc;
-        }
-        if (gw) {
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-          if (lane == 0) gws[off + i] += acc;
-        }
-      }
+      tot += acc;
     }
-    __syncthreads();
+    if (gw) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+      if (lane == 0) gw[r * S_all + j] = tot;
+    }
   }
-  if (gw)
-    for (int i = threadIdx.x; i < S_all; i += 256) gw[r * S_all + i] = gws[i];
 }
 
 static int int_segs(IntSegs& sg, int S_all, int nseg, const float* const* x, const int* ld, const int* C, const int* S, const int* off) {
@@ -391,7 +379,11 @@ extern "C" int ndjir_render_integrate_many(int R, int S_all, const float* w, int
     if (!out[k]) return NDJIR_ERR_ARG;
     sg.out[k] = out[k];
   }
-  hipLaunchKernelGGL(k_integrate_many, dim3(R), dim3(256), 0, stream, S_all, w, sg);
+  int cmax = 1;
+  for (int k = 0; k < nseg; ++k) cmax = C[k] > cmax ? C[k] : cmax;
+  int ny = (cmax + 63) / 64;
+  if (ny > 8) ny = 8;
+  hipLaunchKernelGGL(k_integrate_many, dim3(R, ny), dim3(256), 0, stream, S_all, w, sg);
   return ndjir_check_launch();
 }
 
@@ -400,12 +392,17 @@ extern "C" int ndjir_render_integrate_many_backward(int R, int S_all, const floa
                                                     float* const* gx, float* gw, hipStream_t stream) {
   if (R <= 0) return NDJIR_OK;
   IntSegs sg;
-  if (!w || !g || !gx || S_all > RD_SLOTS || int_segs(sg, S_all, nseg, x, ld, C, S, off) != NDJIR_OK) return NDJIR_ERR_ARG;
+  if (!w || !g || !gx || int_segs(sg, S_all, nseg, x, ld, C, S, off) != NDJIR_OK) return NDJIR_ERR_ARG;
   for (int k = 0; k < nseg; ++k) {
     sg.g[k] = g[k];
     sg.out[k] = gx[k];
   }
-  hipLaunchKernelGGL(k_integrate_many_bwd, dim3(R), dim3(256), 0, stream, S_all, w, sg, gw);
+  // enough workgroups for a bandwidth-bound pass (the feature segment alone writes R x S x 256 floats): ~4096 in all
+  int ny = (4096 + R - 1) / R;
+  const int ny_max = (S_all + 3) / 4;
+  if (ny > ny_max) ny = ny_max;
+  if (ny < 1) ny = 1;
+  hipLaunchKernelGGL(k_integrate_many_bwd, dim3(R, ny), dim3(256), 0, stream, S_all, w, sg, gw);
   return ndjir_check_launch();
 }
 

@@ -39,6 +39,19 @@ def _enc_call(fam, name, P, C, *args):
     lib.call(f"{fam.prefix}_{name}", P * C, *args)
 
 
+_ONES = {}
+
+
+def _ones(P, dev):
+    """(P, 1) of ones: the seed d(sdf) = 1 of the sdf chain (constant, kept per size)"""
+    t = _ONES.get((P, dev))
+    if t is None:
+        if len(_ONES) > 16:
+            _ONES.clear()
+        t = _ONES[(P, dev)] = torch.ones((P, 1), device=dev, dtype=torch.float32)
+    return t
+
+
 def _flops(P, Ks, Ns):
     return 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
 
@@ -104,7 +117,7 @@ class GeometricMain(Function):
                 shape=f"{P}:geo {K0}-" + "-".join(map(str, Ns)))
 
         # ---- sdf chain: backward chain seeded with d(sdf) = 1, first step = column 0 of the last layer ----
-        ones = torch.ones((P, 1), device=dev, dtype=torch.float32)
+        ones = _ones(P, dev)
         s = [None] * L                                     # s[j] = d sdf / d z_j, j < L-1
         s_store = [None] * L
         Wp, bK, bN, side_in, side_out, ld, side_am = [], [], [], [], [], [], []

@@ -53,6 +53,8 @@ SIGS = {
     "render_integrate_many_backward": "iipiPAAAAPPp",
     "render_material_head": "ii" + "p" * 7 + "iiiffff" + "ppp",
     "render_material_head_backward": "ii" + "p" * 7 + "iiiffff" + "pp" + "p" * 6,
+    "render_pixel_normal": "ifpp",
+    "render_pixel_normal_backward": "ifppp",
     "render_pixel_compose": "iiippppp",
     "render_pixel_compose_backward": "iiippppppp" + "p",
     # R N color gt mask grad_x tv0 D0 tv1 D1 prior mask_sum inv_rays weights[5] l2 workspace terms

@@ -23,7 +23,7 @@ from .network import (background_network, base_color_network, material_nets_raw,
                       soft_visibility_light_network, specular_reflectance_network)
 from .sampler import sample_importance_directions, sample_points, sample_uniform_directions
 from .specular_brdf import dot, specular_brdf_model
-from .volume import (alpha_weights, diffuse_light, integrate, integrate_many, material_head, pixel_compose,
+from .volume import (alpha_weights, diffuse_light, integrate, integrate_many, material_head, pixel_compose, pixel_normal,
                      specular_light_filament)
 
 
@@ -116,7 +116,7 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
                 and not sr.fixme and sr.channels == 3)
     G = conf.geometric_network.voxel.grid_size
     rad = conf.renderer.bounding_sphere_radius
-    x_fg_ptb = x_fg + rand["noise"] * (math.sqrt(3) * 2 * rad / G)
+    x_fg_ptb = torch.add(x_fg, rand["noise"], alpha=math.sqrt(3) * 2 * rad / G)
     prior_partials = None
     bg_pixel = None
     if use_head:
@@ -160,8 +160,11 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
         grad_vr, x_vr, feat_vr = VR(grad_x_fg), VR(x_fg), VR(feature_x_fg)
 
     # Normal (renderer.py:90-91)
-    grad_pixel = grad_vr + eps_normal
-    normal_pixel = grad_pixel / torch.sqrt((grad_pixel * grad_pixel).sum(-1, keepdim=True))
+    if grad_vr.is_cuda and not os.environ.get("NDJIR_NO_FUSED_TAIL"):
+        normal_pixel = pixel_normal(grad_vr, eps_normal)
+    else:
+        grad_pixel = grad_vr + eps_normal
+        normal_pixel = grad_pixel / torch.sqrt((grad_pixel * grad_pixel).sum(-1, keepdim=True))
     x_fg_pixel = x_vr.reshape(B, R, 1, 3)
     feature_pixel = feat_vr.reshape(B, R, 1, D)
     normal_bc = normal_pixel[:, :, None, :]
