@@ -117,11 +117,11 @@ def chain_workspace(device, bgrads):
 
 
 def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, keep_hidden=False, row_bias=None,
-                  row_bias_div=1, K0=None):
+                  row_bias_div=1, K0=None, out=None):
     """x (P, ld) contiguous; the net reads its first K0 columns (default: all).  Returns y (P, N_last), the list of stored activations A_1..A_{L-1} (inputs of layers
     1..L-1) when keep_hidden, and their recorded maxima (slot j <-> A_j, slot 0 = x; None unless keep_hidden).
     row_bias (P / row_bias_div, N_0): added to the first layer's pre-activation of each group of row_bias_div
-    consecutive rows."""
+    consecutive rows.  out = (tensor or pointer wrapper, row stride): where y goes instead of a fresh (P, N_last) tensor."""
     P, ldx = x.shape
     K0 = ldx if K0 is None else int(K0)
     L = len(weights)
@@ -135,7 +135,10 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
         kin = W.shape[1] + (K0 if j == skip_layer else 0)
         if keep_hidden and j < L - 1:
             hidden.append(torch.empty((P, kin), device=x.device, dtype=torch.float32))
-    y = torch.empty((P, Ns[-1]), device=x.device, dtype=torch.float32)
+    if out is None:
+        y, ldy = torch.empty((P, Ns[-1]), device=x.device, dtype=torch.float32), Ns[-1]
+    else:
+        y, ldy = out
     side_out = (hidden + [None]) if keep_hidden else [None] * L
     ld_side = [h.shape[1] if h is not None else 0 for h in side_out]
     flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
@@ -144,13 +147,13 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
     side_am = [_slot(am, j + 1) if (keep_hidden and j < L - 1) else None for j in range(L)]
     if row_bias is None:
         _launch("chain_fwd", flops, "mlp_chain", 0, P, x, ldx, K0, L, Wp, bl,
-                Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
+                Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, ldy, 0, 1, float(beta),
                 int(skip_layer), float(skip_scale), 0, None, 0, None, None, side_am, _slot(am, 0),
                 shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
     else:
         assert P % row_bias_div == 0 and tuple(row_bias.shape) == (P // row_bias_div, Ns[0])
         _launch("chain_fwd", flops, "mlp_chain_ex", 0, P, x, ldx, K0, L, Wp, bl,
-                Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, Ns[-1], 0, 1, float(beta),
+                Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, ldy, 0, 1, float(beta),
                 int(skip_layer), float(skip_scale), 0, None, 0, [None] * L, [None] * L, [None] * L,
                 row_bias.detach().contiguous(), int(row_bias_div), None, None, side_am, _slot(am, 0),
                 shape=f"{P}:{K0}(+rows/{row_bias_div})-" + "-".join(map(str, Ns)))
@@ -199,6 +202,32 @@ def colsum(X, out=None, accum=False):
     return out
 
 
+_ZCOL = {}
+
+
+def _zeros_col(P, dev):
+    t = _ZCOL.get((P, dev))
+    if t is None:
+        if len(_ZCOL) > 16:
+            _ZCOL.clear()
+        t = _ZCOL[(P, dev)] = torch.zeros((P, 1), device=dev, dtype=torch.float32)
+    return t
+
+
+class _ColumnPtr:
+    """Raw pointer to column c of a row-major GPU matrix."""
+    is_cuda, dtype = True, torch.float32
+
+    def __init__(self, t, c):
+        self.t, self.c = t, c
+
+    def is_contiguous(self):
+        return True
+
+    def data_ptr(self):
+        return self.t.data_ptr() + 4 * self.c
+
+
 class _Strided:
     """Lets lib.call pass a row-strided 2-D view (column stride 1) as a raw pointer."""
     is_cuda, dtype = True, torch.float32
@@ -216,18 +245,33 @@ class _Strided:
 
 class FusedMLP(Function):
     @staticmethod
-    def forward(ctx, x, row_bias, row_bias_div, beta, skip_layer, skip_scale, *params):
+    def forward(ctx, x, row_bias, row_bias_div, beta, skip_layer, skip_scale, pack, *params):
         L = len(params) // 2
         weights, biases = list(params[:L]), list(params[L:])
         x2 = x.detach().reshape(-1, x.shape[-1]).contiguous()
         train = any(ctx.needs_input_grad)
         rb = None if row_bias is None else row_bias.detach().reshape(-1, row_bias.shape[-1])
+        out = Zp = None
+        if pack is not None:
+            # output y = [y_0 | y_1 ...] placed inside Zp = [pack (c columns) | y_1 ... | spare] (the packed sample inputs of
+            # ndjir_amd/geometric.py): y starts at column c - 1, then `pack` overwrites y_0
+            pk = pack.detach().reshape(x2.shape[0], -1).contiguous()
+            c = pk.shape[1]
+            No = weights[-1].shape[1]
+            ldz = (c + No - 1 + 3 + 1 + 3) // 4 * 4
+            Zp = torch.empty((x2.shape[0], ldz), device=x2.device, dtype=torch.float32)
+            out = (_Strided(Zp.view(-1)[c - 1:]), ldz)
         y, hidden, am = chain_forward(x2, weights, biases, beta, skip_layer, skip_scale,
-                                      keep_hidden=train, row_bias=rb, row_bias_div=row_bias_div)
+                                      keep_hidden=train, row_bias=rb, row_bias_div=row_bias_div, out=out)
         if train:
             ctx.save_for_backward(x2, *hidden, *weights, am)
             ctx.cfg = (beta, skip_layer, skip_scale, L, tuple(x.shape))
             ctx.rb = (None if row_bias is None else tuple(row_bias.shape), int(row_bias_div))
+        ctx.pack = None
+        if pack is not None:
+            lib.call("copy_columns", pk.shape[0], c, pk, c, Zp, ldz)
+            ctx.pack = (c, ldz, No)
+            return Zp.view(x.shape[:-1] + (ldz,))
         return y.view(x.shape[:-1] + (y.shape[-1],))
 
     @staticmethod
@@ -241,8 +285,17 @@ class FusedMLP(Function):
         am = saved[2 * L]                    # recorded maxima of A[j]
         P, K0 = x2.shape
         need_x = ctx.needs_input_grad[0]
-        need_w = any(ctx.needs_input_grad[6:6 + L])
-        gy2 = gy.reshape(P, -1).contiguous()
+        need_w = any(ctx.needs_input_grad[7:7 + L])
+        if ctx.pack is not None:
+            # gradient of the packed output: columns c .. c + No - 2 belong to y_1 ..; y_0 was overwritten (no gradient)
+            c, ldz, No = ctx.pack
+            g = gy.reshape(P, ldz)
+            if not g.is_contiguous():
+                g = g.contiguous()
+            lib.call("copy_columns", P, 1, _zeros_col(P, g.device), 1, _ColumnPtr(g, c - 1), ldz)
+            gy2 = g[:, c - 1:c - 1 + No]
+        else:
+            gy2 = gy.reshape(P, -1).contiguous()
         # backward chain: step i applies W_{L-1-i}^T
         steps = L if need_x else L - 1
         deltas = [None] * L                  # deltas[j] = dL/dz_j
@@ -296,10 +349,10 @@ class FusedMLP(Function):
                     ldg = (K0 + 3) // 4 * 4
                     gx = torch.empty((P, ldg), device=x2.device, dtype=torch.float32)[:, :K0]
             flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
-            if need_w and ctx.needs_input_grad[6 + 2 * L - 1]:
+            if need_w and ctx.needs_input_grad[7 + 2 * L - 1]:
                 # bias gradient of the output layer = column sums of dL/dY: accumulated by the chain's input load
                 gb_last = torch.empty((gy2.shape[1],), device=x2.device, dtype=torch.float32)
-            _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
+            _launch("chain_bwd", flops, "mlp_chain", 1, P, _Strided(gy2), gy2.stride(0), gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
                      side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
                      1 if bwd_skip >= 0 else 0, 1 if need_x else 0,
                      float(beta), int(bwd_skip), float(skip_scale), int(split),
@@ -309,9 +362,9 @@ class FusedMLP(Function):
         gb = [None] * L
         if need_w:
             for j in range(L):
-                if ctx.needs_input_grad[6 + j]:
+                if ctx.needs_input_grad[7 + j]:
                     gW[j] = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
-                if ctx.needs_input_grad[6 + L + j]:
+                if ctx.needs_input_grad[7 + L + j]:
                     gb[j] = bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))
         g_rb = None
         rb_shape, rb_div = ctx.rb
@@ -322,15 +375,16 @@ class FusedMLP(Function):
             g_rb = torch.empty((G, d0.shape[1]), device=d0.device, dtype=torch.float32)
             lib.call("mlp_group_colsum", _Strided(d0), d0.stride(0), d0.shape[1], G, rb_div, g_rb)
             g_rb = g_rb.view(rb_shape)
-        return (gx.reshape(xshape) if gx is not None else None, g_rb, None, None, None, None, *gW, *gb)
+        return (gx.reshape(xshape) if gx is not None else None, g_rb, None, None, None, None, None, *gW, *gb)
 
 
-def fused_mlp(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, row_bias=None, row_bias_div=1):
+def fused_mlp(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, row_bias=None, row_bias_div=1, pack=None):
     """x (..., K0); weights[j] (K_j, N_j); biases[j] (N_j,) or None.  softplus(beta) hidden activations,
     linear output; optional IDR-style skip: output of `skip_layer` is scaled by `skip_scale` and the
     scaled input is appended (python/network.py:221-224).  row_bias (..., N_0): term added to the first
-    layer's pre-activation, constant over each group of `row_bias_div` consecutive rows of x."""
-    return FusedMLP.apply(x, row_bias, row_bias_div, beta, skip_layer, skip_scale, *weights, *biases)
+    layer's pre-activation, constant over each group of `row_bias_div` consecutive rows of x.
+    pack (..., c): the result is the packed tensor Zp (..., ld) = [pack | y[..., 1:] | spare] instead of y (see FusedMLP)."""
+    return FusedMLP.apply(x, row_bias, row_bias_div, beta, skip_layer, skip_scale, pack, *weights, *biases)
 
 
 class MultiMLP(Function):

@@ -81,11 +81,12 @@ def affine(h, D, use_wn=False, w_init=None, b_init=None, name=None):
     return linear(h, W, b)
 
 
-def _run_mlp(h, Ws, bs, act, skip_layer=-1, skip_scale=1.0, inputs=None):
+def _run_mlp(h, Ws, bs, act, skip_layer=-1, skip_scale=1.0, inputs=None, pack=None):
     """softplus-MLP on the last axis: fused chain kernel, or layer by layer."""
     if USE_FUSED and act is softplus:
         from .mlp import fused_mlp
-        return fused_mlp(h, Ws, bs, 100.0, skip_layer, skip_scale)
+        return fused_mlp(h, Ws, bs, 100.0, skip_layer, skip_scale, pack=pack)
+    assert pack is None
     from .mlp import linear
     for j, (W, b) in enumerate(zip(Ws, bs)):
         h = linear(h, W, b)          # own one-layer kernels (no library GEMM), see ndjir_amd/mlp.py
@@ -230,14 +231,16 @@ def _geometric_param_lists(conf):
     return Ws, bs, skip_at, scale
 
 
-def geometric_network(x, conf, first_order_only=False, sdf_only=False):
+def geometric_network(x, conf, first_order_only=False, sdf_only=False, packed=False):
     """network.py:154-232.  x (..., 3) -> sdf (..., 1), feature (..., 256), gain (1,).
 
     `first_order_only`: the caller will differentiate the outputs at most once w.r.t. the
     parameters (sampler rounds, base-colour perturbation pass); the whole net then runs as one
     fused MFMA chain.  The main pass of pb_render goes through `nn.grad` (second-order terms) and
     runs layer by layer.  `sdf_only` (sampler) skips the 256 feature columns of the last layer --
-    the reference computes and discards them (sampler.py:193)."""
+    the reference computes and discards them (sampler.py:193).
+    `packed` (with first_order_only, fused path): a fourth result Zp (..., ld) = [x | feature | spare], the packed input of the
+    nets that read cat(x, feature) (feature is then a view of it and the sdf is not returned); None when not available."""
     with P.parameter_scope("geometric-network"):
         g = conf.geometric_network
         D, L, M = g.feature_size, g.layers, g.pe_bands
@@ -298,8 +301,13 @@ def geometric_network(x, conf, first_order_only=False, sdf_only=False):
             if sdf_only:
                 Ws = Ws[:-1] + [_sdf_column(Ws[-1])]
                 bs = bs[:-1] + [_sdf_column(bs[-1])]
+            Zp = None
             if first_order_only and USE_FUSED and act is softplus:
-                h = _run_mlp(inputs, Ws, bs, act, skip_at, scale)
+                if packed and not sdf_only and x.is_cuda and not os.environ.get("NDJIR_NO_PACKED_INPUT"):
+                    Zp = _run_mlp(inputs, Ws, bs, act, skip_at, scale, pack=x)
+                    h = None
+                else:
+                    h = _run_mlp(inputs, Ws, bs, act, skip_at, scale)
             else:
                 from .mlp import linear
                 for l in range(L):
@@ -308,10 +316,15 @@ def geometric_network(x, conf, first_order_only=False, sdf_only=False):
                         h = act(h)
                         if l == skip_at:
                             h = torch.cat([h, inputs], dim=-1) * scale
-        sdf, feature = h[..., 0:1], h[..., 1:]
+        if g.geometric_init and Zp is not None:
+            sdf, feature = None, Zp[..., x.shape[-1]:x.shape[-1] + D]
+        else:
+            sdf, feature = h[..., 0:1], h[..., 1:]
         gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain]), True)
         # (the sampler's and the perturbation pass's callers ignore the gain: three launches saved per call)
         gain = None if (sdf_only or first_order_only) else torch.exp(gain * 10).clamp(1e-6, 5e4)
+    if packed:
+        return sdf, feature, gain, (Zp if g.geometric_init else None)
     return sdf, feature, gain
 
 
@@ -437,11 +450,18 @@ class _ColumnView:
         return self.t.data_ptr() + 4 * self.c
 
 
-def base_color_network(x, feature, normal, conf, raw=False):
-    """network.py:235-263.  raw=True: the net's output before the sigmoid (for volume.material_head)."""
+def base_color_network(x, feature, normal, conf, raw=False, packed=None):
+    """network.py:235-263.  raw=True: the net's output before the sigmoid (for volume.material_head).
+    packed: a tensor whose leading columns are cat(x, feature[, normal]) (geometric_network(packed=True)): read in place."""
     with P.parameter_scope("base-color-network"):
         c = conf.base_color_network
-        h = _mlp(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, 3, _act(c.act), conf.use_wn)
+        if (packed is not None and USE_FUSED and c.act == "softplus" and not conf.use_wn and c.use_geometric_feature
+                and (normal is not None or not c.use_normal)):
+            from .mlp import multi_mlp
+            Din = x.shape[-1] + feature.shape[-1] + (normal.shape[-1] if c.use_normal else 0)
+            h = multi_mlp(packed, [_mlp_params(Din, c.feature_size, c.layers, 3, conf.use_wn)], widths=[Din], lazy_pad=True)[0]
+        else:
+            h = _mlp(_cat_inputs(x, feature, normal, c), c.feature_size, c.layers, 3, _act(c.act), conf.use_wn)
         return h if raw else torch.sigmoid(h)
 
 

@@ -116,7 +116,9 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
                 and not sr.fixme and sr.channels == 3)
     G = conf.geometric_network.voxel.grid_size
     rad = conf.renderer.bounding_sphere_radius
-    x_fg_ptb = torch.add(x_fg, rand["noise"], alpha=math.sqrt(3) * 2 * rad / G)
+    # (detached: the sample positions carry no parameter gradient, python/sampler.py -- the perturbed pass is first-order in
+    # the parameters only, so its encoding and grid query need no d/dx)
+    x_fg_ptb = torch.add(x_fg.detach(), rand["noise"], alpha=math.sqrt(3) * 2 * rad / G)
     prior_partials = None
     bg_pixel = None
     if use_head:
@@ -138,8 +140,8 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
             # perturbation branch there (it feeds the prior term of the loss, python/loss.py:108-115)
             raw_ptb = raw_bc
         else:
-            _, feature_ptb, _ = geometric_network(x_fg_ptb, conf, first_order_only=True)
-            raw_ptb = base_color_network(x_fg_ptb, feature_ptb, None, conf, raw=True)
+            _, feature_ptb, _, packed_ptb = geometric_network(x_fg_ptb, conf, first_order_only=True, packed=True)
+            raw_ptb = base_color_network(x_fg_ptb, feature_ptb, None, conf, raw=True, packed=packed_ptb)
         remap = conf.specular_brdf.model == "filament" and conf.specular_brdf.remap
         V, aux, prior_partials = material_head(
             raw_bc, raw_ptb, raw_imp, raw_photo, photo_gain, raw_rough, raw_spec, remap, conf.diffuse_brdf.entangle,
