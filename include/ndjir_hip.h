@@ -94,6 +94,12 @@ int ndjir_voxel_feature_check_touched(int N, const float* grad_feature, const fl
 int ndjir_voxel_feature_pack_rows(int N, const float* grad_feature, const float* query, const int* grid_sizes, int D,
                                   const float* min, const float* max, unsigned* bitmap, int* ids, float* rows, int* count,
                                   int capacity, hipStream_t stream);
+/* Tuning switch of the tri-plane scatters (grad_feature, grad_query_grad_feature): from `points` query points on they bin the
+ * (point, plane) pairs by tile and accumulate each tile in LDS (default 2^18; < 0 restores it).  Results do not depend on it
+ * beyond fp32 summation order. */
+void ndjir_grid_set_scatter_bins_from(long long points);
+long long ndjir_grid_get_scatter_bins_from(void);
+
 /* topo 0 dense voxel (grid_sizes[3]) / 1 tri-plane / 2 tri-line (grid_sizes[0] = G); interp 0 linear / 1 cosine / 2 Lanczos */
 int ndjir_grid_pack_rows(int topo, int interp, int N, const float* grad_feature, const float* query, const int* grid_sizes, int D,
                          const float* min, const float* max, unsigned* bitmap, int* ids, float* rows, int* count, int capacity,

@@ -788,7 +788,7 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
       // a tensor whose producer did not record its maximum: one streaming pass over it (the slots live behind the
       // partial sums; pick_splits' upper bound sized the workspace)
       unsigned* slots = reinterpret_cast<unsigned*>(workspace + wgrad_workspace(K, N, P) - 4);
-      if (hipMemsetAsync(slots, 0, 2 * sizeof(unsigned), stream) != hipSuccess) return NDJIR_ERR_LAUNCH;
+      zero_fill(reinterpret_cast<float*>(slots), 2, stream);      // (a kernel: memset nodes misbehaved inside captured graphs, see csrc/grid.hip)
       long long nb = (P * (K > N ? K : N) + 256 * 16 - 1) / (256 * 16);     // ~16 elements per thread
       if (nb > 2048) nb = 2048;
       if (nb < 1) nb = 1;

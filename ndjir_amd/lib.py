@@ -155,6 +155,9 @@ def load():
         _lib.ndjir_mlp_chain_workspace.argtypes = [ctypes.c_int]
         _lib.ndjir_mlp_colsum_workspace.restype = ctypes.c_longlong
         _lib.ndjir_mlp_colsum_workspace.argtypes = [ctypes.c_int, ctypes.c_longlong]
+        _lib.ndjir_grid_set_scatter_bins_from.restype = None
+        _lib.ndjir_grid_set_scatter_bins_from.argtypes = [ctypes.c_longlong]
+        _lib.ndjir_grid_get_scatter_bins_from.restype = ctypes.c_longlong
     return _lib
 
 
@@ -249,7 +252,8 @@ def symbols():
                                             "ndjir_hash_table_size", "ndjir_hash_num_params",
                                             "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_colsum_workspace",
                                             "ndjir_mlp_chain_workspace", "ndjir_mlp_set_math", "ndjir_mlp_get_math",
-                                            "ndjir_mlp_debug_timeline", "ndjir_loss_terms_workspace"]
+                                            "ndjir_mlp_debug_timeline", "ndjir_loss_terms_workspace", "ndjir_grid_set_scatter_bins_from",
+                                            "ndjir_grid_get_scatter_bins_from"]
 
 
 def hash_num_params(G0, growth_factor, T0, L, D):

@@ -99,6 +99,31 @@ def test_hash_scatter_through_lds_table(gpu, family, P, hash_cfg):
     _family_check(gpu, family, P, None, hash_cfg, fine=True)
 
 
+@pytest.mark.parametrize("family,P,G,D", [("triplane", 20000, 256, 8), ("triplane", 30000, 200, 4), ("cosine_triplane", 20000, 128, 8),
+                                          ("lanczos_triplane", 17000, 96, 4)])
+def test_triplane_scatter_binned_by_tiles(gpu, family, P, G, D, binned_scatter):
+    """grad_feature / grad_query_grad_feature of the tri-plane families at point counts where the scatter bins the (point, plane)
+    pairs by tile and accumulates each tile in LDS (csrc/grid.hip k_plane_scatter_tiles); several tiles per axis, queries
+    beyond the box (clamped to border cells)."""
+    _family_check(gpu, family, P, G, None, D=D, fine=True)      # (G >= 96: the tolerance class of the fine hash levels)
+
+
+def test_triplane_scatter_binned_heavy_tile(gpu, binned_scatter):
+    """Every point in one cell (what clamped out-of-box samples do to a border tile): the tile is split over several workgroups;
+    the result equals the sum formed in float64."""
+    from ndjir_amd.grid_feature import _core
+    P, G, D = 3 * 4096 + 777, 128, 8
+    q = torch.full((P, 3), 0.3, device=gpu) + torch.rand(P, 3, device=gpu) * 1e-4
+    og = torch.randn(P, 3 * D, device=gpu)
+    f = torch.zeros(3, G, G, D, device=gpu, requires_grad=True)
+    gf = _core.grad_feature("triplane", og, q, f)
+    # reference: per plane, the four corner weights of each point times its output gradient (float64)
+    o = K.GridOracle("triplane")
+    ref = o.grad_feature(og.cpu().numpy(), q.cpu().numpy(), (3, G, G, D))
+    scale = float(np.abs(ref).max())
+    np.testing.assert_allclose(gf.detach().cpu().numpy(), ref, atol=2e-5 * scale)
+
+
 def _hip_family(family):
     from ndjir_amd.grid_feature import _core
     return _core
