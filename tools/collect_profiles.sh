@@ -31,6 +31,22 @@ for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_
   python tools/pmc_table.py "$f" "k_wgrad" >> $O/pmc_mfma_bench.txt
   rm -rf $O/pmc_m
 done
+# 5) the grid-feature micro-benchmark (the reference authors' shape: 2^19 points) with FETCH_SIZE / WRITE_SIZE per launch
+{
+  echo "# python tools/grid_bench.py 10   (1x MI355X; the reference authors' micro-benchmark shape, scripts/bench_voxel_hash.py / bench_lanczos_voxel.py: P = 2^19 points)"
+  python tools/grid_bench.py 10 2> $O/grid_bench_err.txt
+  echo
+  echo "# HBM traffic of the same launches: rocprofv3 --pmc FETCH_SIZE -- python3 tools/grid_bench.py 2 ; rocprofv3 --pmc WRITE_SIZE -- python3 tools/grid_bench.py 2 (separate passes)"
+  echo "# mean per launch over the uniform and the ray-coherent point sets, KB (FETCH_SIZE uncorrected: these are 16-byte gathers, not wide streaming reads)"
+  echo "# kernel template arguments: <topology 0 voxel / 1 triplane / 2 triline / 3 hash, interpolation 0 linear / 2 lanczos, ...>"
+} > $O/grid_bench.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $O/pmc_g -o run --output-format csv -- python3 tools/grid_bench.py 2 > /dev/null 2> $O/pmc_grid_err.txt
+  f=$(find $O/pmc_g -name "*counter_collection.csv" | head -1)
+  echo "## $c" >> $O/grid_bench.txt
+  python tools/pmc_table.py "$f" ndjir >> $O/grid_bench.txt
+  rm -rf $O/pmc_g
+done
 python bench.py > $O/bench_default.json 2> $O/bench_default_err.txt
 bash tools/chain_shapes.sh f16x3 bf16x6 > $O/chain_shapes.txt 2>&1
 tail -c 600 $O/bench_default.json
