@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode,variant", [("eager", "default"), ("graph", "default"), ("eager", "custom"), ("eager", "triplaneline")])
+@pytest.mark.parametrize("mode,variant", [("eager", "default"), ("graph", "default"), ("eager", "custom"), ("eager", "triplaneline"),
+                                          ("graph", "triplaneline")])
 def test_two_ranks_equal_one_process(gpu, mode, variant):
     """variant: default (linear voxel, D = 4), custom (Lanczos voxel: 4 x 4 x 4 taps), triplaneline (tri-plane + tri-line,
     D = 8): every grid gradient goes through the sparse row exchange -- no all-reduce larger than the MLP bucket."""
