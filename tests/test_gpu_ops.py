@@ -508,3 +508,74 @@ def test_grid_pack_rows_lists_every_nonzero_row_once(gpu, family, D):
     assert float(recv.abs().max()) == 0.0
     lib.call("sparse_rows_zero", ids_all, torch.zeros_like(counts), 2, cap, lim_dev, 0, ids, count, gf, D)      # own list only
     assert float(gf.abs().max()) == 0.0
+
+
+def test_geometric_glue_kernels(gpu):
+    """csrc/geo.hip against their torch spelling: the chain input encoding, the normal from the sdf chain's input gradient
+    (with the packed sample inputs Z), the backward begin, g-bar_0, column copies and the inverse squared distance."""
+    from ndjir_amd import lib
+    from ndjir_amd.mlp import _Strided
+    from ndjir_amd.network import _ColumnView
+    gen = torch.Generator(device=gpu).manual_seed(3)
+    P, M, C0, C1, D = 1000, 6, 4, 5, 16
+    r = lambda *s: torch.randn(*s, device=gpu, generator=gen)
+    x, f0, f1 = r(P, 3) * 0.7, r(P, C0), r(P, C1)
+    K0 = 3 + 6 * M + C0 + C1
+    e = torch.empty(P, K0, device=gpu)
+    lib.call("geo_encode", P, M, x, 2, [f0, f1], [C0, C1], e, K0)
+    bands = 2.0 ** torch.arange(M, device=gpu)
+    xb = x.unsqueeze(-1) * bands
+    want = torch.cat([x, torch.cos(xb).reshape(P, -1), torch.sin(xb).reshape(P, -1), f0, f1], dim=-1)
+    assert float((e - want).abs().max()) <= 2e-6
+
+    g0, gq0, gq1 = r(P, K0), r(P, 3), r(P, 3)
+    ldz = (3 + D + 3 + 1 + 3) // 4 * 4
+    Z = torch.full((P, ldz), 7.0, device=gpu)
+    y = r(P, 1 + D)
+    Z.view(-1)[2:].as_strided((P, 1 + D), (ldz, 1)).copy_(y)                 # where the forward chain stores [sdf | feature]
+    n, sdf = torch.empty(P, 3, device=gpu), torch.empty(P, 1, device=gpu)
+    lib.call("geo_normal", P, M, e, K0, g0, K0, 2, [gq0, gq1], n, Z, ldz, D, sdf)
+    cosb, sinb = e[:, 3:3 + 3 * M].reshape(P, 3, M), e[:, 3 + 3 * M:3 + 6 * M].reshape(P, 3, M)
+    gc, gs = g0[:, 3:3 + 3 * M].reshape(P, 3, M), g0[:, 3 + 3 * M:3 + 6 * M].reshape(P, 3, M)
+    n_want = g0[:, :3] + ((gs * cosb - gc * sinb) * bands).sum(-1) + gq0 + gq1
+    assert float((n - n_want).abs().max()) <= 1e-4 * float(n_want.abs().max())
+    assert torch.equal(sdf, y[:, :1]) and torch.equal(Z[:, :3], x) and torch.equal(Z[:, 3:3 + D], y[:, 1:])
+    assert torch.equal(Z[:, 3 + D:6 + D], n) and float(Z[:, 6 + D:].abs().max()) == 0.0
+
+    g_sdf, g_feat, g_n, gZ = r(P), r(P, D), r(P, 3), r(P, ldz)
+    gy, nbar = torch.empty(P, 1 + D, device=gpu), torch.empty(P, 3, device=gpu)
+    lib.call("geo_backward_begin", P, D, g_sdf, g_feat, D, g_n, gZ, ldz, gy, nbar)
+    assert torch.equal(gy[:, 0], g_sdf) and torch.equal(gy[:, 1:], g_feat + gZ[:, 3:3 + D]) and torch.equal(nbar, g_n + gZ[:, 3 + D:6 + D])
+    lib.call("geo_backward_begin", P, D, None, None, 0, None, gZ, ldz, gy, nbar)
+    assert float(gy[:, 0].abs().max()) == 0.0 and torch.equal(gy[:, 1:], gZ[:, 3:3 + D]) and torch.equal(nbar, gZ[:, 3 + D:6 + D])
+
+    gb0 = torch.empty(P, K0, device=gpu)
+    lib.call("geo_gbar0", P, M, e, K0, nbar, 2, [f0, f1], [C0, C1], gb0)
+    nb = nbar.unsqueeze(-1) * bands
+    want = torch.cat([nbar, (-sinb * nb).reshape(P, -1), (cosb * nb).reshape(P, -1), f0, f1], dim=-1)
+    assert float((gb0 - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+    dst = torch.zeros(P, 7, device=gpu)
+    lib.call("copy_columns", P, 5, _Strided(e[:, 2:]), K0, _ColumnView(dst, 1), 7)
+    assert torch.equal(dst[:, 1:6], e[:, 2:7]) and float(dst[:, 0].abs().max()) == 0.0 and float(dst[:, 6].abs().max()) == 0.0
+
+    B, rows = 2, P // 2
+    cam = r(B, 3)
+    out = torch.zeros(P, 4, device=gpu)
+    lib.call("inverse_squared_distance", P, rows, e, K0, cam, _ColumnView(out, 3), 4)
+    d = x.reshape(B, rows, 3) - cam[:, None, :]
+    want = (1.0 / (torch.sqrt((d * d).sum(-1)) ** 2 + 1e-5)).reshape(P)
+    assert float(((out[:, 3] - want) / want).abs().max()) <= 1e-5 and float(out[:, :3].abs().max()) == 0.0
+
+
+def test_pixel_normal_matches_composite(gpu):
+    from ndjir_amd.volume import pixel_normal
+    g64 = torch.randn(1, 300, 3, dtype=torch.float64, device=gpu, requires_grad=True)
+    eps = 1e-6
+    ref = (g64 + eps) / torch.sqrt(((g64 + eps) ** 2).sum(-1, keepdim=True))
+    g32 = g64.detach().float().requires_grad_(True)
+    out = pixel_normal(g32, eps)
+    assert float((out.double() - ref).abs().max()) <= 1e-6
+    w = torch.randn_like(ref)
+    (a,), (b,) = torch.autograd.grad(out, [g32], w.float()), torch.autograd.grad(ref, [g64], w)
+    assert float((a.double() - b).abs().max()) <= 1e-5 * float(b.abs().max())
