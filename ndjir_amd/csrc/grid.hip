@@ -500,6 +500,51 @@ __global__ void __launch_bounds__(256) k_scatter_hash_lds(long long P, float* __
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tri-line scatters through an LDS image of a whole line (G x D floats: 64 KB at G = 2048, D = 8), the 1-D case of the hash
+// path above: workgroup (s, k) owns line s for the points k, k + K, ..., adds their taps with LDS atomics and flushes the
+// line once.  Pays when the points outnumber the line's cells by far (the micro-benchmark's 2^19 points: 25 M global
+// atomics become 3 x K x 16384); the launcher keeps the aggregated path for a training step's 65 536 samples.
+// ------------------------------------------------------------------------------------------------
+template <int I, int MODE>
+__global__ void __launch_bounds__(256) k_scatter_line_lds(long long P, float* __restrict__ gf, const float* __restrict__ gg_query,
+                                                          const float* __restrict__ grad_output, const float* __restrict__ query,
+                                                          GridDesc g, int shares) {
+  constexpr int TOPO = TRILINE;
+  constexpr int ND = 1, NT = NTaps<I>::v;
+  extern __shared__ float hs_tab[];
+  const int share = blockIdx.x % shares, s = blockIdx.x / shares;
+  const int D = g.D, n_fl = g.G[0] * D;
+  for (int t = threadIdx.x; t < n_fl; t += 256) hs_tab[t] = 0.f;
+  __syncthreads();
+  for (long long b = (long long)share * 256 + threadIdx.x; b < P; b += (long long)shares * 256) {
+    float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
+    Stencil<TOPO, I> st;
+    make_stencil<TOPO, I>(st, g, s, q);
+    float ggs = 0.f;
+    if constexpr (MODE == 1) ggs = gg_query[b * 3 + st.axis[0]] * st.scale[0] * st.ax[0].gm;
+    float og[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) og[d] = d < D ? grad_output[out_index<TOPO>(g, P, b, s, d)] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const float w = (MODE == 0) ? st.ax[0].w[i] : ggs * st.ax[0].dw[i];
+      const int e = (int)st.ax[0].idx[i] * D;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) if (d < D) atomicAdd(&hs_tab[e + d], og[d] * w);
+    }
+  }
+  __syncthreads();
+  float* dst = gf + (long long)s * n_fl;
+  for (int t = threadIdx.x; t < n_fl; t += 256) {
+    const float v = hs_tab[t];
+    if (v != 0.f) {
+      if (shares == 1) dst[t] += v;
+      else atomicAdd(dst + t, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tri-plane scatters by tiles.  A plane (2048^2 x 8 floats = 134 MB) does not fit on chip and uniformly spread points do
 // not share cells, so the workgroup-aggregated scatter above removes nothing there: 96 global atomics per point at the
 // device-wide ~20 G atomics/s.  Here the (point, plane) pairs are first binned by the TS x TS-cell tiles their stencil
@@ -1126,6 +1171,31 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
   int taps = 1;
   for (int a = 0; a < nd; ++a) taps *= nt;
   const int per_point = taps * (g.D / 4);
+  if (g.topo == TRILINE && g.D <= 8 && g.G[0] * g.D <= HASH_LDS_FLOATS && P >= 64LL * g.G[0] && !no_agg) {
+    long long shares = 170;                                           // 3 lines x 170 = 510 workgroups
+    const long long max_shares = P / (8LL * g.G[0]);                  // >= 8 points per cell of the line and workgroup
+    if (shares > max_shares) shares = max_shares;
+    if (shares < 1) shares = 1;
+    const size_t lds = (size_t)g.G[0] * g.D * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      const int mx = HASH_LDS_FLOATS * (int)sizeof(float);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line_lds<LINEAR, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line_lds<LINEAR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line_lds<COSINE, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line_lds<COSINE, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line_lds<LANCZOS, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_line_lds<LANCZOS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+      attr = true;
+    }
+#define NDJIR_LINE_LDS(IV) { if (mode == 0) hipLaunchKernelGGL((k_scatter_line_lds<IV, 0>), dim3((unsigned)(3 * shares)), dim3(256), lds, stream, P, gf, gg_query, grad_output, query, g, (int)shares); \
+                            else hipLaunchKernelGGL((k_scatter_line_lds<IV, 1>), dim3((unsigned)(3 * shares)), dim3(256), lds, stream, P, gf, gg_query, grad_output, query, g, (int)shares); }
+    if (interp == LINEAR) NDJIR_LINE_LDS(LINEAR)
+    else if (interp == COSINE) NDJIR_LINE_LDS(COSINE)
+    else NDJIR_LINE_LDS(LANCZOS)
+#undef NDJIR_LINE_LDS
+    return ndjir_check_launch();
+  }
   static const bool no_bins = getenv("NDJIR_SCATTER_NO_BINS") != nullptr;    // A/B switch
   // Tile binning pays for large, spread point sets (2^19 uniform points on 3 x 2048^2 x 8: 2.5 -> 0.62 ms); the 65536
   // ray-coherent samples of a training step revisit cells, which the workgroup-aggregated path below merges without the

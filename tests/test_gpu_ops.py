@@ -108,6 +108,13 @@ def test_triplane_scatter_binned_by_tiles(gpu, family, P, G, D, binned_scatter):
     _family_check(gpu, family, P, G, None, D=D, fine=True)      # (G >= 96: the tolerance class of the fine hash levels)
 
 
+@pytest.mark.parametrize("family,P,G,D", [("triline", 20000, 128, 8), ("cosine_triline", 9000, 64, 8), ("lanczos_triline", 9000, 64, 4)])
+def test_triline_scatter_through_lds_image(gpu, family, P, G, D):
+    """grad_feature / grad_query_grad_feature of the tri-line families at point counts (>= 64 G) where a workgroup accumulates a
+    whole line in LDS (csrc/grid.hip k_scatter_line_lds)."""
+    _family_check(gpu, family, P, G, None, D=D, fine=True)
+
+
 def test_triplane_scatter_binned_heavy_tile(gpu, binned_scatter):
     """Every point in one cell (what clamped out-of-box samples do to a border tile): the tile is split over several workgroups;
     the result equals the sum formed in float64."""
