@@ -554,49 +554,59 @@ __global__ void __launch_bounds__(256) k_scatter_line_lds(long long P, float* __
 // exactly one owner, no global float atomic is left.  Tiles that hold more than BIN_CAP pairs (clamped out-of-box samples
 // pile up on border cells) are split over several workgroups, which then flush with atomics.
 // ------------------------------------------------------------------------------------------------
-constexpr int BIN_LDS_FLOATS = 32768;        // tile image: 128 KB
+constexpr int BIN_LDS_FLOATS = 32768;        // tile image: at most 128 KB
 constexpr int BIN_CAP = 4096;                // pairs per workgroup
-constexpr int BIN_MAX_TILES = 16384;
+constexpr int BIN_MAX_TILES = 32768;
 
+// TRIPLANE: pairs = (point, plane), square tiles of TS x TS cells of plane s;  VOXEL: pairs = points, cubes of TS^3 cells
 struct BinPlan {
-  int TS, tpa, ntiles;           // tile edge (cells), tiles per axis, 3 * tpa^2
+  int TS, ntiles;
+  int tpa[3];                    // tiles per axis (tri-plane: [0] = [1], [2] unused)
 };
 
-// the (up to 4) tiles a pair's stencil touches: tile ids in t[], returns their number
-template <int I>
-__device__ __forceinline__ int plane_tiles(const GridDesc& g, const BinPlan& bp, int s, const float* q, int* t) {
-  constexpr int NT = NTaps<I>::v;
-  Stencil<TRIPLANE, I> st;
-  make_stencil<TRIPLANE, I>(st, g, s, q);
-  const int a0 = (int)(st.ax[0].idx[0] / (unsigned)bp.TS), a1 = (int)(st.ax[0].idx[NT - 1] / (unsigned)bp.TS);
-  const int b0 = (int)(st.ax[1].idx[0] / (unsigned)bp.TS), b1 = (int)(st.ax[1].idx[NT - 1] / (unsigned)bp.TS);
+template <int TOPO> struct BinDims { static constexpr int subs = (TOPO == TRIPLANE) ? 3 : 1, nd = (TOPO == TRIPLANE) ? 2 : 3; };
+
+// the (up to 2^nd) tiles a pair's stencil touches: tile ids in t[], returns their number
+template <int TOPO, int I>
+__device__ __forceinline__ int bin_tiles(const GridDesc& g, const BinPlan& bp, int s, const float* q, int* t) {
+  constexpr int NT = NTaps<I>::v, ND = BinDims<TOPO>::nd;
+  Stencil<TOPO, I> st;
+  make_stencil<TOPO, I>(st, g, s, q);
+  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < ND; ++a) {
+    lo[a] = (int)(st.ax[a].idx[0] / (unsigned)bp.TS);
+    hi[a] = (int)(st.ax[a].idx[NT - 1] / (unsigned)bp.TS);
+  }
   int n = 0;
-  t[n++] = (s * bp.tpa + a0) * bp.tpa + b0;
-  if (b1 != b0) t[n++] = (s * bp.tpa + a0) * bp.tpa + b1;
-  if (a1 != a0) {
-    t[n++] = (s * bp.tpa + a1) * bp.tpa + b0;
-    if (b1 != b0) t[n++] = (s * bp.tpa + a1) * bp.tpa + b1;
+  if constexpr (TOPO == TRIPLANE) {
+    for (int a = lo[0]; a <= hi[0]; ++a)
+      for (int b = lo[1]; b <= hi[1]; ++b) t[n++] = (s * bp.tpa[0] + a) * bp.tpa[1] + b;
+  } else {
+    for (int a = lo[0]; a <= hi[0]; ++a)
+      for (int b = lo[1]; b <= hi[1]; ++b)
+        for (int c = lo[2]; c <= hi[2]; ++c) t[n++] = (a * bp.tpa[1] + b) * bp.tpa[2] + c;
   }
   return n;
 }
 
-template <int I>
-__global__ void __launch_bounds__(256) k_plane_bin_count(long long P, const float* __restrict__ query, GridDesc g, BinPlan bp,
-                                                         int* __restrict__ count) {
-  const long long total = P * 3;
+template <int TOPO, int I>
+__global__ void __launch_bounds__(256) k_bin_count(long long P, const float* __restrict__ query, GridDesc g, BinPlan bp,
+                                                   int* __restrict__ count) {
+  const long long total = P * BinDims<TOPO>::subs;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
     const int s = (int)(t / P);
     const long long b = t - (long long)s * P;
     const float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
-    int tl[4];
-    const int n = plane_tiles<I>(g, bp, s, q, tl);
+    int tl[8];
+    const int n = bin_tiles<TOPO, I>(g, bp, s, q, tl);
     for (int k = 0; k < n; ++k) atomicAdd(count + tl[k], 1);
   }
 }
 
 // start[t] = exclusive prefix of count; work items (tile, part) for every BIN_CAP pairs of a tile; fill[] = 0; *nwork
-__global__ void __launch_bounds__(1024) k_plane_bin_scan(int ntiles, const int* __restrict__ count, int* __restrict__ start,
-                                                         int* __restrict__ fill, int* __restrict__ work, int* __restrict__ nwork) {
+__global__ void __launch_bounds__(1024) k_bin_scan(int ntiles, const int* __restrict__ count, int* __restrict__ start,
+                                                   int* __restrict__ fill, int* __restrict__ work, int* __restrict__ nwork) {
   __shared__ int sh[2][1024];
   const int per = (ntiles + 1023) / 1024;
   const int t0 = threadIdx.x * per;
@@ -630,41 +640,48 @@ __global__ void __launch_bounds__(1024) k_plane_bin_scan(int ntiles, const int* 
   if (threadIdx.x == 1023) *nwork = sh[1][1023];
 }
 
-template <int I>
-__global__ void __launch_bounds__(256) k_plane_bin_fill(long long P, const float* __restrict__ query, GridDesc g, BinPlan bp,
-                                                        const int* __restrict__ start, int* __restrict__ fill,
-                                                        int* __restrict__ order) {
-  const long long total = P * 3;
+template <int TOPO, int I>
+__global__ void __launch_bounds__(256) k_bin_fill(long long P, const float* __restrict__ query, GridDesc g, BinPlan bp,
+                                                  const int* __restrict__ start, int* __restrict__ fill, int* __restrict__ order) {
+  const long long total = P * BinDims<TOPO>::subs;
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
     const int s = (int)(t / P);
     const long long b = t - (long long)s * P;
     const float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
-    int tl[4];
-    const int n = plane_tiles<I>(g, bp, s, q, tl);
+    int tl[8];
+    const int n = bin_tiles<TOPO, I>(g, bp, s, q, tl);
     for (int k = 0; k < n; ++k) order[start[tl[k]] + atomicAdd(fill + tl[k], 1)] = (int)b;
   }
 }
 
-template <int I, int MODE>
-__global__ void __launch_bounds__(256) k_plane_scatter_tiles(long long P, float* __restrict__ gf, const float* __restrict__ gg_query,
-                                                             const float* __restrict__ grad_output, const float* __restrict__ query,
-                                                             GridDesc g, BinPlan bp, const int* __restrict__ count,
-                                                             const int* __restrict__ start, const int* __restrict__ order,
-                                                             const int* __restrict__ work, const int* __restrict__ nwork) {
-  constexpr int TOPO = TRIPLANE;
-  constexpr int ND = 2, NT = NTaps<I>::v;
+template <int TOPO, int I, int MODE>
+__global__ void __launch_bounds__(256) k_scatter_tiles(long long P, float* __restrict__ gf, const float* __restrict__ gg_query,
+                                                       const float* __restrict__ grad_output, const float* __restrict__ query,
+                                                       GridDesc g, BinPlan bp, const int* __restrict__ count,
+                                                       const int* __restrict__ start, const int* __restrict__ order,
+                                                       const int* __restrict__ work, const int* __restrict__ nwork) {
+  constexpr int ND = BinDims<TOPO>::nd, NT = NTaps<I>::v;
   extern __shared__ float hs_tab[];
-  const int D = g.D, G = g.G[0];
-  const int n_fl = bp.TS * bp.TS * D;
+  const int D = g.D, TS = bp.TS;
+  const int cells = (ND == 2) ? TS * TS : TS * TS * TS;
+  const int n_fl = cells * D;
   for (int wi = blockIdx.x; wi < *nwork; wi += gridDim.x) {                 // uniform per workgroup
     const int tile = work[wi] >> 6, part = work[wi] & 63;
     const int n = count[tile];
     const bool split = n > BIN_CAP;
     int p0 = part * BIN_CAP, p1 = p0 + BIN_CAP;
     if (part == 63 || p1 > n) p1 = n;                                       // the last listed part takes the remainder
-    const int s = tile / (bp.tpa * bp.tpa);
-    const int ti = (tile / bp.tpa) % bp.tpa, tj = tile % bp.tpa;
-    const unsigned i_lo = (unsigned)(ti * bp.TS), j_lo = (unsigned)(tj * bp.TS);
+    int s = 0;
+    unsigned lo[3] = {0u, 0u, 0u};
+    if constexpr (TOPO == TRIPLANE) {
+      s = tile / (bp.tpa[0] * bp.tpa[1]);
+      lo[0] = (unsigned)(((tile / bp.tpa[1]) % bp.tpa[0]) * TS);
+      lo[1] = (unsigned)((tile % bp.tpa[1]) * TS);
+    } else {
+      lo[0] = (unsigned)((tile / (bp.tpa[1] * bp.tpa[2])) * TS);
+      lo[1] = (unsigned)(((tile / bp.tpa[2]) % bp.tpa[1]) * TS);
+      lo[2] = (unsigned)((tile % bp.tpa[2]) * TS);
+    }
     for (int t = threadIdx.x; t < n_fl; t += 256) hs_tab[t] = 0.f;
     __syncthreads();
     for (int p = p0 + threadIdx.x; p < p1; p += 256) {
@@ -681,17 +698,19 @@ __global__ void __launch_bounds__(256) k_plane_scatter_tiles(long long P, float*
 #pragma unroll
       for (int d = 0; d < 8; ++d) og[d] = d < D ? grad_output[out_index<TOPO>(g, P, b, s, d)] : 0.f;
       NDJIR_FOR_TAPS(ND, NT) {
-        float w;
-        if constexpr (MODE == 0) {
-          w = tap_w(st, i, j, k);
-        } else {
-          w = 0.f;
+        const unsigned ri = st.ax[0].idx[i] - lo[0], rj = st.ax[1].idx[j] - lo[1];      // (unsigned: below the tile wraps to huge)
+        unsigned rk = 0u;
+        if constexpr (ND == 3) rk = st.ax[2].idx[k] - lo[2];
+        if (ri < (unsigned)TS && rj < (unsigned)TS && rk < (unsigned)TS) {              // this tap's cell belongs to this tile
+          float w;
+          if constexpr (MODE == 0) {
+            w = tap_w(st, i, j, k);
+          } else {
+            w = 0.f;
 #pragma unroll
-          for (int a = 0; a < ND; ++a) w += ggs[a] * tap_dw(st, a, i, j, k);
-        }
-        const unsigned ri = st.ax[0].idx[i] - i_lo, rj = st.ax[1].idx[j] - j_lo;      // (unsigned: below the tile wraps to huge)
-        if (ri < (unsigned)bp.TS && rj < (unsigned)bp.TS) {                           // this tap's cell belongs to this tile
-          const int e = ((int)ri * bp.TS + (int)rj) * D;
+            for (int a = 0; a < ND; ++a) w += ggs[a] * tap_dw(st, a, i, j, k);
+          }
+          const int e = ((ND == 2) ? ((int)ri * TS + (int)rj) : (((int)ri * TS + (int)rj) * TS + (int)rk)) * D;
 #pragma unroll
           for (int d = 0; d < 8; ++d) if (d < D) atomicAdd(&hs_tab[e + d], og[d] * w);
         }
@@ -699,9 +718,10 @@ __global__ void __launch_bounds__(256) k_plane_scatter_tiles(long long P, float*
     }
     __syncthreads();
     // write back: batches of 8 float4 per thread, the reads of a batch in flight together
-    float* plane = gf + (long long)s * G * G * D;
     const int D4 = D >> 2;
-    const int n4 = bp.TS * bp.TS * D4;
+    const int n4 = cells * D4;
+    const int G0 = g.G[0], G1 = (TOPO == TRIPLANE) ? g.G[0] : g.G[1], G2 = (TOPO == TRIPLANE) ? 1 : g.G[2];
+    float* sub = gf + ((TOPO == TRIPLANE) ? (long long)s * G0 * G0 * D : 0LL);
     for (int t0 = 0; t0 < n4; t0 += 256 * 8) {
       float4 v[8], o[8];
       float* dst[8];
@@ -710,14 +730,16 @@ __global__ void __launch_bounds__(256) k_plane_scatter_tiles(long long P, float*
       for (int u = 0; u < 8; ++u) {
         const int t = t0 + u * 256 + threadIdx.x;
         kind[u] = 0;
-        dst[u] = plane;
+        dst[u] = sub;
         if (t < n4) {
           const int cell = t / D4, c4 = t - cell * D4;
-          const int ii = cell / bp.TS, jj = cell - ii * bp.TS;
-          const int gi = (int)i_lo + ii, gj = (int)j_lo + jj;
+          int ii, jj, kk = 0;
+          if constexpr (ND == 2) { ii = cell / TS; jj = cell - ii * TS; }
+          else { ii = cell / (TS * TS); jj = (cell / TS) % TS; kk = cell % TS; }
+          const int gi = (int)lo[0] + ii, gj = (int)lo[1] + jj, gk = (int)lo[2] + kk;
           v[u] = *reinterpret_cast<const float4*>(hs_tab + cell * D + 4 * c4);
-          if (gi < G && gj < G && (v[u].x != 0.f || v[u].y != 0.f || v[u].z != 0.f || v[u].w != 0.f)) {
-            dst[u] = plane + ((long long)gi * G + gj) * D + 4 * c4;
+          if (gi < G0 && gj < G1 && gk < G2 && (v[u].x != 0.f || v[u].y != 0.f || v[u].z != 0.f || v[u].w != 0.f)) {
+            dst[u] = sub + (((long long)gi * G1 + gj) * G2 + gk) * D + 4 * c4;
             kind[u] = split ? 2 : 1;
           }
         }
@@ -764,51 +786,56 @@ static int* bin_scratch(size_t ints, hipStream_t stream) {
 }
 
 // returns NDJIR_OK when the binned path ran, -1 when it does not apply (the caller falls back)
-template <int I>
-static int plane_scatter_binned(const GridDesc& g, long long P, int mode, float* gf, const float* gg_query, const float* grad_output,
-                                const float* query, hipStream_t stream) {
-  constexpr int NT = NTaps<I>::v;
+template <int TOPO, int I>
+static int scatter_binned(const GridDesc& g, long long P, int mode, float* gf, const float* gg_query, const float* grad_output,
+                          const float* query, hipStream_t stream) {
+  constexpr int NT = NTaps<I>::v, ND = BinDims<TOPO>::nd, SUBS = BinDims<TOPO>::subs;
   // tile image: the smallest of 32 / 64 / 128 KB of LDS that keeps the tile count within BIN_MAX_TILES -- small tiles let
   // several workgroups share a CU, which is what hides the latency of the write-back's scattered reads
   BinPlan bp;
   int lds_floats = 0;
   for (int f = 8192; f <= BIN_LDS_FLOATS; f *= 2) {
     int side = 1;
-    while ((side + 1) * (side + 1) * g.D <= f) ++side;
+    if (ND == 2) while ((side + 1) * (side + 1) * g.D <= f) ++side;
+    else while ((side + 1) * (side + 1) * (side + 1) * g.D <= f) ++side;
     bp.TS = side;
     if (bp.TS < 2 * NT) continue;                     // a stencil spans at most two tiles per axis
-    bp.tpa = (g.G[0] + bp.TS - 1) / bp.TS;
-    bp.ntiles = 3 * bp.tpa * bp.tpa;
-    if (bp.ntiles <= BIN_MAX_TILES) { lds_floats = f; break; }
+    long long nt = SUBS;
+    for (int a = 0; a < 3; ++a) {
+      bp.tpa[a] = a < ND ? (g.G[TOPO == TRIPLANE ? 0 : a] + bp.TS - 1) / bp.TS : 1;
+      nt *= bp.tpa[a];
+    }
+    if (nt <= BIN_MAX_TILES) { bp.ntiles = (int)nt; lds_floats = f; break; }
   }
-  if (!lds_floats || 12 * P > 0x7fffffffLL) return -1;
-  const long long max_work = bp.ntiles + (12 * P) / BIN_CAP + 1;
-  // layout: count[ntiles] start[ntiles] fill[ntiles] nwork[4] work[max_work] order[12 P] (a pair is listed in <= 4 tiles)
-  const size_t ints = (size_t)3 * bp.ntiles + 4 + (size_t)max_work + (size_t)12 * P;
+  const long long per_pair = 1LL << ND;               // a pair is listed in at most 2^nd tiles
+  if (!lds_floats || SUBS * per_pair * P > 0x7fffffffLL) return -1;
+  const long long max_work = bp.ntiles + (SUBS * per_pair * P) / BIN_CAP + 1;
+  // layout: count[ntiles] start[ntiles] fill[ntiles] nwork[4] work[max_work] order[subs 2^nd P]
+  const size_t ints = (size_t)3 * bp.ntiles + 4 + (size_t)max_work + (size_t)(SUBS * per_pair * P);
   int* sc = bin_scratch(ints, stream);
   if (!sc) return -1;
   int *count = sc, *start = sc + bp.ntiles, *fill = sc + 2 * bp.ntiles, *nwork = sc + 3 * bp.ntiles;
   int *work = nwork + 4, *order = work + max_work;
-  // (a kernel, not hipMemsetAsync: as a memset node of a captured HIP graph this 48 KB clear faulted on replay -- ROCm 7.2)
+  // (a kernel, not hipMemsetAsync: as a memset node of a captured HIP graph this clear faulted on replay -- ROCm 7.2)
   zero_fill(reinterpret_cast<float*>(count), bp.ntiles, stream);
-  const int blocks = grid_blocks(P * 3);
-  hipLaunchKernelGGL(k_plane_bin_count<I>, dim3(blocks), dim3(256), 0, stream, P, query, g, bp, count);
-  hipLaunchKernelGGL(k_plane_bin_scan, dim3(1), dim3(1024), 0, stream, bp.ntiles, count, start, fill, work, nwork);
-  hipLaunchKernelGGL(k_plane_bin_fill<I>, dim3(blocks), dim3(256), 0, stream, P, query, g, bp, start, fill, order);
+  const int blocks = grid_blocks(P * SUBS);
+  hipLaunchKernelGGL((k_bin_count<TOPO, I>), dim3(blocks), dim3(256), 0, stream, P, query, g, bp, count);
+  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, bp.ntiles, count, start, fill, work, nwork);
+  hipLaunchKernelGGL((k_bin_fill<TOPO, I>), dim3(blocks), dim3(256), 0, stream, P, query, g, bp, start, fill, order);
   const size_t lds = (size_t)lds_floats * sizeof(float);
   static bool attr = false;
   if (!attr) {
     const size_t lds_max = (size_t)BIN_LDS_FLOATS * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plane_scatter_tiles<I, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_plane_scatter_tiles<I, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_tiles<TOPO, I, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_tiles<TOPO, I, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     attr = true;
   }
   int wg = (int)(max_work < 4096 ? max_work : 4096);
   if (mode == 0)
-    hipLaunchKernelGGL((k_plane_scatter_tiles<I, 0>), dim3(wg), dim3(256), lds, stream, P, gf, gg_query, grad_output, query, g, bp, count,
+    hipLaunchKernelGGL((k_scatter_tiles<TOPO, I, 0>), dim3(wg), dim3(256), lds, stream, P, gf, gg_query, grad_output, query, g, bp, count,
                        start, order, work, nwork);
   else
-    hipLaunchKernelGGL((k_plane_scatter_tiles<I, 1>), dim3(wg), dim3(256), lds, stream, P, gf, gg_query, grad_output, query, g, bp, count,
+    hipLaunchKernelGGL((k_scatter_tiles<TOPO, I, 1>), dim3(wg), dim3(256), lds, stream, P, gf, gg_query, grad_output, query, g, bp, count,
                        start, order, work, nwork);
   return ndjir_check_launch();
 }
@@ -1202,9 +1229,15 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
   // binning passes (measured on config/triplaneline.yaml: 12.4 ms per step aggregated, 12.95 ms binned).
   if (g.topo == TRIPLANE && (g.D == 4 || g.D == 8) && P >= scatter_bins_from() && !no_agg && !no_bins) {
     int rc = -1;
-    if (interp == LINEAR) rc = plane_scatter_binned<LINEAR>(g, P, mode, gf, gg_query, grad_output, query, stream);
-    else if (interp == COSINE) rc = plane_scatter_binned<COSINE>(g, P, mode, gf, gg_query, grad_output, query, stream);
-    else rc = plane_scatter_binned<LANCZOS>(g, P, mode, gf, gg_query, grad_output, query, stream);
+    if (interp == LINEAR) rc = scatter_binned<TRIPLANE, LINEAR>(g, P, mode, gf, gg_query, grad_output, query, stream);
+    else if (interp == COSINE) rc = scatter_binned<TRIPLANE, COSINE>(g, P, mode, gf, gg_query, grad_output, query, stream);
+    else rc = scatter_binned<TRIPLANE, LANCZOS>(g, P, mode, gf, gg_query, grad_output, query, stream);
+    if (rc >= 0) return rc;
+  }
+  // Lanczos voxel (64 taps per point): the same tile binning in 3-D.  (The 8-tap linear / cosine voxel keeps the aggregated
+  // path: at 2^19 points on 512^3 a 16^3 tile holds 16 points -- clearing and scanning its image would cost more than the taps.)
+  if (g.topo == VOXEL && interp == LANCZOS && g.D == 4 && P >= scatter_bins_from() && !no_agg && !no_bins) {
+    const int rc = scatter_binned<VOXEL, LANCZOS>(g, P, mode, gf, gg_query, grad_output, query, stream);
     if (rc >= 0) return rc;
   }
   if (g.topo != HASH && (g.D & 3) == 0 && per_point <= 128 && !no_agg) {

@@ -100,7 +100,7 @@ def test_hash_scatter_through_lds_table(gpu, family, P, hash_cfg):
 
 
 @pytest.mark.parametrize("family,P,G,D", [("triplane", 20000, 256, 8), ("triplane", 30000, 200, 4), ("cosine_triplane", 20000, 128, 8),
-                                          ("lanczos_triplane", 17000, 96, 4)])
+                                          ("lanczos_triplane", 17000, 96, 4), ("lanczos_voxel", 17000, 40, 4)])
 def test_triplane_scatter_binned_by_tiles(gpu, family, P, G, D, binned_scatter):
     """grad_feature / grad_query_grad_feature of the tri-plane families at point counts where the scatter bins the (point, plane)
     pairs by tile and accumulates each tile in LDS (csrc/grid.hip k_plane_scatter_tiles); several tiles per axis, queries
