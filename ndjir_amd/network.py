@@ -367,6 +367,10 @@ def _mlp(h, D, L, Dout, act, use_wn, shift=0):
 
 
 def _cat_inputs(x, feature, normal, c):
+    if c.use_normal and normal is None:
+        # the reference concatenates None here and fails the same way (python/network.py:251-254 called from the perturbed
+        # pass, python/renderer.py:193 "normal is not used"): a net evaluated there cannot have use_normal set
+        raise ValueError("use_normal=true for a network that is also evaluated without a normal (perturbed base-colour pass)")
     inputs = [x] + ([feature] if c.use_geometric_feature else []) + ([normal] if c.use_normal else [])
     return torch.cat(inputs, dim=-1) if len(inputs) > 1 else x
 
