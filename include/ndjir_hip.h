@@ -367,16 +367,18 @@ int ndjir_render_pixel_normal_backward(int R, float eps, const float* grad_pixel
  * ndjir_loss_terms: python/loss.py:59-178 without the mask term (train.mask_weight = 0) -- RGB error (l1 / l2), eikonal
  *   term, sampled TV term(s), the five prior / regulariser sums of the material head (prior (R,5), may be null) and the
  *   weighted total, normalised by sum(mask) N + 1e-5 (mask_sum_global: device scalar holding the sum over all ray shards,
- *   or null = this call's own sum).  weights5 (host) = eikonal, tv, base colour prior, roughness prior, specular prior.
+ *   or null = this call's own sum); the five prior sums by sum(mask) N_prior + 1e-5 (python/loss.py:36, 72, 118: N_prior is
+ *   the sample count when the eikonal term is on, renderer.n_samples0 when it is off).  A term whose weight is 0 is
+ *   reported as 0 and left out of the total (the reference does not evaluate it).  weights5 (host) = eikonal, tv, base colour prior, roughness prior, specular prior.
  *   workspace: ndjir_loss_terms_workspace(R) floats; terms (device, 12 floats): total, rgb, eikonal, tv, prior base colour,
- *   prior roughness, reg std roughness, prior specular, reg std specular, 1 / denorm, sum(mask), 0.  Per-ray partial sums
+ *   prior roughness, reg std roughness, prior specular, reg std specular, 1 / denorm, sum(mask), 1 / denorm of the priors.  Per-ray partial sums
  *   and a fixed-order final reduction: the loss is bit-reproducible.  The backward takes the gradient of terms[0]. */
 int ndjir_render_pixel_compose(int R, int Ce, int entangle, const float* pix, const float* env, const float* spec, const float* bg,
                                float* color, hipStream_t stream);
 int ndjir_render_pixel_compose_backward(int R, int Ce, int entangle, const float* pix, const float* env, const float* spec,
                                         const float* g, float* g_pix, float* g_env, float* g_spec, float* g_bg, hipStream_t stream);
 int ndjir_loss_terms_workspace(int R);
-int ndjir_loss_terms(int R, int N, const float* color, const float* color_gt, const float* mask, const float* grad_x,
+int ndjir_loss_terms(int R, int N, int N_prior, const float* color, const float* color_gt, const float* mask, const float* grad_x,
                      const float* tv0, int D0, const float* tv1, int D1, const float* prior, const float* mask_sum_global,
                      float inv_rays, const float* weights5, int l2, float* workspace, float* terms, hipStream_t stream);
 int ndjir_loss_terms_backward(int R, int N, const float* color, const float* color_gt, const float* mask, const float* grad_x,

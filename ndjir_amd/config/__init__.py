@@ -43,6 +43,7 @@ _VARIANTS = {
                      "geometric_network.voxel.grid_size=2048",
                      "geometric_network.voxel.feature_size=8"],
     "no_voxel": ["geometric_network.voxel.type=none"],
+    "ste": ["geometric_network.voxel.use_ste=true"],
     "custom": ["geometric_network.initial_sphere_radius=0.5",
                "geometric_network.voxel.type=lanczos_voxel",
                "renderer.eps_normal=1.0e-08", "train.tv_weight=1.0",

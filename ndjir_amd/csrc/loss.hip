@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) k_pixel_compose_bwd(int R, int Ce, int en
 constexpr int LT_COLS = 9;
 // terms (device, LT_TERMS floats):
 //   0 loss   1 loss_rgb   2 loss_eikonal   3 loss_tv   4 prior_base_color   5 prior_roughness   6 reg_std_roughness
-//   7 prior_specular_reflectance   8 reg_std_specular_reflectance   9 1 / denorm   10 sum(mask)   11 spare
+//   7 prior_specular_reflectance   8 reg_std_specular_reflectance   9 1 / denorm   10 sum(mask)   11 1 / denorm of the priors
 constexpr int LT_TERMS = 12;
 
 struct LossWeights {
@@ -149,8 +149,12 @@ __global__ void __launch_bounds__(256) k_loss_partial(int R, int N, const float*
 }
 
 // one workgroup: column sums of `partial` in a fixed order, normalisation (loss.py:74, 95, 118: every term but the RGB one is
-// divided by sum(mask) N + 1e-5 -- sum(mask) over ALL ray shards when mask_sum_global is given), weighted total
-__global__ void __launch_bounds__(256) k_loss_finish(int R, int N, const float* __restrict__ partial,
+// divided by sum(mask) N + 1e-5 -- sum(mask) over ALL ray shards when mask_sum_global is given), weighted total.
+// The priors' N is its own argument: python/loss.py:36 binds N = n_samples0, :72 rebinds it to the sample count only inside
+// `if eikonal_weight > 0`, and :118 divides the priors by whatever N is then -- with the eikonal term off that is n_samples0.
+// A term whose weight is zero is not evaluated by the reference (python/loss.py:70, 85, 124, 135, 152): it is reported as 0
+// and stays out of the total, so that a non-finite value of a switched-off term (0 * Inf) cannot poison the loss.
+__global__ void __launch_bounds__(256) k_loss_finish(int R, int N, int Np, const float* __restrict__ partial,
                                                      const float* __restrict__ mask_sum_global, LossWeights w,
                                                      float* __restrict__ terms) {
   __shared__ float red[LT_COLS][256];
@@ -172,16 +176,25 @@ __global__ void __launch_bounds__(256) k_loss_finish(int R, int N, const float* 
   if (threadIdx.x == 0) {
     const float msum = mask_sum_global ? mask_sum_global[0] : red[8][0];
     const float denorm = msum * (float)N + 1e-5f;
+    const float dprior = msum * (float)Np + 1e-5f;
     const float inv = 1.f / denorm;
     const float l_rgb = red[0][0] * w.inv_rays;
-    const float l_eik = red[1][0] / denorm, l_tv = red[2][0] / denorm;
-    const float p_bc = red[3][0] / denorm, p_r = red[4][0] / denorm, g_r = red[5][0] / denorm, p_s = red[6][0] / denorm,
-                g_s = red[7][0] / denorm;
+    const float l_eik = w.eikonal > 0.f ? red[1][0] / denorm : 0.f, l_tv = w.tv > 0.f ? red[2][0] / denorm : 0.f;
+    const float p_bc = w.base_color > 0.f ? red[3][0] / dprior : 0.f;
+    const float p_r = w.roughness > 0.f ? red[4][0] / dprior : 0.f, g_r = w.roughness > 0.f ? red[5][0] / dprior : 0.f;
+    const float p_s = w.specular > 0.f ? red[6][0] / dprior : 0.f, g_s = w.specular > 0.f ? red[7][0] / dprior : 0.f;
     terms[1] = l_rgb; terms[2] = l_eik; terms[3] = l_tv; terms[4] = p_bc; terms[5] = p_r; terms[6] = g_r; terms[7] = p_s;
-    terms[8] = g_s; terms[9] = inv; terms[10] = red[8][0]; terms[11] = 0.f;
+    terms[8] = g_s; terms[9] = inv; terms[10] = red[8][0]; terms[11] = 1.f / dprior;
     // python/loss.py:168-178 in its order of additions
-    terms[0] = l_rgb + w.eikonal * l_eik + w.tv * l_tv + w.base_color * p_bc + w.roughness * p_r + w.specular * p_s +
-               w.roughness * g_r + w.specular * g_s;
+    float total = l_rgb;
+    if (w.eikonal > 0.f) total += w.eikonal * l_eik;
+    if (w.tv > 0.f) total += w.tv * l_tv;
+    if (w.base_color > 0.f) total += w.base_color * p_bc;
+    if (w.roughness > 0.f) total += w.roughness * p_r;
+    if (w.specular > 0.f) total += w.specular * p_s;
+    if (w.roughness > 0.f) total += w.roughness * g_r;
+    if (w.specular > 0.f) total += w.specular * g_s;
+    terms[0] = total;
   }
 }
 
@@ -195,7 +208,7 @@ __global__ void __launch_bounds__(256) k_loss_bwd(int R, int N, const float* __r
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wave;
   if (r >= R) return;
-  const float g = g_loss[0], inv = terms[9], m = mask[r];
+  const float g = g_loss[0], inv = terms[9], inv_prior = terms[11], m = mask[r];
   if (g_grad_x) {
     const float k = g * w.eikonal * inv * m * m;
     for (int i = lane; i < N; i += 64) {
@@ -216,7 +229,7 @@ __global__ void __launch_bounds__(256) k_loss_bwd(int R, int N, const float* __r
   }
   if (g_prior && lane < 5) {
     const float wk = lane == 0 ? w.base_color : (lane <= 2 ? w.roughness : w.specular);
-    g_prior[r * 5 + lane] = g * wk * inv * m;
+    g_prior[r * 5 + lane] = g * wk * inv_prior * m;
   }
 }
 
@@ -268,15 +281,15 @@ static LossWeights make_weights(float inv_rays, const float* weights5, int l2) {
 
 extern "C" int ndjir_loss_terms_workspace(int R) { return R * LT_COLS; }
 
-extern "C" int ndjir_loss_terms(int R, int N, const float* color, const float* color_gt, const float* mask, const float* grad_x,
+extern "C" int ndjir_loss_terms(int R, int N, int N_prior, const float* color, const float* color_gt, const float* mask, const float* grad_x,
                                 const float* tv0, int D0, const float* tv1, int D1, const float* prior,
                                 const float* mask_sum_global, float inv_rays, const float* weights5, int l2, float* workspace,
                                 float* terms, hipStream_t stream) {
-  if (R <= 0 || N <= 0) return NDJIR_ERR_ARG;
+  if (R <= 0 || N <= 0 || N_prior <= 0) return NDJIR_ERR_ARG;
   if (!color || !color_gt || !mask || !weights5 || !workspace || !terms) return NDJIR_ERR_ARG;
   hipLaunchKernelGGL(k_loss_partial, dim3((R + 3) / 4), dim3(256), 0, stream, R, N, color, color_gt, mask, grad_x, tv0, D0, tv1, D1,
                      prior, l2, workspace);
-  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, stream, R, N, workspace, mask_sum_global,
+  hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, stream, R, N, N_prior, workspace, mask_sum_global,
                      make_weights(inv_rays, weights5, l2), terms);
   return ndjir_check_launch();
 }

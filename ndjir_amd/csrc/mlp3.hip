@@ -42,6 +42,10 @@ constexpr int GPS = 32 * 4 + 4;  // staging tile: dwords per group of 4 columns 
 constexpr int STG = 8 * GPS;     // staging dwords per wave (32 x 32 tile)
 constexpr int IN_CACHE = 10;     // float4 groups of the chain input a thread keeps between the max pass and the split
 constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+#ifndef NDJIR_BWD_KLOOP_BARRIER
+#define NDJIR_BWD_KLOOP_BARRIER 0
+#endif
+constexpr bool BWD_KLOOP_BARRIER = NDJIR_BWD_KLOOP_BARRIER;   // (A/B switch; measured +-0 on the backward chain, off)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -92,6 +96,15 @@ __device__ __forceinline__ float wave_max(float m) {
   return m;
 }
 
+// lane-crossing without the LDS crossbar (ds_bpermute + lgkmcnt round trip): DPP controls of gfx9
+//   quad_perm [1,0,3,2] = xor 1, quad_perm [2,3,0,1] = xor 2, row_half_mirror (i -> 7 - i inside a group of 8 lanes),
+//   row_ror:8 = xor 8 inside a row of 16 lanes
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROR8 = 0x128;
+
 // ---- weight packing -----------------------------------------------------------------------------
 // dst (16-byte units): [Np/32][Kp/16][plane 0..1][lane 0..63], lane (c = lane & 31, h = lane >> 5) holds
 // W[16 ks + 8 h + j][32 nb + c] * s_nb, j = 0..7, of plane p (0 = hi, 1 = lo * 2^11); behind the planes, at float
@@ -141,6 +154,7 @@ __global__ void __launch_bounds__(PACK_T) k_pack3(const float* __restrict__ W, _
 template <int MODE, int TM>
 __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
   constexpr bool BWD = (MODE == 1);
+  constexpr bool BATCH_EPILOGUE = (MODE == 0);
   constexpr int RB = TM / 32;
   constexpr int TMP = TM + 4;          // rows per k-group incl. pad: (TMP * 16) % 256 == 64 -> conflict-free plane writes
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -154,6 +168,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
+  // an opaque copy of the lane id: addresses derived from it are formed where they are used instead of being hoisted out of
+  // the tile / layer loops into registers that stay occupied (or spilled) through the k-loops
+  auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
   float* stage_all = lds + (size_t)2 * PLANE * 4;
   float* stage = stage_all + wave * 2 * STG;      // two 32 x 32 tiles per wave: one per output block of a layer
   float* bsum = lds + a.bg_lds;
@@ -303,8 +320,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
         for (int q = 0; q < RBU; ++q) { acc0[SLOT + q] = f32x16{0}; acc1[SLOT + q] = f32x16{0}; }
-        const gptr<const f16x8> Bp = p_wp + ((long long)nb * KS) * 2 * 64 + lane;
-        const f16x8* A0 = act + h * TMP + rb0 * 32 + r;
+        const int lane_k = fresh_lane();
+        const gptr<const f16x8> Bp = p_wp + ((long long)nb * KS) * 2 * 64 + lane_k;
+        const f16x8* A0 = act + (lane_k >> 5) * TMP + rb0 * 32 + (lane_k & 31);
         // Software pipeline (static register slots, unrolled by 3): weight fragments 3 steps ahead, activation
         // fragments one step ahead (double buffered).
         f16x8 b[3][2];                 // [slot][plane]
@@ -435,6 +453,199 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         m4 = fmaxf(m4, __shfl_xor(m4, 4));
         if (g == 0) atomicMax(&s_rmax[cur][row], __float_as_uint(m4));
       };
+      // ---- batched epilogue of a hidden layer (every job of the wave is a full 32 x 32 block of full rows) ----
+      // Straight-line code over the wave's NJ blocks x 4 row steps: all side loads are requested at once, ahead of the
+      // staging round trip; the results stay in registers across the row-maximum barrier (phase B splits them from
+      // there: no parking in the staging tile); the 8-lane row maxima and the bias-gradient column sums cross lanes by
+      // DPP instead of ds_bpermute.  (The per-job path below keeps the ragged / output-layer / multi-round cases.)
+      f32x4 pv[2][4];          // phase A results of the batched path: [job][row step]
+      auto phase_a_batched = [&](auto nj_tag, auto rb_tag) {
+        constexpr int NJ = decltype(nj_tag)::value;
+        constexpr bool HAS_RB = decltype(rb_tag)::value;
+        // (lane-derived addresses are formed here, from an opaque copy of the lane id: hoisted out of the layer / tile loops
+        // they would sit in -- spilled -- registers through the k-loops)
+        const int lane_o = fresh_lane();
+        const int g = lane_o & 7, l8 = lane_o >> 3, r = lane_o & 31, h = lane_o >> 5;
+        int nbj[NJ], rbj[NJ];
+        unsigned lo[NJ];          // element offset of (row lane / 8 of row block, column group g of column block) in the tile
+        float winv[NJ];
+        // uniform base (SGPR pair) + 32-bit lane offset: one address register per access instead of a 64-bit pair
+        const long long tile_off = row0 * l_ld;
+        const unsigned step = 8u * (unsigned)l_ld;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          nbj[j] = (jobs >> (8 * j)) & 31;
+          rbj[j] = (jobs >> (8 * j + 5)) & 7;
+          lo[j] = (unsigned)(rbj[j] * 32 + l8) * (unsigned)l_ld + (unsigned)(nbj[j] * 32 + g * 4);
+          winv[j] = p_winv[nbj[j]];
+        }
+        // side loads first (independent of the staging tile)
+        f32x4 hs[NJ][4], ex[NJ][4], bb[NJ];
+        if (MODE == 0) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            bb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p_bias) bb[j] = *((gptr<const f32x4>)(p_bias + (unsigned)(nbj[j] * 32 + g * 4))) * b2;
+          }
+          if (HAS_RB) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              // row group of (row0 + 32 rb + lane / 8 + 8 it): the tile-level part is wave-uniform
+              const unsigned base = (unsigned)(row0 + rbj[j] * 32);
+              const unsigned d = (unsigned)rb_div;
+              const unsigned q0 = pin((int)(base / d)), r0 = pin((int)(base % d));
+#pragma unroll
+              for (int it = 0; it < 4; ++it) {
+                const unsigned t = r0 + (unsigned)l8 + 8u * it;
+                const unsigned grp = q0 + (d >= 32u ? (t >= d ? 1u : 0u) : t / d);
+                hs[j][it] = *((gptr<const f32x4>)(p_rowbias + (long long)grp * l_N + nbj[j] * 32 + g * 4));
+              }
+            }
+          }
+        }
+#ifndef HS_LATE
+        if (MODE != 0) {
+          const gptr<const float> b_in = p_side_in + tile_off;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) hs[j][it] = *((gptr<const f32x4>)(b_in + (lo[j] + it * step)));
+        }
+#endif
+        // pass 1: acc0 + acc1 2^-11 -> staging tiles (conflict-free: column groups GPS apart, rows 4 dwords apart)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          float* dst = stage + j * STG + (r >> 2) * GPS + (r & 3);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dst[acc_row(i, h) * 4] = fmaf(acc1[j][i], LO_INV, acc0[j][i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // second set of side loads (backward: extra adjoints; tangent: s) once the accumulators are out of the registers
+        if (MODE != 0) {
+#ifdef HS_LATE
+          const gptr<const float> b_in = p_side_in + tile_off;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) hs[j][it] = *((gptr<const f32x4>)(b_in + (lo[j] + it * step)));
+#endif
+          const gptr<const float> p_ex = MODE == 1 ? p_side_add : p_side_in2;
+          if (p_ex) {
+            const gptr<const float> b_ex = p_ex + tile_off;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+              for (int it = 0; it < 4; ++it) ex[j][it] = *((gptr<const f32x4>)(b_ex + (lo[j] + it * step)));
+          } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+              for (int it = 0; it < 4; ++it) ex[j][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // pass 2: lane = (column group g of 4 columns, row lane / 8 of every 8-row step)
+        float sa[NJ][4];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float* lp = stage + j * STG + g * GPS + l8 * 4;
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            pv[j][it] = *reinterpret_cast<const f32x4*>(lp + it * 32);
+            sa[j][it] = s_ainv[rbj[j] * 32 + l8 + 8 * it];
+          }
+        }
+        const gptr<float> b_out2 = (MODE == 2 && p_side_out2) ? p_side_out2 + tile_off : nullptr;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float wk = MODE == 0 ? winv[j] * b2 : winv[j];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const f32x4 z = pv[j][it] * (sa[j][it] * wk);
+            f32x4 v;
+            if (MODE == 0) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float u = z[q] + bb[j][q];                             // b2 * (pre-activation)
+                if (HAS_RB) u = fmaf(hs[j][it][q], b2, u);
+                // softplus_beta(t) = (max(u, 0) + log2(1 + 2^-|u|)) ln2 / beta,  u = beta log2(e) t
+                const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-fabsf(u)));
+                v[q] = (fmaxf(u, 0.f) + l2) * ib2sc;
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float e = __builtin_amdgcn_exp2f(nb2 * hs[j][it][q]);
+                const float sp = (1.f - e) * sc;
+                if (MODE == 1) v[q] = fmaf(z[q], sp, ex[j][it][q]);
+                else { v[q] = z[q] * sp; ex[j][it][q] = beta * z[q] * ex[j][it][q] * e; }     // (the extra adjoint, in place)
+              }
+              if (MODE == 2 && b_out2) *((gptr<f32x4>)(b_out2 + (lo[j] + it * step))) = ex[j][it];
+            }
+            pv[j][it] = v;
+          }
+        }
+        if (p_side_out) {
+          const gptr<float> b_out = p_side_out + tile_off;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) *((gptr<f32x4>)(b_out + (lo[j] + it * step))) = pv[j][it];
+        }
+        // row maxima: the lane's 4 values, the row's 8 lanes by DPP, one LDS atomic per row and block.  v_max ignores NaN;
+        // a group holding an Inf (or only NaN) goes through the bit-pattern filter.
+        float m4[NJ][4];
+        bool odd = false;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const f32x4 v = pv[j][it];
+            m4[j][it] = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            odd |= !(m4[j][it] < 3.0e38f);
+          }
+        if (__builtin_expect(odd, 0)) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              unsigned mb = 0;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { const unsigned b = finite_abs_bits(pv[j][it][q]); mb = b > mb ? b : mb; }
+              m4[j][it] = __uint_as_float(mb);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            float m = m4[j][it];
+            m = fmaxf(m, dpp<DPP_XOR1>(m));
+            m = fmaxf(m, dpp<DPP_XOR2>(m));
+            m = fmaxf(m, dpp<DPP_HALF_MIRROR>(m));
+            m4[j][it] = m;
+          }
+        if (g == 0) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) atomicMax(&s_rmax[cur][rbj[j] * 32 + l8 + 8 * it], __float_as_uint(m4[j][it]));
+        }
+        // bias gradient: column sums of the deltas (rows 8 apart share a lane; xor 8 by DPP, the rest by LDS atomics)
+        if (MODE != 0 && p_bgrad) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            f32x4 c = pv[j][0] + pv[j][1] + pv[j][2] + pv[j][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] += dpp<DPP_ROR8>(c[q]);
+            if ((lane_o & 8) == 0) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) atomicAdd(p_bgrad + nbj[j] * 32 + g * 4 + q, c[q]);
+            }
+          }
+        }
+      };
+      bool batched = false;
 #pragma unroll 1
       for (int round = 0; round < nrounds; ++round) {
       jobs = 0; njobs = 0;
@@ -455,11 +666,18 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
       }
       if (round == 0) stamp(li, 1);
       __builtin_amdgcn_wave_barrier();     // (a later round reuses the staging tiles)
+      batched = BATCH_EPILOGUE && !last && nrounds == 1 && njobs > 0 && (l_ld & 3) == 0 && rows == TM && (!p_rowbias || (l_N & 3) == 0) &&
+                (row0 + TM) < (1LL << 31);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) if (j < njobs && !((((jobs >> (8 * j)) & 31) * 32 + 31) < nlim)) batched = false;
+      if (!batched)        // (batched: nrounds == 1, the epilogue follows the loop -- its results must not be live in here)
 #pragma unroll 1
       for (int j = 0; j < njobs; ++j) {
         const int nb = (jobs >> (8 * j)) & 31, rb0 = (jobs >> (8 * j + 5)) & 7;
         const float winv = p_winv[nb];
         float* const stj = stage + j * STG;
+        const int lane = fresh_lane();
+        const int r = lane & 31, h = lane >> 5, g = lane & 7;
         // pass 1: acc0 + acc1 2^-11 -> staging tile (conflict-free: column groups GPS apart, rows 4 dwords apart)
         {
           float* dst = stj + (r >> 2) * GPS + (r & 3);
@@ -477,7 +695,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         const int n4 = nb * 32 + g * 4;
         const int mbase = rb0 * 32 + (lane >> 3);
         const long long off0 = (row0 + mbase) * l_ld + n4;
-        const bool fast = !last && (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && rows == TM && (!p_rowbias || (l_N & 3) == 0);
+        // (forward: full blocks of full tiles take the batched path after the round loop; what arrives here is ragged, an
+        // output layer, or a wave whose other block is ragged -- the barrier waits for that wave anyway.  Backward and
+        // tangent keep the block-by-block fast path: their side loads come from HBM at the burst rate of the chip,
+        // ~11 B / clk / CU, and requesting all of a wave's blocks at once measured 6 % slower than this spread-out order)
+        const bool fast = !BATCH_EPILOGUE && !last && (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && rows == TM && (!p_rowbias || (l_N & 3) == 0);
         f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
         float* lp = stj + g * GPS + (lane >> 3) * 4;
         if (fast) {
@@ -529,97 +751,97 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
             *reinterpret_cast<f32x4*>(lp + it * 32) = v;       // parked for phase B (same lane reads it back)
           }
         } else {
-          const bool vec_ok = (n4 + 3 < nlim);
-          const bool vec_side = vec_ok && (l_ld & 3) == 0;
-          f32x4 cm, bias4 = {0.f, 0.f, 0.f, 0.f};
+        const bool vec_ok = (n4 + 3 < nlim);
+        const bool vec_side = vec_ok && (l_ld & 3) == 0;
+        f32x4 cm, bias4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) cm[q] = (n4 + q < nlim) ? 1.f : 0.f;
-          if (MODE == 0 && p_bias) {
+        for (int q = 0; q < 4; ++q) cm[q] = (n4 + q < nlim) ? 1.f : 0.f;
+        if (MODE == 0 && p_bias) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (n4 + q < l_N) bias4[q] = p_bias[n4 + q];
-          }
+          for (int q = 0; q < 4; ++q) if (n4 + q < l_N) bias4[q] = p_bias[n4 + q];
+        }
 #pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const int m = mbase + 8 * it;
-            const bool mrow = m < rows;
-            const float rm = mrow ? 1.f : 0.f;
-            const long long grow = row0 + m;
-            const long long off = off0 + (long long)it * 8 * l_ld;
-            const f32x4 z = *reinterpret_cast<const f32x4*>(lp + it * 32) * s_ainv[m] * winv;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (last) {
-              if (mrow) {
-                float* y = a.Y + grow * a.ldy + n4;
-                if (vec_ok && (a.ldy & 3) == 0 && ((uintptr_t)a.Y & 15) == 0) {
-                  f32x4 t = z;
-                  if (MODE == 0) t += bias4;
-                  if (a.accum_y) t += *reinterpret_cast<const f32x4*>(y);
-                  *reinterpret_cast<f32x4*>(y) = t;
-                } else {
+        for (int it = 0; it < 4; ++it) {
+          const int m = mbase + 8 * it;
+          const bool mrow = m < rows;
+          const float rm = mrow ? 1.f : 0.f;
+          const long long grow = row0 + m;
+          const long long off = off0 + (long long)it * 8 * l_ld;
+          const f32x4 z = *reinterpret_cast<const f32x4*>(lp + it * 32) * s_ainv[m] * winv;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (last) {
+            if (mrow) {
+              float* y = a.Y + grow * a.ldy + n4;
+              if (vec_ok && (a.ldy & 3) == 0 && ((uintptr_t)a.Y & 15) == 0) {
+                f32x4 t = z;
+                if (MODE == 0) t += bias4;
+                if (a.accum_y) t += *reinterpret_cast<const f32x4*>(y);
+                *reinterpret_cast<f32x4*>(y) = t;
+              } else {
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) {
-                    if (n4 + q < l_N) {
-                      const float t = z[q] + (MODE == 0 ? bias4[q] : 0.f);
-                      y[q] = a.accum_y ? y[q] + t : t;
-                    }
+                for (int q = 0; q < 4; ++q) {
+                  if (n4 + q < l_N) {
+                    const float t = z[q] + (MODE == 0 ? bias4[q] : 0.f);
+                    y[q] = a.accum_y ? y[q] + t : t;
                   }
                 }
               }
-              continue;
             }
-            if (MODE == 0) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                float t = z[q] + bias4[q];
-                if (p_rowbias && mrow && n4 + q < l_N) t += p_rowbias[(grow / rb_div) * (long long)l_N + n4 + q];
-                const float u = b2 * t;
-                const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-fabsf(u)));
-                v[q] = (fmaxf(u, 0.f) + l2) * (ib2sc * cm[q] * rm);
-              }
-              if (mrow && p_side_out) {
-                if (vec_side) *((gptr<f32x4>)(p_side_out + off)) = v;
-                else {
-#pragma unroll
-                  for (int q = 0; q < 4; ++q) if (n4 + q < l_N) p_side_out[off + q] = v[q];
-                }
-              }
-            } else {
-              f32x4 hs = {0.f, 0.f, 0.f, 0.f}, ex = {0.f, 0.f, 0.f, 0.f}, x2 = {0.f, 0.f, 0.f, 0.f};
-              if (mrow) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (n4 + q < nlim) {
-                  hs[q] = p_side_in[off + q];
-                  if (MODE == 1 && p_side_add) ex[q] = p_side_add[off + q];
-                  if (MODE == 2 && p_side_in2) ex[q] = p_side_in2[off + q];
-                }
-              }
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float e = __builtin_amdgcn_exp2f(nb2 * hs[q]);
-                const float sp = (1.f - e) * sc;
-                const float mk = cm[q] * rm;
-                if (MODE == 1) v[q] = (z[q] * sp + ex[q]) * mk;
-                else { v[q] = z[q] * sp * mk; x2[q] = beta * z[q] * ex[q] * e * mk; }
-              }
-              if (MODE == 1 && is_skip && mrow && a.Xskip) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  const int n = n4 + q;
-                  if (n >= a.skip_split && n < l_N) a.Xskip[grow * a.ld_xskip + (n - a.skip_split)] = z[q] * sc;
-                }
-              }
-              if (mrow) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (n4 + q < nlim) {
-                  if (p_side_out) p_side_out[off + q] = v[q];
-                  if (MODE == 2 && p_side_out2) p_side_out2[off + q] = x2[q];
-                }
-              }
-              colsum += v;
-            }
-            row_max(m, v);
-            *reinterpret_cast<f32x4*>(lp + it * 32) = v;
+            continue;
           }
+          if (MODE == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              float t = z[q] + bias4[q];
+              if (p_rowbias && mrow && n4 + q < l_N) t += p_rowbias[(grow / rb_div) * (long long)l_N + n4 + q];
+              const float u = b2 * t;
+              const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-fabsf(u)));
+              v[q] = (fmaxf(u, 0.f) + l2) * (ib2sc * cm[q] * rm);
+            }
+            if (mrow && p_side_out) {
+              if (vec_side) *((gptr<f32x4>)(p_side_out + off)) = v;
+              else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (n4 + q < l_N) p_side_out[off + q] = v[q];
+              }
+            }
+          } else {
+            f32x4 hs = {0.f, 0.f, 0.f, 0.f}, ex = {0.f, 0.f, 0.f, 0.f}, x2 = {0.f, 0.f, 0.f, 0.f};
+            if (mrow) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (n4 + q < nlim) {
+                hs[q] = p_side_in[off + q];
+                if (MODE == 1 && p_side_add) ex[q] = p_side_add[off + q];
+                if (MODE == 2 && p_side_in2) ex[q] = p_side_in2[off + q];
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float e = __builtin_amdgcn_exp2f(nb2 * hs[q]);
+              const float sp = (1.f - e) * sc;
+              const float mk = cm[q] * rm;
+              if (MODE == 1) v[q] = (z[q] * sp + ex[q]) * mk;
+              else { v[q] = z[q] * sp * mk; x2[q] = beta * z[q] * ex[q] * e * mk; }
+            }
+            if (MODE == 1 && is_skip && mrow && a.Xskip) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int n = n4 + q;
+                if (n >= a.skip_split && n < l_N) a.Xskip[grow * a.ld_xskip + (n - a.skip_split)] = z[q] * sc;
+              }
+            }
+            if (mrow) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) if (n4 + q < nlim) {
+                if (p_side_out) p_side_out[off + q] = v[q];
+                if (MODE == 2 && p_side_out2) p_side_out2[off + q] = x2[q];
+              }
+            }
+            colsum += v;
+          }
+          row_max(m, v);
+          *reinterpret_cast<f32x4*>(lp + it * 32) = v;
+        }
         }
         if (MODE != 0 && !last && p_bgrad) {
 #pragma unroll
@@ -633,6 +855,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         }
       }
       }   // rounds
+      // Backward / tangent: the epilogue's side loads come from HBM.  The CU's vector memory path returns in order, so a
+      // wave that leaves its k-loop early and requests them stalls the weight fragments (L2 hits) of the waves still in
+      // theirs: the loads are held back until every wave is through its k-loop (measured: k-loop of the slowest wave
+      // 13.7 k -> ~10 k cycles per 256-wide layer).
+      if (MODE != 0 && !last && BWD_KLOOP_BARRIER) __syncthreads();
+      if (batched) {
+        using TT = std::true_type;
+        using FF = std::false_type;
+        if (njobs == 2) { if (MODE == 0 && p_rowbias) phase_a_batched(I2{}, TT{}); else phase_a_batched(I2{}, FF{}); }
+#ifndef NO_NJ1
+        else { if (MODE == 0 && p_rowbias) phase_a_batched(I1{}, TT{}); else phase_a_batched(I1{}, FF{}); }
+#endif
+      }
       stamp(li, 2);
 
       if (last) {              // the output layer leaves nothing in the planes: no maximum, no split
@@ -650,9 +885,31 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
       stamp(li, 3);
 
       // ================= phase B: per-row scale, 2-way split, planes updated in place =================
+      if (batched) {
+        const int lane_o = fresh_lane();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (j < njobs) {
+            const int nb = (jobs >> (8 * j)) & 31, rb0 = (jobs >> (8 * j + 5)) & 7;
+            const int n4 = nb * 32 + (lane_o & 7) * 4;
+            const int mbase = rb0 * 32 + (lane_o >> 3);
+            unsigned mx[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) mx[it] = s_rmax[cur][mbase + 8 * it];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              float s_row, inv_row;
+              scale_from_max(mx[it], s_row, inv_row);
+              put4(n4, mbase + 8 * it, pv[j][it], s_row);
+            }
+          }
+        }
+      } else
 #pragma unroll 1
       for (int j = 0; j < njobs; ++j) {
         const int nb = (jobs >> (8 * j)) & 31, rb0 = (jobs >> (8 * j + 5)) & 7;
+        const int lane = fresh_lane();
+        const int g = lane & 7;
         const int n4 = nb * 32 + g * 4;
         const int mbase = rb0 * 32 + (lane >> 3);
         const float* lp = stage + j * STG + g * GPS + (lane >> 3) * 4;

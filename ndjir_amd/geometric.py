@@ -63,14 +63,17 @@ def _sdf_col(W):
 
 class GeometricMain(Function):
     """(x, cfg, *grids, *W, *b) -> sdf (..,1), feature (..,D), n (..,3), Z (.., ldz).
-    `cfg` = (M, skip_at, scale, min, max, families): one grid-feature family name per grid tensor.
+    `cfg` = (M, skip_at, scale, min, max, families, ste): one grid-feature family name per grid tensor; `ste`
+    (`voxel.use_ste`, config/ste.yaml): the grid lookups contribute nothing to n = d(sdf)/dx -- the reference's registered
+    backward returns (None, None) for them (python/grid_feature/voxel_feature.py:383-399) -- so J_e(x) is the positional
+    encoding's Jacobian alone: no grad_query in the forward, no grad_query_grad_* in the backward.
     Z = [x | feature | n | spare columns] is the packed input of the per-sample material nets (cat(x, feature, normal),
     python/network.py:235-263, 300-336, 380-509): `feature` is a view of its columns, and a gradient arriving for Z counts
     for feature and n."""
 
     @staticmethod
     def forward(ctx, x, cfg, *tensors):
-        M, skip_at, scale, min_, max_, fam_names = cfg
+        M, skip_at, scale, min_, max_, fam_names, ste = cfg
         NG = len(fam_names)
         grids, params = list(tensors[:NG]), tensors[NG:]
         fams = [_core.FAMILIES[f] for f in fam_names]
@@ -152,6 +155,8 @@ class GeometricMain(Function):
         # ---- n = J_e(x)^T g_0 (one launch; it also completes Z and moves the sdf out of it) ----
         gqs, gos = [], []
         for fam, fd, sa, C, c0 in enc:
+            if ste:
+                break
             go = torch.empty((P, C), device=dev, dtype=torch.float32)
             lib.call("copy_columns", P, C, _Strided(g0[:, c0:]), K0, go, C)
             gq = torch.empty((P, 3), device=dev, dtype=torch.float32)
@@ -162,7 +167,7 @@ class GeometricMain(Function):
         sdf = torch.empty((P, 1), device=dev, dtype=torch.float32)
         lib.call("geo_normal", P, M, e, K0, g0, K0, len(gqs), gqs, n, Z, ldz, D, sdf)
 
-        ctx.cfg = (M, skip_at, scale, min_, max_, L, tuple(x.shape), fam_names, bskip, split)
+        ctx.cfg = (M, skip_at, scale, min_, max_, L, tuple(x.shape), fam_names, bskip, split, ste)
         ctx.A, ctx.s_store, ctx.s = A, s_store, s
         ctx.am, ctx.sm = am, sm
         ctx.aux = (xf, gos, ldz)
@@ -174,7 +179,7 @@ class GeometricMain(Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_sdf, g_feat, g_n, g_Z):
-        M, skip_at, scale, min_, max_, L, xshape, fam_names, bskip, split = ctx.cfg
+        M, skip_at, scale, min_, max_, L, xshape, fam_names, bskip, split, ste = ctx.cfg
         saved = ctx.saved_tensors
         W = list(saved[:L])
         grids = list(saved[L:])
@@ -220,12 +225,14 @@ class GeometricMain(Function):
         if nbar is not None:
             # ---- g-bar_0 = J_e(x) n-bar ----
             ggos = []
-            for (fam, fd, sa, C, c0, gdst, _), go in zip(enc, gos):
+            for (fam, fd, sa, C, c0, gdst, _), go in zip(enc, [] if ste else gos):
                 ggo = torch.empty((P, C), device=dev, dtype=torch.float32)
                 _enc_call(fam, "grad_query_grad_grad_output", P, C, ggo, nbar, xf, fd, *sa, min_, max_, 0, 0)
                 ggos.append(ggo)
                 # n depends on the grid directly through the interpolation derivative
                 _enc_call(fam, "grad_query_grad_feature", P, C, gdst, nbar, go, xf, *sa, min_, max_, 0, 1)
+            if ste:      # J_e(x) without the grid part: zero columns where the grid encodings sit (the kernel takes its row
+                ggos = [torch.zeros((P, C), device=dev, dtype=torch.float32) for (_, _, _, C, _, _, _) in enc]   # width from the segments)
             gb0 = torch.empty((P, K0), device=dev, dtype=torch.float32)
             lib.call("geo_gbar0", P, M, e, K0, nbar, len(ggos), ggos, [t.shape[1] for t in ggos], gb0)
             gbar[0] = gb0
@@ -305,12 +312,12 @@ class GeometricMain(Function):
         return (None, None, *g_grids, *gW, *gb)
 
 
-def geometric_main(x, grids, weights, biases, M, skip_at, scale, min_=(-1, -1, -1), max_=(1, 1, 1)):
+def geometric_main(x, grids, weights, biases, M, skip_at, scale, min_=(-1, -1, -1), max_=(1, 1, 1), use_ste=False):
     """grids: None, one dense-voxel feature tensor, or a list of (family name, feature tensor) in the order their
     outputs are concatenated behind the positional encoding."""
     if grids is None:
         grids = []
     elif torch.is_tensor(grids):
         grids = [("voxel", grids)]
-    cfg = (int(M), int(skip_at), float(scale), tuple(min_), tuple(max_), tuple(f for f, _ in grids))
+    cfg = (int(M), int(skip_at), float(scale), tuple(min_), tuple(max_), tuple(f for f, _ in grids), bool(use_ste))
     return GeometricMain.apply(x, cfg, *[t for _, t in grids], *weights, *biases)

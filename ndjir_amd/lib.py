@@ -58,7 +58,7 @@ SIGS = {
     "render_pixel_compose": "iiippppp",
     "render_pixel_compose_backward": "iiippppppp" + "p",
     # R N color gt mask grad_x tv0 D0 tv1 D1 prior mask_sum inv_rays weights[5] l2 workspace terms
-    "loss_terms": "iipppppipippfWipp",
+    "loss_terms": "iiipppppipippfWipp",
     "loss_terms_backward": "iippppiippfWippppp",
     "geo_encode": "lipiPApi",
     "geo_normal": "lipipiiPppiip",

@@ -39,6 +39,9 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
     res = pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, conf, rand)
     zero = torch.zeros((), dtype=x_fg.dtype, device=x_fg.device)
     N = x_fg.shape[2]
+    # python/loss.py:36 binds N = n_samples0 and :72 rebinds it to the sample count only inside `if eikonal_weight > 0`;
+    # the priors' normaliser (:118) uses whichever N is bound by then
+    N_prior = N if tr.eikonal_weight > 0.0 else conf.renderer.n_samples0
 
     # The default structure (material head with its per-ray prior sums, no object-mask term): every term below and the
     # weighted total are ONE pass over the rays plus a fixed-order final reduction (csrc/loss.hip), and as much in
@@ -61,8 +64,9 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
         terms = loss_terms(res["color_pixel"], color_gt, mask, res["grad_x_fg"] if tr.eikonal_weight > 0.0 else None,
                            res["prior_partials"], msg, N, 1.0 / (B * R * ray_shards),
                            (tr.eikonal_weight, tr.tv_weight, tr.base_color_prior_weight, tr.roughness_prior_weight,
-                            tr.specular_reflectance_prior_weight), tr.rgb_loss == "l2", tvs)
-        out = {k: terms[i] for i, k in enumerate(LOSS_TERM_NAMES)}
+                            tr.specular_reflectance_prior_weight), tr.rgb_loss == "l2", tvs, N_prior=N_prior)
+        # only the total carries a gradient (the kernel pair differentiates terms[0]); the reported terms are detached
+        out = {k: (terms[i] if i == 0 else terms[i].detach()) for i, k in enumerate(LOSS_TERM_NAMES)}
         # (a term whose weight is zero is reported as zero, as the reference does not evaluate it)
         for k, w in (("loss_eikonal", tr.eikonal_weight), ("prior_base_color", tr.base_color_prior_weight),
                      ("prior_roughness", tr.roughness_prior_weight), ("reg_std_roughness", tr.roughness_prior_weight),
@@ -102,6 +106,7 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
         mask_sum = mask_sum.clone()
         dist.all_reduce(mask_sum)
     denorm = mask_sum * N + 1e-5
+    denorm_prior = mask_sum * N_prior + 1e-5
 
     # Eikonal loss (loss.py:68-76)
     loss_eikonal = zero
@@ -133,14 +138,14 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
     pp = res.get("prior_partials")
     if pp is not None:
         # per-ray sums of the five integrands from the fused material head (volume.material_head)
-        pm = (pp * mask.reshape(B, R, 1)).sum(dim=(0, 1)) / denorm
+        pm = (pp * mask.reshape(B, R, 1)).sum(dim=(0, 1)) / denorm_prior
     prior_base_color = zero
     if pp is not None:
         if tr.base_color_prior_weight > 0.0:
             prior_base_color = pm[0]
     elif tr.base_color_prior_weight > 0.0:
         bc = res["base_color"] if tr.base_color_prior_sym_backward else res["base_color"].detach()
-        prior_base_color = ((bc - res["base_color_ptb"]).abs() * mask).sum() / denorm
+        prior_base_color = ((bc - res["base_color_ptb"]).abs() * mask).sum() / denorm_prior
 
     prior_roughness = reg_std_roughness = zero
     if pp is not None:
@@ -148,8 +153,8 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
             prior_roughness, reg_std_roughness = pm[1], pm[2]
     elif tr.roughness_prior_weight > 0.0:
         pr = (res["roughness"] - conf.roughness_network.prior_value).abs() / res["std_roughness"]
-        prior_roughness = (pr * mask).sum() / denorm
-        reg_std_roughness = (torch.log(res["std_roughness"]).clamp(1e-5, 1e5) * mask).sum() / denorm
+        prior_roughness = (pr * mask).sum() / denorm_prior
+        reg_std_roughness = (torch.log(res["std_roughness"]).clamp(1e-5, 1e5) * mask).sum() / denorm_prior
 
     prior_spec = reg_std_spec = zero
     if pp is not None:
@@ -158,8 +163,8 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, conf, rand,
     elif tr.specular_reflectance_prior_weight > 0.0:
         ps = (res["specular_reflectance"] - conf.specular_reflectance_network.prior_value).abs() \
             / res["std_specular_reflectance"]
-        prior_spec = (ps * mask).sum() / denorm
-        reg_std_spec = (torch.log(res["std_specular_reflectance"]).clamp(1e-5, 1e5) * mask).sum() / denorm
+        prior_spec = (ps * mask).sum() / denorm_prior
+        reg_std_spec = (torch.log(res["std_specular_reflectance"]).clamp(1e-5, 1e5) * mask).sum() / denorm_prior
 
     loss = (loss_rgb + tr.eikonal_weight * loss_eikonal + tr.tv_weight * loss_tv + tr.mask_weight * loss_mask
             + tr.base_color_prior_weight * prior_base_color + tr.roughness_prior_weight * prior_roughness

@@ -178,7 +178,7 @@ def uses_fused_geometric(conf):
     """True when `geometric_network_with_grad` runs as fused chains that produce d(sdf)/dx themselves (no autograd
     graph needed for a forward-only render)."""
     g = conf.geometric_network
-    return bool(USE_FUSED and g.geometric_init and g.act == "softplus" and g.voxel.type in _FUSED_GRIDS and not g.voxel.use_ste)
+    return bool(USE_FUSED and g.geometric_init and g.act == "softplus" and g.voxel.type in _FUSED_GRIDS)
 
 
 def geometric_network_with_grad(x, conf, packed=False):
@@ -197,7 +197,7 @@ def geometric_network_with_grad(x, conf, packed=False):
         Ws, bs, skip_at, scale = _geometric_param_lists(conf)
         params = P.get_parameters()
         grids = [(f, params[f"geometric-network/{scope}/F"]) for f, scope in fused_grids[v.type]]
-        sdf, feat, grad_x, Z = geometric_main(x, grids, Ws, bs, g.pe_bands, skip_at, scale)
+        sdf, feat, grad_x, Z = geometric_main(x, grids, Ws, bs, g.pe_bands, skip_at, scale, use_ste=v.use_ste)
         with P.parameter_scope("geometric-network"):
             gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain]), True)
         gain = torch.exp(gain * 10).clamp(1e-6, 5e4)

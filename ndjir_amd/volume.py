@@ -313,12 +313,13 @@ class LossTerms(Function):
     their weighted total in one pass over the rays plus a fixed-order final reduction (csrc/loss.hip).
     color, color_gt (B,R,3); mask (B,R,1,1); grad_x (B,R,N,3) or None; prior (B,R,5) or None (per-ray sums of the material
     head); mask_sum_global 0-d tensor or None; cfg = (N, inv_rays, (w_eikonal, w_tv, w_base_color, w_roughness,
-    w_specular), l2); tvs: up to two (B,R,N,D) sampled TV tensors.
-    -> terms (12,): see LOSS_TERM_NAMES for [0..8]; only terms[0] (the total) carries a gradient."""
+    w_specular), l2, N_prior); tvs: up to two (B,R,N,D) sampled TV tensors.
+    -> terms (12,): see LOSS_TERM_NAMES for [0..8]; only terms[0] (the total) carries a gradient -- take the other
+    entries detached (`total_loss` does)."""
 
     @staticmethod
     def forward(ctx, color, color_gt, mask, grad_x, prior, mask_sum_global, cfg, *tvs):
-        N, inv_rays, weights, l2 = cfg
+        N, inv_rays, weights, l2, N_prior = cfg
         R = color.shape[0] * color.shape[1]
         dev = color.device
         assert len(tvs) <= 2
@@ -327,7 +328,7 @@ class LossTerms(Function):
         args = [_c(color), _c(color_gt), _c(mask).reshape(-1), None if grad_x is None else _c(grad_x)]
         ws = torch.empty(lib.load().ndjir_loss_terms_workspace(R), device=dev, dtype=torch.float32)
         terms = torch.empty(12, device=dev, dtype=torch.float32)
-        lib.call("loss_terms", R, N, *args, tv[0], D[0], tv[1], D[1], None if prior is None else _c(prior),
+        lib.call("loss_terms", R, N, N_prior, *args, tv[0], D[0], tv[1], D[1], None if prior is None else _c(prior),
                  None if mask_sum_global is None else _c(mask_sum_global).reshape(1), float(inv_rays), [float(w) for w in weights],
                  int(l2), ws, terms)
         ctx.save_for_backward(args[0], args[1], args[2], *([args[3]] if args[3] is not None else []), terms)
@@ -355,6 +356,7 @@ class LossTerms(Function):
         return (g_color, None, None, g_gx, g_prior, None, None, *g_tv[:n_tv])
 
 
-def loss_terms(color, color_gt, mask, grad_x, prior, mask_sum_global, N, inv_rays, weights, l2, tvs):
-    return LossTerms.apply(color, color_gt, mask, grad_x, prior, mask_sum_global, (int(N), float(inv_rays), tuple(weights), bool(l2)),
-                           *tvs)
+def loss_terms(color, color_gt, mask, grad_x, prior, mask_sum_global, N, inv_rays, weights, l2, tvs, N_prior=None):
+    """N_prior: the N that divides the five prior sums (python/loss.py:118); None = N."""
+    return LossTerms.apply(color, color_gt, mask, grad_x, prior, mask_sum_global,
+                           (int(N), float(inv_rays), tuple(weights), bool(l2), int(N if N_prior is None else N_prior)), *tvs)

@@ -43,12 +43,18 @@ def positional_encoding(x, M=6, include_input=True):
 
 
 def query_on_grid(x, params, conf, scope="geometric-network"):
-    """network.py:120-151.  x (..., 3) -> (..., C) or None."""
+    """network.py:120-151.  x (..., 3) -> (..., C) or None.
+    `voxel.use_ste` (config/ste.yaml:22): the registered `nn.grad` backward of every grid op returns (None, None)
+    (grid_feature/voxel_feature.py:383-399 and the same lines of the other families), i.e. d(sdf)/dx does not flow
+    through the grid lookup; `.backward()` (backward_impl, :108-116) still reaches the grid parameter.  The query
+    point is no parameter, so detaching it for the lookup is exactly that."""
     v = conf.geometric_network.voxel
     typ = v.type
     if typ == "none":
         return None
     q = x.reshape(-1, 3)
+    if v.use_ste:
+        q = q.detach()
 
     def one(kind_topo):
         if kind_topo.startswith("lanczos_"):
@@ -588,6 +594,9 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, rand, param
         loss_rgb = err.sum() / (B * R)
 
     denorm = mask.sum() * N + 1e-5
+    # loss.py:36 binds N = n_samples0; :72 rebinds N to the sample count only inside `if eikonal_weight > 0` (the
+    # nested compute_tv_loss has its own N); :118 forms the priors' normaliser from whichever N is bound by then
+    denorm_prior = mask.sum() * (N if tr.eikonal_weight > 0.0 else conf.renderer.n_samples0) + 1e-5
     loss_eikonal = zero
     if tr.eikonal_weight > 0.0:
         gx = res["grad_x_fg"]
@@ -613,20 +622,20 @@ def total_loss(camloc, raydir, color_gt, obj_mask, cos_anneal_ratio, rand, param
     prior_base_color = zero
     if tr.base_color_prior_weight > 0.0:
         bc = res["base_color"] if tr.base_color_prior_sym_backward else res["base_color"].detach()
-        prior_base_color = ((bc - res["base_color_ptb"]).abs() * mask).sum() / denorm
+        prior_base_color = ((bc - res["base_color_ptb"]).abs() * mask).sum() / denorm_prior
 
     prior_roughness = reg_std_roughness = zero
     if tr.roughness_prior_weight > 0.0:
         pr = (res["roughness"] - conf.roughness_network.prior_value).abs() / res["std_roughness"]
-        prior_roughness = (pr * mask).sum() / denorm
-        reg_std_roughness = (torch.log(res["std_roughness"]).clamp(1e-5, 1e5) * mask).sum() / denorm
+        prior_roughness = (pr * mask).sum() / denorm_prior
+        reg_std_roughness = (torch.log(res["std_roughness"]).clamp(1e-5, 1e5) * mask).sum() / denorm_prior
 
     prior_spec = reg_std_spec = zero
     if tr.specular_reflectance_prior_weight > 0.0:
         ps = (res["specular_reflectance"] - conf.specular_reflectance_network.prior_value).abs() \
             / res["std_specular_reflectance"]
-        prior_spec = (ps * mask).sum() / denorm
-        reg_std_spec = (torch.log(res["std_specular_reflectance"]).clamp(1e-5, 1e5) * mask).sum() / denorm
+        prior_spec = (ps * mask).sum() / denorm_prior
+        reg_std_spec = (torch.log(res["std_specular_reflectance"]).clamp(1e-5, 1e5) * mask).sum() / denorm_prior
 
     loss = (loss_rgb + tr.eikonal_weight * loss_eikonal + tr.tv_weight * loss_tv
             + tr.mask_weight * loss_mask + tr.base_color_prior_weight * prior_base_color

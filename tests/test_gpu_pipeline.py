@@ -14,9 +14,10 @@ PIXEL_TOL = 1e-4
 GRAD_RTOL = 2e-3   # fp32 round-off through double backward; fp32-vs-fp64 oracle itself shows ~1e-4
 
 
-@pytest.mark.parametrize("variant,G", [("default", 32), ("no_voxel", 8), ("triplaneline", 64), ("custom", 32)])
+@pytest.mark.parametrize("variant,G", [("default", 32), ("no_voxel", 8), ("triplaneline", 64), ("custom", 32), ("ste", 32)])
 def test_step_parity_given_samples(gpu, variant, G):
-    """Renderer + loss + backward parity with the oracle fed the product's sample points."""
+    """Renderer + loss + backward parity with the oracle fed the product's sample points.  `ste` = config/ste.yaml
+    (`voxel.use_ste`: the grid lookups stay out of n = d(sdf)/dx, python/grid_feature/voxel_feature.py:383-399)."""
     conf = small_conf(grid_size=G, n_rays=16, variant=variant)
     prod = run_product_step(conf, B=2, R=16, device=gpu)
     s = prod["samples"]
@@ -43,6 +44,50 @@ def test_step_parity_given_samples(gpu, variant, G):
                                         samples=(s["x_fg"], s["t_fg"], s["x_bg"], s["t_bg"], s["mask"]))
             e64, o64 = rel_err(gp, ref64["grads"][k]), rel_err(g, ref64["grads"][k])
             assert e64 <= 3 * o64, (k, e, e64, o64)
+
+
+def test_ste_fused_path_matches_layer_by_layer(gpu):
+    """config/ste.yaml through the fused geometric operator (J_e without the grid part) and through the layer-by-layer
+    autograd path (the grid operator's nn.grad backward returning None for the query): same loss and gradients."""
+    from ndjir_amd import network
+    conf = small_conf(grid_size=32, n_rays=8, variant="ste")
+    assert network.uses_fused_geometric(conf)
+    fused = run_product_step(conf, B=1, R=8, device=gpu)
+    network.USE_FUSED = False
+    try:
+        plain = run_product_step(conf, B=1, R=8, device=gpu)
+    finally:
+        network.USE_FUSED = True
+    assert abs(float(fused["loss"]) - float(plain["loss"])) <= 2e-5 * abs(float(plain["loss"]))
+    for k, g in plain["grads"].items():
+        gp = fused["grads"][k]
+        assert (g is None) == (gp is None), k
+        if g is not None:
+            assert rel_err(gp, g) < GRAD_RTOL, (k, rel_err(gp, g))
+
+
+@pytest.mark.parametrize("fused_tail", [True, False])
+def test_prior_normaliser_without_eikonal_term(gpu, fused_tail, monkeypatch):
+    """python/loss.py:36, 72, 118: with train.eikonal_weight = 0 the priors are divided by sum(mask) n_samples0, not by
+    sum(mask) times the sample count -- in the fused loss tail (csrc/loss.hip, N_prior) and in the stock-op branch."""
+    from ndjir_amd import loss as L
+    monkeypatch.setattr(L, "_NO_FUSED_TAIL", not fused_tail)
+    conf = small_conf(grid_size=16, n_rays=8, overrides=["train.eikonal_weight=0", "train.base_color_prior_weight=1.0",
+                                                         "train.roughness_prior_weight=0.01"])
+    prod = run_product_step(conf, B=1, R=8, device=gpu)
+    s = prod["samples"]
+    ref = run_oracle_step(conf, prod["params_cpu"], prod["inputs_cpu"],
+                          samples=(s["x_fg"], s["t_fg"], s["x_bg"], s["t_bg"], s["mask"]))
+    l0, l1 = float(prod["loss"]), float(ref["loss"])
+    assert abs(l0 - l1) <= LOSS_RTOL * abs(l1), (l0, l1)
+    assert float(prod["terms"]["loss_eikonal"]) == 0.0
+    for k, v in ref["terms"].items():
+        assert abs(float(prod["terms"][k]) - float(v)) <= 2e-4 * max(abs(float(v)), 1e-3), k
+    for k, g in ref["grads"].items():
+        gp = prod["grads"][k]
+        assert (g is None) == (gp is None), k
+        if g is not None:
+            assert rel_err(gp, g) < 3 * GRAD_RTOL, (k, rel_err(gp, g))
 
 
 # BASELINE.json config 1 (no up-sampling rounds: 64 samples / ray) and config 5's sampler setting

@@ -98,3 +98,76 @@ def test_importance_round_c_vs_torch(N, M):
     assert bool((t_c[:, :, 1:] >= t_c[:, :, :-1]).all())
     same = (i_c == i_t).all(dim=2)
     np.testing.assert_allclose(t_c[same].numpy(), t_t[same].numpy(), atol=2e-5)
+
+
+def test_prior_normaliser_follows_the_bound_N():
+    """python/loss.py:36 binds N = n_samples0, :72 rebinds it to the sample count only inside `if eikonal_weight > 0`,
+    :118 divides the priors by sum(mask) N: with the eikonal term switched off the priors are n_samples / n_samples0
+    times larger, every other term unchanged."""
+    conf_on = small_conf(grid_size=8, n_rays=4, variant="default")
+    conf_off = small_conf(grid_size=8, n_rays=4, variant="default", overrides=["train.eikonal_weight=0"])
+    p = random_oracle_params(conf_on)
+    inp = _inputs(conf_on, 1, 4)
+    on = run_oracle_step(conf_on, p, inp, torch.float64, backward=False)
+    samples = [on["out"][k] for k in ("x_fg", "t_fg", "x_bg", "t_bg", "mask")]
+    off = run_oracle_step(conf_off, p, inp, torch.float64, backward=False, samples=samples)
+    r = conf_on.renderer
+    ratio = (r.n_samples0 + r.n_samples1 * r.n_upsamples) / r.n_samples0
+    msum = float(on["out"]["mask"].sum())
+    assert msum > 0
+    for k in ("prior_base_color", "prior_roughness", "reg_std_roughness", "prior_specular_reflectance",
+              "reg_std_specular_reflectance"):
+        a, b = float(on["terms"][k]), float(off["terms"][k])
+        # (a * (msum N + 1e-5) = b * (msum N0 + 1e-5): the 1e-5 keeps the ratio from being exact)
+        assert abs(b / a - ratio) < 1e-6 * ratio, (k, a, b)
+    assert float(off["terms"]["loss_eikonal"]) == 0.0
+    for k in ("loss_rgb", "loss_tv"):
+        assert float(on["terms"][k]) == float(off["terms"][k])
+
+
+def test_ste_cuts_the_grid_out_of_the_normal():
+    """config/ste.yaml (`voxel.use_ste: true`): the grid ops' registered nn.grad backward returns (None, None)
+    (python/grid_feature/voxel_feature.py:383-399), so n = d(sdf)/dx is the derivative through the positional encoding
+    alone; the sdf itself, and the grid parameter's gradient through `.backward()`, are unaffected."""
+    conf = small_conf(grid_size=8, n_rays=4, variant="default")
+    ste = small_conf(grid_size=8, n_rays=4, variant="ste")
+    assert ste.geometric_network.voxel.use_ste and not conf.geometric_network.voxel.use_ste
+    p = {k: v.double() for k, v in random_oracle_params(conf).items()}
+    p["geometric-network/voxel_feature/F"] = p["geometric-network/voxel_feature/F"] * 30      # make the grid matter
+    x = (torch.rand(64, 3, dtype=torch.float64) * 1.6 - 0.8).requires_grad_(True)
+    n = {}
+    for name, c in (("plain", conf), ("ste", ste)):
+        sdf, _, _ = G.geometric_network(x, p, c)
+        n[name] = torch.autograd.grad(sdf.sum(), x, create_graph=True)[0]
+        if name == "plain":
+            sdf_plain = sdf.detach()
+        else:
+            assert torch.equal(sdf.detach(), sdf_plain)
+    assert float((n["plain"] - n["ste"]).abs().max()) > 1e-3
+    # the same derivative with the grid feature held constant (a grid whose lookups do not depend on x)
+    vf = G.query_on_grid(x.detach(), p, conf)
+
+    def sdf_const_grid(xx):
+        pe = G.positional_encoding(xx, conf.geometric_network.pe_bands)
+        inputs = torch.cat([pe, vf], dim=-1)
+        h = inputs
+        L = conf.geometric_network.layers
+        for l in range(L):
+            if l == L - 1:
+                h = G.affine(p, "geometric-network/affine-last", h)
+            else:
+                h = G.softplus100(G.affine(p, f"geometric-network/affine-{l:02d}", h))
+                if l != 0 and l not in conf.geometric_network.skip_layers and (l + 1) in conf.geometric_network.skip_layers:
+                    h = torch.cat([h, inputs], dim=-1) / np.sqrt(2)
+        return h[..., 0:1]
+    x2 = x.detach().clone().requires_grad_(True)
+    n_ref = torch.autograd.grad(sdf_const_grid(x2).sum(), x2)[0]
+    np.testing.assert_allclose(n["ste"].detach().numpy(), n_ref.numpy(), rtol=1e-10, atol=1e-12)
+    # the grid parameter still receives a gradient from a loss on n and sdf under STE (through the sdf path only)
+    F = p["geometric-network/voxel_feature/F"].clone().requires_grad_(True)
+    p2 = dict(p)
+    p2["geometric-network/voxel_feature/F"] = F
+    sdf, _, _ = G.geometric_network(x, p2, ste)
+    nn_ = torch.autograd.grad(sdf.sum(), x, create_graph=True)[0]
+    gF = torch.autograd.grad((nn_ ** 2).sum() + sdf.sum(), F)[0]
+    assert float(gF.abs().max()) > 0
