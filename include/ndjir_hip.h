@@ -446,6 +446,11 @@ int ndjir_inverse_squared_distance(long long P, long long rows_per_batch, const 
                                  FMA chain's, 3/16 of the matrix time (default) */
 int ndjir_mlp_set_math(int math);   /* selects the arithmetic of pack / chain; packed weights are mode specific */
 int ndjir_mlp_get_math(void);
+/* Points per workgroup tile of the f16x3 chain kernels: 0 = per launch (128 for launches of >= 32768 points that the
+ * wide-tile kernel supports, else 64; 32 for small launches), 32 / 64 / 128 = forced (128: where supported).  A point's
+ * forward result does not depend on the tile height. */
+int ndjir_mlp_set_tile_rows(int rows);
+int ndjir_mlp_get_tile_rows(void);
 long long ndjir_mlp_packed_size(int K, int N, int transpose);
 int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
 int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L,

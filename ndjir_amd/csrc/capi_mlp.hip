@@ -41,6 +41,20 @@ extern "C" int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int tran
 
 static long long* g_timeline = nullptr;   // diagnostics only, see ndjir_mlp_debug_timeline
 
+// Points per workgroup tile of the chain kernels: 0 = chosen per launch (128 for large launches the wide-tile kernel
+// supports, else 64, 32 for small launches); 32 / 64 / 128 force one (128: where supported).  Results do not depend on it.
+static int g_tile_rows = -1;
+static int tile_rows_setting() {
+  if (g_tile_rows < 0) { const char* e = getenv("NDJIR_MLP_TILE"); g_tile_rows = e ? atoi(e) : 0; }
+  return g_tile_rows;
+}
+extern "C" int ndjir_mlp_set_tile_rows(int rows) {
+  if (rows != 0 && rows != 32 && rows != 64 && rows != 128) return NDJIR_ERR_ARG;
+  g_tile_rows = rows;
+  return NDJIR_OK;
+}
+extern "C" int ndjir_mlp_get_tile_rows(void) { return tile_rows_setting(); }
+
 static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int L,
                                const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
                                const float* const* side_in, float* const* side_out, const int* ld_side,
@@ -61,10 +75,12 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
   if (!X || L < 1 || L > MAX_CHAIN_LAYERS || !Wp || !Ks || !Ns) return NDJIR_ERR_ARG;
   if (has_output && !Y) return NDJIR_ERR_ARG;
   ChainArgs a{};
-  // 64-point tiles; 32-point tiles when 64 would leave CUs without a tile (small launches such as the
-  // sampler's 16-samples-per-ray rounds).  Results do not depend on the tile height.  NDJIR_MLP_TILE forces one.
-  static const int tile_env = [] { const char* e = getenv("NDJIR_MLP_TILE"); return e ? atoi(e) : 0; }();
-  a.tile_rows = tile_env ? tile_env : ((P + 63) / 64 < 256 ? 32 : 64);
+  // 128-point tiles (mlp3w.hip) for large launches, else 64-point tiles; 32-point tiles when 64 would leave CUs without a
+  // tile (small launches such as the sampler's 16-samples-per-ray rounds).  Results do not depend on the tile height.
+  // NDJIR_MLP_TILE / ndjir_mlp_set_tile_rows force one.
+  const int forced = tile_rows_setting();
+  a.tile_rows = forced ? forced : ((P + 63) / 64 < 256 ? 32 : 64);
+  a.forced_tile = forced;
   a.timeline = g_timeline;
   a.bg_partial = workspace;
   if (row_bias && (bwd != 0 || L < 2 || row_bias_div < 1)) return NDJIR_ERR_ARG;

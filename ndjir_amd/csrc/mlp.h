@@ -37,7 +37,8 @@ struct ChainArgs {
                         // bwd: layer whose output is that concatenated gradient
   int skip_split;       // bwd: first column of the concatenated-input part
   int lds_split;        // filled by launch_chain
-  int tile_rows;        // 64 (default) or 32 points per workgroup
+  int tile_rows;        // 64 (default), 32 or 128 points per workgroup
+  int forced_tile;      // tile_rows was forced by the caller (else 64 may be widened to 128 where mlp3w.hip supports the launch)
   float skip_scale;
   float beta;
   const float* row_bias;  // forward: (P / row_bias_div, N_0) term added to the first layer's pre-activation of each row group
@@ -62,6 +63,8 @@ int launch_chain6(const ChainArgs& a, int mode, hipStream_t stream);
 long long packed_size3(int K, int N, int transpose);
 int launch_pack3(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
 int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream);
+// f16 2-way-split engine on 128-point tiles (mlp3w.hip); NDJIR_ERR_UNSUPPORTED = not a launch for this kernel
+int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream);
 constexpr int CHAIN_MAX_GRID_BG = 512;   // workgroups of a chain launch that produces bias gradients
 inline long long chain_workspace(int bg_total) { return (long long)CHAIN_MAX_GRID_BG * bg_total; }
 long long wgrad_workspace(int K, int N, long long P);

@@ -31,9 +31,12 @@
 
 #include "common.h"
 #include "mlp.h"
+#include "mlp3_util.h"
 
 namespace ndjir {
 namespace x3 {
+
+using namespace x3u;
 
 constexpr int NWAVES = 8;
 constexpr int NTHREADS = NWAVES * 64;
@@ -41,69 +44,12 @@ constexpr int MAXNB = 16;        // widest layer: 512 columns (2 column blocks p
 constexpr int GPS = 32 * 4 + 4;  // staging tile: dwords per group of 4 columns (32 rows + pad)
 constexpr int STG = 8 * GPS;     // staging dwords per wave (32 x 32 tile)
 constexpr int IN_CACHE = 10;     // float4 groups of the chain input a thread keeps between the max pass and the split
-constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
 #ifndef NDJIR_BWD_KLOOP_BARRIER
 #define NDJIR_BWD_KLOOP_BARRIER 0
 #endif
 constexpr bool BWD_KLOOP_BARRIER = NDJIR_BWD_KLOOP_BARRIER;   // (A/B switch; measured +-0 on the backward chain, off)
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
-
-__device__ __forceinline__ int pin(int v) {
-  v = __builtin_amdgcn_readfirstlane(v);
-  asm volatile("" : "+s"(v));
-  return v;
-}
-__device__ __forceinline__ float pin(float v) { return __int_as_float(pin(__float_as_int(v))); }
-template <class T>
-using gptr = T __attribute__((address_space(1)))*;
-template <class T>
-__device__ __forceinline__ gptr<T> pin(T* p) {
-  asm volatile("" : "+s"(p));
-  return (gptr<T>)p;
-}
-
-// Power-of-two scale that puts a group whose largest finite magnitude has bit pattern `mbits` at [2^14, 2^15);
-// inv = 1 / s exactly.  An all-zero group gets a large harmless scale.
-__host__ __device__ __forceinline__ void scale_from_max(unsigned mbits, float& s, float& inv) {
-  int E = (int)(mbits >> 23);
-  if (E < 1) E = 1;
-  int se = 268 - E;                  // biased exponent of s: max * s = 1.x * 2^14
-  if (se > 253) se = 253;
-  if (se < 1) se = 1;
-  union { int i; float f; } a, b;
-  a.i = se << 23;
-  b.i = (254 - se) << 23;
-  s = a.f;
-  inv = b.f;
-}
-
-// |v| as ordered bits, Inf / NaN ignored (they stay confined to their own rows; the group's scale is taken from
-// the finite values)
-__device__ __forceinline__ unsigned finite_abs_bits(float v) {
-  const unsigned b = __float_as_uint(v) & 0x7fffffffu;
-  return b < 0x7f800000u ? b : 0u;
-}
-
-__device__ __forceinline__ float wave_max(float m) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  return m;
-}
-
-// lane-crossing without the LDS crossbar (ds_bpermute + lgkmcnt round trip): DPP controls of gfx9
-//   quad_perm [1,0,3,2] = xor 1, quad_perm [2,3,0,1] = xor 2, row_half_mirror (i -> 7 - i inside a group of 8 lanes),
-//   row_ror:8 = xor 8 inside a row of 16 lanes
-template <int CTRL>
-__device__ __forceinline__ float dpp(float v) {
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROR8 = 0x128;
 
 // ---- weight packing -----------------------------------------------------------------------------
 // dst (16-byte units): [Np/32][Kp/16][plane 0..1][lane 0..63], lane (c = lane & 31, h = lane >> 5) holds
@@ -180,18 +126,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
   };
   // write 4 consecutive features k..k+3 (k % 4 == 0) of row m, scaled by s, into the two planes
   auto put4 = [&](int k, int m, f32x4 v, float s) {
-    const f32x4 xs = v * s;
-    const f16x4 ph = __builtin_convertvector(xs, f16x4);
-    const f32x4 res = (xs - __builtin_convertvector(ph, f32x4)) * LO_SCALE;
-    const f16x4 pl = __builtin_convertvector(res, f16x4);
+    f16x4 ph, pl;
+    split4(v, s, ph, pl);
     char* p = actb + ((size_t)((k >> 3) * TMP + m) * 16 + (k & 7) * 2);
     *reinterpret_cast<f16x4*>(p) = ph;
     *reinterpret_cast<f16x4*>(p + (size_t)PLANE * 16) = pl;
   };
   auto put1 = [&](int k, int m, float v, float s) {
-    const float xs = v * s;
-    const _Float16 ph = (_Float16)xs;
-    const _Float16 pl = (_Float16)((xs - (float)ph) * LO_SCALE);
+    _Float16 ph, pl;
+    split1(v, s, ph, pl);
     char* p = actb + ((size_t)((k >> 3) * TMP + m) * 16 + (k & 7) * 2);
     *reinterpret_cast<_Float16*>(p) = ph;
     *reinterpret_cast<_Float16*>(p + (size_t)PLANE * 16) = pl;
@@ -399,7 +342,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         float* part = stage_all;                 // [kq][m][n]: KSPLIT x TM x 32 floats
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (kq < KSPLIT) part[(kq * TM + rb * 32 + acc_row(i, h)) * 32 + r] = fmaf(acc1[0][i], LO_INV, acc0[0][i]);
+          if (kq < KSPLIT) part[(kq * TM + rb * 32 + acc_row(i, h)) * 32 + r] = acc_sum(acc0[0][i], acc1[0][i]);
         __syncthreads();
         const float winv = p_winv[0];
         for (int t = tid; t < TM * 32; t += NTHREADS) {
@@ -407,15 +350,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
           float z = 0.f;
 #pragma unroll
           for (int q = 0; q < KSPLIT; ++q) z += part[q * TM * 32 + t];
-          z = z * s_ainv[m] * winv;
+          z = out_z(z, s_ainv[m], winv);
           if (n < l_N && m < rows) {
-            if (MODE == 0) {
-              z += p_bias ? p_bias[n] : 0.f;
-              if (!last) { const float bz = beta * z; z = bz > 20.f ? z : log1pf(__expf(bz)) / beta; }
-            }
-            if (last) {
+            if (MODE == 0) z = out_add(z, p_bias ? p_bias[n] : 0.f);
+            if (last) {      // (a narrow layer is always an output layer: chain_impl refuses it elsewhere)
               float* y = a.Y + (row0 + m) * a.ldy + n;
-              *y = a.accum_y ? *y + z : z;
+              *y = a.accum_y ? out_add(z, *y) : z;
             }
           }
         }
@@ -558,21 +498,20 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         const gptr<float> b_out2 = (MODE == 2 && p_side_out2) ? p_side_out2 + tile_off : nullptr;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const float wk = MODE == 0 ? winv[j] * b2 : winv[j];
+          const float wk = winv[j];
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
-            const f32x4 z = pv[j][it] * (sa[j][it] * wk);
-            f32x4 v;
+            f32x4 z, v;
             if (MODE == 0) {
+              const float kk = fwd_kk(sa[j][it], winv[j], b2);
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                float u = z[q] + bb[j][q];                             // b2 * (pre-activation)
-                if (HAS_RB) u = fmaf(hs[j][it][q], b2, u);
-                // softplus_beta(t) = (max(u, 0) + log2(1 + 2^-|u|)) ln2 / beta,  u = beta log2(e) t
-                const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-fabsf(u)));
-                v[q] = (fmaxf(u, 0.f) + l2) * ib2sc;
+                float u = fwd_u(pv[j][it][q], kk, bb[j][q]);          // b2 * (pre-activation)
+                if (HAS_RB) u = fwd_u_rowbias(u, hs[j][it][q], b2);
+                v[q] = softplus_u(u, ib2sc);
               }
             } else {
+              z = pv[j][it] * (sa[j][it] * wk);
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 const float e = __builtin_amdgcn_exp2f(nb2 * hs[j][it][q]);
@@ -767,36 +706,42 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
           const float rm = mrow ? 1.f : 0.f;
           const long long grow = row0 + m;
           const long long off = off0 + (long long)it * 8 * l_ld;
-          const f32x4 z = *reinterpret_cast<const f32x4*>(lp + it * 32) * s_ainv[m] * winv;
+          const f32x4 pvs = *reinterpret_cast<const f32x4*>(lp + it * 32);      // acc0 + acc1 2^-11
+          f32x4 z;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) z[q] = out_z(pvs[q], s_ainv[m], winv);
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
           if (last) {
             if (mrow) {
               float* y = a.Y + grow * a.ldy + n4;
+              f32x4 t = z;
+              if (MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[q] = out_add(z[q], bias4[q]);
+              }
               if (vec_ok && (a.ldy & 3) == 0 && ((uintptr_t)a.Y & 15) == 0) {
-                f32x4 t = z;
-                if (MODE == 0) t += bias4;
-                if (a.accum_y) t += *reinterpret_cast<const f32x4*>(y);
+                if (a.accum_y) {
+                  const f32x4 y0 = *reinterpret_cast<const f32x4*>(y);
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) t[q] = out_add(t[q], y0[q]);
+                }
                 *reinterpret_cast<f32x4*>(y) = t;
               } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                  if (n4 + q < l_N) {
-                    const float t = z[q] + (MODE == 0 ? bias4[q] : 0.f);
-                    y[q] = a.accum_y ? y[q] + t : t;
-                  }
+                  if (n4 + q < l_N) y[q] = a.accum_y ? out_add(t[q], y[q]) : t[q];
                 }
               }
             }
             continue;
           }
           if (MODE == 0) {
+            const float kk = fwd_kk(s_ainv[m], winv, b2);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              float t = z[q] + bias4[q];
-              if (p_rowbias && mrow && n4 + q < l_N) t += p_rowbias[(grow / rb_div) * (long long)l_N + n4 + q];
-              const float u = b2 * t;
-              const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-fabsf(u)));
-              v[q] = (fmaxf(u, 0.f) + l2) * (ib2sc * cm[q] * rm);
+              float u = fwd_u(pvs[q], kk, bias4[q] * b2);
+              if (p_rowbias && mrow && n4 + q < l_N) u = fwd_u_rowbias(u, p_rowbias[(grow / rb_div) * (long long)l_N + n4 + q], b2);
+              v[q] = (cm[q] != 0.f && mrow) ? softplus_u(u, ib2sc) : 0.f;
             }
             if (mrow && p_side_out) {
               if (vec_side) *((gptr<f32x4>)(p_side_out + off)) = v;
@@ -988,6 +933,10 @@ int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream) {
   using namespace x3;
   constexpr int LDS_DYN_MAX = 160 * 1024 - 2048;      // the kernel also holds 1.3 KB of static LDS (row maxima / scales)
   if (a.P <= 0) return NDJIR_OK;
+  if (a.tile_rows == 128 || (a.tile_rows == 64 && a.forced_tile == 0)) {      // large launches: 128-point tiles where supported
+    const int rc = launch_chainw(a, mode, stream);
+    if (rc != NDJIR_ERR_UNSUPPORTED) return rc;
+  }
   int TM = a.tile_rows == 32 ? 32 : 64;
   // widest activation the planes have to hold: chain input, every hidden output (+ skip concat)
   int wmax = round_up(a.K0, 16);

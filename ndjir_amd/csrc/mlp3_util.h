@@ -1,0 +1,119 @@
+// mlp3_util.h -- what the two f16x3 chain kernels share (mlp3.hip: 32 / 64-point tiles with a staged epilogue; mlp3w.hip:
+// 128-point tiles with the epilogue in the accumulator registers): vector types, SGPR pinning, the power-of-two scaling, the
+// two-way f16 split, and -- the reason this header exists -- ONE spelling of every forward expression, with floating-point
+// contraction switched off and the fused multiply-adds written out.  A point's forward result must not depend on which
+// kernel, tile height or code path evaluated it (the sampler evaluates the SDF of new samples only and merges them with
+// earlier evaluations bit for bit; tests/test_gpu_extract.py::test_volume_is_batch_invariant), so neither kernel may leave
+// the choice between a*b+c and fma(a,b,c) to the optimiser.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ndjir {
+namespace x3u {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ int pin(int v) {
+  v = __builtin_amdgcn_readfirstlane(v);
+  asm volatile("" : "+s"(v));
+  return v;
+}
+__device__ __forceinline__ float pin(float v) { return __int_as_float(pin(__float_as_int(v))); }
+template <class T>
+using gptr = T __attribute__((address_space(1)))*;
+template <class T>
+__device__ __forceinline__ gptr<T> pin(T* p) {
+  asm volatile("" : "+s"(p));
+  return (gptr<T>)p;
+}
+
+// Power-of-two scale that puts a group whose largest finite magnitude has bit pattern `mbits` at [2^14, 2^15);
+// inv = 1 / s exactly.  An all-zero group gets a large harmless scale.
+__host__ __device__ __forceinline__ void scale_from_max(unsigned mbits, float& s, float& inv) {
+  int E = (int)(mbits >> 23);
+  if (E < 1) E = 1;
+  int se = 268 - E;                  // biased exponent of s: max * s = 1.x * 2^14
+  if (se > 253) se = 253;
+  if (se < 1) se = 1;
+  union { int i; float f; } a, b;
+  a.i = se << 23;
+  b.i = (254 - se) << 23;
+  s = a.f;
+  inv = b.f;
+}
+
+// |v| as ordered bits, Inf / NaN ignored (they stay confined to their own rows; the group's scale is taken from
+// the finite values)
+__device__ __forceinline__ unsigned finite_abs_bits(float v) {
+  const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+  return b < 0x7f800000u ? b : 0u;
+}
+
+__device__ __forceinline__ float wave_max(float m) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  return m;
+}
+
+// lane-crossing without the LDS crossbar (ds_bpermute + lgkmcnt round trip): DPP controls of gfx9
+//   quad_perm [1,0,3,2] = xor 1, quad_perm [2,3,0,1] = xor 2, row_half_mirror (i -> 7 - i inside a group of 8 lanes),
+//   row_mirror (i -> 15 - i inside a row of 16 lanes), row_ror:8 = xor 8 inside a row of 16 lanes
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128;
+
+// ---- the two-way split:  x s = hi + lo 2^-11 -------------------------------------------------------------------------------
+__device__ __forceinline__ void split4(f32x4 v, float s, f16x4& ph, f16x4& pl) {
+#pragma clang fp contract(off)
+  const f32x4 xs = v * s;
+  ph = __builtin_convertvector(xs, f16x4);
+  const f32x4 res = (xs - __builtin_convertvector(ph, f32x4)) * LO_SCALE;
+  pl = __builtin_convertvector(res, f16x4);
+}
+__device__ __forceinline__ void split1(float v, float s, _Float16& ph, _Float16& pl) {
+#pragma clang fp contract(off)
+  const float xs = v * s;
+  ph = (_Float16)xs;
+  pl = (_Float16)((xs - (float)ph) * LO_SCALE);
+}
+
+// ---- forward expressions (one spelling for every kernel and code path) -----------------------------------------------------
+// the two accumulators of a product:  hi hi'  +  (hi lo' + lo hi') 2^-11
+__device__ __forceinline__ float acc_sum(float acc0, float acc1) { return __builtin_fmaf(acc1, LO_INV, acc0); }
+
+// hidden layer: u = beta log2(e) * (pre-activation);  kk = (1 / row scale) * ((1 / column-block scale) * beta log2(e)),
+// bb = bias * beta log2(e)
+__device__ __forceinline__ float fwd_u(float pv, float kk, float bb) { return __builtin_fmaf(pv, kk, bb); }
+__device__ __forceinline__ float fwd_kk(float row_inv, float winv, float b2) {
+#pragma clang fp contract(off)
+  return row_inv * (winv * b2);
+}
+// + per-row-group term of the first layer
+__device__ __forceinline__ float fwd_u_rowbias(float u, float rb, float b2) { return __builtin_fmaf(rb, b2, u); }
+// softplus_beta(t) = (max(u, 0) + log2(1 + 2^-|u|)) ln2 / beta,  u = beta log2(e) t;  ib2sc = ln2 / beta * (skip scale)
+__device__ __forceinline__ float softplus_u(float u, float ib2sc) {
+#pragma clang fp contract(off)
+  const float l2 = __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-__builtin_fabsf(u)));
+  return (__builtin_fmaxf(u, 0.f) + l2) * ib2sc;
+}
+// output layer / narrow output layer:  z = pv (1 / row scale) (1 / column-block scale)  [+ bias]
+__device__ __forceinline__ float out_z(float pv, float row_inv, float winv) {
+#pragma clang fp contract(off)
+  return (pv * row_inv) * winv;
+}
+__device__ __forceinline__ float out_add(float z, float b) {
+#pragma clang fp contract(off)
+  return z + b;
+}
+
+}  // namespace x3u
+}  // namespace ndjir

@@ -1,0 +1,706 @@
+// mlp3w.hip -- the f16x3 chain (see mlp3.hip for the arithmetic) on 128-point tiles, epilogue in the accumulator registers.
+//
+// Why a second kernel.  In mlp3.hip a weight fragment fetched from L2 feeds the two row blocks of a 64-point tile: a
+// 256-wide layer streams 256 KB of packed weights per tile, 27 B / clk / CU achieved against the ~42 B / clk the matrix pipe
+// could consume -- the k-loops wait for the L2 -> CU stream, not for the MFMAs (measured: k-loop of the slower wave of a SIMD
+// 9.7 k cycles per layer against a 6.1 k matrix floor, with or without the activation stores).  Twice the rows per weight
+// fetch need a 128-point tile, whose two f16 planes (135 KB at 256 columns) leave no room for the 67 KB of fp32 staging
+// tiles through which mlp3.hip transposes its accumulators.  So this kernel does not transpose:
+//   * the MFMA operands are swapped -- A = weight fragment (rows = output features), B = activation fragment (columns =
+//     points) -- so that a lane's 16 accumulator values are 4 x 4 consecutive FEATURES of ONE point.  Bias, activation,
+//     softplus' products, the row maximum (a lane-local max + one LDS atomic), the 2-way split and the plane writes
+//     (ds_write_b64, conflict-free) all happen on the accumulator registers; side loads / stores are 16 bytes per lane
+//     (32 contiguous bytes per point and instruction);
+//   * a wave owns ONE column block and up to FOUR row blocks of it (128 accumulator registers): 12 MFMAs per pair of
+//     weight fragments instead of 6;
+//   * the results wait in the accumulator registers for the row-maximum barrier; no staging memory exists.
+// The packed weights, the plane layout, the scaling groups and every forward expression (mlp3_util.h) are those of
+// mlp3.hip: a point's forward result is bit-identical whichever kernel evaluates it (tests/test_gpu_mlp.py).
+// Launched for P % 128 == 0, P >= 32768, hidden layers of at most 8 column blocks; everything else stays with mlp3.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "mlp.h"
+#include "mlp3_util.h"
+
+namespace ndjir {
+namespace x3w {
+
+using namespace x3u;
+
+constexpr int NWAVES = 8;
+constexpr int NTHREADS = NWAVES * 64;
+constexpr int TM = 128;
+constexpr int TMP = TM + 4;      // rows per k-group incl. pad: (TMP * 16) % 256 == 64 -> conflict-free plane writes
+constexpr int IN_CACHE = 10;     // float4 groups of the chain input a thread keeps between the max pass and the split
+
+// accumulator register i of lane (r = lane & 31, hh = lane >> 5): point r of the row block, feature acc_feat(i, hh) of the
+// column block -- four groups (i >> 2) of four consecutive features
+__device__ __forceinline__ int acc_feat(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
+
+// RPW: row blocks per wave -- 4 (hidden layers of up to 8 column blocks: one wave per column block) or 2 (up to 4 column
+// blocks: two waves per column block).  One k-loop instantiation per kernel: the register allocator sees one hot loop.
+template <int MODE, int RPW>
+__global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
+  constexpr bool BWD = (MODE == 1);
+  constexpr int G = 4 / RPW;           // wave groups sharing a column block's rows
+  constexpr int CB = NWAVES / G;       // column blocks per round
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ unsigned s_rmax[2][TM];   // per row: largest finite |output| of the layer (bit pattern; ping-pong by layer)
+  __shared__ unsigned s_xmax[2][TM];   // per row: largest finite |x| of the chain input tile (ping-pong by tile)
+  __shared__ float s_ainv[TM];         // per row: 1 / scale of the planes the next k-loop reads
+  const int PLANE = a.lds_split;       // 16-byte units per plane ( = k-groups * TMP )
+  f16x8* act = reinterpret_cast<f16x8*>(lds);
+  char* actb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // an opaque copy of the lane id: addresses derived from it are formed where they are used instead of being hoisted out of
+  // the tile / layer loops into registers that stay occupied (or spilled) through the k-loops
+  auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+  float* bsum = lds + a.bg_lds;
+  const float beta = a.beta;
+  auto stamp = [&](int li, int phase) {
+    if (a.timeline && blockIdx.x == 0 && lane == 0) a.timeline[(li * 5 + phase) * NWAVES + wave] = (long long)__builtin_amdgcn_s_memtime();
+  };
+  auto stamp_rt = [&](int phase) {
+    if (a.timeline && blockIdx.x == 0 && lane == 0) a.timeline[((MAX_CHAIN_LAYERS - 2) * 5 + phase) * NWAVES + wave] = (long long)__builtin_amdgcn_s_memrealtime();
+  };
+  // write 4 consecutive features k..k+3 (k % 4 == 0) of row m, scaled by s, into the two planes
+  auto put4 = [&](int k, int m, f32x4 v, float s) {
+    f16x4 ph, pl;
+    split4(v, s, ph, pl);
+    char* p = actb + ((size_t)((k >> 3) * TMP + m) * 16 + (k & 7) * 2);
+    *reinterpret_cast<f16x4*>(p) = ph;
+    *reinterpret_cast<f16x4*>(p + (size_t)PLANE * 16) = pl;
+  };
+  auto put1 = [&](int k, int m, float v, float s) {
+    _Float16 ph, pl;
+    split1(v, s, ph, pl);
+    char* p = actb + ((size_t)((k >> 3) * TMP + m) * 16 + (k & 7) * 2);
+    *reinterpret_cast<_Float16*>(p) = ph;
+    *reinterpret_cast<_Float16*>(p + (size_t)PLANE * 16) = pl;
+  };
+
+  stamp(MAX_CHAIN_LAYERS - 1, 0);
+  stamp_rt(0);
+  if (MODE != 0) for (int i = tid; i < a.bg_total; i += NTHREADS) bsum[i] = 0.f;
+  if (tid < 2 * TM) { (&s_rmax[0][0])[tid] = 0u; (&s_xmax[0][0])[tid] = 0u; }
+  __syncthreads();
+  int xpar = 0;                        // ping-pong slot of the input row maxima
+
+  for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const long long row0 = tile * TM;  // (the launcher guarantees P % TM == 0: every tile is full)
+
+    // ---- chain input tile -> planes (zero padded to a multiple of 16 features) ----
+    {
+      const int K0p = a.K0p, K0 = a.K0;
+      const float* X = a.X + row0 * a.ldx;
+      int groups = K0p >> 2;
+      asm volatile("" : "+s"(groups));      // (keeps the per-thread addresses below out of the tile loop's preheader)
+      const int total = groups * TM;
+      const bool vec = (a.ldx & 3) == 0 && ((uintptr_t)a.X & 15) == 0;
+      auto load = [&](int t) -> f32x4 {
+        const int g = t % groups, m = t / groups;
+        const int k = g * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vec && k + 3 < K0) v = *reinterpret_cast<const f32x4*>(X + (long long)m * a.ldx + k);
+        else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (k + q < K0) v[q] = X[(long long)m * a.ldx + k + q];
+        }
+        return v;
+      };
+      f32x4 cache[IN_CACHE];
+      auto rowmax = [&](int t, f32x4 v) {
+        unsigned mb = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const unsigned b = finite_abs_bits(v[q]); mb = b > mb ? b : mb; }
+        if (mb) atomicMax(&s_xmax[xpar][t / groups], mb);
+      };
+#pragma unroll
+      for (int i = 0; i < IN_CACHE; ++i) {
+        const int t = tid + i * NTHREADS;
+        cache[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < total) { cache[i] = load(t); rowmax(t, cache[i]); }
+      }
+      for (int t = tid + IN_CACHE * NTHREADS; t < total; t += NTHREADS) rowmax(t, load(t));
+      __syncthreads();
+      if (tid < TM) {
+        float s_row, inv_row;
+        scale_from_max(s_xmax[xpar][tid], s_row, inv_row);
+        s_ainv[tid] = inv_row;
+        s_xmax[xpar ^ 1][tid] = 0u;                    // the other slot: next tile's input stage, many barriers away
+      }
+      if (a.x_amax && tid < TM) {
+        const float wm = wave_max(__uint_as_float(s_xmax[xpar][tid]));
+        if (lane == 0) atomicMax(a.x_amax, __float_as_uint(wm));
+      }
+      auto emit = [&](int t, f32x4 v) {
+        const int g = t % groups, m = t / groups;
+        const int k = g * 4;
+        float s_in, inv_in;
+        scale_from_max(s_xmax[xpar][m], s_in, inv_in);
+        put4(k, m, v, s_in);
+        if (MODE != 0 && a.in_bgrad) {      // bias gradient of the output layer: column sums of the input
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if (k + q < K0) atomicAdd(bsum + a.in_bg_off + k + q, v[q]);
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < IN_CACHE; ++i) {
+        const int t = tid + i * NTHREADS;
+        if (t < total) emit(t, cache[i]);
+      }
+      for (int t = tid + IN_CACHE * NTHREADS; t < total; t += NTHREADS) emit(t, load(t));
+    }
+    __syncthreads();
+    if (tile == blockIdx.x) stamp(MAX_CHAIN_LAYERS - 1, 1);
+
+    int cur = 0;                         // ping-pong slot of the layer's row maxima
+    for (int li = 0; li < a.L; ++li) {
+      const ChainLayer& ly = a.layers[li];
+      const int KS = (ly.Kp + 15) >> 4;          // k-steps of 16 (planes are zero beyond Kp)
+      const int NB = ly.Np >> 5;
+      const bool last = a.has_output && (li == a.L - 1);
+      stamp(li, 0);
+      const gptr<const f16x8> p_wp = (gptr<const f16x8>)pin(ly.Wp);
+      const gptr<const float> p_winv = pin(ly.Wp + (long long)KS * 16 * ly.Np);   // [NB] behind the planes
+      const gptr<const float> p_bias = pin(ly.bias);
+      const gptr<const float> p_rowbias = pin((MODE == 0 && li == 0) ? a.row_bias : nullptr);
+      const int rb_div = pin(a.row_bias_div > 0 ? a.row_bias_div : 1);
+      const gptr<const float> p_side_in = pin(ly.side_in);
+      const gptr<const float> p_side_ex = pin(MODE == 1 ? ly.side_add : ly.side_in2);
+      const gptr<float> p_side_out = pin(ly.side_out);
+      const gptr<float> p_side_out2 = pin(ly.side_out2);
+      float* const p_bgrad = (MODE != 0 && ly.bgrad) ? bsum + pin(ly.bg_off) : nullptr;
+      const int l_N = pin(ly.N);
+      const int l_ld = pin(ly.ld_side);
+      const bool is_skip = (li == a.skip_layer);
+      const float sc = pin(is_skip ? a.skip_scale : 1.f);
+      const int nlim = pin((BWD && is_skip) ? a.skip_split : l_N);
+      const float b2 = beta * LOG2E, ib2sc = LN2 / beta * sc;
+      const float hsc = (MODE != 0 && is_skip) ? 1.f / sc : 1.f;
+      const float nb2 = -b2 * hsc;
+
+      // Accumulator pairs of up to four 32 x 32 blocks (static indices only).
+      f32x16 acc0[4], acc1[4];
+      // One k-loop: RPW row blocks rb0.. of column block nb, k-steps [ks0, ks1), into accumulator slots SLOT.. .
+      // Weight fragments (the MFMA's A operand here) 3 steps ahead in rotating static slots; activation fragments (B operand)
+      // per unit of two row blocks: with two units (RPW = 4) a unit's registers are reloaded for the next k-step as soon as
+      // its six MFMAs have issued, i.e. one unit = 6 MFMAs ahead of their use; with one unit they are double buffered.
+      auto kloop = [&](const int nb, const int rb0, const int ks0, const int ks1) {
+        constexpr int SLOT = 0;
+        constexpr int U = 2;                       // row blocks per unit
+        constexpr int NU = RPW / U;                // units per k-step
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) { acc0[SLOT + q] = f32x16{0}; acc1[SLOT + q] = f32x16{0}; }
+        const int lane_k = fresh_lane();
+        const gptr<const f16x8> Bp = p_wp + ((long long)nb * KS) * 2 * 64 + lane_k;
+        const f16x8* A0 = act + (lane_k >> 5) * TMP + rb0 * 32 + (lane_k & 31);
+        f16x8 b[3][2];                 // [slot][plane]
+        f16x8 af[2][2][U];             // NU == 2: [unit][plane][row block of the unit]; NU == 1: [buffer][plane][row block]
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) b[s][p] = Bp[(long long)((ks0 + s < ks1 ? ks0 + s : ks0) * 2 + p) * 64];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+          const f16x8* An = A0 + 2 * ks0 * TMP;
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int q = 0; q < U; ++q) { af[u][0][q] = An[(u * U + q) * 32]; af[u][1][q] = An[PLANE + (u * U + q) * 32]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto kstep = [&](auto stag, auto btag, auto gtag, const int ks) {
+          constexpr int S = decltype(stag)::value;       // weight slot
+          constexpr int C = decltype(btag)::value;       // activation buffer (NU == 1)
+          constexpr bool GUARD = decltype(gtag)::value;
+          const bool nxt = !GUARD || ks + 1 < ks1;
+          const f16x8* An = A0 + 2 * (ks + 1) * TMP;
+          if (NU == 1) {
+            if (nxt) {
+#pragma unroll
+              for (int q = 0; q < U; ++q) { af[C ^ 1][0][q] = An[q * 32]; af[C ^ 1][1][q] = An[PLANE + q * 32]; }
+            }
+            // three partial products (operands swapped: A = weights): w_hi x_lo, w_lo x_hi -> acc1; w_hi x_hi -> acc0
+#pragma unroll
+            for (int q = 0; q < U; ++q) acc1[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][1][q], acc1[SLOT + q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < U; ++q) acc0[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][0][q], acc0[SLOT + q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < U; ++q) acc1[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][1], af[C][0][q], acc1[SLOT + q], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+#pragma unroll
+              for (int q = 0; q < U; ++q) acc1[SLOT + u * U + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[u][1][q], acc1[SLOT + u * U + q], 0, 0, 0);
+#pragma unroll
+              for (int q = 0; q < U; ++q) acc0[SLOT + u * U + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[u][0][q], acc0[SLOT + u * U + q], 0, 0, 0);
+#pragma unroll
+              for (int q = 0; q < U; ++q) acc1[SLOT + u * U + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][1], af[u][0][q], acc1[SLOT + u * U + q], 0, 0, 0);
+              if (nxt) {
+#pragma unroll
+                for (int q = 0; q < U; ++q) { af[u][0][q] = An[(u * U + q) * 32]; af[u][1][q] = An[PLANE + (u * U + q) * 32]; }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if (!GUARD || ks + 3 < ks1) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) b[S][p] = Bp[(long long)((ks + 3) * 2 + p) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        {
+          using T = std::true_type;
+          using F = std::false_type;
+          using S0 = std::integral_constant<int, 0>;
+          using S1 = std::integral_constant<int, 1>;
+          using S2 = std::integral_constant<int, 2>;
+          int ks = ks0;
+          // the weight slots rotate with period 3, the activation buffers (NU == 1) with period 2: unroll by 6
+          for (; ks + 9 <= ks1; ks += 6) {
+            kstep(S0{}, S0{}, F{}, ks); kstep(S1{}, S1{}, F{}, ks + 1); kstep(S2{}, S0{}, F{}, ks + 2);
+            kstep(S0{}, S1{}, F{}, ks + 3); kstep(S1{}, S0{}, F{}, ks + 4); kstep(S2{}, S1{}, F{}, ks + 5);
+          }
+          for (; ks < ks1; ks += 6) {
+            kstep(S0{}, S0{}, T{}, ks);
+            if (ks + 1 < ks1) kstep(S1{}, S1{}, T{}, ks + 1);
+            if (ks + 2 < ks1) kstep(S2{}, S0{}, T{}, ks + 2);
+            if (ks + 3 < ks1) kstep(S0{}, S1{}, T{}, ks + 3);
+            if (ks + 4 < ks1) kstep(S1{}, S0{}, T{}, ks + 4);
+            if (ks + 5 < ks1) kstep(S2{}, S1{}, T{}, ks + 5);
+          }
+        }
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      using I3 = std::integral_constant<int, 3>;
+      using I4 = std::integral_constant<int, 4>;
+      using TT = std::true_type;
+      using FF = std::false_type;
+
+      // ---- general layer: wave -> (column block nb, RPW consecutive row blocks from rb0) ----
+      // RPW = 4: one wave per column block with all 4 row blocks (hidden layers of up to 8 column blocks); RPW = 2: two waves
+      // per column block with 2 row blocks each (up to 4 column blocks); an output layer wider than that takes rounds.
+      // A narrow output layer (N <= 32, NB = 1) splits K instead: four quarters, one per wave (and half of the rows when
+      // RPW = 2), each accumulated from zero; the quarters meet in the plane memory -- free once every wave is through its
+      // k-loop -- and are summed in a fixed order: the order of mlp3.hip's split-K path, whatever the tile height.
+      {
+        const bool narrow = NB == 1;
+        const int nrounds = (NB + CB - 1) / CB;       // (> 1 only for an output layer)
+        const int wc = narrow ? 0 : wave % CB;        // column of the round
+        const int wg = narrow ? wave >> 2 : wave / CB;   // row group
+        const int kq = wave & 3;
+        const int ks0 = narrow ? (KS * kq) / 4 : 0, ks1 = narrow ? (KS * (kq + 1)) / 4 : KS;
+        int nb = 0;
+        const int rb0 = wg * RPW;
+        bool active = false;
+#pragma unroll 1
+        for (int round = 0; round < nrounds; ++round) {
+          nb = CB * round + wc;
+          active = nb < NB && wg < G;
+          if (active) kloop(nb, rb0, ks0, ks1);         // (the kernel's only k-loop instantiation)
+          if (round == 0) stamp(li, 1);
+          if (narrow) break;
+          if (!last || !active) continue;
+          // ---- output layer: z = acc / scales (+ bias) -> Y ----
+          const int lane_o = fresh_lane();
+          const int r_o = lane_o & 31, hh = lane_o >> 5;
+          const int fb = nb * 32 + 4 * hh;
+          const float winv = p_winv[nb];
+          const bool vec_y = (nb * 32 + 31 < l_N) && (a.ldy & 3) == 0 && ((uintptr_t)a.Y & 15) == 0;
+          f32x4 bias4[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bias4[g][q] = (MODE == 0 && p_bias && fb + 8 * g + q < l_N) ? p_bias[fb + 8 * g + q] : 0.f;
+#pragma unroll
+          for (int J = 0; J < RPW; ++J) {
+            const int R = (rb0 + J) * 32 + r_o;
+            const float sa = s_ainv[R];
+            float* y = a.Y + (row0 + R) * a.ldy + fb;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              f32x4 t;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float z = out_z(acc_sum(acc0[J][4 * g + q], acc1[J][4 * g + q]), sa, winv);
+                t[q] = MODE == 0 ? out_add(z, bias4[g][q]) : z;
+              }
+              if (vec_y) {
+                if (a.accum_y) {
+                  const f32x4 y0 = *reinterpret_cast<const f32x4*>(y + 8 * g);
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) t[q] = out_add(t[q], y0[q]);
+                }
+                *reinterpret_cast<f32x4*>(y + 8 * g) = t;
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  if (fb + 8 * g + q < l_N) y[8 * g + q] = a.accum_y ? out_add(t[q], y[8 * g + q]) : t[q];
+              }
+            }
+          }
+        }   // rounds
+        if (narrow) {
+          __syncthreads();
+          float* part = lds;                       // [kq][m][n]: 4 x TM x 32 floats = 64 KB <= the planes
+          if (active) {
+            const int lane_o = fresh_lane();
+            const int r_o = lane_o & 31, hh = lane_o >> 5;
+#pragma unroll
+            for (int J = 0; J < RPW; ++J) {
+              float* dst = part + ((size_t)(kq * TM + (rb0 + J) * 32 + r_o)) * 32 + 4 * hh;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = acc_sum(acc0[J][4 * g + q], acc1[J][4 * g + q]);
+                *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
+              }
+            }
+          }
+          __syncthreads();
+          const float winv = p_winv[0];
+          for (int t = tid; t < TM * 32; t += NTHREADS) {
+            const int n = t & 31, m = t >> 5;
+            float z = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z += part[q * TM * 32 + t];
+            z = out_z(z, s_ainv[m], winv);
+            if (n < l_N) {
+              if (MODE == 0) z = out_add(z, p_bias ? p_bias[n] : 0.f);
+              if (last) {      // (a narrow layer is always an output layer: chain_impl refuses it elsewhere)
+                float* y = a.Y + (row0 + m) * a.ldy + n;
+                *y = a.accum_y ? out_add(z, *y) : z;
+              }
+            }
+          }
+          __syncthreads();
+          continue;
+        }
+        if (last) {              // the output layer leaves nothing in the planes: no maximum, no split
+          stamp(li, 2);
+          __syncthreads();
+          stamp(li, 4);
+          continue;
+        }
+
+        // ================= phase A (hidden layer): activation math on the accumulator registers =================
+        if (active) {
+          const int lane_o = fresh_lane();
+          const int r_o = lane_o & 31, hh = lane_o >> 5;
+          const int fb = nb * 32 + 4 * hh;                  // first feature of register group 0
+          const float winv = p_winv[nb];
+          const bool full = (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && (!p_rowbias || (l_N & 3) == 0);
+          const long long tile_off = row0 * l_ld;           // uniform base + 32-bit lane offset: one address register per access
+          // the accumulator pairs become single values at once: acc1 is dead from here on
+#pragma unroll
+          for (int J = 0; J < RPW; ++J)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc0[J][i] = acc_sum(acc0[J][i], acc1[J][i]);
+          f32x4 bbv[4];                                     // forward: bias * beta log2(e)
+          if (MODE == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              if (full && p_bias) bbv[g] = *((gptr<const f32x4>)(p_bias + (unsigned)(fb + 8 * g))) * b2;
+              else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bbv[g][q] = (p_bias && fb + 8 * g + q < l_N ? p_bias[fb + 8 * g + q] : 0.f) * b2;
+              }
+            }
+          }
+          f32x4 hs[2][4], ex[2][4];                         // backward / tangent: side loads, one block ahead
+          // side loads of block J (backward: stored activation + extra adjoint; tangent: stored activation + s)
+          auto side_loads = [&](auto jt, auto ft) {
+            constexpr int J = decltype(jt)::value;
+            constexpr bool FULL = decltype(ft)::value;
+            const unsigned rowoff = (unsigned)((rb0 + J) * 32 + r_o) * (unsigned)l_ld + (unsigned)fb;
+            const gptr<const float> b_in = p_side_in + tile_off;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              if (FULL) hs[J & 1][g] = *((gptr<const f32x4>)(b_in + (rowoff + 8 * g)));
+              else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hs[J & 1][g][q] = fb + 8 * g + q < nlim ? b_in[rowoff + 8 * g + q] : 0.f;
+              }
+            }
+            if (p_side_ex) {
+              const gptr<const float> b_ex = p_side_ex + tile_off;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                if (FULL) ex[J & 1][g] = *((gptr<const f32x4>)(b_ex + (rowoff + 8 * g)));
+                else {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) ex[J & 1][g][q] = fb + 8 * g + q < nlim ? b_ex[rowoff + 8 * g + q] : 0.f;
+                }
+              }
+            } else {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) ex[J & 1][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+          };
+          auto hidden_block = [&](auto jt, auto ft) {
+            constexpr int J = decltype(jt)::value;
+            constexpr bool FULL = decltype(ft)::value;
+            const int R = (rb0 + J) * 32 + r_o;             // row of the tile
+            const float sa = s_ainv[R];
+            const unsigned rowoff = (unsigned)R * (unsigned)l_ld + (unsigned)fb;
+            if (MODE == 0) {
+              const float kk = fwd_kk(sa, winv, b2);
+              gptr<const float> rbp = nullptr;
+              if (p_rowbias) rbp = p_rowbias + (long long)((unsigned)(row0 + R) / (unsigned)rb_div) * l_N + fb;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                f32x4 rbv = {0.f, 0.f, 0.f, 0.f};
+                if (p_rowbias) {
+                  if (FULL) rbv = *((gptr<const f32x4>)(rbp + 8 * g));
+                  else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < l_N) rbv[q] = rbp[8 * g + q];
+                  }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int i = 4 * g + q;
+                  float u = fwd_u(acc0[J][i], kk, bbv[g][q]);       // b2 * (pre-activation)
+                  if (p_rowbias) u = fwd_u_rowbias(u, rbv[q], b2);
+                  float v = softplus_u(u, ib2sc);
+                  if (!FULL) v = (fb + 8 * g + q < nlim) ? v : 0.f;
+                  acc0[J][i] = v;
+                }
+              }
+            } else {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                f32x4 x2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const int i = 4 * g + q;
+                  const float zz = acc0[J][i] * sa * winv;
+                  const float e = __builtin_amdgcn_exp2f(nb2 * hs[J & 1][g][q]);
+                  const float sp = (1.f - e) * sc;
+                  float v;
+                  if (MODE == 1) v = zz * sp + ex[J & 1][g][q];
+                  else { v = zz * sp; x2[q] = beta * zz * ex[J & 1][g][q] * e; }
+                  if (!FULL) {
+                    const int f = fb + 8 * g + q;
+                    if (MODE == 1 && is_skip && a.Xskip && f >= a.skip_split && f < l_N)
+                      a.Xskip[(row0 + R) * a.ld_xskip + (f - a.skip_split)] = zz * sc;
+                    if (f >= nlim) { v = 0.f; x2[q] = 0.f; }
+                  }
+                  acc0[J][i] = v;
+                }
+                if (MODE == 2 && p_side_out2) {
+                  const gptr<float> b_out2 = p_side_out2 + tile_off;
+                  if (FULL) *((gptr<f32x4>)(b_out2 + (rowoff + 8 * g))) = x2;
+                  else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < nlim) b_out2[rowoff + 8 * g + q] = x2[q];
+                  }
+                }
+              }
+            }
+            if (p_side_out) {
+              const gptr<float> b_out = p_side_out + tile_off;
+              const int lim = MODE == 0 ? l_N : nlim;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                if (FULL) *((gptr<f32x4>)(b_out + (rowoff + 8 * g))) = f32x4{acc0[J][4 * g], acc0[J][4 * g + 1], acc0[J][4 * g + 2], acc0[J][4 * g + 3]};
+                else {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < lim) b_out[rowoff + 8 * g + q] = acc0[J][4 * g + q];
+                }
+              }
+            }
+            // row maximum of the block's 16 values of this point: v_max ignores NaN; a value set holding an Inf (or only
+            // NaN) goes through the bit-pattern filter.  One LDS atomic per lane (the two half-waves of a row: 2-way).
+            float m = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m = fmaxf(m, fabsf(acc0[J][i]));
+            if (!(m < 3.0e38f)) {
+              unsigned mb = 0;
+#pragma unroll
+              for (int i = 0; i < 16; ++i) { const unsigned b = finite_abs_bits(acc0[J][i]); mb = b > mb ? b : mb; }
+              m = __uint_as_float(mb);
+            }
+            atomicMax(&s_rmax[cur][R], __float_as_uint(m));
+          };
+          auto run = [&](auto ft) {
+            if (MODE != 0) side_loads(I0{}, ft);
+            if (MODE != 0) side_loads(I1{}, ft);
+            hidden_block(I0{}, ft);
+            if constexpr (RPW > 2) { if (MODE != 0) side_loads(I2{}, ft); }
+            hidden_block(I1{}, ft);
+            if constexpr (RPW > 2) {
+              if (MODE != 0) side_loads(I3{}, ft);
+              hidden_block(I2{}, ft);
+              hidden_block(I3{}, ft);
+            }
+          };
+          if (full) run(TT{}); else run(FF{});
+          // bias gradient: column sums of the deltas over the wave's points (its blocks first: they share the features) --
+          // 16-lane rows by DPP (xor 1, xor 2, half mirror, mirror), then one LDS atomic per feature from the first lane of
+          // every row
+          if (MODE != 0 && p_bgrad) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              float c = acc0[0][i] + acc0[1][i];
+              if constexpr (RPW > 2) c += acc0[2][i] + acc0[3][i];
+              c += dpp<DPP_XOR1>(c);
+              c += dpp<DPP_XOR2>(c);
+              c += dpp<DPP_HALF_MIRROR>(c);
+              c += dpp<DPP_MIRROR>(c);
+              const int f = fb + acc_feat(i, 0);
+              if ((lane_o & 15) == 0 && f < nlim) atomicAdd(p_bgrad + f, c);
+            }
+          }
+        }
+        stamp(li, 2);
+
+        // ---- row maxima of this layer's outputs are in s_rmax[cur] (incl. the skip concatenation's input part) ----
+        if (MODE != 1 && is_skip && tid < TM) {
+          const float xm = __uint_as_float(s_xmax[xpar][tid]) * fabsf(a.skip_scale);
+          atomicMax(&s_rmax[cur][tid], __float_as_uint(xm));
+        }
+        __syncthreads();          // every wave has read the planes and contributed its maxima
+        stamp(li, 3);
+
+        // ================= phase B: per-row scale, 2-way split, planes updated in place =================
+        if (active) {
+          const int lane_o = fresh_lane();
+          const int r_o = lane_o & 31, hh = lane_o >> 5;
+          const int kb = nb * 32 + 4 * hh;
+#pragma unroll
+          for (int J = 0; J < RPW; ++J) {
+            const int R = (rb0 + J) * 32 + r_o;
+            float s_row, inv_row;
+            scale_from_max(s_rmax[cur][R], s_row, inv_row);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              put4(kb + 8 * g, R, f32x4{acc0[J][4 * g], acc0[J][4 * g + 1], acc0[J][4 * g + 2], acc0[J][4 * g + 3]}, s_row);
+          }
+        }
+      }
+      if (tid < TM) {
+        float s_row, inv_row;
+        scale_from_max(s_rmax[cur][tid], s_row, inv_row);
+        s_ainv[tid] = inv_row;           // read by the next layer's phase A, two barriers on
+      }
+      if (ly.side_amax && tid < TM) {
+        const float wm = wave_max(__uint_as_float(s_rmax[cur][tid]));
+        if (lane == 0) atomicMax(ly.side_amax, __float_as_uint(wm));
+      }
+
+      // ---- forward skip connection: append the (scaled) chain input after the skip layer's output ----
+      if (MODE != 1 && is_skip) {
+        __syncthreads();
+        const int K0 = a.K0, base = l_N;
+        const float* X = a.X + row0 * a.ldx;
+        for (int t = tid; t < K0 * TM; t += NTHREADS) {
+          const int k = t % K0, m = t / K0;
+          const float v = X[(long long)m * a.ldx + k] * a.skip_scale;
+          const int kk = base + k;
+          float s_row, inv_row;
+          scale_from_max(s_rmax[cur][m], s_row, inv_row);
+          put1(kk, m, v, s_row);
+          if (ly.side_out) ly.side_out[(row0 + m) * ly.ld_side + kk] = v;
+        }
+        // zero the tail up to the next multiple of 16
+        const int wcat = base + K0, wpad = (wcat + 15) & ~15;
+        for (int t = tid; t < (wpad - wcat) * TM; t += NTHREADS) put1(wcat + t % (wpad - wcat), t / (wpad - wcat), 0.f, 1.f);
+      }
+      __syncthreads();
+      if (tid < TM) s_rmax[cur][tid] = 0u;      // next use: two layers on, two barriers away
+      cur ^= 1;
+      stamp(li, 4);
+    }
+    if (tile == blockIdx.x) stamp(MAX_CHAIN_LAYERS - 1, 2);
+    xpar ^= 1;
+  }
+  stamp(MAX_CHAIN_LAYERS - 1, 3);
+  stamp_rt(1);
+  if (MODE != 0 && a.bg_total > 0) {
+    __syncthreads();
+    float* part = a.bg_partial + (long long)blockIdx.x * a.bg_total;
+    for (int i = tid; i < a.bg_total; i += NTHREADS) part[i] = bsum[i];
+  }
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace x3w
+
+// NDJIR_ERR_UNSUPPORTED = "not a launch for this kernel" (the caller falls back to mlp3.hip's 64 / 32-point tiles).
+int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) {
+  using namespace x3w;
+  constexpr int LDS_DYN_MAX = 160 * 1024 - 4096;      // the kernel also holds 2.5 KB of static LDS (row maxima / scales)
+  if ((a.P % TM) != 0) return NDJIR_ERR_UNSUPPORTED;
+  if (a.P < 128 * 256 && a.tile_rows != 128) return NDJIR_ERR_UNSUPPORTED;      // (a forced 128 takes small launches too: tests)
+  int wmax = round_up(a.K0, 16), hmax = 0;
+  for (int i = 0; i < a.L; ++i) {
+    const bool last = a.has_output && i == a.L - 1;
+    if (!last && (a.layers[i].Np > NWAVES * 32 || a.layers[i].Np < 64)) return NDJIR_ERR_UNSUPPORTED;
+    if (!last && a.layers[i].Np > wmax) wmax = a.layers[i].Np;
+    if (!last && a.layers[i].Np > hmax) hmax = a.layers[i].Np;
+  }
+  const int rpw = hmax <= 128 ? 2 : 4;      // widest hidden layer: <= 4 column blocks -> two waves per column block
+  if (a.skip_layer >= 0 && mode != 1) { int w = round_up(a.layers[a.skip_layer].N + a.K0, 16); if (w > wmax) wmax = w; }
+  ChainArgs b = a;
+  b.K0p = round_up(a.K0, 16);
+  b.lds_split = (wmax / 8) * TMP;                          // 16-byte units per plane
+  size_t lds_bytes = (size_t)2 * b.lds_split * 16;
+  b.n_tiles = a.P / TM;
+  float* bg_ptr[MAX_CHAIN_LAYERS + 1];
+  int bg_off[MAX_CHAIN_LAYERS + 1];
+  int bg_n = 0, bg_total = 0;
+  if (mode != 0) {
+    for (int i = 0; i < a.L; ++i) if (a.layers[i].bgrad && !(a.has_output && i == a.L - 1)) {
+      b.layers[i].bg_off = bg_total;
+      bg_ptr[bg_n] = a.layers[i].bgrad;
+      bg_off[bg_n] = bg_total;
+      ++bg_n;
+      bg_total += a.layers[i].N;
+    } else b.layers[i].bgrad = nullptr;
+  }
+  if (mode != 0 && a.in_bgrad) {
+    b.in_bg_off = bg_total;
+    bg_ptr[bg_n] = a.in_bgrad;
+    bg_off[bg_n] = bg_total;
+    ++bg_n;
+    bg_total += a.K0;
+  }
+  b.bg_total = bg_total;
+  b.bg_lds = (int)(lds_bytes / 4);
+  lds_bytes += (size_t)bg_total * 4;
+  if (bg_total > 0 && !a.bg_partial) return NDJIR_ERR_ARG;
+  if (lds_bytes > LDS_DYN_MAX) return NDJIR_ERR_UNSUPPORTED;
+  long long blocks = b.n_tiles;
+  if (blocks > 256LL * 8) blocks = 256LL * 8;
+  if (bg_total > 0 && blocks > CHAIN_MAX_GRID_BG) blocks = CHAIN_MAX_GRID_BG;
+  static bool attr_set = false;
+  if (!attr_set) {
+#define NDJIR_SET(M, R) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw<M, R>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX)
+    NDJIR_SET(0, 4); NDJIR_SET(1, 4); NDJIR_SET(2, 4); NDJIR_SET(0, 2); NDJIR_SET(1, 2); NDJIR_SET(2, 2);
+#undef NDJIR_SET
+    attr_set = true;
+  }
+#define NDJIR_GO(M, R) hipLaunchKernelGGL((k_chainw<M, R>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b)
+  if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4); else if (mode == 1) NDJIR_GO(1, 4); else NDJIR_GO(2, 4); }
+  else { if (mode == 0) NDJIR_GO(0, 2); else if (mode == 1) NDJIR_GO(1, 2); else NDJIR_GO(2, 2); }
+#undef NDJIR_GO
+  int rc = ndjir_check_launch();
+  if (rc != NDJIR_OK) return rc;
+  if (bg_total > 0) return launch_bgrad_reduce(a.bg_partial, (int)blocks, bg_total, bg_ptr, bg_off, bg_n, stream);
+  return NDJIR_OK;
+}
+
+}  // namespace ndjir

@@ -252,6 +252,7 @@ def symbols():
                                             "ndjir_hash_table_size", "ndjir_hash_num_params",
                                             "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_colsum_workspace",
                                             "ndjir_mlp_chain_workspace", "ndjir_mlp_set_math", "ndjir_mlp_get_math",
+                                            "ndjir_mlp_set_tile_rows", "ndjir_mlp_get_tile_rows",
                                             "ndjir_mlp_debug_timeline", "ndjir_loss_terms_workspace", "ndjir_grid_set_scatter_bins_from",
                                             "ndjir_grid_get_scatter_bins_from"]
 

@@ -36,6 +36,16 @@ def get_math():
     return int(lib.load().ndjir_mlp_get_math())
 
 
+def set_tile_rows(rows):
+    """Points per workgroup tile of the chain kernels: 0 = chosen per launch, 32 / 64 / 128 = forced (A/B runs, tests)."""
+    if lib.load().ndjir_mlp_set_tile_rows(int(rows)) != 0:
+        raise ValueError(f"tile rows {rows}")
+
+
+def get_tile_rows():
+    return int(lib.load().ndjir_mlp_get_tile_rows())
+
+
 def _init_math():
     import os
     env = os.environ.get("NDJIR_MLP_MATH")

@@ -1,0 +1,154 @@
+"""The 128-point-tile chain kernel (ndjir_amd/csrc/mlp3w.hip: operands swapped, epilogue in the accumulator registers)
+against the 64-point-tile kernel (mlp3.hip) and against fp64: a point's FORWARD result must be bit-identical whichever
+kernel evaluates it (the sampler merges SDF values of different launches bit for bit), the backward / tangent chains agree to
+round-off.  `ndjir_mlp_set_tile_rows(128)` sends launches of any size that the wide kernel supports (P % 128 == 0, hidden
+layers of 2..8 column blocks, planes within the LDS) to it; by default only launches of >= 32768 points go there."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_mlp import make, ref_mlp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def tile():
+    from ndjir_amd import mlp
+    old = mlp.get_tile_rows()
+    yield mlp.set_tile_rows
+    mlp.set_tile_rows(old)
+
+
+CASES = [
+    ((259, 256, 256, 256, 3), 256, -1),       # base colour net: K0 = 259 -> 272 columns of planes, narrow output
+    ((39, 128, 128, 128, 1), 384, -1),        # environment light net: two waves per column block
+    ((262, 128, 128, 128, 6), 128, -1),       # specular reflectance net
+    ((52, 256, 256, 256, 257), 256, -1),      # background geometric net: 257-wide output = 9 column blocks, two rounds
+    ((43, 256, 256, 256, 213, 256, 256, 256, 257), 256, 3),   # geometric net: skip concatenation, a 7-block layer
+    ((43, 256, 256, 256, 213, 256, 256, 256, 1), 128, 3),     # sdf-only variant (sampler)
+    ((43, 128, 128, 129), 256, -1),           # 5-block output layer behind 4-block hidden layers (rounds of 4)
+    ((43, 96, 96, 40), 128, -1),              # 3 column blocks: one idle wave pair; 2-block output
+    ((32, 160, 160, 97), 128, -1),            # 5 column blocks: three idle waves
+]
+
+
+@pytest.mark.parametrize("dims,P,skip", CASES)
+def test_forward_is_bitwise_the_64_point_kernel(gpu, tile, dims, P, skip):
+    from ndjir_amd.mlp import chain_forward
+    scale = 1.0 / np.sqrt(2.0) if skip >= 0 else 1.0
+    Ws, bs = make(dims, 5, skip)
+    rng = np.random.RandomState(17)
+    x = torch.tensor(rng.randn(P, dims[0]) * 0.5, dtype=torch.float32).to(gpu)
+    Wd = [w.to(gpu) for w in Ws]
+    bd = [b.to(gpu) for b in bs]
+    res = {}
+    for rows in (64, 32, 128):
+        tile(rows)
+        y, hidden, am = chain_forward(x, Wd, bd, 100.0, skip, scale, keep_hidden=True)
+        torch.cuda.synchronize()
+        res[rows] = (y.clone(), [h.clone() for h in hidden], am.clone())
+    y64 = ref_mlp(x.cpu().double(), [w.double() for w in Ws], [b.double() for b in bs], 100.0, skip, scale)
+    assert float((res[128][0].cpu().double() - y64).norm() / y64.norm()) < 2e-6
+    for other in (64, 32):
+        assert torch.equal(res[128][0], res[other][0]), f"output differs from the {other}-point tiles"
+        for j, (h_w, h_o) in enumerate(zip(res[128][1], res[other][1])):
+            assert torch.equal(h_w, h_o), f"stored activation {j + 1} differs from the {other}-point tiles"
+        assert torch.equal(res[128][2], res[other][2]), "recorded maxima differ"
+
+
+@pytest.mark.parametrize("dims,P,skip", CASES)
+def test_gradients_match_fp64_and_the_64_point_kernel(gpu, tile, dims, P, skip):
+    from ndjir_amd.mlp import fused_mlp
+    scale = 1.0 / np.sqrt(2.0) if skip >= 0 else 1.0
+    Ws, bs = make(dims, 7, skip)
+    rng = np.random.RandomState(11)
+    x = torch.tensor(rng.randn(P, dims[0]) * 0.5, dtype=torch.float32)
+    gy = torch.tensor(rng.randn(P, dims[-1]), dtype=torch.float32)
+
+    def run(rows):
+        tile(rows)
+        xd = x.to(gpu).requires_grad_(True)
+        Wd = [w.to(gpu).requires_grad_(True) for w in Ws]
+        bd = [b.to(gpu).requires_grad_(True) for b in bs]
+        y = fused_mlp(xd, Wd, bd, 100.0, skip, scale)
+        return y, torch.autograd.grad(y, [xd] + Wd + bd, gy.to(gpu))
+
+    y_w, g_w = run(128)
+    y_o, g_o = run(64)
+    x64 = x.double().requires_grad_(True)
+    W64 = [w.double().requires_grad_(True) for w in Ws]
+    b64 = [b.double().requires_grad_(True) for b in bs]
+    y64 = ref_mlp(x64, W64, b64, 100.0, skip, scale)
+    g64 = torch.autograd.grad(y64, [x64] + W64 + b64, gy.double())
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b.detach().cpu().double()).norm() / max(float(b.norm()), 1e-30))
+
+    assert torch.equal(y_w, y_o)
+    names = ["x"] + [f"W{j}" for j in range(len(Ws))] + [f"b{j}" for j in range(len(bs))]
+    for n, a, o, r in zip(names, g_w, g_o, g64):
+        assert rel(a, r) < 2e-5, (n, rel(a, r))
+        assert rel(a, o) < 5e-6, (n, rel(a, o))
+
+
+def test_row_term_and_accumulating_output(gpu, tile):
+    """The per-row-group term of the first layer (soft-visibility / photogrammetric nets) and a backward chain that
+    accumulates into an existing dL/dx (MultiMLP), on the wide kernel."""
+    from ndjir_amd.mlp import fused_mlp
+    P, div, K0, Dh, No = 512, 128, 39, 128, 1
+    Ws, bs = make((K0, Dh, Dh, Dh, No), 3)
+    rng = np.random.RandomState(5)
+    x = torch.tensor(rng.randn(P, K0) * 0.5, dtype=torch.float32)
+    rb = torch.tensor(rng.randn(P // div, Dh) * 0.3, dtype=torch.float32)
+    gy = torch.tensor(rng.randn(P, No), dtype=torch.float32)
+    outs = {}
+    for rows in (128, 64):
+        tile(rows)
+        xd = x.to(gpu).requires_grad_(True)
+        rbd = rb.to(gpu).requires_grad_(True)
+        Wd = [w.to(gpu).requires_grad_(True) for w in Ws]
+        bd = [b.to(gpu).requires_grad_(True) for b in bs]
+        y = fused_mlp(xd, Wd, bd, 100.0, row_bias=rbd, row_bias_div=div)
+        outs[rows] = (y, torch.autograd.grad(y, [xd, rbd] + Wd + bd, gy.to(gpu)))
+    assert torch.equal(outs[128][0], outs[64][0])
+    for a, o in zip(outs[128][1], outs[64][1]):
+        assert float((a - o).norm() / max(float(o.norm()), 1e-30)) < 5e-6
+    # fp64
+    x64, rb64 = x.double().requires_grad_(True), rb.double().requires_grad_(True)
+    W64 = [w.double().requires_grad_(True) for w in Ws]
+    h = torch.nn.functional.softplus(x64 @ W64[0] + bs[0].double() + rb64.repeat_interleave(div, dim=0), beta=100.0)
+    y64 = ref_mlp(h, W64[1:], [b.double() for b in bs[1:]], 100.0)
+    g64 = torch.autograd.grad(y64, [x64, rb64] + W64, gy.double())
+    assert float((outs[128][0].cpu().double() - y64).norm() / y64.norm()) < 2e-6
+    for a, r in zip(outs[128][1][:2 + len(Ws)], g64):
+        assert float((a.cpu().double() - r).norm() / r.norm()) < 2e-5
+
+
+@pytest.mark.parametrize("grid", [True, False])
+def test_geometric_double_backward_on_the_wide_kernel(gpu, tile, grid):
+    """sdf chain, tangent chain and the augmented backward chain of the geometric network's main pass (nn.grad) on
+    128-point tiles: same values as on 64-point tiles to round-off."""
+    from ndjir_amd.geometric import geometric_main
+    rng = np.random.RandomState(2)
+    P, M = 256, 6
+    K0 = 3 + 6 * M + (4 if grid else 0)
+    dims = (K0, 256, 256, 256, 256 - K0, 256, 256, 256, 257)
+    Ws, bs = make(dims, 4, 3)
+    x = torch.tensor(rng.rand(P, 3) * 1.6 - 0.8, dtype=torch.float32)
+    F = torch.tensor(rng.randn(16, 16, 16, 4) * 0.05, dtype=torch.float32)
+    cot = [torch.tensor(rng.randn(P, c), dtype=torch.float32) for c in (1, 256, 3)]
+    res = {}
+    for rows in (128, 64):
+        tile(rows)
+        Wd = [w.to(gpu).requires_grad_(True) for w in Ws]
+        bd = [b.to(gpu).requires_grad_(True) for b in bs]
+        Fd = F.to(gpu).requires_grad_(True)
+        sdf, feat, n, Z = geometric_main(x.to(gpu), Fd if grid else None, Wd, bd, M, 3, 1.0 / np.sqrt(2.0))
+        loss = (sdf * cot[0].to(gpu)).sum() + (feat * cot[1].to(gpu)).sum() + (n * cot[2].to(gpu)).sum()
+        g = torch.autograd.grad(loss, Wd + bd + ([Fd] if grid else []))
+        res[rows] = (sdf, feat, n, g)
+    assert torch.equal(res[128][0], res[64][0]) and torch.equal(res[128][1], res[64][1])
+    assert float((res[128][2] - res[64][2]).abs().max()) <= 1e-5 * float(res[64][2].abs().max())
+    for a, o in zip(res[128][3], res[64][3]):
+        assert float((a - o).norm() / max(float(o.norm()), 1e-30)) < 2e-5
