@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
                 for (int q = 0; q < 4; ++q) {
                   const int i = 4 * g + q;
                   float u = fwd_u(acc0[J][i], kk, bbv[g][q]);       // b2 * (pre-activation)
-                  if (p_rowbias) u = fwd_u_rowbias(u, rbv[q], b2);
+                  u = fwd_u_rowbias(u, rbv[q], b2);                // (rbv = 0 without a row term: fma(0, b2, u) = u exactly)
                   float v = softplus_u(u, ib2sc);
                   if (!FULL) v = (fb + 8 * g + q < nlim) ? v : 0.f;
                   acc0[J][i] = v;
