@@ -42,7 +42,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 # f16x3 engine: as 3 f16 MFMA FLOPs (scaled two-way split) -- f16 and bf16 MFMA run at the same rate
 PEAK_BF16X6_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_F16X3_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def parse():
@@ -50,7 +50,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=512, help="rays per GPU per step (B=1)")
+    ap.add_argument("--rays", type=int, default=512, help="rays per GPU per step (B=1); weak scaling")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's contract): --rays per GPU whatever N; strong: --total-rays split over the "
+                         "N ranks (BASELINE.json config 4: `--scaling strong --config no_voxel`, 4096 rays / N per GPU)")
+    ap.add_argument("--total-rays", type=int, default=4096, help="rays per step over all GPUs with --scaling strong")
     ap.add_argument("--config", default="default")
     ap.add_argument("--override", action="append", default=[])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -281,6 +285,40 @@ def kernel_report(profile):
     return rep
 
 
+def kernel_table(kr, steps, peak):
+    """Per kernel class of the MLP engine: launches and time per step, algorithmic TFLOP/s and its fraction of both
+    yardsticks -- the peak of the executed instruction mix (dense 16-bit MFMA / partial products per algorithmic FLOP) and
+    the fp32-input MFMA peak (what an fp32 GEMM engine could reach at best on this chip)."""
+    out = {}
+    for k, v in kr.items():
+        out[k] = dict(launches_per_step=round(v["launches"] / max(steps, 1), 2), avg_us=round(v["avg_us"], 2),
+                      ms_per_step=round(v["launches"] * v["avg_us"] / max(steps, 1) / 1e3, 4),
+                      gflop_per_launch=round(v["gflop_per_launch"], 3), tflops=round(v["tflops"], 2),
+                      frac_of_executed_mix_peak=round(v["tflops"] / peak, 4),
+                      frac_of_fp32_mfma_peak=round(v["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4))
+    return out
+
+
+def kernel_symbol(kind, math):
+    """(symbol as rocprofv3 prints it, description) of the kernel a class of the engine's launches runs."""
+    from ndjir_amd import mlp
+    mode = {"chain_fwd": 0, "chain_bwd": 1, "chain_tan": 2}.get(kind.replace("_t32", ""))
+    what = {0: "forward", 1: "backward", 2: "tangent"}.get(mode, "")
+    if kind.startswith("wgrad"):
+        return "ndjir::k_wgrad3<2, 2, 2, 2>", "weight gradient A^T delta, P split over workgroups (csrc/wgrad.hip)"
+    if math == mlp.MATH_F16X3:
+        if kind.endswith("_t32") or os.environ.get("NDJIR_MLP_TILE") in ("32", "64"):
+            t = os.environ.get("NDJIR_MLP_TILE", "32")
+            return f"ndjir::x3::k_chain3<{mode}, {t}>", f"fused MLP {what} chain, {t}-point tiles (csrc/mlp3.hip)"
+        return (f"ndjir::x3w::k_chainw<{mode}, 4>",
+                f"fused MLP {what} chain on 128-point tiles, epilogue in the accumulator registers (csrc/mlp3w.hip; the 128-wide "
+                f"nets run the <{mode}, 2> instantiation): fp32 operands scaled by powers of two and split into 2 f16 planes, 3 "
+                "v_mfma_f32_32x32x16_f16 partial products per fp32 product in two fp32 accumulators")
+    if math == mlp.MATH_BF16X6:
+        return f"ndjir::x6::k_chain6<{mode}, 64>", f"fused MLP {what} chain; 3 bf16 planes, 6 partial products per fp32 product"
+    return f"ndjir::k_mlp_chain<{mode}, 64>", f"fused MLP {what} chain, fp32 MFMA 32x32x2"
+
+
 def kernel_detail(profile, steps):
     """Per (kind, shape) table of the engine's launches -> stderr (NDJIR_BENCH_DETAIL=1)."""
     agg = {}
@@ -322,6 +360,9 @@ def main():
     lib.load()  # fail loudly if the HIP extension is missing
     conf = cfg.load(a.config, a.override)
     R = a.rays
+    if a.scaling == "strong":
+        assert a.total_rays % world == 0, f"--total-rays {a.total_rays} does not split over {world} ranks"
+        R = a.total_rays // world
     step = Step(conf, R, device, rank, world)
 
     def barrier():
@@ -437,18 +478,16 @@ def main():
         kr = kernel_report(profile)
         if os.environ.get("NDJIR_BENCH_DETAIL"):
             kernel_detail(profile, profile_steps)
-        dom = kr.get("chain_fwd", dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0))
         step_tflops = MFLOP_PER_RAY_FWD_BWD * 1e6 * R / (ms * 1e-3) / 1e12      # per GPU
-        tile = os.environ.get("NDJIR_MLP_TILE", "64")
         math = mlp.get_math()
         x6, x3 = math == mlp.MATH_BF16X6, math == mlp.MATH_F16X3
         peak = PEAK_F16X3_EFFECTIVE_TFLOPS if x3 else PEAK_BF16X6_EFFECTIVE_TFLOPS if x6 else PEAK_FP32_MFMA_TFLOPS
-        ksym = f"ndjir::x3::k_chain3<0, {tile}>" if x3 else f"ndjir::x6::k_chain6<0, {tile}>" if x6 else f"ndjir::k_mlp_chain<0, {tile}>"
-        kname = ksym + (" (fused MLP forward chain; fp32 operands scaled by powers of two and split into 2 f16 planes, "
-                        "3 v_mfma_f32_32x32x16_f16 partial products per fp32 product in two fp32 accumulators)" if x3 else
-                        " (fused MLP forward chain; fp32 operands split exactly into 3 bf16 planes, 6 v_mfma_f32_32x32x16_bf16 "
-                        "partial products per fp32 product, fp32 accumulate)" if x6 else
-                        " (fused MLP forward chain, fp32 MFMA 32x32x2)")
+        # the roofline block is for the kernel class with the largest time per step (the backward chain since round 2)
+        table = kernel_table(kr, profile_steps, peak)
+        cands = [k for k in ("chain_fwd", "chain_bwd", "chain_tan", "wgrad") if k in table]
+        dom_kind = max(cands, key=lambda k: table[k]["ms_per_step"]) if cands else "chain_fwd"
+        dom = kr.get(dom_kind, dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0))
+        ksym, kname = kernel_symbol(dom_kind, math)
         peak_note = ("dense 16-bit MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 3 partial products per algorithmic FLOP" if x3 else
                      "dense bf16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 6 partial products per algorithmic FLOP" if x6 else
                      "fp32-input MFMA peak (MI355X_MICROARCH.md)")
@@ -457,20 +496,21 @@ def main():
         out = {
             "metric": "rays/sec (fwd+bwd) at 512 rays x 128 samples",
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": f"config/{a.config}.yaml, B=1, R={R} rays/GPU x N={N} fg samples (+{r.n_bg_samples} bg, "
                                    f"{r.n_thetas * 2 * r.n_thetas} lights), voxel {conf.geometric_network.voxel.type} "
                                    f"{conf.geometric_network.voxel.grid_size}^3x{conf.geometric_network.voxel.feature_size}, "
                                    f"total_loss fwd+bwd to all parameter gradients",
-                       "rays_per_gpu": R, "samples_per_ray": N, "parallelism": f"ray-sharded x{world}"},
+                       "rays_per_gpu": R, "samples_per_ray": N, "parallelism": f"ray-sharded x{world}",
+                       **({"total_rays": a.total_rays} if a.scaling == "strong" else {})},
             "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": dom["tflops"] / peak,
                          "traffic": committed_pmc_traffic(ksym),
                          "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes "
-                                         f"of this command, profiles/{PROFILE_ROUND}_pmc_hbm_bench.txt -- mostly the stored activations "
-                                         "(every hidden activation is written once for the backward pass); the kernel's algorithmic "
-                                         "measure is FLOPs",
+                                         f"of this command, profiles/{PROFILE_ROUND}_pmc_hbm_bench.txt -- the stored activations the "
+                                         "chain reads (backward / tangent) and the activations / deltas it writes for the weight "
+                                         "gradients; the kernel's algorithmic measure is FLOPs",
                          "kernel": kname, "peak_note": peak_note,
                          # the same algorithmic fp32 FLOP/s against the fp32-input MFMA peak (what an fp32 GEMM engine could
                          # reach at best on this chip) and against the bf16x6 engine's effective peak (round 1's yardstick)
@@ -478,9 +518,12 @@ def main():
                          "frac_of_bf16x6_peak": dom["tflops"] / PEAK_BF16X6_EFFECTIVE_TFLOPS,
                          "launches_per_step": dom["launches"] / max(profile_steps, 1), "avg_launch_us": dom["avg_us"],
                          "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
-                         "note": "64-point-tile launches only (small launches use the 32-point-tile instantiation, listed as "
-                                 "chain_fwd_t32 under `kernels`); an event interval spans the launch gap of the host-bound eager pass "
-                                 "as well as the kernel, ~5-7 % more than rocprofv3's kernel-only average in "
+                         "kernel_class": dom_kind,
+                         "ms_per_step": table.get(dom_kind, {}).get("ms_per_step"),
+                         "note": "the kernel class with the largest time per step (`kernels` lists all of them with both "
+                                 "yardsticks); large launches only (small ones use mlp3.hip's 32-point-tile instantiation, listed "
+                                 "as *_t32); an event interval spans the launch gap of the host-bound eager pass as well as the "
+                                 "kernel, ~5-7 % more than rocprofv3's kernel-only average in "
                                  f"profiles/{PROFILE_ROUND}_bench_kernel_summary.txt",
                          "method": ("HIP events on the launching stream around every launch of the same K steps issued "
                                     "eagerly right after the timed graph replays (events cannot be recorded inside a "
@@ -488,7 +531,7 @@ def main():
                                    ("HIP events on the launching stream around every launch of two untimed steps before "
                                     "the timed region (N > 1)") if world > 1 else
                                    "HIP events on the launching stream around every launch in the timed region"},
-            "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kr.items()},
+            "kernels": table,
             "step_roofline": {"achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
                               "frac": step_tflops / peak,
                               "scope": "whole step: 2168.9 MFLOP/ray fwd+bwd (SURVEY 8d) / step time",
@@ -499,6 +542,12 @@ def main():
                               "executed_tflops": step_tflops * (2168.9 - 323.1 + 128 * 0.786944) / 2168.9},
             "loss": float(loss),
         }
+        if step.multi:
+            # an exchange that overflowed its wire size delivered an incomplete grid gradient: the measurement must say so
+            rep = step.exchange_report()
+            out["exchange"] = rep
+            if any(b["overflowed_exchanges"] > 0 for b in rep["buffers"].values()):
+                out["exchange"]["warning"] = "sparse grid exchange overflowed during the run: gradients of those steps were incomplete"
         out["execution"] = (("one captured HIP graph per step (torch.cuda.CUDAGraph), K replays timed"
                              + ("; the RCCL gradient exchange is issued eagerly between replays" if world > 1 else ""))
                             if exec_mode == "graph" else "eager stream launches")

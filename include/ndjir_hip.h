@@ -85,8 +85,10 @@ int ndjir_voxel_feature_check_touched(int N, const float* grad_feature, const fl
  * cell) of the cells in the interpolation stencils of the N query points to a packed list -- ids (capacity) int32, rows
  * (capacity, D) -- each cell once (bitmap: 1 bit per cell, all zero before the first call, cleared again by
  * ndjir_sparse_rows_clear_bitmap); *count (device int) keeps counting past capacity.  After all-gathers of the counts
- * and of the first `limit` rows of every rank -- ids (world, capacity), rows (world, capacity, D), counts (world), all
- * device memory, only [r][0..limit) communicated -- ndjir_sparse_rows_apply adds every other rank's rows into the local
+ * and of the first `limit` rows of every rank -- ids (world, limit), rows (world, limit, D) packed with row stride
+ * `capacity` (ndjir_sparse_rows_apply; pass capacity = limit for the layout one all_gather_into_tensor leaves behind) or
+ * `*limit` (ndjir_sparse_rows_zero), counts (world), all device memory -- ndjir_sparse_rows_apply adds every other rank's
+ * rows into the local
  * buffer, ndjir_sparse_rows_overflow raises a device flag when some rank listed more than `limit` rows (the caller
  * vetoes that optimizer step and grows `limit`; no host synchronisation per step), and ndjir_sparse_rows_zero clears
  * all listed rows (own_ids / own_count non-null: this rank's own rows from its local list, which may exceed `limit`),
@@ -107,8 +109,11 @@ int ndjir_grid_pack_rows(int topo, int interp, int N, const float* grad_feature,
 int ndjir_sparse_rows_clear_bitmap(const int* ids, const int* count, int capacity, unsigned* bitmap, hipStream_t stream);
 int ndjir_sparse_rows_apply(const int* ids, const float* rows, const int* counts, int world, int capacity, int limit,
                             int skip_rank, float* grad_feature, int D, hipStream_t stream);
-int ndjir_sparse_rows_overflow(const int* counts, int world, int limit, int* flag, hipStream_t stream);
-/* (`limit`: device int here -- the call may be replayed from a captured HIP graph after the limit has grown) */
+/* stats (device, 2 ints, may be null): [0] running maximum of the counts over all exchanges (the host sizes `limit` from it
+ * at its next look, whichever exchange overflowed), [1] number of exchanges that overflowed */
+int ndjir_sparse_rows_overflow(const int* counts, int world, int limit, int* flag, int* stats, hipStream_t stream);
+/* (`limit`: device int here -- the call may be replayed from a captured HIP graph after the limit has grown; it is also the
+ * row stride of the communicated lists; `capacity`: that of this rank's own list) */
 int ndjir_sparse_rows_zero(const int* ids, const int* counts, int world, int capacity, const int* limit, int own_rank,
                            const int* own_ids, const int* own_count, float* grad_feature, int D, hipStream_t stream);
 NDJIR_DECL_VOXEL_FAMILY(cosine_voxel_feature)
@@ -453,6 +458,14 @@ int ndjir_mlp_set_tile_rows(int rows);
 int ndjir_mlp_get_tile_rows(void);
 long long ndjir_mlp_packed_size(int K, int N, int transpose);
 int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
+/* f16x3 arithmetic: W (K, N) with row stride ldw (a column slice of a wider matrix packs without a copy) */
+int ndjir_mlp_pack_strided(const float* W, int ldw, float* dst, int K, int N, int transpose, hipStream_t stream);
+/* f16x3 arithmetic: re-pack many matrices in ONE launch (what the optimizer step issues after its update instead of one
+ * pack per weight and orientation).  table: DEVICE array of n entries of ndjir_mlp_pack_entry_bytes() = 48 bytes:
+ * { const float* W; float* dst; int K, N, ldw, transpose, Kp, Np, first_block, pad } -- Kp = round_up(transpose ? N : K, 16),
+ * Np = round_up(transpose ? K : N, 32), first_block = running sum of Np / 32; total_blocks = that sum over all entries. */
+int ndjir_mlp_pack_table(const void* table, int n, int total_blocks, hipStream_t stream);
+int ndjir_mlp_pack_entry_bytes(void);
 int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L,
                     const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
                     const float* const* side_in, float* const* side_out, const int* ld_side,

@@ -35,9 +35,28 @@ extern "C" long long ndjir_mlp_packed_size(int K, int N, int transpose) {
 extern "C" int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream) {
   if (!W || !dst || K <= 0 || N <= 0) return NDJIR_ERR_ARG;
   if (g_math == NDJIR_MATH_BF16X6) return launch_pack6(W, dst, K, N, transpose, stream);
-  if (g_math == NDJIR_MATH_F16X3) return launch_pack3(W, dst, K, N, transpose, stream);
+  if (g_math == NDJIR_MATH_F16X3) return launch_pack3(W, N, dst, K, N, transpose, stream);
   return launch_pack(W, dst, K, N, transpose, stream);
 }
+
+// f16x3 arithmetic only: W (K, N) with row stride ldw >= N (a column slice of a wider matrix, packed without a copy)
+extern "C" int ndjir_mlp_pack_strided(const float* W, int ldw, float* dst, int K, int N, int transpose, hipStream_t stream) {
+  if (!W || !dst || K <= 0 || N <= 0 || ldw < N) return NDJIR_ERR_ARG;
+  if (g_math != NDJIR_MATH_F16X3) return NDJIR_ERR_UNSUPPORTED;
+  return launch_pack3(W, ldw, dst, K, N, transpose, stream);
+}
+
+// f16x3 arithmetic only: re-pack many matrices in one launch.  `table`: DEVICE array of n entries of
+// ndjir_mlp_pack_entry_bytes() bytes each -- { const float* W; float* dst; int K, N, ldw, transpose, Kp, Np, first_block, pad } with
+// Kp / Np the padded dims of the packed matrix (ndjir_mlp_packed_dims) and first_block the running sum of Np / 32;
+// total_blocks = that sum over all entries.
+extern "C" int ndjir_mlp_pack_table(const void* table, int n, int total_blocks, hipStream_t stream) {
+  if (n <= 0) return NDJIR_OK;
+  if (!table || total_blocks <= 0) return NDJIR_ERR_ARG;
+  if (g_math != NDJIR_MATH_F16X3) return NDJIR_ERR_UNSUPPORTED;
+  return launch_pack3_table(static_cast<const PackEntry*>(table), n, total_blocks, stream);
+}
+extern "C" int ndjir_mlp_pack_entry_bytes(void) { return (int)sizeof(PackEntry); }
 
 static long long* g_timeline = nullptr;   // diagnostics only, see ndjir_mlp_debug_timeline
 

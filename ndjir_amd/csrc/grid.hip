@@ -766,22 +766,28 @@ __global__ void __launch_bounds__(256) k_scatter_tiles(long long P, float* __res
 
 static inline int grid_blocks(long long threads);
 
-// device scratch of the binned scatter, kept by the library (grown outside stream capture only)
+// Device scratch of the binned scatter, kept by the library.  A HIP graph captured earlier holds the block's address in its
+// count / scan / fill / scatter nodes, so a block is NEVER freed or moved once it has been handed out: a larger request
+// (outside stream capture only) allocates a NEW block and retires the old one, which stays alive for the replays that still
+// point at it (a handful of blocks per process at most: sizes grow by 1.5x).  One block serves one stream at a time: the
+// launches that use it are ordered on the caller's stream, and two streams scattering concurrently must not share the
+// library's block -- the step issues its scatters on one stream.
 static int* g_bin_scratch = nullptr;
 static size_t g_bin_scratch_ints = 0;
+static int g_bin_retired = 0;          // blocks kept alive for earlier captures
 
 static int* bin_scratch(size_t ints, hipStream_t stream) {
   if (ints <= g_bin_scratch_ints) return g_bin_scratch;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-  if (hipDeviceSynchronize() != hipSuccess) return nullptr;                 // nobody may still be using the old block
-  if (g_bin_scratch) (void)hipFree(g_bin_scratch);
-  g_bin_scratch = nullptr;
-  g_bin_scratch_ints = 0;
-  size_t want = ints + ints / 2;
-  if (hipMalloc(reinterpret_cast<void**>(&g_bin_scratch), want * sizeof(int)) != hipSuccess) { g_bin_scratch = nullptr; return nullptr; }
+  const size_t want = ints + ints / 2;
+  int* fresh = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(int)) != hipSuccess) return nullptr;
+  if (g_bin_scratch) ++g_bin_retired;  // (deliberately not freed: see above)
+  g_bin_scratch = fresh;
   g_bin_scratch_ints = want;
-  if (getenv("NDJIR_DEBUG_SCRATCH")) fprintf(stderr, "[ndjir] bin scratch -> %zu ints at %p\n", want, (void*)g_bin_scratch);
+  if (getenv("NDJIR_DEBUG_SCRATCH"))
+    fprintf(stderr, "[ndjir] bin scratch -> %zu ints at %p (%d retired block(s) kept)\n", want, (void*)g_bin_scratch, g_bin_retired);
   return g_bin_scratch;
 }
 

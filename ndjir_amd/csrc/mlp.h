@@ -61,7 +61,17 @@ int launch_pack6(const float* W, float* dst, int K, int N, int transpose, hipStr
 int launch_chain6(const ChainArgs& a, int mode, hipStream_t stream);
 // f16 2-way-split engine (mlp3.hip): same ChainArgs, weights packed by launch_pack3 (per-column-block scales inside)
 long long packed_size3(int K, int N, int transpose);
-int launch_pack3(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
+int launch_pack3(const float* W, int ldw, float* dst, int K, int N, int transpose, hipStream_t stream);
+// one entry of the device table of ndjir_mlp_pack_table (layout shared with ndjir_amd/mlp.py: 2 pointers + 8 ints = 48 bytes)
+struct PackEntry {
+  const float* W;       // (K, N) fp32, row stride ldw
+  float* dst;           // packed_size3(K, N, transpose) floats
+  int K, N, ldw, transpose;
+  int Kp, Np;           // padded dims of the packed matrix (rows of 16, columns of 32)
+  int first_block;      // first workgroup of this entry ( = sum of Np / 32 of the entries before it)
+  int pad;
+};
+int launch_pack3_table(const PackEntry* table, int n, int total_blocks, hipStream_t stream);
 int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream);
 // f16 2-way-split engine on 128-point tiles (mlp3w.hip); NDJIR_ERR_UNSUPPORTED = not a launch for this kernel
 int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream);

@@ -57,10 +57,9 @@ __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >
 // offset Kp * Np: 1 / s_nb for every column block.  One workgroup per column block: slab maximum, then the split.
 // transpose packs W^T.
 constexpr int PACK_T = 1024;
-__global__ void __launch_bounds__(PACK_T) k_pack3(const float* __restrict__ W, _Float16* __restrict__ dst, float* __restrict__ inv_out,
-                                               int K, int N, int transpose, int Kp, int Np) {
-  __shared__ unsigned red[PACK_T];
-  const int nb = blockIdx.x;
+// one column block nb of one matrix: W (K, N) with row stride ldw (a column slice of a wider matrix packs in place)
+__device__ __forceinline__ void pack3_block(const float* __restrict__ W, int ldw, _Float16* __restrict__ dst, float* __restrict__ inv_out,
+                                            int K, int N, int transpose, int Kp, int Np, int nb, unsigned* red) {
   const int KS = Kp >> 4;
   const int total = Kp * 32;
   auto value = [&](int t) -> float {
@@ -68,8 +67,8 @@ __global__ void __launch_bounds__(PACK_T) k_pack3(const float* __restrict__ W, _
     if (!transpose) { c = t & 31; k = t >> 5; } else { k = t % Kp; c = t / Kp; }     // contiguous axis fastest
     const int n = nb * 32 + c;
     float v = 0.f;
-    if (!transpose) { if (k < K && n < N) v = W[(long long)k * N + n]; }
-    else { if (k < N && n < K) v = W[(long long)n * N + k]; }
+    if (!transpose) { if (k < K && n < N) v = W[(long long)k * ldw + n]; }
+    else { if (k < N && n < K) v = W[(long long)n * ldw + k]; }
     return v;
   };
   unsigned m = 0;
@@ -94,6 +93,27 @@ __global__ void __launch_bounds__(PACK_T) k_pack3(const float* __restrict__ W, _
     dst[base] = hi;
     dst[base + 64 * 8] = lo;
   }
+}
+
+__global__ void __launch_bounds__(PACK_T) k_pack3(const float* __restrict__ W, int ldw, _Float16* __restrict__ dst,
+                                               float* __restrict__ inv_out, int K, int N, int transpose, int Kp, int Np) {
+  __shared__ unsigned red[PACK_T];
+  pack3_block(W, ldw, dst, inv_out, K, N, transpose, Kp, Np, blockIdx.x, red);
+}
+
+// Many matrices in ONE launch: a device table of (matrix, orientation) entries, one workgroup per column block of every
+// entry.  What the optimizer step launches after its update instead of one pack per weight and orientation (~50 launches
+// per training iteration): the packed copies are persistent buffers, rewritten in place.
+__global__ void __launch_bounds__(PACK_T) k_pack3_table(const PackEntry* __restrict__ tab, int n) {
+  __shared__ unsigned red[PACK_T];
+  int lo = 0, hi = n - 1;                       // last entry whose first_block <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackEntry e = tab[lo];
+  pack3_block(e.W, e.ldw, reinterpret_cast<_Float16*>(e.dst), e.dst + (long long)e.Kp * e.Np, e.K, e.N, e.transpose, e.Kp, e.Np,
+              (int)blockIdx.x - e.first_block, red);
 }
 
 // ---- the chain kernel ---------------------------------------------------------------------------
@@ -922,10 +942,16 @@ long long packed_size3(int K, int N, int transpose) {
   return (long long)Kp * Np + x3::round_up(Np / 32, 4);       // two f16 planes + 1/scale per column block, in floats
 }
 
-int launch_pack3(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream) {
+int launch_pack3(const float* W, int ldw, float* dst, int K, int N, int transpose, hipStream_t stream) {
   const int Kp = x3::round_up(transpose ? N : K, 16), Np = x3::round_up(transpose ? K : N, 32);
-  hipLaunchKernelGGL(x3::k_pack3, dim3(Np / 32), dim3(x3::PACK_T), 0, stream, W, reinterpret_cast<_Float16*>(dst),
+  hipLaunchKernelGGL(x3::k_pack3, dim3(Np / 32), dim3(x3::PACK_T), 0, stream, W, ldw, reinterpret_cast<_Float16*>(dst),
                      dst + (long long)Kp * Np, K, N, transpose, Kp, Np);
+  return ndjir_check_launch();
+}
+
+int launch_pack3_table(const PackEntry* table, int n, int total_blocks, hipStream_t stream) {
+  if (n <= 0 || total_blocks <= 0) return NDJIR_OK;
+  hipLaunchKernelGGL(x3::k_pack3_table, dim3(total_blocks), dim3(x3::PACK_T), 0, stream, table, n);
   return ndjir_check_launch();
 }
 

@@ -2,8 +2,10 @@
 // The reference has no distributed code; a dense grid gradient (2 GiB for the 512^3 x 4 voxel grid, 403 MB for the
 // 3 x 2048^2 x 8 tri-plane) is exchanged as packed lists of (cell id, row of D floats) per rank
 // (ndjir_grid_pack_rows), all-gathered with a common, fixed number of rows:
-//   lists: ids (world, cap) int32, rows (world, cap, D) fp32, counts (world) int32 -- all in device memory;
-//   `limit` = rows per rank that were actually communicated (a rank whose count exceeds it raised the overflow flag).
+//   lists: ids (world, limit) int32, rows (world, limit, D) fp32 -- packed with row stride `limit`, the layout one
+//   all_gather_into_tensor of every rank's first `limit` rows leaves behind (no per-rank copies) --, counts (world) int32,
+//   all in device memory; `limit` = rows per rank that were actually communicated (a rank whose count exceeds it raised
+//   the overflow flag and entered the statistics from which the host grows `limit`).
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -35,6 +37,7 @@ __global__ void __launch_bounds__(256) k_rows_apply(const int* __restrict__ ids,
 // buf[cell] = 0 for every listed row: the other ranks' communicated rows and ALL of this rank's own rows (own_ids /
 // own_count: the local list, which may be longer than `limit`) -- re-arms the accumulate-in-place buffer
 // (`limit` is read from device memory: the call may be replayed from a captured HIP graph after the limit has grown)
+// `cap`: capacity of the own list (and upper bound of `limit`)
 template <int D4>
 __global__ void __launch_bounds__(256) k_rows_zero(const int* __restrict__ ids, const int* __restrict__ counts, int world, int cap,
                                                    const int* __restrict__ limit_p, int own_rank, const int* __restrict__ own_ids,
@@ -49,7 +52,7 @@ __global__ void __launch_bounds__(256) k_rows_zero(const int* __restrict__ ids, 
     if (t < remote) {
       const int r = (int)(t / limit), i = (int)(t - (long long)r * limit);
       if ((own_ids && r == own_rank) || i >= counts[r]) continue;
-      cell = ids[(long long)r * cap + i];
+      cell = ids[(long long)r * limit + i];          // (packed lists: row stride = the communicated size)
     } else {
       cell = own_ids[t - remote];
     }
@@ -68,11 +71,21 @@ __global__ void __launch_bounds__(256) k_rows_clear_bitmap(const int* __restrict
 }
 
 // *flag |= 1 when a rank listed more rows than were communicated (the step's grid gradient is then incomplete: the
-// caller vetoes the optimizer step on the device and grows the communicated size)
-__global__ void k_rows_overflow(const int* __restrict__ counts, int world, int limit, int* __restrict__ flag) {
+// caller vetoes the optimizer step on the device and grows the communicated size).  stats (may be null): [0] running
+// maximum of the counts over all exchanges -- what the host sizes `limit` from at its next look, whichever exchange
+// overflowed --, [1] number of exchanges that overflowed.
+__global__ void k_rows_overflow(const int* __restrict__ counts, int world, int limit, int* __restrict__ flag,
+                                int* __restrict__ stats) {
   bool over = false;
-  for (int r = threadIdx.x; r < world; r += 64) over |= counts[r] > limit;
-  if (__any(over) && threadIdx.x == 0) *flag = 1;
+  int most = 0;
+  for (int r = threadIdx.x; r < world; r += 64) { over |= counts[r] > limit; most = counts[r] > most ? counts[r] : most; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(most, off); most = o > most ? o : most; }
+  const bool any_over = __any(over);
+  if (threadIdx.x == 0) {
+    if (any_over) *flag = 1;
+    if (stats) { if (most > stats[0]) stats[0] = most; if (any_over) stats[1] += 1; }
+  }
 }
 
 static int blocks_for(long long n) {
@@ -117,9 +130,9 @@ extern "C" int ndjir_sparse_rows_clear_bitmap(const int* ids, const int* count, 
   return ndjir_check_launch();
 }
 
-extern "C" int ndjir_sparse_rows_overflow(const int* counts, int world, int limit, int* flag, hipStream_t stream) {
+extern "C" int ndjir_sparse_rows_overflow(const int* counts, int world, int limit, int* flag, int* stats, hipStream_t stream) {
   if (world <= 0) return NDJIR_OK;
   if (!counts || !flag) return NDJIR_ERR_ARG;
-  hipLaunchKernelGGL(k_rows_overflow, dim3(1), dim3(64), 0, stream, counts, world, limit, flag);
+  hipLaunchKernelGGL(k_rows_overflow, dim3(1), dim3(64), 0, stream, counts, world, limit, flag, stats);
   return ndjir_check_launch();
 }

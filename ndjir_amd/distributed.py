@@ -83,6 +83,7 @@ class SparseRows:
     def zero(self, buf):
         from . import lib
         st = self.st
+        # (the communicated lists are packed with row stride *limit_dev; cap = capacity of this rank's own list)
         lib.call("sparse_rows_zero", st["ids_all"], st["counts_all"], st["world"], st["cap"], st["limit_dev"], self.rank,
                  st["ids"], st["count"], buf, buf.shape[-1])
 
@@ -112,6 +113,7 @@ def _state(buf, capacity, world):
                   bitmap=torch.zeros((cells + 31) // 32, dtype=torch.int32, device=dev),
                   count=torch.zeros(1, dtype=torch.int32, device=dev),
                   overflow=torch.zeros(1, dtype=torch.int32, device=dev),
+                  stats=torch.zeros(2, dtype=torch.int32, device=dev),
                   limit_dev=torch.zeros(1, dtype=torch.int32, device=dev),
                   ids=torch.empty(capacity, dtype=torch.int32, device=dev),
                   rows=torch.empty((capacity, D), dtype=torch.float32, device=dev),
@@ -136,8 +138,9 @@ def exchange_grid_rows_hip(buf, family, queries, min_=(-1.0, -1.0, -1.0), max_=(
 
     No host synchronisation per step: `limit` (rows per rank on the wire) is fixed -- measured on the first exchange
     with 50 % head-room -- and a device flag (`st["overflow"]`, returned with the handle) is raised when some rank listed
-    more; the caller vetoes that optimizer step on the device (Step.optimizer_step) and `limit` grows at the next look
-    at the counts, every CHECK_EVERY exchanges.  List capacity = the worst case (every stencil cell distinct): lists
+    more; the caller vetoes that optimizer step on the device (Step.optimizer_step, which counts the vetoes) and `limit`
+    grows at the next look, every CHECK_EVERY exchanges, from the running maximum the device keeps over ALL exchanges
+    (`st["stats"]`).  List capacity = the worst case (every stencil cell distinct): lists
     never grow, their addresses never change.  Returns the buffer's `SparseRows` handle."""
     from . import lib
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -160,22 +163,44 @@ def exchange_grid_rows_hip(buf, family, queries, min_=(-1.0, -1.0, -1.0), max_=(
     lib.call("sparse_rows_clear_bitmap", st["ids"], st["count"], cap, st["bitmap"])
     counts = st["counts_all"]
     gg = grid_group(group) if world > 1 else group
-    dist.all_gather(list(counts.view(world, 1).unbind(0)), st["count"], group=gg)
+    _gather_into(counts, st["count"], world, gg)
     st["calls"] += 1
     if st["limit"] is None or st["calls"] % CHECK_EVERY == 0:
-        most = int(counts.max().item())               # the only host synchronisation, once per CHECK_EVERY exchanges
+        # the only host synchronisation, once per CHECK_EVERY exchanges: the largest list of THIS exchange and the running
+        # maximum the device has kept over all exchanges since the last look (k_rows_overflow), so that an overflow on any of
+        # the steps in between grows the limit, not only one on the step that happens to be looked at
+        most = max(int(counts.max().item()), int(st["stats"][0].item()))
         assert most <= cap, "more distinct cells than stencil taps"
         want = min(cap, max(4096, -(-int(most * 1.5) // 4096) * 4096))
         if st["limit"] is None or want > st["limit"]:
             st["limit"] = want
             st["limit_dev"].fill_(want)
     m = st["limit"]
-    ids, rows = st["ids_all"], st["rows_all"]
-    dist.all_gather([ids[r, :m] for r in range(world)], st["ids"][:m], group=gg)
-    dist.all_gather([rows[r, :m] for r in range(world)], st["rows"][:m], group=gg)
-    lib.call("sparse_rows_overflow", counts, world, m, st["overflow"])
-    lib.call("sparse_rows_apply", ids, rows, counts, world, cap, m, rank, buf, D)
+    # every rank's first m rows, packed (world, m): the layout all_gather_into_tensor fills without per-rank copies
+    ids = st["ids_all"].view(-1)[:world * m].view(world, m)
+    rows = st["rows_all"].view(-1)[:world * m * D].view(world, m, D)
+    _gather_into(ids, st["ids"][:m], world, gg)
+    _gather_into(rows, st["rows"][:m], world, gg)
+    lib.call("sparse_rows_overflow", counts, world, m, st["overflow"], st["stats"])
+    lib.call("sparse_rows_apply", ids, rows, counts, world, m, m, rank, buf, D)
     return SparseRows(st, rank)
+
+
+def _gather_into(out, mine, world, group):
+    """out (world, ...) <- every rank's `mine` (...): one collective into one contiguous tensor."""
+    if world == 1 and not dist.is_initialized():
+        out.view(-1).copy_(mine.reshape(-1))
+        return
+    try:
+        dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError):          # a backend without the flat form
+        dist.all_gather(list(out.unbind(0)), mine.contiguous(), group=group)
+
+
+def exchange_statistics():
+    """{buffer address: (largest list seen, exchanges that overflowed the wire size, current wire size)} of every sparsely
+    exchanged grid gradient (host synchronisation: for reports / tests, not for the step)."""
+    return {k: (int(st["stats"][0].item()), int(st["stats"][1].item()), st["limit"]) for k, st in _STATE.items()}
 
 
 def allreduce_voxel_rows_hip(buf, queries, min_=(-1.0, -1.0, -1.0), max_=(1.0, 1.0, 1.0), group=None):

@@ -39,6 +39,8 @@ def _family(prefix, fwd, tail):
 SIGS = {
     "zero": "pl",
     "mlp_pack": "ppiii",
+    "mlp_pack_strided": "pipiii",
+    "mlp_pack_table": "xii",
     # bwd P X ldx K0 L Wp bias Ks Ns side_in side_out ld_side bgrad Y ldy accum has_out beta skip scale split Xskip ld
     # ... in_bgrad workspace side_amax x_amax
     "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi" + "pp" + "Pp",
@@ -90,7 +92,7 @@ SIGS = {
     "sparse_rows_clear_bitmap": "qqiq",
     "grid_pack_rows": "iiippIiFFqqpqi",
     "sparse_rows_apply": "qpqiiiipi",
-    "sparse_rows_overflow": "qiiq",
+    "sparse_rows_overflow": "qiiqq",
     "sparse_rows_zero": "qqiiqiqqpi",
     "generate_raydir_camloc": "iixxqpipp",
     "solver_adam_begin": "xffqq",
@@ -252,7 +254,7 @@ def symbols():
                                             "ndjir_hash_table_size", "ndjir_hash_num_params",
                                             "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_colsum_workspace",
                                             "ndjir_mlp_chain_workspace", "ndjir_mlp_set_math", "ndjir_mlp_get_math",
-                                            "ndjir_mlp_set_tile_rows", "ndjir_mlp_get_tile_rows",
+                                            "ndjir_mlp_set_tile_rows", "ndjir_mlp_get_tile_rows", "ndjir_mlp_pack_entry_bytes",
                                             "ndjir_mlp_debug_timeline", "ndjir_loss_terms_workspace", "ndjir_grid_set_scatter_bins_from",
                                             "ndjir_grid_get_scatter_bins_from"]
 

@@ -75,11 +75,18 @@ _MATH_READY = False
 
 
 def _packed(W, transpose):
-    """MFMA-fragment-order copy of W (or W^T); cached per (storage, version)."""
+    """MFMA-fragment-order copy of W (or W^T).  Untracked weights: cached per (storage, version).  Tracked weights
+    (`track_weights`, f16x3 arithmetic): a persistent packed buffer per (weight, orientation) that `repack_tracked` -- one
+    launch, issued by the optimizer after its update -- rewrites in place; W may then be a column slice of a wider
+    matrix (row stride > width), packed without a copy."""
     global _MATH_READY
     if not _MATH_READY:
         _init_math()
         _MATH_READY = True
+    if _TRACK is not None and get_math() == MATH_F16X3 and W.is_cuda and W.dim() == 2 and W.stride(1) == 1:
+        return _tracked(W, bool(transpose))
+    if not W.is_contiguous():
+        W = W.contiguous()
     key = (W.data_ptr(), W._version, tuple(W.shape), bool(transpose), get_math())
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0]() is W:     # same live tensor object, same version
@@ -92,6 +99,82 @@ def _packed(W, transpose):
         _PACK_CACHE.clear()
     _PACK_CACHE[key] = (weakref.ref(W), dst)
     return dst
+
+
+# ---- tracked weights: persistent packed copies, refreshed by ONE launch after the optimizer's update -----------------------
+_TRACK = None          # None = off; else {key: entry}
+_TRACK_TABLE = None    # (device table, entries, total column blocks) or None when entries were added since it was built
+
+
+class _Entry:
+    __slots__ = ("W", "transpose", "dst", "version", "K", "N", "ldw")
+
+
+def track_weights(on=True):
+    """Training mode of the packed-weight store (python/train.py's iteration changes every weight every step): every
+    (weight, orientation) a chain asks for from now on gets a persistent packed buffer, and `repack_tracked()` rewrites
+    all of them with one launch.  A weight changed by anyone else (its version counter moved) is re-packed on its next
+    use.  off: back to the per-version cache (the buffers are dropped)."""
+    global _TRACK, _TRACK_TABLE
+    _TRACK = {} if on else None
+    _TRACK_TABLE = None
+
+
+def _base_version(W):
+    return W._base._version if W._base is not None else W._version
+
+
+def _tracked(W, transpose):
+    global _TRACK_TABLE
+    key = (W.data_ptr(), tuple(W.shape), W.stride(0), transpose)
+    e = _TRACK.get(key)
+    if e is None:
+        K, N = W.shape
+        e = _Entry()
+        e.W, e.transpose, e.K, e.N, e.ldw = W.detach(), transpose, K, N, W.stride(0)
+        e.dst = torch.empty(lib.load().ndjir_mlp_packed_size(K, N, int(transpose)), device=W.device, dtype=torch.float32)
+        e.version = None
+        if len(_TRACK) > 2048:
+            _TRACK.clear()
+        _TRACK[key] = e
+        _TRACK_TABLE = None
+    v = _base_version(W)
+    if e.version != v:             # new, or changed behind the store's back: this one alone, now
+        lib.call("mlp_pack_strided", _Strided(e.W), e.ldw, e.dst, e.K, e.N, int(transpose))
+        e.version = v
+    return e.dst
+
+
+def repack_tracked():
+    """Rewrite every tracked packed buffer from its weight: one launch (ndjir_mlp_pack_table).  Called by the optimizer
+    right after its update -- inside the captured training graph when there is one."""
+    global _TRACK_TABLE
+    if not _TRACK:
+        return
+    if _TRACK_TABLE is None:
+        if torch.cuda.is_current_stream_capturing():
+            # entries appeared during the capture itself (a weight used for the first time): pack them one by one
+            for e in _TRACK.values():
+                lib.call("mlp_pack_strided", _Strided(e.W), e.ldw, e.dst, e.K, e.N, int(e.transpose))
+            return
+        import numpy as np
+        ents = list(_TRACK.values())
+        assert lib.load().ndjir_mlp_pack_entry_bytes() == 48
+        rec = np.zeros(len(ents), dtype=np.dtype([("W", "<u8"), ("dst", "<u8"), ("K", "<i4"), ("N", "<i4"), ("ldw", "<i4"),
+                                                   ("transpose", "<i4"), ("Kp", "<i4"), ("Np", "<i4"), ("first", "<i4"), ("pad", "<i4")]))
+        first = 0
+        for i, e in enumerate(ents):
+            Kp = -(-(e.N if e.transpose else e.K) // 16) * 16
+            Np = -(-(e.K if e.transpose else e.N) // 32) * 32
+            rec[i] = (e.W.data_ptr(), e.dst.data_ptr(), e.K, e.N, e.ldw, int(e.transpose), Kp, Np, first, 0)
+            first += Np // 32
+        dev = ents[0].dst.device
+        table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+        _TRACK_TABLE = (table, ents, first)
+    table, ents, blocks = _TRACK_TABLE
+    lib.call("mlp_pack_table", table, len(ents), blocks)
+    for e in ents:
+        e.version = _base_version(e.W)
 
 
 _AMAX_ARENA = {}      # device -> [zeroed tensor, next free slot]

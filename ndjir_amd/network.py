@@ -334,6 +334,9 @@ _SDF_COL_CACHE = {}
 def _sdf_column(t):
     """Column 0 of the last layer (weights (D, 1+D) -> (D, 1), bias (1+D,) -> (1,)) as a stable
     tensor object (so that its packed copy is cached); refreshed when the parameter changes."""
+    from . import mlp as _mlp
+    if t.dim() == 2 and _mlp._TRACK is not None and t.is_cuda:
+        return t.detach()[..., 0:1]          # tracked weights pack straight from the parameter (row stride = its width)
     key = (t.data_ptr(), t._version)
     hit = _SDF_COL_CACHE.get(key)
     if hit is None or hit[0] is not t:

@@ -80,6 +80,10 @@ def set_parameters(d):
 
 def clear_parameters():
     _params.clear()
+    import sys
+    m = sys.modules.get("ndjir_amd.mlp")
+    if m is not None and m._TRACK is not None:      # persistent packed copies point at the parameters that just went away
+        m.track_weights(False)
 
 
 def save_parameters(path):

@@ -168,6 +168,11 @@ class Adam:
                      self.beta2, self.eps, d, self.state)
         for p in self.params:            # kernels wrote the parameters behind autograd's back: packed-weight caches etc.
             torch.autograd.graph.increment_version(p)
+        if any(p.dim() == 2 for p in self.params):
+            # the MLP weights' packed (MFMA fragment order) copies: ONE launch over every tracked (weight, orientation)
+            # instead of one pack launch per weight and orientation at their next use (ndjir_amd/mlp.py `track_weights`)
+            from . import mlp
+            mlp.repack_tracked()
 
     # -- introspection ---------------------------------------------------------------------------------------------
     def step_count(self):

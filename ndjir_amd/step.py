@@ -55,6 +55,7 @@ class Step:
         self.touched_ptb = None  # ... and their perturbed twins (x_fg + the noise of THAT step: redraw_rand may follow)
         self.remote_rows = {}    # multi-GPU: grid rows received from the other ranks in the previous exchange
         self.mask_sum = torch.zeros((), device=device)   # multi-GPU: all-reduced sum of the ray masks
+        self.vetoed_steps = torch.zeros(1, dtype=torch.int32, device=device)   # optimizer steps skipped because an exchange overflowed
         self.x_fg = None
         self.mlp_names = None
         self._zeros = None
@@ -193,6 +194,19 @@ class Step:
         # a rank that listed more rows than fit on the wire: this step's grid gradient is incomplete -> veto the update
         self.exchange_overflow = [h.st["overflow"] for h in self.remote_rows.values() if isinstance(h, SparseRows)]
 
+    def exchange_report(self):
+        """Host-side numbers of the sparse grid exchange since the step was built (one synchronisation: reports / tests /
+        the end of a bench run, not the step): exchanges that overflowed the wire size -- their grid gradient was
+        incomplete --, the largest list seen, the wire size, and the optimizer steps vetoed for it."""
+        from ndjir_amd.distributed import SparseRows
+        rep = {}
+        for name, h in self.remote_rows.items():
+            if isinstance(h, SparseRows):
+                st = h.st
+                rep[name] = dict(largest_list=int(st["stats"][0].item()), overflowed_exchanges=int(st["stats"][1].item()),
+                                 wire_rows=st["limit"])
+        return dict(buffers=rep, vetoed_optimizer_steps=int(self.vetoed_steps.item()))
+
     def forward_backward(self):
         self.pre_exchange()
         loss = self.compute()
@@ -209,6 +223,8 @@ class Step:
         conf.train.batch_size, conf.train.n_rays = 1, self.R * self.world      # learning rates scale with B R / 512
         self.solvers = Solvers(conf)
         self.solvers.set_parameters()
+        from ndjir_amd import mlp
+        mlp.track_weights(True)      # persistent packed weights, re-packed by one launch after every update
         t = conf.train
         self.solvers.update_learning_rate(int(t.epoch * t.warmup_term_ratio) if epoch_index is None else epoch_index)
         self.rearm_grid_buffers()
@@ -217,6 +233,9 @@ class Step:
                 buf = self.grid_bufs[name]
                 buf.view(-1, buf.shape[-1]).index_fill_(0, rows, 0.0)
         self.remote_rows = {}
+        for flag in getattr(self, "exchange_overflow", []):      # a flag left by forward_backward-only steps must not veto
+            flag.zero_()                                          # the first training step (it is reported, see below)
+        self.vetoed_steps.zero_()
 
     def train_compute(self):
         """Everything of a training iteration that holds no collective (one GPU: the whole iteration)."""
@@ -233,8 +252,11 @@ class Step:
         self.set_solver_gradients()
         loss = self.loss
         for flag in getattr(self, "exchange_overflow", []):
-            # (device-side: an overflowing sparse exchange turns the loss the guard sees into NaN, which skips the update)
+            # (device-side: an overflowing sparse exchange turns the loss the guard sees into NaN, which skips the update;
+            # the skips are counted -- `exchange_report` -- and the wire size grows at the exchange's next look at the
+            # device's running maximum, ndjir_amd/distributed.py)
             loss = torch.where(flag > 0, torch.full_like(loss, float("nan")), loss)
+            self.vetoed_steps += (flag > 0).to(torch.int32)
             flag.zero_()
         self.solvers.guarded_update(loss)     # python/train.py:141-146: non-finite gradients or a NaN loss skip the update
 

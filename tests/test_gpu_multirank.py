@@ -17,10 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("mode,variant", [("eager", "default"), ("graph", "default"), ("eager", "custom"), ("eager", "triplaneline"),
-                                          ("graph", "triplaneline")])
+                                          ("graph", "triplaneline"), ("eager", "no_voxel"), ("graph", "no_voxel")])
 def test_two_ranks_equal_one_process(gpu, mode, variant):
     """variant: default (linear voxel, D = 4), custom (Lanczos voxel: 4 x 4 x 4 taps), triplaneline (tri-plane + tri-line,
-    D = 8): every grid gradient goes through the sparse row exchange -- no all-reduce larger than the MLP bucket."""
+    D = 8): every grid gradient goes through the sparse row exchange -- no all-reduce larger than the MLP bucket;
+    no_voxel (BASELINE.json config 4: config/no_voxel.yaml, ray-sharded): no grid at all, the exchange is the bucket alone."""
     import bench
     from ndjir_amd import config as cfg, parameter as P
     from ndjir_amd.grid_feature import set_grad_buffer
@@ -34,7 +35,7 @@ def test_two_ranks_equal_one_process(gpu, mode, variant):
         assert res.returncode == 0, res.stderr[-3000:]
         ranks = [torch.load(os.path.join(out, f"rank{r}.pt")) for r in range(2)]
     want = {"geometric-network/triplane_feature/F": "SparseRows", "geometric-network/triline_feature/F": "SparseRows"} \
-        if variant == "triplaneline" else {"geometric-network/voxel_feature/F": "SparseRows"}
+        if variant == "triplaneline" else {} if variant == "no_voxel" else {"geometric-network/voxel_feature/F": "SparseRows"}
     assert ranks[0]["handle"] == want                                                      # the HIP path ran
     n_mlp = int(ranks[0]["flat"].numel())
     assert max(ranks[0]["reduced"]) <= n_mlp, ("a dense grid all-reduce was issued", max(ranks[0]["reduced"]), n_mlp)

@@ -403,10 +403,11 @@ def test_sparse_row_exchange_kernels(gpu):
     # and zeroing with the rank's own full list still clears everything it wrote
     m = 4096
     flag = torch.zeros(1, dtype=torch.int32, device=gpu)
-    lib.call("sparse_rows_overflow", counts, 2, cap, flag)
-    assert int(flag) == 0
-    lib.call("sparse_rows_overflow", counts, 2, m, flag)
-    assert int(flag) == 1
+    stats = torch.zeros(2, dtype=torch.int32, device=gpu)
+    lib.call("sparse_rows_overflow", counts, 2, cap, flag, stats)
+    assert int(flag) == 0 and stats.tolist() == [int(counts.max()), 0]
+    lib.call("sparse_rows_overflow", counts, 2, m, flag, stats)
+    assert int(flag) == 1 and stats.tolist() == [int(counts.max()), 1]      # running maximum of the lists, overflowing exchanges
     buf = torch.zeros(G, G, G, D, device=gpu)
     lib.call("sparse_rows_apply", ids, rows, counts, 2, cap, m, 0, buf, D)
     want = torch.zeros(G ** 3, D, device=gpu)
@@ -415,7 +416,8 @@ def test_sparse_row_exchange_kernels(gpu):
     limit.fill_(m)
     own_cnt = counts[0:1].clone()
     buf.view(-1, D)[ids[0, :int(counts[0])].long()] = 1.0
-    lib.call("sparse_rows_zero", ids, counts, 2, cap, limit, 0, ids[0], own_cnt, buf, D)
+    packed = ids[:, :m].contiguous()           # the communicated lists are packed with row stride `limit`
+    lib.call("sparse_rows_zero", packed, counts, 2, cap, limit, 0, ids[0], own_cnt, buf, D)
     assert float(buf.abs().max()) == 0.0
     # overflow: the count runs past the capacity, nothing is written beyond it
     buf = dense.clone()
@@ -505,15 +507,16 @@ def test_grid_pack_rows_lists_every_nonzero_row_once(gpu, family, D):
     lib.call("sparse_rows_apply", ids_all, rows_all, counts, 2, cap, limit, 0, recv, D)
     assert torch.equal(recv, gf)
     flag = torch.zeros(1, dtype=torch.int32, device=gpu)
-    lib.call("sparse_rows_overflow", counts, 2, limit, flag)
+    lib.call("sparse_rows_overflow", counts, 2, limit, flag, None)
     assert int(flag) == 0
     if n > 1:
-        lib.call("sparse_rows_overflow", counts, 2, n - 1, flag)
+        lib.call("sparse_rows_overflow", counts, 2, n - 1, flag, None)
         assert int(flag) == 1
     lim_dev = torch.tensor([limit], dtype=torch.int32, device=gpu)
-    lib.call("sparse_rows_zero", ids_all, counts, 2, cap, lim_dev, 0, None, None, recv, D)
+    packed = ids_all[:, :limit].contiguous()   # the communicated lists are packed with row stride `limit`
+    lib.call("sparse_rows_zero", packed, counts, 2, cap, lim_dev, 0, None, None, recv, D)
     assert float(recv.abs().max()) == 0.0
-    lib.call("sparse_rows_zero", ids_all, torch.zeros_like(counts), 2, cap, lim_dev, 0, ids, count, gf, D)      # own list only
+    lib.call("sparse_rows_zero", packed, torch.zeros_like(counts), 2, cap, lim_dev, 0, ids, count, gf, D)      # own list only
     assert float(gf.abs().max()) == 0.0
 
 

@@ -111,3 +111,83 @@ def test_nan_loss_vetoes_the_update(gpu, bad):
     assert moved == (not bad)
     assert step.solvers.solver_weight.step_count() == t0 + (0 if bad else 1)
     assert step.solvers.solver_weight.skipped() == bad
+
+
+def test_tracked_packed_weights(gpu):
+    """Training mode of the packed-weight store (ndjir_amd/mlp.py `track_weights`): persistent packed copies, one
+    re-pack launch after the optimizer's update (ndjir_mlp_pack_table), a weight changed by someone else re-packed at its
+    next use, and a column slice of a wider matrix packed in place (the sdf column of the geometric net's last layer)."""
+    from ndjir_amd import mlp
+    rng = np.random.RandomState(2)
+    Ws = [torch.tensor(rng.randn(*s) * 0.1, dtype=torch.float32, device=gpu) for s in ((39, 128), (128, 128), (128, 257))]
+    bs = [torch.zeros(s, device=gpu) for s in (128, 128, 257)]
+    x = torch.tensor(rng.randn(256, 39), dtype=torch.float32, device=gpu)
+    try:
+        mlp.track_weights(False)
+        want0 = mlp.fused_mlp(x, Ws, bs).clone()
+        mlp.track_weights(True)
+        assert torch.equal(mlp.fused_mlp(x, Ws, bs), want0)                 # first use packs each weight on its own
+        n_entries = len(mlp._TRACK)
+        assert n_entries == 3
+        # (a) an in-place change that autograd sees: re-packed at the next use
+        Ws[1].mul_(1.5)
+        got = mlp.fused_mlp(x, Ws, bs).clone()
+        mlp.track_weights(False)
+        assert torch.equal(got, mlp.fused_mlp(x, Ws, bs))
+        # (b) a change behind autograd's back (what the optimizer kernels and a replayed graph do) + the one-launch re-pack
+        mlp.track_weights(True)
+        mlp.fused_mlp(x, Ws, bs)
+        for W in Ws:
+            W.data.mul_(0.5)                                              # no version bump
+        stale = mlp.fused_mlp(x, Ws, bs).clone()
+        mlp.repack_tracked()
+        fresh = mlp.fused_mlp(x, Ws, bs).clone()
+        mlp.track_weights(False)
+        mlp._PACK_CACHE.clear()                # (the per-version cache cannot see a change that moved no version either)
+        want = mlp.fused_mlp(x, Ws, bs)
+        assert torch.equal(fresh, want) and not torch.equal(stale, want)
+        # (c) a column slice packs like its contiguous copy, both orientations
+        mlp.track_weights(True)
+        col = Ws[2][:, 0:1]
+        assert not col.is_contiguous()
+        for tr in (False, True):
+            a = mlp._packed(col, tr).clone()
+            mlp.repack_tracked()
+            b = mlp._packed(col, tr).clone()
+            mlp.track_weights(False)
+            c = mlp._packed(col.contiguous(), tr)
+            assert torch.equal(a, c) and torch.equal(b, c)
+            mlp.track_weights(True)
+    finally:
+        mlp.track_weights(False)
+
+
+def test_training_graph_replay_then_eager(gpu):
+    """A captured training iteration (optimizer + the one-launch re-pack inside the graph) replayed, then the same step
+    issued eagerly, then replayed again: the eager step must run on the weights the replays left behind -- the packed
+    copies are rewritten by the graph itself, not keyed on a version counter that replays do not move."""
+    from ndjir_amd import mlp
+    step = _step(gpu, R=16, G=16)
+    try:
+        step.enable_training()
+        for _ in range(2):
+            step.train_step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step.train_compute()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        loss_eager = float(step.compute(rearm=True))                       # eager forward on the replays' weights
+        # reference: the same forward with every packed copy rebuilt from the current weights
+        mlp.track_weights(False)
+        mlp._PACK_CACHE.clear()
+        loss_fresh = float(step.compute(rearm=True))
+        assert loss_eager == loss_fresh
+        mlp.track_weights(True)
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.isfinite(float(step.loss))
+    finally:
+        mlp.track_weights(False)

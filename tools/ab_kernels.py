@@ -8,4 +8,5 @@ out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--train-
 d = json.loads(out)
 print(f"ms/step {d['ms_per_step']:.3f} (eager {d['eager']['ms_per_step']:.3f})  rays/s {d['value']:.0f}  loss {d['loss']:.10f}")
 for k, v in d["kernels"].items():
-    print(f"   {k:14s} {v['launches']:5d} x {v['avg_us']:8.1f} us = {v['launches'] * v['avg_us'] / d['steps'] / 1e3:6.3f} ms/step")
+    print(f"   {k:14s} {v['launches_per_step']:6.1f} x {v['avg_us']:8.1f} us = {v['ms_per_step']:6.3f} ms/step  {v['tflops']:6.1f} TFLOP/s")
+print("   roofline:", d["roofline"]["kernel_class"], d["roofline"]["kernel"][:60], round(d["roofline"]["frac"], 3))
