@@ -249,6 +249,169 @@ __global__ void __launch_bounds__(256) k_query(long long P, float* __restrict__ 
   NDJIR_GRID_THREAD_EPILOGUE
 }
 
+// Tri-plane / tri-line forward, one lane per POINT: the three sub-grids of a point are gathered by the same lane, which then
+// owns the point's whole output row (D, 3) -- D * 3 contiguous floats, written as 16-byte stores.  (k_query's lane per
+// (sub-grid, point) stores D scalars at a stride of 12 bytes into rows that three lanes of different workgroups share:
+// measured 4.2x / 3.1x write amplification at the reference authors' micro-benchmark shape.)
+template <int TOPO, int I, int D>
+__global__ void __launch_bounds__(256) k_query_rows(long long P, float* __restrict__ out, const float* __restrict__ query,
+                                                    const float* __restrict__ feature, GridDesc g) {
+  static_assert(TOPO == TRIPLANE || TOPO == TRILINE, "three sub-grids per point");
+  constexpr int ND = NDims<TOPO>::v, NT = NTaps<I>::v;
+  for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < P; b += (long long)gridDim.x * blockDim.x) {
+    const float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
+    float row[D * 3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      Stencil<TOPO, I> st;
+      make_stencil<TOPO, I>(st, g, s, q);
+      float acc[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc[d] = 0.f;
+      NDJIR_FOR_TAPS(ND, NT) {
+        const float w = tap_w(st, i, j, k);
+        const float* cell = feature + cell_offset(st, i, j, k);
+#pragma unroll
+        for (int d0 = 0; d0 < D; d0 += 4) {
+          const float4 f = *reinterpret_cast<const float4*>(cell + d0);
+          acc[d0] += w * f.x; acc[d0 + 1] += w * f.y; acc[d0 + 2] += w * f.z; acc[d0 + 3] += w * f.w;
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < D; ++d) row[d * 3 + s] = acc[d];           // (D, 3): plane fastest (reference layout)
+    }
+    float4* o = reinterpret_cast<float4*>(out + b * (D * 3));
+#pragma unroll
+    for (int v = 0; v < D * 3 / 4; ++v) o[v] = make_float4(row[4 * v], row[4 * v + 1], row[4 * v + 2], row[4 * v + 3]);
+  }
+}
+
+// Tri-plane / tri-line grad_query (MODE 0) and grad_query_grad_grad_output (MODE 1), one lane per POINT: the three sub-grids'
+// contributions to the point's gradient are summed in registers (k_dquery: one fp32 atomic per sub-grid, point and axis), and
+// the (D, 3) rows of grad_output / of the result are read / written as contiguous 16-byte pieces.
+template <int TOPO, int I, int D, int MODE>
+__global__ void __launch_bounds__(256) k_dquery_rows(long long P, float* __restrict__ dst, const float* __restrict__ src,
+                                                     const float* __restrict__ query, const float* __restrict__ feature, GridDesc g,
+                                                     int accum) {
+  static_assert(TOPO == TRIPLANE || TOPO == TRILINE, "three sub-grids per point");
+  constexpr int ND = NDims<TOPO>::v, NT = NTaps<I>::v;
+  for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < P; b += (long long)gridDim.x * blockDim.x) {
+    const float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
+    float row[D * 3];                    // MODE 0: grad_output row (read); MODE 1: result row (written)
+    float gq[3] = {0.f, 0.f, 0.f};
+    float gg[3] = {0.f, 0.f, 0.f};
+    if (MODE == 0) {
+      const float4* o = reinterpret_cast<const float4*>(src + b * (D * 3));
+#pragma unroll
+      for (int v = 0; v < D * 3 / 4; ++v) { const float4 t = o[v]; row[4 * v] = t.x; row[4 * v + 1] = t.y; row[4 * v + 2] = t.z; row[4 * v + 3] = t.w; }
+    } else {
+      gg[0] = src[b * 3]; gg[1] = src[b * 3 + 1]; gg[2] = src[b * 3 + 2];
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      Stencil<TOPO, I> st;
+      make_stencil<TOPO, I>(st, g, s, q);
+      float ga[ND][D];
+#pragma unroll
+      for (int a = 0; a < ND; ++a)
+#pragma unroll
+        for (int d = 0; d < D; ++d) ga[a][d] = 0.f;
+      NDJIR_FOR_TAPS(ND, NT) {
+        const float* cell = feature + cell_offset(st, i, j, k);
+        float f[D];
+#pragma unroll
+        for (int d0 = 0; d0 < D; d0 += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(cell + d0);
+          f[d0] = t.x; f[d0 + 1] = t.y; f[d0 + 2] = t.z; f[d0 + 3] = t.w;
+        }
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          const float dw = tap_dw(st, a, i, j, k);
+#pragma unroll
+          for (int d = 0; d < D; ++d) ga[a][d] += dw * f[d];
+        }
+      }
+      if (MODE == 0) {
+        float lv[ND];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) lv[a] = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+          for (int a = 0; a < ND; ++a) lv[a] += row[d * 3 + s] * st.scale[a] * st.ax[a].gm * ga[a][d];
+#pragma unroll
+        for (int a = 0; a < ND; ++a) gq[st.axis[a]] += lv[a];
+      } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          float r = 0.f;
+#pragma unroll
+          for (int a = 0; a < ND; ++a) r += gg[st.axis[a]] * st.scale[a] * st.ax[a].gm * ga[a][d];
+          row[d * 3 + s] = r;
+        }
+      }
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) dst[b * 3 + a] = accum ? dst[b * 3 + a] + gq[a] : gq[a];
+    } else {
+      float4* o = reinterpret_cast<float4*>(dst + b * (D * 3));
+#pragma unroll
+      for (int v = 0; v < D * 3 / 4; ++v) {
+        float4 t = make_float4(row[4 * v], row[4 * v + 1], row[4 * v + 2], row[4 * v + 3]);
+        if (accum) { const float4 c = o[v]; t.x += c.x; t.y += c.y; t.z += c.z; t.w += c.w; }
+        o[v] = t;
+      }
+    }
+  }
+}
+
+// Hash grid grad_query, one lane per POINT: the L levels of a point are summed in registers and the point's (3) gradient is
+// written once.  (k_dquery's lane per (level, point) issues one fp32 atomic per level, point and axis: 48 atomics per point
+// at L = 16 -- measured 295 MB written for a 6 MB result.)
+template <int I, int VW>
+__global__ void __launch_bounds__(256) k_dquery_hash_point(long long P, float* __restrict__ gq_out, const float* __restrict__ grad_output,
+                                                           const float* __restrict__ query, const float* __restrict__ feature,
+                                                           GridDesc g, int accum) {
+  constexpr int TOPO = HASH, ND = 3, NT = NTaps<I>::v;
+  for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < P; b += (long long)gridDim.x * blockDim.x) {
+    const float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
+    float gq[3] = {0.f, 0.f, 0.f};
+    for (int s = 0; s < g.S; ++s) {
+      Stencil<TOPO, I> st;
+      make_stencil<TOPO, I>(st, g, s, q);
+      float lv[3] = {0.f, 0.f, 0.f};
+      for (int d0 = 0; d0 < g.D; d0 += VW) {
+        float ga[ND][VW];
+#pragma unroll
+        for (int a = 0; a < ND; ++a)
+#pragma unroll
+          for (int v = 0; v < VW; ++v) ga[a][v] = 0.f;
+        NDJIR_FOR_TAPS(ND, NT) {
+          float f[VW];
+          vload<VW>(f, feature + cell_offset(st, i, j, k) + d0);
+#pragma unroll
+          for (int a = 0; a < ND; ++a) {
+            const float dw = tap_dw(st, a, i, j, k);
+#pragma unroll
+            for (int v = 0; v < VW; ++v) ga[a][v] += dw * f[v];
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < VW; ++v) {
+          const float og = grad_output[out_index<TOPO>(g, P, b, s, d0 + v)];
+#pragma unroll
+          for (int a = 0; a < ND; ++a) lv[a] += og * st.scale[a] * st.ax[a].gm * ga[a][v];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < ND; ++a) gq[st.axis[a]] += lv[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gq_out[b * 3 + a] = accum ? gq_out[b * 3 + a] + gq[a] : gq[a];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // grad_query: gq[b, axis] += sum_d og[d] * scale * gm * sum_taps dw * F   (voxel_feature_cuda.cu:124-204)
 // grad_query_grad_grad_output: ggo[d] = sum_axis gg[axis] * scale * gm * sum_taps dw * F  (:328-412)
@@ -1160,6 +1323,19 @@ void zero_fill(float* p, long long n, hipStream_t stream) {
 int launch_query(int interp, const GridDesc& g, long long P, float* out, const float* query, const float* feature,
                  bool accum, hipStream_t stream) {
   if (P <= 0) return NDJIR_OK;
+  static const bool no_rows = getenv("NDJIR_QUERY_NO_ROWS") != nullptr;      // A/B switch
+  if ((g.topo == TRIPLANE || g.topo == TRILINE) && !accum && (g.D == 4 || g.D == 8) && !no_rows &&
+      (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(feature) & 15) == 0) {
+    // one lane per point emits the point's contiguous (D, 3) row
+    const int rb = grid_blocks(P);
+#define NDJIR_ROWS(T, II, DD) hipLaunchKernelGGL((k_query_rows<T, II, DD>), dim3(rb), dim3(256), 0, stream, P, out, query, feature, g)
+#define NDJIR_ROWS_I(T, DD) { if (interp == LINEAR) NDJIR_ROWS(T, LINEAR, DD); else if (interp == COSINE) NDJIR_ROWS(T, COSINE, DD); else NDJIR_ROWS(T, LANCZOS, DD); }
+    if (g.topo == TRIPLANE) { if (g.D == 4) NDJIR_ROWS_I(TRIPLANE, 4) else NDJIR_ROWS_I(TRIPLANE, 8) }
+    else { if (g.D == 4) NDJIR_ROWS_I(TRILINE, 4) else NDJIR_ROWS_I(TRILINE, 8) }
+#undef NDJIR_ROWS_I
+#undef NDJIR_ROWS
+    return ndjir_check_launch();
+  }
   int blocks = grid_blocks(P * g.S);
   NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
     if (accum) hipLaunchKernelGGL((k_query<TOPO, I, VW, true>), dim3(blocks), dim3(256), 0, stream, P, out, query, feature, g);
@@ -1172,6 +1348,35 @@ int launch_query(int interp, const GridDesc& g, long long P, float* out, const f
 int launch_dquery(int interp, const GridDesc& g, long long P, int mode, float* dst, const float* src, const float* query,
                   const float* feature, bool accum, hipStream_t stream) {
   if (P <= 0) return NDJIR_OK;
+  static const bool no_point = getenv("NDJIR_HASH_DQUERY_ATOMIC") != nullptr;    // A/B switch
+  if (mode == 0 && g.topo == HASH && !no_point) {
+    // one lane per point sums the levels on chip: no atomics, one write per point and axis
+    const int pb = grid_blocks(P);
+    const int vw = pick_vw(g.D);
+#define NDJIR_HP(II, VV) hipLaunchKernelGGL((k_dquery_hash_point<II, VV>), dim3(pb), dim3(256), 0, stream, P, dst, src, query, feature, g, accum ? 1 : 0)
+#define NDJIR_HP_V(II) { if (vw == 4) NDJIR_HP(II, 4); else if (vw == 2) NDJIR_HP(II, 2); else NDJIR_HP(II, 1); }
+    if (interp == COSINE) return NDJIR_ERR_UNSUPPORTED;            // (no cosine hash family)
+    if (interp == LANCZOS) NDJIR_HP_V(LANCZOS) else NDJIR_HP_V(LINEAR)
+#undef NDJIR_HP_V
+#undef NDJIR_HP
+    return ndjir_check_launch();
+  }
+  static const bool no_rows = getenv("NDJIR_QUERY_NO_ROWS") != nullptr;      // A/B switch
+  if ((g.topo == TRIPLANE || g.topo == TRILINE) && (g.D == 4 || g.D == 8) && !no_rows &&
+      (reinterpret_cast<uintptr_t>(mode == 0 ? (const void*)src : (const void*)dst) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(feature) & 15) == 0) {
+    const int rb = grid_blocks(P);
+    const int acc = accum ? 1 : 0;
+#define NDJIR_DR(T, II, DD, MM) hipLaunchKernelGGL((k_dquery_rows<T, II, DD, MM>), dim3(rb), dim3(256), 0, stream, P, dst, src, query, feature, g, acc)
+#define NDJIR_DR_M(T, II, DD) { if (mode == 0) NDJIR_DR(T, II, DD, 0); else NDJIR_DR(T, II, DD, 1); }
+#define NDJIR_DR_I(T, DD) { if (interp == LINEAR) NDJIR_DR_M(T, LINEAR, DD) else if (interp == COSINE) NDJIR_DR_M(T, COSINE, DD) else NDJIR_DR_M(T, LANCZOS, DD) }
+    if (g.topo == TRIPLANE) { if (g.D == 4) NDJIR_DR_I(TRIPLANE, 4) else NDJIR_DR_I(TRIPLANE, 8) }
+    else { if (g.D == 4) NDJIR_DR_I(TRILINE, 4) else NDJIR_DR_I(TRILINE, 8) }
+#undef NDJIR_DR_I
+#undef NDJIR_DR_M
+#undef NDJIR_DR
+    return ndjir_check_launch();
+  }
   if (mode == 0 && !accum) zero_fill(dst, P * 3, stream);
   int blocks = grid_blocks(P * g.S);
   NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
