@@ -383,10 +383,10 @@ class FusedMLP(Function):
             # gradient of the packed output: columns c .. c + No - 2 belong to y_1 ..; y_0 was overwritten (no gradient)
             c, ldz, No = ctx.pack
             g = gy.reshape(P, ldz)
-            if not g.is_contiguous():
-                g = g.contiguous()
-            lib.call("copy_columns", P, 1, _zeros_col(P, g.device), 1, _ColumnPtr(g, c - 1), ldz)
-            gy2 = g[:, c - 1:c - 1 + No]
+            # y_0's column is zeroed below: on a private copy of the gradient's (P, No) slice -- the incoming tensor belongs
+            # to autograd (another consumer, a hook or retain_grad may still read it)
+            gy2 = g[:, c - 1:c - 1 + No].contiguous()
+            lib.call("copy_columns", P, 1, _zeros_col(P, g.device), 1, gy2, No)
         else:
             gy2 = gy.reshape(P, -1).contiguous()
         # backward chain: step i applies W_{L-1-i}^T
@@ -532,6 +532,12 @@ class MultiMLP(Function):
             gx[:, kmax:].zero_()
         # the widest net first: its chain assigns every column any net writes, the others accumulate
         order = sorted(range(len(net_cfg)), key=lambda i: -net_cfg[i][1])
+        if need_x:
+            # ... unless the widest net(s) received no gradient: the first chain that runs assigns only its own K0 columns, and
+            # the columns between them and the widest net's K0 would stay uninitialised
+            live = [net_cfg[i][1] for i in order if gys[i] is not None]
+            if live and live[0] < kmax:
+                gx[:, live[0]:kmax].zero_()
         spos, ppos, sp, pp = [], [], 1, 4
         for L, K0, div in net_cfg:
             spos.append(sp)

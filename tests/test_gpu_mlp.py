@@ -311,6 +311,32 @@ def test_multi_mlp_on_packed_input_with_row_term(gpu):
         assert _rel(a, b.cpu()) < 2e-5, i
 
 
+def test_multi_mlp_widest_net_without_gradient(gpu):
+    """When the widest net of a MultiMLP receives no gradient, the first backward chain that runs assigns only its own
+    input columns: the columns up to the widest net's width must come out as zeros, not as uninitialised memory."""
+    from ndjir_amd.mlp import multi_mlp
+    rng = np.random.RandomState(4)
+    P, ld, Dh = 256, 24, 64
+
+    def net(K, No, seed):
+        r = np.random.RandomState(seed)
+        dims = [K, Dh, No]
+        return ([torch.tensor(r.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i]), dtype=torch.float32, device=gpu).requires_grad_(True)
+                 for i in range(2)],
+                [torch.tensor(r.randn(dims[i + 1]) * 0.1, dtype=torch.float32, device=gpu).requires_grad_(True) for i in range(2)])
+
+    nets = [net(12, 3, 1), net(20, 2, 2)]
+    x = torch.tensor(rng.randn(P, ld), dtype=torch.float32, device=gpu, requires_grad=True)
+    torch.empty(1 << 22, device=gpu).fill_(float("nan"))          # poison the allocator's free blocks
+    y = multi_mlp(x, [(nets[0][0], nets[0][1]), (nets[1][0], nets[1][1])], widths=[12, 20])
+    gx, = torch.autograd.grad(y[0], [x], torch.ones_like(y[0]))      # only the NARROW net gets a gradient
+    ref = x.detach().double().requires_grad_(True)
+    h = TF.softplus(ref[:, :12] @ nets[0][0][0].double() + nets[0][1][0].double(), beta=100) @ nets[0][0][1].double() + nets[0][1][1].double()
+    gref, = torch.autograd.grad(h, [ref], torch.ones_like(h))
+    assert torch.isfinite(gx).all()
+    assert _rel(gx[:, :12], gref[:, :12].cpu()) < 2e-5 and float(gx[:, 12:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("P,K,N", [(512, 262, 128), (100, 43, 256), (7, 3, 5), (4096, 256, 257)])
 def test_linear_is_twice_differentiable(gpu, P, K, N):
     """mlp.linear (PF.affine, python/network.py:88-93) on the chain / wgrad / colsum kernels: value, first derivatives and
