@@ -9,12 +9,14 @@ samples, 128 lights), synthetic rays, reference-initialised weights.  Rays shard
 (weak scaling: 512 rays per GPU); one gradient exchange per step over RCCL.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 
-`roofline` is for the dominant hand-written kernel, the fused MLP forward chain
-(`ndjir::x3::k_chain3<0, TM>`; `ndjir::x6::k_chain6` / `ndjir::k_mlp_chain` with NDJIR_MLP_MATH=bf16x6 / fp32):
-achieved = sum of the algorithmic FLOPs (2*in*out per affine per point) of its launches / sum of
-their durations, measured live with HIP events recorded on the launching stream around every launch
-inside the timed region.  In the default f16x3 arithmetic one algorithmic FLOP costs three f16 MFMA
-FLOPs, so the peak it is priced against is the dense 16-bit MFMA peak / 3 (bf16x6: / 6).
+`roofline` is for the hand-written kernel class with the largest time per step -- since round 2 the fused MLP BACKWARD chain
+(`ndjir::x3w::k_chainw<1, 4>` / `<1, 2>`, csrc/mlp3w.hip; `ndjir::x3::k_chain3` for small launches or NDJIR_MLP_TILE=64;
+`ndjir::x6::k_chain6` / `ndjir::k_mlp_chain` with NDJIR_MLP_MATH=bf16x6 / fp32): achieved = sum of the algorithmic FLOPs
+(2*in*out per affine per point) of its launches / sum of their durations, measured live with HIP events recorded on
+the launching stream around every launch.  In the default f16x3 arithmetic one algorithmic FLOP costs three f16 MFMA FLOPs, so
+the peak it is priced against is the dense 16-bit MFMA peak / 3 (bf16x6: / 6).  `kernels` lists every class of the engine (forward /
+backward / tangent chains, weight gradients) with launches and time per step and both yardsticks (that peak, and the fp32-input
+MFMA peak).  `--scaling strong --total-rays 4096 --config no_voxel` is BASELINE.json's config 4 (rays split over the ranks).
 Execution: the compute part of the step (ndjir_amd/step.py `Step.compute`: no collective inside) is captured once
 into a HIP graph and the timed region replays it (`--exec graph`, default; no host-side launch work in the timed
 region; N > 1: the scalar mask all-reduce and the gradient exchange are issued eagerly around every replay).  HIP events
