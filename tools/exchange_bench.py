@@ -45,7 +45,13 @@ for r in range(1, world):
     ids[r] = (ids[0] + 977 * r) % (G ** 3)
     rows[r] = rows[0]
 counts = torch.full((world,), n, dtype=torch.int32, device=dev)
-t_apply = T(lambda: lib.call("sparse_rows_apply", ids, rows, counts, world, cap, 0, buf, D))
-t_zero = T(lambda: lib.call("sparse_rows_zero", ids, counts, world, cap, buf, D))
-print(f"rows per rank {n}; pack (2 query sets + bitmap clear) {t_pack:.1f} us; apply 7 x {n} rows {t_apply:.1f} us; "
-      f"re-arm 8 x {n} rows {t_zero:.1f} us; payload per rank {n * 20 / 1e6:.2f} MB")
+limit = -(-int(n * 1.5) // 4096) * 4096                 # the wire size the step would pick (50 % head-room, 4096-row granules)
+ids_w = ids[:, :limit].contiguous()                     # packed (world, limit) lists, as all_gather_into_tensor leaves them
+rows_w = rows[:, :limit].contiguous()
+lim_dev = torch.tensor([limit], dtype=torch.int32, device=dev)
+own = cnt.clone()
+t_apply = T(lambda: lib.call("sparse_rows_apply", ids_w, rows_w, counts, world, limit, limit, 0, buf, D))
+t_zero = T(lambda: lib.call("sparse_rows_zero", ids_w, counts, world, cap, lim_dev, 0, ids[0].contiguous(), own, buf, D))
+print(f"rows per rank {n}, wire size {limit} rows; pack (2 query sets + bitmap clear) {t_pack:.1f} us; apply 7 x {n} rows {t_apply:.1f} us; "
+      f"re-arm (7 x {n} received + {n} own rows) {t_zero:.1f} us; payload per rank on the wire {limit * 20 / 1e6:.2f} MB "
+      f"(ids + {D} floats per row) -> {limit * 20 * 7 / 1e6:.1f} MB received per rank in an 8-rank all-gather")
