@@ -317,6 +317,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
           const int fb = nb * 32 + 4 * hh;
           const float winv = p_winv[nb];
           const bool vec_y = (nb * 32 + 31 < l_N) && (a.ldy & 3) == 0 && ((uintptr_t)a.Y & 15) == 0;
+          // (the geometric net's output lives at Z + 2 floats, ndjir_amd/geometric.py: 8-byte aligned rows -> pairs)
+          const bool vec2_y = !vec_y && (nb * 32 + 31 < l_N) && (a.ldy & 1) == 0 && ((uintptr_t)a.Y & 7) == 0;
           f32x4 bias4[4];
 #pragma unroll
           for (int g = 0; g < 4; ++g)
@@ -342,6 +344,17 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
                   for (int q = 0; q < 4; ++q) t[q] = out_add(t[q], y0[q]);
                 }
                 *reinterpret_cast<f32x4*>(y + 8 * g) = t;
+              } else if (vec2_y) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                  f32x2 u = {t[q], t[q + 1]};
+                  if (a.accum_y) {
+                    const f32x2 y0 = *reinterpret_cast<const f32x2*>(y + 8 * g + q);
+                    u[0] = out_add(u[0], y0[0]); u[1] = out_add(u[1], y0[1]);
+                  }
+                  *reinterpret_cast<f32x2*>(y + 8 * g + q) = u;
+                }
               } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
