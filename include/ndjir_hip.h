@@ -466,6 +466,9 @@ int ndjir_mlp_pack_strided(const float* W, int ldw, float* dst, int K, int N, in
  * Np = round_up(transpose ? K : N, 32), first_block = running sum of Np / 32; total_blocks = that sum over all entries. */
 int ndjir_mlp_pack_table(const void* table, int n, int total_blocks, hipStream_t stream);
 int ndjir_mlp_pack_entry_bytes(void);
+/* ndjir_mlp_chain / _ex: `accum_y` bit 0 = Y += result; bit 1 = the bias gradients (bgrad of every layer, in_bgrad) are
+ * ADDED to their destinations instead of overwriting them -- nnabla's `accum` protocol for parameters whose gradient
+ * buffer several operators share (python/train.py:136-140 zeroes the gradients once per iteration, every backward adds). */
 int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L,
                     const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
                     const float* const* side_in, float* const* side_out, const int* ld_side,

@@ -107,7 +107,7 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
   a.in_bgrad = (bwd != 0) ? in_bgrad : nullptr;
   a.x_amax = x_amax;
   a.P = P; a.X = X; a.ldx = ldx; a.K0 = K0; a.K0p = round_up(K0, 8); a.L = L;
-  a.Y = Y; a.ldy = ldy; a.accum_y = accum_y; a.has_output = has_output; a.beta = beta;
+  a.Y = Y; a.ldy = ldy; a.accum_y = accum_y & 1; a.bg_accum = (accum_y >> 1) & 1; a.has_output = has_output; a.beta = beta;
   a.skip_layer = skip_layer; a.skip_scale = skip_scale; a.skip_split = skip_split; a.Xskip = Xskip; a.ld_xskip = ld_xskip;
   int kin = K0;
   for (int i = 0; i < L; ++i) {

@@ -32,6 +32,7 @@ struct ChainArgs {
   int K0, K0p;
   int L;
   int accum_y;          // Y += result
+  int bg_accum;         // bias gradients (bgrad of every layer, in_bgrad) += their sums instead of being overwritten
   int has_output;       // last layer writes Y (else the chain ends with a hidden epilogue)
   int skip_layer;       // -1: none.  fwd: layer whose output is concatenated with X and scaled;
                         // bwd: layer whose output is that concatenated gradient
@@ -54,7 +55,7 @@ struct ChainArgs {
 
 int launch_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
 int launch_chain(const ChainArgs& a, int mode, hipStream_t stream);
-int launch_bgrad_reduce(const float* partial, int S, int total, float* const* ptr, const int* off, int n, hipStream_t stream);
+int launch_bgrad_reduce(const float* partial, int S, int total, float* const* ptr, const int* off, int n, int accum, hipStream_t stream);
 // bf16 3-way-split engine (mlp6.hip): same ChainArgs, weights packed by launch_pack6
 long long packed_size6(int K, int N, int transpose);   // in floats (for allocation through the same API)
 int launch_pack6(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);

@@ -512,6 +512,7 @@ struct BgOut {
   float* ptr[MAX_CHAIN_LAYERS + 1];
   int off[MAX_CHAIN_LAYERS + 2];
   int n;
+  int accum;       // destinations += sums
 };
 __global__ void __launch_bounds__(256) k_bgrad_reduce(const float* __restrict__ partial, int S, int total, BgOut o) {
   __shared__ float red[256];
@@ -530,13 +531,15 @@ __global__ void __launch_bounds__(256) k_bgrad_reduce(const float* __restrict__ 
     for (int q = 0; q < 8; ++q) t += red[q * 32 + tx];
     int l = 0;
     while (l + 1 < o.n && i >= o.off[l + 1]) ++l;
-    o.ptr[l][i - o.off[l]] = t;
+    float* dst = o.ptr[l] + (i - o.off[l]);
+    *dst = o.accum ? *dst + t : t;
   }
 }
 
-int launch_bgrad_reduce(const float* partial, int S, int total, float* const* ptr, const int* off, int n, hipStream_t stream) {
+int launch_bgrad_reduce(const float* partial, int S, int total, float* const* ptr, const int* off, int n, int accum, hipStream_t stream) {
   BgOut o{};
   o.n = n;
+  o.accum = accum;
   for (int i = 0; i < n; ++i) { o.ptr[i] = ptr[i]; o.off[i] = off[i]; }
   o.off[n] = total;
   hipLaunchKernelGGL(k_bgrad_reduce, dim3((total + 31) / 32), dim3(256), 0, stream, partial, S, total, o);
@@ -579,6 +582,7 @@ int launch_chain(const ChainArgs& a, int mode, hipStream_t stream) {
   b.n_tiles = (a.P + TM - 1) / TM;   // TM defined above
   size_t lds_bytes = szA + szB;
   BgOut bg{};
+  bg.accum = a.bg_accum;
   int bg_total = 0;
   if (mode != 0) {
     for (int i = 0; i < a.L; ++i) if (a.layers[i].bgrad && !(a.has_output && i == a.L - 1)) {

@@ -624,7 +624,7 @@ int launch_chain6(const ChainArgs& a, int mode, hipStream_t stream) {
 #undef NDJIR_GO
   int rc = ndjir_check_launch();
   if (rc != NDJIR_OK) return rc;
-  if (bg_total > 0) return launch_bgrad_reduce(a.bg_partial, (int)blocks, bg_total, bg_ptr, bg_off, bg_n, stream);
+  if (bg_total > 0) return launch_bgrad_reduce(a.bg_partial, (int)blocks, bg_total, bg_ptr, bg_off, bg_n, a.bg_accum, stream);
   return NDJIR_OK;
 }
 

@@ -30,7 +30,7 @@ from torch.autograd import Function
 
 from . import lib
 from .grid_feature import _core
-from .mlp import _launch, _packed, _Strided, amax_slots, chain_workspace, colsum, wgrad
+from .mlp import _launch, _packed, _Strided, amax_slots, chain_workspace, colsum, grad_target, wgrad
 
 
 
@@ -168,6 +168,7 @@ class GeometricMain(Function):
         lib.call("geo_normal", P, M, e, K0, g0, K0, len(gqs), gqs, n, Z, ldz, D, sdf)
 
         ctx.cfg = (M, skip_at, scale, min_, max_, L, tuple(x.shape), fam_names, bskip, split, ste)
+        ctx.btgt = [grad_target(t) for t in b]       # accumulate-in-place gradient buffers of the biases (mlp.set_grad_buffer)
         ctx.A, ctx.s_store, ctx.s = A, s_store, s
         ctx.am, ctx.sm = am, sm
         ctx.aux = (xf, gos, ldz)
@@ -262,6 +263,11 @@ class GeometricMain(Function):
         deltas = [None] * L
         deltas[L - 1] = gy
         bgrads = [None] * L
+        nb = [ctx.needs_input_grad[2 + NG + L + j] for j in range(L)]
+        btgt = [t if nb[j] else None for j, t in enumerate(ctx.btgt)]
+        if any(nb[j] and btgt[j] is None for j in range(L)):
+            btgt = [None] * L                      # all of the net's biases accumulate in place, or none (one flag per chain)
+        bg_acc = 2 if any(t is not None for t in btgt) else 0
         Wp, bK, bN, side_in, side_out, side_add, ld, bg, side_am = [], [], [], [], [], [], [], [], []
         for i in range(steps):
             j = L - 1 - i
@@ -273,7 +279,7 @@ class GeometricMain(Function):
                 wide = A[j].shape[1]
                 dbuf = torch.empty((P, wide), device=dev, dtype=torch.float32)
                 deltas[below] = dbuf[:, :Ns[below]]
-                bgrads[below] = torch.empty((Ns[below],), device=dev, dtype=torch.float32)
+                bgrads[below] = btgt[below] if btgt[below] is not None else torch.empty((Ns[below],), device=dev, dtype=torch.float32)
                 side_in.append(A[j])
                 side_out.append(dbuf)
                 side_add.append(extras[below])
@@ -284,9 +290,9 @@ class GeometricMain(Function):
                 side_in.append(None); side_out.append(None); side_add.append(None); ld.append(0); bg.append(None)
                 side_am.append(None)
         gx = torch.zeros((P, K0), device=dev, dtype=torch.float32) if need_x else None
-        gb_last = torch.empty((Ns[-1],), device=dev, dtype=torch.float32)     # bias gradient of the output layer
+        gb_last = btgt[L - 1] if btgt[L - 1] is not None else torch.empty((Ns[-1],), device=dev, dtype=torch.float32)     # bias gradient of the output layer
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain_ex", 1, P, gy, Ns[-1], Ns[-1], steps, Wp, [None] * steps, bK, bN,
-                side_in, side_out, ld, bg, gx, K0, 1 if (bskip >= 0 and need_x) else 0, 1 if need_x else 0, beta,
+                side_in, side_out, ld, bg, gx, K0, (1 if (bskip >= 0 and need_x) else 0) | bg_acc, 1 if need_x else 0, beta,
                 bskip, scale, split, gx if (bskip >= 0 and need_x) else None, K0, [None] * steps, side_add, [None] * steps,
                 None, 0, gb_last, chain_workspace(dev, bg + [gb_last]), side_am, dm[L - 1:L], shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
 
@@ -299,12 +305,17 @@ class GeometricMain(Function):
         gW, gb = [None] * L, [None] * L
         for j in range(L):
             if ctx.needs_input_grad[2 + NG + j]:
-                gW[j] = wgrad(A[j], deltas[j], amax_a=am[j:j + 1], amax_b=dm[j:j + 1])
+                wt = grad_target(W[j])           # accumulate-in-place gradient buffer of the weight, if registered
+                dst = wt if wt is not None else wgrad(A[j], deltas[j], amax_a=am[j:j + 1], amax_b=dm[j:j + 1])
+                if wt is not None:
+                    wgrad(A[j], deltas[j], out=wt, accum=True, amax_a=am[j:j + 1], amax_b=dm[j:j + 1])
+                else:
+                    gW[j] = dst
                 if nbar is not None and j < L - 1:
-                    wgrad(gbar[j], s[j], out=gW[j], accum=True, amax_a=gm[j:j + 1], amax_b=sm[j:j + 1])
+                    wgrad(gbar[j], s[j], out=dst, accum=True, amax_a=gm[j:j + 1], amax_b=sm[j:j + 1])
                 if nbar is not None and j == L - 1:
-                    gW[j][:, 0] += col_last
-            if ctx.needs_input_grad[2 + NG + L + j]:
+                    dst[:, 0] += col_last
+            if ctx.needs_input_grad[2 + NG + L + j] and btgt[j] is None:
                 gb[j] = bgrads[j] if j < L - 1 else gb_last
         g_grids = [gdst if (ctx.needs_input_grad[2 + k] and not own) else None
                    for k, (_, _, _, _, _, gdst, own) in enumerate(enc)]

@@ -177,6 +177,42 @@ def repack_tracked():
         e.version = _base_version(e.W)
 
 
+# ---- accumulate-in-place gradient buffers of MLP parameters (nnabla's `accum` protocol) --------------------------------------
+# python/train.py:136-140 zeroes every parameter's gradient once per iteration and each backward function ADDS into it.  A
+# parameter registered here gets the same: the operators of this module write dL/dW and dL/db straight into (a view of) its
+# buffer and return no gradient for it, so autograd neither sums the contributions of a parameter used by two operators
+# (the geometric and base-colour nets run twice per step) nor materialises slice gradients of a first-layer weight that one
+# operator reads by rows.  ndjir_amd/step.py registers views of one flat bucket -- also what the multi-GPU step all-reduces.
+_GRAD_BUF = []         # (first byte, bytes, buffer) per registered parameter
+
+
+def set_grad_buffer(p, buf):
+    """Register `buf` (same shape as the contiguous parameter `p`; the caller zeroes it once per step) as p's accumulate-in-
+    place gradient; buf = None unregisters."""
+    ptr = p.data_ptr()
+    _GRAD_BUF[:] = [e for e in _GRAD_BUF if e[0] != ptr]
+    if buf is not None:
+        assert p.is_contiguous() and buf.is_contiguous() and buf.shape == p.shape and buf.dtype == p.dtype
+        _GRAD_BUF.append((ptr, p.numel() * p.element_size(), buf))
+
+
+def clear_grad_buffers():
+    del _GRAD_BUF[:]
+
+
+def grad_target(t):
+    """The view of a registered gradient buffer that corresponds to `t` -- a registered parameter or a contiguous piece of
+    one (a block of rows of a weight matrix) --, or None."""
+    if not _GRAD_BUF or t is None or not t.is_contiguous():
+        return None
+    ptr, nbytes = t.data_ptr(), t.numel() * t.element_size()
+    for p0, nb, buf in _GRAD_BUF:
+        if p0 <= ptr and ptr + nbytes <= p0 + nb:
+            off = (ptr - p0) // t.element_size()
+            return buf.view(-1)[off:off + t.numel()].view(t.shape)
+    return None
+
+
 _AMAX_ARENA = {}      # device -> [zeroed tensor, next free slot]
 
 
@@ -360,6 +396,7 @@ class FusedMLP(Function):
             ctx.save_for_backward(x2, *hidden, *weights, am)
             ctx.cfg = (beta, skip_layer, skip_scale, L, tuple(x.shape))
             ctx.rb = (None if row_bias is None else tuple(row_bias.shape), int(row_bias_div))
+            ctx.btgt = [grad_target(b) if torch.is_tensor(b) else None for b in biases]
         ctx.pack = None
         if pack is not None:
             lib.call("copy_columns", pk.shape[0], c, pk, c, Zp, ldz)
@@ -398,6 +435,11 @@ class FusedMLP(Function):
         gb_last = None
         dm = amax_slots(x2.device, L)        # recorded maxima of deltas[j]; slot L-1 = the chain input gy2
         have_dm = steps > 0
+        # accumulate-in-place gradient buffers (set_grad_buffer): all of the net's biases or none (one flag per chain launch)
+        btgt = [t if ctx.needs_input_grad[7 + L + j] else None for j, t in enumerate(ctx.btgt)]
+        if any(ctx.needs_input_grad[7 + L + j] and btgt[j] is None for j in range(L)):
+            btgt = [None] * L
+        bg_acc = 2 if any(t is not None for t in btgt) else 0
         if steps > 0:
             Wp, Ks, Ns, side_in, side_out, ld_side, bg, side_am = [], [], [], [], [], [], [], []
             bwd_skip, split = -1, 0
@@ -410,7 +452,8 @@ class FusedMLP(Function):
                     below = j - 1                       # layer whose delta this step produces
                     width = W[below].shape[1]
                     deltas[below] = torch.empty((P, width), device=x2.device, dtype=torch.float32)
-                    bgrads[below] = torch.empty((width,), device=x2.device, dtype=torch.float32)
+                    bgrads[below] = (btgt[below] if btgt[below] is not None
+                                     else torch.empty((width,), device=x2.device, dtype=torch.float32))
                     side_in.append(A[j])
                     side_out.append(deltas[below])
                     side_am.append(_slot(dm, below))
@@ -444,10 +487,10 @@ class FusedMLP(Function):
             flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
             if need_w and ctx.needs_input_grad[7 + 2 * L - 1]:
                 # bias gradient of the output layer = column sums of dL/dY: accumulated by the chain's input load
-                gb_last = torch.empty((gy2.shape[1],), device=x2.device, dtype=torch.float32)
+                gb_last = btgt[L - 1] if btgt[L - 1] is not None else torch.empty((gy2.shape[1],), device=x2.device, dtype=torch.float32)
             _launch("chain_bwd", flops, "mlp_chain", 1, P, _Strided(gy2), gy2.stride(0), gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
                      side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
-                     1 if bwd_skip >= 0 else 0, 1 if need_x else 0,
+                     (1 if bwd_skip >= 0 else 0) | bg_acc, 1 if need_x else 0,
                      float(beta), int(bwd_skip), float(skip_scale), int(split),
                      gx if bwd_skip >= 0 else None, K0, gb_last, chain_workspace(x2.device, bg + [gb_last]),
                      side_am, _slot(dm, L - 1), shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)))
@@ -456,9 +499,17 @@ class FusedMLP(Function):
         if need_w:
             for j in range(L):
                 if ctx.needs_input_grad[7 + j]:
-                    gW[j] = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
+                    wt = grad_target(W[j])
+                    if wt is not None:
+                        wgrad(A[j], deltas[j], out=wt, accum=True, amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
+                    else:
+                        gW[j] = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
                 if ctx.needs_input_grad[7 + L + j]:
-                    gb[j] = bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))
+                    if btgt[j] is not None:
+                        if j == L - 1 and gb_last is None:
+                            colsum(gy2, out=btgt[j], accum=True)
+                    else:
+                        gb[j] = bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))
         g_rb = None
         rb_shape, rb_div = ctx.rb
         if rb_shape is not None and ctx.needs_input_grad[1]:
@@ -499,6 +550,7 @@ class MultiMLP(Function):
         x2 = x.detach().reshape(-1, ld).contiguous()
         train = any(ctx.needs_input_grad)
         ys, saved, off = [], [x2], 0
+        btgts = []
         for L, K0, div in net_cfg:
             rb = None
             if div > 0:
@@ -510,10 +562,12 @@ class MultiMLP(Function):
             ys.append(y.view(x.shape[:-1] + (y.shape[-1],)))
             if train:
                 saved += hidden + W + [am]
+                btgts.append([grad_target(t) if torch.is_tensor(t) else None for t in b])
         if train:
             ctx.save_for_backward(*saved)
             ctx.cfg = (float(beta), tuple(net_cfg), tuple(x.shape), [tuple(p.shape) if torch.is_tensor(p) else None for p in params],
                        bool(lazy_pad))
+            ctx.btgts = btgts
         return tuple(ys)
 
     @staticmethod
@@ -564,6 +618,11 @@ class MultiMLP(Function):
             deltas, bgrads = [None] * L, [None] * L
             deltas[L - 1] = gy2
             gb_last = None
+            # accumulate-in-place gradient buffers (set_grad_buffer): all of the net's biases or none (one flag per chain)
+            btgt = [t if nb[j] else None for j, t in enumerate(ctx.btgts[n])]
+            if any(nb[j] and btgt[j] is None for j in range(L)):
+                btgt = [None] * L
+            bg_acc = 2 if any(t is not None for t in btgt) else 0
             dm = amax_slots(dev, L) if steps > 0 else None
             if steps > 0:
                 Wp, Ks, Ns, side_in, side_out, ld_side, bg, side_am = [], [], [], [], [], [], [], []
@@ -575,17 +634,17 @@ class MultiMLP(Function):
                     if i < L - 1:
                         width = W[j - 1].shape[1]
                         deltas[j - 1] = torch.empty((P, width), device=dev, dtype=torch.float32)
-                        bgrads[j - 1] = torch.empty((width,), device=dev, dtype=torch.float32)
+                        bgrads[j - 1] = btgt[j - 1] if btgt[j - 1] is not None else torch.empty((width,), device=dev, dtype=torch.float32)
                         side_in.append(A[j]); side_out.append(deltas[j - 1]); ld_side.append(A[j].shape[1]); bg.append(bgrads[j - 1])
                         side_am.append(_slot(dm, j - 1))
                     else:
                         side_in.append(None); side_out.append(None); ld_side.append(0); bg.append(None); side_am.append(None)
                 if any(nW) and nb[L - 1]:
-                    gb_last = torch.empty((gy2.shape[1],), device=dev, dtype=torch.float32)
+                    gb_last = btgt[L - 1] if btgt[L - 1] is not None else torch.empty((gy2.shape[1],), device=dev, dtype=torch.float32)
                 flops = 2.0 * P * sum(k * m for k, m in zip(Ks, Ns))
                 _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
                         side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
-                        0 if first else 1, 1 if need_x else 0, float(beta), -1, 1.0, 0, None, K0, gb_last,
+                        (0 if first else 1) | bg_acc, 1 if need_x else 0, float(beta), -1, 1.0, 0, None, K0, gb_last,
                         chain_workspace(dev, bg + [gb_last]), side_am, _slot(dm, L - 1), shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)) + ("" if first else " (+=)"))
                 first = False
             if need_rb:
@@ -596,9 +655,17 @@ class MultiMLP(Function):
                 out[poff - 4] = g_rb.view(pshapes[poff - 4])
             for j in range(L):
                 if nW[j]:
-                    out[wo - 4 + j] = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j))
+                    wt = grad_target(W[j])
+                    if wt is not None:
+                        wgrad(A[j], deltas[j], out=wt, accum=True, amax_a=_slot(am, j), amax_b=_slot(dm, j))
+                    else:
+                        out[wo - 4 + j] = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j))
                 if nb[j]:
-                    out[wo - 4 + L + j] = bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))
+                    if btgt[j] is not None:
+                        if j == L - 1 and gb_last is None:
+                            colsum(gy2, out=btgt[j], accum=True)
+                    else:
+                        out[wo - 4 + L + j] = bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))
         if need_x and first:
             gx = None
         return (gx.reshape(xshape) if gx is not None else None, None, None, None, *out)
@@ -631,6 +698,7 @@ class MatMul(Function):
         ctx.save_for_backward(x, W)
         ctx.t = bool(transpose)
         ctx.has_bias = bias is not None
+        ctx.btgt = grad_target(bias) if bias is not None else None
         x2 = x.detach().reshape(-1, x.shape[-1]).contiguous()
         y = _mm(x2, W.detach(), ctx.t, bias)
         return y.view(x.shape[:-1] + (y.shape[-1],))
@@ -641,11 +709,19 @@ class MatMul(Function):
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
             gx = MatMul.apply(gy, W, not ctx.t, None)
+        first_order = not torch.is_grad_enabled()      # (create_graph: the gradients themselves are differentiated -> graph nodes)
         if ctx.needs_input_grad[1]:
             x2, g2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
-            gW = WGradOp.apply(g2, x2) if ctx.t else WGradOp.apply(x2, g2)
+            wt = grad_target(W) if (first_order and not ctx.t) else None
+            if wt is not None:       # accumulate-in-place gradient buffer (set_grad_buffer): W may be a block of rows of a parameter
+                wgrad(x2.detach().contiguous(), g2.detach().contiguous(), out=wt, accum=True)
+            else:
+                gW = WGradOp.apply(g2, x2) if ctx.t else WGradOp.apply(x2, g2)
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            gb = ColSumOp.apply(gy.reshape(-1, gy.shape[-1]))
+            if first_order and ctx.btgt is not None:
+                colsum(gy.detach().reshape(-1, gy.shape[-1]).contiguous(), out=ctx.btgt, accum=True)
+            else:
+                gb = ColSumOp.apply(gy.reshape(-1, gy.shape[-1]))
         return gx, gW, None, gb
 
 

@@ -84,6 +84,8 @@ def clear_parameters():
     m = sys.modules.get("ndjir_amd.mlp")
     if m is not None and m._TRACK is not None:      # persistent packed copies point at the parameters that just went away
         m.track_weights(False)
+    if m is not None:
+        m.clear_grad_buffers()                       # ... and so do the accumulate-in-place gradient buffers
 
 
 def save_parameters(path):

@@ -69,7 +69,20 @@ class Step:
         self.mlp_names = [k for k in params if not k.endswith("feature/F")]
         self.mlp_params = [params[k] for k in self.mlp_names]
         self.grid_params = [p for k, p in P.get_parameters().items() if k.endswith("feature/F")]
+        # One flat gradient bucket for every MLP parameter (what the multi-GPU step all-reduces).  The MLP operators
+        # accumulate dL/dW and dL/db straight into its views (ndjir_amd.mlp.set_grad_buffer = nnabla's accum protocol,
+        # python/train.py:136-140: gradients are zeroed once per iteration, every backward adds): autograd neither sums the
+        # contributions of parameters used by two operators nor materialises slice gradients, and no copy packs the bucket.
         self.flat_grad = torch.zeros(sum(p.numel() for p in self.mlp_params), device=device)
+        self.grad_views, off = [], 0
+        from ndjir_amd import mlp
+        self.in_place = device.type == "cuda" and not os.environ.get("NDJIR_NO_GRAD_BUFFERS")
+        for p in self.mlp_params:
+            v = self.flat_grad[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+            self.grad_views.append(v)
+            if self.in_place and p.is_contiguous():
+                mlp.set_grad_buffer(p, v)
 
     def set_rays(self, camloc, raydir, color_gt, obj_mask=None):
         """Feed the next iteration's rays (python/train.py:124-133: `raydir.d = ...`, `camloc.d = ...`, `color_gt.d = ...`,
@@ -138,6 +151,8 @@ class Step:
         from ndjir_amd import mlp
         from ndjir_amd.loss import total_loss
         mlp.begin_step(self.device)          # fresh (zeroed) operand-maximum slots: part of the graph when captured
+        if self.mlp_names is not None:
+            self.flat_grad.zero_()           # python/train.py:136 `zero_grad` for the MLP parameters: one launch
         if rearm:
             self.rearm_grid_buffers()
         use_mask = self.conf.train.mask_weight > 0.0
@@ -150,6 +165,12 @@ class Step:
             torch.autograd.grad(loss, params, allow_unused=True)
             return loss.detach()
         grads = torch.autograd.grad(loss, self.mlp_params + self.grid_params, allow_unused=True)
+        # what autograd still returns for an MLP parameter (stock-op paths: gains, the concatenated row blocks of the two
+        # split first-layer weights) joins what the operators accumulated in place
+        for v, g in zip(self.grad_views, grads):
+            if g is not None:
+                v.add_(g)
+        grads = tuple(self.grad_views) + tuple(grads[len(self.grad_views):])
         self.x_fg = out["samples"]["x_fg"].detach()
         if self.grid_bufs:
             # persistent buffers (not the step's own tensors): a captured graph must find them at the same address.  The
@@ -163,12 +184,7 @@ class Step:
             torch.add(self.x_fg, self.rand["noise"], alpha=self._ptb_scale(), out=self.touched_ptb)
         self.grads = grads               # the step's product: every parameter gradient, materialised
         self.loss = loss.detach().reshape(1)
-        if self.multi:
-            # pack the MLP gradients into one flat bucket for the all-reduce (one batched copy, not one launch per tensor)
-            if self._zeros is None:
-                self._zeros = [torch.zeros(p.numel(), device=self.device) for p in self.mlp_params]
-            torch.cat([g.reshape(-1) if g is not None else z for g, z in zip(grads, self._zeros)], out=self.flat_grad)
-        return loss.detach()
+        return loss.detach()         # (the flat bucket already holds the MLP gradients: nothing to pack for the all-reduce)
 
     def exchange(self):
         """N > 1: one gradient exchange.  total_loss already normalised by the GLOBAL ray / mask counts, so the

@@ -51,6 +51,8 @@ def test_loss_and_gradients_add_over_ray_shards(step):
     s = step
     loss_full = float(s.forward_backward())
     g_full = [g.clone() if g is not None else None for g in s.grads]
+    from ndjir_amd import mlp
+    mlp.clear_grad_buffers()        # the shard passes below take their gradients from autograd (the step's bucket is filled in place)
     grid_full = {k: v.clone() for k, v in s.grid_bufs.items()}
     with torch.no_grad():
         _, _, mask = SamplePoints(s.conf).t_near_far(s.camloc, s.raydir)
@@ -162,6 +164,8 @@ def test_cfg3_loss_and_gradients_add_over_ray_shards(step_tpl):
     loss_full = float(s.forward_backward())
     assert math.isfinite(loss_full)
     g_full = [g.clone() if g is not None else None for g in s.grads]
+    from ndjir_amd import mlp
+    mlp.clear_grad_buffers()        # the shard passes below take their gradients from autograd (the step's bucket is filled in place)
     grid_full = {k: b.clone() for k, b in s.grid_bufs.items()}
     with torch.no_grad():
         _, _, mask = SamplePoints(s.conf).t_near_far(s.camloc, s.raydir)

@@ -191,3 +191,26 @@ def test_training_graph_replay_then_eager(gpu):
         assert np.isfinite(float(step.loss))
     finally:
         mlp.track_weights(False)
+
+
+@pytest.mark.parametrize("variant", ["default", "no_voxel"])
+def test_in_place_gradient_bucket_equals_autograd(gpu, variant):
+    """Step's flat MLP gradient bucket, filled in place by the operators (ndjir_amd.mlp.set_grad_buffer: weights, biases, the
+    row blocks of the split first-layer weights), against the same step with every gradient returned through autograd."""
+    from ndjir_amd import config as cfg, mlp
+    from ndjir_amd.step import Step
+    conf = cfg.load(variant, ["geometric_network.voxel.grid_size=16"])
+    step = Step(conf, 16, gpu, 0, 1)
+    assert step.in_place and len(mlp._GRAD_BUF) == len(step.mlp_params)
+    for _ in range(2):                       # twice: the bucket is re-zeroed, not accumulated across steps
+        step.forward_backward()
+    got = step.flat_grad.clone()
+    mlp.clear_grad_buffers()
+    step.forward_backward()
+    want = step.flat_grad.clone()
+    assert float(want.abs().max()) > 0
+    for name, v in zip(step.mlp_names, step.grad_views):
+        off = v.storage_offset()
+        a, b = got[off:off + v.numel()], want[off:off + v.numel()]
+        err = float((a - b).norm() / max(float(b.norm()), 1e-30))
+        assert err < 2e-5, (name, err)
