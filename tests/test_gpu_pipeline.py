@@ -310,6 +310,18 @@ def test_bench_step_graph_replay_matches_eager(gpu):
         assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-12)
     for k, v in step.grid_bufs.items():
         assert float((v - grid_e[k]).abs().max()) <= 1e-5 * max(float(grid_e[k].abs().max()), 1e-12), k
+    # replay -> eager steps -> replay (a replay that followed eager steps once produced another loss -- memset
+    # nodes of the library, since replaced by kernels): state shared between eager launches and the captured graph
+    # (library scratch, the operand-maximum arena, packed weights, the gradient bucket) must not leak either way
+    for _ in range(2):
+        loss_e2 = step.forward_backward()
+    assert abs(float(loss_e2) - float(loss_e)) <= 1e-6 * abs(float(loss_e))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert abs(float(loss_g) - float(loss_e)) <= 1e-6 * abs(float(loss_e))
+    for a, b in zip(step.grads, eager):
+        if b is not None:
+            assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-12)
 
 
 @pytest.mark.parametrize("case", ["all_miss", "single_ray", "ragged_rays"])
