@@ -9,6 +9,7 @@ keep nnabla's layout, W (in, out) and y = x W + b.
 Backward: one fused chain launch for the data path (delta of every layer + bias gradients + input
 gradient); weight gradients H^T delta by the split-P MFMA kernel of csrc/wgrad.hip.
 """
+import contextlib
 import os
 import weakref
 
@@ -89,7 +90,8 @@ def _packed(W, transpose):
         W = W.contiguous()
     key = (W.data_ptr(), W._version, tuple(W.shape), bool(transpose), get_math())
     hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0]() is W:     # same live tensor object, same version
+    owner = W._base if W._base is not None else W      # (a view of a long-lived tensor -- rows_except's cached copy -- counts as it)
+    if hit is not None and hit[0]() is owner:           # same live storage owner, same version
         return hit[1]
     K, N = W.shape
     n = lib.load().ndjir_mlp_packed_size(K, N, int(transpose))
@@ -97,7 +99,7 @@ def _packed(W, transpose):
     lib.call("mlp_pack", W.detach().contiguous(), dst, K, N, int(transpose))
     if len(_PACK_CACHE) > 512:
         _PACK_CACHE.clear()
-    _PACK_CACHE[key] = (weakref.ref(W), dst)
+    _PACK_CACHE[key] = (weakref.ref(owner), dst)
     return dst
 
 
@@ -114,10 +116,25 @@ def track_weights(on=True):
     """Training mode of the packed-weight store (python/train.py's iteration changes every weight every step): every
     (weight, orientation) a chain asks for from now on gets a persistent packed buffer, and `repack_tracked()` rewrites
     all of them with one launch.  A weight changed by anyone else (its version counter moved) is re-packed on its next
-    use.  off: back to the per-version cache (the buffers are dropped)."""
+    use.  off: back to the per-version cache -- the buffers AND the re-pack table are dropped, so a captured graph that
+    contains the re-pack launch must not be replayed afterwards (use `tracking_suspended` to step around the store while
+    such a graph is alive)."""
     global _TRACK, _TRACK_TABLE
     _TRACK = {} if on else None
     _TRACK_TABLE = None
+
+
+@contextlib.contextmanager
+def tracking_suspended():
+    """The per-version cache for the duration of the block; the tracked buffers (whose addresses a captured training graph
+    holds) stay alive and are current again once the next `repack_tracked` has run."""
+    global _TRACK, _TRACK_TABLE
+    saved = (_TRACK, _TRACK_TABLE)
+    _TRACK, _TRACK_TABLE = None, None
+    try:
+        yield
+    finally:
+        _TRACK, _TRACK_TABLE = saved
 
 
 def _base_version(W):
@@ -151,6 +168,7 @@ def repack_tracked():
     global _TRACK_TABLE
     if not _TRACK:
         return
+    _refresh_row_copies()          # (rows_except's copies are tracked weights too: bring them up to date first)
     if _TRACK_TABLE is None:
         if torch.cuda.is_current_stream_capturing():
             # entries appeared during the capture itself (a weight used for the first time): pack them one by one
@@ -748,6 +766,63 @@ class ColSumOp(Function):
     @staticmethod
     def backward(ctx, gz):
         return gz.reshape(1, -1).expand(ctx.rows, -1)
+
+
+_ROWS_CACHE = {}
+
+
+def _refresh_rows(ent, W, a, b):
+    torch.cat([W.detach()[:a], W.detach()[b:]], dim=0, out=ent[1])
+    ent[0] = W._version
+
+
+def _refresh_row_copies():
+    """Every live copy whose parameter moved (the optimizer's update): refreshed here, as part of the one re-pack after the
+    update, so that a captured training graph always contains the refresh -- not only when the capture happened to see
+    a stale copy at its first use."""
+    for (_, _, a, b), ent in _ROWS_CACHE.items():
+        W = ent[2]()
+        if W is not None and ent[0] != W._version:
+            _refresh_rows(ent, W, a, b)
+
+
+class RowsExcept(Function):
+    """Rows [0:a) and [b:) of a weight matrix as one matrix: the per-sample part of a first layer whose per-ray rows sit in
+    the MIDDLE of the reference's input order ([x, pe(view), feature, normal, ...], python/network.py:380-424, 339-377).
+    The copy is kept per parameter version (weights change once per optimizer step, not per use); the gradient of the copy
+    is added to the two row blocks of the parameter's accumulate-in-place buffer when it has one (set_grad_buffer) -- two
+    launches instead of autograd's slice / cat backward (two zero-fills, two copies, a sum)."""
+
+    @staticmethod
+    def forward(ctx, W, a, b):
+        key = (W.data_ptr(), tuple(W.shape), a, b)
+        ent = _ROWS_CACHE.get(key)
+        if ent is None or ent[2]() is not W:
+            if len(_ROWS_CACHE) > 64:
+                _ROWS_CACHE.clear()
+            ent = _ROWS_CACHE[key] = [None, torch.empty((W.shape[0] - (b - a), W.shape[1]), device=W.device, dtype=W.dtype),
+                                      weakref.ref(W)]
+        if ent[0] != W._version:          # refreshed in place: the copy keeps its address (packed-weight store, captured graphs)
+            _refresh_rows(ent, W, a, b)
+        ctx.ab = (a, b, tuple(W.shape))
+        ctx.tgt = grad_target(W)
+        return ent[1].view(ent[1].shape)  # (a fresh tensor object per call: autograd owns what it returns)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, shape = ctx.ab
+        if ctx.tgt is not None and not torch.is_grad_enabled():
+            ctx.tgt[:a].add_(g[:a])
+            ctx.tgt[b:].add_(g[a:])
+            return None, None, None
+        gW = g.new_zeros(shape)
+        gW[:a] = g[:a]
+        gW[b:] = g[a:]
+        return gW, None, None
+
+
+def rows_except(W, a, b):
+    return RowsExcept.apply(W, int(a), int(b))
 
 
 def linear(x, W, b=None):

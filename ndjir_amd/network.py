@@ -427,10 +427,10 @@ def material_nets_raw(x, feature, normal, conf, packed=None, photo=None):
             extra = 1 if pc.use_inverse_distance else 0
             Ws, bs = _mlp_params(Din + npe + extra, pc.feature_size, pc.layers, pc.channels, conf.use_wn)
             pgain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain_lv_start]), False)
-        from .mlp import linear
+        from .mlp import linear, rows_except
         # reference input order [x, pe(view), feature, normal, 1/d^2]: the pe rows of the first layer act per ray
         row_term = linear(pe_view.reshape(B * R, npe), Ws[0][nx:nx + npe], bs[0])
-        W0 = torch.cat([Ws[0][:nx], Ws[0][nx + npe:]], dim=0)
+        W0 = rows_except(Ws[0], nx, nx + npe)
         if extra:
             Z2 = packed.detach().view(-1, packed.shape[-1])
             lib.call("inverse_squared_distance", Z2.shape[0], R * N, Z2, Z2.shape[1], camloc.detach().reshape(B, 3).contiguous(),
@@ -512,8 +512,8 @@ def soft_visibility_light_network(x, light_dirs, feature, normal, conf):
             Ws, bs = _mlp_params(nx + npe + sum(t.shape[-1] for t in per_ray[1:]), c.feature_size, c.layers, c.channels,
                                  conf.use_wn)
             ray_in = torch.cat([t[:, :, 0, :] for t in per_ray], dim=-1)
-            W0_ray = torch.cat([Ws[0][:nx], Ws[0][nx + npe:]], dim=0)
-            from .mlp import fused_mlp, linear
+            from .mlp import fused_mlp, linear, rows_except
+            W0_ray = rows_except(Ws[0], nx, nx + npe)
             row_term = linear(ray_in.reshape(B * R, -1), W0_ray, bs[0]).view(B, R, -1)
             h = fused_mlp(pe, [Ws[0][nx:nx + npe]] + Ws[1:], [None] + bs[1:], 100.0, row_bias=row_term, row_bias_div=M)
         else:

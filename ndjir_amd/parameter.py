@@ -86,6 +86,7 @@ def clear_parameters():
         m.track_weights(False)
     if m is not None:
         m.clear_grad_buffers()                       # ... and so do the accumulate-in-place gradient buffers
+        m._ROWS_CACHE.clear()                        # ... and the row-block copies of first-layer weights
 
 
 def save_parameters(path):

@@ -465,3 +465,28 @@ def test_wgrad_operand_scales(gpu, scale_a, scale_b):
     bm = B.abs().max().reshape(1).to(gpu)
     out2 = wgrad(A.to(gpu), B.to(gpu), amax_a=am, amax_b=bm)
     assert float((out2.cpu().double() - ref).norm() / ref.norm()) < 2e-6
+
+
+def test_rows_except_value_gradient_and_cache(gpu):
+    """mlp.rows_except (the per-sample rows of a first-layer weight whose per-ray rows sit in the middle): value, gradient
+    through autograd, gradient into an accumulate-in-place buffer, and the refresh of the cached copy after an in-place update."""
+    from ndjir_amd import mlp
+    W = torch.randn(12, 8, device=gpu, requires_grad=True)
+    c = torch.randn(9, 8, device=gpu)
+    y = mlp.rows_except(W, 3, 6)
+    assert torch.equal(y, torch.cat([W[:3], W[6:]]).detach())
+    g, = torch.autograd.grad((y * c).sum(), W)
+    want = torch.zeros_like(W)
+    want[:3], want[6:] = c[:3], c[3:]
+    assert torch.equal(g, want)
+    buf = torch.zeros(12, 8, device=gpu)
+    try:
+        mlp.set_grad_buffer(W, buf)
+        y = mlp.rows_except(W, 3, 6)
+        res = torch.autograd.grad((y * c).sum() + (W * 2).sum(), W)      # the stock path still returns its own part
+        assert torch.equal(res[0], torch.full_like(W, 2.0)) and torch.equal(buf, want)
+    finally:
+        mlp.set_grad_buffer(W, None)
+    with torch.no_grad():
+        W.mul_(3.0)
+    assert torch.equal(mlp.rows_except(W, 3, 6), torch.cat([W[:3], W[6:]]).detach())

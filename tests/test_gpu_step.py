@@ -179,13 +179,17 @@ def test_training_graph_replay_then_eager(gpu):
         for _ in range(3):
             g.replay()
         torch.cuda.synchronize()
+        live = [(k, e, e[2]()) for k, e in mlp._ROWS_CACHE.items() if e[2]() is not None]
+        assert live                               # (the row-block copies of first-layer weights are refreshed by the graph too)
+        for (_, _, a, b), e, W in live:
+            assert torch.equal(e[1], torch.cat([W.detach()[:a], W.detach()[b:]]))
         loss_eager = float(step.compute(rearm=True))                       # eager forward on the replays' weights
-        # reference: the same forward with every packed copy rebuilt from the current weights
-        mlp.track_weights(False)
-        mlp._PACK_CACHE.clear()
-        loss_fresh = float(step.compute(rearm=True))
+        # reference: the same forward with every packed copy rebuilt from the current weights (the tracked buffers stay
+        # alive meanwhile: the graph holds their addresses)
+        with mlp.tracking_suspended():
+            mlp._PACK_CACHE.clear()
+            loss_fresh = float(step.compute(rearm=True))
         assert loss_eager == loss_fresh
-        mlp.track_weights(True)
         g.replay()
         torch.cuda.synchronize()
         assert np.isfinite(float(step.loss))
