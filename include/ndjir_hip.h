@@ -326,6 +326,42 @@ int ndjir_render_specular_light_filament_backward(int R, int M, int C, const flo
                                                   const float* g, float* g_normal, float* g_roughness, float* g_specular_color,
                                                   float* g_soft_vis, float* g_env, hipStream_t stream);
 
+/* Background head (python/network.py:543-556): h (P, 1 + F) = output of the background model's geometric net, x (P, nx) its
+ * inverted-sphere sample coordinates, delta (P) the sample spacing.  alpha (P) = 1 - exp(-softplus_100(h_0) delta);
+ * inp (P, nx + F) = [x | h_1..F], the per-sample input of the background lighting net (its per-ray inputs enter the fused
+ * chain as a row term).  Backward: g_h (P, 1 + F) from g_alpha (P) and g_inp (P, nx + F) (either may be null = zero). */
+int ndjir_render_background_head(long long P, int nx, int F, const float* h, const float* x, const float* delta, float* alpha,
+                                 float* inp, hipStream_t stream);
+int ndjir_render_background_head_backward(long long P, int nx, int F, const float* h, const float* delta, const float* g_alpha,
+                                          const float* g_inp, float* g_h, hipStream_t stream);
+
+/* The geometric network's SDF-to-density gain  clamp(exp(scale p), lo, hi)  of its scalar parameter(s) p (n values):
+ * python/network.py:229-231 (`F.clip_by_value(F.exp(gain * 10), 1e-6, 5e4)`), one launch each way; the backward passes the
+ * gradient where lo <= exp(scale p) <= hi. */
+int ndjir_render_gain(int n, const float* p, float scale, float lo, float hi, float* out, hipStream_t stream);
+int ndjir_render_gain_backward(int n, const float* p, float scale, float lo, float hi, const float* g, float* gp,
+                               hipStream_t stream);
+
+/* Both light integrals AND the pixel composition of a ray in one launch each way (the default branch of
+ * python/renderer.py:105-178: filament BRDF, importance sampling, no split sum).  The environment-light and soft-visibility
+ * nets run once over the 2 M directions [diffuse (M) | specular (M)] of a ray and hand over their RAW outputs: light_dirs
+ * (R,2M,3), raw_soft_vis (R,2M), raw_env (R,2M,C), C = 1 | 3.  acts[2] = output activation of (soft_vis, env): 0 identity,
+ * 1 softplus(beta) (python/network.py:288-296 `act_last` with `inverse_black_degree`), 2 sigmoid, 3 relu; params[5] =
+ * (beta_soft_vis, beta_env, env upper bound (> 0: clamp(., 0, ub), python/network.py:295-296), eps_dot, specular weight).
+ * pix (R,9) = VR of the material head's V [implicit, roughness, specular x3, photo, base x3]; bg (R,3) or null.
+ * Writes color (R,3) (= ndjir_render_pixel_compose of the two integrals) and keeps env_pixel (R,C), spec_pixel (R,3) for the
+ * backward, which writes g_normal (R,3), the raw outputs' gradients over all 2 M directions, the full g_pix row (R,9)
+ * and g_bg (R,3; may be null). */
+int ndjir_render_direct_light(int R, int M, int C, const int* acts, const float* params, int entangle, const float* normal,
+                              const float* view_dir, const float* light_dirs, const float* raw_soft_vis, const float* raw_env,
+                              const float* pix, const float* bg, float* color, float* env_pixel, float* spec_pixel,
+                              hipStream_t stream);
+int ndjir_render_direct_light_backward(int R, int M, int C, const int* acts, const float* params, int entangle, const float* normal,
+                                       const float* view_dir, const float* light_dirs, const float* raw_soft_vis,
+                                       const float* raw_env, const float* pix, const float* env_pixel, const float* spec_pixel,
+                                       const float* g_color, float* g_normal, float* g_raw_soft_vis, float* g_raw_env, float* g_pix,
+                                       float* g_bg, hipStream_t stream);
+
 /* Material head: the output activations of the per-sample nets and the integrands of the prior terms in one
  * launch each way (python/network.py:262, 335, 423, 456-463, 498-508; python/loss.py:117-166).
  * Inputs are the nets' raw outputs for the R x N foreground samples: base colour (P,3), base colour of the

@@ -612,7 +612,350 @@ __global__ void __launch_bounds__(SH_THREADS) k_specular_light_bwd(int M, int C,
   }
 }
 
+// ---- background head (python/network.py:543-556) ---------------------------------------------------------------------------
+// h (P, 1 + F) = output of the background geometric net: density = softplus_100(h_0), alpha = 1 - exp(-density delta), and the
+// lighting net's per-sample input  [x (nx) | feature (F)]  (its per-ray inputs, the view direction and its encoding, enter
+// the fused chain as a row term).  One launch each way instead of slice / softplus / mul / neg / exp / rsub / cat and their
+// backward launches; one thread per element of the (P, nx + F) input, the thread of column 0 also does the row's alpha.
+__global__ void __launch_bounds__(256) k_background_head(long long P, int nx, int F, const float* __restrict__ h,
+                                                         const float* __restrict__ x, const float* __restrict__ delta,
+                                                         float* __restrict__ alpha, float* __restrict__ inp) {
+  const int W = nx + F;
+  const long long n = P * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long p = i / W;
+    const int c = (int)(i - p * W);
+    inp[i] = c < nx ? x[p * nx + c] : h[p * (F + 1) + 1 + (c - nx)];
+    if (c == 0) {
+      const float v = h[p * (F + 1)];
+      const float density = 100.f * v > 20.f ? v : log1pf(expf(100.f * v)) / 100.f;
+      alpha[p] = 1.f - expf(-density * delta[p]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_background_head_bwd(long long P, int nx, int F, const float* __restrict__ h,
+                                                             const float* __restrict__ delta, const float* __restrict__ g_alpha,
+                                                             const float* __restrict__ g_inp, float* __restrict__ g_h) {
+  const int W = F + 1;
+  const long long n = P * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long p = i / W;
+    const int c = (int)(i - p * W);
+    if (c > 0) {
+      g_h[i] = g_inp ? g_inp[p * (nx + F) + nx + (c - 1)] : 0.f;
+    } else {
+      float gv = 0.f;
+      if (g_alpha) {
+        const float v = h[i], d = delta[p];
+        const bool lin = 100.f * v > 20.f;
+        const float e = lin ? 0.f : expf(100.f * v);
+        const float density = lin ? v : log1pf(e) / 100.f;
+        const float dsoft = lin ? 1.f : e / (e + 1.f);
+        gv = g_alpha[p] * d * expf(-density * d) * dsoft;
+      }
+      g_h[i] = gv;
+    }
+  }
+}
+
+// ---- the SDF-to-density gain: clamp(exp(scale p), lo, hi) of a scalar parameter (python/network.py:229-231) -----------------
+// Three elementwise functions forward and eight backward in the reference's spelling; one single-thread launch each way.
+__global__ void k_gain(int n, const float* __restrict__ p, float scale, float lo, float hi, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fminf(fmaxf(expf(scale * p[i]), lo), hi);
+}
+
+__global__ void k_gain_bwd(int n, const float* __restrict__ p, float scale, float lo, float hi, const float* __restrict__ g,
+                           float* __restrict__ gp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float e = expf(scale * p[i]);
+  gp[i] = (e >= lo && e <= hi) ? g[i] * e * scale : 0.f;       // clamp passes the gradient inside [lo, hi] (bounds included)
+}
+
+// ---- both light integrals + the pixel composition of a ray in one launch each way ------------------------------------
+// python/renderer.py:105-178 for the default branch (filament BRDF, importance sampling, no split sum, fused material head):
+// the environment-light and soft-visibility nets are evaluated once over the 2 M directions [diffuse | specular] of a ray
+// and hand over their RAW outputs; their output activations (python/network.py:288-296, 372-376), the two light integrals
+// above and  diffuse = env + implicit;  color = base * diffuse + photo * spec  (entangle) | photo * (base * diffuse + spec);
+// color += background  (csrc/loss.hip k_pixel_compose) run here per ray.  pix (R,9) = VR of the material head's V:
+// [implicit, roughness, specular x3, photo, base x3].  The backward writes the gradient of the raw net outputs for all 2 M
+// directions and the FULL g_pix row (roughness / specular columns from the specular integral) -- no slices of the 2 M
+// tensors or of pix exist on either pass.
+struct LightCfg {
+  int M, C;                       // lights per integral, env channels (1 | 3)
+  int act_sv, act_env;            // 0 identity, 1 softplus(beta), 2 sigmoid, 3 relu
+  float beta_sv, beta_env;
+  float ub_env;                   // > 0: clamp(act(env), 0, ub)
+  float eps_dot, weight;
+  int entangle;
+};
+
+__device__ __forceinline__ float light_act(int kind, float beta, float v, float& d) {
+  if (kind == 1) {                // TF.softplus(v, beta), threshold 20
+    const float bv = beta * v;
+    if (bv > 20.f) { d = 1.f; return v; }
+    const float e = expf(bv);
+    d = e / (e + 1.f);
+    return log1pf(e) / beta;
+  }
+  if (kind == 2) { const float y = 1.f / (1.f + expf(-v)); d = y * (1.f - y); return y; }
+  if (kind == 3) { d = v > 0.f ? 1.f : 0.f; return fmaxf(v, 0.f); }
+  d = 1.f;
+  return v;
+}
+
+__device__ __forceinline__ float env_act(const LightCfg& c, float v, float& d) {
+  float y = light_act(c.act_env, c.beta_env, v, d);
+  if (c.ub_env > 0.f) {
+    if (!(y >= 0.f && y <= c.ub_env)) d = 0.f;
+    y = fminf(fmaxf(y, 0.f), c.ub_env);
+  }
+  return y;
+}
+
+__global__ void __launch_bounds__(SH_THREADS) k_direct_light(LightCfg c, const float* __restrict__ normal, const float* __restrict__ view,
+                                                             const float* __restrict__ dirs, const float* __restrict__ raw_sv,
+                                                             const float* __restrict__ raw_env, const float* __restrict__ pix,
+                                                             const float* __restrict__ bg, float* __restrict__ color,
+                                                             float* __restrict__ env_pix, float* __restrict__ spec_pix) {
+  __shared__ float red[2];
+  const long long r = blockIdx.x;
+  const int M = c.M, C = c.C;
+  const float nx = normal[r * 3], ny = normal[r * 3 + 1], nz = normal[r * 3 + 2];
+  const float vx = view[r * 3], vy = view[r * 3 + 1], vz = view[r * 3 + 2];
+  const float ro = pix[r * 9 + 1];
+  float dsum[3] = {0.f, 0.f, 0.f}, ssum[3] = {0.f, 0.f, 0.f}, d_;
+  for (int m = threadIdx.x; m < M; m += SH_THREADS) {
+    const long long e = r * 2 * M + m;
+    const float cs = fmaxf(nx * dirs[e * 3] + ny * dirs[e * 3 + 1] + nz * dirs[e * 3 + 2], c.eps_dot);
+    const float t = light_act(c.act_sv, c.beta_sv, raw_sv[e], d_) * cs;
+    for (int k = 0; k < C; ++k) dsum[k] += t * env_act(c, raw_env[e * C + k], d_);
+  }
+  for (int m = threadIdx.x; m < M; m += SH_THREADS) {
+    const long long e = r * 2 * M + M + m;
+    SpecTerms t = spec_terms(nx, ny, nz, vx, vy, vz, dirs[e * 3], dirs[e * 3 + 1], dirs[e * 3 + 2], ro, c.eps_dot);
+    const float V = t.V1l * t.V1v;
+    const float f5 = powf(1.f - t.voh, 5.f);
+    const float Kf = 4.f * t.voh / t.noh * t.mask;
+    const float sv = light_act(c.act_sv, c.beta_sv, raw_sv[e], d_);
+    float ev[3];
+    for (int k = 0; k < C; ++k) ev[k] = env_act(c, raw_env[e * C + k], d_);
+    for (int k = 0; k < 3; ++k) {
+      const float sc = pix[r * 9 + 2 + k];
+      const float Fs = sc + (1.f - sc) * f5;
+      ssum[k] += V * Fs * Kf * sv * ev[C == 1 ? 0 : k] * t.nol;
+    }
+  }
+  float envp[3] = {0.f, 0.f, 0.f}, specp[3];
+  for (int k = 0; k < C; ++k) envp[k] = sh_block_sum(dsum[k], red) / (float)M;
+  for (int k = 0; k < 3; ++k) specp[k] = c.weight * sh_block_sum(ssum[k], red) / (float)M;
+  if (threadIdx.x == 0) {
+    const float imp = pix[r * 9], photo = pix[r * 9 + 5];
+    for (int k = 0; k < C; ++k) env_pix[r * C + k] = envp[k];
+    for (int k = 0; k < 3; ++k) {
+      spec_pix[r * 3 + k] = specp[k];
+      const float diff = envp[C == 3 ? k : 0] + imp;
+      const float base = pix[r * 9 + 6 + k];
+      const float fg = c.entangle ? base * diff + photo * specp[k] : photo * (base * diff + specp[k]);
+      color[r * 3 + k] = fg + (bg ? bg[r * 3 + k] : 0.f);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(SH_THREADS) k_direct_light_bwd(LightCfg c, const float* __restrict__ normal,
+                                                                 const float* __restrict__ view, const float* __restrict__ dirs,
+                                                                 const float* __restrict__ raw_sv, const float* __restrict__ raw_env,
+                                                                 const float* __restrict__ pix, const float* __restrict__ env_pix,
+                                                                 const float* __restrict__ spec_pix, const float* __restrict__ g,
+                                                                 float* __restrict__ g_normal, float* __restrict__ g_raw_sv,
+                                                                 float* __restrict__ g_raw_env, float* __restrict__ g_pix,
+                                                                 float* __restrict__ g_bg) {
+  __shared__ float red[2];
+  const long long r = blockIdx.x;
+  const int M = c.M, C = c.C;
+  const float nx = normal[r * 3], ny = normal[r * 3 + 1], nz = normal[r * 3 + 2];
+  const float vx = view[r * 3], vy = view[r * 3 + 1], vz = view[r * 3 + 2];
+  const float ro = pix[r * 9 + 1];
+  // composition backward (every thread: it needs g_env_pix / g_spec_pix for its lights)
+  const float imp = pix[r * 9], photo = pix[r * 9 + 5];
+  float g_imp = 0.f, g_photo = 0.f, gd[3], gk[3], sc[3], g_base[3];
+  for (int k = 0; k < 3; ++k) {
+    const float gc = g[r * 3 + k];
+    const float diff = env_pix[r * C + (C == 3 ? k : 0)] + imp;
+    const float base = pix[r * 9 + 6 + k], sp = spec_pix[r * 3 + k];
+    float g_sp;
+    if (c.entangle) { g_base[k] = gc * diff; gd[k] = gc * base; g_photo += gc * sp; g_sp = gc * photo; }
+    else { g_photo += gc * (base * diff + sp); g_base[k] = gc * photo * diff; gd[k] = gc * photo * base; g_sp = gc * photo; }
+    g_imp += gd[k];
+    gk[k] = g_sp * c.weight / (float)M;
+    sc[k] = pix[r * 9 + 2 + k];
+  }
+  float ge_pix[3];                       // d / d env_pixel
+  if (C == 3) { ge_pix[0] = gd[0]; ge_pix[1] = gd[1]; ge_pix[2] = gd[2]; }
+  else { ge_pix[0] = gd[0] + gd[1] + gd[2]; ge_pix[1] = ge_pix[2] = 0.f; }
+  const float inv = 1.f / (float)M;
+  float gn[3] = {0.f, 0.f, 0.f}, ga2 = 0.f, gsc[3] = {0.f, 0.f, 0.f};
+  // diffuse integral
+  for (int m = threadIdx.x; m < M; m += SH_THREADS) {
+    const long long e = r * 2 * M + m;
+    const float lx = dirs[e * 3], ly = dirs[e * 3 + 1], lz = dirs[e * 3 + 2];
+    const float raw = nx * lx + ny * ly + nz * lz;
+    const float cs = fmaxf(raw, c.eps_dot);
+    float dsv;
+    const float sv = light_act(c.act_sv, c.beta_sv, raw_sv[e], dsv);
+    float ge = 0.f;
+    for (int k = 0; k < C; ++k) {
+      float de;
+      const float ev = env_act(c, raw_env[e * C + k], de);
+      const float gkk = ge_pix[k] * inv;
+      ge += gkk * ev;
+      g_raw_env[e * C + k] = gkk * sv * cs * de;
+    }
+    g_raw_sv[e] = ge * cs * dsv;
+    const float gc = (raw >= c.eps_dot) ? ge * sv : 0.f;
+    gn[0] += gc * lx; gn[1] += gc * ly; gn[2] += gc * lz;
+  }
+  // specular integral
+  for (int m = threadIdx.x; m < M; m += SH_THREADS) {
+    const long long e = r * 2 * M + M + m;
+    const float lx = dirs[e * 3], ly = dirs[e * 3 + 1], lz = dirs[e * 3 + 2];
+    SpecTerms t = spec_terms(nx, ny, nz, vx, vy, vz, lx, ly, lz, ro, c.eps_dot);
+    const float V = t.V1l * t.V1v;
+    const float omv = 1.f - t.voh;
+    const float f4 = omv * omv * omv * omv, f5 = f4 * omv;
+    const float Kf = 4.f * t.voh / t.noh * t.mask;
+    float dsv_;
+    const float sv = light_act(c.act_sv, c.beta_sv, raw_sv[e], dsv_);
+    float ev[3], de[3];
+    for (int k = 0; k < C; ++k) ev[k] = env_act(c, raw_env[e * C + k], de[k]);
+    float dV = 0.f, dK = 0.f, dnol = 0.f, dsv = 0.f;
+    float denv[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; ++k) {
+      const float ek = ev[C == 1 ? 0 : k];
+      const float Fs = sc[k] + (1.f - sc[k]) * f5;
+      const float sB = V * Fs * Kf;
+      const float dsB = gk[k] * sv * ek * t.nol;
+      dsv += gk[k] * sB * ek * t.nol;
+      denv[C == 1 ? 0 : k] += gk[k] * sB * sv * t.nol;
+      dnol += gk[k] * sB * sv * ek;
+      dV += dsB * Fs * Kf;
+      dK += dsB * V * Fs;
+      gsc[k] += dsB * V * Kf * (1.f - f5);
+    }
+    g_raw_sv[e] = dsv * dsv_;
+    for (int k = 0; k < C; ++k) g_raw_env[e * C + k] = denv[k] * de[k];
+    const float dnoh = -dK * 4.f * t.voh / (t.noh * t.noh) * t.mask;     // (voh only reaches h: no gradient)
+    const float dV1l = dV * t.V1v, dV1v = dV * t.V1l;
+    const float om = 1.f - t.a2;
+    dnol += dV1l * (-t.V1l * t.V1l) * (1.f + om * t.nol / t.sl);
+    const float dnov = dV1v * (-t.V1v * t.V1v) * (1.f + om * t.nov / t.sv_);
+    ga2 += dV1l * (-t.V1l * t.V1l) * (1.f - t.nol * t.nol) / (2.f * t.sl) + dV1v * (-t.V1v * t.V1v) * (1.f - t.nov * t.nov) / (2.f * t.sv_);
+    const float cl = (t.rnol >= c.eps_dot) ? dnol : 0.f, cv = (t.rnov >= c.eps_dot) ? dnov : 0.f, ch = (t.rnoh >= c.eps_dot) ? dnoh : 0.f;
+    gn[0] += cl * lx + cv * vx + ch * t.hx;
+    gn[1] += cl * ly + cv * vy + ch * t.hy;
+    gn[2] += cl * lz + cv * vz + ch * t.hz;
+  }
+  for (int k = 0; k < 3; ++k) {
+    const float s = sh_block_sum(gn[k], red);
+    if (threadIdx.x == 0) g_normal[r * 3 + k] = s;
+  }
+  for (int k = 0; k < 3; ++k) {
+    const float s = sh_block_sum(gsc[k], red);
+    if (threadIdx.x == 0) g_pix[r * 9 + 2 + k] = s;
+  }
+  {
+    const float s = sh_block_sum(ga2, red);
+    if (threadIdx.x == 0) g_pix[r * 9 + 1] = s * 2.f * ro;
+  }
+  if (threadIdx.x == 0) {
+    g_pix[r * 9] = g_imp;
+    g_pix[r * 9 + 5] = g_photo;
+    for (int k = 0; k < 3; ++k) {
+      g_pix[r * 9 + 6 + k] = g_base[k];
+      if (g_bg) g_bg[r * 3 + k] = g[r * 3 + k];
+    }
+  }
+}
+
 }  // namespace ndjir
+
+extern "C" int ndjir_render_background_head(long long P, int nx, int F, const float* h, const float* x, const float* delta,
+                                            float* alpha, float* inp, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  if (nx < 1 || F < 1) return NDJIR_ERR_UNSUPPORTED;
+  if (!h || !x || !delta || !alpha || !inp) return NDJIR_ERR_ARG;
+  const long long blocks = (P * (nx + F) + 255) / 256;
+  hipLaunchKernelGGL(ndjir::k_background_head, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, P, nx, F, h, x,
+                     delta, alpha, inp);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_background_head_backward(long long P, int nx, int F, const float* h, const float* delta,
+                                                     const float* g_alpha, const float* g_inp, float* g_h, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  if (nx < 1 || F < 1) return NDJIR_ERR_UNSUPPORTED;
+  if (!h || !delta || !g_h) return NDJIR_ERR_ARG;
+  const long long blocks = (P * (F + 1) + 255) / 256;
+  hipLaunchKernelGGL(ndjir::k_background_head_bwd, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, P, nx, F, h,
+                     delta, g_alpha, g_inp, g_h);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_gain(int n, const float* p, float scale, float lo, float hi, float* out, hipStream_t stream) {
+  if (n <= 0) return NDJIR_OK;
+  if (!p || !out) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(ndjir::k_gain, dim3((n + 63) / 64), dim3(64), 0, stream, n, p, scale, lo, hi, out);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_gain_backward(int n, const float* p, float scale, float lo, float hi, const float* g, float* gp,
+                                          hipStream_t stream) {
+  if (n <= 0) return NDJIR_OK;
+  if (!p || !g || !gp) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(ndjir::k_gain_bwd, dim3((n + 63) / 64), dim3(64), 0, stream, n, p, scale, lo, hi, g, gp);
+  return ndjir_check_launch();
+}
+
+static int light_cfg(ndjir::LightCfg& c, int M, int C, const int* acts, const float* params, int entangle) {
+  if (M < 1 || (C != 1 && C != 3) || !acts || !params) return NDJIR_ERR_ARG;
+  if (acts[0] < 0 || acts[0] > 3 || acts[1] < 0 || acts[1] > 3) return NDJIR_ERR_UNSUPPORTED;
+  c.M = M; c.C = C; c.act_sv = acts[0]; c.act_env = acts[1];
+  c.beta_sv = params[0]; c.beta_env = params[1]; c.ub_env = params[2]; c.eps_dot = params[3]; c.weight = params[4];
+  c.entangle = entangle;
+  return NDJIR_OK;
+}
+
+extern "C" int ndjir_render_direct_light(int R, int M, int C, const int* acts, const float* params, int entangle, const float* normal,
+                                         const float* view_dir, const float* light_dirs, const float* raw_soft_vis,
+                                         const float* raw_env, const float* pix, const float* bg, float* color, float* env_pixel,
+                                         float* spec_pixel, hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  ndjir::LightCfg c;
+  if (int e = light_cfg(c, M, C, acts, params, entangle)) return e;
+  if (!normal || !view_dir || !light_dirs || !raw_soft_vis || !raw_env || !pix || !color || !env_pixel || !spec_pixel) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(ndjir::k_direct_light, dim3(R), dim3(ndjir::SH_THREADS), 0, stream, c, normal, view_dir, light_dirs, raw_soft_vis,
+                     raw_env, pix, bg, color, env_pixel, spec_pixel);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_direct_light_backward(int R, int M, int C, const int* acts, const float* params, int entangle,
+                                                  const float* normal, const float* view_dir, const float* light_dirs,
+                                                  const float* raw_soft_vis, const float* raw_env, const float* pix,
+                                                  const float* env_pixel, const float* spec_pixel, const float* g_color,
+                                                  float* g_normal, float* g_raw_soft_vis, float* g_raw_env, float* g_pix, float* g_bg,
+                                                  hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  ndjir::LightCfg c;
+  if (int e = light_cfg(c, M, C, acts, params, entangle)) return e;
+  if (!normal || !view_dir || !light_dirs || !raw_soft_vis || !raw_env || !pix || !env_pixel || !spec_pixel || !g_color || !g_normal ||
+      !g_raw_soft_vis || !g_raw_env || !g_pix)
+    return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(ndjir::k_direct_light_bwd, dim3(R), dim3(ndjir::SH_THREADS), 0, stream, c, normal, view_dir, light_dirs,
+                     raw_soft_vis, raw_env, pix, env_pixel, spec_pixel, g_color, g_normal, g_raw_soft_vis, g_raw_env, g_pix, g_bg);
+  return ndjir_check_launch();
+}
 
 extern "C" int ndjir_render_diffuse_light(int R, int M, int C, const float* normal, const float* light_dir, const float* soft_vis,
                                           const float* env, float eps_dot, float* out, hipStream_t stream) {

@@ -74,6 +74,12 @@ SIGS = {
     "render_diffuse_light_backward": "iiippppfpppp",
     "render_specular_light_filament": "iii" + "p" * 7 + "ffp",
     "render_specular_light_filament_backward": "iii" + "p" * 7 + "ff" + "p" * 6,
+    "render_background_head": "liippppp",
+    "render_background_head_backward": "liippppp",
+    "render_gain": "ipfffp",
+    "render_gain_backward": "ipfffpp",
+    "render_direct_light": "iiiAWi" + "p" * 10,
+    "render_direct_light_backward": "iiiAWi" + "p" * 14,
     "render_integrate_backward": "iiipipipppi",
     "sampler_importance_round": "iiifpppppqqp",
     "sampler_begin": "liippppppppp",

@@ -97,6 +97,12 @@ def _run_mlp(h, Ws, bs, act, skip_layer=-1, skip_scale=1.0, inputs=None, pack=No
     return h
 
 
+def _sdf_gain(p):
+    """network.py:229-231: clip(exp(10 gain), 1e-6, 5e4)."""
+    from .volume import sdf_gain
+    return sdf_gain(p, 10.0, 1e-6, 5e4)
+
+
 def softplus(x, beta=100):
     return TF.softplus(x, beta=beta)
 
@@ -200,7 +206,7 @@ def geometric_network_with_grad(x, conf, packed=False):
         sdf, feat, grad_x, Z = geometric_main(x, grids, Ws, bs, g.pe_bands, skip_at, scale, use_ste=v.use_ste)
         with P.parameter_scope("geometric-network"):
             gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain]), True)
-        gain = torch.exp(gain * 10).clamp(1e-6, 5e4)
+        gain = _sdf_gain(gain)
         return (sdf, feat, gain, grad_x, Z) if packed else (sdf, feat, gain, grad_x)
     from .grid_feature import grad as nn_grad
     sdf, feat, gain = geometric_network(x, conf)
@@ -322,7 +328,7 @@ def geometric_network(x, conf, first_order_only=False, sdf_only=False, packed=Fa
             sdf, feature = h[..., 0:1], h[..., 1:]
         gain = P.get_parameter_or_create("gain", (1,), np.asarray([conf.train.sigmoid_gain]), True)
         # (the sampler's and the perturbation pass's callers ignore the gain: three launches saved per call)
-        gain = None if (sdf_only or first_order_only) else torch.exp(gain * 10).clamp(1e-6, 5e4)
+        gain = None if (sdf_only or first_order_only) else _sdf_gain(gain)
     if packed:
         return sdf, feature, gain, (Zp if g.geometric_init else None)
     return sdf, feature, gain
@@ -472,12 +478,15 @@ def base_color_network(x, feature, normal, conf, raw=False, packed=None):
         return h if raw else torch.sigmoid(h)
 
 
-def environment_light_network(light_dirs, conf):
-    """network.py:266-297."""
+def environment_light_network(light_dirs, conf, raw=False):
+    """network.py:266-297.  raw=True: the net's output before `act_last` and the upper-bound clamp (volume.direct_light
+    applies both)."""
     with P.parameter_scope("environment-light-network"):
         c = conf.environment_light_network
         h = positional_encoding(light_dirs, c.pe_bands) if c.pe_bands > 0 else light_dirs
         h = _mlp(h, c.feature_size, c.layers, c.channels, _act(c.act), conf.use_wn)
+        if raw:
+            return h
         out = _last_act(c.act_last, c.inverse_black_degree)(h)
         if c.upper_bound > 0:
             out = out.clamp(0.0, c.upper_bound)
@@ -494,8 +503,8 @@ def implicit_illumination_network(x, feature, normal, conf, raw=False):
         return h if raw else _last_act(c.act_last, c.inverse_black_degree)(h)
 
 
-def soft_visibility_light_network(x, light_dirs, feature, normal, conf):
-    """network.py:339-377."""
+def soft_visibility_light_network(x, light_dirs, feature, normal, conf, raw=False):
+    """network.py:339-377.  raw=True: the net's output before `act_last`."""
     with P.parameter_scope("soft-visibility-light-network"):
         c = conf.soft_visibility_light_network
         pe = positional_encoding(light_dirs, c.pe_bands) if c.pe_bands > 0 else light_dirs
@@ -520,7 +529,7 @@ def soft_visibility_light_network(x, light_dirs, feature, normal, conf):
             per_ray = [t.expand(t.shape[0], t.shape[1], pe.shape[2], t.shape[3]) for t in per_ray]
             inputs = [per_ray[0], pe] + per_ray[1:]
             h = _mlp(torch.cat(inputs, dim=-1), c.feature_size, c.layers, c.channels, act, conf.use_wn)
-        return _last_act(c.act_last, c.inverse_black_degree)(h)
+        return h if raw else _last_act(c.act_last, c.inverse_black_degree)(h)
 
 
 def photogrammetric_light_network(x, camloc, view, feature, normal, conf, raw=False):
@@ -583,16 +592,36 @@ def background_network(x, view, delta, conf):
         c = conf.background_network
         B, R, N, _ = x.shape
         act = _act(c.act)
+        fused = (USE_FUSED and act is softplus and not conf.use_wn and c.layers1 >= 2 and x.is_cuda and view.shape[2] == 1
+                 and not x.requires_grad and not delta.requires_grad and not os.environ.get("NDJIR_NO_BACKGROUND_HEAD"))
         with P.parameter_scope("geometric-network"):
             h = positional_encoding(x, c.pe_bands0) if c.pe_bands0 > 0 else x
             h = _mlp(h, c.feature_size0, c.layers0, c.feature_size0 + 1, act, conf.use_wn)
-            density, feature = softplus(h[..., 0:1], 100), h[..., 1:]
-            alpha = 1 - torch.exp(-density * delta)
-        with P.parameter_scope("lighting-network"):
-            view = view.expand(B, R, N, 3)
-            if c.pe_bands1 > 0:
-                h = torch.cat([x, feature, view, positional_encoding(view, c.pe_bands1)], dim=-1)
+            if fused:
+                # density, alpha and the lighting net's per-sample input [x | feature] in one launch (volume.background_head)
+                from .volume import background_head
+                alpha, inp = background_head(h, x, delta)
             else:
-                h = torch.cat([x, feature, view], dim=-1)
-            color = torch.sigmoid(_mlp(h, c.feature_size1, c.layers1, 3, act, conf.use_wn))
+                density, feature = softplus(h[..., 0:1], 100), h[..., 1:]
+                alpha = 1 - torch.exp(-density * delta)
+        with P.parameter_scope("lighting-network"):
+            if fused:
+                # reference input order [x, feature, view, pe(view)]: the view rows of the first layer act per RAY -- their
+                # share of the first affine (+ its bias) enters the fused chain as a row term, the (B,R,N,287) concatenation
+                # is never built
+                view_ray = view.reshape(B, R, 3)
+                per_ray = torch.cat([view_ray, positional_encoding(view_ray, c.pe_bands1)], dim=-1) if c.pe_bands1 > 0 else view_ray
+                ns = inp.shape[-1]
+                Ws, bs = _mlp_params(ns + per_ray.shape[-1], c.feature_size1, c.layers1, 3, conf.use_wn)
+                from .mlp import fused_mlp, linear
+                row_term = linear(per_ray.reshape(B * R, -1), Ws[0][ns:], bs[0]).view(B, R, -1)
+                raw = fused_mlp(inp, [Ws[0][:ns]] + Ws[1:], [None] + bs[1:], 100.0, row_bias=row_term, row_bias_div=N)
+                color = torch.sigmoid(raw)
+            else:
+                view = view.expand(B, R, N, 3)
+                if c.pe_bands1 > 0:
+                    h = torch.cat([x, feature, view, positional_encoding(view, c.pe_bands1)], dim=-1)
+                else:
+                    h = torch.cat([x, feature, view], dim=-1)
+                color = torch.sigmoid(_mlp(h, c.feature_size1, c.layers1, 3, act, conf.use_wn))
     return alpha, color

@@ -23,8 +23,8 @@ from .network import (background_network, base_color_network, material_nets_raw,
                       soft_visibility_light_network, specular_reflectance_network)
 from .sampler import sample_importance_directions, sample_points, sample_uniform_directions
 from .specular_brdf import dot, specular_brdf_model
-from .volume import (alpha_weights, diffuse_light, integrate, integrate_many, material_head, pixel_compose, pixel_normal,
-                     specular_light_filament)
+from .volume import (LIGHT_ACTS, alpha_weights, diffuse_light, direct_light, integrate, integrate_many, material_head, pixel_compose,
+                     pixel_normal, specular_light_filament)
 
 
 def make_rand(B, R, conf, device, n_fg=None, include_samples=True):
@@ -196,36 +196,55 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
     # once for the diffuse and once for the specular directions; the 2 M directions go through them in one pass
     # here (row-independent nets: same values; their weight gradients come from one reduction over 2 M lights)
     dirs_all = torch.cat([uniform_light_dir, imp_dir], dim=2)
-    env_all = environment_light_network(dirs_all, conf)
-    # (per-ray inputs are passed un-broadcast, (B,R,1,*): the net folds them into a per-ray first-layer term)
-    soft_vis_all = soft_visibility_light_network(x_fg_pixel, dirs_all, feature_pixel, normal_bc, conf)
-    env_d, env = env_all[:, :, :M], env_all[:, :, M:]
-    soft_vis_d, soft_vis = soft_vis_all[:, :, :M], soft_vis_all[:, :, M:]
-
-    # Diffuse colour (renderer.py:117-120)
-    # mean_m soft_vis * env * clamp(n.l): one fused launch (csrc/render.hip) instead of dot/clamp/mul/mean
-    env_pixel = diffuse_light(normal_pixel, uniform_light_dir, soft_vis_d, env_d, conf.renderer.eps_dot)
-
-    # Specular colour (renderer.py:141-161)
     sb = conf.specular_brdf
-    if (sb.model == "filament" and sb.sampling == "importance" and not sb.use_split_sum
-            and not (ii.use_me and ii.use_me_on_specular) and env.shape[-1] in (1, 3) and spec_refl_pixel.shape[-1] == 3):
-        # the default configuration: BRDF algebra and the light integral fused (csrc/render.hip)
-        spec_pixel = specular_light_filament(normal_pixel, view_dir.reshape(B, R, 3), imp_dir, roughness_pixel,
-                                             spec_refl_pixel, soft_vis, env, conf.renderer.eps_dot, sb.weight)
+    el, sl = conf.environment_light_network, conf.soft_visibility_light_network
+    color_pixel = None
+    fused_lights = (use_head and sb.model == "filament" and sb.sampling == "importance" and not sb.use_split_sum
+                    and not (ii.use_me and ii.use_me_on_specular) and el.channels in (1, 3) and sl.channels == 1
+                    and el.act_last in LIGHT_ACTS and sl.act_last in LIGHT_ACTS and dirs_all.is_cuda
+                    and not os.environ.get("NDJIR_NO_FUSED_TAIL") and not os.environ.get("NDJIR_NO_FUSED_LIGHTS"))
+    if fused_lights:
+        # the default configuration: both nets hand over their raw outputs; output activations, the two light integrals and
+        # the pixel composition are one launch each way (csrc/render.hip k_direct_light) -- no (B,R,2M,*) slice, activation
+        # or gradient sum exists as a separate launch
+        raw_env = environment_light_network(dirs_all, conf, raw=True)
+        raw_sv = soft_visibility_light_network(x_fg_pixel, dirs_all, feature_pixel, normal_bc, conf, raw=True)
+        color_pixel = direct_light(normal_pixel, view_dir.reshape(B, R, 3), dirs_all, raw_sv, raw_env, pix,
+                                   bg_pixel if bg_pixel is not None else VR(color_bg, N),
+                                   (LIGHT_ACTS[sl.act_last], LIGHT_ACTS[el.act_last]),
+                                   (sl.inverse_black_degree, el.inverse_black_degree, el.upper_bound, conf.renderer.eps_dot, sb.weight),
+                                   conf.diffuse_brdf.entangle)
     else:
-        sBRDF, cos = specular_brdf_model(normal_pixel, view_dir, imp_dir, roughness_pixel, spec_refl_pixel, conf)
-        if sb.use_split_sum:
-            spec_pixel = (soft_vis * env).mean(dim=2) * (sBRDF * cos).mean(dim=2)
+        env_all = environment_light_network(dirs_all, conf)
+        # (per-ray inputs are passed un-broadcast, (B,R,1,*): the net folds them into a per-ray first-layer term)
+        soft_vis_all = soft_visibility_light_network(x_fg_pixel, dirs_all, feature_pixel, normal_bc, conf)
+        env_d, env = env_all[:, :, :M], env_all[:, :, M:]
+        soft_vis_d, soft_vis = soft_vis_all[:, :, :M], soft_vis_all[:, :, M:]
+
+        # Diffuse colour (renderer.py:117-120)
+        # mean_m soft_vis * env * clamp(n.l): one fused launch (csrc/render.hip) instead of dot/clamp/mul/mean
+        env_pixel = diffuse_light(normal_pixel, uniform_light_dir, soft_vis_d, env_d, conf.renderer.eps_dot)
+
+        # Specular colour (renderer.py:141-161)
+        if (sb.model == "filament" and sb.sampling == "importance" and not sb.use_split_sum
+                and not (ii.use_me and ii.use_me_on_specular) and env.shape[-1] in (1, 3) and spec_refl_pixel.shape[-1] == 3):
+            # BRDF algebra and the light integral fused (csrc/render.hip)
+            spec_pixel = specular_light_filament(normal_pixel, view_dir.reshape(B, R, 3), imp_dir, roughness_pixel,
+                                                 spec_refl_pixel, soft_vis, env, conf.renderer.eps_dot, sb.weight)
         else:
-            spec_pixel = (sBRDF * soft_vis * env * cos).mean(dim=2)
-        if ii.use_me and ii.use_me_on_specular:
-            spec_pixel = spec_pixel + (sBRDF * implicit_pixel[:, :, :, None]).mean(dim=2)
-        spec_pixel = sb.weight * spec_pixel
+            sBRDF, cos = specular_brdf_model(normal_pixel, view_dir, imp_dir, roughness_pixel, spec_refl_pixel, conf)
+            if sb.use_split_sum:
+                spec_pixel = (soft_vis * env).mean(dim=2) * (sBRDF * cos).mean(dim=2)
+            else:
+                spec_pixel = (sBRDF * soft_vis * env * cos).mean(dim=2)
+            if ii.use_me and ii.use_me_on_specular:
+                spec_pixel = spec_pixel + (sBRDF * implicit_pixel[:, :, :, None]).mean(dim=2)
+            spec_pixel = sb.weight * spec_pixel
 
     # Diffuse + specular composition (renderer.py:163-176)
-    color_pixel = None
-    if use_head and env_pixel.shape[-1] in (1, 3) and spec_pixel.shape[-1] == 3 and not os.environ.get("NDJIR_NO_FUSED_TAIL"):
+    if color_pixel is not None:
+        pass
+    elif use_head and env_pixel.shape[-1] in (1, 3) and spec_pixel.shape[-1] == 3 and not os.environ.get("NDJIR_NO_FUSED_TAIL"):
         # one launch: diffuse = env + implicit, the entangled / disentangled product, + VR(color_bg)
         color_pixel = pixel_compose(pix, env_pixel, spec_pixel, bg_pixel if bg_pixel is not None else VR(color_bg, N),
                                     conf.diffuse_brdf.entangle)

@@ -304,6 +304,108 @@ def pixel_compose(pix, env, spec, bg, entangle):
     return PixelCompose.apply(pix, env, spec, bg, bool(entangle))
 
 
+class BackgroundHead(Function):
+    """python/network.py:543-556 between the background model's two nets, one launch each way (csrc/render.hip):
+    h (B,R,N,1+F), x (B,R,N,nx) [no grad], delta (B,R,N,1) [no grad] -> alpha (B,R,N,1) = 1 - exp(-softplus_100(h_0) delta) and
+    the lighting net's per-sample input [x | h_1..F] (B,R,N,nx+F)."""
+
+    @staticmethod
+    def forward(ctx, h, x, delta):
+        hc, xc, dc = _c(h), _c(x), _c(delta)
+        F, nx = hc.shape[-1] - 1, xc.shape[-1]
+        P = hc.numel() // (F + 1)
+        alpha = torch.empty(hc.shape[:-1] + (1,), device=hc.device, dtype=torch.float32)
+        inp = torch.empty(hc.shape[:-1] + (nx + F,), device=hc.device, dtype=torch.float32)
+        lib.call("render_background_head", P, nx, F, hc, xc, dc, alpha, inp)
+        ctx.save_for_backward(hc, dc)
+        ctx.cfg = (P, nx, F)
+        return alpha, inp
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_alpha, g_inp):
+        hc, dc = ctx.saved_tensors
+        P, nx, F = ctx.cfg
+        g_h = torch.empty_like(hc)
+        lib.call("render_background_head_backward", P, nx, F, hc, dc, None if g_alpha is None else g_alpha.contiguous(),
+                 None if g_inp is None else g_inp.contiguous(), g_h)
+        return g_h, None, None
+
+
+def background_head(h, x, delta):
+    return BackgroundHead.apply(h, x, delta)
+
+
+class Gain(Function):
+    """clamp(exp(scale p), lo, hi) of the geometric network's scalar gain parameter (python/network.py:229-231): one launch
+    each way instead of mul / exp / clamp and their eight backward launches."""
+
+    @staticmethod
+    def forward(ctx, p, scale, lo, hi):
+        pc = _c(p)
+        out = torch.empty_like(pc)
+        lib.call("render_gain", pc.numel(), pc, scale, lo, hi, out)
+        ctx.save_for_backward(pc)
+        ctx.cfg = (scale, lo, hi)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (pc,) = ctx.saved_tensors
+        gp = torch.empty_like(pc)
+        lib.call("render_gain_backward", pc.numel(), pc, *ctx.cfg, g.contiguous(), gp)
+        return gp, None, None, None
+
+
+def sdf_gain(p, scale=10.0, lo=1e-6, hi=5e4):
+    if p.is_cuda and p.dtype == torch.float32:
+        return Gain.apply(p, float(scale), float(lo), float(hi))
+    return torch.exp(p * scale).clamp(lo, hi)
+
+
+LIGHT_ACTS = {"identity": 0, "softplus": 1, "sigmoid": 2, "relu": 3}
+
+
+class DirectLight(Function):
+    """renderer.py:105-178, default branch, one launch each way (csrc/render.hip k_direct_light): output activations of the
+    environment-light / soft-visibility nets, the diffuse and the filament-specular light integrals and the pixel
+    composition.  normal, view_dir (B,R,3); light_dirs (B,R,2M,3) [diffuse | specular, no grad]; raw_soft_vis (B,R,2M,1),
+    raw_env (B,R,2M,C): the nets' outputs BEFORE `act_last`; pix (B,R,9) = VR of the material head's V; bg (B,R,3) or None
+    -> color_pixel (B,R,3).  cfg = (acts (sv, env), params (beta_sv, beta_env, ub_env, eps_dot, weight), entangle)."""
+
+    @staticmethod
+    def forward(ctx, normal, view_dir, light_dirs, raw_sv, raw_env, pix, bg, cfg):
+        B, R, M2, C = raw_env.shape
+        acts, params, entangle = cfg
+        args = [_c(normal), _c(view_dir), _c(light_dirs), _c(raw_sv), _c(raw_env), _c(pix)]
+        dev = pix.device
+        color = torch.empty((B, R, 3), device=dev, dtype=torch.float32)
+        env_pix = torch.empty((B, R, C), device=dev, dtype=torch.float32)
+        spec_pix = torch.empty((B, R, 3), device=dev, dtype=torch.float32)
+        lib.call("render_direct_light", B * R, M2 // 2, C, acts, params, int(entangle), *args, None if bg is None else _c(bg),
+                 color, env_pix, spec_pix)
+        ctx.save_for_backward(*args, env_pix, spec_pix)
+        ctx.cfg = (B, R, M2 // 2, C, cfg, bg is not None)
+        return color
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        B, R, M, C, (acts, params, entangle), has_bg = ctx.cfg
+        normal, view, dirs, raw_sv, raw_env, pix, env_pix, spec_pix = ctx.saved_tensors
+        gn, gsv, genv, gpix = torch.empty_like(normal), torch.empty_like(raw_sv), torch.empty_like(raw_env), torch.empty_like(pix)
+        gbg = torch.empty((B, R, 3), device=pix.device, dtype=torch.float32) if has_bg and ctx.needs_input_grad[6] else None
+        lib.call("render_direct_light_backward", B * R, M, C, acts, params, int(entangle), normal, view, dirs, raw_sv, raw_env, pix,
+                 env_pix, spec_pix, g.contiguous(), gn, gsv, genv, gpix, gbg)
+        return gn, None, None, gsv, genv, gpix, gbg, None
+
+
+def direct_light(normal, view_dir, light_dirs, raw_soft_vis, raw_env, pix, bg, acts, params, entangle):
+    cfg = (tuple(int(a) for a in acts), tuple(float(p) for p in params), bool(entangle))
+    return DirectLight.apply(normal, view_dir, light_dirs, raw_soft_vis, raw_env, pix, bg, cfg)
+
+
 LOSS_TERM_NAMES = ("loss", "loss_rgb", "loss_eikonal", "loss_tv", "prior_base_color", "prior_roughness", "reg_std_roughness",
                    "prior_specular_reflectance", "reg_std_specular_reflectance")
 

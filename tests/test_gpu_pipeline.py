@@ -66,6 +66,24 @@ def test_ste_fused_path_matches_layer_by_layer(gpu):
             assert rel_err(gp, g) < GRAD_RTOL, (k, rel_err(gp, g))
 
 
+@pytest.mark.parametrize("switch", ["NDJIR_NO_FUSED_LIGHTS", "NDJIR_NO_BACKGROUND_HEAD"])
+def test_fused_ray_operators_equal_their_stock_spelling(gpu, switch, monkeypatch):
+    """volume.direct_light (light nets' output activations + both light integrals + pixel composition) and
+    volume.background_head (+ the lighting net's per-ray row term) against the same step with that stage spelled the
+    reference's way -- slices of the 2 M light tensors / the (B,R,N,287) background concatenation, stock activations."""
+    conf = small_conf(grid_size=16, n_rays=8)
+    fused = run_product_step(conf, B=1, R=8, device=gpu)
+    monkeypatch.setenv(switch, "1")
+    plain = run_product_step(conf, B=1, R=8, device=gpu)
+    assert abs(float(fused["loss"]) - float(plain["loss"])) <= 2e-6 * abs(float(plain["loss"]))
+    assert float((fused["color_pixel"] - plain["color_pixel"]).abs().max()) <= 2e-6
+    for k, g in plain["grads"].items():
+        gp = fused["grads"][k]
+        assert (g is None) == (gp is None), k
+        if g is not None:
+            assert rel_err(gp, g) < 2e-4, (k, rel_err(gp, g))
+
+
 @pytest.mark.parametrize("fused_tail", [True, False])
 def test_prior_normaliser_without_eikonal_term(gpu, fused_tail, monkeypatch):
     """python/loss.py:36, 72, 118: with train.eikonal_weight = 0 the priors are divided by sum(mask) n_samples0, not by

@@ -279,6 +279,112 @@ def test_pixel_compose_matches_composite(gpu, entangle, Ce):
         assert float((a.cpu().double() - b).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("B,R,M,C,acts,ub,entangle,with_bg", [
+    (1, 40, 128, 1, ("sigmoid", "softplus"), -1.0, True, True),          # the default configuration
+    (2, 7, 32, 3, ("sigmoid", "softplus"), 0.8, False, True),            # RGB light with an upper bound, disentangled
+    (1, 5, 200, 1, ("softplus", "relu"), -1.0, True, False),
+    (1, 9, 16, 3, ("relu", "sigmoid"), 0.6, True, True)])
+def test_direct_light_matches_the_separate_operators(gpu, B, R, M, C, acts, ub, entangle, with_bg):
+    """volume.direct_light (output activations of both light nets + diffuse integral + filament specular integral + pixel
+    composition, one launch each way) against the fp64 stock-op composite of python/network.py:288-296, 372-376 and
+    python/renderer.py:117-178 -- value and the gradient of every differentiable input, incl. the roughness / specular
+    columns of pix and the upper-bound clamp."""
+    from types import SimpleNamespace as NS
+    import torch.nn.functional as TF
+    from ndjir_amd.specular_brdf import dot, filament_specular_brdf
+    from ndjir_amd.volume import LIGHT_ACTS, direct_light
+    rng = np.random.RandomState(M + C)
+    normal, view, l_d, _, _, _, _ = _light_inputs(B, R, M, C, 21 + M, gpu)
+    _, _, l_s, _, _, _, _ = _light_inputs(B, R, M, C, 22 + M, gpu)
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64, device=gpu)
+    raw_sv, raw_env = t64(rng.randn(B, R, 2 * M, 1) * 2), t64(rng.randn(B, R, 2 * M, C) * 1.5)
+    pix = t64(rng.rand(B, R, 9))
+    pix[..., 1] = pix[..., 1] * 0.9 + 0.05
+    pix[..., 2:5] *= 0.16
+    bg = t64(rng.rand(B, R, 3)) if with_bg else None
+    betas = (1.7, 0.6)
+    eps, weight = 1e-8, 0.7
+    conf = NS(renderer=NS(eps_dot=eps), specular_brdf=NS(sampling="importance"))
+    act = {"softplus": lambda v, b: TF.softplus(v, beta=b), "sigmoid": lambda v, b: torch.sigmoid(v), "relu": lambda v, b: torch.relu(v)}
+    dirs = torch.cat([l_d, l_s], dim=2)
+
+    def composite(n, rsv, renv, px, bgv):
+        sv = act[acts[0]](rsv, betas[0])
+        env = act[acts[1]](renv, betas[1])
+        if ub > 0:
+            env = env.clamp(0.0, ub)
+        env_pixel = (sv[:, :, :M] * env[:, :, :M] * dot(n[:, :, None, :].expand(B, R, M, 3), l_d.to(n.dtype), False, eps)).mean(dim=2)
+        sB, cos = filament_specular_brdf(n, view.to(n.dtype).reshape(B, R, 1, 3), l_s.to(n.dtype), px[..., 1:2], px[..., 2:5], conf)
+        spec = weight * (sB * sv[:, :, M:] * env[:, :, M:] * cos).mean(dim=2)
+        imp, photo, base = px[..., 0:1], px[..., 5:6], px[..., 6:9]
+        diff = env_pixel + imp
+        fg = base * diff + photo * spec if entangle else photo * (base * diff + spec)
+        return fg + bgv if bgv is not None else fg
+
+    ins64 = [normal, raw_sv, raw_env, pix] + ([bg] if with_bg else [])
+    a64 = [t.clone().requires_grad_(True) for t in ins64]
+    ref = composite(*a64, *(() if with_bg else (None,)))
+    a32 = [t.detach().float().requires_grad_(True) for t in ins64]
+    out = direct_light(a32[0], view.float(), dirs.float(), a32[1], a32[2], a32[3], a32[4] if with_bg else None,
+                       (LIGHT_ACTS[acts[0]], LIGHT_ACTS[acts[1]]), (betas[0], betas[1], ub, eps, weight), entangle)
+    s32 = [t.detach().float().requires_grad_(True) for t in ins64]
+    stock = composite(*s32, *(() if with_bg else (None,)))
+    scale = max(1.0, float(ref.abs().max()))
+    err, err_stock = float((out.detach().double() - ref.detach()).abs().max()), float((stock.detach().double() - ref.detach()).abs().max())
+    assert err < max(4.0 * err_stock, 2e-6 * scale), (err, err_stock)
+    g = t64(np.random.RandomState(2).randn(B, R, 3))
+    gref = torch.autograd.grad(ref, a64, g)
+    gout = torch.autograd.grad(out, a32, g.float())
+    gstock = torch.autograd.grad(stock, s32, g.float())
+    for name, go, gr, gs in zip(("normal", "raw_soft_vis", "raw_env", "pix", "bg"), gout, gref, gstock):
+        sc = max(float(gr.abs().max()), 1e-6)
+        e1, e2 = float((go.double() - gr).abs().max()) / sc, float((gs.double() - gr).abs().max()) / sc
+        assert e1 < max(4.0 * e2, 2e-5), (name, e1, e2)
+
+
+def test_gain_matches_composite(gpu):
+    """python/network.py:229-231: clip(exp(10 p), 1e-6, 5e4), value and gradient incl. both saturated ends."""
+    from ndjir_amd.volume import sdf_gain
+    for v in (0.3, -2.0, 1.2, -1.38, 1.08):                     # inside, below lo, above hi, just inside either bound
+        p64 = torch.tensor([v], dtype=torch.float64, device=gpu, requires_grad=True)
+        ref = torch.exp(p64 * 10).clamp(1e-6, 5e4)
+        (gref,) = torch.autograd.grad(ref, p64, torch.tensor([0.7], dtype=torch.float64, device=gpu))
+        p32 = torch.tensor([v], dtype=torch.float32, device=gpu, requires_grad=True)
+        out = sdf_gain(p32)
+        (gout,) = torch.autograd.grad(out, p32, torch.tensor([0.7], device=gpu))
+        stock = torch.exp(p32.detach() * 10).clamp(1e-6, 5e4)
+        assert float((out.detach() - stock).abs().max()) <= 2e-6 * float(stock), v
+        assert float((gout.double() - gref).abs().max()) <= 1e-5 * max(float(gref.abs().max()), 1e-12), v
+
+
+@pytest.mark.parametrize("B,R,N,nx,F", [(1, 37, 32, 4, 256), (2, 5, 7, 3, 17)])
+def test_background_head_matches_composite(gpu, B, R, N, nx, F):
+    """volume.background_head vs python/network.py:543-556 spelled with stock ops (fp64 autograd)."""
+    import torch.nn.functional as TF
+    from ndjir_amd.volume import background_head
+    rng = np.random.RandomState(N)
+    h = torch.tensor(rng.randn(B, R, N, 1 + F) * 0.05, dtype=torch.float64, device=gpu)
+    h[0, 0, 0, 0] = 0.5                                          # beta h > 20: softplus' linear branch
+    x = torch.tensor(rng.randn(B, R, N, nx), dtype=torch.float64, device=gpu)
+    delta = torch.tensor(rng.rand(B, R, N, 1) * 3, dtype=torch.float64, device=gpu)
+    h64 = h.clone().requires_grad_(True)
+    density, feature = TF.softplus(h64[..., 0:1], beta=100), h64[..., 1:]
+    alpha_ref = 1 - torch.exp(-density * delta)
+    inp_ref = torch.cat([x, feature], dim=-1)
+    ga = torch.tensor(rng.randn(*alpha_ref.shape), dtype=torch.float64, device=gpu)
+    gi = torch.tensor(rng.randn(*inp_ref.shape), dtype=torch.float64, device=gpu)
+    (gref,) = torch.autograd.grad([alpha_ref, inp_ref], h64, [ga, gi])
+    h32 = h.float().requires_grad_(True)
+    alpha, inp = background_head(h32, x.float(), delta.float())
+    assert torch.equal(inp, inp_ref.detach().float())
+    assert float((alpha.detach().double() - alpha_ref.detach()).abs().max()) < 2e-6
+    (gout,) = torch.autograd.grad([alpha, inp], h32, [ga.float(), gi.float()], retain_graph=True)
+    assert float((gout.double() - gref).abs().max()) < 2e-5 * float(gref.abs().max())
+    # either gradient alone
+    (g1,) = torch.autograd.grad(alpha, h32, ga.float())
+    assert float(g1[..., 1:].abs().max()) == 0.0 and torch.allclose(g1[..., 0], gout[..., 0])
+
+
 @pytest.mark.parametrize("l2", [False, True])
 @pytest.mark.parametrize("n_tv,shards", [(0, 1), (1, 1), (2, 4)])
 def test_loss_terms_match_composite(gpu, l2, n_tv, shards):
