@@ -19,6 +19,7 @@
 // Launched for P % 128 == 0, P >= 32768, hidden layers of at most 8 column blocks; everything else stays with mlp3.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -31,8 +32,6 @@ namespace x3w {
 
 using namespace x3u;
 
-constexpr int NWAVES = 8;
-constexpr int NTHREADS = NWAVES * 64;
 constexpr int TM = 128;
 constexpr int TMP = TM + 4;      // rows per k-group incl. pad: (TMP * 16) % 256 == 64 -> conflict-free plane writes
 constexpr int IN_CACHE = 10;     // float4 groups of the chain input a thread keeps between the max pass and the split
@@ -43,8 +42,11 @@ __device__ __forceinline__ int acc_feat(int i, int hh) { return (i & 3) + 8 * (i
 
 // RPW: row blocks per wave -- 4 (hidden layers of up to 8 column blocks: one wave per column block) or 2 (up to 4 column
 // blocks: two waves per column block).  One k-loop instantiation per kernel: the register allocator sees one hot loop.
-template <int MODE, int RPW>
-__global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
+// NWAVES: 8 (one workgroup per CU) or 4 (RPW = 4, hidden layers of up to 4 column blocks: TWO workgroups per CU, one wave
+// of each per SIMD -- the epilogue of one runs beside the k-loop of the other).
+template <int MODE, int RPW, int NWAVES>
+__global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
+  constexpr int NTHREADS = NWAVES * 64;
   constexpr bool BWD = (MODE == 1);
   constexpr int G = 4 / RPW;           // wave groups sharing a column block's rows
   constexpr int CB = NWAVES / G;       // column blocks per round
@@ -64,10 +66,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
   float* bsum = lds + a.bg_lds;
   const float beta = a.beta;
   auto stamp = [&](int li, int phase) {
-    if (a.timeline && blockIdx.x == 0 && lane == 0) a.timeline[(li * 5 + phase) * NWAVES + wave] = (long long)__builtin_amdgcn_s_memtime();
+    if (a.timeline && blockIdx.x == 0 && lane == 0) a.timeline[(li * 5 + phase) * 8 + wave] = (long long)__builtin_amdgcn_s_memtime();
   };
   auto stamp_rt = [&](int phase) {
-    if (a.timeline && blockIdx.x == 0 && lane == 0) a.timeline[((MAX_CHAIN_LAYERS - 2) * 5 + phase) * NWAVES + wave] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (a.timeline && blockIdx.x == 0 && lane == 0) a.timeline[((MAX_CHAIN_LAYERS - 2) * 5 + phase) * 8 + wave] = (long long)__builtin_amdgcn_s_memrealtime();
   };
   // write 4 consecutive features k..k+3 (k % 4 == 0) of row m, scaled by s, into the two planes
   auto put4 = [&](int k, int m, f32x4 v, float s) {
@@ -433,9 +435,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
           }
           f32x4 hs[2][4], ex[2][4];                         // backward / tangent: side loads, one block ahead
           // side loads of block J (backward: stored activation + extra adjoint; tangent: stored activation + s)
-          auto side_loads = [&](auto jt, auto ft) {
+          auto side_loads = [&](auto jt, auto ft, auto et) {
             constexpr int J = decltype(jt)::value;
             constexpr bool FULL = decltype(ft)::value;
+            constexpr bool HAS_EX = decltype(et)::value;
             const unsigned rowoff = (unsigned)((rb0 + J) * 32 + r_o) * (unsigned)l_ld + (unsigned)fb;
             const gptr<const float> b_in = p_side_in + tile_off;
 #pragma unroll
@@ -446,7 +449,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
                 for (int q = 0; q < 4; ++q) hs[J & 1][g][q] = fb + 8 * g + q < nlim ? b_in[rowoff + 8 * g + q] : 0.f;
               }
             }
-            if (p_side_ex) {
+            if (HAS_EX) {
               const gptr<const float> b_ex = p_side_ex + tile_off;
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
@@ -456,14 +459,31 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
                   for (int q = 0; q < 4; ++q) ex[J & 1][g][q] = fb + 8 * g + q < nlim ? b_ex[rowoff + 8 * g + q] : 0.f;
                 }
               }
-            } else {
-#pragma unroll
-              for (int g = 0; g < 4; ++g) ex[J & 1][g] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
           };
-          auto hidden_block = [&](auto jt, auto ft) {
+          // activations (forward) / deltas (backward, tangent) of block J -> side_out.  The values stay in acc0 until phase B,
+          // so the backward issues these stores AFTER the last block's side loads: loads and stores share one in-order
+          // counter (vmcnt), and a block's loads queued behind its predecessor's stores cost 24 k instead of 10 k cycles per layer
+          auto side_store = [&](auto jt, auto ft) {
             constexpr int J = decltype(jt)::value;
             constexpr bool FULL = decltype(ft)::value;
+            if (!p_side_out) return;
+            const unsigned rowoff = (unsigned)((rb0 + J) * 32 + r_o) * (unsigned)l_ld + (unsigned)fb;
+            const gptr<float> b_out = p_side_out + tile_off;
+            const int lim = MODE == 0 ? l_N : nlim;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              if (FULL) *((gptr<f32x4>)(b_out + (rowoff + 8 * g))) = f32x4{acc0[J][4 * g], acc0[J][4 * g + 1], acc0[J][4 * g + 2], acc0[J][4 * g + 3]};
+              else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < lim) b_out[rowoff + 8 * g + q] = acc0[J][4 * g + q];
+              }
+            }
+          };
+          auto hidden_block = [&](auto jt, auto ft, auto et) {
+            constexpr int J = decltype(jt)::value;
+            constexpr bool FULL = decltype(ft)::value;
+            constexpr bool HAS_EX = decltype(et)::value;      // backward: an extra adjoint is added (tangent: always has s)
             const int R = (rb0 + J) * 32 + r_o;             // row of the tile
             const float sa = s_ainv[R];
             const unsigned rowoff = (unsigned)R * (unsigned)l_ld + (unsigned)fb;
@@ -502,7 +522,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
                   const float e = __builtin_amdgcn_exp2f(nb2 * hs[J & 1][g][q]);
                   const float sp = (1.f - e) * sc;
                   float v;
-                  if (MODE == 1) v = zz * sp + ex[J & 1][g][q];
+                  if (MODE == 1) v = HAS_EX ? zz * sp + ex[J & 1][g][q] : zz * sp;
                   else { v = zz * sp; x2[q] = beta * zz * ex[J & 1][g][q] * e; }
                   if (!FULL) {
                     const int f = fb + 8 * g + q;
@@ -522,18 +542,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
                 }
               }
             }
-            if (p_side_out) {
-              const gptr<float> b_out = p_side_out + tile_off;
-              const int lim = MODE == 0 ? l_N : nlim;
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                if (FULL) *((gptr<f32x4>)(b_out + (rowoff + 8 * g))) = f32x4{acc0[J][4 * g], acc0[J][4 * g + 1], acc0[J][4 * g + 2], acc0[J][4 * g + 3]};
-                else {
-#pragma unroll
-                  for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < lim) b_out[rowoff + 8 * g + q] = acc0[J][4 * g + q];
-                }
-              }
-            }
+            // (backward / tangent: the block's side stores wait until every block's side loads have been consumed, see `run`)
+            if (MODE != 1) side_store(jt, ft);
             // row maximum of the block's 16 values of this point: v_max ignores NaN; a value set holding an Inf (or only
             // NaN) goes through the bit-pattern filter.  One LDS atomic per lane (the two half-waves of a row: 2-way).
             float m = 0.f;
@@ -547,19 +557,31 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chainw(ChainArgs a) {
             }
             atomicMax(&s_rmax[cur][R], __float_as_uint(m));
           };
-          auto run = [&](auto ft) {
-            if (MODE != 0) side_loads(I0{}, ft);
-            if (MODE != 0) side_loads(I1{}, ft);
-            hidden_block(I0{}, ft);
-            if constexpr (RPW > 2) { if (MODE != 0) side_loads(I2{}, ft); }
-            hidden_block(I1{}, ft);
+          auto run = [&](auto ft, auto et) {
+            if (MODE != 0) side_loads(I0{}, ft, et);
+            if (MODE != 0) side_loads(I1{}, ft, et);
+            hidden_block(I0{}, ft, et);
+            if constexpr (RPW > 2) { if (MODE != 0) side_loads(I2{}, ft, et); }
+            hidden_block(I1{}, ft, et);
             if constexpr (RPW > 2) {
-              if (MODE != 0) side_loads(I3{}, ft);
-              hidden_block(I2{}, ft);
-              hidden_block(I3{}, ft);
+              if (MODE != 0) side_loads(I3{}, ft, et);
+              hidden_block(I2{}, ft, et);
+              hidden_block(I3{}, ft, et);
+            }
+            if (MODE == 1) {
+              side_store(I0{}, ft);
+              side_store(I1{}, ft);
+              if constexpr (RPW > 2) { side_store(I2{}, ft); side_store(I3{}, ft); }
             }
           };
-          if (full) run(TT{}); else run(FF{});
+          if constexpr (MODE == 1) {
+            if (p_side_ex) { if (full) run(TT{}, TT{}); else run(FF{}, TT{}); }
+            else { if (full) run(TT{}, FF{}); else run(FF{}, FF{}); }
+          } else if constexpr (MODE == 2) {
+            if (full) run(TT{}, TT{}); else run(FF{}, TT{});
+          } else {
+            if (full) run(TT{}, FF{}); else run(FF{}, FF{});
+          }
           // bias gradient: column sums of the deltas over the wave's points (its blocks first: they share the features) --
           // 16-lane rows by DPP (xor 1, xor 2, half mirror, mirror), then one LDS atomic per feature from the first lane of
           // every row
@@ -661,7 +683,7 @@ int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) {
   int wmax = round_up(a.K0, 16), hmax = 0;
   for (int i = 0; i < a.L; ++i) {
     const bool last = a.has_output && i == a.L - 1;
-    if (!last && (a.layers[i].Np > NWAVES * 32 || a.layers[i].Np < 64)) return NDJIR_ERR_UNSUPPORTED;
+    if (!last && (a.layers[i].Np > 8 * 32 || a.layers[i].Np < 64)) return NDJIR_ERR_UNSUPPORTED;
     if (!last && a.layers[i].Np > wmax) wmax = a.layers[i].Np;
     if (!last && a.layers[i].Np > hmax) hmax = a.layers[i].Np;
   }
@@ -700,15 +722,22 @@ int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) {
   if (blocks > 256LL * 8) blocks = 256LL * 8;
   if (bg_total > 0 && blocks > CHAIN_MAX_GRID_BG) blocks = CHAIN_MAX_GRID_BG;
   static bool attr_set = false;
+  static int nw4 = 1;
   if (!attr_set) {
-#define NDJIR_SET(M, R) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw<M, R>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX)
-    NDJIR_SET(0, 4); NDJIR_SET(1, 4); NDJIR_SET(2, 4); NDJIR_SET(0, 2); NDJIR_SET(1, 2); NDJIR_SET(2, 2);
+#define NDJIR_SET(M, R, W) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw<M, R, W>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX)
+    NDJIR_SET(0, 4, 8); NDJIR_SET(1, 4, 8); NDJIR_SET(2, 4, 8); NDJIR_SET(0, 2, 8); NDJIR_SET(1, 2, 8); NDJIR_SET(2, 2, 8);
+    NDJIR_SET(0, 4, 4); NDJIR_SET(1, 4, 4); NDJIR_SET(2, 4, 4);
 #undef NDJIR_SET
+    // 4-wave workgroups (two per CU) for nets of up to 4 column blocks whose planes fit twice: bit 0 forward, bit 1 backward,
+    // bit 2 tangent.  Measured (env-light / soft-visibility nets, 131072 points): forward 145 -> 133 us, backward 166 -> 173 us
+    const char* e = getenv("NDJIR_CHAINW_NW4");
+    nw4 = e ? atoi(e) : 1;
     attr_set = true;
   }
-#define NDJIR_GO(M, R) hipLaunchKernelGGL((k_chainw<M, R>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b)
-  if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4); else if (mode == 1) NDJIR_GO(1, 4); else NDJIR_GO(2, 4); }
-  else { if (mode == 0) NDJIR_GO(0, 2); else if (mode == 1) NDJIR_GO(1, 2); else NDJIR_GO(2, 2); }
+#define NDJIR_GO(M, R, W) hipLaunchKernelGGL((k_chainw<M, R, W>), dim3((unsigned)blocks), dim3(W * 64), lds_bytes, stream, b)
+  if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4, 8); else if (mode == 1) NDJIR_GO(1, 4, 8); else NDJIR_GO(2, 4, 8); }
+  else if (((nw4 >> mode) & 1) && lds_bytes <= 78 * 1024) { if (mode == 0) NDJIR_GO(0, 4, 4); else if (mode == 1) NDJIR_GO(1, 4, 4); else NDJIR_GO(2, 4, 4); }
+  else { if (mode == 0) NDJIR_GO(0, 2, 8); else if (mode == 1) NDJIR_GO(1, 2, 8); else NDJIR_GO(2, 2, 8); }
 #undef NDJIR_GO
   int rc = ndjir_check_launch();
   if (rc != NDJIR_OK) return rc;
