@@ -44,6 +44,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 # f16x3 engine: as 3 f16 MFMA FLOPs (scaled two-way split) -- f16 and bf16 MFMA run at the same rate
 PEAK_BF16X6_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_F16X3_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PROFILE_ROUND = "r03"
 
 
@@ -252,10 +253,13 @@ def train_leg(step, steps, barrier, use_graph):
     return out
 
 
-def committed_pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/<round>_pmc_hbm_bench.txt: FETCH_SIZE and WRITE_SIZE in KB per launch, collected in separate runs as
-    MI355X_MICROARCH.md prescribes; FETCH doubled per its gfx950 note).  Not a live measurement: None if the file is absent."""
+def committed_pmc_traffic(kernels):
+    """HBM bytes per launch of the kernel class made of the symbols `kernels` (launch-weighted mean) from the committed
+    rocprofv3 PMC passes of this same command (profiles/<round>_pmc_hbm_bench.txt: FETCH_SIZE and WRITE_SIZE in KB per launch,
+    collected in separate runs as MI355X_MICROARCH.md prescribes; FETCH doubled per its gfx950 note -- calibrated here on
+    ndjir::k_adam, whose 6.44 GB of reads per launch show as 3.17 GB).  Not a live measurement: None if the file is absent."""
+    if isinstance(kernels, str):
+        kernels = [kernels]
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{PROFILE_ROUND}_pmc_hbm_bench.txt")
     try:
         vals, section = {}, None
@@ -263,27 +267,36 @@ def committed_pmc_traffic(kernel):
         for i, line in enumerate(lines):
             if line.startswith("## "):
                 section = line[3:].strip()
-            elif section and line.startswith(kernel + "  launches=") and i + 1 < len(lines):
-                vals[section] = float(lines[i + 1].split()[-1])
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-            return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+                continue
+            for k in kernels:
+                if section and line.startswith(k + "  launches=") and i + 1 < len(lines):
+                    n = int(line.split("launches=")[1].split()[0])
+                    vals.setdefault(k, {})[section] = (n, float(lines[i + 1].split()[-1]))
+        tot, cnt = 0.0, 0
+        for k, v in vals.items():
+            if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                n = v["FETCH_SIZE"][0]
+                tot += n * (2.0 * v["FETCH_SIZE"][1] + v["WRITE_SIZE"][1]) * 1024.0
+                cnt += n
+        return tot / cnt if cnt else None
     except Exception:
-        pass
-    return None
+        return None
 
 
 def kernel_report(profile):
     """Aggregate the live HIP-event records of the MLP engine (ndjir_amd.mlp.PROFILE)."""
     agg = {}
-    for kind, flops, e0, e1, _shape in profile:
-        a = agg.setdefault(kind, [0, 0.0, 0.0])
+    for kind, flops, e0, e1, _shape, nbytes in profile:
+        a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
         a[2] += e0.elapsed_time(e1) * 1e-3
+        a[3] += nbytes
     rep = {}
-    for kind, (n, flops, sec) in agg.items():
+    for kind, (n, flops, sec, nbytes) in agg.items():
         rep[kind] = dict(launches=n, avg_us=1e6 * sec / max(n, 1), tflops=flops / max(sec, 1e-12) / 1e12,
-                         gflop_per_launch=flops / max(n, 1) / 1e9)
+                         gflop_per_launch=flops / max(n, 1) / 1e9, mbytes_per_launch=nbytes / max(n, 1) / 1e6,
+                         tbps=nbytes / max(sec, 1e-12) / 1e12)
     return rep
 
 
@@ -297,7 +310,9 @@ def kernel_table(kr, steps, peak):
                       ms_per_step=round(v["launches"] * v["avg_us"] / max(steps, 1) / 1e3, 4),
                       gflop_per_launch=round(v["gflop_per_launch"], 3), tflops=round(v["tflops"], 2),
                       frac_of_executed_mix_peak=round(v["tflops"] / peak, 4),
-                      frac_of_fp32_mfma_peak=round(v["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4))
+                      frac_of_fp32_mfma_peak=round(v["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                      mbytes_per_launch=round(v["mbytes_per_launch"], 2), hbm_tbps=round(v["tbps"], 3),
+                      frac_of_hbm_peak=round(v["tbps"] * 1e3 / PEAK_HBM_GBPS, 4))
     return out
 
 
@@ -324,15 +339,16 @@ def kernel_symbol(kind, math):
 def kernel_detail(profile, steps):
     """Per (kind, shape) table of the engine's launches -> stderr (NDJIR_BENCH_DETAIL=1)."""
     agg = {}
-    for kind, flops, e0, e1, shape in profile:
-        a = agg.setdefault((kind, shape), [0, 0.0, 0.0])
+    for kind, flops, e0, e1, shape, nbytes in profile:
+        a = agg.setdefault((kind, shape), [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
         a[2] += e0.elapsed_time(e1) * 1e-3
-    print(f"{'kind':10s} {'shape':48s} {'n/step':>6s} {'avg us':>8s} {'ms/step':>8s} {'TFLOP/s':>8s}", file=sys.stderr)
-    for (kind, shape), (n, flops, sec) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+        a[3] += nbytes
+    print(f"{'kind':10s} {'shape':48s} {'n/step':>6s} {'avg us':>8s} {'ms/step':>8s} {'TFLOP/s':>8s} {'MB':>8s} {'TB/s':>6s}", file=sys.stderr)
+    for (kind, shape), (n, flops, sec, nbytes) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
         print(f"{kind:10s} {shape:48s} {n / steps:6.1f} {1e6 * sec / n:8.1f} {1e3 * sec / steps:8.3f} "
-              f"{flops / max(sec, 1e-12) / 1e12:8.1f}", file=sys.stderr)
+              f"{flops / max(sec, 1e-12) / 1e12:8.1f} {nbytes / n / 1e6:8.1f} {nbytes / max(sec, 1e-12) / 1e12:6.2f}", file=sys.stderr)
 
 
 def main():
@@ -488,13 +504,28 @@ def main():
         table = kernel_table(kr, profile_steps, peak)
         cands = [k for k in ("chain_fwd", "chain_bwd", "chain_tan", "wgrad") if k in table]
         dom_kind = max(cands, key=lambda k: table[k]["ms_per_step"]) if cands else "chain_fwd"
-        dom = kr.get(dom_kind, dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0))
+        dom = kr.get(dom_kind, dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0, tbps=0.0, mbytes_per_launch=0.0))
         ksym, kname = kernel_symbol(dom_kind, math)
         peak_note = ("dense 16-bit MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 3 partial products per algorithmic FLOP" if x3 else
                      "dense bf16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 6 partial products per algorithmic FLOP" if x6 else
                      "fp32-input MFMA peak (MI355X_MICROARCH.md)")
         dtype = ("f32 (f16x2-split MFMA products, f32 accumulate; error vs fp64 below an fp32 FMA chain's)" if x3 else
                  "f32 (bf16x3-split MFMA products, f32 accumulate)" if x6 else "f32")
+        # Two yardsticks for that kernel: the matrix pipe (algorithmic FLOPs against the executed mix's peak) and HBM (the
+        # (P, width) fp32 tensors the launch must read / write once -- stored activations, deltas, input, output -- against
+        # 8 TB/s).  The block's top-level numbers are those of the limit the kernel is closer to.
+        roof_mfma = {"achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
+                     "algorithmic_gflop_per_launch": dom["gflop_per_launch"]}
+        roof_hbm = {"achieved": dom.get("tbps", 0.0) * 1e3, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": dom.get("tbps", 0.0) * 1e3 / PEAK_HBM_GBPS,
+                    "algorithmic_mbytes_per_launch": dom.get("mbytes_per_launch", 0.0),
+                    "note": "algorithmic bytes = every (points, width) fp32 tensor of the launch counted once (ndjir_amd/mlp.py "
+                            "_launch_bytes): chain input, output, per hidden layer the stored activation it reads and the delta / "
+                            "activation it writes; packed weights (L2-resident) not counted"}
+        hbm_bound = roof_hbm["frac"] >= roof_mfma["frac"]
+        roof_top = ({"bound": "hbm", "achieved": roof_hbm["achieved"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": roof_hbm["frac"]}
+                    if hbm_bound else
+                    {"bound": "mfma", "achieved": roof_mfma["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": roof_mfma["frac"]})
         out = {
             "metric": "rays/sec (fwd+bwd) at 512 rays x 128 samples",
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -506,13 +537,14 @@ def main():
                                    f"total_loss fwd+bwd to all parameter gradients",
                        "rays_per_gpu": R, "samples_per_ray": N, "parallelism": f"ray-sharded x{world}",
                        **({"total_rays": a.total_rays} if a.scaling == "strong" else {})},
-            "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": dom["tflops"] / peak,
-                         "traffic": committed_pmc_traffic(ksym),
+            "roofline": {**roof_top,
+                         "traffic": committed_pmc_traffic([ksym, ksym.replace(", 4>", ", 2>")]),
                          "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes "
-                                         f"of this command, profiles/{PROFILE_ROUND}_pmc_hbm_bench.txt -- the stored activations the "
-                                         "chain reads (backward / tangent) and the activations / deltas it writes for the weight "
-                                         "gradients; the kernel's algorithmic measure is FLOPs",
+                                         f"of this command, profiles/{PROFILE_ROUND}_pmc_hbm_bench.txt (launch-weighted over the class's two "
+                                         "instantiations <mode, 4> and <mode, 2>), beside `hbm.algorithmic_mbytes_per_launch`"
+                                         ": the stored activations the chain reads (backward / tangent) and the activations / "
+                                         "deltas it writes for the weight gradients",
+                         "mfma": roof_mfma, "hbm": roof_hbm,
                          "kernel": kname, "peak_note": peak_note,
                          # the same algorithmic fp32 FLOP/s against the fp32-input MFMA peak (what an fp32 GEMM engine could
                          # reach at best on this chip) and against the bf16x6 engine's effective peak (round 1's yardstick)

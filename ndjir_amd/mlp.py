@@ -54,7 +54,7 @@ def _init_math():
         set_math({"fp32": MATH_FP32, "bf16x6": MATH_BF16X6, "f16x3": MATH_F16X3}[env.lower()])
 
 # Optional live timing of the engine's launches with HIP events on the launching stream
-# (bench.py sets PROFILE = [] around its timed region): entries (kind, algorithmic_flops, e0, e1, shape).
+# (bench.py sets PROFILE = [] around its timed region): entries (kind, algorithmic_flops, e0, e1, shape, algorithmic_bytes).
 PROFILE = None
 
 
@@ -69,7 +69,30 @@ def _launch(kind, flops, name, *args, shape=""):
     e0.record()
     lib.call(name, *args)
     e1.record()
-    PROFILE.append((kind, flops, e0, e1, shape))
+    PROFILE.append((kind, flops, e0, e1, shape, _launch_bytes(name, args)))
+
+
+def _launch_bytes(name, args):
+    """Algorithmic HBM bytes of a launch (profiling only): every (P, width) fp32 tensor the launch has to read or write once
+    -- chain input, output (twice when accumulated into), stored activations / deltas / adjoints of the hidden layers --;
+    the packed weights (L2-resident, < 1 MB per net) are not counted.  wgrad: both operands + the gradient."""
+    if name in ("mlp_chain", "mlp_chain_ex"):
+        P, K0, L = int(args[1]), int(args[4]), int(args[5])
+        Ns, ld = args[9], args[12]
+        n = P * K0
+        lists = [args[10], args[11]] + ([args[24], args[25], args[26]] if name == "mlp_chain_ex" else [])
+        for lst in lists:
+            if lst is not None:
+                n += sum(P * int(ld[j]) for j, t in enumerate(lst) if t is not None)
+        if args[14] is not None and int(args[17]):
+            n += P * int(Ns[L - 1]) * (2 if int(args[16]) & 1 else 1)
+        return 4.0 * n
+    if name == "mlp_wgrad":
+        K, N, P = int(args[4]), int(args[5]), int(args[6])
+        return 4.0 * (P * (K + N) + K * N * (2 if int(args[8]) else 1))
+    if name == "mlp_colsum":
+        return 4.0 * int(args[2]) * int(args[3])
+    return 0.0
 
 
 _MATH_READY = False
