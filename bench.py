@@ -327,9 +327,9 @@ def kernel_symbol(kind, math):
         if kind.endswith("_t32") or os.environ.get("NDJIR_MLP_TILE") in ("32", "64"):
             t = os.environ.get("NDJIR_MLP_TILE", "32")
             return f"ndjir::x3::k_chain3<{mode}, {t}>", f"fused MLP {what} chain, {t}-point tiles (csrc/mlp3.hip)"
-        return (f"ndjir::x3w::k_chainw<{mode}, 4>",
+        return (f"ndjir::x3w::k_chainw<{mode}, 4, 8>",
                 f"fused MLP {what} chain on 128-point tiles, epilogue in the accumulator registers (csrc/mlp3w.hip; the 128-wide "
-                f"nets run the <{mode}, 2> instantiation): fp32 operands scaled by powers of two and split into 2 f16 planes, 3 "
+                f"nets run the <{mode}, 2, 8> instantiation, the forward of the two light nets <0, 4, 4>): fp32 operands scaled by powers of two and split into 2 f16 planes, 3 "
                 "v_mfma_f32_32x32x16_f16 partial products per fp32 product in two fp32 accumulators")
     if math == mlp.MATH_BF16X6:
         return f"ndjir::x6::k_chain6<{mode}, 64>", f"fused MLP {what} chain; 3 bf16 planes, 6 partial products per fp32 product"
@@ -538,10 +538,10 @@ def main():
                        "rays_per_gpu": R, "samples_per_ray": N, "parallelism": f"ray-sharded x{world}",
                        **({"total_rays": a.total_rays} if a.scaling == "strong" else {})},
             "roofline": {**roof_top,
-                         "traffic": committed_pmc_traffic([ksym, ksym.replace(", 4>", ", 2>")]),
+                         "traffic": committed_pmc_traffic([ksym, ksym.replace(", 4, 8>", ", 2, 8>"), ksym.replace(", 4, 8>", ", 4, 4>")]),
                          "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes "
                                          f"of this command, profiles/{PROFILE_ROUND}_pmc_hbm_bench.txt (launch-weighted over the class's two "
-                                         "instantiations <mode, 4> and <mode, 2>), beside `hbm.algorithmic_mbytes_per_launch`"
+                                         "instantiations <mode, 4, 8>, <mode, 2, 8> (and <0, 4, 4>)), beside `hbm.algorithmic_mbytes_per_launch`"
                                          ": the stored activations the chain reads (backward / tangent) and the activations / "
                                          "deltas it writes for the weight gradients",
                          "mfma": roof_mfma, "hbm": roof_hbm,

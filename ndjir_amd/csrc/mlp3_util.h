@@ -71,6 +71,30 @@ __device__ __forceinline__ float dpp(float v) {
 }
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128;
 
+// 4 x 4 transpose inside every quad of lanes: v[g] (g = 0..3, a 16-byte chunk) of lane j (= lane & 3) becomes the old v[j] of lane g.
+// Two butterfly stages (lanes j ^ 1 with chunk pairs (0,1) (2,3); lanes j ^ 2 with (0,2) (1,3)), one DPP move and two selects per
+// dword and stage.  An involution.  mlp3w.hip hands its accumulator blocks to memory through it: before, a lane holds four chunks
+// of ONE point (every load / store instruction touches 32 rows x 32 bytes); after, chunk j of four consecutive points, so that the
+// eight lanes of a point's two quads cover its full 128-byte row in one instruction (8 rows x 128 bytes) -- 3 x what the CU's memory
+// path moves in the first shape (tools/ubench/sidepat.hip: 15 vs 37-48 B / clk / CU).
+__device__ __forceinline__ void quad_swap(f32x4& a, f32x4& b, bool odd, bool stage2) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float xa = a[q], xb = b[q];
+    const float x = odd ? xa : xb;                  // what the partner lane needs
+    const float y = stage2 ? dpp<DPP_XOR2>(x) : dpp<DPP_XOR1>(x);
+    a[q] = odd ? y : xa;
+    b[q] = odd ? xb : y;
+  }
+}
+__device__ __forceinline__ void quad_transpose(f32x4 (&v)[4], int lane) {
+  const bool o1 = lane & 1, o2 = lane & 2;
+  quad_swap(v[0], v[1], o1, false);
+  quad_swap(v[2], v[3], o1, false);
+  quad_swap(v[0], v[2], o2, true);
+  quad_swap(v[1], v[3], o2, true);
+}
+
 // ---- the two-way split:  x s = hi + lo 2^-11 -------------------------------------------------------------------------------
 __device__ __forceinline__ void split4(f32x4 v, float s, f16x4& ph, f16x4& pl) {
 #pragma clang fp contract(off)

@@ -440,10 +440,12 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
             constexpr bool FULL = decltype(ft)::value;
             constexpr bool HAS_EX = decltype(et)::value;
             const unsigned rowoff = (unsigned)((rb0 + J) * 32 + r_o) * (unsigned)l_ld + (unsigned)fb;
+            // full rows: instruction g reads chunk (lane & 3) of point (r & ~3) + g; hidden_block transposes the quads back
+            const unsigned rowoff_t = (unsigned)((rb0 + J) * 32 + (r_o & ~3)) * (unsigned)l_ld + (unsigned)(nb * 32 + 8 * (r_o & 3) + 4 * hh);
             const gptr<const float> b_in = p_side_in + tile_off;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              if (FULL) hs[J & 1][g] = *((gptr<const f32x4>)(b_in + (rowoff + 8 * g)));
+              if (FULL) hs[J & 1][g] = *((gptr<const f32x4>)(b_in + (rowoff_t + (unsigned)g * (unsigned)l_ld)));
               else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) hs[J & 1][g][q] = fb + 8 * g + q < nlim ? b_in[rowoff + 8 * g + q] : 0.f;
@@ -453,7 +455,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
               const gptr<const float> b_ex = p_side_ex + tile_off;
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
-                if (FULL) ex[J & 1][g] = *((gptr<const f32x4>)(b_ex + (rowoff + 8 * g)));
+                if (FULL) ex[J & 1][g] = *((gptr<const f32x4>)(b_ex + (rowoff_t + (unsigned)g * (unsigned)l_ld)));
                 else {
 #pragma unroll
                   for (int q = 0; q < 4; ++q) ex[J & 1][g][q] = fb + 8 * g + q < nlim ? b_ex[rowoff + 8 * g + q] : 0.f;
@@ -471,13 +473,26 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
             const unsigned rowoff = (unsigned)((rb0 + J) * 32 + r_o) * (unsigned)l_ld + (unsigned)fb;
             const gptr<float> b_out = p_side_out + tile_off;
             const int lim = MODE == 0 ? l_N : nlim;
+            if (FULL && MODE == 0) {
+              // forward: 16 bytes per lane at the lane's own point (its epilogue is VALU-bound: the transposition below costs more
+              // issue slots than the wider stores give back -- measured +2 %)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              if (FULL) *((gptr<f32x4>)(b_out + (rowoff + 8 * g))) = f32x4{acc0[J][4 * g], acc0[J][4 * g + 1], acc0[J][4 * g + 2], acc0[J][4 * g + 3]};
-              else {
+              for (int g = 0; g < 4; ++g)
+                *((gptr<f32x4>)(b_out + (rowoff + 8 * g))) = f32x4{acc0[J][4 * g], acc0[J][4 * g + 1], acc0[J][4 * g + 2], acc0[J][4 * g + 3]};
+            } else if (FULL) {
+              // full rows: a transposed copy of the block (quad_transpose), instruction g writes chunk (lane & 3) of point (r & ~3) + g
+              f32x4 t[4];
+#pragma unroll
+              for (int g = 0; g < 4; ++g) t[g] = f32x4{acc0[J][4 * g], acc0[J][4 * g + 1], acc0[J][4 * g + 2], acc0[J][4 * g + 3]};
+              quad_transpose(t, lane_o);
+              const unsigned rowoff_t = (unsigned)((rb0 + J) * 32 + (r_o & ~3)) * (unsigned)l_ld + (unsigned)(nb * 32 + 8 * (r_o & 3) + 4 * hh);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) *((gptr<f32x4>)(b_out + (rowoff_t + (unsigned)g * (unsigned)l_ld))) = t[g];
+            } else {
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < lim) b_out[rowoff + 8 * g + q] = acc0[J][4 * g + q];
-              }
             }
           };
           auto hidden_block = [&](auto jt, auto ft, auto et) {
@@ -512,6 +527,10 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
                 }
               }
             } else {
+              if (FULL) {                // the side loads came in by full rows: back to "four chunks of my point"
+                quad_transpose(hs[J & 1], lane_o);
+                if (HAS_EX) quad_transpose(ex[J & 1], lane_o);
+              }
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
                 f32x4 x2;
@@ -534,12 +553,19 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
                 }
                 if (MODE == 2 && p_side_out2) {
                   const gptr<float> b_out2 = p_side_out2 + tile_off;
-                  if (FULL) *((gptr<f32x4>)(b_out2 + (rowoff + 8 * g))) = x2;
+                  if (FULL) ex[J & 1][g] = x2;      // (its s values are consumed: the second output leaves by full rows below)
                   else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < nlim) b_out2[rowoff + 8 * g + q] = x2[q];
                   }
                 }
+              }
+              if (MODE == 2 && FULL && p_side_out2) {
+                const gptr<float> b_out2 = p_side_out2 + tile_off;
+                quad_transpose(ex[J & 1], lane_o);
+                const unsigned rowoff_t = (unsigned)((rb0 + J) * 32 + (r_o & ~3)) * (unsigned)l_ld + (unsigned)(nb * 32 + 8 * (r_o & 3) + 4 * hh);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *((gptr<f32x4>)(b_out2 + (rowoff_t + (unsigned)g * (unsigned)l_ld))) = ex[J & 1][g];
               }
             }
             // (backward / tangent: the block's side stores wait until every block's side loads have been consumed, see `run`)
