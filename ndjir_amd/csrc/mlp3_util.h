@@ -71,6 +71,10 @@ __device__ __forceinline__ float dpp(float v) {
 }
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128;
 
+// a 16-byte vector at 4-byte alignment: rows that start at an odd float offset (the geometric net's output inside Z, 257-wide
+// gradients) still move as dwordx4 -- correct on gfx950 and within 10 % of the aligned rate (tools/ubench/unaligned.hip)
+typedef f32x4 f32x4u __attribute__((aligned(4)));
+
 // 4 x 4 transpose inside every quad of lanes: v[g] (g = 0..3, a 16-byte chunk) of lane j (= lane & 3) becomes the old v[j] of lane g.
 // Two butterfly stages (lanes j ^ 1 with chunk pairs (0,1) (2,3); lanes j ^ 2 with (0,2) (1,3)), one DPP move and two selects per
 // dword and stage.  An involution.  mlp3w.hip hands its accumulator blocks to memory through it: before, a lane holds four chunks

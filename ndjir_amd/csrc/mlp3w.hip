@@ -104,12 +104,11 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
       int groups = K0p >> 2;
       asm volatile("" : "+s"(groups));      // (keeps the per-thread addresses below out of the tile loop's preheader)
       const int total = groups * TM;
-      const bool vec = (a.ldx & 3) == 0 && ((uintptr_t)a.X & 15) == 0;
       auto load = [&](int t) -> f32x4 {
         const int g = t % groups, m = t / groups;
         const int k = g * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (vec && k + 3 < K0) v = *reinterpret_cast<const f32x4*>(X + (long long)m * a.ldx + k);
+        if (k + 3 < K0) v = *reinterpret_cast<const f32x4u*>(X + (long long)m * a.ldx + k);     // (any row stride / base offset)
         else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) if (k + q < K0) v[q] = X[(long long)m * a.ldx + k + q];
@@ -318,9 +317,9 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
           const int r_o = lane_o & 31, hh = lane_o >> 5;
           const int fb = nb * 32 + 4 * hh;
           const float winv = p_winv[nb];
-          const bool vec_y = (nb * 32 + 31 < l_N) && (a.ldy & 3) == 0 && ((uintptr_t)a.Y & 15) == 0;
-          // (the geometric net's output lives at Z + 2 floats, ndjir_amd/geometric.py: 8-byte aligned rows -> pairs)
-          const bool vec2_y = !vec_y && (nb * 32 + 31 < l_N) && (a.ldy & 1) == 0 && ((uintptr_t)a.Y & 7) == 0;
+          // (16-byte stores at whatever alignment the rows have: the geometric net's output lives at Z + 2 floats, the packed
+          // first-order pass's at Z + 3, ndjir_amd/geometric.py / mlp.py)
+          const bool vec_y = (nb * 32 + 31 < l_N);
           f32x4 bias4[4];
 #pragma unroll
           for (int g = 0; g < 4; ++g)
@@ -341,22 +340,11 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
               }
               if (vec_y) {
                 if (a.accum_y) {
-                  const f32x4 y0 = *reinterpret_cast<const f32x4*>(y + 8 * g);
+                  const f32x4 y0 = *reinterpret_cast<const f32x4u*>(y + 8 * g);
 #pragma unroll
                   for (int q = 0; q < 4; ++q) t[q] = out_add(t[q], y0[q]);
                 }
-                *reinterpret_cast<f32x4*>(y + 8 * g) = t;
-              } else if (vec2_y) {
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int q = 0; q < 4; q += 2) {
-                  f32x2 u = {t[q], t[q + 1]};
-                  if (a.accum_y) {
-                    const f32x2 y0 = *reinterpret_cast<const f32x2*>(y + 8 * g + q);
-                    u[0] = out_add(u[0], y0[0]); u[1] = out_add(u[1], y0[1]);
-                  }
-                  *reinterpret_cast<f32x2*>(y + 8 * g + q) = u;
-                }
+                *reinterpret_cast<f32x4u*>(y + 8 * g) = t;
               } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)

@@ -413,6 +413,23 @@ class _Strided:
         return self.t.data_ptr()
 
 
+_TAIL_CACHE = {}
+
+
+def _col_tail(W):
+    """Columns 1.. of a (K, N) weight as a stable tensor object (its packed copy is then cached / tracked like any weight's):
+    tracked weights pack straight from the parameter (row stride = its width), else a contiguous copy per parameter version."""
+    if _TRACK is not None and W.is_cuda and get_math() == MATH_F16X3:
+        return W.detach()[:, 1:]
+    key = (W.data_ptr(), tuple(W.shape))
+    hit = _TAIL_CACHE.get(key)
+    if hit is None or hit[0]() is not W or hit[1] != W._version:
+        if len(_TAIL_CACHE) > 16:
+            _TAIL_CACHE.clear()
+        hit = _TAIL_CACHE[key] = (weakref.ref(W), W._version, W.detach()[:, 1:].contiguous())
+    return hit[2]
+
+
 class FusedMLP(Function):
     @staticmethod
     def forward(ctx, x, row_bias, row_bias_div, beta, skip_layer, skip_scale, pack, *params):
@@ -422,16 +439,20 @@ class FusedMLP(Function):
         train = any(ctx.needs_input_grad)
         rb = None if row_bias is None else row_bias.detach().reshape(-1, row_bias.shape[-1])
         out = Zp = None
+        w_run, b_run = weights, biases
         if pack is not None:
-            # output y = [y_0 | y_1 ...] placed inside Zp = [pack (c columns) | y_1 ... | spare] (the packed sample inputs of
-            # ndjir_amd/geometric.py): y starts at column c - 1, then `pack` overwrites y_0
+            # Zp = [pack (c columns) | y_1 ... | spare] (the packed sample inputs of ndjir_amd/geometric.py): y_0 is not part
+            # of it, so the output layer runs WITHOUT its column 0 -- 256 instead of 257 columns at the geometric net's width
+            # (8 column blocks: one k-loop round instead of two), written at column c
             pk = pack.detach().reshape(x2.shape[0], -1).contiguous()
             c = pk.shape[1]
             No = weights[-1].shape[1]
             ldz = (c + No - 1 + 3 + 1 + 3) // 4 * 4
             Zp = torch.empty((x2.shape[0], ldz), device=x2.device, dtype=torch.float32)
-            out = (_Strided(Zp.view(-1)[c - 1:]), ldz)
-        y, hidden, am = chain_forward(x2, weights, biases, beta, skip_layer, skip_scale,
+            out = (_Strided(Zp.view(-1)[c:]), ldz)
+            w_run = weights[:-1] + [_col_tail(weights[-1])]
+            b_run = biases[:-1] + [biases[-1].detach()[1:] if torch.is_tensor(biases[-1]) else None]
+        y, hidden, am = chain_forward(x2, w_run, b_run, beta, skip_layer, skip_scale,
                                       keep_hidden=train, row_bias=rb, row_bias_div=row_bias_div, out=out)
         if train:
             ctx.save_for_backward(x2, *hidden, *weights, am)
@@ -457,14 +478,13 @@ class FusedMLP(Function):
         P, K0 = x2.shape
         need_x = ctx.needs_input_grad[0]
         need_w = any(ctx.needs_input_grad[7:7 + L])
-        if ctx.pack is not None:
-            # gradient of the packed output: columns c .. c + No - 2 belong to y_1 ..; y_0 was overwritten (no gradient)
+        tail = ctx.pack is not None
+        if tail:
+            # gradient of the packed output: columns c .. c + No - 2 belong to y_1 ..: read in place (row stride ldz), the
+            # output layer runs backward without its column 0 as it ran forward (no gradient for W[:, 0], b[0] from here)
             c, ldz, No = ctx.pack
-            g = gy.reshape(P, ldz)
-            # y_0's column is zeroed below: on a private copy of the gradient's (P, No) slice -- the incoming tensor belongs
-            # to autograd (another consumer, a hook or retain_grad may still read it)
-            gy2 = g[:, c - 1:c - 1 + No].contiguous()
-            lib.call("copy_columns", P, 1, _zeros_col(P, g.device), 1, gy2, No)
+            gy2 = gy.reshape(P, ldz).contiguous()[:, c:c + No - 1]
+            W = W[:-1] + [_col_tail(W[-1])]
         else:
             gy2 = gy.reshape(P, -1).contiguous()
         # backward chain: step i applies W_{L-1-i}^T
@@ -528,7 +548,13 @@ class FusedMLP(Function):
             flops = 2.0 * P * sum(k * n for k, n in zip(Ks, Ns))
             if need_w and ctx.needs_input_grad[7 + 2 * L - 1]:
                 # bias gradient of the output layer = column sums of dL/dY: accumulated by the chain's input load
-                gb_last = btgt[L - 1] if btgt[L - 1] is not None else torch.empty((gy2.shape[1],), device=x2.device, dtype=torch.float32)
+                if btgt[L - 1] is not None:
+                    gb_last = btgt[L - 1][1:] if tail else btgt[L - 1]
+                elif tail:
+                    gb_full = torch.zeros((gy2.shape[1] + 1,), device=x2.device, dtype=torch.float32)
+                    gb_last = gb_full[1:]
+                else:
+                    gb_last = torch.empty((gy2.shape[1],), device=x2.device, dtype=torch.float32)
             _launch("chain_bwd", flops, "mlp_chain", 1, P, _Strided(gy2), gy2.stride(0), gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
                      side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
                      (1 if bwd_skip >= 0 else 0) | bg_acc, 1 if need_x else 0,
@@ -540,15 +566,30 @@ class FusedMLP(Function):
         if need_w:
             for j in range(L):
                 if ctx.needs_input_grad[7 + j]:
-                    wt = grad_target(W[j])
-                    if wt is not None:
-                        wgrad(A[j], deltas[j], out=wt, accum=True, amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
+                    if tail and j == L - 1:
+                        # the gradient of W[:, 1:] (contiguous) added to / placed in the parameter's columns 1..
+                        gt = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
+                        wt = grad_target(saved[2 * L - 1])
+                        if wt is not None:
+                            wt[:, 1:].add_(gt)
+                        else:
+                            gW[j] = torch.zeros_like(saved[2 * L - 1])
+                            gW[j][:, 1:] = gt
                     else:
-                        gW[j] = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
+                        wt = grad_target(W[j])
+                        if wt is not None:
+                            wgrad(A[j], deltas[j], out=wt, accum=True, amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
+                        else:
+                            gW[j] = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
                 if ctx.needs_input_grad[7 + L + j]:
                     if btgt[j] is not None:
                         if j == L - 1 and gb_last is None:
-                            colsum(gy2, out=btgt[j], accum=True)
+                            colsum(gy2, out=btgt[j][1:] if tail else btgt[j], accum=True)
+                    elif j == L - 1 and tail:
+                        if gb_last is None:
+                            gb_full = torch.zeros((gy2.shape[1] + 1,), device=x2.device, dtype=torch.float32)
+                            colsum(gy2, out=gb_full[1:])
+                        gb[j] = gb_full
                     else:
                         gb[j] = bgrads[j] if j < L - 1 else (gb_last if gb_last is not None else colsum(gy2))
         g_rb = None

@@ -467,6 +467,51 @@ def test_wgrad_operand_scales(gpu, scale_a, scale_b):
     assert float((out2.cpu().double() - ref).norm() / ref.norm()) < 2e-6
 
 
+@pytest.mark.parametrize("P,dims,in_place", [(256, (43, 128, 128, 257), False), (32768, (43, 256, 256, 257), True), (640, (12, 64, 9), False)])
+def test_packed_output_runs_without_column_zero(gpu, P, dims, in_place):
+    """fused_mlp(pack=): the result is Zp = [pack | y_1 .. | spare]; the output layer runs without its column 0 forward and
+    backward (python/renderer.py:186-193's perturbed pass needs the features only).  Value and every gradient against the fp64
+    composite -- dL/dW[:, 0] and dL/db[0] are exactly zero --, with and without accumulate-in-place gradient buffers, on the 32-,
+    64- and 128-point kernels (the packed rows start 3 floats into a row: unaligned 16-byte stores)."""
+    from ndjir_amd import mlp
+    rng = np.random.RandomState(P % 97)
+    Ws = [torch.tensor(rng.randn(a, b) / np.sqrt(a), dtype=torch.float32, device=gpu, requires_grad=True) for a, b in zip(dims[:-1], dims[1:])]
+    bs = [torch.tensor(rng.randn(b) * 0.1, dtype=torch.float32, device=gpu, requires_grad=True) for b in dims[1:]]
+    x = torch.tensor(rng.randn(P, dims[0]), dtype=torch.float32, device=gpu, requires_grad=True)
+    pk = torch.tensor(rng.randn(P, 3), dtype=torch.float32, device=gpu)
+    No = dims[-1]
+    bufs = []
+    try:
+        if in_place:
+            for t in Ws + bs:
+                bufs.append(torch.zeros_like(t))
+                mlp.set_grad_buffer(t, bufs[-1])
+        Zp = mlp.fused_mlp(x, Ws, bs, pack=pk)
+        assert Zp.shape[0] == P and Zp.shape[1] % 4 == 0 and Zp.shape[1] >= 3 + No - 1
+        g = torch.tensor(rng.randn(*Zp.shape), dtype=torch.float32, device=gpu)
+        with torch.no_grad() if in_place else torch.enable_grad():
+            grads = torch.autograd.grad(Zp, [x] + Ws + bs, g, allow_unused=True)
+        got = [grads[0]] + ([b.clone() for b in bufs] if in_place else list(grads[1:]))
+    finally:
+        mlp.clear_grad_buffers()
+    h = x.detach().double().requires_grad_(True)
+    W64 = [w.detach().double().requires_grad_(True) for w in Ws]
+    b64 = [b.detach().double().requires_grad_(True) for b in bs]
+    a = h
+    for j, (w, b) in enumerate(zip(W64, b64)):
+        a = a @ w + b
+        if j < len(W64) - 1:
+            a = TF.softplus(a, beta=100)
+    ref = torch.cat([pk.double(), a[:, 1:]], dim=1)
+    assert torch.equal(Zp[:, :3], pk)
+    assert float((Zp[:, 3:3 + No - 1].detach().double() - ref[:, 3:]).abs().max()) < 2e-5 * float(ref.abs().max())
+    gref = torch.autograd.grad(ref, [h] + W64 + b64, g[:, :3 + No - 1].double())
+    for i, (a_, b_) in enumerate(zip(got, gref)):
+        assert a_ is not None, i
+        assert float((a_.double() - b_).norm()) <= 3e-5 * float(b_.norm()), i
+    assert float(got[len(Ws)][:, 0].abs().max()) == 0.0 and float(got[-1][0].abs()) == 0.0      # column 0 of the output layer
+
+
 def test_rows_except_value_gradient_and_cache(gpu):
     """mlp.rows_except (the per-sample rows of a first-layer weight whose per-ray rows sit in the middle): value, gradient
     through autograd, gradient into an accumulate-in-place buffer, and the refresh of the cached copy after an in-place update."""
