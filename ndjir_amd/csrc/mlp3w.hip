@@ -750,7 +750,8 @@ int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) {
   }
 #define NDJIR_GO(M, R, W) hipLaunchKernelGGL((k_chainw<M, R, W>), dim3((unsigned)blocks), dim3(W * 64), lds_bytes, stream, b)
   if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4, 8); else if (mode == 1) NDJIR_GO(1, 4, 8); else NDJIR_GO(2, 4, 8); }
-  else if (((nw4 >> mode) & 1) && lds_bytes <= 78 * 1024) { if (mode == 0) NDJIR_GO(0, 4, 4); else if (mode == 1) NDJIR_GO(1, 4, 4); else NDJIR_GO(2, 4, 4); }
+  // (two workgroups per CU: 2 x (dynamic + 2.5 KB static) <= 160 KB)
+  else if (((nw4 >> mode) & 1) && lds_bytes <= 77 * 1024) { if (mode == 0) NDJIR_GO(0, 4, 4); else if (mode == 1) NDJIR_GO(1, 4, 4); else NDJIR_GO(2, 4, 4); }
   else { if (mode == 0) NDJIR_GO(0, 2, 8); else if (mode == 1) NDJIR_GO(1, 2, 8); else NDJIR_GO(2, 2, 8); }
 #undef NDJIR_GO
   int rc = ndjir_check_launch();
