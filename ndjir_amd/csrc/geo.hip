@@ -25,9 +25,10 @@ __global__ void __launch_bounds__(256) k_geo_encode(long long P, int M, const fl
                                                     float* __restrict__ e, int lde, int W) {
   const int npe = 3 + 6 * M;
   const long long total = P * W;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const long long p = t / W;
-    int c = (int)(t - p * W);
+  RowCol rc((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, W);
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256, rc.next()) {
+    const long long p = rc.p;
+    int c = rc.c;
     float v;
     if (c < 3) v = x[p * 3 + c];
     else if (c < npe) {
@@ -91,9 +92,10 @@ __global__ void __launch_bounds__(256) k_geo_bwd_begin(long long P, int D, const
                                                        float* __restrict__ nbar) {
   const int W = 1 + D + 3;
   const long long total = P * W;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const long long p = t / W;
-    const int c = (int)(t - p * W);
+  RowCol rc((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, W);
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256, rc.next()) {
+    const long long p = rc.p;
+    const int c = rc.c;
     if (c == 0) gy[p * (1 + D)] = g_sdf ? g_sdf[p] : 0.f;
     else if (c <= D) {
       float v = g_feat ? g_feat[p * ldf + c - 1] : 0.f;
@@ -113,9 +115,10 @@ __global__ void __launch_bounds__(256) k_geo_gbar0(long long P, int M, const flo
                                                    const float* __restrict__ nbar, GeoSegs s, float* __restrict__ gb0, int W) {
   const int npe = 3 + 6 * M;
   const long long total = P * W;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const long long p = t / W;
-    const int c = (int)(t - p * W);
+  RowCol rc((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, W);
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256, rc.next()) {
+    const long long p = rc.p;
+    const int c = rc.c;
     float v;
     if (c < 3) v = nbar[p * 3 + c];
     else if (c < npe) {
@@ -144,9 +147,10 @@ __global__ void __launch_bounds__(256) k_geo_gbar0(long long P, int M, const flo
 __global__ void __launch_bounds__(256) k_copy_cols(long long P, int C, const float* __restrict__ src, int lds,
                                                    float* __restrict__ dst, int ldd) {
   const long long total = P * C;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const long long p = t / C;
-    const int c = (int)(t - p * C);
+  RowCol rc((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, C);
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256, rc.next()) {
+    const long long p = rc.p;
+    const int c = rc.c;
     dst[p * ldd + c] = src[p * lds + c];
   }
 }
@@ -165,7 +169,7 @@ __global__ void __launch_bounds__(256) k_inv_distance(long long P, long long row
 
 static inline unsigned geo_blocks(long long total) {
   long long b = (total + 255) / 256;
-  return (unsigned)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
+  return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));      // (8 workgroups per CU x 4 rounds; a thread then visits several elements)
 }
 
 static inline int geo_segs(GeoSegs& s, int n, const float* const* p, const int* C) {

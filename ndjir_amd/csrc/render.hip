@@ -622,9 +622,10 @@ __global__ void __launch_bounds__(256) k_background_head(long long P, int nx, in
                                                          float* __restrict__ alpha, float* __restrict__ inp) {
   const int W = nx + F;
   const long long n = P * W;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const long long p = i / W;
-    const int c = (int)(i - p * W);
+  RowCol rc((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, W);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256, rc.next()) {
+    const long long p = rc.p;
+    const int c = rc.c;
     inp[i] = c < nx ? x[p * nx + c] : h[p * (F + 1) + 1 + (c - nx)];
     if (c == 0) {
       const float v = h[p * (F + 1)];
@@ -639,9 +640,10 @@ __global__ void __launch_bounds__(256) k_background_head_bwd(long long P, int nx
                                                              const float* __restrict__ g_inp, float* __restrict__ g_h) {
   const int W = F + 1;
   const long long n = P * W;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const long long p = i / W;
-    const int c = (int)(i - p * W);
+  RowCol rc((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, W);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256, rc.next()) {
+    const long long p = rc.p;
+    const int c = rc.c;
     if (c > 0) {
       g_h[i] = g_inp ? g_inp[p * (nx + F) + nx + (c - 1)] : 0.f;
     } else {
@@ -887,7 +889,7 @@ extern "C" int ndjir_render_background_head(long long P, int nx, int F, const fl
   if (nx < 1 || F < 1) return NDJIR_ERR_UNSUPPORTED;
   if (!h || !x || !delta || !alpha || !inp) return NDJIR_ERR_ARG;
   const long long blocks = (P * (nx + F) + 255) / 256;
-  hipLaunchKernelGGL(ndjir::k_background_head, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, P, nx, F, h, x,
+  hipLaunchKernelGGL(ndjir::k_background_head, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, P, nx, F, h, x,
                      delta, alpha, inp);
   return ndjir_check_launch();
 }
@@ -898,7 +900,7 @@ extern "C" int ndjir_render_background_head_backward(long long P, int nx, int F,
   if (nx < 1 || F < 1) return NDJIR_ERR_UNSUPPORTED;
   if (!h || !delta || !g_h) return NDJIR_ERR_ARG;
   const long long blocks = (P * (F + 1) + 255) / 256;
-  hipLaunchKernelGGL(ndjir::k_background_head_bwd, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream, P, nx, F, h,
+  hipLaunchKernelGGL(ndjir::k_background_head_bwd, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, P, nx, F, h,
                      delta, g_alpha, g_inp, g_h);
   return ndjir_check_launch();
 }
@@ -1014,9 +1016,10 @@ __global__ void __launch_bounds__(256) k_posenc(long long P, int C, int M, int i
                                                 float* __restrict__ out) {
   const int CM = C * M, W = (include_input ? C : 0) + 2 * CM;
   const long long total = P * W;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const long long p = t / W;
-    int c = (int)(t - p * W);
+  RowCol rc((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, W);
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256, rc.next()) {
+    const long long p = rc.p;
+    int c = rc.c;
     float v;
     if (include_input && c < C) v = x[p * C + c];
     else {
@@ -1035,9 +1038,10 @@ __global__ void __launch_bounds__(256) k_posenc_bwd(long long P, int C, int M, i
                                                     const float* __restrict__ g, float* __restrict__ gx) {
   const int CM = C * M, W = (include_input ? C : 0) + 2 * CM, off = include_input ? C : 0;
   const long long total = P * C;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const long long p = t / C;
-    const int i = (int)(t - p * C);
+  RowCol rc((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, C);
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256, rc.next()) {
+    const long long p = rc.p;
+    const int i = rc.c;
     const float xv = x[t];
     const float* gp = g + p * W;
     float acc = include_input ? gp[i] : 0.f;
@@ -1057,7 +1061,7 @@ extern "C" int ndjir_positional_encoding(long long P, int C, int M, int include_
   if (M < 0 || M > 30 || !x || !out) return NDJIR_ERR_ARG;
   const long long total = P * ((include_input ? C : 0) + 2LL * C * M);
   long long blocks = (total + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(k_posenc, dim3((unsigned)blocks), dim3(256), 0, stream, P, C, M, include_input, x, out);
   return ndjir_check_launch();
 }
@@ -1067,7 +1071,7 @@ extern "C" int ndjir_positional_encoding_backward(long long P, int C, int M, int
   if (P <= 0 || C <= 0) return NDJIR_OK;
   if (M < 0 || M > 30 || !x || !g || !gx) return NDJIR_ERR_ARG;
   long long blocks = (P * C + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(k_posenc_bwd, dim3((unsigned)blocks), dim3(256), 0, stream, P, C, M, include_input, x, g, gx);
   return ndjir_check_launch();
 }
