@@ -534,6 +534,7 @@ __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restr
   __shared__ float vals[AGG_HT * 4];
   const long long total = P * g.S;
   const long long per_pass = (long long)gridDim.x * ppp;
+  const int cw_log = (g.D == 8) ? 1 : 0;          // float4 chunks per table entry = 1 << cw_log
   for (long long base = (long long)blockIdx.x * ppp; base < total; base += per_pass) {   // uniform per workgroup
     for (int t = threadIdx.x; t < AGG_HT; t += 256) {
       keys[t] = -1;
@@ -566,25 +567,27 @@ __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restr
             for (int a = 0; a < ND; ++a) w += ggs[a] * tap_dw(st, a, i, j, k);
           }
           const int key = (int)((cell_offset(st, i, j, k) + d0) >> 2);     // float4 index
-          unsigned slot = ((unsigned)key * 2654435761u) >> 20;             // 12 bits
+          // a table entry is a float4 (D = 4, 12, ...) or, for D = 8, the cell's two float4s side by side: the flush below
+          // then covers a whole 32-byte cell with one request
+          const int ek = key >> cw_log, ce = key & ((1 << cw_log) - 1);
+          unsigned slot = ((unsigned)ek * 2654435761u) >> (20 + cw_log);   // 12 (11) bits
           while (true) {
-            const int old = atomicCAS(&keys[slot], -1, key);
-            if (old == -1 || old == key) break;
-            slot = (slot + 1) & (AGG_HT - 1);
+            const int old = atomicCAS(&keys[slot], -1, ek);
+            if (old == -1 || old == ek) break;
+            slot = (slot + 1) & ((AGG_HT >> cw_log) - 1);
           }
 #pragma unroll
-          for (int v = 0; v < 4; ++v) atomicAdd(&vals[4 * slot + v], og[v] * w);
+          for (int v = 0; v < 4; ++v) atomicAdd(&vals[4 * ((slot << cw_log) + ce) + v], og[v] * w);
         }
       }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < AGG_HT; t += 256) {
-      const int key = keys[t];
-      if (key >= 0) {
-        float* p = gf + ((long long)key << 2);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) atomicAdd(p + v, vals[4 * t + v]);
-      }
+    // one lane per FLOAT: the 4 (8) lanes of an entry address 16 (32) contiguous bytes, which the memory-side atomic unit takes
+    // as one request -- its rate is per request, not per float (tools/ubench/atomics_shape.hip: 20 G requests/s either way, i.e.
+    // 4 x (8 x) the floats per second of a lane-per-cell flush with one instruction per float)
+    for (int t = threadIdx.x; t < AGG_HT * 4; t += 256) {
+      const int ek = keys[t >> (2 + cw_log)];
+      if (ek >= 0) atomicAdd(gf + ((long long)ek << (2 + cw_log)) + (t & ((4 << cw_log) - 1)), vals[t]);
     }
     __syncthreads();
   }
@@ -1186,16 +1189,18 @@ __global__ void __launch_bounds__(256) k_tv_bwd_agg(long long P, float* __restri
   __shared__ float vals[AGG_HT * 4];
   const long long total = P * g.S;
   const long long per_pass = (long long)gridDim.x * 256;
+  const int cw_log = (g.D == 8) ? 1 : 0;          // float4 chunks per table entry (see k_scatter_agg)
   auto add = [&](long long off, const float* v4) {
     const int key = (int)(off >> 2);
-    unsigned slot = ((unsigned)key * 2654435761u) >> 20;
+    const int ek = key >> cw_log, ce = key & ((1 << cw_log) - 1);
+    unsigned slot = ((unsigned)ek * 2654435761u) >> (20 + cw_log);
     while (true) {
-      const int old = atomicCAS(&keys[slot], -1, key);
-      if (old == -1 || old == key) break;
-      slot = (slot + 1) & (AGG_HT - 1);
+      const int old = atomicCAS(&keys[slot], -1, ek);
+      if (old == -1 || old == ek) break;
+      slot = (slot + 1) & ((AGG_HT >> cw_log) - 1);
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v) atomicAdd(&vals[4 * slot + v], v4[v]);
+    for (int v = 0; v < 4; ++v) atomicAdd(&vals[4 * ((slot << cw_log) + ce) + v], v4[v]);
   };
   for (long long base = (long long)blockIdx.x * 256; base < total; base += per_pass) {
     for (int t = threadIdx.x; t < AGG_HT; t += 256) {
@@ -1238,13 +1243,9 @@ __global__ void __launch_bounds__(256) k_tv_bwd_agg(long long P, float* __restri
       }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < AGG_HT; t += 256) {
-      const int key = keys[t];
-      if (key >= 0) {
-        float* p = dst + ((long long)key << 2);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) atomicAdd(p + v, vals[4 * t + v]);
-      }
+    for (int t = threadIdx.x; t < AGG_HT * 4; t += 256) {       // (one lane per float, see k_scatter_agg)
+      const int ek = keys[t >> (2 + cw_log)];
+      if (ek >= 0) atomicAdd(dst + ((long long)ek << (2 + cw_log)) + (t & ((4 << cw_log) - 1)), vals[t]);
     }
     __syncthreads();
   }

@@ -17,20 +17,19 @@ template <int D4>
 __global__ void __launch_bounds__(256) k_rows_apply(const int* __restrict__ ids, const float4* __restrict__ rows,
                                                     const int* __restrict__ counts, int world, int cap, int limit, int skip_rank,
                                                     float* __restrict__ buf) {
-  const long long total = (long long)world * limit;
+  // one lane per FLOAT of a row: the 4 D4 lanes of a row address contiguous bytes -- the memory-side atomic unit serves a request,
+  // not a float, at its ~20 G / s (tools/ubench/atomics_shape.hip)
+  constexpr int D = 4 * D4;
+  const long long total = (long long)world * limit * D;
+  const float* rowf = reinterpret_cast<const float*>(rows);
   for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const int r = (int)(t / limit), i = (int)(t - (long long)r * limit);
+    const long long row = t / D;
+    const int d = (int)(t - row * D);
+    const int r = (int)(row / limit), i = (int)(row - (long long)r * limit);
     if (r == skip_rank || i >= counts[r]) continue;
     const long long e = (long long)r * cap + i;
-    float* p = buf + (long long)ids[e] * (4 * D4);
-#pragma unroll
-    for (int c = 0; c < D4; ++c) {
-      const float4 v = rows[e * D4 + c];
-      if (v.x != 0.f) atomicAdd(p + 4 * c, v.x);
-      if (v.y != 0.f) atomicAdd(p + 4 * c + 1, v.y);
-      if (v.z != 0.f) atomicAdd(p + 4 * c + 2, v.z);
-      if (v.w != 0.f) atomicAdd(p + 4 * c + 3, v.w);
-    }
+    const float v = rowf[e * D + d];
+    if (v != 0.f) atomicAdd(buf + (long long)ids[e] * D + d, v);
   }
 }
 
@@ -102,7 +101,7 @@ extern "C" int ndjir_sparse_rows_apply(const int* ids, const float* rows, const 
   if (world <= 0 || capacity <= 0 || limit <= 0) return NDJIR_OK;
   if (!ids || !rows || !counts || !buf || limit > capacity) return NDJIR_ERR_ARG;
   if (D != 4 && D != 8) return NDJIR_ERR_UNSUPPORTED;
-  const int blocks = blocks_for((long long)world * limit);
+  const int blocks = blocks_for((long long)world * limit * D);
   if (D == 4) hipLaunchKernelGGL(k_rows_apply<1>, dim3(blocks), dim3(256), 0, stream, ids, reinterpret_cast<const float4*>(rows), counts,
                                  world, capacity, limit, skip_rank, buf);
   else hipLaunchKernelGGL(k_rows_apply<2>, dim3(blocks), dim3(256), 0, stream, ids, reinterpret_cast<const float4*>(rows), counts, world,
