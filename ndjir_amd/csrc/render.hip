@@ -289,10 +289,24 @@ __global__ void __launch_bounds__(256) k_integrate_many_bwd(int S_all, const flo
       const float* x = sg.x[k] + (r * (long long)S + i) * ldx;
       float* gx = sg.out[k] ? sg.out[k] + (r * (long long)S + i) * C : nullptr;
       float acc = 0.f;
-      for (int c = lane; c < C; c += 64) {
-        const float gc = gr[c];
-        if (gw) acc += x[c] * gc;
-        if (gx) gx[c] = wj * gc;
+      if ((C & 3) == 0) {
+        // wide segments (the 256 feature channels): 16 bytes per lane, x at whatever alignment its packed row has
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef f4 f4u __attribute__((aligned(4)));
+        for (int c = 4 * lane; c < C; c += 256) {
+          const f4 gc = *reinterpret_cast<const f4u*>(gr + c);
+          if (gw) {
+            const f4 xv = *reinterpret_cast<const f4u*>(x + c);
+            acc += xv[0] * gc[0] + xv[1] * gc[1] + xv[2] * gc[2] + xv[3] * gc[3];
+          }
+          if (gx) *reinterpret_cast<f4u*>(gx + c) = gc * wj;
+        }
+      } else {
+        for (int c = lane; c < C; c += 64) {
+          const float gc = gr[c];
+          if (gw) acc += x[c] * gc;
+          if (gx) gx[c] = wj * gc;
+        }
       }
       tot += acc;
     }
