@@ -547,6 +547,21 @@ int ndjir_mlp_group_colsum(const float* X, int ldx, int N, long long G, int div,
 long long ndjir_mlp_wgrad_workspace(int K, int N, long long P);
 int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out,
                     int accum, float* workspace, const unsigned* amax_a, const unsigned* amax_b, hipStream_t stream);
+/* Many weight gradients in ONE launch (+ one split-reduction launch): out[o] (K[o] x N[o], row stride ldo[o]) (+)= the sum
+ * over the sources i with out_id[i] == o of A[i]^T B[i] (A[i]: P[i] x K[o], row stride lda[i]; B[i]: P[i] x N[o], row stride
+ * ldb[i]).  A training step's ~47 per-layer GEMMs (nnabla's affine backward, python/network.py:88-93) share the machine:
+ * splits of thousands of points instead of hundreds, partial slabs smaller by the number of layers grouped, one reduction
+ * launch for all.  Two sources of one output: the geometric network's dW_j = A_j^T delta_j + gbar_j^T s_j (its double
+ * backward through nn.grad, python/renderer.py:52).  NDJIR_MATH_F16X3 only (NDJIR_ERR_UNSUPPORTED otherwise); amax_a[i] /
+ * amax_b[i] (device, recorded maxima as for ndjir_mlp_wgrad) are required except for outputs <= 8 wide, which take the
+ * streaming path.  `workspace`: ndjir_mlp_wgrad_group_workspace(...) floats for the same sources / outputs / target_items
+ * (work items the launch aims for: the point axis of every source is split accordingly; 0 = default, 4 per CU). */
+long long ndjir_mlp_wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id,
+                                          int n_out, const int* K, const int* N, int target_items);
+int ndjir_mlp_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb,
+                          const long long* P, const unsigned* const* amax_a, const unsigned* const* amax_b, const int* out_id,
+                          int n_out, float* const* out, const int* ldo, const int* K, const int* N, const int* accum,
+                          float* workspace, int target_items, hipStream_t stream);
 /* Bias gradient of a layer: out (N) (+)= column sums of its deltas X (P x N, row stride ldx); the
  * reference gets it from nnabla's affine backward (a reduction kernel per layer). */
 long long ndjir_mlp_colsum_workspace(int N, long long P);   /* floats */

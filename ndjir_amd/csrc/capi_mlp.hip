@@ -180,6 +180,26 @@ extern "C" int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb,
   return launch_wgrad(A, lda, B, ldb, K, N, P, out, accum, workspace, g_math, amax_a, amax_b, stream);
 }
 
+extern "C" long long ndjir_mlp_wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P,
+                                                     const int* out_id, int n_out, const int* K, const int* N, int target_items) {
+  if (n_src <= 0 || n_out <= 0 || !lda || !P || !out_id || !K || !N) return 0;
+  for (int i = 0; i < n_src; ++i)
+    if (out_id[i] < 0 || out_id[i] >= n_out) return 0;
+  return wgrad_group_workspace(n_src, A, lda, P, out_id, n_out, K, N, target_items);
+}
+
+extern "C" int ndjir_mlp_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb,
+                                     const long long* P, const unsigned* const* amax_a, const unsigned* const* amax_b,
+                                     const int* out_id, int n_out, float* const* out, const int* ldo, const int* K, const int* N,
+                                     const int* accum, float* workspace, int target_items, hipStream_t stream) {
+  if (n_src <= 0 || n_out <= 0) return NDJIR_OK;
+  if (!A || !lda || !B || !ldb || !P || !out_id || !out || !ldo || !K || !N || !workspace) return NDJIR_ERR_ARG;
+  if (g_math != NDJIR_MATH_F16X3) return NDJIR_ERR_UNSUPPORTED;
+  for (int o = 0; o < n_out; ++o)
+    if (K[o] <= 0 || N[o] <= 0) return NDJIR_ERR_ARG;
+  return launch_wgrad_group(n_src, A, lda, B, ldb, P, amax_a, amax_b, out_id, n_out, out, ldo, K, N, accum, workspace, target_items, stream);
+}
+
 extern "C" long long ndjir_mlp_colsum_workspace(int N, long long P) { return colsum_workspace(N, P); }
 
 extern "C" int ndjir_mlp_colsum(const float* X, int ldx, int N, long long P, float* out, int accum, float* workspace,

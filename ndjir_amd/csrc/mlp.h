@@ -83,6 +83,14 @@ long long wgrad_workspace(int K, int N, long long P);
 int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out, int accum,
                  float* workspace, int math, const unsigned* amax_a, const unsigned* amax_b, hipStream_t stream);
 
+// many weight gradients in one launch + one split-reduction launch (f16x3 arithmetic; wgrad.hip "grouped weight gradients")
+long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id, int n_out,
+                                const int* K, const int* N, int target_items);
+int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb, const long long* P,
+                       const unsigned* const* amax_a, const unsigned* const* amax_b, const int* out_id, int n_out,
+                       float* const* out, const int* ldo, const int* K, const int* N, const int* accum, float* workspace,
+                       int target_items, hipStream_t stream);
+
 long long colsum_workspace(int N, long long P);
 int launch_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, hipStream_t stream);
 int launch_colsum(const float* X, int ldx, int N, long long P, float* out, int accum, float* workspace,

@@ -314,35 +314,21 @@ __host__ __device__ __forceinline__ void wg_scale_from_max(unsigned mbits, float
   inv = b.f;
 }
 
+// One output tile of dW over the points [p_begin, p_end): `out` = this split's (K x N) partial slab.
 template <int WK, int WN, int BK, int BN>
-__global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad3(const float* __restrict__ A, int lda, const float* __restrict__ B,
-                                                          int ldb, int K, int N, long long P, float* __restrict__ partial,
-                                                          int S, int tiles_k, int tiles_n, long long rows_per_split,
-                                                          int k_off, int n_off, int k_end, int n_end,
-                                                          const unsigned* __restrict__ amax_a, const unsigned* __restrict__ amax_b) {
+__device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int N,
+                                            long long p_begin, long long p_end, float* __restrict__ out, int k0, int n0,
+                                            int k_end, int n_end, float sa, float ia, float sb, float ib,
+                                            unsigned short* wg_lds) {
   static_assert(WK * WN == 4, "4 waves");
   constexpr int TK = WK * BK * 32, TN = WN * BN * 32;
   constexpr int PA = TK / 8, PB = TN / 8;          // points per thread and chunk (multiples of 4)
-  extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
   _Float16* As = reinterpret_cast<_Float16*>(wg_lds);      // [2][TK][WG_CP]
   _Float16* Bs = As + 2 * TK * WG_CP;                      // [2][TN][WG_CP]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wk = wave / WN, wn = wave % WN;
-  const int T = tiles_k * tiles_n;
-  const int nblk = gridDim.x;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  int vid = (nblk & 7) == 0 ? xcd * (nblk >> 3) + local : blockIdx.x;
-  const int split = vid / T, tile = vid - split * T;
-  const int tk = tile / tiles_n, tn = tile - tk * tiles_n;
-  const int k0 = k_off + tk * TK, n0 = n_off + tn * TN;
-  const long long p_begin = (long long)split * rows_per_split;
-  long long p_end = p_begin + rows_per_split;
-  if (p_end > P) p_end = P;
-  float sa, ia, sb, ib;
-  wg_scale_from_max(*amax_a, sa, ia);
-  wg_scale_from_max(*amax_b, sb, ib);
 
   f32x16 acc0[BK][BN] = {}, acc1[BK][BN] = {};
   float ra[PA], rb[PB];
@@ -419,7 +405,6 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad3(const float* __restric
     }
   }
 
-  float* out = partial + (long long)split * K * N;
 #pragma unroll
   for (int bi = 0; bi < BK; ++bi)
 #pragma unroll
@@ -431,6 +416,31 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad3(const float* __restric
         if (k < k_end && n < n_end) out[(long long)k * N + n] = fmaf(acc1[bi][bj][i], 1.f / 2048.f, acc0[bi][bj][i]) * ia * ib;
       }
     }
+}
+
+template <int WK, int WN, int BK, int BN>
+__global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad3(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                          int ldb, int K, int N, long long P, float* __restrict__ partial,
+                                                          int S, int tiles_k, int tiles_n, long long rows_per_split,
+                                                          int k_off, int n_off, int k_end, int n_end,
+                                                          const unsigned* __restrict__ amax_a, const unsigned* __restrict__ amax_b) {
+  constexpr int TK = WK * BK * 32, TN = WN * BN * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
+  const int T = tiles_k * tiles_n;
+  const int nblk = gridDim.x;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  int vid = (nblk & 7) == 0 ? xcd * (nblk >> 3) + local : blockIdx.x;
+  const int split = vid / T, tile = vid - split * T;
+  const int tk = tile / tiles_n, tn = tile - tk * tiles_n;
+  const int k0 = k_off + tk * TK, n0 = n_off + tn * TN;
+  const long long p_begin = (long long)split * rows_per_split;
+  long long p_end = p_begin + rows_per_split;
+  if (p_end > P) p_end = P;
+  float sa, ia, sb, ib;
+  wg_scale_from_max(*amax_a, sa, ia);
+  wg_scale_from_max(*amax_b, sb, ib);
+  wgrad3_tile<WK, WN, BK, BN>(A, lda, B, ldb, N, p_begin, p_end, partial + (long long)split * K * N, k0, n0, k_end, n_end, sa, ia,
+                              sb, ib, wg_lds);
 }
 
 template <int WK, int WN, int BK, int BN>
@@ -840,6 +850,367 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
                        workspace, S, pl.tk, pl.sn, rows, 0, pl.Nm, pl.Km, N);
   }
   return launch_split_reduce(workspace, out, (long long)K * N, S, accum, stream);
+}
+
+
+// ---- grouped weight gradients: MANY dW_o = sum_src A^T B in ONE launch + ONE split-reduction launch (round 4) -------------
+// A training step issues ~47 weight-gradient GEMMs of one net layer each.  Launched one by one, each has to fill 256 CUs on
+// its own: 128 point-axis splits per 256 x 256 gradient, i.e. 32 MB of partial slabs written and re-read per layer (1.5 GB
+// per step), a prologue / epilogue per 16 chunks of work, and a reduction launch (k_reduce_tall, 61 per step).  Grouped, the
+// work items of all layers share the machine: a split is thousands of points long, the slabs shrink by the number of layers
+// in the group, and one reduction launch serves them all.  An output may have several operand pairs ("sources": the
+// geometric net's dW_j = A_j^T delta_j + gbar_j^T s_j), each with its own operand scales: every work item writes a
+// de-scaled partial slab, the reduction sums the slabs of all sources of an output.
+// Work-item kinds: 0 = 128 x 128 main tile, 1 = 32 x 128 strip (ragged K), 2 = 128 x 32 strip (ragged N), 3 = streaming
+// reduction for outputs <= 8 wide.  Items are ordered main tiles first (long), strips and narrow items last (short).
+constexpr int WGG_MAX_SRC = 24;
+constexpr int WGG_MAX_SEG = 64;
+constexpr int WGG_MAX_OUT = 24;
+constexpr int WGG_NARROW_ROWS = 1024;     // points per narrow work item
+
+struct WggSrc {
+  const float* A;
+  const float* B;
+  const unsigned* amax_a;
+  const unsigned* amax_b;
+  float* partial;            // this source's slabs: partial[split][K][N]
+  long long P;
+  long long rows;            // points per split (multiple of WG_C)
+  int lda, ldb, K, N;
+  int S, pad;
+};
+struct WggSeg {              // a run of consecutive workgroups doing one kind of work for one source
+  int first, count;          // first workgroup (multiple of 8), workgroups (multiple of 8; the ones past S * tiles idle)
+  short src, kind;
+};
+struct WggArgs {
+  int n_seg, pad;
+  WggSrc src[WGG_MAX_SRC];
+  WggSeg seg[WGG_MAX_SEG];
+};
+struct WggOut {
+  float* out;                // (K, N), row stride ldo
+  const float* partial;      // partial[S][K * N]
+  int KN, N, ldo, S, accum;
+  int first;                 // first workgroup of this output in the reduction launch
+};
+struct WggRedArgs {
+  int n_out, pad;
+  WggOut out[WGG_MAX_OUT];
+};
+
+__host__ __device__ static inline void wgg_plan(int K, int N, int& Km, int& Nm, int& tk, int& tn, int& sk, int& sn, int& tn_all) {
+  const int rk = K % WG_T, rn = N % WG_T;
+  Km = (rk != 0 && rk <= 2 * WG_STRIP) ? K - rk : K;
+  Nm = (rn != 0 && rn <= 2 * WG_STRIP) ? N - rn : N;
+  tk = (Km + WG_T - 1) / WG_T;
+  tn = (Nm + WG_T - 1) / WG_T;
+  sk = (K - Km + WG_STRIP - 1) / WG_STRIP;
+  sn = (N - Nm + WG_STRIP - 1) / WG_STRIP;
+  tn_all = (N + WG_T - 1) / WG_T;
+}
+
+// streaming item for N <= 8 (K % 4 == 0, lda % 4 == 0, A 16-byte aligned): the body of k_wgrad_narrow over [p0, p1)
+template <int NMAX>
+__device__ __forceinline__ void wgrad_narrow_rows(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                  int K, int N, long long p0, long long p1, float* __restrict__ part,
+                                                  float4* red) {
+  const int KQ = K >> 2;
+  const int TX = pow2_at_least(KQ), TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  for (int q0 = 0; q0 < KQ; q0 += TX) {
+    const int kq = q0 + tx;
+    float4 acc[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kq < KQ) {
+#pragma unroll 4
+      for (long long p = p0 + ty; p < p1; p += TY) {
+        const float4 a = *reinterpret_cast<const float4*>(A + p * lda + 4 * kq);
+        const float* b = B + p * ldb;
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) if (n < N) {
+          const float bn = b[n];
+          acc[n].x = fmaf(a.x, bn, acc[n].x); acc[n].y = fmaf(a.y, bn, acc[n].y);
+          acc[n].z = fmaf(a.z, bn, acc[n].z); acc[n].w = fmaf(a.w, bn, acc[n].w);
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      if (n < N) {                                   // uniform
+        red[threadIdx.x] = acc[n];
+        __syncthreads();
+        for (int s = TY / 2; s > 0; s >>= 1) {
+          if (ty < s) {
+            float4 o = red[threadIdx.x + s * TX], m = red[threadIdx.x];
+            red[threadIdx.x] = make_float4(m.x + o.x, m.y + o.y, m.z + o.z, m.w + o.w);
+          }
+          __syncthreads();
+        }
+        if (ty == 0 && kq < KQ) {
+          const float4 t = red[tx];
+          float* o = part + (long long)(4 * kq) * N + n;
+          o[0] = t.x; o[N] = t.y; o[2 * N] = t.z; o[3 * N] = t.w;
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
+  const int b = blockIdx.x;
+  int si = 0;
+  for (int i = 1; i < a.n_seg; ++i)
+    if (b >= a.seg[i].first) si = i;
+  const int first = a.seg[si].first, count = a.seg[si].count, kind = a.seg[si].kind;
+  const WggSrc& s = a.src[a.seg[si].src];
+  const int K = s.K, N = s.N;
+  // whole splits per XCD (workgroups are dealt round-robin to the 8 XCDs; first % 8 == 0, count % 8 == 0): the tiles that
+  // share a range of points share an L2
+  const int local = b - first;
+  const int vid = (local & 7) * (count >> 3) + (local >> 3);
+  if (kind == 3) {
+    if (vid >= s.S) return;
+    const long long p0 = (long long)vid * s.rows;
+    const long long p1 = (p0 + s.rows < s.P) ? p0 + s.rows : s.P;
+    wgrad_narrow_rows<SW_NMAX>(s.A, s.lda, s.B, s.ldb, K, N, p0, p1, s.partial + (long long)vid * K * N,
+                               reinterpret_cast<float4*>(wg_lds));
+    return;
+  }
+  int Km, Nm, tk, tn, sk, sn, tn_all;
+  wgg_plan(K, N, Km, Nm, tk, tn, sk, sn, tn_all);
+  const int tiles_n = kind == 0 ? tn : kind == 1 ? tn_all : sn;
+  const int T = (kind == 0 ? tk : kind == 1 ? sk : tk) * tiles_n;
+  const int split = vid / T, tile = vid - split * T;
+  if (split >= s.S) return;
+  const int ti = tile / tiles_n, tj = tile - ti * tiles_n;
+  const long long p_begin = (long long)split * s.rows;
+  long long p_end = p_begin + s.rows;
+  if (p_end > s.P) p_end = s.P;
+  float sa, ia, sb, ib;
+  wg_scale_from_max(*s.amax_a, sa, ia);
+  wg_scale_from_max(*s.amax_b, sb, ib);
+  float* slab = s.partial + (long long)split * K * N;
+  if (kind == 0)
+    wgrad3_tile<2, 2, 2, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, ti * WG_T, tj * WG_T, Km < K ? Km : K, Nm < N ? Nm : N,
+                            sa, ia, sb, ib, wg_lds);
+  else if (kind == 1)        // rows [Km, K) of dW, all columns
+    wgrad3_tile<1, 4, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, Km + ti * WG_STRIP, tj * WG_T, K, N, sa, ia, sb, ib, wg_lds);
+  else                       // columns [Nm, N), rows [0, Km)
+    wgrad3_tile<4, 1, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, ti * WG_T, Nm + tj * WG_STRIP, Km, N, sa, ia, sb, ib, wg_lds);
+}
+
+// out (+)= sum over the S slabs: a workgroup owns 32 vectors (VEC floats each) of one output, 8 slab phases
+template <int VEC>
+__device__ __forceinline__ void wgg_reduce_block(const WggOut& o, int blk, float* red) {
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long i = ((long long)blk * 32 + tx) * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  if (i < o.KN) {
+    const float* p = o.partial + i;
+#pragma unroll 4
+    for (int sidx = ty; sidx < o.S; sidx += 8) {
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + (long long)sidx * o.KN);
+        acc[0] += t.x; acc[1 % VEC] += t.y; acc[2 % VEC] += t.z; acc[3 % VEC] += t.w;
+      } else {
+        acc[0] += p[(long long)sidx * o.KN];
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) red[v * 256 + threadIdx.x] = acc[v];
+  __syncthreads();
+  if (ty == 0 && i < o.KN) {
+    float t[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      t[v] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[v] += red[v * 256 + q * 32 + tx];
+    }
+    if (VEC == 4) {            // contiguous, 16-byte aligned output
+      float4* dst = reinterpret_cast<float4*>(o.out + i);
+      float4 r = make_float4(t[0], t[1 % VEC], t[2 % VEC], t[3 % VEC]);
+      if (o.accum) { const float4 c = *dst; r.x += c.x; r.y += c.y; r.z += c.z; r.w += c.w; }
+      *dst = r;
+    } else {
+      const long long row = i / o.N;
+      float* dst = o.out + row * o.ldo + (i - row * o.N);
+      *dst = o.accum ? *dst + t[0] : t[0];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_wgrad_group_reduce(const WggRedArgs a) {
+  __shared__ float red[4 * 256];
+  const int b = blockIdx.x;
+  int oi = 0;
+  for (int i = 1; i < a.n_out; ++i)
+    if (b >= a.out[i].first) oi = i;
+  const WggOut& o = a.out[oi];
+  const bool vec = (o.KN & 3) == 0 && o.ldo == o.N && (reinterpret_cast<uintptr_t>(o.out) & 15) == 0;
+  if (vec) wgg_reduce_block<4>(o, b - o.first, red);
+  else wgg_reduce_block<1>(o, b - o.first, red);
+}
+
+static inline bool wgg_narrow(const float* A, int lda, int K, int N) {
+  return N <= SW_NMAX && (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+}
+
+constexpr int WGG_DEFAULT_ITEMS = 1024;     // main-tile work items a grouped launch aims for (4 per CU)
+
+// outputs [o0, o1) whose sources (those with points) and segments fit one argument block
+static int wgg_chunk_end(int o0, int n_src, const long long* P, const int* out_id, int n_out) {
+  int ns = 0, o1 = o0;
+  while (o1 < n_out && o1 - o0 < WGG_MAX_OUT) {
+    int cnt = 0;
+    for (int i = 0; i < n_src; ++i) cnt += (out_id[i] == o1 && P[i] > 0);
+    if (ns + cnt > WGG_MAX_SRC || 3 * (ns + cnt) > WGG_MAX_SEG) break;
+    ns += cnt;
+    ++o1;
+  }
+  return o1;
+}
+
+// splits / rows per split of the sources of outputs [o0, o1) -- one launch (same rule for the workspace size and the launch)
+static void wgg_split_plan(int o0, int o1, int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id,
+                           const int* K, const int* N, int target_items, int* S, long long* rows) {
+  if (target_items <= 0) target_items = WGG_DEFAULT_ITEMS;
+  double units = 0.0;               // main-tile equivalents x points
+  for (int i = 0; i < n_src; ++i) {
+    const int o = out_id[i];
+    if (o < o0 || o >= o1 || P[i] <= 0 || wgg_narrow(A ? A[i] : nullptr, lda[i], K[o], N[o])) continue;
+    units += (double)wgrad_plan(K[o], N[o]).units / 16.0 * (double)P[i];
+  }
+  long long target = (long long)(units / target_items);
+  target = (target + WG_C - 1) / WG_C * WG_C;
+  if (target < 16 * WG_C) target = 16 * WG_C;
+  for (int i = 0; i < n_src; ++i) {
+    const int o = out_id[i];
+    if (o < o0 || o >= o1) continue;
+    if (P[i] <= 0) { S[i] = 0; rows[i] = 0; continue; }
+    if (wgg_narrow(A ? A[i] : nullptr, lda[i], K[o], N[o])) {
+      rows[i] = WGG_NARROW_ROWS;
+      S[i] = (int)((P[i] + WGG_NARROW_ROWS - 1) / WGG_NARROW_ROWS);
+      continue;
+    }
+    long long s = (P[i] + target - 1) / target;
+    long long r = (P[i] + s - 1) / s;
+    r = (r + WG_C - 1) / WG_C * WG_C;
+    S[i] = (int)((P[i] + r - 1) / r);
+    rows[i] = r;
+  }
+}
+
+long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id, int n_out,
+                                const int* K, const int* N, int target_items) {
+  if (n_src <= 0 || n_src > 4096) return 0;
+  int* S = (int*)alloca(sizeof(int) * n_src);
+  long long* rows = (long long*)alloca(sizeof(long long) * n_src);
+  long long total = 0;
+  for (int o0 = 0; o0 < n_out;) {
+    const int o1 = wgg_chunk_end(o0, n_src, P, out_id, n_out);
+    if (o1 == o0) return 0;
+    wgg_split_plan(o0, o1, n_src, A, lda, P, out_id, K, N, target_items, S, rows);
+    for (int o = o0; o < o1; ++o) {
+      long long st = 0;
+      for (int i = 0; i < n_src; ++i)
+        if (out_id[i] == o) st += S[i];
+      total += (st * K[o] * N[o] + 3) / 4 * 4;
+    }
+    o0 = o1;
+  }
+  return total + 4;
+}
+
+int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb, const long long* P,
+                       const unsigned* const* amax_a, const unsigned* const* amax_b, const int* out_id, int n_out,
+                       float* const* out, const int* ldo, const int* K, const int* N, const int* accum, float* workspace,
+                       int target_items, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_group), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr = true;
+  }
+  if (n_src > 4096) return NDJIR_ERR_ARG;
+  for (int i = 0; i < n_src; ++i)
+    if (out_id[i] < 0 || out_id[i] >= n_out) return NDJIR_ERR_ARG;
+  int* S = (int*)alloca(sizeof(int) * n_src);
+  long long* rows = (long long*)alloca(sizeof(long long) * n_src);
+  long long off = 0;                 // running slab offset in the workspace (mirrors wgrad_group_workspace)
+  // one launch (+ one reduction launch) per chunk of outputs whose sources / segments fit an argument block
+  for (int o0 = 0; o0 < n_out;) {
+    const int o1 = wgg_chunk_end(o0, n_src, P, out_id, n_out);
+    if (o1 == o0) return NDJIR_ERR_UNSUPPORTED;       // one output with more sources than an argument block holds
+    wgg_split_plan(o0, o1, n_src, A, lda, P, out_id, K, N, target_items, S, rows);
+    WggArgs args{};
+    WggRedArgs red{};
+    int ns = 0;
+    for (int o = o0; o < o1; ++o) {
+      // the slabs of an output's sources are consecutive: the reduction sums S_total slabs of K * N floats
+      if (!out[o] || ldo[o] < N[o]) return NDJIR_ERR_ARG;
+      const long long kn = (long long)K[o] * N[o];
+      int s_seen = 0;
+      for (int i = 0; i < n_src; ++i) {
+        if (out_id[i] != o || S[i] <= 0) continue;
+        if (!A[i] || !B[i] || lda[i] < K[o] || ldb[i] < N[o]) return NDJIR_ERR_ARG;
+        const bool narrow = wgg_narrow(A[i], lda[i], K[o], N[o]);
+        if (!narrow && (!amax_a || !amax_b || !amax_a[i] || !amax_b[i])) return NDJIR_ERR_ARG;
+        WggSrc& s = args.src[ns++];
+        s.A = A[i]; s.B = B[i]; s.amax_a = amax_a ? amax_a[i] : nullptr; s.amax_b = amax_b ? amax_b[i] : nullptr;
+        s.partial = workspace + off + (long long)s_seen * kn;
+        s_seen += S[i];
+        s.P = P[i]; s.rows = rows[i]; s.lda = lda[i]; s.ldb = ldb[i]; s.K = K[o]; s.N = N[o]; s.S = S[i];
+      }
+      WggOut& w = red.out[red.n_out++];
+      w.out = out[o]; w.partial = workspace + off; w.KN = (int)kn; w.N = N[o]; w.ldo = ldo[o];
+      w.S = s_seen; w.accum = accum ? accum[o] : 0;
+      off += ((long long)s_seen * kn + 3) / 4 * 4;
+    }
+    // segments: main tiles of every source first, then the strips, then the narrow items
+    int blocks = 0;
+    for (int kind = 0; kind < 4; ++kind)
+      for (int i = 0; i < ns; ++i) {
+        const WggSrc& s = args.src[i];
+        const bool narrow = wgg_narrow(s.A, s.lda, s.K, s.N);
+        int items = 0;
+        if (narrow) {
+          if (kind == 3) items = s.S;
+        } else if (kind < 3) {
+          int Km, Nm, tk, tn, sk, sn, tn_all;
+          wgg_plan(s.K, s.N, Km, Nm, tk, tn, sk, sn, tn_all);
+          items = s.S * (kind == 0 ? tk * tn : kind == 1 ? sk * tn_all : tk * sn);
+        }
+        if (items <= 0) continue;
+        if (args.n_seg >= WGG_MAX_SEG) return NDJIR_ERR_UNSUPPORTED;
+        WggSeg& g = args.seg[args.n_seg++];
+        g.first = blocks; g.count = (items + 7) / 8 * 8; g.src = (short)i; g.kind = (short)kind;
+        blocks += g.count;
+      }
+    if (blocks > 0) {
+      hipLaunchKernelGGL(k_wgrad_group, dim3(blocks), dim3(WG_THREADS), 2 * (WG_T + WG_T) * WG_CP * sizeof(unsigned short), stream, args);
+      if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
+    }
+    int rb = 0;
+    for (int i = 0; i < red.n_out; ++i) {
+      WggOut& w = red.out[i];
+      const bool vec = (w.KN & 3) == 0 && w.ldo == w.N && (reinterpret_cast<uintptr_t>(w.out) & 15) == 0;
+      w.first = rb;
+      rb += (int)(((long long)w.KN + (vec ? 128 : 32) - 1) / (vec ? 128 : 32));
+    }
+    if (rb > 0) {
+      hipLaunchKernelGGL(k_wgrad_group_reduce, dim3(rb), dim3(256), 0, stream, red);
+      if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
+    }
+    o0 = o1;
+  }
+  return NDJIR_OK;
 }
 
 }  // namespace ndjir

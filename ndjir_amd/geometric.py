@@ -30,7 +30,7 @@ from torch.autograd import Function
 
 from . import lib
 from .grid_feature import _core
-from .mlp import _launch, _packed, _Strided, amax_slots, chain_workspace, colsum, grad_target, wgrad
+from .mlp import _launch, _packed, _Strided, amax_slots, chain_workspace, colsum, grad_target, wgrad, wgrad_group
 
 
 
@@ -303,18 +303,22 @@ class GeometricMain(Function):
 
         # ---- weight / bias gradients ----
         gW, gb = [None] * L, [None] * L
+        jobs = []           # dW_j = A_j^T delta_j + gbar_j^T s_j: two operand pairs per output, all layers in one grouped launch
         for j in range(L):
             if ctx.needs_input_grad[2 + NG + j]:
                 wt = grad_target(W[j])           # accumulate-in-place gradient buffer of the weight, if registered
-                dst = wt if wt is not None else wgrad(A[j], deltas[j], amax_a=am[j:j + 1], amax_b=dm[j:j + 1])
-                if wt is not None:
-                    wgrad(A[j], deltas[j], out=wt, accum=True, amax_a=am[j:j + 1], amax_b=dm[j:j + 1])
-                else:
+                dst = wt if wt is not None else torch.empty(tuple(W[j].shape), device=dev, dtype=torch.float32)
+                if wt is None:
                     gW[j] = dst
+                src = [(A[j], deltas[j], am[j:j + 1], dm[j:j + 1])]
                 if nbar is not None and j < L - 1:
-                    wgrad(gbar[j], s[j], out=dst, accum=True, amax_a=gm[j:j + 1], amax_b=sm[j:j + 1])
-                if nbar is not None and j == L - 1:
-                    dst[:, 0] += col_last
+                    src.append((gbar[j], s[j], gm[j:j + 1], sm[j:j + 1]))
+                jobs.append((dst, wt is not None, src))
+        wgrad_group(jobs)
+        for j in range(L):
+            if ctx.needs_input_grad[2 + NG + j] and nbar is not None and j == L - 1:
+                dst = grad_target(W[j]) if gW[j] is None else gW[j]
+                dst[:, 0] += col_last
             if ctx.needs_input_grad[2 + NG + L + j] and btgt[j] is None:
                 gb[j] = bgrads[j] if j < L - 1 else gb_last
         g_grids = [gdst if (ctx.needs_input_grad[2 + k] and not own) else None

@@ -47,6 +47,8 @@ SIGS = {
     "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP" + "pi" + "pp" + "Pp",
     "mlp_group_colsum": "piilip",
     "mlp_wgrad": "pipiiilpippp",
+    # n_src A lda B ldb P amax_a amax_b out_id n_out out ldo K N accum workspace target_items
+    "mlp_wgrad_group": "iPAPALPPAiPAAAApi",
     "mlp_colsum": "piilpip",
     "render_alpha_weights": "iii" + "p" * 11,
     "render_alpha_weights_backward": "iii" + "p" * 16,
@@ -163,6 +165,11 @@ def load():
         _lib.ndjir_mlp_chain_workspace.argtypes = [ctypes.c_int]
         _lib.ndjir_mlp_colsum_workspace.restype = ctypes.c_longlong
         _lib.ndjir_mlp_colsum_workspace.argtypes = [ctypes.c_int, ctypes.c_longlong]
+        _lib.ndjir_mlp_wgrad_group_workspace.restype = ctypes.c_longlong
+        _lib.ndjir_mlp_wgrad_group_workspace.argtypes = [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int),
+                                                         ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int),
+                                                         ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                                         ctypes.c_int]
         _lib.ndjir_grid_set_scatter_bins_from.restype = None
         _lib.ndjir_grid_set_scatter_bins_from.argtypes = [ctypes.c_longlong]
         _lib.ndjir_grid_get_scatter_bins_from.restype = ctypes.c_longlong
@@ -258,7 +265,7 @@ def symbols():
     """Every symbol include/ndjir_hip.h declares (for the load/export test)."""
     return ["ndjir_" + n for n in SIGS] + ["ndjir_version", "ndjir_hash_force_align", "ndjir_hash_grid_size",
                                             "ndjir_hash_table_size", "ndjir_hash_num_params",
-                                            "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_colsum_workspace",
+                                            "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_wgrad_group_workspace", "ndjir_mlp_colsum_workspace",
                                             "ndjir_mlp_chain_workspace", "ndjir_mlp_set_math", "ndjir_mlp_get_math",
                                             "ndjir_mlp_set_tile_rows", "ndjir_mlp_get_tile_rows", "ndjir_mlp_pack_entry_bytes",
                                             "ndjir_mlp_debug_timeline", "ndjir_loss_terms_workspace", "ndjir_grid_set_scatter_bins_from",

@@ -92,6 +92,10 @@ def _launch_bytes(name, args):
         return 4.0 * (P * (K + N) + K * N * (2 if int(args[8]) else 1))
     if name == "mlp_colsum":
         return 4.0 * int(args[2]) * int(args[3])
+    if name == "mlp_wgrad_group":
+        Ps, oid, Ks, Ns, acc = args[5], args[8], args[12], args[13], args[14]
+        n = sum(int(p) * (int(Ks[o]) + int(Ns[o])) for p, o in zip(Ps, oid))
+        return 4.0 * (n + sum(int(k) * int(m) * (2 if a else 1) for k, m, a in zip(Ks, Ns, acc)))
     return 0.0
 
 
@@ -359,6 +363,100 @@ def wgrad(A, B, out=None, accum=False, amax_a=None, amax_b=None):
     return out
 
 
+_WORKSPACE_G = {}
+WGRAD_GROUP_ITEMS = int(os.environ.get("NDJIR_WGRAD_ITEMS", "0"))     # work items a grouped launch aims for (0 = the library's default)
+_NO_GROUP = bool(os.environ.get("NDJIR_NO_WGRAD_GROUP"))            # A/B: every weight gradient through the per-layer kernel
+_DEFERRED = None       # None = off; else the list of pending (out, accum, sources) jobs of `deferred_wgrads`
+
+
+def _wgrad_group_now(jobs):
+    """jobs: [(out, accum, [(A, B, amax_a, amax_b), ...]), ...] -> ndjir_mlp_wgrad_group (one launch + one reduction launch
+    per 24 operand pairs)."""
+    import ctypes
+    A, lda, B, ldb, Ps, ama, amb, oid, outs, ldo, Ks, Ns, acc = ([] for _ in range(13))
+    for o, (out, accum, srcs) in enumerate(jobs):
+        K, N = out.shape
+        assert out.stride(1) == 1 or N == 1
+        outs.append(_Strided(out))
+        ldo.append(out.stride(0) if K > 1 else N)
+        Ks.append(K); Ns.append(N); acc.append(1 if accum else 0)
+        for a, b, ma, mb in srcs:
+            assert a.shape[1] == K and b.shape[1] == N and a.shape[0] == b.shape[0] and a.stride(1) == 1 and (b.stride(1) == 1 or N == 1)
+            A.append(_Strided(a)); lda.append(a.stride(0) if a.shape[0] > 1 else K)
+            B.append(_Strided(b)); ldb.append(b.stride(0) if b.shape[0] > 1 else N)
+            Ps.append(a.shape[0]); ama.append(ma); amb.append(mb); oid.append(o)
+    dev = jobs[0][0].device
+    n, m = len(A), len(jobs)
+    vp = ctypes.c_void_p
+    need = int(lib.load().ndjir_mlp_wgrad_group_workspace(
+        n, (vp * n)(*[t.data_ptr() for t in A]), (ctypes.c_int * n)(*lda), (ctypes.c_longlong * n)(*Ps), (ctypes.c_int * n)(*oid),
+        m, (ctypes.c_int * m)(*Ks), (ctypes.c_int * m)(*Ns), int(WGRAD_GROUP_ITEMS)))
+    ws = _WORKSPACE_G.get(dev)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            ws = torch.empty(need, device=dev, dtype=torch.float32)      # owned by the graph being captured, not kept
+        else:
+            ws = _WORKSPACE_G[dev] = torch.empty(max(need, 1 << 24), device=dev, dtype=torch.float32)
+    flops = 2.0 * sum(p * Ks[o] * Ns[o] for p, o in zip(Ps, oid))
+    _launch("wgrad", flops, "mlp_wgrad_group", n, A, lda, B, ldb, Ps, ama, amb, oid, m, outs, ldo, Ks, Ns, acc, ws, int(WGRAD_GROUP_ITEMS),
+            shape=f"group {m} out / {n} src {flops / 2e9:.1f} GMAC " + ",".join(f"{p}:{Ks[o]}x{Ns[o]}" for p, o in list(zip(Ps, oid))[:2]))
+
+
+def wgrad_group(jobs):
+    """Weight gradients of several layers in one launch (ndjir_amd/csrc/wgrad.hip, "grouped weight gradients").
+    jobs: list of (out, accum, sources); out (K, N) with column stride 1 (row stride free: a column slice of a parameter's
+    gradient buffer); accum: add to `out`; sources: list of (A (P, K), B (P, N), amax_a, amax_b) whose products are summed --
+    row-major views with column stride 1, recorded maxima as for `wgrad`.  Inside `deferred_wgrads()` the jobs are queued
+    and launched together when the block ends.  Operand pairs without a recorded maximum, and any arithmetic but f16x3,
+    take the per-layer kernel."""
+    jobs = [(o, a, [s for s in srcs if s[0].shape[0] > 0]) for o, a, srcs in jobs]
+    grouped = []
+    for out, accum, srcs in jobs:
+        narrow = out.shape[1] <= 8
+        ok = not _NO_GROUP and get_math() == MATH_F16X3 and out.is_cuda and srcs and all((narrow or (ma is not None and mb is not None)) for _, _, ma, mb in srcs)
+        if ok:
+            grouped.append((out, accum, srcs))
+            continue
+        first = not accum
+        if not srcs and first:
+            out.zero_()
+        for a, b, ma, mb in srcs:
+            if out.is_contiguous():
+                wgrad(a, b, out=out, accum=not first, amax_a=ma, amax_b=mb)
+            elif first:
+                out.copy_(wgrad(a, b, amax_a=ma, amax_b=mb))
+            else:
+                out.add_(wgrad(a, b, amax_a=ma, amax_b=mb))
+            first = False
+    if not grouped:
+        return
+    if _DEFERRED is not None and all(a for _, a, _ in grouped):
+        _DEFERRED.extend(grouped)
+        return
+    _wgrad_group_now(grouped)
+
+
+@contextlib.contextmanager
+def deferred_wgrads():
+    """Queue every ACCUMULATING grouped weight gradient issued inside the block (the operators' backward passes, when the
+    parameters have accumulate-in-place gradient buffers: `set_grad_buffer`) and launch them together at its end: one
+    launch for all layers of all nets of a training step.  The operands (stored activations, deltas) stay alive until
+    then.  Gradients that are returned to autograd rather than accumulated are computed at once."""
+    global _DEFERRED
+    if _DEFERRED is not None:
+        yield
+        return
+    _DEFERRED = []
+    try:
+        yield
+        jobs = _DEFERRED
+        _DEFERRED = None
+        if jobs:
+            _wgrad_group_now(jobs)
+    finally:
+        _DEFERRED = None
+
+
 def colsum(X, out=None, accum=False):
     """Column sums of a (P, N) row-major view (column stride 1): the bias gradient of a layer."""
     P, N = X.shape
@@ -564,23 +662,27 @@ class FusedMLP(Function):
         gW = [None] * L
         gb = [None] * L
         if need_w:
+            jobs = []           # every weight gradient of the net: one grouped launch (or queued: `deferred_wgrads`)
             for j in range(L):
                 if ctx.needs_input_grad[7 + j]:
+                    src = [(A[j], deltas[j], _slot(am, j), _slot(dm, j) if have_dm else None)]
                     if tail and j == L - 1:
-                        # the gradient of W[:, 1:] (contiguous) added to / placed in the parameter's columns 1..
-                        gt = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
+                        # the gradient of W[:, 1:] added to / placed in the parameter's columns 1.. (row stride = its width)
                         wt = grad_target(saved[2 * L - 1])
                         if wt is not None:
-                            wt[:, 1:].add_(gt)
+                            jobs.append((wt[:, 1:], True, src))
                         else:
                             gW[j] = torch.zeros_like(saved[2 * L - 1])
-                            gW[j][:, 1:] = gt
+                            jobs.append((gW[j][:, 1:], False, src))
                     else:
                         wt = grad_target(W[j])
                         if wt is not None:
-                            wgrad(A[j], deltas[j], out=wt, accum=True, amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
+                            jobs.append((wt, True, src))
                         else:
-                            gW[j] = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j) if have_dm else None)
+                            gW[j] = torch.empty(tuple(W[j].shape), device=x2.device, dtype=torch.float32)
+                            jobs.append((gW[j], False, src))
+            wgrad_group(jobs)
+            for j in range(L):
                 if ctx.needs_input_grad[7 + L + j]:
                     if btgt[j] is not None:
                         if j == L - 1 and gb_last is None:
@@ -735,13 +837,18 @@ class MultiMLP(Function):
                 g_rb = torch.empty((G, d0.shape[1]), device=dev, dtype=torch.float32)
                 lib.call("mlp_group_colsum", _Strided(d0), d0.stride(0), d0.shape[1], G, div, g_rb)
                 out[poff - 4] = g_rb.view(pshapes[poff - 4])
+            jobs = []
             for j in range(L):
                 if nW[j]:
+                    src = [(A[j], deltas[j], _slot(am, j), _slot(dm, j))]
                     wt = grad_target(W[j])
                     if wt is not None:
-                        wgrad(A[j], deltas[j], out=wt, accum=True, amax_a=_slot(am, j), amax_b=_slot(dm, j))
+                        jobs.append((wt, True, src))
                     else:
-                        out[wo - 4 + j] = wgrad(A[j], deltas[j], amax_a=_slot(am, j), amax_b=_slot(dm, j))
+                        out[wo - 4 + j] = torch.empty(tuple(W[j].shape), device=dev, dtype=torch.float32)
+                        jobs.append((out[wo - 4 + j], False, src))
+            wgrad_group(jobs)
+            for j in range(L):
                 if nb[j]:
                     if btgt[j] is not None:
                         if j == L - 1 and gb_last is None:

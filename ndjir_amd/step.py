@@ -12,6 +12,7 @@ into the three parts the execution schemes need:
 plus the optimizer part (`enable_training`, `train_compute`, `optimizer_step`: ndjir_amd/solver.py).  bench.py times it;
 synthetic inputs come from ndjir_amd/synthetic.py (no dataset on the box).
 """
+import contextlib
 import os
 
 import torch
@@ -164,7 +165,10 @@ class Step:
             params = [p for p in self.P.get_parameters(grad_only=True).values()]
             torch.autograd.grad(loss, params, allow_unused=True)
             return loss.detach()
-        grads = torch.autograd.grad(loss, self.mlp_params + self.grid_params, allow_unused=True)
+        # the weight gradients of every net accumulate into the bucket: queued by the operators' backward passes and issued as
+        # ONE grouped launch when the backward pass is through (ndjir_amd.mlp.deferred_wgrads; NDJIR_NO_WGRAD_DEFER: per net)
+        with (contextlib.nullcontext() if os.environ.get("NDJIR_NO_WGRAD_DEFER") else mlp.deferred_wgrads()):
+            grads = torch.autograd.grad(loss, self.mlp_params + self.grid_params, allow_unused=True)
         # what autograd still returns for an MLP parameter (stock-op paths: gains, the concatenated row blocks of the two
         # split first-layer weights) joins what the operators accumulated in place
         for v, g in zip(self.grad_views, grads):

@@ -535,3 +535,71 @@ def test_rows_except_value_gradient_and_cache(gpu):
     with torch.no_grad():
         W.mul_(3.0)
     assert torch.equal(mlp.rows_except(W, 3, 6), torch.cat([W[:3], W[6:]]).detach())
+
+
+def _group_case(rng, gpu, P, K, N, n_src, strided_out, accum, scale=1.0):
+    """one output of a grouped weight-gradient launch: operands (strided views), the destination, its fp64 reference"""
+    srcs, ref = [], torch.zeros(K, N, dtype=torch.float64)
+    for i in range(n_src):
+        Pi = P if i == 0 else max(P // 2 + 7, 1)
+        A = torch.tensor(rng.randn(Pi, K + 3) * scale, dtype=torch.float32)
+        B = torch.tensor(rng.randn(Pi, N + 5) * (3.0 + i), dtype=torch.float32)
+        ref += A[:, :K].double().t() @ B[:, 2:2 + N].double()
+        Ad, Bd = A.to(gpu)[:, :K], B.to(gpu)[:, 2:2 + N]
+        srcs.append((Ad, Bd, Ad.abs().max().reshape(1), (Bd.abs().max() * 2.0).reshape(1)))
+    base = torch.tensor(rng.randn(K, N + (1 if strided_out else 0)), dtype=torch.float32)
+    full = base.to(gpu).clone() if accum else torch.full_like(base, float("nan")).to(gpu)
+    out = full[:, 1:] if strided_out else full
+    if accum:
+        ref = ref + (base[:, 1:] if strided_out else base).double()
+    return (out, accum, srcs), ref
+
+
+@pytest.mark.parametrize("items", [64, 1024])
+def test_wgrad_group_kernel(gpu, items, monkeypatch):
+    """Many weight gradients in one launch (csrc/wgrad.hip k_wgrad_group + k_wgrad_group_reduce) vs fp64: main tiles, ragged
+    strips in K and N, streaming outputs <= 8 wide, two operand pairs of different length per output, strided and unaligned
+    destinations, accumulate and overwrite, more outputs than one argument block holds (24)."""
+    from ndjir_amd import mlp
+    monkeypatch.setattr(mlp, "WGRAD_GROUP_ITEMS", items)
+    rng = np.random.RandomState(11)
+    shapes = [(4096, 256, 256, 1), (20000, 259, 256, 2), (5000, 256, 257, 1), (3000, 43, 256, 1), (65536, 128, 6, 1), (1000, 301, 128, 2),
+              (33, 5, 7, 1), (3000, 600, 2, 1), (100, 128, 9, 1), (5000, 290, 256, 1), (777, 52, 40, 1), (3000, 300, 300, 1), (65, 39, 1, 1),
+              (2000, 128, 192, 2), (1000, 64, 64, 1), (70000, 262, 128, 1), (9000, 256, 213, 2), (512, 27, 256, 1)]
+    jobs, refs = [], []
+    for rep in range(2):            # 36 outputs, 46 operand pairs: three argument blocks
+        for i, (P, K, N, n_src) in enumerate(shapes):
+            job, ref = _group_case(rng, gpu, P, K, N, n_src, strided_out=(i % 3 == 1), accum=(i % 2 == 0), scale=10.0 ** (i % 5 - 2))
+            jobs.append(job)
+            refs.append(ref)
+    mlp.wgrad_group(jobs)
+    for (out, _, _), ref in zip(jobs, refs):
+        err = float((out.cpu().double() - ref).norm() / ref.norm())
+        assert err < 2e-6, (tuple(out.shape), err)
+
+
+def test_wgrad_group_deferred_and_fallback(gpu):
+    """`deferred_wgrads`: accumulating jobs are queued and launched at the end of the block, overwriting jobs at once; operand
+    pairs without recorded maxima take the per-layer kernel; empty operand lists leave / zero the destination."""
+    from ndjir_amd import mlp
+    rng = np.random.RandomState(12)
+    j_acc, r_acc = _group_case(rng, gpu, 3000, 128, 128, 1, False, True)
+    j_new, r_new = _group_case(rng, gpu, 3000, 100, 36, 1, True, False)
+    before = j_acc[0].clone()
+    with mlp.deferred_wgrads():
+        mlp.wgrad_group([j_acc])
+        torch.cuda.synchronize()
+        assert torch.equal(j_acc[0], before)                 # queued, not run
+        mlp.wgrad_group([j_new])                             # overwriting: runs now
+        assert float((j_new[0].cpu().double() - r_new).norm() / r_new.norm()) < 2e-6
+    assert float((j_acc[0].cpu().double() - r_acc).norm() / r_acc.norm()) < 2e-6
+    # no recorded maxima -> per-layer kernel (its own pre-pass), contiguous and strided destinations, accumulate and overwrite
+    for strided, accum in ((False, True), (True, True), (True, False), (False, False)):
+        (out, acc, srcs), ref = _group_case(rng, gpu, 2000, 130, 70, 2, strided, accum)
+        mlp.wgrad_group([(out, acc, [(a, b, None, None) for a, b, _, _ in srcs])])
+        assert float((out.cpu().double() - ref).norm() / ref.norm()) < 2e-6
+    z = torch.ones(4, 5, device=gpu)
+    mlp.wgrad_group([(z, True, [])])
+    assert torch.equal(z, torch.ones_like(z))
+    mlp.wgrad_group([(z, False, [])])
+    assert torch.equal(z, torch.zeros_like(z))
