@@ -237,6 +237,10 @@ int ndjir_inverse_transform_sample_importance_directions(int size, float* light_
                                                          int batch_size, int n_lights, int n_thes, int n_phis, float eps,
                                                          hipStream_t stream);
 
+/* Diagnostics (no reference counterpart): output[i] = ndjir_expf(input[i]) (sigmoid != 0: ndjir_sigmoidf) -- the shared
+ * definitions of include/ndjir_math.h on which the sampler's bin decisions are built, evaluated on the device so that a
+ * test can compare their bits with the host's and their values with float64 exp. */
+int ndjir_math_expf(int size, float* output, const float* input, int sigmoid, hipStream_t stream);
 /* ---- csrc/activation/squareplus_cuda.cu:62-93 (built by the reference, unused by its model) */
 int ndjir_squareplus_forward(int size, float* output, const float* input, float b, hipStream_t stream);
 int ndjir_squareplus_backward(int size, float* dinput, const float* doutput, const float* input, float b, int accum,

@@ -328,6 +328,10 @@ extern "C" int ndjir_inverse_transform_sample_importance_directions(int size, fl
   (void)batch_size; CHECK_PTRS(light_dirs, normal, cdf_the, cdf_phi, alpha);
   return launch_sample_dirs(size, light_dirs, normal, cdf_the, cdf_phi, alpha, n_lights, n_thes, n_phis, eps, st);
 }
+extern "C" int ndjir_math_expf(int size, float* output, const float* input, int sigmoid, hipStream_t st) {
+  if (size > 0 && (!output || !input)) return NDJIR_ERR_ARG;
+  return launch_math_expf(size, output, input, sigmoid, st);
+}
 extern "C" int ndjir_squareplus_forward(int size, float* output, const float* input, float b, hipStream_t st) {
   CHECK_PTRS(output, input);
   return launch_squareplus(size, false, output, nullptr, input, b, false, st);

@@ -36,6 +36,7 @@ int launch_hash_index(const GridDesc& g, long long P, float* out, const float* q
 int launch_ray_aabb(int N, float* tn, float* tf, float* nh, const float* camloc, const float* raydir, int R, const float* mn, const float* mx, hipStream_t stream);
 int launch_ray_sphere(int N, float* tn, float* tf, float* nh, const float* camloc, const float* raydir, int R, float radius, hipStream_t stream);
 int launch_sample_dirs(int size, float* light_dirs, const float* normal, const float* cdf_the, const float* cdf_phi, const float* alpha, int n_lights, int n_thes, int n_phis, float eps, hipStream_t stream);
+int launch_math_expf(int n, float* y, const float* x, int sigmoid, hipStream_t stream);
 int launch_squareplus(int n, bool bwd, float* out, const float* dy, const float* x, float b, bool accum, hipStream_t stream);
 
 }  // namespace ndjir

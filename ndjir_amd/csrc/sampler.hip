@@ -269,6 +269,19 @@ __global__ void __launch_bounds__(256) k_sampler_finish(long long R, int N, int 
   }
 }
 
+// diagnostics: the shared exp / sigmoid definitions of include/ndjir_math.h (what the sampler's bin decisions are built on)
+__global__ void __launch_bounds__(256) k_math_expf(int n, float* __restrict__ y, const float* __restrict__ x, int sigmoid) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = sigmoid ? ndjir_sigmoidf(x[i]) : ndjir_expf(x[i]);
+}
+
+
+int launch_math_expf(int n, float* y, const float* x, int sigmoid, hipStream_t stream) {
+  if (n <= 0) return NDJIR_OK;
+  hipLaunchKernelGGL(k_math_expf, dim3((n + 255) / 256), dim3(256), 0, stream, n, y, x, sigmoid);
+  return ndjir_check_launch();
+}
+
 }  // namespace ndjir
 
 extern "C" int ndjir_sampler_importance_round(int R, int N, int M, float gain, const float* t, const float* sdf,

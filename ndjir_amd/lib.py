@@ -91,6 +91,7 @@ SIGS = {
     "ray_sphere_intersection": "ipppppiif",
     "inverse_transform_sample_uniform_directions": "ippppiiiif",
     "inverse_transform_sample_importance_directions": "ipppppiiiif",
+    "math_expf": "ippi",
     "squareplus_forward": "ippf",
     "squareplus_backward": "ipppfi",
     "voxel_feature_zero_touched": "ippIiFF",

@@ -96,6 +96,7 @@ _SIGS = {
     "tv_loss_on_voxel_hash": "ipppifiiiFF",
     "tv_loss_on_voxel_hash_backward": "ippppifiiiFFi",
     "sampler_importance_round": "iiifppppp" + "Q",
+    "math_expf": "ippi",
     "squareplus_forward": "ippf",
     "squareplus_backward": "ipppfi",
 }

@@ -152,3 +152,103 @@ def test_geometric_double_backward_on_the_wide_kernel(gpu, tile, grid):
     assert float((res[128][2] - res[64][2]).abs().max()) <= 1e-5 * float(res[64][2].abs().max())
     for a, o in zip(res[128][3], res[64][3]):
         assert float((a - o).norm() / max(float(o.norm()), 1e-30)) < 2e-5
+
+
+# ---- the grid-stride tile loop of the wide kernel (mlp3w.hip: `for (tile = blockIdx.x; tile < n_tiles; tile += gridDim.x)`, the
+# xpar / cur ping-pong of the row maxima, bias-gradient sums carried across a workgroup's tiles): a workgroup takes a second
+# tile only when a launch has more than 2048 tiles, or more than CHAIN_MAX_GRID_BG = 512 when it produces bias gradients --
+# which is what the bench's 65 536 / 131 072-point backward launches do.  fp64 references run on the device (torch stock ops).
+def _rel64(a, b):
+    return float((a.detach().double() - b.detach()).norm() / max(float(b.detach().norm()), 1e-30))
+
+
+@pytest.mark.parametrize("dims,skip", [((259, 256, 256, 256, 3), -1), ((39, 128, 128, 128, 1), -1),
+                                       ((43, 256, 256, 256, 213, 256, 256, 256, 257), 3)])
+def test_tile_loop_forward_2100_tiles(gpu, tile, dims, skip):
+    """Forward chain at P = 128 x 2100: every workgroup loops over >= 2 tiles; output and every stored activation vs fp64,
+    and bitwise against the 64-point kernel (one tile per workgroup step there too, but a different kernel)."""
+    from ndjir_amd.mlp import chain_forward
+    P = 128 * 2100
+    scale = 1.0 / np.sqrt(2.0) if skip >= 0 else 1.0
+    Ws, bs = make(dims, 21, skip)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = (torch.randn(P, dims[0], generator=g) * 0.5).to(gpu)
+    Wd, bd = [w.to(gpu) for w in Ws], [b.to(gpu) for b in bs]
+    tile(0)                                   # the default dispatch: P >= 32768, P % 128 == 0 -> mlp3w.hip
+    y, hidden, am = chain_forward(x, Wd, bd, 100.0, skip, scale, keep_hidden=True)
+    h = x.double()
+    for j, (W, b) in enumerate(zip(Wd, bd)):
+        z = h @ W.double() + b.double()
+        if j == len(Wd) - 1:
+            assert _rel64(y, z) < 2e-6
+            break
+        h = torch.nn.functional.softplus(z, beta=100.0)
+        if j == skip:
+            h = torch.cat([h, x.double()], dim=-1) * scale
+        assert _rel64(hidden[j], h) < 2e-6, j
+        assert abs(float(am[j + 1]) - float(hidden[j].abs().max())) <= 1e-6 * float(hidden[j].abs().max())
+    tile(64)
+    y64, hidden64, _ = chain_forward(x, Wd, bd, 100.0, skip, scale, keep_hidden=True)
+    assert torch.equal(y, y64) and all(torch.equal(a, b) for a, b in zip(hidden, hidden64))
+
+
+@pytest.mark.parametrize("dims,skip", [((259, 256, 256, 256, 3), -1), ((39, 128, 128, 128, 1), -1), ((262, 128, 128, 128, 6), -1)])
+def test_tile_loop_backward_with_bias_gradients_1100_tiles(gpu, tile, dims, skip):
+    """Backward chain WITH bias gradients at P = 128 x 1100: the launch is clamped to 512 workgroups, each loops over 2-3
+    tiles and carries its bias-gradient sums across them; dL/dx, every dL/dW, every dL/db vs fp64 autograd."""
+    from ndjir_amd.mlp import fused_mlp
+    P = 128 * 1100
+    Ws, bs = make(dims, 23, skip)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = (torch.randn(P, dims[0], generator=g) * 0.5).to(gpu)
+    gy = torch.randn(P, dims[-1], generator=g).to(gpu)
+    tile(0)
+    xd = x.clone().requires_grad_(True)
+    Wd = [w.to(gpu).requires_grad_(True) for w in Ws]
+    bd = [b.to(gpu).requires_grad_(True) for b in bs]
+    y = fused_mlp(xd, Wd, bd, 100.0)
+    grads = torch.autograd.grad(y, [xd] + Wd + bd, gy)
+    x64 = x.double().requires_grad_(True)
+    W64 = [w.to(gpu).double().requires_grad_(True) for w in Ws]
+    b64 = [b.to(gpu).double().requires_grad_(True) for b in bs]
+    y64 = ref_mlp(x64, W64, b64, 100.0)
+    g64 = torch.autograd.grad(y64, [x64] + W64 + b64, gy.double())
+    assert _rel64(y, y64) < 2e-6
+    names = ["x"] + [f"W{j}" for j in range(len(Ws))] + [f"b{j}" for j in range(len(bs))]
+    for n, a, r in zip(names, grads, g64):
+        assert _rel64(a, r) < 2e-5, (n, _rel64(a, r))
+
+
+def test_tile_loop_tangent_chain_1100_tiles(gpu, tile):
+    """The geometric network's main pass at P = 128 x 1100 (no grid): sdf chain, TANGENT chain (mode 2, with its column sum
+    for the last layer -> clamped to 512 workgroups, 2-3 tiles each) and the augmented backward chain on the wide kernel;
+    sdf, feature, n and every parameter gradient of a loss through all three vs fp64 autograd (nn.grad's double backward,
+    python/renderer.py:52)."""
+    from ndjir_amd.geometric import geometric_main
+    from oracle import graph as G
+    P, M = 128 * 1100, 6
+    K0 = 3 + 6 * M
+    dims = (K0, 256, 256, 256, 256 - K0, 256, 256, 256, 257)
+    Ws, bs = make(dims, 29, 3)
+    c = 1.0 / np.sqrt(2.0)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = (torch.rand(P, 3, generator=g) * 1.6 - 0.8).to(gpu)
+    cot = [torch.randn(P, k, generator=g).to(gpu) for k in (1, 256, 3)]
+    tile(0)
+    Wd = [w.to(gpu).requires_grad_(True) for w in Ws]
+    bd = [b.to(gpu).requires_grad_(True) for b in bs]
+    sdf, feat, n, Z = geometric_main(x, None, Wd, bd, M, 3, c)
+    loss = (sdf * cot[0]).sum() + (feat * cot[1]).sum() + ((n * cot[2]).sum(-1) ** 2).sum()
+    grads = torch.autograd.grad(loss, Wd + bd)
+    x64 = x.double().requires_grad_(True)
+    W64 = [w.to(gpu).double().requires_grad_(True) for w in Ws]
+    b64 = [b.to(gpu).double().requires_grad_(True) for b in bs]
+    y = ref_mlp(G.positional_encoding(x64, M), W64, b64, 100.0, 3, c)
+    sdf64, feat64 = y[:, :1], y[:, 1:]
+    n64, = torch.autograd.grad(sdf64.sum(), x64, create_graph=True)
+    loss64 = (sdf64 * cot[0].double()).sum() + (feat64 * cot[1].double()).sum() + ((n64 * cot[2].double()).sum(-1) ** 2).sum()
+    g64 = torch.autograd.grad(loss64, W64 + b64)
+    assert _rel64(sdf, sdf64) < 1e-5 and _rel64(feat, feat64) < 1e-5 and _rel64(n, n64) < 2e-5
+    names = [f"W{j}" for j in range(8)] + [f"b{j}" for j in range(8)]
+    for nm, a, r in zip(names, grads, g64):
+        assert _rel64(a, r) < 1e-3, (nm, _rel64(a, r))        # (fp32 vs fp64 through the beta = 100 second-order terms)

@@ -14,10 +14,26 @@ PIXEL_TOL = 1e-4
 GRAD_RTOL = 2e-3   # fp32 round-off through double backward; fp32-vs-fp64 oracle itself shows ~1e-4
 
 
-@pytest.mark.parametrize("variant,G", [("default", 32), ("no_voxel", 8), ("triplaneline", 64), ("custom", 32), ("ste", 32)])
-def test_step_parity_given_samples(gpu, variant, G):
+@pytest.fixture
+def tile_rows(request):
+    """Points per workgroup tile of the chain kernels for the test (0 = chosen per launch).  128 sends every launch the wide
+    kernel supports to csrc/mlp3w.hip -- the kernel bench.py times; at the parity tests' 4 096 points the default would
+    pick csrc/mlp3.hip's 64 / 32-point tiles."""
+    from ndjir_amd import mlp
+    old = mlp.get_tile_rows()
+    mlp.set_tile_rows(request.param)
+    yield request.param
+    mlp.set_tile_rows(old)
+
+
+@pytest.mark.parametrize("variant,G,tile_rows", [("default", 32, 0), ("no_voxel", 8, 0), ("triplaneline", 64, 0), ("custom", 32, 0),
+                                                  ("ste", 32, 0), ("default", 32, 128), ("no_voxel", 8, 128), ("triplaneline", 64, 128)],
+                         indirect=["tile_rows"])
+def test_step_parity_given_samples(gpu, variant, G, tile_rows):
     """Renderer + loss + backward parity with the oracle fed the product's sample points.  `ste` = config/ste.yaml
-    (`voxel.use_ste`: the grid lookups stay out of n = d(sdf)/dx, python/grid_feature/voxel_feature.py:383-399)."""
+    (`voxel.use_ste`: the grid lookups stay out of n = d(sdf)/dx, python/grid_feature/voxel_feature.py:383-399).
+    tile_rows = 128: the same step with every chain launch (forward, backward, tangent; 4 096 sample points, 8 192 light
+    directions, 1 024 background samples -- all multiples of 128) on the 128-point-tile kernel."""
     conf = small_conf(grid_size=G, n_rays=16, variant=variant)
     prod = run_product_step(conf, B=2, R=16, device=gpu)
     s = prod["samples"]
@@ -201,8 +217,10 @@ def test_sampler_parity(gpu):
         assert torch.equal(rec["t_out"][u].cpu(), t_out), f"round {u}: merged distances differ"
 
 
-def test_end_to_end_including_sampler(gpu):
-    """Full path with each side running its own sampler."""
+@pytest.mark.parametrize("tile_rows", [0, 128], indirect=True)
+def test_end_to_end_including_sampler(gpu, tile_rows):
+    """Full path with each side running its own sampler (tile_rows = 128: the sampler's SDF evaluations -- 2 048 and 512
+    points per round -- and the renderer's nets on the 128-point-tile kernel)."""
     conf = small_conf(grid_size=32, n_rays=32)
     prod = run_product_step(conf, B=1, R=32, device=gpu, backward=False)
     ref = run_oracle_step(conf, prod["params_cpu"], prod["inputs_cpu"], backward=False)

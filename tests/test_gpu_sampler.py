@@ -153,3 +153,24 @@ def test_fused_sampler_equals_step_by_step(gpu, monkeypatch, variant, ov, R):
             assert torch.equal(a, b), (n, float((a - b).abs().max()))
     N = conf.renderer.n_samples0 + conf.renderer.n_samples1 * conf.renderer.n_upsamples
     assert fused[0].shape == (B, R, N, 3) and fused[1].shape == (B, R, N + 1, 1)
+
+
+def test_shared_expf_device_bits_and_accuracy(gpu):
+    """ndjir_expf / ndjir_sigmoidf of include/ndjir_math.h evaluated by the device (ndjir_math_expf, compiled in the
+    sampler's translation unit): the same BITS as the host's evaluation (what makes the sampler's bin indices bit-exact
+    between kernel and oracle) and within 1.5 / 3 ulp of float64 -- the bit-exact tests alone could not see a defect that both
+    sides share."""
+    from ndjir_amd import lib
+    from tests.test_oracle_cpu import _expf_inputs, _ulps
+    x = _expf_inputs()
+    xd = torch.from_numpy(x).to(gpu)
+    for sig, tol in ((0, 1.5), (1, 3.0)):
+        yd = torch.empty_like(xd)
+        lib.call("math_expf", x.size, yd, xd, sig)
+        y = yd.cpu().numpy()
+        yh = np.empty_like(x)
+        K.call("math_expf", x.size, yh, x, sig)
+        assert np.array_equal(y.view(np.uint32), yh.view(np.uint32)), f"{int((y.view(np.uint32) != yh.view(np.uint32)).sum())} values differ in bits"
+        x64 = x.astype(np.float64)
+        ref = np.exp(np.clip(x64, -87.0, 88.0)) if sig == 0 else 1.0 / (1.0 + np.exp(np.clip(-x64, -87.0, 88.0)))
+        assert float(_ulps(y, ref).max()) <= tol

@@ -208,3 +208,27 @@ def test_hash_table_layout_quirks():
         assert K.hash_num_params(G0, gf, T0, L, D) == C.compute_num_params(G0, gf, T0, D, L)
         for l in range(L):
             assert K.hash_grid_size(G0, gf, l) == C.compute_grid_size(G0, gf, l)
+
+
+def _expf_inputs():
+    rng = np.random.RandomState(3)
+    x = np.concatenate([np.linspace(-87.0, 88.0, 400001), rng.uniform(-87.0, 88.0, 200000), rng.uniform(-1.0, 1.0, 100000),
+                        np.asarray([0.0, -0.0, 1e-30, -1e-30, 88.0, -87.0, 100.0, -100.0, 0.6931472, -0.6931472])])
+    return x.astype(np.float32)
+
+
+def _ulps(y, ref64):
+    return np.abs(y.astype(np.float64) - ref64) / np.spacing(ref64.astype(np.float32)).astype(np.float64)
+
+
+def test_shared_expf_against_float64():
+    """include/ndjir_math.h (shared by the sampler kernel and the oracle, so a defect in it would be invisible to the bit-exact
+    sampler tests): ndjir_expf within 1.5 ulp of float64 exp over the clamped range, ndjir_sigmoidf within 3 ulp."""
+    x = _expf_inputs()
+    y = np.empty_like(x)
+    K.call("math_expf", x.size, y, x, 0)
+    xc = np.clip(x.astype(np.float64), -87.0, 88.0)           # the definition clamps its argument
+    assert float(_ulps(y, np.exp(xc)).max()) <= 1.5
+    s = np.empty_like(x)
+    K.call("math_expf", x.size, s, x, 1)
+    assert float(_ulps(s, 1.0 / (1.0 + np.exp(np.clip(-x.astype(np.float64), -87.0, 88.0)))).max()) <= 3.0
