@@ -6,11 +6,58 @@ random 2^a x 2^b patch (`_generate_patch_rays`, :58-84) or with a fixed share in
 (`_generate_mask_rays`, :86-108) -- and `train.py:124-133` copies colours, mask, and the host-computed rays to the device.
 Here the scene lives on the device once; an iteration draws the pixel INDICES on the host with the reference's own
 sequence of numpy RNG calls (so the same pixels are read), uploads those few KB, gathers colours and mask on the device
-and generates the rays there (`ndjir_generate_raydir_camloc`).  Loading the files (imageio / cv2 camera decomposition,
-:110-140) is outside the hot path and not part of this module: construct it from arrays.
+and generates the rays there (`ndjir_generate_raydir_camloc`).  `load_idr_scene` reads a scene directory in the IDR / DTU
+layout (`_load_data`, :110-140: image/*, mask/*, cameras.npz with world_mat_i / scale_mat_i) -- the camera decomposition
+without OpenCV (`helper.load_K_Rt_from_P`), the images through PIL.
 """
+import glob
+import os
+
 import numpy as np
 import torch
+
+
+def _read_image(path, gray=False):
+    if path.endswith(".npy"):
+        return np.load(path)
+    try:
+        from PIL import Image
+    except ImportError as e:      # (the reference reads through imageio / nnabla's image_utils)
+        raise ImportError(f"reading {path} needs PIL; store the scene's images as .npy arrays otherwise") from e
+    with Image.open(path) as im:
+        return np.asarray(im.convert("F")) if gray else np.asarray(im.convert("RGB"))
+
+
+def load_idr_scene(path):
+    """python/dataset.py:110-140 (`IDRDataSource._load_data`): every image / mask / camera of a scene directory
+
+        <path>/image/*      RGB images (sorted by name; .png / .jpg through PIL, or .npy (H, W, 3) uint8)
+        <path>/mask/*       object masks, thresholded at 127.5 of their grey value
+        <path>/cameras.npz  world_mat_<i>, scale_mat_<i> (4 x 4) per image
+
+    -> dict(images (M,H,W,3) float32 in [0,1], masks (M,H,W,1) float64 in {0,1}, intrinsics (M,3,3), poses (M,4,4) float32
+    camera-to-world, scale, trans).  P_i = (world_mat_i @ scale_mat_i)[:3, :4] in float32 as in the reference, decomposed by
+    `helper.load_K_Rt_from_P`; `scale` / `trans` are those of the LAST scale matrix (the reference's loop variable)."""
+    from .helper import load_K_Rt_from_P
+    image_files = sorted(glob.glob(os.path.join(path, "image", "*")))
+    mask_files = sorted(glob.glob(os.path.join(path, "mask", "*")))
+    if not image_files:
+        raise FileNotFoundError(f"no images under {os.path.join(path, 'image')}")
+    images = np.asarray([_read_image(f) for f in image_files]) / 255.0
+    masks = np.asarray([np.asarray(_read_image(f, gray=True), np.float64).reshape(images.shape[1], images.shape[2], -1)[:, :, :1] > 127.5
+                        for f in mask_files]) * 1.0
+    cameras = np.load(os.path.join(path, "cameras.npz"))
+    intrinsics, poses = [], []
+    S = np.eye(4, dtype=np.float32)
+    for idx in range(len(images)):
+        W = cameras["world_mat_%d" % idx].astype(np.float32)
+        S = cameras["scale_mat_%d" % idx].astype(np.float32)
+        P = (W @ S)[:3, :4]
+        intrinsic, pose = load_K_Rt_from_P(P)
+        intrinsics.append(intrinsic[:3, :3])
+        poses.append(pose)
+    return dict(images=images.astype(np.float32), masks=masks, intrinsics=np.asarray(intrinsics), poses=np.asarray(poses),
+                scale=S[0, 0], trans=S[:3, 3])
 
 
 class IDRRaySource:
@@ -31,6 +78,15 @@ class IDRRaySource:
         self.poses = torch.from_numpy(np.ascontiguousarray(poses, np.float64)).to(self.device)
         self._position = 0
         self.reset()
+
+    @classmethod
+    def from_path(cls, path, conf, shuffle=False, rng=None, device=None):
+        """The scene directory `path` (IDR / DTU layout, `load_idr_scene`) on the device; `scale` / `trans` as attributes
+        (python/dataset.py:135-136: read by the mesh extraction to map back to the scan's coordinates)."""
+        d = load_idr_scene(path)
+        src = cls(d["images"], d["masks"], d["intrinsics"], d["poses"], conf, shuffle=shuffle, rng=rng, device=device)
+        src.scale, src.trans = d["scale"], d["trans"]
+        return src
 
     @property
     def size(self):

@@ -455,6 +455,47 @@ def test_training_iterations_on_the_device_data_feed(gpu):
         P.clear_parameters()
 
 
+def test_training_iterations_from_a_scene_directory(gpu, tmp_path):
+    """f2 end to end: a synthetic scene on disk in the IDR / DTU layout (image/, mask/, cameras.npz with world_mat_i and a
+    scale_mat_i of non-unit scale and translation) -> `IDRRaySource.from_path` (camera decode without OpenCV) -> device ray
+    feed -> three training iterations.  The rays of the device feed equal the reference's numpy ray generation on the
+    decoded cameras (python/helper.py:44-73), colours / masks are the image's pixels."""
+    from ndjir_amd import config as cfg, parameter as P
+    from ndjir_amd.dataset import IDRRaySource
+    from ndjir_amd.grid_feature import set_grad_buffer
+    from ndjir_amd.helper import generate_raydir_camloc
+    from ndjir_amd.step import Step
+    from tests.test_dataset_cpu import write_idr_scene
+    R = 64
+    conf = cfg.load("default", ["geometric_network.voxel.grid_size=32", f"train.n_rays={R}", "train.batch_size=1"])
+    path = str(tmp_path / "scan")
+    images, masks, cams, _ = write_idr_scene(path, M=3, H=24, W=32, seed=4)
+    src = IDRRaySource.from_path(path, conf, rng=np.random.RandomState(313), device=gpu)
+    assert src.size == 3 and abs(float(src.scale) - 2.5) < 1e-6
+    img, idx = src.pixel_indices(0)
+    color, mask, raydir, camloc = src.next_batch(1)
+    xy = np.stack([idx % 32, idx // 32], axis=-1)[None]
+    rd, cl = generate_raydir_camloc(src.poses[img:img + 1].cpu().numpy(), src.intrinsics[img:img + 1].cpu().numpy(), xy)
+    assert float(np.abs(raydir.cpu().numpy() - rd).max()) <= 1e-6 and float(np.abs(camloc.cpu().numpy() - cl).max()) <= 1e-6
+    np.testing.assert_allclose(camloc.cpu().numpy()[0], cams[img][2], atol=1e-4)           # the camera the scene was written with
+    np.testing.assert_allclose(color.cpu().numpy()[0], images[img].reshape(-1, 3)[idx] / 255.0, atol=1e-6)
+    assert np.array_equal(mask.cpu().numpy()[0, :, 0], (masks[img].reshape(-1)[idx] > 127.5) * 1.0)
+    step = Step(conf, R, gpu, 0, 1)
+    try:
+        step.enable_training()
+        gen = torch.Generator(device=gpu).manual_seed(0)
+        for it in range(3):
+            color, mask, raydir, camloc = src.next_batch(1)
+            step.set_rays(camloc, raydir, color)
+            step.redraw_rand(gen)
+            assert np.isfinite(float(step.train_step())), it
+        assert step.solvers.solver_feat.step_count() == 3 and not step.solvers.solver_feat.skipped()
+    finally:
+        for p in step.grid_params:
+            set_grad_buffer(p, None)
+        P.clear_parameters()
+
+
 @pytest.mark.parametrize("gtype,G,D", [("cosine_voxel", 16, 4), ("lanczos_triplaneline", 32, 4), ("cosine_triplaneline", 32, 8),
                                        ("triplane", 32, 8)])
 def test_step_parity_other_grid_types(gpu, gtype, G, D):
