@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
                                                       long long KN, int S, int accum) {
   // one float4 of the output per thread; 8 independent loads in flight per thread
   const long long n4 = KN >> 2;
-  const bool vec = ((KN & 3) == 0);
+  const bool vec = ((KN & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);      // (out may be a view into a flat gradient bucket at any 4-byte offset)
   if (vec) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -103,24 +103,38 @@ def grid_group(group=None):
     return _GRID_GROUP[key]
 
 
-def _state(buf, capacity, world):
+def _state(buf, capacity, world, group=None):
+    """Exchange state of a dense gradient buffer: the packed lists (own and gathered), counts, flags, statistics.  Created at
+    the buffer's first exchange -- on every rank in the same call, so it may hold a collective: the list CAPACITY is the
+    maximum over the ranks of their worst cases (every stencil cell of the rank's query points distinct), because the wire
+    size derived from it must be the same number everywhere even when the ranks have different numbers of query points.
+    Fixed from then on: a rank whose query points outgrow it is an error (re-creating the state on one rank alone would
+    issue a collective the others do not)."""
     st = _STATE.get(buf.data_ptr())
     D = buf.shape[-1]
     cells = buf.numel() // D
-    if st is None or st["cells"] != cells or st["cap"] < capacity or st["world"] != world:
-        dev = buf.device
-        st = dict(cells=cells, cap=capacity, world=world, limit=None, calls=0,
-                  bitmap=torch.zeros((cells + 31) // 32, dtype=torch.int32, device=dev),
-                  count=torch.zeros(1, dtype=torch.int32, device=dev),
-                  overflow=torch.zeros(1, dtype=torch.int32, device=dev),
-                  stats=torch.zeros(2, dtype=torch.int32, device=dev),
-                  limit_dev=torch.zeros(1, dtype=torch.int32, device=dev),
-                  ids=torch.empty(capacity, dtype=torch.int32, device=dev),
-                  rows=torch.empty((capacity, D), dtype=torch.float32, device=dev),
-                  ids_all=torch.zeros((world, capacity), dtype=torch.int32, device=dev),
-                  rows_all=torch.empty((world, capacity, D), dtype=torch.float32, device=dev),
-                  counts_all=torch.zeros(world, dtype=torch.int32, device=dev))
-        _STATE[buf.data_ptr()] = st
+    if st is not None and st["cells"] == cells and st["world"] == world:
+        if capacity > st["cap"]:
+            raise RuntimeError(f"sparse grid exchange: {capacity} stencil cells exceed the list capacity {st['cap']} fixed at the "
+                               "buffer's first exchange (the number of query points per rank grew)")
+        return st
+    dev = buf.device
+    if world > 1:
+        caps = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(caps, torch.tensor([capacity], dtype=torch.int64, device=dev), group=group)
+        capacity = min(cells, max(int(c.item()) for c in caps))
+    st = dict(cells=cells, cap=capacity, world=world, limit=None, calls=0,
+              bitmap=torch.zeros((cells + 31) // 32, dtype=torch.int32, device=dev),
+              count=torch.zeros(1, dtype=torch.int32, device=dev),
+              overflow=torch.zeros(1, dtype=torch.int32, device=dev),
+              stats=torch.zeros(2, dtype=torch.int32, device=dev),
+              limit_dev=torch.zeros(1, dtype=torch.int32, device=dev),
+              ids=torch.empty(capacity, dtype=torch.int32, device=dev),
+              rows=torch.empty((capacity, D), dtype=torch.float32, device=dev),
+              ids_all=torch.zeros((world, capacity), dtype=torch.int32, device=dev),
+              rows_all=torch.empty((world, capacity, D), dtype=torch.float32, device=dev),
+              counts_all=torch.zeros(world, dtype=torch.int32, device=dev))
+    _STATE[buf.data_ptr()] = st
     return st
 
 
@@ -153,7 +167,7 @@ def exchange_grid_rows_hip(buf, family, queries, min_=(-1.0, -1.0, -1.0), max_=(
         gs, sub, nd = [buf.shape[1]] * 3, 3, (2 if topo == 1 else 1)
     cells = buf.numel() // D
     cap = min(cells, sum(q.numel() // 3 for q in queries) * sub * _TAPS[interp] ** nd)
-    st = _state(buf, cap, world)
+    st = _state(buf, cap, world, group)
     cap = st["cap"]
     st["count"].zero_()
     for q in queries:
@@ -163,13 +177,18 @@ def exchange_grid_rows_hip(buf, family, queries, min_=(-1.0, -1.0, -1.0), max_=(
     lib.call("sparse_rows_clear_bitmap", st["ids"], st["count"], cap, st["bitmap"])
     counts = st["counts_all"]
     gg = grid_group(group) if world > 1 else group
-    _gather_into(counts, st["count"], world, gg)
+    if "flat" not in st:
+        st["flat"] = _flat_gather_supported(gg, buf.device) if dist.is_initialized() else True
+    flat = st["flat"]
+    _gather_into(counts, st["count"], world, gg, flat)
     st["calls"] += 1
     if st["limit"] is None or st["calls"] % CHECK_EVERY == 0:
         # the only host synchronisation, once per CHECK_EVERY exchanges: the largest list of THIS exchange and the running
         # maximum the device has kept over all exchanges since the last look (k_rows_overflow), so that an overflow on any of
         # the steps in between grows the limit, not only one on the step that happens to be looked at
         most = max(int(counts.max().item()), int(st["stats"][0].item()))
+        # (the same number on every rank: it comes from the gathered counts and is clipped by the list capacity, which
+        # `_state` made the same on every rank -- ranks that disagreed here would disagree on the size of the collective)
         assert most <= cap, "more distinct cells than stencil taps"
         want = min(cap, max(4096, -(-int(most * 1.5) // 4096) * 4096))
         if st["limit"] is None or want > st["limit"]:
@@ -179,21 +198,43 @@ def exchange_grid_rows_hip(buf, family, queries, min_=(-1.0, -1.0, -1.0), max_=(
     # every rank's first m rows, packed (world, m): the layout all_gather_into_tensor fills without per-rank copies
     ids = st["ids_all"].view(-1)[:world * m].view(world, m)
     rows = st["rows_all"].view(-1)[:world * m * D].view(world, m, D)
-    _gather_into(ids, st["ids"][:m], world, gg)
-    _gather_into(rows, st["rows"][:m], world, gg)
+    _gather_into(ids, st["ids"][:m], world, gg, flat)
+    _gather_into(rows, st["rows"][:m], world, gg, flat)
     lib.call("sparse_rows_overflow", counts, world, m, st["overflow"], st["stats"])
     lib.call("sparse_rows_apply", ids, rows, counts, world, m, m, rank, buf, D)
     return SparseRows(st, rank)
 
 
-def _gather_into(out, mine, world, group):
-    """out (world, ...) <- every rank's `mine` (...): one collective into one contiguous tensor."""
+_FLAT_GATHER = {}      # (group, device type) -> does the backend implement all_gather_into_tensor
+
+
+def _flat_gather_supported(group, device):
+    """Probed ONCE per (group, device type) with a tiny tensor, when the exchange state of a buffer is created -- every rank
+    probes at the same point of the same call sequence and a backend's capability is the same on all of them.  The exchanges
+    themselves never catch an error around a collective: a failure on one rank must not make it issue a different
+    collective than the others."""
+    key = (id(group), device.type)
+    if key not in _FLAT_GATHER:
+        world = dist.get_world_size(group)
+        probe_out = torch.zeros(world, dtype=torch.int32, device=device)
+        try:
+            dist.all_gather_into_tensor(probe_out, torch.zeros(1, dtype=torch.int32, device=device), group=group)
+            _FLAT_GATHER[key] = True
+        except (RuntimeError, NotImplementedError):      # a backend without the flat form: the list form from now on
+            _FLAT_GATHER[key] = False
+    return _FLAT_GATHER[key]
+
+
+def _gather_into(out, mine, world, group, flat=True):
+    """out (world, ...) <- every rank's `mine` (...): one collective into one contiguous tensor (`flat`: the backend has
+    all_gather_into_tensor, see `_flat_gather_supported`; else the list form writes the same rows)."""
     if world == 1 and not dist.is_initialized():
         out.view(-1).copy_(mine.reshape(-1))
         return
-    try:
-        dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
-    except (RuntimeError, NotImplementedError):          # a backend without the flat form
+    if flat:
+        # the concatenating form on 1-D views (gloo accepts no other shape pairing; out is contiguous by construction)
+        dist.all_gather_into_tensor(out.view(-1), mine.contiguous().view(-1), group=group)
+    else:
         dist.all_gather(list(out.unbind(0)), mine.contiguous(), group=group)
 
 

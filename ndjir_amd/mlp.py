@@ -178,8 +178,10 @@ def _tracked(W, transpose):
         e.W, e.transpose, e.K, e.N, e.ldw = W.detach(), transpose, K, N, W.stride(0)
         e.dst = torch.empty(lib.load().ndjir_mlp_packed_size(K, N, int(transpose)), device=W.device, dtype=torch.float32)
         e.version = None
-        if len(_TRACK) > 2048:
-            _TRACK.clear()
+        if len(_TRACK) >= 8192:
+            # never dropped while tracking is on: a captured training graph holds the buffers' addresses.  A store this large
+            # means weights are being re-created every step (new data_ptr each time) -- a caller bug, not a cache policy
+            raise lib.NdjirHipError("tracked packed-weight store: more than 8192 (weight, orientation) entries")
         _TRACK[key] = e
         _TRACK_TABLE = None
     v = _base_version(W)
@@ -194,6 +196,12 @@ def repack_tracked():
     right after its update -- inside the captured training graph when there is one."""
     global _TRACK_TABLE
     if not _TRACK:
+        return
+    if get_math() != MATH_F16X3:
+        # the table launch exists for the f16x3 packing only (set_math / NDJIR_MLP_MATH A/B runs with live tracked entries):
+        # mark every entry stale instead -- it re-packs on its next use, like an untracked weight whose version moved
+        for e in _TRACK.values():
+            e.version = None
         return
     _refresh_row_copies()          # (rows_except's copies are tracked weights too: bring them up to date first)
     if _TRACK_TABLE is None:
@@ -243,6 +251,29 @@ def set_grad_buffer(p, buf):
 
 def clear_grad_buffers():
     del _GRAD_BUF[:]
+
+
+@contextlib.contextmanager
+def grad_buffers(pairs):
+    """(parameter, buffer) pairs registered as accumulate-in-place gradients for the duration of the block only -- what
+    `Step.compute` wraps its forward + backward in.  The registry is process-global: a registration that outlives its
+    owner's backward pass would make every other first-order backward over the same parameters (a validation pass, a
+    second consumer) return no gradient for them and add into the owner's buffer instead.  Entries registered by
+    `set_grad_buffer` outside a block stay as they are (single-owner use: tests, scripts)."""
+    added = []
+    for p, buf in pairs:
+        assert p.is_contiguous() and buf.is_contiguous() and buf.shape == p.shape and buf.dtype == p.dtype
+        e = (p.data_ptr(), p.numel() * p.element_size(), buf)
+        _GRAD_BUF.append(e)
+        added.append(e)
+    try:
+        yield
+    finally:
+        for e in added:
+            for i in range(len(_GRAD_BUF) - 1, -1, -1):
+                if _GRAD_BUF[i] is e:
+                    del _GRAD_BUF[i]
+                    break
 
 
 def grad_target(t):

@@ -134,9 +134,11 @@ class Adam:
         self._check()
         return bool(self.flag.item())
 
-    def update(self, guard_flags=None):
+    def update(self, guard_flags=None, repack=True):
         """One Adam step.  guard_flags: (flag_a, flag_b) device ints -- the update is skipped on the device when both
-        are raised (python/solver.py:67-69); None = unconditional, as nnabla's `update()`."""
+        are raised (python/solver.py:67-69); None = unconditional, as nnabla's `update()`.  repack: refresh the tracked
+        packed weights afterwards (`Solvers` does it once for both of its solvers instead: a hash grid's 2-D feature table
+        would otherwise trigger a second launch)."""
         fa, fb = guard_flags if guard_flags is not None else (None, None)
         lib.call("solver_adam_begin", self.state, self.beta1, self.beta2, fa, fb)
         scales = self._decay_scales
@@ -168,7 +170,7 @@ class Adam:
                      self.beta2, self.eps, d, self.state)
         for p in self.params:            # kernels wrote the parameters behind autograd's back: packed-weight caches etc.
             torch.autograd.graph.increment_version(p)
-        if any(p.dim() == 2 for p in self.params):
+        if repack and any(p.dim() == 2 for p in self.params):
             # the MLP weights' packed (MFMA fragment order) copies: ONE launch over every tracked (weight, orientation)
             # instead of one pack launch per weight and orientation at their next use (ndjir_amd/mlp.py `track_weights`)
             from . import mlp
@@ -213,8 +215,15 @@ class Solvers:
         self.solver_feat.set_gradients(grads, touched)
 
     def update(self):
-        self.solver_weight.update()
-        self.solver_feat.update()
+        self.solver_weight.update(repack=False)
+        self.solver_feat.update(repack=False)
+        self._repack()
+
+    @staticmethod
+    def _repack():
+        """ONE re-pack launch for the tracked packed weights after both solvers' updates (ndjir_amd/mlp.py `repack_tracked`)."""
+        from . import mlp
+        mlp.repack_tracked()
 
     def guarded_update(self, loss=None):
         """`if check_inf_or_nan_grad(): continue`, `if isnan(loss): continue`, `update()` (python/train.py:141-148)
@@ -224,8 +233,9 @@ class Solvers:
         flags = (self.solver_weight.flag, self.solver_feat.flag)
         if loss is not None:        # a NaN loss vetoes the step whatever the gradients look like: raise both flags
             lib.call("solver_veto_if_nan", 1, loss.detach().reshape(1), flags[0], flags[1])
-        self.solver_weight.update(flags)
-        self.solver_feat.update(flags)
+        self.solver_weight.update(flags, repack=False)
+        self.solver_feat.update(flags, repack=False)
+        self._repack()
 
     def zero_grad(self):
         self.solver_weight.zero_grad()

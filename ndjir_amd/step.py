@@ -78,12 +78,16 @@ class Step:
         self.grad_views, off = [], 0
         from ndjir_amd import mlp
         self.in_place = device.type == "cuda" and not os.environ.get("NDJIR_NO_GRAD_BUFFERS")
+        # (parameter, view) pairs registered with the MLP operators ONLY while `compute` runs (mlp.grad_buffers): any other
+        # backward pass over the same parameters -- a validation pass, a second consumer -- gets ordinary autograd gradients
+        # and cannot pollute the bucket
+        self._grad_pairs = []
         for p in self.mlp_params:
             v = self.flat_grad[off:off + p.numel()].view(p.shape)
             off += p.numel()
             self.grad_views.append(v)
             if self.in_place and p.is_contiguous():
-                mlp.set_grad_buffer(p, v)
+                self._grad_pairs.append((p, v))
 
     def set_rays(self, camloc, raydir, color_gt, obj_mask=None):
         """Feed the next iteration's rays (python/train.py:124-133: `raydir.d = ...`, `camloc.d = ...`, `color_gt.d = ...`,
@@ -157,18 +161,25 @@ class Step:
         if rearm:
             self.rearm_grid_buffers()
         use_mask = self.conf.train.mask_weight > 0.0
-        out = total_loss(self.camloc, self.raydir, self.color_gt, self.obj_mask if use_mask else None, self.car, self.conf,
-                         self.rand, ray_shards=self.world, mask_sum_global=self.mask_sum if self.multi else None,
-                         obj_mask_sum_global=self.obj_mask_sum if (self.multi and use_mask) else None)
-        loss = out["loss"]
         if self.mlp_names is None:
+            out = total_loss(self.camloc, self.raydir, self.color_gt, self.obj_mask if use_mask else None, self.car, self.conf,
+                             self.rand, ray_shards=self.world, mask_sum_global=self.mask_sum if self.multi else None,
+                             obj_mask_sum_global=self.obj_mask_sum if (self.multi and use_mask) else None)
+            loss = out["loss"]
             params = [p for p in self.P.get_parameters(grad_only=True).values()]
             torch.autograd.grad(loss, params, allow_unused=True)
             return loss.detach()
-        # the weight gradients of every net accumulate into the bucket: queued by the operators' backward passes and issued as
-        # ONE grouped launch when the backward pass is through (ndjir_amd.mlp.deferred_wgrads; NDJIR_NO_WGRAD_DEFER: per net)
-        with (contextlib.nullcontext() if os.environ.get("NDJIR_NO_WGRAD_DEFER") else mlp.deferred_wgrads()):
-            grads = torch.autograd.grad(loss, self.mlp_params + self.grid_params, allow_unused=True)
+        # forward and backward run with the bucket's views registered as the parameters' accumulate-in-place gradients (the
+        # operators look their targets up in both passes); the weight gradients of every net are queued by the operators'
+        # backward passes and issued as ONE grouped launch when the backward pass is through (ndjir_amd.mlp.deferred_wgrads;
+        # NDJIR_NO_WGRAD_DEFER: one launch per net)
+        with mlp.grad_buffers(self._grad_pairs):
+            out = total_loss(self.camloc, self.raydir, self.color_gt, self.obj_mask if use_mask else None, self.car, self.conf,
+                             self.rand, ray_shards=self.world, mask_sum_global=self.mask_sum if self.multi else None,
+                             obj_mask_sum_global=self.obj_mask_sum if (self.multi and use_mask) else None)
+            loss = out["loss"]
+            with (contextlib.nullcontext() if os.environ.get("NDJIR_NO_WGRAD_DEFER") else mlp.deferred_wgrads()):
+                grads = torch.autograd.grad(loss, self.mlp_params + self.grid_params, allow_unused=True)
         # what autograd still returns for an MLP parameter (stock-op paths: gains, the concatenated row blocks of the two
         # split first-layer weights) joins what the operators accumulated in place
         for v, g in zip(self.grad_views, grads):
@@ -217,7 +228,8 @@ class Step:
     def exchange_report(self):
         """Host-side numbers of the sparse grid exchange since the step was built (one synchronisation: reports / tests /
         the end of a bench run, not the step): exchanges that overflowed the wire size -- their grid gradient was
-        incomplete --, the largest list seen, the wire size, and the optimizer steps vetoed for it."""
+        incomplete --, the largest list seen over ALL exchanges so far (a running maximum the device keeps; never reset),
+        the wire size, and the optimizer steps vetoed for an overflow (one per step, however many buffers overflowed)."""
         from ndjir_amd.distributed import SparseRows
         rep = {}
         for name, h in self.remote_rows.items():
@@ -271,13 +283,18 @@ class Step:
     def optimizer_step(self):
         self.set_solver_gradients()
         loss = self.loss
-        for flag in getattr(self, "exchange_overflow", []):
+        flags = getattr(self, "exchange_overflow", [])
+        if flags:
             # (device-side: an overflowing sparse exchange turns the loss the guard sees into NaN, which skips the update;
-            # the skips are counted -- `exchange_report` -- and the wire size grows at the exchange's next look at the
-            # device's running maximum, ndjir_amd/distributed.py)
-            loss = torch.where(flag > 0, torch.full_like(loss, float("nan")), loss)
-            self.vetoed_steps += (flag > 0).to(torch.int32)
-            flag.zero_()
+            # the skip is counted ONCE per optimizer step however many buffers overflowed -- `exchange_report` -- and the
+            # wire size grows at the exchange's next look at the device's running maximum, ndjir_amd/distributed.py)
+            any_flag = flags[0] > 0
+            for flag in flags[1:]:
+                any_flag = any_flag | (flag > 0)
+            loss = torch.where(any_flag, torch.full_like(loss, float("nan")), loss)
+            self.vetoed_steps += any_flag.to(torch.int32)
+            for flag in flags:
+                flag.zero_()
         self.solvers.guarded_update(loss)     # python/train.py:141-146: non-finite gradients or a NaN loss skip the update
 
     def set_solver_gradients(self):

@@ -82,3 +82,76 @@ def test_bench_graph_replay_around_rccl_calls(gpu):
     assert res2.returncode == 0, res2.stderr[-3000:]
     d2 = json.loads(res2.stdout.strip().splitlines()[-1])
     assert d["loss"] == pytest.approx(d2["loss"], rel=1e-6)
+
+
+def _launch(world, mode, out, port, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "multi_rank_worker2.py"), mode, out]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-3000:]
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("world", [4, 8])
+def test_sparse_exchange_overflow_and_limit_growth(gpu, world):
+    """ndjir_amd/distributed.py `exchange_grid_rows_hip` at world 4 and 8 (3 / 7 remote lists per rank): equal to a dense
+    all-reduce; a wire size cut below the lists raises the device flag on every rank, counts the exchange in the device
+    statistics and delivers an incomplete sum WITHOUT touching the wire size; at the next look (every CHECK_EVERY exchanges,
+    from the running maximum the device kept) the wire grows and the sums are whole again."""
+    with tempfile.TemporaryDirectory() as out:
+        _launch(world, "exchange", out, 29551 + world)
+        recs = [torch.load(os.path.join(out, f"rank{r}.pt")) for r in range(world)]
+    for r, rec in enumerate(recs):
+        assert rec["world"] == world and rec["first_ok"] and rec["first_overflow"] == 0 and rec["zero_ok"], (r, rec)
+        assert rec["first_limit"] >= max(x["n_own"] for x in recs), (r, rec)          # every rank sized the wire for the largest list
+        assert rec["cut_overflow_flag"] == 1 and rec["cut_incomplete"] and rec["cut_limit_unchanged"], (r, rec)
+        assert rec["cut_stats"][0] >= max(x["n_own"] for x in recs) and rec["cut_stats"][1] >= 1, (r, rec)
+        assert rec["cut3_limit"] == 4096, (r, rec)                                     # no look between the checks
+        assert rec["grown_limit"] >= max(x["n_own"] for x in recs) and rec["grown_ok"], (r, rec)
+        assert rec["overflowed_exchanges"] == 2 and rec["after_ok"], (r, rec)          # exchanges 2 and 3 overflowed, 4 did not
+    assert len({rec["grown_limit"] for rec in recs}) == 1                              # ... and they agree on the new wire size
+
+
+@pytest.mark.timeout(1200)
+def test_overflowing_exchange_vetoes_the_optimizer_step(gpu):
+    """Step.optimizer_step under an overflowing sparse exchange (4 ranks): the update is skipped on the device (solver step
+    counter and weights unchanged, python/train.py:141-146's skip), counted once per step, and reported."""
+    world = 4
+    with tempfile.TemporaryDirectory() as out:
+        _launch(world, "veto", out, 29571)
+        recs = [torch.load(os.path.join(out, f"rank{r}.pt")) for r in range(world)]
+    for r, rec in enumerate(recs):
+        assert np.isfinite(rec["l0"]) and np.isfinite(rec["l1"]), (r, rec)
+        assert rec["steps_after"] == rec["steps_before"] and rec["weights_unchanged"], (r, rec)
+        assert rec["report"]["vetoed_optimizer_steps"] == 1, (r, rec)
+        b = rec["report"]["buffers"]["geometric-network/voxel_feature/F"]
+        assert b["overflowed_exchanges"] == 1 and b["largest_list"] > 4096 and b["wire_rows"] == 4096, (r, rec)
+
+
+@pytest.mark.timeout(900)
+def test_render_image_on_two_ranks_equals_one_process(gpu):
+    """renderer.render_image(rank, world) (BASELINE.json config 5's tiling, python/renderer.py:212-272): two processes render
+    alternate tiles and sum their partial frames over torch.distributed -- the frame of the single-process render, bit for
+    bit (a pixel is written by exactly one rank); each partial frame holds its rank's tiles only."""
+    from ndjir_amd import network, parameter as P
+    from ndjir_amd.renderer import render_image
+    from tests.parity_utils import small_conf
+    with tempfile.TemporaryDirectory() as out:
+        _launch(2, "render", out, 29581)
+        parts = [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(2)]
+        parts = [dict(img=p["img"], part=p["part"]) for p in parts]
+    conf = small_conf(grid_size=16, n_rays=16, overrides=["valid.n_rays=48", "valid.n_down_samples=0"])
+    P.clear_parameters()
+    P.set_device(gpu)
+    network.seed(313)
+    pose = np.eye(4, dtype=np.float64)[None]
+    pose[0, :3, 3] = [0.0, 0.0, -2.5]
+    K = np.array([[[20.0, 0, 8], [0, 20.0, 6], [0, 0, 1]]])
+    img = render_image(pose, K, (16, 12), conf, device=gpu)
+    np.testing.assert_array_equal(parts[0]["img"], img)
+    np.testing.assert_array_equal(parts[1]["img"], img)
+    np.testing.assert_array_equal(parts[0]["part"] + parts[1]["part"], img)
+    flat = [p["part"].reshape(3, -1).sum(0) for p in parts]
+    assert not np.any((flat[0] != 0) & (flat[1] != 0))                    # disjoint tiles
+    P.clear_parameters()
