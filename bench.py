@@ -9,14 +9,15 @@ samples, 128 lights), synthetic rays, reference-initialised weights.  Rays shard
 (weak scaling: 512 rays per GPU); one gradient exchange per step over RCCL.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 
-`roofline` is for the hand-written kernel class with the largest time per step -- since round 2 the fused MLP BACKWARD chain
-(`ndjir::x3w::k_chainw<1, 4>` / `<1, 2>`, csrc/mlp3w.hip; `ndjir::x3::k_chain3` for small launches or NDJIR_MLP_TILE=64;
-`ndjir::x6::k_chain6` / `ndjir::k_mlp_chain` with NDJIR_MLP_MATH=bf16x6 / fp32): achieved = sum of the algorithmic FLOPs
-(2*in*out per affine per point) of its launches / sum of their durations, measured live with HIP events recorded on
-the launching stream around every launch.  In the default f16x3 arithmetic one algorithmic FLOP costs three f16 MFMA FLOPs, so
-the peak it is priced against is the dense 16-bit MFMA peak / 3 (bf16x6: / 6).  `kernels` lists every class of the engine (forward /
-backward / tangent chains, weight gradients) with launches and time per step and both yardsticks (that peak, and the fp32-input
-MFMA peak).  `--scaling strong --total-rays 4096 --config no_voxel` is BASELINE.json's config 4 (rays split over the ranks).
+`roofline` is for the hand-written KERNEL (one symbol, as rocprofv3 prints it; the library reports which kernel a launch runs:
+ndjir_mlp_chain_kernel) with the largest time per step: achieved = sum of the algorithmic FLOPs (2*in*out per affine per point,
+SURVEY 8d) / bytes of ITS launches / sum of their durations, measured live with HIP events recorded on the launching stream
+around every launch.  In the default f16x3 arithmetic one algorithmic FLOP costs three f16 MFMA FLOPs, so the matrix peak it is
+priced against is the dense 16-bit MFMA peak / 3 (bf16x6: / 6).  `kernels_by_symbol` lists every kernel of the engine that way,
+`kernels` the same launches by class (forward / backward / tangent chains, weight gradients), each with both yardsticks.
+`b4` = the reference's real training-step shape, 4 images x 512 rays (config/default.yaml:126-127); `redraw` = replays with
+new pixels (device data feed) and new random tensors before every replay, as a training loop has them.
+`--scaling strong --total-rays 4096 --config no_voxel` is BASELINE.json's config 4 (rays split over the ranks).
 Execution: the compute part of the step (ndjir_amd/step.py `Step.compute`: no collective inside) is captured once
 into a HIP graph and the timed region replays it (`--exec graph`, default; no host-side launch work in the timed
 region; N > 1: the scalar mask all-reduce and the gradient exchange are issued eagerly around every replay).  HIP events
@@ -45,7 +46,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_BF16X6_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_F16X3_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def parse():
@@ -67,6 +68,9 @@ def parse():
                          "eagerly around every replay); 'eager' = ordinary stream launches.  Falls back to "
                          "eager if the capture fails on any rank or replaying is not faster.")
     ap.add_argument("--cpu-rays", type=int, default=32)
+    ap.add_argument("--no-extra-legs", dest="extra_legs", action="store_false",
+                    help="skip the `redraw` (new pixels + new random tensors before every replay) and `b4` (4 images x R rays, the "
+                         "reference's training-step shape) side measurements")
     ap.add_argument("--train-steps", type=int, default=10,
                     help="after the fwd+bwd measurement: time this many full training iterations (fwd+bwd + the two Adam "
                          "solvers with weight decay, python/train.py:136-148) and report them as `train_step`; 0 = skip")
@@ -185,6 +189,68 @@ def replay_step(step, graph):
     step.exchange()
 
 
+def redraw_leg(step, graph, steps, barrier):
+    """The timed replays again, but as a training loop sees them (python/train.py:124-133): before every replay the next
+    batch of pixels comes from the device data feed (ndjir_amd/dataset.py: new rays, colours -- other grid cells than the
+    step before) and every random tensor is redrawn on the device.  The headline number replays ONE set of rays, whose
+    ~1.6 M touched grid cells can sit in the 256 MiB Infinity Cache from replay to replay; this one cannot."""
+    import copy
+    import numpy as np
+    from ndjir_amd.dataset import IDRRaySource
+    from ndjir_amd.synthetic import make_scene
+    conf = copy.deepcopy(step.conf)
+    conf.train.n_rays = step.R
+    images, masks, Ks, poses = make_scene(8, 256, 256, seed=5)
+    src = IDRRaySource(images, masks, Ks, poses, conf, rng=np.random.RandomState(313), device=step.device)
+    gen = torch.Generator(device=step.device).manual_seed(0)
+
+    def one():
+        color, _mask, raydir, camloc = src.next_batch(step.B)
+        step.set_rays(camloc, raydir, color)
+        step.redraw_rand(gen)
+        if graph is not None:
+            graph.replay()
+        else:
+            step.forward_backward()
+    for _ in range(2):
+        one()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    barrier()
+    el = time.perf_counter() - t0
+    loss = float(step.loss)
+    return {"ms_per_step": 1e3 * el / steps, "rays_per_s": step.B * step.R * steps / el, "steps": steps, "loss": loss,
+            "scope": "fwd+bwd replays with the next batch from the device data feed (8 synthetic views, 256 x 256) and freshly "
+                     "drawn random tensors before every replay; includes the feed's launches and one small host->device copy"}
+
+
+def b4_leg(conf, R, device, steps, barrier, use_graph):
+    """The reference's real training-step shape: train.batch_size = 4 images x train.n_rays = 512 rays
+    (config/default.yaml:126-127, python/train.py:38-51), forward + backward.  Beside the headline metric (B = 1), not it."""
+    step = Step(conf, R, device, 0, 1, B=4)
+    for _ in range(2):
+        step.forward_backward()
+    graph, mode = None, "eager stream launches"
+    if use_graph:
+        try:
+            graph, _ = capture_step(step)
+            mode = "one captured HIP graph per step"
+        except Exception:
+            torch.cuda.synchronize()
+    fn = (lambda: replay_step(step, graph)) if graph is not None else step.forward_backward
+    fn()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier()
+    el = time.perf_counter() - t0
+    return {"ms_per_step": 1e3 * el / steps, "rays_per_s": 4 * R * steps / el, "steps": steps, "images": 4, "rays_per_image": R,
+            "execution": mode, "loss": float(step.loss)}
+
+
 def train_leg(step, steps, barrier, use_graph):
     """Full training iterations (fwd+bwd + optimizer), timed like the main region.  Reported next to the headline
     metric, never as it: the metric is fwd+bwd (BASELINE.json)."""
@@ -283,12 +349,12 @@ def committed_pmc_traffic(kernels):
         return None
 
 
-def kernel_report(profile):
-    """Aggregate the live HIP-event records of the MLP engine (ndjir_amd.mlp.PROFILE)."""
+def kernel_report(profile, by_symbol=False):
+    """Aggregate the live HIP-event records of the MLP engine (ndjir_amd.mlp.PROFILE) by class, or by kernel symbol."""
     agg = {}
-    for kind, flops, e0, e1, _shape, nbytes in profile:
-        a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0])
-        a[0] += 1
+    for kind, flops, e0, e1, _shape, nbytes, sym, n_kernels in profile:
+        a = agg.setdefault(sym if by_symbol else kind, [0, 0.0, 0.0, 0.0])
+        a[0] += n_kernels            # (a grouped weight-gradient call = one kernel launch per argument block)
         a[1] += flops
         a[2] += e0.elapsed_time(e1) * 1e-3
         a[3] += nbytes
@@ -316,30 +382,28 @@ def kernel_table(kr, steps, peak):
     return out
 
 
-def kernel_symbol(kind, math):
-    """(symbol as rocprofv3 prints it, description) of the kernel a class of the engine's launches runs."""
+def kernel_description(sym, math):
     from ndjir_amd import mlp
-    mode = {"chain_fwd": 0, "chain_bwd": 1, "chain_tan": 2}.get(kind.replace("_t32", ""))
-    what = {0: "forward", 1: "backward", 2: "tangent"}.get(mode, "")
-    if kind.startswith("wgrad"):
-        return "ndjir::k_wgrad3<2, 2, 2, 2>", "weight gradient A^T delta, P split over workgroups (csrc/wgrad.hip)"
-    if math == mlp.MATH_F16X3:
-        if kind.endswith("_t32") or os.environ.get("NDJIR_MLP_TILE") in ("32", "64"):
-            t = os.environ.get("NDJIR_MLP_TILE", "32")
-            return f"ndjir::x3::k_chain3<{mode}, {t}>", f"fused MLP {what} chain, {t}-point tiles (csrc/mlp3.hip)"
-        return (f"ndjir::x3w::k_chainw<{mode}, 4, 8>",
-                f"fused MLP {what} chain on 128-point tiles, epilogue in the accumulator registers (csrc/mlp3w.hip; the 128-wide "
-                f"nets run the <{mode}, 2, 8> instantiation, the forward of the two light nets <0, 4, 4>): fp32 operands scaled by powers of two and split into 2 f16 planes, 3 "
-                "v_mfma_f32_32x32x16_f16 partial products per fp32 product in two fp32 accumulators")
-    if math == mlp.MATH_BF16X6:
-        return f"ndjir::x6::k_chain6<{mode}, 64>", f"fused MLP {what} chain; 3 bf16 planes, 6 partial products per fp32 product"
-    return f"ndjir::k_mlp_chain<{mode}, 64>", f"fused MLP {what} chain, fp32 MFMA 32x32x2"
+    if "k_wgrad" in sym:
+        return ("weight gradients A^T delta of every layer of the step in one grouped launch (csrc/wgrad.hip k_wgrad_group: 128 x 128 "
+                "tiles, P split over workgroups) + the split reduction k_wgrad_group_reduce; the event interval spans both")
+    what = {"<0": "forward", "<1": "backward", "<2": "tangent"}.get(sym[sym.find("<"):sym.find("<") + 2], "")
+    if "k_chainw" in sym:
+        return (f"fused MLP {what} chain on 128-point tiles, epilogue in the accumulator registers (csrc/mlp3w.hip; template "
+                "arguments: mode, row blocks per wave -- 4: nets up to 256 wide, 2: up to 128 wide --, waves per workgroup): fp32 "
+                "operands scaled by powers of two and split into 2 f16 planes, 3 v_mfma_f32_32x32x16_f16 partial products per fp32 "
+                "product in two fp32 accumulators")
+    if "k_chain3" in sym:
+        return f"fused MLP {what} chain, 64 / 32-point tiles (csrc/mlp3.hip; small launches: the sampler's rounds, per-ray nets)"
+    if "k_chain6" in sym:
+        return f"fused MLP {what} chain; 3 bf16 planes, 6 partial products per fp32 product (csrc/mlp6.hip)"
+    return f"fused MLP {what} chain, fp32 MFMA 32x32x2 (csrc/mlp.hip)"
 
 
 def kernel_detail(profile, steps):
     """Per (kind, shape) table of the engine's launches -> stderr (NDJIR_BENCH_DETAIL=1)."""
     agg = {}
-    for kind, flops, e0, e1, shape, nbytes in profile:
+    for kind, flops, e0, e1, shape, nbytes, _sym, _n in profile:
         a = agg.setdefault((kind, shape), [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
@@ -483,7 +547,19 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         profile, mlp.PROFILE = mlp.PROFILE, None
+    ranks_info = None
     if world > 1:
+        # what the collective library saw: one line per rank (device, its own time over the timed region), so that a scaling
+        # record can be checked for "N ranks on N devices" and for the spread between them
+        import torch.distributed as dist
+        mine = dict(rank=rank, local_rank=local_rank, device=torch.cuda.current_device(), name=torch.cuda.get_device_name(),
+                    pci=getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "pci_bus_id", None),
+                    ms_per_step=1e3 * el / a.steps)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_info = dict(world_size=dist.get_world_size(), backend=dist.get_backend(), devices=gathered,
+                          ms_per_step_min=min(g["ms_per_step"] for g in gathered),
+                          ms_per_step_max=max(g["ms_per_step"] for g in gathered))
         t = torch.tensor([el], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
@@ -500,12 +576,16 @@ def main():
         math = mlp.get_math()
         x6, x3 = math == mlp.MATH_BF16X6, math == mlp.MATH_F16X3
         peak = PEAK_F16X3_EFFECTIVE_TFLOPS if x3 else PEAK_BF16X6_EFFECTIVE_TFLOPS if x6 else PEAK_FP32_MFMA_TFLOPS
-        # the roofline block is for the kernel class with the largest time per step (the backward chain since round 2)
+        # the roofline block is for the KERNEL (one symbol, as rocprofv3 prints it) with the largest time per step, with its
+        # own launches' FLOPs and bytes -- not a class average over several instantiations
         table = kernel_table(kr, profile_steps, peak)
-        cands = [k for k in ("chain_fwd", "chain_bwd", "chain_tan", "wgrad") if k in table]
-        dom_kind = max(cands, key=lambda k: table[k]["ms_per_step"]) if cands else "chain_fwd"
-        dom = kr.get(dom_kind, dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0, tbps=0.0, mbytes_per_launch=0.0))
-        ksym, kname = kernel_symbol(dom_kind, math)
+        ks = kernel_report(profile, by_symbol=True)
+        sym_table = kernel_table(ks, profile_steps, peak)
+        ksym = max(sym_table, key=lambda k: sym_table[k]["ms_per_step"]) if sym_table else "none"
+        dom = ks.get(ksym, dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0, tbps=0.0, mbytes_per_launch=0.0))
+        dom_kind = next((rec[0] for rec in profile if rec[6] == ksym), "none")
+        kname = kernel_description(ksym, math)
+        pmc_syms = ["ndjir::k_wgrad_group", "ndjir::k_wgrad_group_reduce"] if "k_wgrad_group" in ksym else [ksym]
         peak_note = ("dense 16-bit MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 3 partial products per algorithmic FLOP" if x3 else
                      "dense bf16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 6 partial products per algorithmic FLOP" if x6 else
                      "fp32-input MFMA peak (MI355X_MICROARCH.md)")
@@ -538,14 +618,12 @@ def main():
                        "rays_per_gpu": R, "samples_per_ray": N, "parallelism": f"ray-sharded x{world}",
                        **({"total_rays": a.total_rays} if a.scaling == "strong" else {})},
             "roofline": {**roof_top,
-                         "traffic": committed_pmc_traffic([ksym, ksym.replace(", 4, 8>", ", 2, 8>"), ksym.replace(", 4, 8>", ", 4, 4>")]),
-                         "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes "
-                                         f"of this command, profiles/{PROFILE_ROUND}_pmc_hbm_bench.txt (launch-weighted over the class's two "
-                                         "instantiations <mode, 4, 8>, <mode, 2, 8> (and <0, 4, 4>)), beside `hbm.algorithmic_mbytes_per_launch`"
-                                         ": the stored activations the chain reads (backward / tangent) and the activations / "
-                                         "deltas it writes for the weight gradients",
+                         "traffic": (sum(t for t in (committed_pmc_traffic(x) for x in pmc_syms) if t) or None),
+                         "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) of " + " + ".join(pmc_syms) + " from the "
+                                         f"committed rocprofv3 --pmc passes of this command, profiles/{PROFILE_ROUND}_pmc_hbm_bench.txt, "
+                                         "beside `hbm.algorithmic_mbytes_per_launch` (null: no committed pass lists the symbol)",
                          "mfma": roof_mfma, "hbm": roof_hbm,
-                         "kernel": kname, "peak_note": peak_note,
+                         "kernel_symbol": ksym, "kernel": kname, "peak_note": peak_note,
                          # the same algorithmic fp32 FLOP/s against the fp32-input MFMA peak (what an fp32 GEMM engine could
                          # reach at best on this chip) and against the bf16x6 engine's effective peak (round 1's yardstick)
                          "frac_of_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
@@ -554,11 +632,10 @@ def main():
                          "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
                          "kernel_class": dom_kind,
                          "ms_per_step": table.get(dom_kind, {}).get("ms_per_step"),
-                         "note": "the kernel class with the largest time per step (`kernels` lists all of them with both "
-                                 "yardsticks); large launches only (small ones use mlp3.hip's 32-point-tile instantiation, listed "
-                                 "as *_t32); an event interval spans the launch gap of the host-bound eager pass as well as the "
-                                 "kernel, ~5-7 % more than rocprofv3's kernel-only average in "
-                                 f"profiles/{PROFILE_ROUND}_bench_kernel_summary.txt",
+                         "note": "the kernel symbol with the largest time per step (`kernels_by_symbol` lists every kernel of the "
+                                 "engine with both yardsticks, `kernels` the same launches by class); an event interval spans the "
+                                 "launch gap of the host-bound eager pass as well as the kernel, ~5-7 % more than rocprofv3's "
+                                 f"kernel-only average in profiles/{PROFILE_ROUND}_bench_kernel_summary.txt",
                          "method": ("HIP events on the launching stream around every launch of the same K steps issued "
                                     "eagerly right after the timed graph replays (events cannot be recorded inside a "
                                     "captured graph)") if exec_mode == "graph" else
@@ -566,6 +643,7 @@ def main():
                                     "the timed region (N > 1)") if world > 1 else
                                    "HIP events on the launching stream around every launch in the timed region"},
             "kernels": table,
+            "kernels_by_symbol": sym_table,
             "step_roofline": {"achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",
                               "frac": step_tflops / peak,
                               "scope": "whole step: 2168.9 MFLOP/ray fwd+bwd (SURVEY 8d) / step time",
@@ -576,6 +654,8 @@ def main():
                               "executed_tflops": step_tflops * (2168.9 - 323.1 + 128 * 0.786944) / 2168.9},
             "loss": float(loss),
         }
+        if ranks_info is not None:
+            out["ranks"] = ranks_info
         if step.multi:
             # an exchange that overflowed its wire size delivered an incomplete grid gradient: the measurement must say so
             rep = step.exchange_report()
@@ -595,6 +675,11 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
+    if world == 1 and not force_dist and a.extra_legs:
+        try:
+            out["redraw"] = redraw_leg(step, graph if exec_mode == "graph" else None, a.steps, barrier)
+        except Exception as e:      # a side measurement must never take the headline number down with it
+            out["redraw"] = {"error": f"{type(e).__name__}: {e}"}
     if a.train_steps > 0:
         tl = train_leg(step, a.train_steps, barrier, use_graph=(a.exec_mode or os.environ.get("NDJIR_BENCH_EXEC") or "graph") == "graph")
         if world > 1:
@@ -606,6 +691,13 @@ def main():
             tl["scope"] = ("fwd+bwd + weight decay + finite-gradient guard + Adam update of every parameter "
                            "(python/train.py:136-148); reported beside the headline metric, not as it")
             out["train_step"] = tl
+    if world == 1 and not force_dist and a.extra_legs:
+        try:
+            del step
+            graph = None
+            out["b4"] = b4_leg(conf, R, device, a.steps, barrier, (a.exec_mode or os.environ.get("NDJIR_BENCH_EXEC") or "graph") == "graph")
+        except Exception as e:
+            out["b4"] = {"error": f"{type(e).__name__}: {e}"}
     if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
     if rank == 0:

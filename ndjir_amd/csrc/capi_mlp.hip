@@ -59,6 +59,7 @@ extern "C" int ndjir_mlp_pack_table(const void* table, int n, int total_blocks, 
 extern "C" int ndjir_mlp_pack_entry_bytes(void) { return (int)sizeof(PackEntry); }
 
 static long long* g_timeline = nullptr;   // diagnostics only, see ndjir_mlp_debug_timeline
+static char* g_dry_name = nullptr;        // diagnostics only, set for the duration of ndjir_mlp_chain_kernel
 
 // Points per workgroup tile of the chain kernels: 0 = chosen per launch (128 for large launches the wide-tile kernel
 // supports, else 64, 32 for small launches); 32 / 64 / 128 force one (128: where supported).  Results do not depend on it.
@@ -101,6 +102,7 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
   a.tile_rows = forced ? forced : ((P + 63) / 64 < 256 ? 32 : 64);
   a.forced_tile = forced;
   a.timeline = g_timeline;
+  a.dry_name = g_dry_name;
   a.bg_partial = workspace;
   if (row_bias && (bwd != 0 || L < 2 || row_bias_div < 1)) return NDJIR_ERR_ARG;
   a.row_bias = row_bias; a.row_bias_div = row_bias_div;
@@ -168,6 +170,26 @@ extern "C" int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx
                     row_bias, row_bias_div, in_bgrad, workspace, side_amax, x_amax, stream);
 }
 
+// Diagnostics: the symbol (as rocprofv3 prints it) of the kernel a chain launch of this shape would run -- the launchers' own
+// decision code, nothing is launched.  bench.py keys its per-kernel roofline table by it.
+extern "C" int ndjir_mlp_chain_kernel(int mode, long long P, int K0, int L, const int* Ks, const int* Ns, int has_output,
+                                      int skip_layer, int with_bias_gradients, char* name, int name_bytes) {
+  if (!name || name_bytes < 64 || mode < 0 || mode > 2 || L < 1 || L > MAX_CHAIN_LAYERS || !Ks || !Ns || P <= 0) return NDJIR_ERR_ARG;
+  static float dummy[4];          // (never dereferenced: the launchers return before any launch)
+  const float* wp[MAX_CHAIN_LAYERS];
+  const float* side[MAX_CHAIN_LAYERS];
+  float* bg[MAX_CHAIN_LAYERS];
+  for (int i = 0; i < L; ++i) { wp[i] = dummy; side[i] = dummy; bg[i] = (with_bias_gradients && mode != 0) ? dummy : nullptr; }
+  g_dry_name = name;
+  name[0] = 0;
+  const int rc = chain_impl(mode, P, dummy, K0, K0, L, wp, nullptr, Ks, Ns, mode != 0 ? side : nullptr, nullptr, nullptr,
+                            mode != 0 ? bg : nullptr, dummy, Ns[L - 1], 0, has_output, 100.f, skip_layer, 1.f,
+                            (mode == 1 && skip_layer >= 0) ? Ns[skip_layer] : 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                            nullptr, dummy, nullptr, nullptr, nullptr);
+  g_dry_name = nullptr;
+  return rc;
+}
+
 extern "C" long long ndjir_mlp_chain_workspace(int bgrad_total) { return chain_workspace(bgrad_total); }
 
 extern "C" long long ndjir_mlp_wgrad_workspace(int K, int N, long long P) { return wgrad_workspace(K, N, P); }
@@ -186,6 +208,11 @@ extern "C" long long ndjir_mlp_wgrad_group_workspace(int n_src, const float* con
   for (int i = 0; i < n_src; ++i)
     if (out_id[i] < 0 || out_id[i] >= n_out) return 0;
   return wgrad_group_workspace(n_src, A, lda, P, out_id, n_out, K, N, target_items);
+}
+
+extern "C" int ndjir_mlp_wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n_out) {
+  if (n_src <= 0 || n_out <= 0 || !P || !out_id) return 0;
+  return wgrad_group_launches(n_src, P, out_id, n_out);
 }
 
 extern "C" int ndjir_mlp_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb,

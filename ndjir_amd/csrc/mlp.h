@@ -50,6 +50,8 @@ struct ChainArgs {
   int bg_total, bg_lds; // filled by launch_chain: accumulator floats / its offset in LDS
   unsigned* x_amax;     // f16x3 engine: atomicMax of the largest finite |X| (bit pattern; caller zeroes), may be null
   long long* timeline;  // diagnostics (tools/chain_timeline.py): per-layer phase stamps of workgroup 0, else null
+  char* dry_name;       // diagnostics (ndjir_mlp_chain_kernel): non-null = write the symbol of the kernel the launcher picks
+                        // (64 bytes) and return WITHOUT launching
   ChainLayer layers[MAX_CHAIN_LAYERS];
 };
 
@@ -86,6 +88,7 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
 // many weight gradients in one launch + one split-reduction launch (f16x3 arithmetic; wgrad.hip "grouped weight gradients")
 long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id, int n_out,
                                 const int* K, const int* N, int target_items);
+int wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n_out);
 int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb, const long long* P,
                        const unsigned* const* amax_a, const unsigned* const* amax_b, const int* out_id, int n_out,
                        float* const* out, const int* ldo, const int* K, const int* N, const int* accum, float* workspace,

@@ -22,6 +22,7 @@
 //   - The +4 pad makes the epilogue's ds_write_b32 of a 32x32 accumulator conflict-free.
 // Packed weight layout (pack kernel below): Wp[nb][kb][lane][j] = W[8*kb + 4*(lane>>5) + j][32*nb + (lane&31)].
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -617,6 +618,7 @@ int launch_chain(const ChainArgs& a, int mode, hipStream_t stream) {
 #undef NDJIR_SET
     attr_set = true;
   }
+  if (a.dry_name) { snprintf(a.dry_name, 64, "ndjir::k_mlp_chain<%d, %d>", mode, TM); return NDJIR_OK; }
 #define NDJIR_GO(M, T) hipLaunchKernelGGL((k_mlp_chain<M, T>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b)
   if (TM == 64) { if (mode == 0) NDJIR_GO(0, 64); else if (mode == 1) NDJIR_GO(1, 64); else NDJIR_GO(2, 64); }
   else { if (mode == 0) NDJIR_GO(0, 32); else if (mode == 1) NDJIR_GO(1, 32); else NDJIR_GO(2, 32); }

@@ -25,6 +25,7 @@
 //                     phase B: per-row scale from the maximum, staging tile -> 2-way split, planes updated in place
 //                     barrier
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -1017,6 +1018,7 @@ int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream) {
 #undef NDJIR_SET
     attr_set = true;
   }
+  if (a.dry_name) { snprintf(a.dry_name, 64, "ndjir::x3::k_chain3<%d, %d>", mode, TM); return NDJIR_OK; }
 #define NDJIR_GO(M, T) hipLaunchKernelGGL((k_chain3<M, T>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b)
   if (TM == 64) { if (mode == 0) NDJIR_GO(0, 64); else if (mode == 1) NDJIR_GO(1, 64); else NDJIR_GO(2, 64); }
   else { if (mode == 0) NDJIR_GO(0, 32); else if (mode == 1) NDJIR_GO(1, 32); else NDJIR_GO(2, 32); }

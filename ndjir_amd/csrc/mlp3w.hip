@@ -18,6 +18,7 @@
 // mlp3.hip: a point's forward result is bit-identical whichever kernel evaluates it (tests/test_gpu_mlp.py).
 // Launched for P % 128 == 0, P >= 32768, hidden layers of at most 8 column blocks; everything else stays with mlp3.hip.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -747,6 +748,11 @@ int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) {
     const char* e = getenv("NDJIR_CHAINW_NW4");
     nw4 = e ? atoi(e) : 1;
     attr_set = true;
+  }
+  if (a.dry_name) {
+    const bool four = rpw != 4 && ((nw4 >> mode) & 1) && lds_bytes <= 77 * 1024;
+    snprintf(a.dry_name, 64, "ndjir::x3w::k_chainw<%d, %d, %d>", mode, (rpw == 4 || four) ? 4 : 2, four ? 4 : 8);
+    return NDJIR_OK;
   }
 #define NDJIR_GO(M, R, W) hipLaunchKernelGGL((k_chainw<M, R, W>), dim3((unsigned)blocks), dim3(W * 64), lds_bytes, stream, b)
   if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4, 8); else if (mode == 1) NDJIR_GO(1, 4, 8); else NDJIR_GO(2, 4, 8); }

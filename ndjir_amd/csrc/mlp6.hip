@@ -21,6 +21,7 @@
 // The epilogue math, the side-array protocol (ChainArgs) and the bias-gradient path are those of
 // mlp.hip; only the matrix arithmetic and the LDS formats differ.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -618,6 +619,7 @@ int launch_chain6(const ChainArgs& a, int mode, hipStream_t stream) {
 #undef NDJIR_SET
     attr_set = true;
   }
+  if (a.dry_name) { snprintf(a.dry_name, 64, "ndjir::x6::k_chain6<%d, %d>", mode, TM); return NDJIR_OK; }
 #define NDJIR_GO(M, T) hipLaunchKernelGGL((k_chain6<M, T>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b)
   if (TM == 64) { if (mode == 0) NDJIR_GO(0, 64); else if (mode == 1) NDJIR_GO(1, 64); else NDJIR_GO(2, 64); }
   else { if (mode == 0) NDJIR_GO(0, 32); else if (mode == 1) NDJIR_GO(1, 32); else NDJIR_GO(2, 32); }

@@ -1316,6 +1316,18 @@ static void wgg_split_plan(int o0, int o1, int n_src, const float* const* A, con
   }
 }
 
+// launches of k_wgrad_group (= launches of k_wgrad_group_reduce) a grouped call issues: one per argument block
+int wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n_out) {
+  int n = 0;
+  for (int o0 = 0; o0 < n_out;) {
+    const int o1 = wgg_chunk_end(o0, n_src, P, out_id, n_out);
+    if (o1 == o0) return -1;
+    ++n;
+    o0 = o1;
+  }
+  return n;
+}
+
 long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id, int n_out,
                                 const int* K, const int* N, int target_items) {
   if (n_src <= 0 || n_src > 4096) return 0;

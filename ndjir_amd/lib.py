@@ -266,10 +266,10 @@ def symbols():
     """Every symbol include/ndjir_hip.h declares (for the load/export test)."""
     return ["ndjir_" + n for n in SIGS] + ["ndjir_version", "ndjir_hash_force_align", "ndjir_hash_grid_size",
                                             "ndjir_hash_table_size", "ndjir_hash_num_params",
-                                            "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_wgrad_group_workspace", "ndjir_mlp_colsum_workspace",
+                                            "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_wgrad_group_workspace", "ndjir_mlp_wgrad_group_launches", "ndjir_mlp_colsum_workspace",
                                             "ndjir_mlp_chain_workspace", "ndjir_mlp_set_math", "ndjir_mlp_get_math",
                                             "ndjir_mlp_set_tile_rows", "ndjir_mlp_get_tile_rows", "ndjir_mlp_pack_entry_bytes",
-                                            "ndjir_mlp_debug_timeline", "ndjir_loss_terms_workspace", "ndjir_grid_set_scatter_bins_from",
+                                            "ndjir_mlp_debug_timeline", "ndjir_mlp_chain_kernel", "ndjir_loss_terms_workspace", "ndjir_grid_set_scatter_bins_from",
                                             "ndjir_grid_get_scatter_bins_from"]
 
 

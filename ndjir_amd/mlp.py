@@ -54,8 +54,35 @@ def _init_math():
         set_math({"fp32": MATH_FP32, "bf16x6": MATH_BF16X6, "f16x3": MATH_F16X3}[env.lower()])
 
 # Optional live timing of the engine's launches with HIP events on the launching stream
-# (bench.py sets PROFILE = [] around its timed region): entries (kind, algorithmic_flops, e0, e1, shape, algorithmic_bytes).
+# (bench.py sets PROFILE = [] around its timed region): entries (kind, algorithmic_flops, e0, e1, shape, algorithmic_bytes,
+# kernel symbol, kernel launches the call issued).
 PROFILE = None
+
+
+def chain_kernel_symbol(mode, P, K0, Ks, Ns, has_output=True, skip_layer=-1, with_bias_gradients=False):
+    """The symbol (as rocprofv3 prints it) of the kernel a chain launch of this shape runs under the current arithmetic and
+    tile setting: the library's own dispatch decision (ndjir_mlp_chain_kernel), nothing is launched."""
+    import ctypes
+    L = len(Ks)
+    buf = ctypes.create_string_buffer(64)
+    f = lib.load().ndjir_mlp_chain_kernel
+    f.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+    f.restype = ctypes.c_int
+    rc = f(int(mode), int(P), int(K0), L, (ctypes.c_int * L)(*[int(k) for k in Ks]), (ctypes.c_int * L)(*[int(n) for n in Ns]),
+           1 if has_output else 0, int(skip_layer), 1 if with_bias_gradients else 0, buf, 64)
+    return buf.value.decode() if rc == 0 else f"ndjir chain (status {rc})"
+
+
+def _launch_symbol(name, args):
+    if name in ("mlp_chain", "mlp_chain_ex"):
+        return chain_kernel_symbol(args[0], args[1], args[4], args[8], args[9], bool(args[17]), args[19],
+                                   any(t is not None for t in args[13]) or (args[29 if name == "mlp_chain_ex" else 24] is not None))
+    if name == "mlp_wgrad_group":
+        return "ndjir::k_wgrad_group (+ k_wgrad_group_reduce)"
+    if name == "mlp_wgrad":
+        return "ndjir::k_wgrad3 / k_wgrad_narrow (+ split reduction)"
+    return "ndjir::" + name
 
 
 def _launch(kind, flops, name, *args, shape=""):
@@ -64,12 +91,19 @@ def _launch(kind, flops, name, *args, shape=""):
         return
     if kind.startswith("chain") and not os.environ.get("NDJIR_MLP_TILE") and (int(args[1]) + 63) // 64 < 256:
         kind += "_t32"            # small launch: the library picks 32-point tiles (a different kernel instantiation)
+    sym = _launch_symbol(name, args)
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     lib.call(name, *args)
     e1.record()
-    PROFILE.append((kind, flops, e0, e1, shape, _launch_bytes(name, args)))
+    n_kernels = 1
+    if name == "mlp_wgrad_group":       # a grouped call is one kernel launch (+ one reduction) per argument block
+        import ctypes
+        n, m = int(args[0]), int(args[9])
+        n_kernels = max(1, int(lib.load().ndjir_mlp_wgrad_group_launches(
+            n, (ctypes.c_longlong * n)(*[int(p) for p in args[5]]), (ctypes.c_int * n)(*[int(o) for o in args[8]]), m)))
+    PROFILE.append((kind, flops, e0, e1, shape, _launch_bytes(name, args), sym, n_kernels))
 
 
 def _launch_bytes(name, args):

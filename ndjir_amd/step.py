@@ -21,7 +21,9 @@ import torch
 class Step:
     """Owns parameters, gradient buffers and the synthetic inputs of one rank."""
 
-    def __init__(self, conf, R, device, rank, world):
+    def __init__(self, conf, R, device, rank, world, B=1):
+        """R rays per image and rank, B images per step (python/train.py:38-51: `train.batch_size` images x `train.n_rays`
+        rays; config/default.yaml:126-127 trains with 4 x 512 -- the headline metric is quoted at B = 1)."""
         from ndjir_amd import network, parameter as P
         from ndjir_amd.grid_feature import set_grad_buffer
         from ndjir_amd.renderer import make_rand
@@ -31,11 +33,10 @@ class Step:
         # distributed code path: N > 1, or forced on one rank (NDJIR_BENCH_FORCE_DIST: a 1-rank RCCL group, to exercise
         # graph capture / replay around real RCCL calls on a single-GPU box)
         self.multi = world > 1 or bool(os.environ.get("NDJIR_BENCH_FORCE_DIST"))
-        self.R = R
+        self.R, self.B = R, B
         P.clear_parameters()
         P.set_device(device)
         network.seed(313)
-        B = 1
         # every rank draws the full (world*R)-ray set and keeps its contiguous slice
         self.camloc, self.raydir, self.color_gt = make_rays(B, R, seed=412, device=device, ray_offset=rank * R,
                                                             total_rays=world * R)
@@ -252,7 +253,7 @@ class Step:
         import copy
         from ndjir_amd.solver import Solvers
         conf = copy.deepcopy(self.conf)
-        conf.train.batch_size, conf.train.n_rays = 1, self.R * self.world      # learning rates scale with B R / 512
+        conf.train.batch_size, conf.train.n_rays = self.B, self.R * self.world      # learning rates scale with B R / 512
         self.solvers = Solvers(conf)
         self.solvers.set_parameters()
         from ndjir_amd import mlp

@@ -25,3 +25,24 @@ def make_rays(B, R, seed=412, cam_radius=2.5, target_half=1.2, device="cpu", ray
     raydir /= np.linalg.norm(raydir, ord=2, axis=-1, keepdims=True)
     f = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32))).to(device)
     return f(camloc), f(raydir), f(color)
+
+
+def make_scene(M, H, W, seed=3, cam_radius=2.5, focal=1.5):
+    """A synthetic multi-view scene for the device data feed (ndjir_amd/dataset.py `IDRRaySource`): M cameras on a sphere of
+    radius `cam_radius` looking at the origin, pinhole intrinsics with focal length `focal` x W, random colours, full masks.
+    Returns images (M,H,W,3) float32, masks (M,H,W,1), intrinsics (M,3,3), poses (M,4,4) camera-to-world."""
+    rng = np.random.RandomState(seed)
+    images = rng.rand(M, H, W, 3).astype(np.float32)
+    masks = np.ones((M, H, W, 1))
+    poses = np.zeros((M, 4, 4))
+    Ks = np.zeros((M, 3, 3))
+    for m in range(M):
+        c = rng.randn(3)
+        c = cam_radius * c / np.linalg.norm(c)
+        fwd = -c / np.linalg.norm(c)
+        right = np.cross(fwd, rng.randn(3))
+        right /= np.linalg.norm(right)
+        poses[m, :3, 0], poses[m, :3, 1], poses[m, :3, 2], poses[m, :3, 3] = right, np.cross(fwd, right), fwd, c
+        poses[m, 3, 3] = 1
+        Ks[m] = [[focal * W, 0, W / 2], [0, focal * W, H / 2], [0, 0, 1]]
+    return images, masks, Ks, poses

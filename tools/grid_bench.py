@@ -49,22 +49,34 @@ def timed(fn):
 rows = []
 
 
-def report(name, dist, us, bytes_per_point):
+RESIDENT_BYTES = 4 << 20      # a table this small stays in one XCD's 4 MiB L2 for the whole launch
+
+
+def report(name, dist, us, bytes_per_point, table_bytes_per_point=0):
+    """bytes_per_point: what has to cross HBM (query, in / out rows, and the table taps unless the table is cache-resident);
+    table_bytes_per_point: taps served from a cache-resident table -- reported beside, never counted as HBM bytes (round 3
+    printed the tri-line kernels at 1.02 / 1.22 'of 8 TB/s' because it did)."""
     gbs = bytes_per_point * P / (us * 1e-6) / 1e9
-    rows.append((name, dist, us, bytes_per_point, gbs))
+    rows.append((name, dist, us, bytes_per_point, gbs, table_bytes_per_point))
 
 
-def family(label, prefix, fwd, n_mult, feat, shape_args, out_ch, b_fwd, b_gq, b_gf):
+def family(label, prefix, fwd, n_mult, feat, shape_args, out_ch, b_fwd, b_gq, b_gf, taps=(0, 0, 0)):
+    """b_*: bytes per point INCLUDING the table taps `taps` = (forward, grad_query, grad_feature); a table of at most
+    RESIDENT_BYTES is cache-resident: its taps are subtracted from the HBM bytes and listed in their own column."""
+    resident = feat.numel() * 4 <= RESIDENT_BYTES
+    cached = taps if resident else (0, 0, 0)
+    b_fwd, b_gq, b_gf = b_fwd - cached[0], b_gq - cached[1], b_gf - cached[2]
     for dist, q in (("uniform", uniform_points()), ("rays", ray_points())):
         out = torch.empty(P * out_ch, device=dev)
         go = torch.randn(P * out_ch, device=dev, generator=gen)
         gq = torch.empty(P, 3, device=dev)
         gf = torch.zeros_like(feat)
         N = P * n_mult
-        report(f"{label} {fwd}", dist, timed(lambda: lib.call(f"{prefix}_{fwd}", N, out, q, feat, *shape_args, MN, MX, 0)), b_fwd)
-        report(f"{label} grad_query", dist, timed(lambda: lib.call(f"{prefix}_grad_query", N, gq, go, q, feat, *shape_args, MN, MX, 0, 0)), b_gq)
+        report(f"{label} {fwd}", dist, timed(lambda: lib.call(f"{prefix}_{fwd}", N, out, q, feat, *shape_args, MN, MX, 0)), b_fwd, cached[0])
+        report(f"{label} grad_query", dist, timed(lambda: lib.call(f"{prefix}_grad_query", N, gq, go, q, feat, *shape_args, MN, MX, 0, 0)), b_gq,
+               cached[1])
         report(f"{label} grad_feature (accumulate)", dist,
-               timed(lambda: lib.call(f"{prefix}_grad_feature", N, gf, go, q, *shape_args, MN, MX, 0, 1)), b_gf)
+               timed(lambda: lib.call(f"{prefix}_grad_feature", N, gf, go, q, *shape_args, MN, MX, 0, 1)), b_gf, cached[2])
         del gf
 
 
@@ -92,7 +104,8 @@ def main():
     F = torch.randn(3, G, G, D, device=dev, generator=gen) * 1e-3
     family("triplane 3x2048^2x8", "triplane_feature", "query_on_triplane", D * 3, F, [G, D], D * 3, 384 + 12 + 96, 384 + 12 + 96 + 12, 768 + 12 + 96)
     F = torch.randn(3, G, D, device=dev, generator=gen) * 1e-3
-    family("triline 3x2048x8", "triline_feature", "query_on_triline", D * 3, F, [G, D], D * 3, 192 + 12 + 96, 192 + 12 + 96 + 12, 384 + 12 + 96)
+    family("triline 3x2048x8", "triline_feature", "query_on_triline", D * 3, F, [G, D], D * 3, 192 + 12 + 96, 192 + 12 + 96 + 12, 384 + 12 + 96,
+           taps=(192, 192, 384))          # 196 KB of lines: cache-resident
     # hash grid, the reference bench's defaults: G0 = 16, growth 1.5, T0 = 2^15, L = 16, D = 2
     G0, gfac, T0, L, D = 16, 1.5, 1 << 15, 16, 2
     n = lib.hash_num_params(G0, gfac, T0, L, D)
@@ -100,9 +113,10 @@ def main():
     family("hash L16 D2", "voxel_hash_feature", "voxel_hash_feature", L, F, [G0, gfac, T0, L, D], D * L, 1024 + 12 + 128, 1024 + 12 + 128 + 12,
            2048 + 12 + 128)
     print(f"# P = {P} query points, {reps} launches each, HIP events; algorithmic bytes per point from SURVEY 8(d) (+ query, in/out rows)")
-    print(f"{'kernel':44s} {'points':8s} {'us/launch':>10s} {'B/point':>8s} {'GB/s':>9s} {'of 8 TB/s':>9s}")
-    for name, dist, us, b, gbs in rows:
-        print(f"{name:44s} {dist:8s} {us:10.1f} {b:8d} {gbs:9.1f} {gbs / 8000:9.3f}")
+    print("# HBM B/point excludes the taps of a cache-resident table (<= 4 MiB: the tri-line's 196 KB), listed as 'cached B/point'")
+    print(f"{'kernel':44s} {'points':8s} {'us/launch':>10s} {'HBM B/pt':>8s} {'GB/s':>9s} {'of 8 TB/s':>9s} {'cached B/pt':>11s}")
+    for name, dist, us, b, gbs, tb in rows:
+        print(f"{name:44s} {dist:8s} {us:10.1f} {b:8d} {gbs:9.1f} {gbs / 8000:9.3f} {tb:11d}")
 
 
 if __name__ == "__main__":
