@@ -18,7 +18,12 @@
  *     (grad_query, grad_feature); grad_query_grad_query, grad_query_grad_feature,
  *     grad_feature_grad_query and every TV backward ALWAYS accumulate, as in the reference
  *   - `boundary_check` is accepted and ignored, as in every reference kernel
- *   - launches are asynchronous on `stream`; no global state; thread-safe per stream
+ *   - launches are asynchronous on `stream`; every scratch buffer is the caller's (`workspace` arguments), so launches on
+ *     different streams share nothing.  The library keeps no state beyond two PROCESS-WIDE TUNING KNOBS of the MLP engine --
+ *     the matrix arithmetic (ndjir_mlp_set_math) and the forced tile height (ndjir_mlp_set_tile_rows), both also readable
+ *     from the environment at first use -- which select between kernels that compute the same values and must not be
+ *     changed while launches that read them are being issued from another thread (packed weights are specific to the
+ *     arithmetic they were packed under), and the diagnostic hooks (ndjir_mlp_debug_timeline, ndjir_mlp_chain_kernel)
  *
  * No torch types appear here; the library links only libamdhip64.
  */
@@ -96,12 +101,6 @@ int ndjir_voxel_feature_check_touched(int N, const float* grad_feature, const fl
 int ndjir_voxel_feature_pack_rows(int N, const float* grad_feature, const float* query, const int* grid_sizes, int D,
                                   const float* min, const float* max, unsigned* bitmap, int* ids, float* rows, int* count,
                                   int capacity, hipStream_t stream);
-/* Tuning switch of the tri-plane scatters (grad_feature, grad_query_grad_feature): from `points` query points on they bin the
- * (point, plane) pairs by tile and accumulate each tile in LDS (default 2^18; < 0 restores it).  Results do not depend on it
- * beyond fp32 summation order. */
-void ndjir_grid_set_scatter_bins_from(long long points);
-long long ndjir_grid_get_scatter_bins_from(void);
-
 /* topo 0 dense voxel (grid_sizes[3]) / 1 tri-plane / 2 tri-line (grid_sizes[0] = G); interp 0 linear / 1 cosine / 2 Lanczos */
 int ndjir_grid_pack_rows(int topo, int interp, int N, const float* grad_feature, const float* query, const int* grid_sizes, int D,
                          const float* min, const float* max, unsigned* bitmap, int* ids, float* rows, int* count, int capacity,

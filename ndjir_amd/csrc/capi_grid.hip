@@ -351,5 +351,3 @@ extern "C" int ndjir_zero(float* p, long long n, hipStream_t st) {
 extern "C" const char* ndjir_version(void) { return "ndjir_amd 0.1 (gfx950)"; }
 
 // point count from which the tri-plane scatters bin their (point, plane) pairs by tile (csrc/grid.hip); < 0 restores the default
-extern "C" void ndjir_grid_set_scatter_bins_from(long long points) { ndjir::set_scatter_bins_from(points); }
-extern "C" long long ndjir_grid_get_scatter_bins_from() { return ndjir::scatter_bins_from(); }

@@ -59,7 +59,7 @@ extern "C" int ndjir_mlp_pack_table(const void* table, int n, int total_blocks, 
 extern "C" int ndjir_mlp_pack_entry_bytes(void) { return (int)sizeof(PackEntry); }
 
 static long long* g_timeline = nullptr;   // diagnostics only, see ndjir_mlp_debug_timeline
-static char* g_dry_name = nullptr;        // diagnostics only, set for the duration of ndjir_mlp_chain_kernel
+static thread_local char* g_dry_name = nullptr;        // diagnostics only, set for the duration of ndjir_mlp_chain_kernel
 
 // Points per workgroup tile of the chain kernels: 0 = chosen per launch (128 for large launches the wide-tile kernel
 // supports, else 64, 32 for small launches); 32 / 64 / 128 force one (128: where supported).  Results do not depend on it.

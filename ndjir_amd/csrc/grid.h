@@ -27,8 +27,6 @@ int launch_pack_rows(int interp, const GridDesc& g, long long P, const float* gf
                      float* rows, int* count, int capacity, hipStream_t stream);
 int launch_zero_touched(int interp, const GridDesc& g, long long P, float* gf, const float* query, int* nonfinite_flag,
                         hipStream_t stream);
-long long scatter_bins_from();
-void set_scatter_bins_from(long long points);
 int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* gf, const float* gg_query, const float* grad_output, const float* query, hipStream_t stream);
 int launch_voxel_gq_gq(const GridDesc& g, long long P, float* gq, const float* gg_query, const float* grad_output, const float* query, const float* feature, hipStream_t stream);
 int launch_tv(const GridDesc& g, long long P, bool bwd, float* dst, const float* grad_output, const float* query, const float* feature, int sym_backward, hipStream_t stream);

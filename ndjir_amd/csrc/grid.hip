@@ -711,308 +711,6 @@ __global__ void __launch_bounds__(256) k_scatter_line_lds(long long P, float* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tri-plane scatters by tiles.  A plane (2048^2 x 8 floats = 134 MB) does not fit on chip and uniformly spread points do
-// not share cells, so the workgroup-aggregated scatter above removes nothing there: 96 global atomics per point at the
-// device-wide ~20 G atomics/s.  Here the (point, plane) pairs are first binned by the TS x TS-cell tiles their stencil
-// touches (count, scan, fill: 2 int atomics per pair and tile; a stencil straddles a tile edge with probability ~ 2 / TS
-// and is then listed in 2 -- rarely 4 -- tiles); then one workgroup per tile adds the taps that fall INTO ITS TILE to an
-// LDS image of the tile and writes the image's non-zero cells back with plain read-modify-write float4s: every cell has
-// exactly one owner, no global float atomic is left.  Tiles that hold more than BIN_CAP pairs (clamped out-of-box samples
-// pile up on border cells) are split over several workgroups, which then flush with atomics.
-// ------------------------------------------------------------------------------------------------
-constexpr int BIN_LDS_FLOATS = 32768;        // tile image: at most 128 KB
-constexpr int BIN_CAP = 4096;                // pairs per workgroup
-constexpr int BIN_MAX_TILES = 32768;
-
-// TRIPLANE: pairs = (point, plane), square tiles of TS x TS cells of plane s;  VOXEL: pairs = points, cubes of TS^3 cells
-struct BinPlan {
-  int TS, ntiles;
-  int tpa[3];                    // tiles per axis (tri-plane: [0] = [1], [2] unused)
-};
-
-template <int TOPO> struct BinDims { static constexpr int subs = (TOPO == TRIPLANE) ? 3 : 1, nd = (TOPO == TRIPLANE) ? 2 : 3; };
-
-// the (up to 2^nd) tiles a pair's stencil touches: tile ids in t[], returns their number
-template <int TOPO, int I>
-__device__ __forceinline__ int bin_tiles(const GridDesc& g, const BinPlan& bp, int s, const float* q, int* t) {
-  constexpr int NT = NTaps<I>::v, ND = BinDims<TOPO>::nd;
-  Stencil<TOPO, I> st;
-  make_stencil<TOPO, I>(st, g, s, q);
-  int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-#pragma unroll
-  for (int a = 0; a < ND; ++a) {
-    lo[a] = (int)(st.ax[a].idx[0] / (unsigned)bp.TS);
-    hi[a] = (int)(st.ax[a].idx[NT - 1] / (unsigned)bp.TS);
-  }
-  int n = 0;
-  if constexpr (TOPO == TRIPLANE) {
-    for (int a = lo[0]; a <= hi[0]; ++a)
-      for (int b = lo[1]; b <= hi[1]; ++b) t[n++] = (s * bp.tpa[0] + a) * bp.tpa[1] + b;
-  } else {
-    for (int a = lo[0]; a <= hi[0]; ++a)
-      for (int b = lo[1]; b <= hi[1]; ++b)
-        for (int c = lo[2]; c <= hi[2]; ++c) t[n++] = (a * bp.tpa[1] + b) * bp.tpa[2] + c;
-  }
-  return n;
-}
-
-template <int TOPO, int I>
-__global__ void __launch_bounds__(256) k_bin_count(long long P, const float* __restrict__ query, GridDesc g, BinPlan bp,
-                                                   int* __restrict__ count) {
-  const long long total = P * BinDims<TOPO>::subs;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const int s = (int)(t / P);
-    const long long b = t - (long long)s * P;
-    const float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
-    int tl[8];
-    const int n = bin_tiles<TOPO, I>(g, bp, s, q, tl);
-    for (int k = 0; k < n; ++k) atomicAdd(count + tl[k], 1);
-  }
-}
-
-// start[t] = exclusive prefix of count; work items (tile, part) for every BIN_CAP pairs of a tile; fill[] = 0; *nwork
-__global__ void __launch_bounds__(1024) k_bin_scan(int ntiles, const int* __restrict__ count, int* __restrict__ start,
-                                                   int* __restrict__ fill, int* __restrict__ work, int* __restrict__ nwork) {
-  __shared__ int sh[2][1024];
-  const int per = (ntiles + 1023) / 1024;
-  const int t0 = threadIdx.x * per;
-  int sum = 0, wsum = 0;
-  for (int i = 0; i < per; ++i) {
-    const int t = t0 + i;
-    if (t < ntiles) { sum += count[t]; const int parts = (count[t] + BIN_CAP - 1) / BIN_CAP; wsum += parts < 64 ? parts : 64; }
-  }
-  sh[0][threadIdx.x] = sum;
-  sh[1][threadIdx.x] = wsum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    int a = 0, b = 0;
-    if ((int)threadIdx.x >= o) { a = sh[0][threadIdx.x - o]; b = sh[1][threadIdx.x - o]; }
-    __syncthreads();
-    sh[0][threadIdx.x] += a;
-    sh[1][threadIdx.x] += b;
-    __syncthreads();
-  }
-  int run = sh[0][threadIdx.x] - sum, wrun = sh[1][threadIdx.x] - wsum;
-  for (int i = 0; i < per; ++i) {
-    const int t = t0 + i;
-    if (t < ntiles) {
-      const int c = count[t];
-      start[t] = run;
-      fill[t] = 0;
-      run += c;
-      for (int k = 0; k * BIN_CAP < c && k < 64; ++k) work[wrun++] = t * 64 + k;      // (part 63 takes all that is left)
-    }
-  }
-  if (threadIdx.x == 1023) *nwork = sh[1][1023];
-}
-
-template <int TOPO, int I>
-__global__ void __launch_bounds__(256) k_bin_fill(long long P, const float* __restrict__ query, GridDesc g, BinPlan bp,
-                                                  const int* __restrict__ start, int* __restrict__ fill, int* __restrict__ order) {
-  const long long total = P * BinDims<TOPO>::subs;
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const int s = (int)(t / P);
-    const long long b = t - (long long)s * P;
-    const float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
-    int tl[8];
-    const int n = bin_tiles<TOPO, I>(g, bp, s, q, tl);
-    for (int k = 0; k < n; ++k) order[start[tl[k]] + atomicAdd(fill + tl[k], 1)] = (int)b;
-  }
-}
-
-template <int TOPO, int I, int MODE>
-__global__ void __launch_bounds__(256) k_scatter_tiles(long long P, float* __restrict__ gf, const float* __restrict__ gg_query,
-                                                       const float* __restrict__ grad_output, const float* __restrict__ query,
-                                                       GridDesc g, BinPlan bp, const int* __restrict__ count,
-                                                       const int* __restrict__ start, const int* __restrict__ order,
-                                                       const int* __restrict__ work, const int* __restrict__ nwork) {
-  constexpr int ND = BinDims<TOPO>::nd, NT = NTaps<I>::v;
-  extern __shared__ float hs_tab[];
-  const int D = g.D, TS = bp.TS;
-  const int cells = (ND == 2) ? TS * TS : TS * TS * TS;
-  const int n_fl = cells * D;
-  for (int wi = blockIdx.x; wi < *nwork; wi += gridDim.x) {                 // uniform per workgroup
-    const int tile = work[wi] >> 6, part = work[wi] & 63;
-    const int n = count[tile];
-    const bool split = n > BIN_CAP;
-    int p0 = part * BIN_CAP, p1 = p0 + BIN_CAP;
-    if (part == 63 || p1 > n) p1 = n;                                       // the last listed part takes the remainder
-    int s = 0;
-    unsigned lo[3] = {0u, 0u, 0u};
-    if constexpr (TOPO == TRIPLANE) {
-      s = tile / (bp.tpa[0] * bp.tpa[1]);
-      lo[0] = (unsigned)(((tile / bp.tpa[1]) % bp.tpa[0]) * TS);
-      lo[1] = (unsigned)((tile % bp.tpa[1]) * TS);
-    } else {
-      lo[0] = (unsigned)((tile / (bp.tpa[1] * bp.tpa[2])) * TS);
-      lo[1] = (unsigned)(((tile / bp.tpa[2]) % bp.tpa[1]) * TS);
-      lo[2] = (unsigned)((tile % bp.tpa[2]) * TS);
-    }
-    for (int t = threadIdx.x; t < n_fl; t += 256) hs_tab[t] = 0.f;
-    __syncthreads();
-    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
-      const long long b = order[start[tile] + p];
-      const float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
-      Stencil<TOPO, I> st;
-      make_stencil<TOPO, I>(st, g, s, q);
-      float ggs[ND];
-      if constexpr (MODE == 1) {
-#pragma unroll
-        for (int a = 0; a < ND; ++a) ggs[a] = gg_query[b * 3 + st.axis[a]] * st.scale[a] * st.ax[a].gm;
-      }
-      float og[8];
-#pragma unroll
-      for (int d = 0; d < 8; ++d) og[d] = d < D ? grad_output[out_index<TOPO>(g, P, b, s, d)] : 0.f;
-      NDJIR_FOR_TAPS(ND, NT) {
-        const unsigned ri = st.ax[0].idx[i] - lo[0], rj = st.ax[1].idx[j] - lo[1];      // (unsigned: below the tile wraps to huge)
-        unsigned rk = 0u;
-        if constexpr (ND == 3) rk = st.ax[2].idx[k] - lo[2];
-        if (ri < (unsigned)TS && rj < (unsigned)TS && rk < (unsigned)TS) {              // this tap's cell belongs to this tile
-          float w;
-          if constexpr (MODE == 0) {
-            w = tap_w(st, i, j, k);
-          } else {
-            w = 0.f;
-#pragma unroll
-            for (int a = 0; a < ND; ++a) w += ggs[a] * tap_dw(st, a, i, j, k);
-          }
-          const int e = ((ND == 2) ? ((int)ri * TS + (int)rj) : (((int)ri * TS + (int)rj) * TS + (int)rk)) * D;
-#pragma unroll
-          for (int d = 0; d < 8; ++d) if (d < D) atomicAdd(&hs_tab[e + d], og[d] * w);
-        }
-      }
-    }
-    __syncthreads();
-    // write back: batches of 8 float4 per thread, the reads of a batch in flight together
-    const int D4 = D >> 2;
-    const int n4 = cells * D4;
-    const int G0 = g.G[0], G1 = (TOPO == TRIPLANE) ? g.G[0] : g.G[1], G2 = (TOPO == TRIPLANE) ? 1 : g.G[2];
-    float* sub = gf + ((TOPO == TRIPLANE) ? (long long)s * G0 * G0 * D : 0LL);
-    for (int t0 = 0; t0 < n4; t0 += 256 * 8) {
-      float4 v[8], o[8];
-      float* dst[8];
-      int kind[8];                       // 0 nothing, 1 plain read-modify-write, 2 atomics (the tile is shared by several workgroups)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int t = t0 + u * 256 + threadIdx.x;
-        kind[u] = 0;
-        dst[u] = sub;
-        if (t < n4) {
-          const int cell = t / D4, c4 = t - cell * D4;
-          int ii, jj, kk = 0;
-          if constexpr (ND == 2) { ii = cell / TS; jj = cell - ii * TS; }
-          else { ii = cell / (TS * TS); jj = (cell / TS) % TS; kk = cell % TS; }
-          const int gi = (int)lo[0] + ii, gj = (int)lo[1] + jj, gk = (int)lo[2] + kk;
-          v[u] = *reinterpret_cast<const float4*>(hs_tab + cell * D + 4 * c4);
-          if (gi < G0 && gj < G1 && gk < G2 && (v[u].x != 0.f || v[u].y != 0.f || v[u].z != 0.f || v[u].w != 0.f)) {
-            dst[u] = sub + (((long long)gi * G1 + gj) * G2 + gk) * D + 4 * c4;
-            kind[u] = split ? 2 : 1;
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (kind[u] == 1) o[u] = *reinterpret_cast<const float4*>(dst[u]);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (kind[u] == 1) {
-          o[u].x += v[u].x; o[u].y += v[u].y; o[u].z += v[u].z; o[u].w += v[u].w;
-          *reinterpret_cast<float4*>(dst[u]) = o[u];
-        } else if (kind[u] == 2) {
-          if (v[u].x != 0.f) atomicAdd(dst[u], v[u].x);
-          if (v[u].y != 0.f) atomicAdd(dst[u] + 1, v[u].y);
-          if (v[u].z != 0.f) atomicAdd(dst[u] + 2, v[u].z);
-          if (v[u].w != 0.f) atomicAdd(dst[u] + 3, v[u].w);
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-static inline int grid_blocks(long long threads);
-
-// Device scratch of the binned scatter, kept by the library.  A HIP graph captured earlier holds the block's address in its
-// count / scan / fill / scatter nodes, so a block is NEVER freed or moved once it has been handed out: a larger request
-// (outside stream capture only) allocates a NEW block and retires the old one, which stays alive for the replays that still
-// point at it (a handful of blocks per process at most: sizes grow by 1.5x).  One block serves one stream at a time: the
-// launches that use it are ordered on the caller's stream, and two streams scattering concurrently must not share the
-// library's block -- the step issues its scatters on one stream.
-static int* g_bin_scratch = nullptr;
-static size_t g_bin_scratch_ints = 0;
-static int g_bin_retired = 0;          // blocks kept alive for earlier captures
-
-static int* bin_scratch(size_t ints, hipStream_t stream) {
-  if (ints <= g_bin_scratch_ints) return g_bin_scratch;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-  const size_t want = ints + ints / 2;
-  int* fresh = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&fresh), want * sizeof(int)) != hipSuccess) return nullptr;
-  if (g_bin_scratch) ++g_bin_retired;  // (deliberately not freed: see above)
-  g_bin_scratch = fresh;
-  g_bin_scratch_ints = want;
-  if (getenv("NDJIR_DEBUG_SCRATCH"))
-    fprintf(stderr, "[ndjir] bin scratch -> %zu ints at %p (%d retired block(s) kept)\n", want, (void*)g_bin_scratch, g_bin_retired);
-  return g_bin_scratch;
-}
-
-// returns NDJIR_OK when the binned path ran, -1 when it does not apply (the caller falls back)
-template <int TOPO, int I>
-static int scatter_binned(const GridDesc& g, long long P, int mode, float* gf, const float* gg_query, const float* grad_output,
-                          const float* query, hipStream_t stream) {
-  constexpr int NT = NTaps<I>::v, ND = BinDims<TOPO>::nd, SUBS = BinDims<TOPO>::subs;
-  // tile image: the smallest of 32 / 64 / 128 KB of LDS that keeps the tile count within BIN_MAX_TILES -- small tiles let
-  // several workgroups share a CU, which is what hides the latency of the write-back's scattered reads
-  BinPlan bp;
-  int lds_floats = 0;
-  for (int f = 8192; f <= BIN_LDS_FLOATS; f *= 2) {
-    int side = 1;
-    if (ND == 2) while ((side + 1) * (side + 1) * g.D <= f) ++side;
-    else while ((side + 1) * (side + 1) * (side + 1) * g.D <= f) ++side;
-    bp.TS = side;
-    if (bp.TS < 2 * NT) continue;                     // a stencil spans at most two tiles per axis
-    long long nt = SUBS;
-    for (int a = 0; a < 3; ++a) {
-      bp.tpa[a] = a < ND ? (g.G[TOPO == TRIPLANE ? 0 : a] + bp.TS - 1) / bp.TS : 1;
-      nt *= bp.tpa[a];
-    }
-    if (nt <= BIN_MAX_TILES) { bp.ntiles = (int)nt; lds_floats = f; break; }
-  }
-  const long long per_pair = 1LL << ND;               // a pair is listed in at most 2^nd tiles
-  if (!lds_floats || SUBS * per_pair * P > 0x7fffffffLL) return -1;
-  const long long max_work = bp.ntiles + (SUBS * per_pair * P) / BIN_CAP + 1;
-  // layout: count[ntiles] start[ntiles] fill[ntiles] nwork[4] work[max_work] order[subs 2^nd P]
-  const size_t ints = (size_t)3 * bp.ntiles + 4 + (size_t)max_work + (size_t)(SUBS * per_pair * P);
-  int* sc = bin_scratch(ints, stream);
-  if (!sc) return -1;
-  int *count = sc, *start = sc + bp.ntiles, *fill = sc + 2 * bp.ntiles, *nwork = sc + 3 * bp.ntiles;
-  int *work = nwork + 4, *order = work + max_work;
-  // (a kernel, not hipMemsetAsync: as a memset node of a captured HIP graph this clear faulted on replay -- ROCm 7.2)
-  zero_fill(reinterpret_cast<float*>(count), bp.ntiles, stream);
-  const int blocks = grid_blocks(P * SUBS);
-  hipLaunchKernelGGL((k_bin_count<TOPO, I>), dim3(blocks), dim3(256), 0, stream, P, query, g, bp, count);
-  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, stream, bp.ntiles, count, start, fill, work, nwork);
-  hipLaunchKernelGGL((k_bin_fill<TOPO, I>), dim3(blocks), dim3(256), 0, stream, P, query, g, bp, start, fill, order);
-  const size_t lds = (size_t)lds_floats * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    const size_t lds_max = (size_t)BIN_LDS_FLOATS * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_tiles<TOPO, I, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_tiles<TOPO, I, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    attr = true;
-  }
-  int wg = (int)(max_work < 4096 ? max_work : 4096);
-  if (mode == 0)
-    hipLaunchKernelGGL((k_scatter_tiles<TOPO, I, 0>), dim3(wg), dim3(256), lds, stream, P, gf, gg_query, grad_output, query, g, bp, count,
-                       start, order, work, nwork);
-  else
-    hipLaunchKernelGGL((k_scatter_tiles<TOPO, I, 1>), dim3(wg), dim3(256), lds, stream, P, gf, gg_query, grad_output, query, g, bp, count,
-                       start, order, work, nwork);
-  return ndjir_check_launch();
-}
-
-// ------------------------------------------------------------------------------------------------
 // zero the cells a set of queries touches (every tap of the stencil): re-arms an accumulate-in-place
 // gradient buffer after use without rewriting all of it (2 GiB for the default 512^3 x 4 grid).
 // Covers grad_feature, grad_query_grad_feature and the TV backward (its cells are a subset of the taps).
@@ -1388,15 +1086,6 @@ int launch_dquery(int interp, const GridDesc& g, long long P, int mode, float* d
   return ndjir_check_launch();
 }
 
-static long long g_bins_from = -1;
-
-long long scatter_bins_from() {
-  if (g_bins_from < 0) { const char* e = getenv("NDJIR_SCATTER_BINS_FROM"); g_bins_from = e ? atoll(e) : (1LL << 18); }
-  return g_bins_from;
-}
-
-void set_scatter_bins_from(long long points) { g_bins_from = points < 0 ? (1LL << 18) : points; }
-
 static inline long long NTapsOf(int interp) { return interp == LANCZOS ? 64 : 8; }
 
 // mode 0: grad_feature ; mode 1: grad_query_grad_feature.  The caller zero-fills when !accum.
@@ -1435,23 +1124,9 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
 #undef NDJIR_LINE_LDS
     return ndjir_check_launch();
   }
-  static const bool no_bins = getenv("NDJIR_SCATTER_NO_BINS") != nullptr;    // A/B switch
-  // Tile binning pays for large, spread point sets (2^19 uniform points on 3 x 2048^2 x 8: 2.5 -> 0.62 ms); the 65536
-  // ray-coherent samples of a training step revisit cells, which the workgroup-aggregated path below merges without the
-  // binning passes (measured on config/triplaneline.yaml: 12.4 ms per step aggregated, 12.95 ms binned).
-  if (g.topo == TRIPLANE && (g.D == 4 || g.D == 8) && P >= scatter_bins_from() && !no_agg && !no_bins) {
-    int rc = -1;
-    if (interp == LINEAR) rc = scatter_binned<TRIPLANE, LINEAR>(g, P, mode, gf, gg_query, grad_output, query, stream);
-    else if (interp == COSINE) rc = scatter_binned<TRIPLANE, COSINE>(g, P, mode, gf, gg_query, grad_output, query, stream);
-    else rc = scatter_binned<TRIPLANE, LANCZOS>(g, P, mode, gf, gg_query, grad_output, query, stream);
-    if (rc >= 0) return rc;
-  }
-  // Lanczos voxel (64 taps per point): the same tile binning in 3-D.  (The 8-tap linear / cosine voxel keeps the aggregated
-  // path: at 2^19 points on 512^3 a 16^3 tile holds 16 points -- clearing and scanning its image would cost more than the taps.)
-  if (g.topo == VOXEL && interp == LANCZOS && g.D == 4 && P >= scatter_bins_from() && !no_agg && !no_bins) {
-    const int rc = scatter_binned<VOXEL, LANCZOS>(g, P, mode, gf, gg_query, grad_output, query, stream);
-    if (rc >= 0) return rc;
-  }
+  // (Round 2 also binned large spread point sets by tiles -- tri-plane, Lanczos voxel -- so that every cell had one owner;
+  // with the request-shaped flushes of round 3 the aggregated path is within 10 % of it on the tri-plane, a training step
+  // never reached its threshold, and its library-owned scratch was the one piece of cross-stream state: removed in round 4.)
   if (g.topo != HASH && (g.D & 3) == 0 && per_point <= 128 && !no_agg) {
     int ppp = 2048 / per_point;
     if (ppp > 256) ppp = 256;

@@ -171,9 +171,6 @@ def load():
                                                          ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int),
                                                          ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                                          ctypes.c_int]
-        _lib.ndjir_grid_set_scatter_bins_from.restype = None
-        _lib.ndjir_grid_set_scatter_bins_from.argtypes = [ctypes.c_longlong]
-        _lib.ndjir_grid_get_scatter_bins_from.restype = ctypes.c_longlong
     return _lib
 
 
@@ -269,8 +266,7 @@ def symbols():
                                             "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_wgrad_group_workspace", "ndjir_mlp_wgrad_group_launches", "ndjir_mlp_colsum_workspace",
                                             "ndjir_mlp_chain_workspace", "ndjir_mlp_set_math", "ndjir_mlp_get_math",
                                             "ndjir_mlp_set_tile_rows", "ndjir_mlp_get_tile_rows", "ndjir_mlp_pack_entry_bytes",
-                                            "ndjir_mlp_debug_timeline", "ndjir_mlp_chain_kernel", "ndjir_loss_terms_workspace", "ndjir_grid_set_scatter_bins_from",
-                                            "ndjir_grid_get_scatter_bins_from"]
+                                            "ndjir_mlp_debug_timeline", "ndjir_mlp_chain_kernel", "ndjir_loss_terms_workspace"]
 
 
 def hash_num_params(G0, growth_factor, T0, L, D):

@@ -21,13 +21,3 @@ def gpu():
     from ndjir_amd import lib
     lib.load()
     return torch.device("cuda:0")
-
-
-@pytest.fixture
-def binned_scatter(gpu):
-    """Tri-plane scatters take the tile-binned path at any point count for the duration of a test."""
-    from ndjir_amd import lib
-    L = lib.load()
-    L.ndjir_grid_set_scatter_bins_from(1)
-    yield
-    L.ndjir_grid_set_scatter_bins_from(-1)

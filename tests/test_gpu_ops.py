@@ -101,10 +101,9 @@ def test_hash_scatter_through_lds_table(gpu, family, P, hash_cfg):
 
 @pytest.mark.parametrize("family,P,G,D", [("triplane", 20000, 256, 8), ("triplane", 30000, 200, 4), ("cosine_triplane", 20000, 128, 8),
                                           ("lanczos_triplane", 17000, 96, 4), ("lanczos_voxel", 17000, 40, 4)])
-def test_triplane_scatter_binned_by_tiles(gpu, family, P, G, D, binned_scatter):
-    """grad_feature / grad_query_grad_feature of the tri-plane families at point counts where the scatter bins the (point, plane)
-    pairs by tile and accumulates each tile in LDS (csrc/grid.hip k_plane_scatter_tiles); several tiles per axis, queries
-    beyond the box (clamped to border cells)."""
+def test_triplane_scatter_large_point_sets(gpu, family, P, G, D):
+    """grad_feature / grad_query_grad_feature of the tri-plane / Lanczos-voxel families at tens of thousands of points (many
+    passes of the workgroup-aggregated scatter, csrc/grid.hip k_scatter_agg), queries beyond the box (clamped to border cells)."""
     _family_check(gpu, family, P, G, None, D=D, fine=True)      # (G >= 96: the tolerance class of the fine hash levels)
 
 
@@ -115,9 +114,9 @@ def test_triline_scatter_through_lds_image(gpu, family, P, G, D):
     _family_check(gpu, family, P, G, None, D=D, fine=True)
 
 
-def test_triplane_scatter_binned_heavy_tile(gpu, binned_scatter):
-    """Every point in one cell (what clamped out-of-box samples do to a border tile): the tile is split over several workgroups;
-    the result equals the sum formed in float64."""
+def test_triplane_scatter_every_point_in_one_cell(gpu):
+    """Every point in one cell (what clamped out-of-box samples do to a border cell): thousands of contributions merge in the
+    workgroups' LDS tables; the result equals the sum formed in float64."""
     from ndjir_amd.grid_feature import _core
     P, G, D = 3 * 4096 + 777, 128, 8
     q = torch.full((P, 3), 0.3, device=gpu) + torch.rand(P, 3, device=gpu) * 1e-4
