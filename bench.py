@@ -189,7 +189,7 @@ def replay_step(step, graph):
     step.exchange()
 
 
-def redraw_leg(step, graph, steps, barrier):
+def redraw_leg(step, graph, loss_t, steps, barrier):
     """The timed replays again, but as a training loop sees them (python/train.py:124-133): before every replay the next
     batch of pixels comes from the device data feed (ndjir_amd/dataset.py: new rays, colours -- other grid cells than the
     step before) and every random tensor is redrawn on the device.  The headline number replays ONE set of rays, whose
@@ -220,7 +220,7 @@ def redraw_leg(step, graph, steps, barrier):
         one()
     barrier()
     el = time.perf_counter() - t0
-    loss = float(step.loss)
+    loss = float(loss_t if graph is not None else step.loss)      # (the captured step writes the tensor it was captured with)
     return {"ms_per_step": 1e3 * el / steps, "rays_per_s": step.B * step.R * steps / el, "steps": steps, "loss": loss,
             "scope": "fwd+bwd replays with the next batch from the device data feed (8 synthetic views, 256 x 256) and freshly "
                      "drawn random tensors before every replay; includes the feed's launches and one small host->device copy"}
@@ -677,7 +677,8 @@ def main():
                                        "sample": f"failed: {type(e).__name__}: {e}"}
     if world == 1 and not force_dist and a.extra_legs:
         try:
-            out["redraw"] = redraw_leg(step, graph if exec_mode == "graph" else None, a.steps, barrier)
+            out["redraw"] = redraw_leg(step, graph if exec_mode == "graph" else None, loss if exec_mode == "graph" else None,
+                                       a.steps, barrier)
         except Exception as e:      # a side measurement must never take the headline number down with it
             out["redraw"] = {"error": f"{type(e).__name__}: {e}"}
     if a.train_steps > 0:

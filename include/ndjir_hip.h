@@ -561,7 +561,7 @@ int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb, int K, int
  * (work items the launch aims for: the point axis of every source is split accordingly; 0 = default, 4 per CU). */
 long long ndjir_mlp_wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id,
                                           int n_out, const int* K, const int* N, int target_items);
-/* (diagnostics) launches of the grouped kernel -- and of its reduction -- that the call issues: one per 20 operand pairs */
+/* (diagnostics) launches of the grouped kernel -- and of its reduction -- that the call issues: one per 24 operand pairs */
 int ndjir_mlp_wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n_out);
 int ndjir_mlp_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb,
                           const long long* P, const unsigned* const* amax_a, const unsigned* const* amax_b, const int* out_id,
@@ -576,7 +576,7 @@ int ndjir_mlp_colsum(const float* X, int ldx, int N, long long P, float* out, in
  * ndjir_mlp_chain / ndjir_mlp_chain_ex would launch for a chain of this shape under the current arithmetic and tile setting
  * (the launchers' own decision code; nothing is launched).  name_bytes >= 64. */
 int ndjir_mlp_chain_kernel(int mode, long long P, int K0, int L, const int* Ks, const int* Ns, int has_output, int skip_layer,
-                           int with_bias_gradients, char* name, int name_bytes);
+                           int skip_split, int with_bias_gradients, char* name, int name_bytes);
 /* Diagnostics (no reference counterpart): with a non-null device buffer of 10 * 5 * 8 int64, later
  * chain launches record shader-clock stamps of workgroup 0, [layer][phase][wave], phases = layer
  * start / k-loop done / accumulators staged / epilogue done / barrier passed.  Null switches it off. */

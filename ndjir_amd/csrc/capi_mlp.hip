@@ -173,7 +173,7 @@ extern "C" int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx
 // Diagnostics: the symbol (as rocprofv3 prints it) of the kernel a chain launch of this shape would run -- the launchers' own
 // decision code, nothing is launched.  bench.py keys its per-kernel roofline table by it.
 extern "C" int ndjir_mlp_chain_kernel(int mode, long long P, int K0, int L, const int* Ks, const int* Ns, int has_output,
-                                      int skip_layer, int with_bias_gradients, char* name, int name_bytes) {
+                                      int skip_layer, int skip_split, int with_bias_gradients, char* name, int name_bytes) {
   if (!name || name_bytes < 64 || mode < 0 || mode > 2 || L < 1 || L > MAX_CHAIN_LAYERS || !Ks || !Ns || P <= 0) return NDJIR_ERR_ARG;
   static float dummy[4];          // (never dereferenced: the launchers return before any launch)
   const float* wp[MAX_CHAIN_LAYERS];
@@ -184,7 +184,7 @@ extern "C" int ndjir_mlp_chain_kernel(int mode, long long P, int K0, int L, cons
   name[0] = 0;
   const int rc = chain_impl(mode, P, dummy, K0, K0, L, wp, nullptr, Ks, Ns, mode != 0 ? side : nullptr, nullptr, nullptr,
                             mode != 0 ? bg : nullptr, dummy, Ns[L - 1], 0, has_output, 100.f, skip_layer, 1.f,
-                            (mode == 1 && skip_layer >= 0) ? Ns[skip_layer] : 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                            skip_split, (mode == 1 && skip_layer >= 0) ? dummy : nullptr, K0, nullptr, nullptr, nullptr, nullptr, 0,
                             nullptr, dummy, nullptr, nullptr, nullptr);
   g_dry_name = nullptr;
   return rc;

@@ -320,9 +320,10 @@ __device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A, int lda
                                             long long p_begin, long long p_end, float* __restrict__ out, int k0, int n0,
                                             int k_end, int n_end, float sa, float ia, float sb, float ib,
                                             unsigned short* wg_lds) {
-  static_assert(WK * WN == 4, "4 waves");
+  constexpr int NT = WK * WN * 64;                  // threads: one wave per (WK, WN) position
   constexpr int TK = WK * BK * 32, TN = WN * BN * 32;
-  constexpr int PA = TK / 8, PB = TN / 8;          // points per thread and chunk (multiples of 4)
+  constexpr int PA = WG_C * TK / NT, PB = WG_C * TN / NT;          // points per thread and chunk (multiples of 4)
+  static_assert(PA % 4 == 0 && PB % 4 == 0 && NT % TK == 0 && NT % TN == 0, "loader shape");
   _Float16* As = reinterpret_cast<_Float16*>(wg_lds);      // [2][TK][WG_CP]
   _Float16* Bs = As + 2 * TK * WG_CP;                      // [2][TN][WG_CP]
   const int tid = threadIdx.x;
@@ -861,14 +862,22 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
 // in the group, and one reduction launch serves them all.  An output may have several operand pairs ("sources": the
 // geometric net's dW_j = A_j^T delta_j + gbar_j^T s_j), each with its own operand scales: every work item writes a
 // de-scaled partial slab, the reduction sums the slabs of all sources of an output.
-// A source's K x N output is cut into regions, each tiled by one kind of work item:
-//   kind 4      full 128 x 128 tiles of k_wgrad_group_big (one 8-wave workgroup per CU: four waves multiply, four load and
-//               split two chunks ahead, double-buffered planes) -- most of the work;
+// A source's K x N output is cut into regions, each tiled by one kind of work item (k_wgrad_group, two workgroups per CU):
 //   kind 0      128 x 128 tile (ragged edges masked), kind 1 = 32 x 128 strip (ragged K), kind 2 = 128 x 32 strip (ragged N),
-//   kind 3      streaming reduction for outputs <= 8 wide        -- k_wgrad_group, two workgroups per CU.
-constexpr int WGG_MAX_SRC = 20;
+//   kind 3      streaming reduction for outputs <= 8 wide.
+// Three other tile designs were written, tested bit-for-bit against these and measured in round 4 on 8 x (256 x 256 x 65 536)
+// (tools/wgrad_group_time.py; this kernel: 50.8 us per layer) -- none is in the tree:
+//   * one 4-wave workgroup per CU with 512 registers per lane, 128 x 256 tile, 16-byte loads, two chunks of operands in
+//     flight, double-buffered planes, split interleaved with the MFMAs by the compiler: 55.1 us;
+//   * 8-wave workgroup with specialised waves (4 multiply, 4 load two chunks ahead and split), one barrier per chunk: 73.8 us;
+//   * this tile template at 256 x 128 with eight waves, one workgroup per CU: 48.6 us alone, but +0.5 ms per step (its ragged
+//     leftovers need a second launch of this kernel).
+// PMC on the grouped kernel (profiles/r04_pmc_wgrad_group.txt): FETCH_SIZE = the algorithmic operand bytes, half of the L2
+// requests hit (the tile pair of a split), the matrix pipe busy 21 %, 63 % of the wave cycles waiting: ~10 bytes / clk / CU
+// of loads whatever the structure -- the rate MI355X_MICROARCH.md gives for HBM-bound global_load_dwordx4.
+constexpr int WGG_MAX_SRC = 24;
 constexpr int WGG_MAX_SEG = 56;
-constexpr int WGG_MAX_OUT = 20;
+constexpr int WGG_MAX_OUT = 24;
 constexpr int WGG_NARROW_ROWS = 1024;     // points per narrow work item
 
 struct WggSrc {
@@ -997,173 +1006,6 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggArgs a) 
                             sa, ia, sb, ib, wg_lds);
 }
 
-// ---- the full tiles: 128 x 128 outputs per 8-wave workgroup with SPECIALISED waves, one workgroup per CU -------------------
-// What bounded the 128 x 128 tile above (4 waves, two workgroups per CU, 256 registers): every wave does everything in
-// turn -- issue a chunk's operand loads, multiply the chunk in the planes, wait for the loads, split them into the planes --
-// with ONE register set for operands in flight (128 accumulator registers leave no room for a second), so an iteration is
-// the exposed load latency: 3.3 TB/s of operands, the matrix pipe busy a quarter of the time (tools/wgrad_time.py: removing
-// the MFMAs gains nothing).  Here the two jobs run in different waves of one workgroup, two waves per SIMD:
-//   waves 0-3 (multipliers)  fragments of chunk c from planes [c & 1] -> 24 MFMAs per chunk into 128 accumulators; nothing else;
-//   waves 4-7 (loaders)      16-byte loads (4 consecutive features of 4 consecutive points per lane) two chunks ahead into
-//                            two register sets, split chunk c + 1 into planes [(c + 1) & 1] while chunk c is multiplied.
-// One barrier per chunk.  The hardware interleaves a SIMD's two waves: the split's VALU work and the loads' latency sit
-// under the other wave's MFMAs by construction, not by instruction scheduling.
-// Plane stores without bank conflicts or register shuffles: a 16-lane store group (ds_write_b64: 32 banks) holds 8 point
-// groups x 2 adjacent float4 columns; store k of a lane writes feature 4 fq + k: the plane pitch of 80 bytes puts features
-// 4 apart 16 banks apart, the 8 point groups fill the 16 banks in 8-byte steps.
-typedef float wg_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-constexpr int WGG_BIG_THREADS = 512;
-constexpr int WGG_BIG_LDS = 2 * 2 * 2 * WG_T * WG_CP * 2;      // bytes: 2 buffers x (A, B) x 2 planes x 128 features x pitch
-
-__device__ __forceinline__ void wgrad3_big_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int N,
-                                                long long p_begin, long long p_end, float* __restrict__ out, int k0, int n0,
-                                                float sa, float ia, float sb, float ib, unsigned short* wg_lds) {
-  constexpr int T = WG_T;
-  constexpr int PLANE = T * WG_CP;                         // halfs per plane
-  constexpr int BUF = 4 * PLANE;                           // halfs per buffer: A hi, A lo, B hi, B lo
-  _Float16* planes = reinterpret_cast<_Float16*>(wg_lds);  // [2 buffers][A hi | A lo | B hi | B lo][T][WG_CP]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  if (p_begin >= p_end) p_end = p_begin;                   // (an empty split still writes its zero slab)
-  const long long n_chunks = (p_end - p_begin + WG_C - 1) / WG_C;
-  const long long n_pairs = (n_chunks + 1) / 2;            // both roles run the same number of barrier pairs
-
-  if (wave >= 4) {
-    // ---------------- loaders ----------------
-    const int lw = wave - 4;
-    const int g = lane & 7;                                  // 4-point group of the chunk
-    const int fq = 2 * ((lane >> 4) + 4 * lw) + ((lane >> 3) & 1);      // float4 column of the 128-feature row
-    const unsigned offa = (unsigned)(4 * g) * (unsigned)lda + (unsigned)(k0 + 4 * fq);     // lane offsets (floats) from a chunk's first row
-    const unsigned offb = (unsigned)(4 * g) * (unsigned)ldb + (unsigned)(n0 + 4 * fq);
-    const int lds_off = (4 * fq) * WG_CP + 4 * g;           // plane offset (halfs) of the lane's first feature
-    wg_f32x4 a0[4], b0[4], a1[4], b1[4];
-    // rows past the split's end re-read its last row and count as zero
-    auto load4 = [&](const float* __restrict__ X, int ld, unsigned off, long long p0, wg_f32x4* v) {
-      const float* base = X + p0 * ld;                        // uniform
-      if (p0 + WG_C <= p_end) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const wg_f32x4u*>(base + (long long)i * ld + off);
-      } else {
-        const long long lastrow = p_end - 1;                  // >= p_begin (n_chunks > 0 when anything is loaded)
-        const wg_f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const long long row = p0 + 4 * g + i;
-          const bool ok = row <= lastrow;
-          const wg_f32x4 t = *reinterpret_cast<const wg_f32x4u*>(X + (ok ? row : lastrow) * ld + (off - (unsigned)(4 * g) * (unsigned)ld));
-          v[i] = ok ? t : z;
-        }
-      }
-    };
-    auto store4 = [&](const wg_f32x4* v, float s, _Float16* hi) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        wg_f32x4 xs = {v[0][k] * s, v[1][k] * s, v[2][k] * s, v[3][k] * s};
-        const wg_f16x4 ph = __builtin_convertvector(xs, wg_f16x4);
-        const wg_f32x4 res = (xs - __builtin_convertvector(ph, wg_f32x4)) * 2048.f;
-        const wg_f16x4 pl = __builtin_convertvector(res, wg_f16x4);
-        *reinterpret_cast<wg_f16x4*>(hi + lds_off + k * WG_CP) = ph;
-        *reinterpret_cast<wg_f16x4*>(hi + PLANE + lds_off + k * WG_CP) = pl;
-      }
-    };
-    if (n_chunks > 0) {
-      load4(A, lda, offa, p_begin, a0);
-      load4(B, ldb, offb, p_begin, b0);
-      load4(A, lda, offa, p_begin + WG_C, a1);
-      load4(B, ldb, offb, p_begin + WG_C, b1);
-      store4(a0, sa, planes);
-      store4(b0, sb, planes + 2 * PLANE);
-      load4(A, lda, offa, p_begin + 2 * WG_C, a0);
-      load4(B, ldb, offb, p_begin + 2 * WG_C, b0);
-    }
-    __syncthreads();
-    for (long long pr = 0, p0 = p_begin; pr < n_pairs; ++pr, p0 += 2 * WG_C) {
-      // chunk p0 is being multiplied from buffer 0: set 1 (chunk p0 + C) -> buffer 1, then its registers take chunk p0 + 3 C
-      store4(a1, sa, planes + BUF);
-      store4(b1, sb, planes + BUF + 2 * PLANE);
-      load4(A, lda, offa, p0 + 3 * WG_C, a1);
-      load4(B, ldb, offb, p0 + 3 * WG_C, b1);
-      __syncthreads();
-      // chunk p0 + C is being multiplied from buffer 1: set 0 (chunk p0 + 2 C) -> buffer 0, its registers take chunk p0 + 4 C
-      store4(a0, sa, planes);
-      store4(b0, sb, planes + 2 * PLANE);
-      load4(A, lda, offa, p0 + 4 * WG_C, a0);
-      load4(B, ldb, offb, p0 + 4 * WG_C, b0);
-      __syncthreads();
-    }
-    return;
-  }
-
-  // ---------------- multipliers ----------------
-  const int r = lane & 31, h = lane >> 5;
-  const int wk = wave >> 1, wn = wave & 1;
-  f32x16 acc0[2][2] = {}, acc1[2][2] = {};
-  const _Float16* Ap = planes + ((wk * 2) * 32 + r) * WG_CP + 8 * h;
-  const _Float16* Bp = planes + 2 * PLANE + ((wn * 2) * 32 + r) * WG_CP + 8 * h;
-  auto multiply = [&](int buf) {
-    wg_f16x8 av[2][2][2], bv[2][2][2];                      // [k-step][block][plane]: all of a chunk's fragments up front
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          av[s][i][p] = *reinterpret_cast<const wg_f16x8*>(Ap + buf * BUF + p * PLANE + i * 32 * WG_CP + 16 * s);
-          bv[s][i][p] = *reinterpret_cast<const wg_f16x8*>(Bp + buf * BUF + p * PLANE + i * 32 * WG_CP + 16 * s);
-        }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s][i][1], bv[s][j][0], acc1[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s][i][0], bv[s][j][0], acc0[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[s][i][0], bv[s][j][1], acc1[i][j], 0, 0, 0);
-    }
-  };
-  __syncthreads();
-  for (long long pr = 0; pr < n_pairs; ++pr) {
-    multiply(0);
-    __syncthreads();
-    multiply(1);          // (an odd chunk count: the loaders filled this buffer with zeros)
-    __syncthreads();
-  }
-#pragma unroll
-  for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-      const int n = n0 + (wn * 2 + bj) * 32 + r;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int k = k0 + (wk * 2 + bi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        out[(long long)k * N + n] = fmaf(acc1[bi][bj][i], 1.f / 2048.f, acc0[bi][bj][i]) * ia * ib;
-      }
-    }
-}
-
-__global__ void __launch_bounds__(WGG_BIG_THREADS, 1) k_wgrad_group_big(const WggArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
-  int si, split, tile;
-  if (!wgg_locate(a, si, split, tile)) return;
-  const WggSeg& g = a.seg[si];
-  const WggSrc& s = a.src[g.src];
-  const long long p_begin = (long long)split * s.rows;
-  long long p_end = p_begin + s.rows;
-  if (p_end > s.P) p_end = s.P;
-  float* slab = s.partial + (long long)split * s.K * s.N;
-  const int ti = tile / g.tiles_n, tj = tile - ti * g.tiles_n;
-  float sa, ia, sb, ib;
-  wg_scale_from_max(*s.amax_a, sa, ia);
-  wg_scale_from_max(*s.amax_b, sb, ib);
-  wgrad3_big_tile(s.A, s.lda, s.B, s.ldb, s.N, p_begin, p_end, slab, g.k_off + ti * WG_T, g.n_off + tj * WG_T, sa, ia, sb, ib, wg_lds);
-}
-
 // out (+)= sum over the S slabs: a workgroup owns 32 vectors (VEC floats each) of one output, 8 slab phases
 template <int VEC>
 __device__ __forceinline__ void wgg_reduce_block(const WggOut& o, int blk, float* red) {
@@ -1226,50 +1068,26 @@ static inline bool wgg_narrow(const float* A, int lda, int K, int N) {
 
 constexpr int WGG_DEFAULT_ITEMS = 1024;     // 128 x 128-tile equivalents a grouped launch aims for (4 per CU)
 
-// The regions of a K x N output and the kind of item that tiles each (at most 5).  big = the full 128-row x 256 / 128-column
-// tiles go to k_wgrad_group_big; what is left (ragged edges) and everything when !big is tiled as the per-layer launcher
-// does: 128 x 128 tiles, remainders of at most 64 as 32-wide strips.
+// The regions of a K x N output and the kind of item that tiles each (at most 3), as the per-layer launcher cuts it: 128 x 128
+// tiles over [0, Km) x [0, Nm), remainders of at most 64 as 32-wide strips (K strip spans all of N, N strip spans [0, Km)),
+// larger remainders as a further (ragged) tile.
 struct WggRegion { int kind, k_off, n_off, k_end, n_end, tiles_k, tiles_n; };
-static int wgg_regions(int K, int N, bool big, WggRegion* rg) {
+static int wgg_regions(int K, int N, WggRegion* rg) {
   int n = 0;
-  int Kb = 0, Nb = 0;
-  if (big) {
-    Kb = K / WG_T * WG_T;
-    Nb = Kb > 0 ? N / WG_T * WG_T : 0;
-    if (Nb == 0) Kb = 0;
-    if (Kb > 0) rg[n++] = {4, 0, 0, Kb, Nb, Kb / WG_T, Nb / WG_T};
-  }
-  // columns [Nb, N) of the rows [0, Kb)
-  if (Kb > 0 && N > Nb) {
-    const int w = N - Nb;
-    if (w <= 2 * WG_STRIP) rg[n++] = {2, 0, Nb, Kb, N, Kb / WG_T, (w + WG_STRIP - 1) / WG_STRIP};
-    else rg[n++] = {0, 0, Nb, Kb, N, Kb / WG_T, (w + WG_T - 1) / WG_T};
-  }
-  // rows [Kb, K), all columns: as the per-layer plan
-  if (K > Kb) {
-    const int hK = K - Kb, rk = hK % WG_T, rn = N % WG_T;
-    const int Km = (rk != 0 && rk <= 2 * WG_STRIP) ? hK - rk : hK;          // rows (from Kb) covered by 128-row tiles
-    const int Nm = (rn != 0 && rn <= 2 * WG_STRIP) ? N - rn : N;
-    if (Km > 0 && Nm > 0) rg[n++] = {0, Kb, 0, Kb + Km, Nm, (Km + WG_T - 1) / WG_T, (Nm + WG_T - 1) / WG_T};
-    if (Km > 0 && N > Nm) rg[n++] = {2, Kb, Nm, Kb + Km, N, (Km + WG_T - 1) / WG_T, (N - Nm + WG_STRIP - 1) / WG_STRIP};
-    if (hK > Km) rg[n++] = {1, Kb + Km, 0, K, N, (hK - Km + WG_STRIP - 1) / WG_STRIP, (N + WG_T - 1) / WG_T};
-  }
+  const int rk = K % WG_T, rn = N % WG_T;
+  const int Km = (rk != 0 && rk <= 2 * WG_STRIP) ? K - rk : K;
+  const int Nm = (rn != 0 && rn <= 2 * WG_STRIP) ? N - rn : N;
+  if (Km > 0 && Nm > 0) rg[n++] = {0, 0, 0, Km, Nm, (Km + WG_T - 1) / WG_T, (Nm + WG_T - 1) / WG_T};
+  if (Km > 0 && N > Nm) rg[n++] = {2, 0, Nm, Km, N, (Km + WG_T - 1) / WG_T, (N - Nm + WG_STRIP - 1) / WG_STRIP};
+  if (K > Km) rg[n++] = {1, Km, 0, K, N, (K - Km + WG_STRIP - 1) / WG_STRIP, (N + WG_T - 1) / WG_T};
   return n;
 }
-static double wgg_units(int K, int N, bool big) {        // work of one split in 128 x 128-tile equivalents
-  WggRegion rg[8];
-  const int n = wgg_regions(K, N, big, rg);
+static double wgg_units(int K, int N) {        // work of one split in 128 x 128-tile equivalents
+  WggRegion rg[4];
+  const int n = wgg_regions(K, N, rg);
   double u = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const double per = (rg[i].kind == 1 || rg[i].kind == 2) ? 0.25 : 1.0;
-    u += per * rg[i].tiles_k * rg[i].tiles_n;
-  }
+  for (int i = 0; i < n; ++i) u += ((rg[i].kind == 1 || rg[i].kind == 2) ? 0.25 : 1.0) * rg[i].tiles_k * rg[i].tiles_n;
   return u;
-}
-
-static bool wgg_use_big() {
-  static const bool v = [] { const char* e = getenv("NDJIR_WGRAD_BIG"); return e && e[0] == '1'; }();      // (opt-in: measured slower, see DESIGN)
-  return v;
 }
 
 // outputs [o0, o1) whose sources (those with points) and segments fit one argument block
@@ -1278,7 +1096,7 @@ static int wgg_chunk_end(int o0, int n_src, const long long* P, const int* out_i
   while (o1 < n_out && o1 - o0 < WGG_MAX_OUT) {
     int cnt = 0;
     for (int i = 0; i < n_src; ++i) cnt += (out_id[i] == o1 && P[i] > 0);
-    if (ns + cnt > WGG_MAX_SRC || 5 * (ns + cnt) > 2 * WGG_MAX_SEG) break;      // (<= 5 regions per source over two launches)
+    if (ns + cnt > WGG_MAX_SRC || 3 * (ns + cnt) > WGG_MAX_SEG) break;      // (<= 3 regions per source)
     ns += cnt;
     ++o1;
   }
@@ -1289,12 +1107,11 @@ static int wgg_chunk_end(int o0, int n_src, const long long* P, const int* out_i
 static void wgg_split_plan(int o0, int o1, int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id,
                            const int* K, const int* N, int target_items, int* S, long long* rows) {
   if (target_items <= 0) target_items = WGG_DEFAULT_ITEMS;
-  const bool big = wgg_use_big();
   double units = 0.0;               // main-tile equivalents x points
   for (int i = 0; i < n_src; ++i) {
     const int o = out_id[i];
     if (o < o0 || o >= o1 || P[i] <= 0 || wgg_narrow(A ? A[i] : nullptr, lda[i], K[o], N[o])) continue;
-    units += wgg_units(K[o], N[o], big) * (double)P[i];
+    units += wgg_units(K[o], N[o]) * (double)P[i];
   }
   long long target = (long long)(units / target_items);
   target = (target + WG_C - 1) / WG_C * WG_C;
@@ -1310,7 +1127,7 @@ static void wgg_split_plan(int o0, int o1, int n_src, const float* const* A, con
     }
     long long s = (P[i] + target - 1) / target;
     long long r = (P[i] + s - 1) / s;
-    r = (r + 2 * WG_C - 1) / (2 * WG_C) * (2 * WG_C);      // whole pairs of chunks (the specialised tile's loop)
+    r = (r + WG_C - 1) / WG_C * WG_C;
     S[i] = (int)((P[i] + r - 1) / r);
     rows[i] = r;
   }
@@ -1356,7 +1173,6 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_group), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_group_big), hipFuncAttributeMaxDynamicSharedMemorySize, WGG_BIG_LDS);
     attr = true;
   }
   if (n_src > 4096) return NDJIR_ERR_ARG;
@@ -1364,12 +1180,10 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
     if (out_id[i] < 0 || out_id[i] >= n_out) return NDJIR_ERR_ARG;
   for (int o = 0; o < n_out; ++o)
     if (K[o] > 32767 || N[o] > 32767) return NDJIR_ERR_UNSUPPORTED;
-  const bool big = wgg_use_big();
   int* S = (int*)alloca(sizeof(int) * n_src);
   long long* rows = (long long*)alloca(sizeof(long long) * n_src);
   long long off = 0;                 // running slab offset in the workspace (mirrors wgrad_group_workspace)
-  // per chunk of outputs whose sources / segments fit an argument block: the full tiles (k_wgrad_group_big), the ragged
-  // rest (k_wgrad_group), the reduction
+  // per chunk of outputs whose sources / segments fit an argument block: one k_wgrad_group launch and its reduction
   for (int o0 = 0; o0 < n_out;) {
     const int o1 = wgg_chunk_end(o0, n_src, P, out_id, n_out);
     if (o1 == o0) return NDJIR_ERR_UNSUPPORTED;       // one output with more sources than an argument block holds
@@ -1398,42 +1212,32 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
       w.S = s_seen; w.accum = accum ? accum[o] : 0;
       off += ((long long)s_seen * kn + 3) / 4 * 4;
     }
-    // pass 0: the big tiles; pass 1: 128 x 128 tiles first, then the strips, then the narrow items
-    for (int pass = 0; pass < 2; ++pass) {
-      args.n_seg = 0;
-      int blocks = 0;
-      static const int order[2][4] = {{4, 5, -1, -1}, {0, 1, 2, 3}};
-      for (int q = 0; q < 4; ++q) {
-        const int kind = order[pass][q];
-        if (kind < 0) continue;
-        for (int i = 0; i < ns; ++i) {
-          const WggSrc& s = args.src[i];
-          const bool narrow = wgg_narrow(s.A, s.lda, s.K, s.N);
-          WggRegion rg[8];
-          int nr = 0;
-          if (narrow) {
-            if (kind == 3) rg[nr++] = {3, 0, 0, s.K, s.N, 1, 1};
-          } else {
-            nr = wgg_regions(s.K, s.N, big, rg);
-          }
-          for (int t = 0; t < nr; ++t) {
-            if (rg[t].kind != kind) continue;
-            const int tiles = rg[t].tiles_k * rg[t].tiles_n;
-            if (tiles <= 0) continue;
-            if (args.n_seg >= WGG_MAX_SEG || tiles > 32767) return NDJIR_ERR_UNSUPPORTED;
-            WggSeg& g = args.seg[args.n_seg++];
-            g.first = blocks; g.count = (s.S * tiles + 7) / 8 * 8; g.src = (short)i; g.kind = (short)kind;
-            g.tiles = (short)tiles; g.tiles_n = (short)rg[t].tiles_n;
-            g.k_off = (short)rg[t].k_off; g.n_off = (short)rg[t].n_off; g.k_end = (short)rg[t].k_end; g.n_end = (short)rg[t].n_end;
-            blocks += g.count;
-          }
+    // segments: 128 x 128 tiles of every source first, then the strips, then the narrow items
+    int blocks = 0;
+    for (int kind = 0; kind < 4; ++kind)
+      for (int i = 0; i < ns; ++i) {
+        const WggSrc& s = args.src[i];
+        WggRegion rg[4];
+        int nr = 0;
+        if (wgg_narrow(s.A, s.lda, s.K, s.N)) {
+          if (kind == 3) rg[nr++] = {3, 0, 0, s.K, s.N, 1, 1};
+        } else {
+          nr = wgg_regions(s.K, s.N, rg);
+        }
+        for (int t = 0; t < nr; ++t) {
+          if (rg[t].kind != kind) continue;
+          const int tiles = rg[t].tiles_k * rg[t].tiles_n;
+          if (tiles <= 0) continue;
+          if (args.n_seg >= WGG_MAX_SEG || tiles > 32767) return NDJIR_ERR_UNSUPPORTED;
+          WggSeg& g = args.seg[args.n_seg++];
+          g.first = blocks; g.count = (s.S * tiles + 7) / 8 * 8; g.src = (short)i; g.kind = (short)kind;
+          g.tiles = (short)tiles; g.tiles_n = (short)rg[t].tiles_n;
+          g.k_off = (short)rg[t].k_off; g.n_off = (short)rg[t].n_off; g.k_end = (short)rg[t].k_end; g.n_end = (short)rg[t].n_end;
+          blocks += g.count;
         }
       }
-      if (blocks <= 0) continue;
-      if (pass == 0)
-        hipLaunchKernelGGL(k_wgrad_group_big, dim3(blocks), dim3(WGG_BIG_THREADS), WGG_BIG_LDS, stream, args);
-      else
-        hipLaunchKernelGGL(k_wgrad_group, dim3(blocks), dim3(WG_THREADS), 2 * (WG_T + WG_T) * WG_CP * sizeof(unsigned short), stream, args);
+    if (blocks > 0) {
+      hipLaunchKernelGGL(k_wgrad_group, dim3(blocks), dim3(WG_THREADS), 2 * (WG_T + WG_T) * WG_CP * sizeof(unsigned short), stream, args);
       if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
     }
     int rb = 0;

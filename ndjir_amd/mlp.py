@@ -59,7 +59,7 @@ def _init_math():
 PROFILE = None
 
 
-def chain_kernel_symbol(mode, P, K0, Ks, Ns, has_output=True, skip_layer=-1, with_bias_gradients=False):
+def chain_kernel_symbol(mode, P, K0, Ks, Ns, has_output=True, skip_layer=-1, skip_split=0, with_bias_gradients=False):
     """The symbol (as rocprofv3 prints it) of the kernel a chain launch of this shape runs under the current arithmetic and
     tile setting: the library's own dispatch decision (ndjir_mlp_chain_kernel), nothing is launched."""
     import ctypes
@@ -67,16 +67,16 @@ def chain_kernel_symbol(mode, P, K0, Ks, Ns, has_output=True, skip_layer=-1, wit
     buf = ctypes.create_string_buffer(64)
     f = lib.load().ndjir_mlp_chain_kernel
     f.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
-                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
     f.restype = ctypes.c_int
     rc = f(int(mode), int(P), int(K0), L, (ctypes.c_int * L)(*[int(k) for k in Ks]), (ctypes.c_int * L)(*[int(n) for n in Ns]),
-           1 if has_output else 0, int(skip_layer), 1 if with_bias_gradients else 0, buf, 64)
+           1 if has_output else 0, int(skip_layer), int(skip_split), 1 if with_bias_gradients else 0, buf, 64)
     return buf.value.decode() if rc == 0 else f"ndjir chain (status {rc})"
 
 
 def _launch_symbol(name, args):
     if name in ("mlp_chain", "mlp_chain_ex"):
-        return chain_kernel_symbol(args[0], args[1], args[4], args[8], args[9], bool(args[17]), args[19],
+        return chain_kernel_symbol(args[0], args[1], args[4], args[8], args[9], bool(args[17]), args[19], args[21],
                                    any(t is not None for t in args[13]) or (args[29 if name == "mlp_chain_ex" else 24] is not None))
     if name == "mlp_wgrad_group":
         return "ndjir::k_wgrad_group (+ k_wgrad_group_reduce)"

@@ -205,16 +205,26 @@ def test_in_place_gradient_bucket_equals_autograd(gpu, variant):
     from ndjir_amd.step import Step
     conf = cfg.load(variant, ["geometric_network.voxel.grid_size=16"])
     step = Step(conf, 16, gpu, 0, 1)
-    assert step.in_place and len(mlp._GRAD_BUF) == len(step.mlp_params)
+    # the views are registered only while `compute` runs (mlp.grad_buffers): outside a step the registry is empty, so another
+    # backward pass over the same parameters gets ordinary autograd gradients and cannot add into the bucket
+    assert step.in_place and len(step._grad_pairs) == len(step.mlp_params) and len(mlp._GRAD_BUF) == 0
     for _ in range(2):                       # twice: the bucket is re-zeroed, not accumulated across steps
         step.forward_backward()
     got = step.flat_grad.clone()
-    mlp.clear_grad_buffers()
+    assert len(mlp._GRAD_BUF) == 0
+    pairs, step._grad_pairs = step._grad_pairs, []      # the same step with every gradient returned through autograd
     step.forward_backward()
     want = step.flat_grad.clone()
+    step._grad_pairs = pairs
     assert float(want.abs().max()) > 0
     for name, v in zip(step.mlp_names, step.grad_views):
         off = v.storage_offset()
         a, b = got[off:off + v.numel()], want[off:off + v.numel()]
         err = float((a - b).norm() / max(float(b.norm()), 1e-30))
         assert err < 2e-5, (name, err)
+    # a backward pass of somebody else over the step's parameters, after the step: real gradients, bucket untouched
+    before = step.flat_grad.clone()
+    W = step.mlp_params[[i for i, p in enumerate(step.mlp_params) if p.dim() == 2][0]]
+    x = torch.randn(64, W.shape[0], device=gpu)
+    g, = torch.autograd.grad(mlp.fused_mlp(x, [W], [None]).square().sum(), [W])
+    assert g is not None and float(g.abs().max()) > 0 and torch.equal(step.flat_grad, before)
