@@ -878,7 +878,8 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
 constexpr int WGG_MAX_SRC = 24;
 constexpr int WGG_MAX_SEG = 56;
 constexpr int WGG_MAX_OUT = 24;
-constexpr int WGG_NARROW_ROWS = 1024;     // points per narrow work item
+constexpr int WGG_NARROW_ROWS = 128;      // points per narrow work item: its row loop is a latency chain (32 steps of 4 rows), so
+                                          // items are kept short and issued FIRST -- a 1024-row item ran ~100 us and was the tail of every launch
 
 struct WggSrc {
   const float* A;
@@ -1212,10 +1213,13 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
       w.S = s_seen; w.accum = accum ? accum[o] : 0;
       off += ((long long)s_seen * kn + 3) / 4 * 4;
     }
-    // segments: 128 x 128 tiles of every source first, then the strips, then the narrow items
+    // segments: the narrow items first (short, but each a serial chain: they finish under the tiles), then the 128 x 128
+    // tiles of every source, then the strips (a quarter of a tile's work each: they fill the tail)
     int blocks = 0;
-    for (int kind = 0; kind < 4; ++kind)
+    static const int order[4] = {3, 0, 1, 2};
+    for (int q = 0; q < 4; ++q)
       for (int i = 0; i < ns; ++i) {
+        const int kind = order[q];
         const WggSrc& s = args.src[i];
         WggRegion rg[4];
         int nr = 0;

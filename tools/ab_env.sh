@@ -2,7 +2,7 @@
 # same-box A/B of the default bench under environment settings: bash tools/ab_env.sh reps "A=1" "B=2 C=3" ...   ("-" = none)
 REPS=$1; shift
 run() {
-  env $2 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --train-steps 0 2>/dev/null | python -c "
+  env $2 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs --train-steps 0 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d['kernels']

@@ -2,7 +2,7 @@
 # same-box A/B of the in-tree library against variants: bash tools/ab_lib.sh <variant.so> [reps]   (bench ms/step + chain kernel averages)
 V=$1; REPS=${2:-3}
 run() {
-  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --train-steps 0 2>/dev/null | python -c "
+  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs --train-steps 0 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d['kernels']

@@ -9,10 +9,10 @@ SA=4; SB=12; WARM=1     # two eager runs per point: per-step kernel time = (run 
 for c in $CONFIGS; do
   for R in 256 512 1024 2048 4096; do
     # whole-step time from graph replays (what the bench line reports)
-    python3 bench.py --config $c --rays $R --steps 10 --warmup 3 --no-cpu-baseline --train-steps 0 > $O/${c}_R$R.json 2> $O/${c}_R$R.err
+    python3 bench.py --config $c --rays $R --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs --train-steps 0 > $O/${c}_R$R.json 2> $O/${c}_R$R.err
     # per-kernel durations from an eager run under the kernel trace
     for S in $SA $SB; do
-      rocprofv3 --kernel-trace --stats -d $O/ks -o run --output-format csv -- python3 bench.py --config $c --rays $R --exec eager --steps $S --warmup $WARM --no-cpu-baseline --train-steps 0 > /dev/null 2>> $O/${c}_R$R.err
+      rocprofv3 --kernel-trace --stats -d $O/ks -o run --output-format csv -- python3 bench.py --config $c --rays $R --exec eager --steps $S --warmup $WARM --no-cpu-baseline --no-extra-legs --train-steps 0 > /dev/null 2>> $O/${c}_R$R.err
       f=$(find $O/ks -name "*kernel_stats.csv" | head -1)
       cp "$f" $O/${c}_R${R}_s$S.csv
       rm -rf $O/ks
