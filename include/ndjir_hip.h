@@ -556,8 +556,9 @@ int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb, int K, int
  * splits of thousands of points instead of hundreds, partial slabs smaller by the number of layers grouped, one reduction
  * launch for all.  Two sources of one output: the geometric network's dW_j = A_j^T delta_j + gbar_j^T s_j (its double
  * backward through nn.grad, python/renderer.py:52).  NDJIR_MATH_F16X3 only (NDJIR_ERR_UNSUPPORTED otherwise); amax_a[i] /
- * amax_b[i] (device, recorded maxima as for ndjir_mlp_wgrad) are required except for outputs <= 8 wide, which take the
- * streaming path.  `workspace`: ndjir_mlp_wgrad_group_workspace(...) floats for the same sources / outputs / target_items
+ * amax_b[i]: device, recorded maxima as for ndjir_mlp_wgrad; a null entry makes every work item find the maximum of the
+ * values it multiplies itself (one extra pass over them: meant for the few-hundred-row per-ray layers); outputs <= 8 wide
+ * take a streaming path that needs none.  `workspace`: ndjir_mlp_wgrad_group_workspace(...) floats for the same sources / outputs / target_items
  * (work items the launch aims for: the point axis of every source is split accordingly; 0 = default, 4 per CU). */
 long long ndjir_mlp_wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id,
                                           int n_out, const int* K, const int* N, int target_items);

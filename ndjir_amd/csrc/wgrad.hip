@@ -977,6 +977,30 @@ __device__ __forceinline__ bool wgg_locate(const WggArgs& a, int& si, int& split
   return split < a.src[a.seg[si].src].S;
 }
 
+// largest finite |X[p][c]| (bit pattern) over the rows [p0, p1) and columns [c0, c1): the operand scale of a work item whose
+// source came without a recorded maximum (single-layer operators on a few hundred per-ray rows).  Every item de-scales its own
+// partial slab, so items of one source may use different scales -- each only has to bound the values the item multiplies.
+__device__ __forceinline__ unsigned wgg_tile_absmax(const float* __restrict__ X, int ld, int c0, int c1, long long p0, long long p1,
+                                                    unsigned* red) {
+  unsigned m = 0;
+  const int w = c1 - c0;
+#pragma unroll 4
+  for (long long p = p0 + (threadIdx.x >> 6); p < p1; p += WG_THREADS / 64)
+    for (int c = threadIdx.x & 63; c < w; c += 64) {
+      const unsigned b = __float_as_uint(X[p * ld + c0 + c]) & 0x7fffffffu;
+      if (b < 0x7f800000u && b > m) m = b;
+    }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int st = WG_THREADS / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st && red[threadIdx.x + st] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + st];
+    __syncthreads();
+  }
+  m = red[0];
+  __syncthreads();
+  return m;
+}
+
 __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
   int si, split, tile;
@@ -993,18 +1017,21 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggArgs a) 
     return;
   }
   const int ti = tile / g.tiles_n, tj = tile - ti * g.tiles_n;
+  const int k0 = g.k_off + ti * (kind == 1 ? WG_STRIP : WG_T), n0 = g.n_off + tj * (kind == 2 ? WG_STRIP : WG_T);
+  unsigned ma, mb;
+  if (s.amax_a) ma = *s.amax_a;
+  else { const int k1 = k0 + (kind == 1 ? WG_STRIP : WG_T); ma = wgg_tile_absmax(s.A, s.lda, k0, k1 < g.k_end ? k1 : g.k_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds)); }
+  if (s.amax_b) mb = *s.amax_b;
+  else { const int n1 = n0 + (kind == 2 ? WG_STRIP : WG_T); mb = wgg_tile_absmax(s.B, s.ldb, n0, n1 < g.n_end ? n1 : g.n_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds)); }
   float sa, ia, sb, ib;
-  wg_scale_from_max(*s.amax_a, sa, ia);
-  wg_scale_from_max(*s.amax_b, sb, ib);
+  wg_scale_from_max(ma, sa, ia);
+  wg_scale_from_max(mb, sb, ib);
   if (kind == 0)
-    wgrad3_tile<2, 2, 2, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, g.k_off + ti * WG_T, g.n_off + tj * WG_T, g.k_end, g.n_end,
-                            sa, ia, sb, ib, wg_lds);
+    wgrad3_tile<2, 2, 2, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
   else if (kind == 1)
-    wgrad3_tile<1, 4, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, g.k_off + ti * WG_STRIP, g.n_off + tj * WG_T, g.k_end, g.n_end,
-                            sa, ia, sb, ib, wg_lds);
+    wgrad3_tile<1, 4, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
   else
-    wgrad3_tile<4, 1, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, g.k_off + ti * WG_T, g.n_off + tj * WG_STRIP, g.k_end, g.n_end,
-                            sa, ia, sb, ib, wg_lds);
+    wgrad3_tile<4, 1, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
 }
 
 // out (+)= sum over the S slabs: a workgroup owns 32 vectors (VEC floats each) of one output, 8 slab phases
@@ -1200,8 +1227,6 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
       for (int i = 0; i < n_src; ++i) {
         if (out_id[i] != o || S[i] <= 0) continue;
         if (!A[i] || !B[i] || lda[i] < K[o] || ldb[i] < N[o]) return NDJIR_ERR_ARG;
-        const bool narrow = wgg_narrow(A[i], lda[i], K[o], N[o]);
-        if (!narrow && (!amax_a || !amax_b || !amax_a[i] || !amax_b[i])) return NDJIR_ERR_ARG;
         WggSrc& s = args.src[ns++];
         s.A = A[i]; s.B = B[i]; s.amax_a = amax_a ? amax_a[i] : nullptr; s.amax_b = amax_b ? amax_b[i] : nullptr;
         s.partial = workspace + off + (long long)s_seen * kn;

@@ -430,6 +430,7 @@ def wgrad(A, B, out=None, accum=False, amax_a=None, amax_b=None):
 
 _WORKSPACE_G = {}
 WGRAD_GROUP_ITEMS = int(os.environ.get("NDJIR_WGRAD_ITEMS", "0"))     # work items a grouped launch aims for (0 = the library's default)
+SELF_AMAX_MAX_ROWS = int(os.environ.get("NDJIR_WGRAD_SELF_AMAX_ROWS", "16384"))      # operand pairs without recorded maxima up to this many rows join a grouped launch
 _NO_GROUP = bool(os.environ.get("NDJIR_NO_WGRAD_GROUP"))            # A/B: every weight gradient through the per-layer kernel
 _DEFERRED = None       # None = off; else the list of pending (out, accum, sources) jobs of `deferred_wgrads`
 
@@ -472,13 +473,15 @@ def wgrad_group(jobs):
     jobs: list of (out, accum, sources); out (K, N) with column stride 1 (row stride free: a column slice of a parameter's
     gradient buffer); accum: add to `out`; sources: list of (A (P, K), B (P, N), amax_a, amax_b) whose products are summed --
     row-major views with column stride 1, recorded maxima as for `wgrad`.  Inside `deferred_wgrads()` the jobs are queued
-    and launched together when the block ends.  Operand pairs without a recorded maximum, and any arithmetic but f16x3,
-    take the per-layer kernel."""
+    and launched together when the block ends.  An operand without a recorded maximum makes the kernel's work items find
+    their own (an extra pass over their rows: fine for the per-ray layers' few hundred rows; from SELF_AMAX_MAX_ROWS rows on
+    such a pair takes the per-layer kernel with its streaming pre-pass).  Any arithmetic but f16x3: the per-layer kernel."""
     jobs = [(o, a, [s for s in srcs if s[0].shape[0] > 0]) for o, a, srcs in jobs]
     grouped = []
     for out, accum, srcs in jobs:
         narrow = out.shape[1] <= 8
-        ok = not _NO_GROUP and get_math() == MATH_F16X3 and out.is_cuda and srcs and all((narrow or (ma is not None and mb is not None)) for _, _, ma, mb in srcs)
+        ok = not _NO_GROUP and get_math() == MATH_F16X3 and out.is_cuda and srcs and all(
+            (narrow or (ma is not None and mb is not None) or a.shape[0] <= SELF_AMAX_MAX_ROWS) for a, _, ma, mb in srcs)
         if ok:
             grouped.append((out, accum, srcs))
             continue
@@ -968,7 +971,7 @@ class MatMul(Function):
             x2, g2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
             wt = grad_target(W) if (first_order and not ctx.t) else None
             if wt is not None:       # accumulate-in-place gradient buffer (set_grad_buffer): W may be a block of rows of a parameter
-                wgrad(x2.detach().contiguous(), g2.detach().contiguous(), out=wt, accum=True)
+                wgrad_group([(wt, True, [(x2.detach().contiguous(), g2.detach().contiguous(), None, None)])])
             else:
                 gW = WGradOp.apply(g2, x2) if ctx.t else WGradOp.apply(x2, g2)
         if ctx.has_bias and ctx.needs_input_grad[3]:
