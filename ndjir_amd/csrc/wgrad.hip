@@ -875,9 +875,9 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
 // PMC on the grouped kernel (profiles/r04_pmc_wgrad_group.txt): FETCH_SIZE = the algorithmic operand bytes, half of the L2
 // requests hit (the tile pair of a split), the matrix pipe busy 21 %, 63 % of the wave cycles waiting: ~10 bytes / clk / CU
 // of loads whatever the structure -- the rate MI355X_MICROARCH.md gives for HBM-bound global_load_dwordx4.
-constexpr int WGG_MAX_SRC = 24;
-constexpr int WGG_MAX_SEG = 56;
-constexpr int WGG_MAX_OUT = 24;
+constexpr int WGG_MAX_SRC = 20;      // per writer launch
+constexpr int WGG_MAX_SEG = 48;
+constexpr int WGG_MAX_OUT = 20;
 constexpr int WGG_NARROW_ROWS = 128;      // points per narrow work item: its row loop is a latency chain (32 steps of 4 rows), so
                                           // items are kept short and issued FIRST -- a 1024-row item ran ~100 us and was the tail of every launch
 
@@ -898,19 +898,31 @@ struct WggSeg {              // a run of consecutive workgroups tiling one regio
   short tiles, tiles_n;      // tiles of the region, tiles per tile row
   short k_off, n_off, k_end, n_end;   // the region: rows [k_off, k_end), columns [n_off, n_end) of dW
 };
-struct WggArgs {
-  int n_seg, pad;
-  WggSrc src[WGG_MAX_SRC];
-  WggSeg seg[WGG_MAX_SEG];
-};
 struct WggOut {
   float* out;                // (K, N), row stride ldo
   const float* partial;      // partial[S][K * N]
   int KN, N, ldo, S, accum;
   int first;                 // first workgroup of this output in the reduction launch
 };
-struct WggRedArgs {
-  int n_out, pad;
+// The whole group's work description lives in DEVICE memory (the head of the caller's workspace): a training step's ~57
+// operand pairs / ~150 segments do not fit the 4 KB of kernel arguments, and cutting the group into several launches costs
+// a drain of the machine per cut.  The table is written by tiny launches that carry pieces of it in THEIR arguments
+// (k_wgg_write: capturable into a HIP graph, no host memory for a replay to re-read), then ONE k_wgrad_group launch and ONE
+// k_wgrad_group_reduce launch read it.
+constexpr int WGT_MAX_SRC = 256;
+constexpr int WGT_MAX_SEG = 768;
+constexpr int WGT_MAX_OUT = 256;
+struct WggTable {
+  int n_seg, n_out, pad0, pad1;
+  WggSrc src[WGT_MAX_SRC];
+  WggSeg seg[WGT_MAX_SEG];
+  WggOut out[WGT_MAX_OUT];
+};
+struct WggPiece;
+struct WggPiece {            // what one writer launch carries (<= 4 KB of kernel arguments)
+  int n_src, n_seg, n_out, src0, seg0, out0, tot_seg, tot_out;
+  WggSrc src[WGG_MAX_SRC];
+  WggSeg seg[WGG_MAX_SEG];
   WggOut out[WGG_MAX_OUT];
 };
 
@@ -965,11 +977,14 @@ __device__ __forceinline__ void wgrad_narrow_rows(const float* __restrict__ A, i
 
 // workgroup -> (segment, split, tile): whole splits per XCD (workgroups are dealt round-robin to the 8 XCDs; first % 8 == 0,
 // count % 8 == 0), so that the tiles that share a range of points share an L2.  Returns false for an idle workgroup.
-__device__ __forceinline__ bool wgg_locate(const WggArgs& a, int& si, int& split, int& tile) {
+__device__ __forceinline__ bool wgg_locate(const WggTable& a, int& si, int& split, int& tile) {
   const int b = blockIdx.x;
-  si = 0;
-  for (int i = 1; i < a.n_seg; ++i)
-    if (b >= a.seg[i].first) si = i;
+  int lo = 0, hi = a.n_seg - 1;          // the last segment whose first workgroup is <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.seg[mid].first <= b) lo = mid; else hi = mid - 1;
+  }
+  si = lo;
   const int local = b - a.seg[si].first, count = a.seg[si].count, T = a.seg[si].tiles;
   const int vid = (local & 7) * (count >> 3) + (local >> 3);
   split = vid / T;
@@ -1001,8 +1016,25 @@ __device__ __forceinline__ unsigned wgg_tile_absmax(const float* __restrict__ X,
   return m;
 }
 
-__global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggArgs a) {
+__global__ void __launch_bounds__(256) k_wgg_write(const WggPiece p, WggTable* __restrict__ t) {
+  const int tid = threadIdx.x;
+  if (tid == 0) { t->n_seg = p.tot_seg; t->n_out = p.tot_out; }
+  // (plain word copies: the structs are PODs of 4-byte-aligned members)
+  const int ws = sizeof(WggSrc) / 4, wg = sizeof(WggSeg) / 4, wo = sizeof(WggOut) / 4;
+  const unsigned* a = reinterpret_cast<const unsigned*>(p.src);
+  unsigned* d = reinterpret_cast<unsigned*>(t->src + p.src0);
+  for (int i = tid; i < p.n_src * ws; i += 256) d[i] = a[i];
+  a = reinterpret_cast<const unsigned*>(p.seg);
+  d = reinterpret_cast<unsigned*>(t->seg + p.seg0);
+  for (int i = tid; i < p.n_seg * wg; i += 256) d[i] = a[i];
+  a = reinterpret_cast<const unsigned*>(p.out);
+  d = reinterpret_cast<unsigned*>(t->out + p.out0);
+  for (int i = tid; i < p.n_out * wo; i += 256) d[i] = a[i];
+}
+
+__global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
+  const WggTable& a = *tab;
   int si, split, tile;
   if (!wgg_locate(a, si, split, tile)) return;
   const WggSeg& g = a.seg[si];
@@ -1078,23 +1110,27 @@ __device__ __forceinline__ void wgg_reduce_block(const WggOut& o, int blk, float
   }
 }
 
-__global__ void __launch_bounds__(256) k_wgrad_group_reduce(const WggRedArgs a) {
+__global__ void __launch_bounds__(256) k_wgrad_group_reduce(const WggTable* __restrict__ tab) {
   __shared__ float red[4 * 256];
+  const WggTable& a = *tab;
   const int b = blockIdx.x;
-  int oi = 0;
-  for (int i = 1; i < a.n_out; ++i)
-    if (b >= a.out[i].first) oi = i;
-  const WggOut& o = a.out[oi];
+  int lo = 0, hi = a.n_out - 1;          // the last output whose first workgroup is <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.out[mid].first <= b) lo = mid; else hi = mid - 1;
+  }
+  const WggOut& o = a.out[lo];
   const bool vec = (o.KN & 3) == 0 && o.ldo == o.N && (reinterpret_cast<uintptr_t>(o.out) & 15) == 0;
-  if (vec) wgg_reduce_block<4>(o, b - o.first, red);
-  else wgg_reduce_block<1>(o, b - o.first, red);
+  const int blk = b - o.first;
+  if (vec) wgg_reduce_block<4>(o, blk, red);
+  else wgg_reduce_block<1>(o, blk, red);
 }
 
 static inline bool wgg_narrow(const float* A, int lda, int K, int N) {
   return N <= SW_NMAX && (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
 }
 
-constexpr int WGG_DEFAULT_ITEMS = 1024;     // 128 x 128-tile equivalents a grouped launch aims for (4 per CU)
+constexpr int WGG_DEFAULT_ITEMS = 2048;     // 128 x 128-tile equivalents a grouped launch aims for (8 per CU; 1024 .. 4096 measured within 1.5 %)
 
 // The regions of a K x N output and the kind of item that tiles each (at most 3), as the per-layer launcher cuts it: 128 x 128
 // tiles over [0, Km) x [0, Nm), remainders of at most 64 as 32-wide strips (K strip spans all of N, N strip spans [0, Km)),
@@ -1118,13 +1154,16 @@ static double wgg_units(int K, int N) {        // work of one split in 128 x 128
   return u;
 }
 
-// outputs [o0, o1) whose sources (those with points) and segments fit one argument block
+static_assert(sizeof(WggPiece) <= 4096, "kernel arguments of k_wgg_write");
+constexpr long long WGT_FLOATS = (sizeof(WggTable) + 15) / 16 * 4;      // the table at the head of the workspace, in floats
+
+// outputs [o0, o1) whose sources (those with points) and segments fit one table
 static int wgg_chunk_end(int o0, int n_src, const long long* P, const int* out_id, int n_out) {
   int ns = 0, o1 = o0;
-  while (o1 < n_out && o1 - o0 < WGG_MAX_OUT) {
+  while (o1 < n_out && o1 - o0 < WGT_MAX_OUT) {
     int cnt = 0;
     for (int i = 0; i < n_src; ++i) cnt += (out_id[i] == o1 && P[i] > 0);
-    if (ns + cnt > WGG_MAX_SRC || 3 * (ns + cnt) > WGG_MAX_SEG) break;      // (<= 3 regions per source)
+    if (ns + cnt > WGT_MAX_SRC || 3 * (ns + cnt) > WGT_MAX_SEG) break;      // (<= 3 regions per source)
     ns += cnt;
     ++o1;
   }
@@ -1161,7 +1200,7 @@ static void wgg_split_plan(int o0, int o1, int n_src, const float* const* A, con
   }
 }
 
-// launches of k_wgrad_group (= launches of k_wgrad_group_reduce) a grouped call issues: one per argument block
+// launches of k_wgrad_group (= launches of k_wgrad_group_reduce) a grouped call issues: one per table
 int wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n_out) {
   int n = 0;
   for (int o0 = 0; o0 < n_out;) {
@@ -1175,7 +1214,7 @@ int wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n
 
 long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id, int n_out,
                                 const int* K, const int* N, int target_items) {
-  if (n_src <= 0 || n_src > 4096) return 0;
+  if (n_src <= 0 || n_src > 65536) return 0;
   int* S = (int*)alloca(sizeof(int) * n_src);
   long long* rows = (long long*)alloca(sizeof(long long) * n_src);
   long long total = 0;
@@ -1183,6 +1222,7 @@ long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda
     const int o1 = wgg_chunk_end(o0, n_src, P, out_id, n_out);
     if (o1 == o0) return 0;
     wgg_split_plan(o0, o1, n_src, A, lda, P, out_id, K, N, target_items, S, rows);
+    total += WGT_FLOATS;
     for (int o = o0; o < o1; ++o) {
       long long st = 0;
       for (int i = 0; i < n_src; ++i)
@@ -1203,22 +1243,23 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_group), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     attr = true;
   }
-  if (n_src > 4096) return NDJIR_ERR_ARG;
+  if (n_src > 65536) return NDJIR_ERR_ARG;
   for (int i = 0; i < n_src; ++i)
     if (out_id[i] < 0 || out_id[i] >= n_out) return NDJIR_ERR_ARG;
   for (int o = 0; o < n_out; ++o)
     if (K[o] > 32767 || N[o] > 32767) return NDJIR_ERR_UNSUPPORTED;
   int* S = (int*)alloca(sizeof(int) * n_src);
   long long* rows = (long long*)alloca(sizeof(long long) * n_src);
-  long long off = 0;                 // running slab offset in the workspace (mirrors wgrad_group_workspace)
-  // per chunk of outputs whose sources / segments fit an argument block: one k_wgrad_group launch and its reduction
+  static thread_local WggTable tab;          // host copy of the table being built (49 KB)
+  long long off = 0;                         // running offset in the workspace (mirrors wgrad_group_workspace)
+  // per table-full of outputs (a training step: one): writer launches, ONE k_wgrad_group launch, ONE reduction launch
   for (int o0 = 0; o0 < n_out;) {
     const int o1 = wgg_chunk_end(o0, n_src, P, out_id, n_out);
-    if (o1 == o0) return NDJIR_ERR_UNSUPPORTED;       // one output with more sources than an argument block holds
+    if (o1 == o0) return NDJIR_ERR_UNSUPPORTED;       // one output with more sources than a table holds
     wgg_split_plan(o0, o1, n_src, A, lda, P, out_id, K, N, target_items, S, rows);
-    WggArgs args{};
-    WggRedArgs red{};
-    int ns = 0;
+    WggTable* dtab = reinterpret_cast<WggTable*>(workspace + off);
+    off += WGT_FLOATS;
+    int ns = 0, no = 0;
     for (int o = o0; o < o1; ++o) {
       // the slabs of an output's sources are consecutive: the reduction sums S_total slabs of K * N floats
       if (!out[o] || ldo[o] < N[o]) return NDJIR_ERR_ARG;
@@ -1227,25 +1268,25 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
       for (int i = 0; i < n_src; ++i) {
         if (out_id[i] != o || S[i] <= 0) continue;
         if (!A[i] || !B[i] || lda[i] < K[o] || ldb[i] < N[o]) return NDJIR_ERR_ARG;
-        WggSrc& s = args.src[ns++];
+        WggSrc& s = tab.src[ns++];
         s.A = A[i]; s.B = B[i]; s.amax_a = amax_a ? amax_a[i] : nullptr; s.amax_b = amax_b ? amax_b[i] : nullptr;
         s.partial = workspace + off + (long long)s_seen * kn;
         s_seen += S[i];
-        s.P = P[i]; s.rows = rows[i]; s.lda = lda[i]; s.ldb = ldb[i]; s.K = K[o]; s.N = N[o]; s.S = S[i];
+        s.P = P[i]; s.rows = rows[i]; s.lda = lda[i]; s.ldb = ldb[i]; s.K = K[o]; s.N = N[o]; s.S = S[i]; s.pad = 0;
       }
-      WggOut& w = red.out[red.n_out++];
+      WggOut& w = tab.out[no++];
       w.out = out[o]; w.partial = workspace + off; w.KN = (int)kn; w.N = N[o]; w.ldo = ldo[o];
       w.S = s_seen; w.accum = accum ? accum[o] : 0;
       off += ((long long)s_seen * kn + 3) / 4 * 4;
     }
     // segments: the narrow items first (short, but each a serial chain: they finish under the tiles), then the 128 x 128
     // tiles of every source, then the strips (a quarter of a tile's work each: they fill the tail)
-    int blocks = 0;
+    int blocks = 0, nseg = 0;
     static const int order[4] = {3, 0, 1, 2};
     for (int q = 0; q < 4; ++q)
       for (int i = 0; i < ns; ++i) {
         const int kind = order[q];
-        const WggSrc& s = args.src[i];
+        const WggSrc& s = tab.src[i];
         WggRegion rg[4];
         int nr = 0;
         if (wgg_narrow(s.A, s.lda, s.K, s.N)) {
@@ -1257,27 +1298,42 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
           if (rg[t].kind != kind) continue;
           const int tiles = rg[t].tiles_k * rg[t].tiles_n;
           if (tiles <= 0) continue;
-          if (args.n_seg >= WGG_MAX_SEG || tiles > 32767) return NDJIR_ERR_UNSUPPORTED;
-          WggSeg& g = args.seg[args.n_seg++];
+          if (nseg >= WGT_MAX_SEG || tiles > 32767) return NDJIR_ERR_UNSUPPORTED;
+          WggSeg& g = tab.seg[nseg++];
           g.first = blocks; g.count = (s.S * tiles + 7) / 8 * 8; g.src = (short)i; g.kind = (short)kind;
           g.tiles = (short)tiles; g.tiles_n = (short)rg[t].tiles_n;
           g.k_off = (short)rg[t].k_off; g.n_off = (short)rg[t].n_off; g.k_end = (short)rg[t].k_end; g.n_end = (short)rg[t].n_end;
           blocks += g.count;
         }
       }
-    if (blocks > 0) {
-      hipLaunchKernelGGL(k_wgrad_group, dim3(blocks), dim3(WG_THREADS), 2 * (WG_T + WG_T) * WG_CP * sizeof(unsigned short), stream, args);
-      if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
-    }
     int rb = 0;
-    for (int i = 0; i < red.n_out; ++i) {
-      WggOut& w = red.out[i];
+    for (int i = 0; i < no; ++i) {
+      WggOut& w = tab.out[i];
       const bool vec = (w.KN & 3) == 0 && w.ldo == w.N && (reinterpret_cast<uintptr_t>(w.out) & 15) == 0;
       w.first = rb;
       rb += (int)(((long long)w.KN + (vec ? 128 : 32) - 1) / (vec ? 128 : 32));
     }
+    // the table -> device memory, a piece per launch
+    for (int s0 = 0, g0 = 0, w0 = 0; s0 < ns || g0 < nseg || w0 < no;) {
+      WggPiece pc{};
+      pc.src0 = s0; pc.seg0 = g0; pc.out0 = w0; pc.tot_seg = nseg; pc.tot_out = no;
+      pc.n_src = ns - s0 < WGG_MAX_SRC ? ns - s0 : WGG_MAX_SRC;
+      pc.n_seg = nseg - g0 < WGG_MAX_SEG ? nseg - g0 : WGG_MAX_SEG;
+      pc.n_out = no - w0 < WGG_MAX_OUT ? no - w0 : WGG_MAX_OUT;
+      for (int i = 0; i < pc.n_src; ++i) pc.src[i] = tab.src[s0 + i];
+      for (int i = 0; i < pc.n_seg; ++i) pc.seg[i] = tab.seg[g0 + i];
+      for (int i = 0; i < pc.n_out; ++i) pc.out[i] = tab.out[w0 + i];
+      hipLaunchKernelGGL(k_wgg_write, dim3(1), dim3(256), 0, stream, pc, dtab);
+      if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
+      s0 += pc.n_src; g0 += pc.n_seg; w0 += pc.n_out;
+    }
+    if (blocks > 0) {
+      hipLaunchKernelGGL(k_wgrad_group, dim3(blocks), dim3(WG_THREADS), 2 * (WG_T + WG_T) * WG_CP * sizeof(unsigned short), stream,
+                         (const WggTable*)dtab);
+      if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
+    }
     if (rb > 0) {
-      hipLaunchKernelGGL(k_wgrad_group_reduce, dim3(rb), dim3(256), 0, stream, red);
+      hipLaunchKernelGGL(k_wgrad_group_reduce, dim3(rb), dim3(256), 0, stream, (const WggTable*)dtab);
       if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
     }
     o0 = o1;

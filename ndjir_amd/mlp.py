@@ -435,9 +435,52 @@ _NO_GROUP = bool(os.environ.get("NDJIR_NO_WGRAD_GROUP"))            # A/B: every
 _DEFERRED = None       # None = off; else the list of pending (out, accum, sources) jobs of `deferred_wgrads`
 
 
+def _disjoint_groups(jobs):
+    """The reduction adds every output's slabs to its destination in one launch, workgroups in no particular order: two jobs
+    must not write the same memory there.  Jobs with the SAME destination view (a net that runs twice per step: the base
+    colour net on the samples and on their perturbed twins; the geometric net likewise) become one job with all their operand
+    pairs; a job whose destination merely OVERLAPS another's (a parameter and its columns 1.. -- the packed first-order pass)
+    goes to a later group, i.e. a later launch."""
+    merged, index = [], {}
+    for out, accum, srcs in jobs:
+        key = (out.data_ptr(), tuple(out.shape), tuple(out.stride()))
+        i = index.get(key)
+        if i is not None and accum:
+            merged[i][2].extend(srcs)
+            continue
+        if i is None:
+            index[key] = len(merged)
+        merged.append([out, accum, list(srcs)])
+
+    def span(t):
+        K, N = t.shape
+        lo = t.data_ptr()
+        return lo, lo + 4 * ((K - 1) * (t.stride(0) if K > 1 else 0) + N)
+    groups = []          # [(jobs, spans)]
+    for job in merged:
+        lo, hi = span(job[0])
+        for g_jobs, g_spans in groups:
+            if all(hi <= a or b <= lo for a, b in g_spans):
+                g_jobs.append(tuple(job))
+                g_spans.append((lo, hi))
+                break
+        else:
+            groups.append(([tuple(job)], [(lo, hi)]))
+    return [g for g, _ in groups]
+
+
 def _wgrad_group_now(jobs):
-    """jobs: [(out, accum, [(A, B, amax_a, amax_b), ...]), ...] -> ndjir_mlp_wgrad_group (one launch + one reduction launch
-    per 24 operand pairs)."""
+    """jobs: [(out, accum, [(A, B, amax_a, amax_b), ...]), ...] -> ndjir_mlp_wgrad_group: one launch + one reduction launch
+    for all of them (a second pair for destinations that overlap others', `_disjoint_groups`)."""
+    groups = _disjoint_groups(jobs)
+    if len(groups) > 1 or len(groups[0]) != len(jobs):
+        for g in groups:
+            _wgrad_group_launch(g)
+        return
+    _wgrad_group_launch(jobs)
+
+
+def _wgrad_group_launch(jobs):
     import ctypes
     A, lda, B, ldb, Ps, ama, amb, oid, outs, ldo, Ks, Ns, acc = ([] for _ in range(13))
     for o, (out, accum, srcs) in enumerate(jobs):

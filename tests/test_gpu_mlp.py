@@ -603,3 +603,25 @@ def test_wgrad_group_deferred_and_fallback(gpu):
     assert torch.equal(z, torch.ones_like(z))
     mlp.wgrad_group([(z, False, [])])
     assert torch.equal(z, torch.zeros_like(z))
+
+
+def test_wgrad_group_same_and_overlapping_destinations(gpu):
+    """Jobs of one grouped call that write the same memory: the same destination twice (a net that runs twice per step) is one
+    reduction over both operand pairs; a parameter and its columns 1.. (the packed first-order pass) are reduced by separate
+    launches -- the result is the sum either way, never a lost update."""
+    from ndjir_amd import mlp
+    rng = np.random.RandomState(13)
+    K, N, P = 256, 257, 6000
+    W0 = torch.tensor(rng.randn(K, N), dtype=torch.float32)
+    Wg = W0.to(gpu).clone()
+    ops, ref = [], W0.double().clone()
+    for i, cols in enumerate((slice(0, N), slice(1, N), slice(0, N), slice(1, N))):
+        A = torch.tensor(rng.randn(P, K), dtype=torch.float32)
+        B = torch.tensor(rng.randn(P, cols.stop - cols.start), dtype=torch.float32)
+        ref[:, cols] += A.double().t() @ B.double()
+        Ad, Bd = A.to(gpu), B.to(gpu)
+        ops.append((Wg[:, cols], True, [(Ad, Bd, Ad.abs().max().reshape(1), Bd.abs().max().reshape(1))]))
+    with mlp.deferred_wgrads():
+        for job in ops:
+            mlp.wgrad_group([job])
+    assert float((Wg.cpu().double() - ref).norm() / ref.norm()) < 2e-6

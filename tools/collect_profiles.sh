@@ -5,14 +5,21 @@
 #    (no trace domains beside --pmc), 3) the default bench line, 4) per-net kernel durations of both split engines.
 export TMPDIR=/tmp
 O=gpurun_out/profiles_new; rm -rf $O; mkdir -p $O
-CMD="python3 bench.py --exec eager --steps 10 --warmup 3 --no-cpu-baseline --train-steps 3"
-rocprofv3 --kernel-trace --stats -d $O/ks -o run --output-format csv -- $CMD > $O/bench_under_rocprof.json 2> $O/ks_err.txt
+# per-step kernel table of the fwd+bwd step: two eager runs of 4 and 12 timed steps, differenced (one-time launches cancel)
+for S in 4 12; do
+  rocprofv3 --kernel-trace --stats -d $O/ks -o run --output-format csv -- python3 bench.py --exec eager --steps $S --warmup 1 --no-cpu-baseline --no-extra-legs --train-steps 0 > $O/bench_under_rocprof.json 2> $O/ks_err.txt
+  f=$(find $O/ks -name "*kernel_stats.csv" | head -1)
+  cp "$f" $O/bench_kernel_stats_s$S.csv
+  rm -rf $O/ks
+done
+python tools/diff_summary.py $O/bench_kernel_stats_s4.csv $O/bench_kernel_stats_s12.csv 4 12 70 > $O/bench_kernel_summary.txt
+# ... and of a run that also holds 3 training iterations (solver kernels; totals, not per step)
+rocprofv3 --kernel-trace --stats -d $O/ks -o run --output-format csv -- python3 bench.py --exec eager --steps 4 --warmup 1 --no-cpu-baseline --no-extra-legs --train-steps 3 > /dev/null 2>> $O/ks_err.txt
 f=$(find $O/ks -name "*kernel_stats.csv" | head -1)
-cp "$f" $O/bench_kernel_stats.csv
-# steps executed under the profiler: the chain-forward launch count / 13 launches per step
-python tools/prof_summary.py $O/bench_kernel_stats.csv 1 60 > $O/bench_kernel_summary.txt
+python tools/prof_summary.py "$f" 1 25 > $O/train_kernel_totals.txt
 rm -rf $O/ks
-PCMD="python3 bench.py --exec eager --steps 3 --warmup 1 --no-cpu-baseline --train-steps 2"
+mv $O/bench_kernel_stats_s12.csv $O/bench_kernel_stats.csv; rm -f $O/bench_kernel_stats_s4.csv
+PCMD="python3 bench.py --exec eager --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs --train-steps 2"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $O/pmc_$c -o run --output-format csv -- $PCMD > /dev/null 2> $O/pmc_${c}_err.txt
   f=$(find $O/pmc_$c -name "*counter_collection.csv" | head -1)
@@ -28,7 +35,7 @@ for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_
   f=$(find $O/pmc_m -name "*counter_collection.csv" | head -1)
   echo "## $tag" >> $O/pmc_mfma_bench.txt
   python tools/pmc_table.py "$f" "ndjir::x" >> $O/pmc_mfma_bench.txt
-  python tools/pmc_table.py "$f" "k_wgrad" >> $O/pmc_mfma_bench.txt
+  python tools/pmc_table.py "$f" "k_wgrad_group" >> $O/pmc_mfma_bench.txt
   rm -rf $O/pmc_m
 done
 # 5) the grid-feature micro-benchmark (the reference authors' shape: 2^19 points) with FETCH_SIZE / WRITE_SIZE per launch
@@ -48,5 +55,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmc_g
 done
 python bench.py > $O/bench_default.json 2> $O/bench_default_err.txt
-bash tools/chain_shapes.sh f16x3 bf16x6 > $O/chain_shapes.txt 2>&1
+bash tools/chain_shapes.sh f16x3 > $O/chain_shapes.txt 2>&1
 tail -c 600 $O/bench_default.json
