@@ -507,7 +507,10 @@ int ndjir_mlp_pack_table(const void* table, int n, int total_blocks, hipStream_t
 int ndjir_mlp_pack_entry_bytes(void);
 /* ndjir_mlp_chain / _ex: `accum_y` bit 0 = Y += result; bit 1 = the bias gradients (bgrad of every layer, in_bgrad) are
  * ADDED to their destinations instead of overwriting them -- nnabla's `accum` protocol for parameters whose gradient
- * buffer several operators share (python/train.py:136-140 zeroes the gradients once per iteration, every backward adds). */
+ * buffer several operators share (python/train.py:136-140 zeroes the gradients once per iteration, every backward adds);
+ * bit 2 (NDJIR_MATH_F16X3) = DEFER the bias-gradient reduction: the launch leaves its per-workgroup partial rows in
+ * `workspace` (layout: ndjir_mlp_chain_bias_partials) and writes no bgrad / in_bgrad -- the caller sums them later, for
+ * all launches of a step at once (ndjir_mlp_wgrad_group's extra outputs). */
 int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L,
                     const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
                     const float* const* side_in, float* const* side_out, const int* ld_side,
@@ -564,10 +567,15 @@ long long ndjir_mlp_wgrad_group_workspace(int n_src, const float* const* A, cons
                                           int n_out, const int* K, const int* N, int target_items);
 /* (diagnostics) launches of the grouped kernel -- and of its reduction -- that the call issues: one per 24 operand pairs */
 int ndjir_mlp_wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n_out);
+/* n_extra reduce-only outputs ride in the same reduction launch: ex_out[i] (ex_n[i] floats) (+)= the sum of ex_S[i] partial
+ * rows at ex_partial[i] + s * ex_stride[i] -- the bias gradients that chain launches with the DEFER flag left in their
+ * workspaces (ndjir_mlp_chain accum_y bit 2, ndjir_mlp_chain_bias_partials), so that a training step's ~13 per-launch
+ * bias reductions become none. */
 int ndjir_mlp_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb,
                           const long long* P, const unsigned* const* amax_a, const unsigned* const* amax_b, const int* out_id,
                           int n_out, float* const* out, const int* ldo, const int* K, const int* N, const int* accum,
-                          float* workspace, int target_items, hipStream_t stream);
+                          float* workspace, int target_items, int n_extra, float* const* ex_out, const float* const* ex_partial,
+                          const int* ex_n, const int* ex_S, const int* ex_stride, const int* ex_accum, hipStream_t stream);
 /* Bias gradient of a layer: out (N) (+)= column sums of its deltas X (P x N, row stride ldx); the
  * reference gets it from nnabla's affine backward (a reduction kernel per layer). */
 long long ndjir_mlp_colsum_workspace(int N, long long P);   /* floats */
@@ -578,6 +586,12 @@ int ndjir_mlp_colsum(const float* X, int ldx, int N, long long P, float* out, in
  * (the launchers' own decision code; nothing is launched).  name_bytes >= 64. */
 int ndjir_mlp_chain_kernel(int mode, long long P, int K0, int L, const int* Ks, const int* Ns, int has_output, int skip_layer,
                            int skip_split, int with_bias_gradients, char* name, int name_bytes);
+/* Layout of the bias-gradient partial rows that a backward / tangent chain launch with the DEFER flag (accum_y bit 2) leaves
+ * in its workspace instead of reducing them itself: *blocks rows of *row_floats floats -- the layers named by bgrad_mask
+ * (bit i = layer i) in order, then the chain input's column sums when in_bgrad.  Same decision code as the launch; nothing
+ * is launched.  NDJIR_ERR_UNSUPPORTED: the current arithmetic's kernels do not defer. */
+int ndjir_mlp_chain_bias_partials(int mode, long long P, int K0, int L, const int* Ks, const int* Ns, int has_output,
+                                  int skip_layer, int skip_split, unsigned bgrad_mask, int in_bgrad, int* blocks, int* row_floats);
 /* Diagnostics (no reference counterpart): with a non-null device buffer of 10 * 5 * 8 int64, later
  * chain launches record shader-clock stamps of workgroup 0, [layer][phase][wave], phases = layer
  * start / k-loop done / accumulators staged / epilogue done / barrier passed.  Null switches it off. */

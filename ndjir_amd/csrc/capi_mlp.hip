@@ -59,7 +59,7 @@ extern "C" int ndjir_mlp_pack_table(const void* table, int n, int total_blocks, 
 extern "C" int ndjir_mlp_pack_entry_bytes(void) { return (int)sizeof(PackEntry); }
 
 static long long* g_timeline = nullptr;   // diagnostics only, see ndjir_mlp_debug_timeline
-static thread_local char* g_dry_name = nullptr;        // diagnostics only, set for the duration of ndjir_mlp_chain_kernel
+static thread_local ChainDry* g_dry = nullptr;         // set for the duration of the two dry-run queries below
 
 // Points per workgroup tile of the chain kernels: 0 = chosen per launch (128 for large launches the wide-tile kernel
 // supports, else 64, 32 for small launches); 32 / 64 / 128 force one (128: where supported).  Results do not depend on it.
@@ -102,14 +102,15 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
   a.tile_rows = forced ? forced : ((P + 63) / 64 < 256 ? 32 : 64);
   a.forced_tile = forced;
   a.timeline = g_timeline;
-  a.dry_name = g_dry_name;
+  a.dry = g_dry;
   a.bg_partial = workspace;
   if (row_bias && (bwd != 0 || L < 2 || row_bias_div < 1)) return NDJIR_ERR_ARG;
   a.row_bias = row_bias; a.row_bias_div = row_bias_div;
   a.in_bgrad = (bwd != 0) ? in_bgrad : nullptr;
   a.x_amax = x_amax;
   a.P = P; a.X = X; a.ldx = ldx; a.K0 = K0; a.K0p = round_up(K0, 8); a.L = L;
-  a.Y = Y; a.ldy = ldy; a.accum_y = accum_y & 1; a.bg_accum = (accum_y >> 1) & 1; a.has_output = has_output; a.beta = beta;
+  a.Y = Y; a.ldy = ldy; a.accum_y = accum_y & 1; a.bg_accum = (accum_y >> 1) & 1; a.defer_bg_reduce = (accum_y >> 2) & 1;
+  a.has_output = has_output; a.beta = beta;
   a.skip_layer = skip_layer; a.skip_scale = skip_scale; a.skip_split = skip_split; a.Xskip = Xskip; a.ld_xskip = ld_xskip;
   int kin = K0;
   for (int i = 0; i < L; ++i) {
@@ -170,24 +171,52 @@ extern "C" int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx
                     row_bias, row_bias_div, in_bgrad, workspace, side_amax, x_amax, stream);
 }
 
-// Diagnostics: the symbol (as rocprofv3 prints it) of the kernel a chain launch of this shape would run -- the launchers' own
-// decision code, nothing is launched.  bench.py keys its per-kernel roofline table by it.
-extern "C" int ndjir_mlp_chain_kernel(int mode, long long P, int K0, int L, const int* Ks, const int* Ns, int has_output,
-                                      int skip_layer, int skip_split, int with_bias_gradients, char* name, int name_bytes) {
-  if (!name || name_bytes < 64 || mode < 0 || mode > 2 || L < 1 || L > MAX_CHAIN_LAYERS || !Ks || !Ns || P <= 0) return NDJIR_ERR_ARG;
+// Dry run of a chain launch of this shape under the current arithmetic / tile setting: the launchers' own decision code,
+// nothing is launched.  bgrad_mask: bit i = layer i produces a bias gradient; in_bgrad: the chain input's column sums too.
+static int chain_dry(int mode, long long P, int K0, int L, const int* Ks, const int* Ns, int has_output, int skip_layer,
+                     int skip_split, unsigned bgrad_mask, int in_bgrad, ChainDry* out) {
+  if (mode < 0 || mode > 2 || L < 1 || L > MAX_CHAIN_LAYERS || !Ks || !Ns || P <= 0) return NDJIR_ERR_ARG;
   static float dummy[4];          // (never dereferenced: the launchers return before any launch)
   const float* wp[MAX_CHAIN_LAYERS];
   const float* side[MAX_CHAIN_LAYERS];
   float* bg[MAX_CHAIN_LAYERS];
-  for (int i = 0; i < L; ++i) { wp[i] = dummy; side[i] = dummy; bg[i] = (with_bias_gradients && mode != 0) ? dummy : nullptr; }
-  g_dry_name = name;
-  name[0] = 0;
+  for (int i = 0; i < L; ++i) { wp[i] = dummy; side[i] = dummy; bg[i] = (mode != 0 && ((bgrad_mask >> i) & 1)) ? dummy : nullptr; }
+  out->name[0] = 0; out->blocks = 0; out->bg_total = 0;
+  g_dry = out;
   const int rc = chain_impl(mode, P, dummy, K0, K0, L, wp, nullptr, Ks, Ns, mode != 0 ? side : nullptr, nullptr, nullptr,
                             mode != 0 ? bg : nullptr, dummy, Ns[L - 1], 0, has_output, 100.f, skip_layer, 1.f,
                             skip_split, (mode == 1 && skip_layer >= 0) ? dummy : nullptr, K0, nullptr, nullptr, nullptr, nullptr, 0,
-                            nullptr, dummy, nullptr, nullptr, nullptr);
-  g_dry_name = nullptr;
+                            (mode != 0 && in_bgrad) ? dummy : nullptr, dummy, nullptr, nullptr, nullptr);
+  g_dry = nullptr;
   return rc;
+}
+
+// Diagnostics: the symbol (as rocprofv3 prints it) of the kernel a chain launch of this shape would run.  bench.py keys its
+// per-kernel roofline table by it.
+extern "C" int ndjir_mlp_chain_kernel(int mode, long long P, int K0, int L, const int* Ks, const int* Ns, int has_output,
+                                      int skip_layer, int skip_split, int with_bias_gradients, char* name, int name_bytes) {
+  if (!name || name_bytes < 64) return NDJIR_ERR_ARG;
+  ChainDry d;
+  const int rc = chain_dry(mode, P, K0, L, Ks, Ns, has_output, skip_layer, skip_split, with_bias_gradients ? ~0u : 0u, 0, &d);
+  for (int i = 0; i < 64; ++i) name[i] = d.name[i];
+  return rc;
+}
+
+// Layout of the bias-gradient partial rows a backward / tangent chain launch with the DEFER flag (accum_y bit 2) leaves in
+// its workspace: *blocks rows of *row_floats floats -- the layers named by bgrad_mask in order (the output layer of a chain
+// with has_output never has one), then the chain input's column sums when in_bgrad.  NDJIR_ERR_UNSUPPORTED: the current
+// arithmetic's kernels do not defer.
+extern "C" int ndjir_mlp_chain_bias_partials(int mode, long long P, int K0, int L, const int* Ks, const int* Ns, int has_output,
+                                             int skip_layer, int skip_split, unsigned bgrad_mask, int in_bgrad, int* blocks,
+                                             int* row_floats) {
+  if (!blocks || !row_floats) return NDJIR_ERR_ARG;
+  ChainDry d;
+  const int rc = chain_dry(mode, P, K0, L, Ks, Ns, has_output, skip_layer, skip_split, bgrad_mask, in_bgrad, &d);
+  if (rc != NDJIR_OK) return rc;
+  if (d.bg_total < 0) return NDJIR_ERR_UNSUPPORTED;
+  *blocks = d.blocks;
+  *row_floats = d.bg_total;
+  return NDJIR_OK;
 }
 
 extern "C" long long ndjir_mlp_chain_workspace(int bgrad_total) { return chain_workspace(bgrad_total); }
@@ -218,13 +247,19 @@ extern "C" int ndjir_mlp_wgrad_group_launches(int n_src, const long long* P, con
 extern "C" int ndjir_mlp_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb,
                                      const long long* P, const unsigned* const* amax_a, const unsigned* const* amax_b,
                                      const int* out_id, int n_out, float* const* out, const int* ldo, const int* K, const int* N,
-                                     const int* accum, float* workspace, int target_items, hipStream_t stream) {
-  if (n_src <= 0 || n_out <= 0) return NDJIR_OK;
-  if (!A || !lda || !B || !ldb || !P || !out_id || !out || !ldo || !K || !N || !workspace) return NDJIR_ERR_ARG;
+                                     const int* accum, float* workspace, int target_items, int n_extra, float* const* ex_out,
+                                     const float* const* ex_partial, const int* ex_n, const int* ex_S, const int* ex_stride,
+                                     const int* ex_accum, hipStream_t stream) {
+  if ((n_src <= 0 || n_out <= 0) && n_extra <= 0) return NDJIR_OK;
+  if (n_src > 0 && (!A || !lda || !B || !ldb || !P || !out_id || !out || !ldo || !K || !N)) return NDJIR_ERR_ARG;
+  if (!workspace || (n_extra > 0 && (!ex_out || !ex_partial || !ex_n || !ex_S || !ex_stride))) return NDJIR_ERR_ARG;
   if (g_math != NDJIR_MATH_F16X3) return NDJIR_ERR_UNSUPPORTED;
   for (int o = 0; o < n_out; ++o)
     if (K[o] <= 0 || N[o] <= 0) return NDJIR_ERR_ARG;
-  return launch_wgrad_group(n_src, A, lda, B, ldb, P, amax_a, amax_b, out_id, n_out, out, ldo, K, N, accum, workspace, target_items, stream);
+  for (int i = 0; i < n_extra; ++i)
+    if (!ex_out[i] || !ex_partial[i] || ex_n[i] <= 0 || ex_S[i] < 0 || ex_stride[i] < ex_n[i]) return NDJIR_ERR_ARG;
+  return launch_wgrad_group(n_src > 0 ? n_src : 0, A, lda, B, ldb, P, amax_a, amax_b, out_id, n_src > 0 ? n_out : 0, out, ldo, K, N, accum,
+                            workspace, target_items, n_extra > 0 ? n_extra : 0, ex_out, ex_partial, ex_n, ex_S, ex_stride, ex_accum, stream);
 }
 
 extern "C" long long ndjir_mlp_colsum_workspace(int N, long long P) { return colsum_workspace(N, P); }

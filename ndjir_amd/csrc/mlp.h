@@ -22,6 +22,12 @@ struct ChainLayer {
   int ld_side;
 };
 
+struct ChainDry {
+  char name[64];        // kernel symbol as rocprofv3 prints it
+  int blocks;           // workgroups of the launch ( = bias-gradient partial rows)
+  int bg_total;         // floats per partial row
+};
+
 struct ChainArgs {
   long long P;          // points (rows)
   long long n_tiles;    // filled by launch_chain
@@ -50,8 +56,11 @@ struct ChainArgs {
   int bg_total, bg_lds; // filled by launch_chain: accumulator floats / its offset in LDS
   unsigned* x_amax;     // f16x3 engine: atomicMax of the largest finite |X| (bit pattern; caller zeroes), may be null
   long long* timeline;  // diagnostics (tools/chain_timeline.py): per-layer phase stamps of workgroup 0, else null
-  char* dry_name;       // diagnostics (ndjir_mlp_chain_kernel): non-null = write the symbol of the kernel the launcher picks
-                        // (64 bytes) and return WITHOUT launching
+  struct ChainDry* dry; // queries (ndjir_mlp_chain_kernel, ndjir_mlp_chain_bias_partials): non-null = report the kernel the
+                        // launcher picks, its grid and its bias-gradient partial layout, and return WITHOUT launching
+  int defer_bg_reduce;  // backward / tangent: leave the per-workgroup bias-gradient partial rows in `bg_partial` ([grid][bg_total];
+                        // layers with a bias gradient in order, then in_bgrad) -- the caller sums them later (one reduction
+                        // launch for a whole step: ndjir_mlp_wgrad_group's extra outputs)
   ChainLayer layers[MAX_CHAIN_LAYERS];
 };
 
@@ -89,10 +98,13 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
 long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id, int n_out,
                                 const int* K, const int* N, int target_items);
 int wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n_out);
+// extras: n_extra reduce-only outputs ex_out[i] (ex_n[i] floats) (+)= the sum of ex_S[i] partial rows ex_partial[i] + s * ex_stride[i]
+// (the deferred bias gradients of chain launches: ChainArgs::defer_bg_reduce), summed by the same reduction launch
 int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb, const long long* P,
                        const unsigned* const* amax_a, const unsigned* const* amax_b, const int* out_id, int n_out,
                        float* const* out, const int* ldo, const int* K, const int* N, const int* accum, float* workspace,
-                       int target_items, hipStream_t stream);
+                       int target_items, int n_extra, float* const* ex_out, const float* const* ex_partial, const int* ex_n,
+                       const int* ex_S, const int* ex_stride, const int* ex_accum, hipStream_t stream);
 
 long long colsum_workspace(int N, long long P);
 int launch_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, hipStream_t stream);

@@ -618,7 +618,7 @@ int launch_chain(const ChainArgs& a, int mode, hipStream_t stream) {
 #undef NDJIR_SET
     attr_set = true;
   }
-  if (a.dry_name) { snprintf(a.dry_name, 64, "ndjir::k_mlp_chain<%d, %d>", mode, TM); return NDJIR_OK; }
+  if (a.dry) { snprintf(a.dry->name, 64, "ndjir::k_mlp_chain<%d, %d>", mode, TM); a.dry->blocks = (int)blocks; a.dry->bg_total = -1; return NDJIR_OK; }
 #define NDJIR_GO(M, T) hipLaunchKernelGGL((k_mlp_chain<M, T>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b)
   if (TM == 64) { if (mode == 0) NDJIR_GO(0, 64); else if (mode == 1) NDJIR_GO(1, 64); else NDJIR_GO(2, 64); }
   else { if (mode == 0) NDJIR_GO(0, 32); else if (mode == 1) NDJIR_GO(1, 32); else NDJIR_GO(2, 32); }

@@ -1018,14 +1018,14 @@ int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream) {
 #undef NDJIR_SET
     attr_set = true;
   }
-  if (a.dry_name) { snprintf(a.dry_name, 64, "ndjir::x3::k_chain3<%d, %d>", mode, TM); return NDJIR_OK; }
+  if (a.dry) { snprintf(a.dry->name, 64, "ndjir::x3::k_chain3<%d, %d>", mode, TM); a.dry->blocks = (int)blocks; a.dry->bg_total = bg_total; return NDJIR_OK; }
 #define NDJIR_GO(M, T) hipLaunchKernelGGL((k_chain3<M, T>), dim3((unsigned)blocks), dim3(NTHREADS), lds_bytes, stream, b)
   if (TM == 64) { if (mode == 0) NDJIR_GO(0, 64); else if (mode == 1) NDJIR_GO(1, 64); else NDJIR_GO(2, 64); }
   else { if (mode == 0) NDJIR_GO(0, 32); else if (mode == 1) NDJIR_GO(1, 32); else NDJIR_GO(2, 32); }
 #undef NDJIR_GO
   int rc = ndjir_check_launch();
   if (rc != NDJIR_OK) return rc;
-  if (bg_total > 0) return launch_bgrad_reduce(a.bg_partial, (int)blocks, bg_total, bg_ptr, bg_off, bg_n, a.bg_accum, stream);
+  if (bg_total > 0 && !a.defer_bg_reduce) return launch_bgrad_reduce(a.bg_partial, (int)blocks, bg_total, bg_ptr, bg_off, bg_n, a.bg_accum, stream);
   return NDJIR_OK;
 }
 

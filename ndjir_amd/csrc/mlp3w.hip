@@ -749,9 +749,10 @@ int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) {
     nw4 = e ? atoi(e) : 1;
     attr_set = true;
   }
-  if (a.dry_name) {
+  if (a.dry) {
     const bool four = rpw != 4 && ((nw4 >> mode) & 1) && lds_bytes <= 77 * 1024;
-    snprintf(a.dry_name, 64, "ndjir::x3w::k_chainw<%d, %d, %d>", mode, (rpw == 4 || four) ? 4 : 2, four ? 4 : 8);
+    snprintf(a.dry->name, 64, "ndjir::x3w::k_chainw<%d, %d, %d>", mode, (rpw == 4 || four) ? 4 : 2, four ? 4 : 8);
+    a.dry->blocks = (int)blocks; a.dry->bg_total = bg_total;
     return NDJIR_OK;
   }
 #define NDJIR_GO(M, R, W) hipLaunchKernelGGL((k_chainw<M, R, W>), dim3((unsigned)blocks), dim3(W * 64), lds_bytes, stream, b)
@@ -762,7 +763,7 @@ int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) {
 #undef NDJIR_GO
   int rc = ndjir_check_launch();
   if (rc != NDJIR_OK) return rc;
-  if (bg_total > 0) return launch_bgrad_reduce(a.bg_partial, (int)blocks, bg_total, bg_ptr, bg_off, bg_n, a.bg_accum, stream);
+  if (bg_total > 0 && !a.defer_bg_reduce) return launch_bgrad_reduce(a.bg_partial, (int)blocks, bg_total, bg_ptr, bg_off, bg_n, a.bg_accum, stream);
   return NDJIR_OK;
 }
 

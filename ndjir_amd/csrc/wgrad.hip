@@ -900,10 +900,17 @@ struct WggSeg {              // a run of consecutive workgroups tiling one regio
 };
 struct WggOut {
   float* out;                // (K, N), row stride ldo
-  const float* partial;      // partial[S][K * N]
+  const float* partial;      // S slabs of KN floats, `pstride` floats apart
   int KN, N, ldo, S, accum;
   int first;                 // first workgroup of this output in the reduction launch
+  int pstride, pad;          // (a weight gradient: KN; deferred bias gradients of a chain launch: the launch's partial-row length)
 };
+// 16-byte accesses in the reduction: contiguous destination, every slab and the destination 16-byte aligned
+__host__ __device__ static inline bool wgg_out_vec(const WggOut& o) {
+  return (o.KN & 3) == 0 && o.ldo == o.N && (o.pstride & 3) == 0 && (reinterpret_cast<uintptr_t>(o.out) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(o.partial) & 15) == 0;
+}
+
 // The whole group's work description lives in DEVICE memory (the head of the caller's workspace): a training step's ~57
 // operand pairs / ~150 segments do not fit the 4 KB of kernel arguments, and cutting the group into several launches costs
 // a drain of the machine per cut.  The table is written by tiny launches that carry pieces of it in THEIR arguments
@@ -1079,10 +1086,10 @@ __device__ __forceinline__ void wgg_reduce_block(const WggOut& o, int blk, float
 #pragma unroll 4
     for (int sidx = ty; sidx < o.S; sidx += 8) {
       if (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(p + (long long)sidx * o.KN);
+        const float4 t = *reinterpret_cast<const float4*>(p + (long long)sidx * o.pstride);
         acc[0] += t.x; acc[1 % VEC] += t.y; acc[2 % VEC] += t.z; acc[3 % VEC] += t.w;
       } else {
-        acc[0] += p[(long long)sidx * o.KN];
+        acc[0] += p[(long long)sidx * o.pstride];
       }
     }
   }
@@ -1120,7 +1127,7 @@ __global__ void __launch_bounds__(256) k_wgrad_group_reduce(const WggTable* __re
     if (a.out[mid].first <= b) lo = mid; else hi = mid - 1;
   }
   const WggOut& o = a.out[lo];
-  const bool vec = (o.KN & 3) == 0 && o.ldo == o.N && (reinterpret_cast<uintptr_t>(o.out) & 15) == 0;
+  const bool vec = wgg_out_vec(o);
   const int blk = b - o.first;
   if (vec) wgg_reduce_block<4>(o, blk, red);
   else wgg_reduce_block<1>(o, blk, red);
@@ -1214,7 +1221,8 @@ int wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n
 
 long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id, int n_out,
                                 const int* K, const int* N, int target_items) {
-  if (n_src <= 0 || n_src > 65536) return 0;
+  if (n_src <= 0) return 2 * WGT_FLOATS + 4;          // (reduce-only calls: room for their tables)
+  if (n_src > 65536) return 0;
   int* S = (int*)alloca(sizeof(int) * n_src);
   long long* rows = (long long*)alloca(sizeof(long long) * n_src);
   long long total = 0;
@@ -1231,13 +1239,14 @@ long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda
     }
     o0 = o1;
   }
-  return total + 4;
+  return total + WGT_FLOATS + 4;      // (+ one table for reduce-only outputs that did not fit the last one)
 }
 
 int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb, const long long* P,
                        const unsigned* const* amax_a, const unsigned* const* amax_b, const int* out_id, int n_out,
                        float* const* out, const int* ldo, const int* K, const int* N, const int* accum, float* workspace,
-                       int target_items, hipStream_t stream) {
+                       int target_items, int n_extra, float* const* ex_out, const float* const* ex_partial, const int* ex_n,
+                       const int* ex_S, const int* ex_stride, const int* ex_accum, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_group), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1253,9 +1262,10 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
   static thread_local WggTable tab;          // host copy of the table being built (49 KB)
   long long off = 0;                         // running offset in the workspace (mirrors wgrad_group_workspace)
   // per table-full of outputs (a training step: one): writer launches, ONE k_wgrad_group launch, ONE reduction launch
-  for (int o0 = 0; o0 < n_out;) {
-    const int o1 = wgg_chunk_end(o0, n_src, P, out_id, n_out);
-    if (o1 == o0) return NDJIR_ERR_UNSUPPORTED;       // one output with more sources than a table holds
+  int ex_done = 0;
+  for (int o0 = 0; o0 < n_out || ex_done < n_extra;) {
+    const int o1 = o0 < n_out ? wgg_chunk_end(o0, n_src, P, out_id, n_out) : o0;
+    if (o0 < n_out && o1 == o0) return NDJIR_ERR_UNSUPPORTED;       // one output with more sources than a table holds
     wgg_split_plan(o0, o1, n_src, A, lda, P, out_id, K, N, target_items, S, rows);
     WggTable* dtab = reinterpret_cast<WggTable*>(workspace + off);
     off += WGT_FLOATS;
@@ -1276,7 +1286,7 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
       }
       WggOut& w = tab.out[no++];
       w.out = out[o]; w.partial = workspace + off; w.KN = (int)kn; w.N = N[o]; w.ldo = ldo[o];
-      w.S = s_seen; w.accum = accum ? accum[o] : 0;
+      w.S = s_seen; w.accum = accum ? accum[o] : 0; w.pstride = (int)kn; w.pad = 0;
       off += ((long long)s_seen * kn + 3) / 4 * 4;
     }
     // segments: the narrow items first (short, but each a serial chain: they finish under the tiles), then the 128 x 128
@@ -1306,10 +1316,16 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
           blocks += g.count;
         }
       }
+    // the reduce-only outputs (deferred bias gradients) ride in the tables' free output slots
+    for (; ex_done < n_extra && no < WGT_MAX_OUT; ++ex_done) {
+      WggOut& w = tab.out[no++];
+      w.out = ex_out[ex_done]; w.partial = ex_partial[ex_done]; w.KN = ex_n[ex_done]; w.N = ex_n[ex_done]; w.ldo = ex_n[ex_done];
+      w.S = ex_S[ex_done]; w.accum = ex_accum ? ex_accum[ex_done] : 0; w.pstride = ex_stride[ex_done]; w.pad = 0;
+    }
     int rb = 0;
     for (int i = 0; i < no; ++i) {
       WggOut& w = tab.out[i];
-      const bool vec = (w.KN & 3) == 0 && w.ldo == w.N && (reinterpret_cast<uintptr_t>(w.out) & 15) == 0;
+      const bool vec = wgg_out_vec(w);
       w.first = rb;
       rb += (int)(((long long)w.KN + (vec ? 128 : 32) - 1) / (vec ? 128 : 32));
     }

@@ -47,8 +47,9 @@ SIGS = {
     "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP" + "pi" + "pp" + "Pp",
     "mlp_group_colsum": "piilip",
     "mlp_wgrad": "pipiiilpippp",
-    # n_src A lda B ldb P amax_a amax_b out_id n_out out ldo K N accum workspace target_items
-    "mlp_wgrad_group": "iPAPALPPAiPAAAApi",
+    # n_src A lda B ldb P amax_a amax_b out_id n_out out ldo K N accum workspace target_items n_extra ex_out ex_partial ex_n ex_S
+    # ex_stride ex_accum
+    "mlp_wgrad_group": "iPAPALPPAiPAAAApi" + "iPPAAAA",
     "mlp_colsum": "piilpip",
     "render_alpha_weights": "iii" + "p" * 11,
     "render_alpha_weights_backward": "iii" + "p" * 16,
@@ -266,7 +267,7 @@ def symbols():
                                             "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_wgrad_group_workspace", "ndjir_mlp_wgrad_group_launches", "ndjir_mlp_colsum_workspace",
                                             "ndjir_mlp_chain_workspace", "ndjir_mlp_set_math", "ndjir_mlp_get_math",
                                             "ndjir_mlp_set_tile_rows", "ndjir_mlp_get_tile_rows", "ndjir_mlp_pack_entry_bytes",
-                                            "ndjir_mlp_debug_timeline", "ndjir_mlp_chain_kernel", "ndjir_loss_terms_workspace"]
+                                            "ndjir_mlp_debug_timeline", "ndjir_mlp_chain_kernel", "ndjir_mlp_chain_bias_partials", "ndjir_loss_terms_workspace"]
 
 
 def hash_num_params(G0, growth_factor, T0, L, D):

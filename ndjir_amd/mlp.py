@@ -85,7 +85,89 @@ def _launch_symbol(name, args):
     return "ndjir::" + name
 
 
+_BIAS_ARENA = {}       # device -> [tensor, next free float]: partial rows of deferred bias-gradient reductions of one step
+_BIAS_LAYOUT = {}      # launch shape -> (partial rows, floats per row)
+
+
+def _bias_region(device, floats):
+    """`floats` floats that stay untouched until the deferred reductions are flushed (one region per chain launch)."""
+    a = _BIAS_ARENA.get(device)
+    if a is None or a[1] + floats > a[0].numel():
+        if torch.cuda.is_current_stream_capturing() and a is not None:
+            t = torch.empty(max(floats, 1 << 22), device=device, dtype=torch.float32)      # owned by the graph being captured
+        else:
+            t = torch.empty(max(floats, 1 << 24, a[0].numel() if a else 0), device=device, dtype=torch.float32)
+        a = _BIAS_ARENA[device] = [t, 0]
+    out = a[0][a[1]:a[1] + floats]
+    a[1] += (floats + 3) // 4 * 4
+    return out
+
+
+def _defer_bias_reduction(name, args):
+    """Inside `deferred_wgrads()`, a backward / tangent chain launch whose bias gradients ACCUMULATE into persistent buffers
+    (`set_grad_buffer`) does not reduce its per-workgroup partial rows itself (one small launch per chain, 13 per step): it
+    leaves them in a private region and the step's one reduction launch sums them with the weight-gradient slabs.
+    Returns the launch's arguments with the DEFER flag and the region in place, or None when the launch does not qualify."""
+    import ctypes
+    if _DEFERRED is None or name not in ("mlp_chain", "mlp_chain_ex") or int(args[0]) == 0 or not (int(args[16]) & 2):
+        return None
+    if get_math() != MATH_F16X3:
+        return None
+    i_in = 29 if name == "mlp_chain_ex" else 24
+    bg, in_bg, L = args[13], args[i_in], int(args[5])
+    has_output = bool(args[17])
+    # the bias gradients the launch produces, in the order of its partial rows: layers (never an output layer), then the input
+    live = [(j, t) for j, t in enumerate(bg) if t is not None and not (has_output and j == L - 1)]
+    if not live and in_bg is None:
+        return None
+    mask = sum(1 << j for j, _ in live)
+    key = (name, int(args[0]), int(args[1]), int(args[4]), tuple(int(k) for k in args[8]), tuple(int(n) for n in args[9]), has_output,
+           int(args[19]), int(args[21]), mask, in_bg is not None, get_tile_rows())
+    lay = _BIAS_LAYOUT.get(key)
+    if lay is None:
+        blocks, row = ctypes.c_int(0), ctypes.c_int(0)
+        f = lib.load().ndjir_mlp_chain_bias_partials
+        f.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                      ctypes.POINTER(ctypes.c_int)]
+        f.restype = ctypes.c_int
+        rc = f(int(args[0]), int(args[1]), int(args[4]), L, (ctypes.c_int * L)(*[int(k) for k in args[8]]),
+               (ctypes.c_int * L)(*[int(n) for n in args[9]]), 1 if has_output else 0, int(args[19]), int(args[21]), mask,
+               1 if in_bg is not None else 0, ctypes.byref(blocks), ctypes.byref(row))
+        lay = _BIAS_LAYOUT[key] = (blocks.value, row.value) if rc == 0 else None
+        if len(_BIAS_LAYOUT) > 4096:
+            _BIAS_LAYOUT.clear()
+    if not lay or lay[0] <= 0 or lay[1] <= 0:
+        return None
+    # one reduction launch sums all deferred rows, workgroups in no particular order: a destination may appear in it once.  A
+    # net that runs twice per step (the base colour net on the perturbed points, the geometric net's first-order pass) keeps
+    # its own reduction for the second run -- it accumulates right away, stream-ordered against the flush
+    targets = [t for _, t in live] + ([in_bg] if in_bg is not None else [])
+    taken = {e[0].data_ptr() for e in _DEFERRED_BIAS}
+    if any(t.data_ptr() in taken for t in targets):
+        return None
+    blocks, row = lay
+    x = args[2]
+    region = _bias_region((x if torch.is_tensor(x) else x.t).device, blocks * row)
+    off = 0
+    for j, t in live:
+        n = int(args[9][j])
+        _DEFERRED_BIAS.append((t, region[off:], n, blocks, row))
+        off += n
+    if in_bg is not None:
+        _DEFERRED_BIAS.append((in_bg, region[off:], int(args[4]), blocks, row))
+        off += int(args[4])
+    assert off == row, (off, row)
+    args = list(args)
+    args[16] = int(args[16]) | 4
+    args[i_in + 1] = region
+    return tuple(args)
+
+
 def _launch(kind, flops, name, *args, shape=""):
+    deferred = _defer_bias_reduction(name, args)
+    if deferred is not None:
+        args = deferred
     if PROFILE is None:
         lib.call(name, *args)
         return
@@ -343,6 +425,9 @@ def amax_slots(device, n):
 
 def begin_step(device):
     _AMAX_ARENA[device] = [torch.zeros(4096, device=device, dtype=torch.float32), 0]
+    a = _BIAS_ARENA.get(device)
+    if a is not None:
+        a[1] = 0                  # (the previous step's deferred reductions have been flushed: its regions are free again)
 
 
 def _slot(am, i):
@@ -433,6 +518,7 @@ WGRAD_GROUP_ITEMS = int(os.environ.get("NDJIR_WGRAD_ITEMS", "0"))     # work ite
 SELF_AMAX_MAX_ROWS = int(os.environ.get("NDJIR_WGRAD_SELF_AMAX_ROWS", "16384"))      # operand pairs without recorded maxima up to this many rows join a grouped launch
 _NO_GROUP = bool(os.environ.get("NDJIR_NO_WGRAD_GROUP"))            # A/B: every weight gradient through the per-layer kernel
 _DEFERRED = None       # None = off; else the list of pending (out, accum, sources) jobs of `deferred_wgrads`
+_DEFERRED_BIAS = []    # pending (bias gradient view, partial rows, floats, rows, row stride) of chain launches (`_defer_bias_reduction`)
 
 
 def _disjoint_groups(jobs):
@@ -469,19 +555,30 @@ def _disjoint_groups(jobs):
     return [g for g, _ in groups]
 
 
-def _wgrad_group_now(jobs):
+def _wgrad_group_now(jobs, extras=()):
     """jobs: [(out, accum, [(A, B, amax_a, amax_b), ...]), ...] -> ndjir_mlp_wgrad_group: one launch + one reduction launch
-    for all of them (a second pair for destinations that overlap others', `_disjoint_groups`)."""
-    groups = _disjoint_groups(jobs)
-    if len(groups) > 1 or len(groups[0]) != len(jobs):
-        for g in groups:
-            _wgrad_group_launch(g)
-        return
-    _wgrad_group_launch(jobs)
+    for all of them (a second pair for destinations that overlap others', `_disjoint_groups`).  extras: deferred bias
+    gradients (view, partial rows, floats, rows, row stride), summed by the first group's reduction launch."""
+    groups = _disjoint_groups(jobs) if jobs else [[]]
+    for i, g in enumerate(groups):
+        _wgrad_group_launch(g, extras if i == 0 else ())
 
 
-def _wgrad_group_launch(jobs):
+def _wgrad_group_launch(jobs, extras=()):
     import ctypes
+    if not jobs:
+        if not extras:
+            return
+        dev = extras[0][0].device
+        ws = _WORKSPACE_G.get(dev)
+        need = int(lib.load().ndjir_mlp_wgrad_group_workspace(0, None, None, None, None, 0, None, None, 0))
+        if ws is None or ws.numel() < need:
+            ws = _WORKSPACE_G[dev] = torch.empty(max(need, 1 << 24), device=dev, dtype=torch.float32)
+        ex = list(extras)
+        lib.call("mlp_wgrad_group", 0, None, [], None, [], [], None, None, [], 0, None, [], [], [], [], ws, 0, len(ex),
+                 [_Strided(e[0]) for e in ex], [_Strided(e[1]) for e in ex], [e[2] for e in ex], [e[3] for e in ex], [e[4] for e in ex],
+                 [1] * len(ex))
+        return
     A, lda, B, ldb, Ps, ama, amb, oid, outs, ldo, Ks, Ns, acc = ([] for _ in range(13))
     for o, (out, accum, srcs) in enumerate(jobs):
         K, N = out.shape
@@ -507,7 +604,10 @@ def _wgrad_group_launch(jobs):
         else:
             ws = _WORKSPACE_G[dev] = torch.empty(max(need, 1 << 24), device=dev, dtype=torch.float32)
     flops = 2.0 * sum(p * Ks[o] * Ns[o] for p, o in zip(Ps, oid))
+    ex = list(extras)
     _launch("wgrad", flops, "mlp_wgrad_group", n, A, lda, B, ldb, Ps, ama, amb, oid, m, outs, ldo, Ks, Ns, acc, ws, int(WGRAD_GROUP_ITEMS),
+            len(ex), [_Strided(e[0]) for e in ex], [_Strided(e[1]) for e in ex], [e[2] for e in ex], [e[3] for e in ex],
+            [e[4] for e in ex], [1] * len(ex),
             shape=f"group {m} out / {n} src {flops / 2e9:.1f} GMAC " + ",".join(f"{p}:{Ks[o]}x{Ns[o]}" for p, o in list(zip(Ps, oid))[:2]))
 
 
@@ -558,14 +658,17 @@ def deferred_wgrads():
         yield
         return
     _DEFERRED = []
+    del _DEFERRED_BIAS[:]
     try:
         yield
-        jobs = _DEFERRED
+        jobs, extras = _DEFERRED, list(_DEFERRED_BIAS)
         _DEFERRED = None
-        if jobs:
-            _wgrad_group_now(jobs)
+        del _DEFERRED_BIAS[:]
+        if jobs or extras:
+            _wgrad_group_now(jobs, extras)
     finally:
         _DEFERRED = None
+        del _DEFERRED_BIAS[:]
 
 
 def colsum(X, out=None, accum=False):
