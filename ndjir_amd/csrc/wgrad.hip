@@ -1117,10 +1117,10 @@ __device__ __forceinline__ void wgg_reduce_block(const WggOut& o, int blk, float
   }
 }
 
-__global__ void __launch_bounds__(256) k_wgrad_group_reduce(const WggTable* __restrict__ tab) {
+__global__ void __launch_bounds__(256) k_wgrad_group_reduce(const WggTable* __restrict__ tab, int block_base) {
   __shared__ float red[4 * 256];
   const WggTable& a = *tab;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x + block_base;
   int lo = 0, hi = a.n_out - 1;          // the last output whose first workgroup is <= b
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -1322,13 +1322,44 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
       w.out = ex_out[ex_done]; w.partial = ex_partial[ex_done]; w.KN = ex_n[ex_done]; w.N = ex_n[ex_done]; w.ldo = ex_n[ex_done];
       w.S = ex_S[ex_done]; w.accum = ex_accum ? ex_accum[ex_done] : 0; w.pstride = ex_stride[ex_done]; w.pad = 0;
     }
+    // The reduction's workgroups run in no particular order: two outputs that touch the same memory (a parameter and its
+    // columns 1..: the packed first-order pass) must not be reduced by the same launch.  Generation of an output = 1 + the
+    // largest generation among the EARLIER outputs it overlaps; outputs are sorted by generation, one reduction launch each.
+    int gen[WGT_MAX_OUT], n_gen = 1;
+    for (int i = 0; i < no; ++i) {
+      const WggOut& w = tab.out[i];
+      const int K_ = w.KN / w.N;
+      const char* lo = reinterpret_cast<const char*>(w.out);
+      const char* hi = lo + 4 * ((long long)(K_ - 1) * w.ldo + w.N);
+      gen[i] = 0;
+      for (int j = 0; j < i; ++j) {
+        const WggOut& v = tab.out[j];
+        const char* lo2 = reinterpret_cast<const char*>(v.out);
+        const char* hi2 = lo2 + 4 * ((long long)(v.KN / v.N - 1) * v.ldo + v.N);
+        if (lo < hi2 && lo2 < hi && gen[j] + 1 > gen[i]) gen[i] = gen[j] + 1;
+      }
+      if (gen[i] + 1 > n_gen) n_gen = gen[i] + 1;
+    }
+    if (n_gen > 1) {          // stable sort by generation (insertion: a handful of outputs move)
+      for (int i = 1; i < no; ++i) {
+        const WggOut w = tab.out[i];
+        const int g = gen[i];
+        int j = i;
+        while (j > 0 && gen[j - 1] > g) { tab.out[j] = tab.out[j - 1]; gen[j] = gen[j - 1]; --j; }
+        tab.out[j] = w; gen[j] = g;
+      }
+    }
     int rb = 0;
+    int gen_first[WGT_MAX_OUT + 1];
+    for (int g = 0; g <= n_gen; ++g) gen_first[g] = 0;
     for (int i = 0; i < no; ++i) {
       WggOut& w = tab.out[i];
       const bool vec = wgg_out_vec(w);
+      if (i == 0 || gen[i] != gen[i - 1]) gen_first[gen[i]] = rb;
       w.first = rb;
       rb += (int)(((long long)w.KN + (vec ? 128 : 32) - 1) / (vec ? 128 : 32));
     }
+    gen_first[n_gen] = rb;
     // the table -> device memory, a piece per launch
     for (int s0 = 0, g0 = 0, w0 = 0; s0 < ns || g0 < nseg || w0 < no;) {
       WggPiece pc{};
@@ -1348,8 +1379,10 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
                          (const WggTable*)dtab);
       if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
     }
-    if (rb > 0) {
-      hipLaunchKernelGGL(k_wgrad_group_reduce, dim3(rb), dim3(256), 0, stream, (const WggTable*)dtab);
+    for (int g = 0; g < n_gen && no > 0; ++g) {
+      const int nb = gen_first[g + 1] - gen_first[g];
+      if (nb <= 0) continue;
+      hipLaunchKernelGGL(k_wgrad_group_reduce, dim3(nb), dim3(256), 0, stream, (const WggTable*)dtab, gen_first[g]);
       if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
     }
     o0 = o1;

@@ -367,6 +367,7 @@ def set_grad_buffer(p, buf):
 
 def clear_grad_buffers():
     del _GRAD_BUF[:]
+    _ROWS_TARGET.clear()
 
 
 @contextlib.contextmanager
@@ -385,6 +386,7 @@ def grad_buffers(pairs):
     try:
         yield
     finally:
+        _ROWS_TARGET.clear()
         for e in added:
             for i in range(len(_GRAD_BUF) - 1, -1, -1):
                 if _GRAD_BUF[i] is e:
@@ -392,11 +394,35 @@ def grad_buffers(pairs):
                     break
 
 
+class SplitTarget:
+    """Gradient destination of a `rows_except` copy: rows [0, a) of the copy belong to `top`, the rest to `bottom` -- two row
+    blocks of the parameter's accumulate-in-place buffer."""
+    __slots__ = ("top", "bottom", "a")
+
+    def __init__(self, top, bottom, a):
+        self.top, self.bottom, self.a = top, bottom, a
+
+
+_ROWS_TARGET = {}      # first byte of a rows_except copy -> (shape, SplitTarget); valid while the buffers are registered
+
+
+def wgrad_jobs(target, A, B, amax_a, amax_b):
+    """Grouped-launch jobs that ADD A^T B to an accumulate-in-place `target` (`grad_target`): one job, or one per row block of
+    a `SplitTarget` (a row block of dW = a column block of A; a bound of A's magnitude bounds every block)."""
+    if isinstance(target, SplitTarget):
+        a = target.a
+        return [(target.top, True, [(A[:, :a], B, amax_a, amax_b)]), (target.bottom, True, [(A[:, a:], B, amax_a, amax_b)])]
+    return [(target, True, [(A, B, amax_a, amax_b)])]
+
+
 def grad_target(t):
     """The view of a registered gradient buffer that corresponds to `t` -- a registered parameter or a contiguous piece of
-    one (a block of rows of a weight matrix) --, or None."""
+    one (a block of rows of a weight matrix) --, a `SplitTarget` for a `rows_except` copy of a registered parameter, or None."""
     if not _GRAD_BUF or t is None or not t.is_contiguous():
         return None
+    hit = _ROWS_TARGET.get(t.data_ptr())
+    if hit is not None and hit[0] == tuple(t.shape):
+        return hit[1]
     ptr, nbytes = t.data_ptr(), t.numel() * t.element_size()
     for p0, nb, buf in _GRAD_BUF:
         if p0 <= ptr and ptr + nbytes <= p0 + nb:
@@ -521,12 +547,11 @@ _DEFERRED = None       # None = off; else the list of pending (out, accum, sourc
 _DEFERRED_BIAS = []    # pending (bias gradient view, partial rows, floats, rows, row stride) of chain launches (`_defer_bias_reduction`)
 
 
-def _disjoint_groups(jobs):
-    """The reduction adds every output's slabs to its destination in one launch, workgroups in no particular order: two jobs
-    must not write the same memory there.  Jobs with the SAME destination view (a net that runs twice per step: the base
-    colour net on the samples and on their perturbed twins; the geometric net likewise) become one job with all their operand
-    pairs; a job whose destination merely OVERLAPS another's (a parameter and its columns 1.. -- the packed first-order pass)
-    goes to a later group, i.e. a later launch."""
+def _merge_same_destination(jobs):
+    """Jobs with the SAME destination view (a net that runs twice per step: the base colour net on the samples and on their
+    perturbed twins; the geometric net likewise) become one job with all their operand pairs -- one output of the reduction.
+    (Destinations that merely OVERLAP -- a parameter and its columns 1.., the packed first-order pass -- are reduced by
+    separate launches inside the library.)"""
     merged, index = [], {}
     for out, accum, srcs in jobs:
         key = (out.data_ptr(), tuple(out.shape), tuple(out.stride()))
@@ -537,31 +562,14 @@ def _disjoint_groups(jobs):
         if i is None:
             index[key] = len(merged)
         merged.append([out, accum, list(srcs)])
-
-    def span(t):
-        K, N = t.shape
-        lo = t.data_ptr()
-        return lo, lo + 4 * ((K - 1) * (t.stride(0) if K > 1 else 0) + N)
-    groups = []          # [(jobs, spans)]
-    for job in merged:
-        lo, hi = span(job[0])
-        for g_jobs, g_spans in groups:
-            if all(hi <= a or b <= lo for a, b in g_spans):
-                g_jobs.append(tuple(job))
-                g_spans.append((lo, hi))
-                break
-        else:
-            groups.append(([tuple(job)], [(lo, hi)]))
-    return [g for g, _ in groups]
+    return [tuple(j) for j in merged]
 
 
 def _wgrad_group_now(jobs, extras=()):
     """jobs: [(out, accum, [(A, B, amax_a, amax_b), ...]), ...] -> ndjir_mlp_wgrad_group: one launch + one reduction launch
-    for all of them (a second pair for destinations that overlap others', `_disjoint_groups`).  extras: deferred bias
-    gradients (view, partial rows, floats, rows, row stride), summed by the first group's reduction launch."""
-    groups = _disjoint_groups(jobs) if jobs else [[]]
-    for i, g in enumerate(groups):
-        _wgrad_group_launch(g, extras if i == 0 else ())
+    for all of them (a second reduction launch for destinations that overlap others').  extras: deferred bias gradients
+    (view, partial rows, floats, rows, row stride), summed by the same reduction."""
+    _wgrad_group_launch(_merge_same_destination(jobs), extras)
 
 
 def _wgrad_group_launch(jobs, extras=()):
@@ -891,7 +899,7 @@ class FusedMLP(Function):
                     else:
                         wt = grad_target(W[j])
                         if wt is not None:
-                            jobs.append((wt, True, src))
+                            jobs += wgrad_jobs(wt, *src[0])
                         else:
                             gW[j] = torch.empty(tuple(W[j].shape), device=x2.device, dtype=torch.float32)
                             jobs.append((gW[j], False, src))
@@ -1057,7 +1065,7 @@ class MultiMLP(Function):
                     src = [(A[j], deltas[j], _slot(am, j), _slot(dm, j))]
                     wt = grad_target(W[j])
                     if wt is not None:
-                        jobs.append((wt, True, src))
+                        jobs += wgrad_jobs(wt, *src[0])
                     else:
                         out[wo - 4 + j] = torch.empty(tuple(W[j].shape), device=dev, dtype=torch.float32)
                         jobs.append((out[wo - 4 + j], False, src))
@@ -1117,7 +1125,7 @@ class MatMul(Function):
             x2, g2 = x.reshape(-1, x.shape[-1]), gy.reshape(-1, gy.shape[-1])
             wt = grad_target(W) if (first_order and not ctx.t) else None
             if wt is not None:       # accumulate-in-place gradient buffer (set_grad_buffer): W may be a block of rows of a parameter
-                wgrad_group([(wt, True, [(x2.detach().contiguous(), g2.detach().contiguous(), None, None)])])
+                wgrad_group(wgrad_jobs(wt, x2.detach().contiguous(), g2.detach().contiguous(), None, None))
             else:
                 gW = WGradOp.apply(g2, x2) if ctx.t else WGradOp.apply(x2, g2)
         if ctx.has_bias and ctx.needs_input_grad[3]:
@@ -1191,6 +1199,10 @@ class RowsExcept(Function):
             _refresh_rows(ent, W, a, b)
         ctx.ab = (a, b, tuple(W.shape))
         ctx.tgt = grad_target(W)
+        if ctx.tgt is not None and not isinstance(ctx.tgt, SplitTarget):
+            # the operators that consume the copy add their weight gradient straight into the parameter's two row blocks
+            # (`wgrad_jobs`) and return no gradient for it: this node's backward then does not run at all
+            _ROWS_TARGET[ent[1].data_ptr()] = (tuple(ent[1].shape), SplitTarget(ctx.tgt[:a], ctx.tgt[b:], a))
         return ent[1].view(ent[1].shape)  # (a fresh tensor object per call: autograd owns what it returns)
 
     @staticmethod
