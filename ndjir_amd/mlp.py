@@ -514,10 +514,13 @@ _WORKSPACE = {}
 
 
 def _workspace(device, need):
-    ws = _WORKSPACE.get(device)
+    """Scratch of a launch, one buffer per (device, stream): launches on different streams (the renderer issues its background
+    branch beside the foreground pass) must not share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else (device, 0)
+    ws = _WORKSPACE.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 22), device=device, dtype=torch.float32)
-        _WORKSPACE[device] = ws
+        _WORKSPACE[key] = ws
     return ws
 
 
