@@ -197,14 +197,15 @@ def test_training_graph_replay_then_eager(gpu):
         mlp.track_weights(False)
 
 
-@pytest.mark.parametrize("variant", ["default", "no_voxel"])
-def test_in_place_gradient_bucket_equals_autograd(gpu, variant):
+@pytest.mark.parametrize("variant,B", [("default", 1), ("no_voxel", 1), ("default", 2)])
+def test_in_place_gradient_bucket_equals_autograd(gpu, variant, B):
     """Step's flat MLP gradient bucket, filled in place by the operators (ndjir_amd.mlp.set_grad_buffer: weights, biases, the
     row blocks of the split first-layer weights), against the same step with every gradient returned through autograd."""
     from ndjir_amd import config as cfg, mlp
     from ndjir_amd.step import Step
     conf = cfg.load(variant, ["geometric_network.voxel.grid_size=16"])
-    step = Step(conf, 16, gpu, 0, 1)
+    step = Step(conf, 16, gpu, 0, 1, B=B)          # (B = 2: two images per step, python/train.py:38-51 -- bench.py's `b4` leg runs B = 4)
+    assert step.raydir.shape[:2] == (B, 16) and step.rand["noise"].shape[:2] == (B, 16)
     # the views are registered only while `compute` runs (mlp.grad_buffers): outside a step the registry is empty, so another
     # backward pass over the same parameters gets ordinary autograd gradients and cannot add into the bucket
     assert step.in_place and len(step._grad_pairs) == len(step.mlp_params) and len(mlp._GRAD_BUF) == 0
