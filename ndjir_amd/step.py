@@ -61,7 +61,7 @@ class Step:
         self.x_fg = None
         self.mlp_names = None
         self._zeros = None
-        self.forward_backward()          # creates the parameters (untimed)
+        self._create_parameters()        # one untimed forward pass: the networks create their parameters on first use
         for name, p in P.get_parameters().items():
             if name.endswith("feature/F"):
                 buf = torch.zeros_like(p)
@@ -89,6 +89,22 @@ class Step:
             self.grad_views.append(v)
             if self.in_place and p.is_contiguous():
                 self._grad_pairs.append((p, v))
+
+    def _create_parameters(self):
+        """The parameters come into being when the networks first run (python/network.py's `PF.affine` scopes): one forward
+        pass of the loss, without a backward where the fused geometric operator makes that possible -- every backward pass of
+        the process then goes through the bucket and the step's one grouped weight-gradient launch."""
+        from ndjir_amd.loss import total_loss
+        from ndjir_amd.network import uses_fused_geometric
+        if not uses_fused_geometric(self.conf) or self.device.type != "cuda":
+            self.forward_backward()      # (the layer-by-layer geometric network takes its normals from autograd: needs grad mode)
+            return
+        self.pre_exchange()
+        use_mask = self.conf.train.mask_weight > 0.0
+        with torch.no_grad():
+            total_loss(self.camloc, self.raydir, self.color_gt, self.obj_mask if use_mask else None, self.car, self.conf,
+                       self.rand, ray_shards=self.world, mask_sum_global=self.mask_sum if self.multi else None,
+                       obj_mask_sum_global=self.obj_mask_sum if (self.multi and use_mask) else None)
 
     def set_rays(self, camloc, raydir, color_gt, obj_mask=None):
         """Feed the next iteration's rays (python/train.py:124-133: `raydir.d = ...`, `camloc.d = ...`, `color_gt.d = ...`,
