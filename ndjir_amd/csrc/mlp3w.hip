@@ -90,10 +90,30 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
 
   stamp(MAX_CHAIN_LAYERS - 1, 0);
   stamp_rt(0);
+#ifndef NDJIR_NO_L2_WARMUP
+  // L2 warm-up.  A launch finds its net's packed weights cold (the previous launch streamed another net's weights and hundreds
+  // of MB of activations through the 4 MB L2 of each XCD), and a layer's first k-steps on every CU of an XCD then miss together:
+  // one memory latency per LAYER, 8 in a row for the geometric net (the fixed-cost fit: 25 - 80 us of intercept per backward /
+  // tangent launch).  Here the workgroups of an XCD's first round (blockIdx & 7 = XCD, blockIdx >> 3 = its index there) each
+  // touch 1 / 32 of EVERY layer's weights, one dword per 128-byte line, before the first tile's input stage: all layers'
+  // misses overlap once.  The values are consumed (an empty asm) before the first barrier.
+  unsigned warm = 0;
+  if (blockIdx.x < 256) {
+    const int part = (blockIdx.x >> 3) & 31;
+    for (int li = 0; li < a.L; ++li) {
+      const ChainLayer& ly = a.layers[li];
+      const long long lines = (((long long)((ly.Kp + 15) >> 4) * 16 * ly.Np + (ly.Np >> 5)) * 4 + 127) >> 7;      // 128-byte lines of the packed matrix
+      const long long per = (lines + 31) >> 5;
+      const unsigned* base = reinterpret_cast<const unsigned*>(ly.Wp);
+      for (long long l = part * per + tid; l < (part + 1) * per && l < lines; l += NTHREADS) warm ^= base[l * 32];
+    }
+  }
+#endif
   if (MODE != 0) for (int i = tid; i < a.bg_total; i += NTHREADS) bsum[i] = 0.f;
   if (tid < 2 * TM) { (&s_rmax[0][0])[tid] = 0u; (&s_xmax[0][0])[tid] = 0u; }
   __syncthreads();
   int xpar = 0;                        // ping-pong slot of the input row maxima
+  bool warm_pending = true;
 
   for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long row0 = tile * TM;  // (the launcher guarantees P % TM == 0: every tile is full)
@@ -159,6 +179,9 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
       }
       for (int t = tid + IN_CACHE * NTHREADS; t < total; t += NTHREADS) emit(t, load(t));
     }
+#ifndef NDJIR_NO_L2_WARMUP
+    if (warm_pending) { asm volatile("" :: "v"(warm)); warm_pending = false; }
+#endif
     __syncthreads();
     if (tile == blockIdx.x) stamp(MAX_CHAIN_LAYERS - 1, 1);
 
