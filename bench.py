@@ -226,10 +226,11 @@ def redraw_leg(step, graph, loss_t, steps, barrier):
                      "drawn random tensors before every replay; includes the feed's launches and one small host->device copy"}
 
 
-def b4_leg(conf, R, device, steps, barrier, use_graph):
+def b4_leg(conf, R, device, steps, barrier, use_graph, B=4):
     """The reference's real training-step shape: train.batch_size = 4 images x train.n_rays = 512 rays
-    (config/default.yaml:126-127, python/train.py:38-51), forward + backward.  Beside the headline metric (B = 1), not it."""
-    step = Step(conf, R, device, 0, 1, B=4)
+    (config/default.yaml:126-127, python/train.py:38-51), forward + backward.  Beside the headline metric (B = 1), not it.
+    (B = 1: a second step of another size, for `--scaling strong`'s projection.)"""
+    step = Step(conf, R, device, 0, 1, B=B)
     for _ in range(2):
         step.forward_backward()
     graph, mode = None, "eager stream launches"
@@ -247,7 +248,7 @@ def b4_leg(conf, R, device, steps, barrier, use_graph):
         fn()
     barrier()
     el = time.perf_counter() - t0
-    return {"ms_per_step": 1e3 * el / steps, "rays_per_s": 4 * R * steps / el, "steps": steps, "images": 4, "rays_per_image": R,
+    return {"ms_per_step": 1e3 * el / steps, "rays_per_s": B * R * steps / el, "steps": steps, "images": B, "rays_per_image": R,
             "execution": mode, "loss": float(step.loss)}
 
 
@@ -693,12 +694,22 @@ def main():
                            "(python/train.py:136-148); reported beside the headline metric, not as it")
             out["train_step"] = tl
     if world == 1 and not force_dist and a.extra_legs:
+        use_graph = (a.exec_mode or os.environ.get("NDJIR_BENCH_EXEC") or "graph") == "graph"
         try:
             del step
             graph = None
-            out["b4"] = b4_leg(conf, R, device, a.steps, barrier, (a.exec_mode or os.environ.get("NDJIR_BENCH_EXEC") or "graph") == "graph")
+            if a.scaling == "strong":
+                # BASELINE.json config 4 on ONE GPU: what 8 ranks would each do (total_rays / 8 rays), and the strong-scaling
+                # ratio that follows if the exchange costs 0.3 ms per step -- a projection from single-GPU times, not a measurement
+                small = b4_leg(conf, a.total_rays // 8, device, a.steps, barrier, use_graph, B=1)
+                out["projected_strong_scaling_8"] = {
+                    "ms_per_step_all_rays_one_gpu": ms, "ms_per_step_one_eighth": small["ms_per_step"], "assumed_exchange_ms": 0.3,
+                    "value": ms / (small["ms_per_step"] + 0.3),
+                    "note": f"t({a.total_rays} rays) / (t({a.total_rays // 8} rays) + 0.3 ms), both on this one GPU"}
+            else:
+                out["b4"] = b4_leg(conf, R, device, a.steps, barrier, use_graph)
         except Exception as e:
-            out["b4"] = {"error": f"{type(e).__name__}: {e}"}
+            out["b4" if a.scaling != "strong" else "projected_strong_scaling_8"] = {"error": f"{type(e).__name__}: {e}"}
     if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
     if rank == 0:

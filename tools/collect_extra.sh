@@ -6,7 +6,7 @@ O=gpurun_out/profiles_new; mkdir -p $O
   echo "# bench.py --config <c> --no-cpu-baseline --train-steps 0 --steps 20 --warmup 3 (512 rays, one box): ms/step, rays/s"
   for c in default triplaneline custom no_voxel ste; do bash tools/ab_cfg.sh $c - 2>/dev/null | tail -1; done
   echo "# bench.py --scaling strong --total-rays 4096 --config no_voxel (N = 1 point of BASELINE config 4's curve)"
-  python bench.py --scaling strong --total-rays 4096 --config no_voxel --no-cpu-baseline --train-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],2), 'ms', round(d['value']), 'rays/s')"
+  python bench.py --scaling strong --total-rays 4096 --config no_voxel --no-cpu-baseline --train-steps 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],2), 'ms', round(d['value']), 'rays/s'); print('projected 8-GPU strong scaling:', d.get('projected_strong_scaling_8'))"
 } > $O/configs.txt 2>&1
 {
   echo "# NDJIR_BENCH_FORCE_DIST=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --train-steps 0   (1-rank RCCL group: the N > 1 code path on one GPU)"
