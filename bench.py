@@ -393,7 +393,9 @@ def kernel_description(sym, math):
         return (f"fused MLP {what} chain on 128-point tiles, epilogue in the accumulator registers (csrc/mlp3w.hip; template "
                 "arguments: mode, row blocks per wave -- 4: nets up to 256 wide, 2: up to 128 wide --, waves per workgroup): fp32 "
                 "operands scaled by powers of two and split into 2 f16 planes, 3 v_mfma_f32_32x32x16_f16 partial products per fp32 "
-                "product in two fp32 accumulators")
+                "product in two fp32 accumulators"
+                + ("; k_chainw_nets: up to three nets of one MultiMLP in one launch, a workgroup takes its tile through them "
+                   "in turn (the per-sample material nets)" if "k_chainw_nets" in sym else ""))
     if "k_chain3" in sym:
         return f"fused MLP {what} chain, 64 / 32-point tiles (csrc/mlp3.hip; small launches: the sampler's rounds, per-ray nets)"
     if "k_chain6" in sym:

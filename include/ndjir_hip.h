@@ -458,6 +458,18 @@ int ndjir_copy_columns(long long P, int C, const float* src, int lds, float* dst
 int ndjir_inverse_squared_distance(long long P, long long rows_per_batch, const float* x, int ldx, const float* camloc, float* out,
                                    int ldo, hipStream_t stream);
 
+/* Chain groups (reference: python/renderer.py:113-128 -- the per-sample material nets read the same row of every sample;
+ * BASELINE.json north_star: "the small MLPs fused per-sample").  Between _begin and _end the chain calls of the calling thread
+ * are RECORDED (validated, nothing launched; the pointer arrays need not outlive the call).  _end launches them in call
+ * order: consecutive calls of one mode on the same number of points that the 128-point-tile kernel can take together (f16x3
+ * arithmetic; at most 3; bias-gradient accumulators of all fit the LDS) as ONE launch in which a workgroup takes its tile
+ * through the nets in turn -- the tile's input row is re-staged from L2, a backward group's accumulating calls (accum_y bit 0)
+ * add to the gradient tile the first call wrote while it is still in cache -- and everything else as the calls alone would
+ * have run.  Results equal those of the separate launches bit for bit.  *launches (may be NULL) = chain kernel launches issued.
+ * NDJIR_ERR_ARG: _begin with a group open, _end without one, more than 16 calls in a group. */
+int ndjir_mlp_chain_group_begin(void);
+int ndjir_mlp_chain_group_end(hipStream_t stream, int* launches);
+
 /* ---- fused MLP engine ------------------------------------------------------------------------------
  * Replaces the reference's per-layer nnabla launches (PF.affine -> cuBLAS GEMM, F.softplus(beta=100),
  * python/network.py:88-93,165 and every network function :154-561) by ONE launch per net and

@@ -59,6 +59,13 @@ extern "C" int ndjir_mlp_pack_table(const void* table, int n, int total_blocks, 
 extern "C" int ndjir_mlp_pack_entry_bytes(void) { return (int)sizeof(PackEntry); }
 
 static long long* g_timeline = nullptr;   // diagnostics only, see ndjir_mlp_debug_timeline
+
+// ---- chain groups: between ndjir_mlp_chain_group_begin and _end, this thread's chain calls are recorded, not launched ----
+constexpr int GROUP_MAX_CALLS = 16;
+struct GroupCall { ChainArgs a; int mode; };
+static thread_local GroupCall* g_group = nullptr;     // non-null = a group is open on this thread
+static thread_local int g_group_n = 0;
+static thread_local int g_group_err = NDJIR_OK;
 static thread_local ChainDry* g_dry = nullptr;         // set for the duration of the two dry-run queries below
 
 // Points per workgroup tile of the chain kernels: 0 = chosen per launch (128 for large launches the wide-tile kernel
@@ -137,9 +144,74 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
     if (bwd != 1 && i == skip_layer) kin = ly.N + K0;
     if (bwd == 1 && i == skip_layer) kin = skip_split;
   }
+  if (g_group && !g_dry) {                 // an open group: the launch happens in ndjir_mlp_chain_group_end
+    if (g_group_n >= GROUP_MAX_CALLS) return g_group_err = NDJIR_ERR_ARG;
+    g_group[g_group_n].a = a;
+    g_group[g_group_n].mode = bwd;
+    ++g_group_n;
+    return NDJIR_OK;
+  }
   if (g_math == NDJIR_MATH_F16X3) return launch_chain3(a, bwd, stream);
   if (g_math == NDJIR_MATH_BF16X6) return launch_chain6(a, bwd, stream);
   return launch_chain(a, bwd, stream);
+}
+
+static int chain_dispatch(const ChainArgs& a, int mode, hipStream_t stream) {
+  if (g_math == NDJIR_MATH_F16X3) return launch_chain3(a, mode, stream);
+  if (g_math == NDJIR_MATH_BF16X6) return launch_chain6(a, mode, stream);
+  return launch_chain(a, mode, stream);
+}
+
+// Chain groups.  The per-sample material nets of the reference (python/renderer.py:113-128: base colour, implicit
+// illumination, roughness, specular reflectance, photogrammetric light) read the same packed row of every sample and their
+// input gradients add up in one tensor.  A caller brackets their chain calls:
+//     ndjir_mlp_chain_group_begin();  ndjir_mlp_chain(...) x n  (recorded, nothing is launched);  ndjir_mlp_chain_group_end(stream, &launches);
+// _end launches the recorded calls IN ORDER -- consecutive calls of one mode that the 128-point-tile kernel can run as one
+// launch (f16x3 arithmetic, same number of points, same tile shape, at most MAX_GROUP_NETS, the accumulators of all fit the
+// LDS beside the planes) as ONE launch in which a workgroup takes its tile through the nets in turn, everything else exactly
+// as the calls alone would have run.  Results are those of the separate launches, bit for bit (same kernel, same per-tile
+// arithmetic; a backward group's `accum_y` calls add to the gradient tile in call order).  The pointer arrays passed to the
+// recorded calls need not outlive them.  Thread-local; a group must be closed on the thread that opened it.
+extern "C" int ndjir_mlp_chain_group_begin(void) {
+  if (g_group) return NDJIR_ERR_ARG;
+  g_group = static_cast<GroupCall*>(malloc(sizeof(GroupCall) * GROUP_MAX_CALLS));
+  if (!g_group) return NDJIR_ERR_LAUNCH;
+  g_group_n = 0;
+  g_group_err = NDJIR_OK;
+  return NDJIR_OK;
+}
+
+extern "C" int ndjir_mlp_chain_group_end(hipStream_t stream, int* launches) {
+  if (!g_group) return NDJIR_ERR_ARG;
+  GroupCall* calls = g_group;
+  const int n = g_group_n;
+  g_group = nullptr;                    // (closed whatever happens below)
+  g_group_n = 0;
+  int rc = g_group_err, issued = 0;
+  ChainArgs run[MAX_GROUP_NETS];
+  for (int i = 0; i < n && rc == NDJIR_OK;) {
+    int m = 1;
+    const ChainArgs& f = calls[i].a;
+    const bool wide = g_math == NDJIR_MATH_F16X3 && (f.tile_rows == 128 || (f.tile_rows == 64 && f.forced_tile == 0));
+    if (wide)
+      while (i + m < n && m < MAX_GROUP_NETS && calls[i + m].mode == calls[i].mode && calls[i + m].a.P == f.P &&
+             calls[i + m].a.tile_rows == f.tile_rows && calls[i + m].a.forced_tile == f.forced_tile) ++m;
+    // the longest prefix of the run the kernel takes as one launch
+    int done = 0;
+    for (int k = m; k >= 2 && !done; --k) {
+      for (int j = 0; j < k; ++j) run[j] = calls[i + j].a;
+      const int r = launch_chainw_group(run, k, calls[i].mode, stream);
+      if (r == NDJIR_OK) { done = k; ++issued; }
+      else if (r != NDJIR_ERR_UNSUPPORTED) rc = r;
+      if (rc != NDJIR_OK) break;
+    }
+    if (rc != NDJIR_OK) break;
+    if (!done) { rc = chain_dispatch(f, calls[i].mode, stream); done = 1; ++issued; }
+    i += done;
+  }
+  free(calls);
+  if (launches) *launches = issued;
+  return rc;
 }
 
 extern "C" int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L,

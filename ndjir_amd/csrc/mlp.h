@@ -64,6 +64,16 @@ struct ChainArgs {
   ChainLayer layers[MAX_CHAIN_LAYERS];
 };
 
+// Several nets on the same points in ONE launch of the 128-point-tile kernel (mlp3w.hip): a workgroup takes a tile through
+// every net of the group in turn (the per-sample material nets of python/renderer.py:113-128 read the same packed row and
+// accumulate into the same input gradient).  By value in the kernel arguments: 3 x sizeof(ChainArgs) stays under the 4 KB limit.
+constexpr int MAX_GROUP_NETS = 3;
+struct ChainGroup {
+  int n, pad;
+  ChainArgs net[MAX_GROUP_NETS];
+};
+static_assert(sizeof(ChainGroup) <= 4096, "kernel arguments are limited to 4 KB");
+
 int launch_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
 int launch_chain(const ChainArgs& a, int mode, hipStream_t stream);
 int launch_bgrad_reduce(const float* partial, int S, int total, float* const* ptr, const int* off, int n, int accum, hipStream_t stream);
@@ -87,6 +97,8 @@ int launch_pack3_table(const PackEntry* table, int n, int total_blocks, hipStrea
 int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream);
 // f16 2-way-split engine on 128-point tiles (mlp3w.hip); NDJIR_ERR_UNSUPPORTED = not a launch for this kernel
 int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream);
+// n <= MAX_GROUP_NETS nets of one mode on the same number of points; NDJIR_ERR_UNSUPPORTED = launch them one by one
+int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stream);
 constexpr int CHAIN_MAX_GRID_BG = 512;   // workgroups of a chain launch that produces bias gradients
 inline long long chain_workspace(int bg_total) { return (long long)CHAIN_MAX_GRID_BG * bg_total; }
 long long wgrad_workspace(int K, int N, long long P);

@@ -33,6 +33,10 @@ namespace x3w {
 
 using namespace x3u;
 
+typedef ChainGroup __attribute__((address_space(4))) KGroup;     // (the kernel-argument segment is constant address space)
+typedef ChainArgs __attribute__((address_space(4))) KArgs;
+typedef ChainLayer __attribute__((address_space(4))) KLayer;
+
 constexpr int TM = 128;
 constexpr int TMP = TM + 4;      // rows per k-group incl. pad: (TMP * 16) % 256 == 64 -> conflict-free plane writes
 constexpr int IN_CACHE = 10;     // float4 groups of the chain input a thread keeps between the max pass and the split
@@ -45,8 +49,24 @@ __device__ __forceinline__ int acc_feat(int i, int hh) { return (i & 3) + 8 * (i
 // blocks: two waves per column block).  One k-loop instantiation per kernel: the register allocator sees one hot loop.
 // NWAVES: 8 (one workgroup per CU) or 4 (RPW = 4, hidden layers of up to 4 column blocks: TWO workgroups per CU, one wave
 // of each per SIMD -- the epilogue of one runs beside the k-loop of the other).
-template <int MODE, int RPW, int NWAVES>
-__global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
+// The launch carries up to MAX_GROUP_NETS nets on the same points (ChainGroup): a workgroup takes its tile through net 0, net 1, ...
+// in turn -- each net stages the tile's input again (L2-resident after the first) and, in the backward, the first net assigns
+// the input gradient's tile and the others add to it while it is still in L2.  One net = the plain launch.
+// NETS: where the argument blocks are -- OneNet: the kernel's by-value ChainArgs (the plain launch: the net loop folds away and
+// the compiler reads the block into scalar registers once, as it always did); ManyNets: a ChainGroup, indexed by the net counter
+// where it lies in the kernel-argument segment (uniform scalar loads; indexing a by-value copy would put all 3.4 KB in scratch).
+struct OneNet {
+  const ChainArgs& a;
+  __device__ __forceinline__ const ChainArgs& get(int) const { return a; }
+  __device__ __forceinline__ int n() const { return 1; }
+};
+struct ManyNets {
+  const KGroup* g;
+  __device__ __forceinline__ const KArgs& get(int i) const { return g->net[i]; }
+  __device__ __forceinline__ int n() const { return g->n; }
+};
+template <int MODE, int RPW, int NWAVES, class NETS>
+__device__ __forceinline__ void chainw_body(const NETS nets) {
   constexpr int NTHREADS = NWAVES * 64;
   constexpr bool BWD = (MODE == 1);
   constexpr int G = 4 / RPW;           // wave groups sharing a column block's rows
@@ -55,7 +75,9 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
   __shared__ unsigned s_rmax[2][TM];   // per row: largest finite |output| of the layer (bit pattern; ping-pong by layer)
   __shared__ unsigned s_xmax[2][TM];   // per row: largest finite |x| of the chain input tile (ping-pong by tile)
   __shared__ float s_ainv[TM];         // per row: 1 / scale of the planes the next k-loop reads
-  const int PLANE = a.lds_split;       // 16-byte units per plane ( = k-groups * TMP )
+  const int n_nets = nets.n();
+  const auto& a0 = nets.get(0);
+  const int PLANE = a0.lds_split;      // 16-byte units per plane ( = k-groups * TMP ); one value for the whole group
   f16x8* act = reinterpret_cast<f16x8*>(lds);
   char* actb = reinterpret_cast<char*>(lds);
   const int tid = threadIdx.x;
@@ -64,13 +86,11 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
   // an opaque copy of the lane id: addresses derived from it are formed where they are used instead of being hoisted out of
   // the tile / layer loops into registers that stay occupied (or spilled) through the k-loops
   auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
-  float* bsum = lds + a.bg_lds;
-  const float beta = a.beta;
   auto stamp = [&](int li, int phase) {
-    if (a.timeline && blockIdx.x == 0 && lane == 0) a.timeline[(li * 5 + phase) * 8 + wave] = (long long)__builtin_amdgcn_s_memtime();
+    if (a0.timeline && blockIdx.x == 0 && lane == 0) a0.timeline[(li * 5 + phase) * 8 + wave] = (long long)__builtin_amdgcn_s_memtime();
   };
   auto stamp_rt = [&](int phase) {
-    if (a.timeline && blockIdx.x == 0 && lane == 0) a.timeline[((MAX_CHAIN_LAYERS - 2) * 5 + phase) * 8 + wave] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (a0.timeline && blockIdx.x == 0 && lane == 0) a0.timeline[((MAX_CHAIN_LAYERS - 2) * 5 + phase) * 8 + wave] = (long long)__builtin_amdgcn_s_memrealtime();
   };
   // write 4 consecutive features k..k+3 (k % 4 == 0) of row m, scaled by s, into the two planes
   auto put4 = [&](int k, int m, f32x4 v, float s) {
@@ -100,23 +120,34 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
   unsigned warm = 0;
   if (blockIdx.x < 256) {
     const int part = (blockIdx.x >> 3) & 31;
-    for (int li = 0; li < a.L; ++li) {
-      const ChainLayer& ly = a.layers[li];
-      const long long lines = (((long long)((ly.Kp + 15) >> 4) * 16 * ly.Np + (ly.Np >> 5)) * 4 + 127) >> 7;      // 128-byte lines of the packed matrix
-      const long long per = (lines + 31) >> 5;
-      const unsigned* base = reinterpret_cast<const unsigned*>(ly.Wp);
-      for (long long l = part * per + tid; l < (part + 1) * per && l < lines; l += NTHREADS) warm ^= base[l * 32];
+    for (int ni = 0; ni < n_nets; ++ni) {
+      const auto& a = nets.get(ni);
+      for (int li = 0; li < a.L; ++li) {
+        const auto& ly = a.layers[li];
+        const long long lines = (((long long)((ly.Kp + 15) >> 4) * 16 * ly.Np + (ly.Np >> 5)) * 4 + 127) >> 7;      // 128-byte lines of the packed matrix
+        const long long per = (lines + 31) >> 5;
+        const unsigned* base = reinterpret_cast<const unsigned*>(ly.Wp);
+        for (long long l = part * per + tid; l < (part + 1) * per && l < lines; l += NTHREADS) warm ^= base[l * 32];
+      }
     }
   }
 #endif
-  if (MODE != 0) for (int i = tid; i < a.bg_total; i += NTHREADS) bsum[i] = 0.f;
+  if (MODE != 0)
+    for (int ni = 0; ni < n_nets; ++ni) {
+      float* bs = lds + nets.get(ni).bg_lds;
+      for (int i = tid; i < nets.get(ni).bg_total; i += NTHREADS) bs[i] = 0.f;
+    }
   if (tid < 2 * TM) { (&s_rmax[0][0])[tid] = 0u; (&s_xmax[0][0])[tid] = 0u; }
   __syncthreads();
   int xpar = 0;                        // ping-pong slot of the input row maxima
   bool warm_pending = true;
 
-  for (long long tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+  for (long long tile = blockIdx.x; tile < a0.n_tiles; tile += gridDim.x) {
     const long long row0 = tile * TM;  // (the launcher guarantees P % TM == 0: every tile is full)
+   for (int ni = 0; ni < n_nets; ++ni) {
+    const auto& a = nets.get(ni);
+    float* const bsum = lds + a.bg_lds;
+    const float beta = a.beta;
 
     // ---- chain input tile -> planes (zero padded to a multiple of 16 features) ----
     {
@@ -187,7 +218,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
 
     int cur = 0;                         // ping-pong slot of the layer's row maxima
     for (int li = 0; li < a.L; ++li) {
-      const ChainLayer& ly = a.layers[li];
+      const auto& ly = a.layers[li];
       const int KS = (ly.Kp + 15) >> 4;          // k-steps of 16 (planes are zero beyond Kp)
       const int NB = ly.Np >> 5;
       const bool last = a.has_output && (li == a.L - 1);
@@ -308,7 +339,6 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
       using I3 = std::integral_constant<int, 3>;
-      using I4 = std::integral_constant<int, 4>;
       using TT = std::true_type;
       using FF = std::false_type;
 
@@ -698,24 +728,46 @@ __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
     }
     if (tile == blockIdx.x) stamp(MAX_CHAIN_LAYERS - 1, 2);
     xpar ^= 1;
+   }   // nets
   }
   stamp(MAX_CHAIN_LAYERS - 1, 3);
   stamp_rt(1);
-  if (MODE != 0 && a.bg_total > 0) {
+  if (MODE != 0) {
     __syncthreads();
-    float* part = a.bg_partial + (long long)blockIdx.x * a.bg_total;
-    for (int i = tid; i < a.bg_total; i += NTHREADS) part[i] = bsum[i];
+    for (int ni = 0; ni < n_nets; ++ni) {
+      const auto& a = nets.get(ni);
+      const float* bs = lds + a.bg_lds;
+      float* part = a.bg_partial + (long long)blockIdx.x * a.bg_total;
+      for (int i = tid; i < a.bg_total; i += NTHREADS) part[i] = bs[i];
+    }
   }
+}
+
+template <int MODE, int RPW, int NWAVES>
+__global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
+  chainw_body<MODE, RPW, NWAVES>(OneNet{a});
+}
+template <int MODE, int RPW, int NWAVES>
+__global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw_nets(ChainGroup /* read in the kernel-argument segment */) {
+  chainw_body<MODE, RPW, NWAVES>(ManyNets{(const KGroup*)__builtin_amdgcn_kernarg_segment_ptr()});
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace x3w
 
-// NDJIR_ERR_UNSUPPORTED = "not a launch for this kernel" (the caller falls back to mlp3.hip's 64 / 32-point tiles).
-int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) {
+// One net's part of a launch plan: the argument block with everything but the LDS offsets filled in.
+struct WidePlan {
+  ChainArgs b;
+  int rpw;                  // row blocks per wave its widest hidden layer asks for
+  int wmax;                 // widest activation its planes hold
+  int bg_n, bg_total;
+  float* bg_ptr[MAX_CHAIN_LAYERS + 1];
+  int bg_off[MAX_CHAIN_LAYERS + 1];
+};
+
+static int wide_plan(const ChainArgs& a, int mode, WidePlan& p) {
   using namespace x3w;
-  constexpr int LDS_DYN_MAX = 160 * 1024 - 4096;      // the kernel also holds 2.5 KB of static LDS (row maxima / scales)
   if ((a.P % TM) != 0) return NDJIR_ERR_UNSUPPORTED;
   if (a.P < 128 * 256 && a.tile_rows != 128) return NDJIR_ERR_UNSUPPORTED;      // (a forced 128 takes small launches too: tests)
   int wmax = round_up(a.K0, 16), hmax = 0;
@@ -725,44 +777,46 @@ int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) {
     if (!last && a.layers[i].Np > wmax) wmax = a.layers[i].Np;
     if (!last && a.layers[i].Np > hmax) hmax = a.layers[i].Np;
   }
-  const int rpw = hmax <= 128 ? 2 : 4;      // widest hidden layer: <= 4 column blocks -> two waves per column block
+  p.rpw = hmax <= 128 ? 2 : 4;      // widest hidden layer: <= 4 column blocks -> two waves per column block
   if (a.skip_layer >= 0 && mode != 1) { int w = round_up(a.layers[a.skip_layer].N + a.K0, 16); if (w > wmax) wmax = w; }
-  ChainArgs b = a;
-  b.K0p = round_up(a.K0, 16);
-  b.lds_split = (wmax / 8) * TMP;                          // 16-byte units per plane
-  size_t lds_bytes = (size_t)2 * b.lds_split * 16;
-  b.n_tiles = a.P / TM;
-  float* bg_ptr[MAX_CHAIN_LAYERS + 1];
-  int bg_off[MAX_CHAIN_LAYERS + 1];
-  int bg_n = 0, bg_total = 0;
+  p.wmax = wmax;
+  p.b = a;
+  p.b.K0p = round_up(a.K0, 16);
+  p.b.n_tiles = a.P / TM;
+  p.bg_n = 0;
+  int bg_total = 0;
   if (mode != 0) {
     for (int i = 0; i < a.L; ++i) if (a.layers[i].bgrad && !(a.has_output && i == a.L - 1)) {
-      b.layers[i].bg_off = bg_total;
-      bg_ptr[bg_n] = a.layers[i].bgrad;
-      bg_off[bg_n] = bg_total;
-      ++bg_n;
+      p.b.layers[i].bg_off = bg_total;
+      p.bg_ptr[p.bg_n] = a.layers[i].bgrad;
+      p.bg_off[p.bg_n] = bg_total;
+      ++p.bg_n;
       bg_total += a.layers[i].N;
-    } else b.layers[i].bgrad = nullptr;
+    } else p.b.layers[i].bgrad = nullptr;
   }
   if (mode != 0 && a.in_bgrad) {
-    b.in_bg_off = bg_total;
-    bg_ptr[bg_n] = a.in_bgrad;
-    bg_off[bg_n] = bg_total;
-    ++bg_n;
+    p.b.in_bg_off = bg_total;
+    p.bg_ptr[p.bg_n] = a.in_bgrad;
+    p.bg_off[p.bg_n] = bg_total;
+    ++p.bg_n;
     bg_total += a.K0;
   }
-  b.bg_total = bg_total;
-  b.bg_lds = (int)(lds_bytes / 4);
-  lds_bytes += (size_t)bg_total * 4;
+  p.b.bg_total = p.bg_total = bg_total;
   if (bg_total > 0 && !a.bg_partial) return NDJIR_ERR_ARG;
-  if (lds_bytes > LDS_DYN_MAX) return NDJIR_ERR_UNSUPPORTED;
-  long long blocks = b.n_tiles;
-  if (blocks > 256LL * 8) blocks = 256LL * 8;
-  if (bg_total > 0 && blocks > CHAIN_MAX_GRID_BG) blocks = CHAIN_MAX_GRID_BG;
+  return NDJIR_OK;
+}
+
+// NDJIR_ERR_UNSUPPORTED = "not a launch for this kernel" (the caller falls back to mlp3.hip's 64 / 32-point tiles; a group is
+// launched net by net).
+int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stream) {
+  using namespace x3w;
+  constexpr int LDS_DYN_MAX = 160 * 1024 - 4096;      // the kernel also holds 2.5 KB of static LDS (row maxima / scales)
+  if (n < 1 || n > MAX_GROUP_NETS) return NDJIR_ERR_UNSUPPORTED;
   static bool attr_set = false;
   static int nw4 = 1;
   if (!attr_set) {
-#define NDJIR_SET(M, R, W) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw<M, R, W>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX)
+#define NDJIR_SET(M, R, W) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw<M, R, W>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX); \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw_nets<M, R, W>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX)
     NDJIR_SET(0, 4, 8); NDJIR_SET(1, 4, 8); NDJIR_SET(2, 4, 8); NDJIR_SET(0, 2, 8); NDJIR_SET(1, 2, 8); NDJIR_SET(2, 2, 8);
     NDJIR_SET(0, 4, 4); NDJIR_SET(1, 4, 4); NDJIR_SET(2, 4, 4);
 #undef NDJIR_SET
@@ -772,22 +826,69 @@ int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) {
     nw4 = e ? atoi(e) : 1;
     attr_set = true;
   }
-  if (a.dry) {
-    const bool four = rpw != 4 && ((nw4 >> mode) & 1) && lds_bytes <= 77 * 1024;
-    snprintf(a.dry->name, 64, "ndjir::x3w::k_chainw<%d, %d, %d>", mode, (rpw == 4 || four) ? 4 : 2, four ? 4 : 8);
-    a.dry->blocks = (int)blocks; a.dry->bg_total = bg_total;
+  // (static: 3.5 KB of argument blocks + plans stay off the stack of every chain call; launches are serialised per thread)
+  static thread_local WidePlan plan[MAX_GROUP_NETS];
+  static thread_local ChainGroup grp;
+  int wmax = 0, bg_sum = 0;
+  bool own_four[MAX_GROUP_NETS];
+  for (int i = 0; i < n; ++i) {
+    const int rc = wide_plan(nets[i], mode, plan[i]);
+    if (rc != NDJIR_OK) return rc;
+    if (plan[i].rpw != plan[0].rpw || nets[i].P != nets[0].P) return NDJIR_ERR_UNSUPPORTED;
+    if (plan[i].wmax > wmax) wmax = plan[i].wmax;
+    bg_sum += plan[i].bg_total;
+    // (the decision a launch of this net alone takes: its planes + its own accumulators)
+    own_four[i] = plan[i].rpw != 4 && ((nw4 >> mode) & 1) && (size_t)2 * (plan[i].wmax / 8) * TMP * 16 + (size_t)plan[i].bg_total * 4 <= 77 * 1024;
+  }
+  const int rpw = plan[0].rpw;
+  const int lds_split = (wmax / 8) * TMP;                      // 16-byte units per plane
+  size_t lds_bytes = (size_t)2 * lds_split * 16;
+  int bg_lds = (int)(lds_bytes / 4);
+  lds_bytes += (size_t)bg_sum * 4;
+  if (lds_bytes > LDS_DYN_MAX) return NDJIR_ERR_UNSUPPORTED;
+  // (two workgroups per CU: 2 x (dynamic + 2.5 KB static) <= 160 KB)
+  const bool four = rpw != 4 && ((nw4 >> mode) & 1) && lds_bytes <= 77 * 1024;
+  // a group runs the kernel each of its nets would run alone (the symbol a profile is keyed by, the grid the deferred bias
+  // partials were laid out for)
+  for (int i = 0; i < n && n > 1; ++i) if (own_four[i] != four) return NDJIR_ERR_UNSUPPORTED;
+  long long blocks = plan[0].b.n_tiles;
+  if (blocks > 256LL * 8) blocks = 256LL * 8;
+  if (bg_sum > 0 && blocks > CHAIN_MAX_GRID_BG) blocks = CHAIN_MAX_GRID_BG;
+  if (n > 1) {          // ... which caps the grid of a net with bias gradients only: every member has to agree on it
+    for (int i = 0; i < n; ++i) {
+      long long own = plan[i].b.n_tiles > 256LL * 8 ? 256LL * 8 : plan[i].b.n_tiles;
+      if (plan[i].bg_total > 0 && own > CHAIN_MAX_GRID_BG) own = CHAIN_MAX_GRID_BG;
+      if (plan[i].bg_total > 0 && own != blocks) return NDJIR_ERR_UNSUPPORTED;
+    }
+  }
+  grp.n = n; grp.pad = 0;
+  for (int i = 0; i < n; ++i) {
+    plan[i].b.lds_split = lds_split;
+    plan[i].b.bg_lds = bg_lds;
+    bg_lds += plan[i].bg_total;
+    grp.net[i] = plan[i].b;
+  }
+  if (nets[0].dry) {
+    snprintf(nets[0].dry->name, 64, "ndjir::x3w::k_chainw%s<%d, %d, %d>", n > 1 ? "_nets" : "", mode, (rpw == 4 || four) ? 4 : 2, four ? 4 : 8);
+    nets[0].dry->blocks = (int)blocks; nets[0].dry->bg_total = plan[0].bg_total;
     return NDJIR_OK;
   }
-#define NDJIR_GO(M, R, W) hipLaunchKernelGGL((k_chainw<M, R, W>), dim3((unsigned)blocks), dim3(W * 64), lds_bytes, stream, b)
+#define NDJIR_GO(M, R, W)                                                                                                   \
+  do {                                                                                                                      \
+    if (n == 1) hipLaunchKernelGGL((k_chainw<M, R, W>), dim3((unsigned)blocks), dim3(W * 64), lds_bytes, stream, grp.net[0]); \
+    else hipLaunchKernelGGL((k_chainw_nets<M, R, W>), dim3((unsigned)blocks), dim3(W * 64), lds_bytes, stream, grp);         \
+  } while (0)
   if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4, 8); else if (mode == 1) NDJIR_GO(1, 4, 8); else NDJIR_GO(2, 4, 8); }
-  // (two workgroups per CU: 2 x (dynamic + 2.5 KB static) <= 160 KB)
-  else if (((nw4 >> mode) & 1) && lds_bytes <= 77 * 1024) { if (mode == 0) NDJIR_GO(0, 4, 4); else if (mode == 1) NDJIR_GO(1, 4, 4); else NDJIR_GO(2, 4, 4); }
+  else if (four) { if (mode == 0) NDJIR_GO(0, 4, 4); else if (mode == 1) NDJIR_GO(1, 4, 4); else NDJIR_GO(2, 4, 4); }
   else { if (mode == 0) NDJIR_GO(0, 2, 8); else if (mode == 1) NDJIR_GO(1, 2, 8); else NDJIR_GO(2, 2, 8); }
 #undef NDJIR_GO
   int rc = ndjir_check_launch();
-  if (rc != NDJIR_OK) return rc;
-  if (bg_total > 0 && !a.defer_bg_reduce) return launch_bgrad_reduce(a.bg_partial, (int)blocks, bg_total, bg_ptr, bg_off, bg_n, a.bg_accum, stream);
-  return NDJIR_OK;
+  for (int i = 0; i < n && rc == NDJIR_OK; ++i)
+    if (plan[i].bg_total > 0 && !nets[i].defer_bg_reduce)
+      rc = launch_bgrad_reduce(nets[i].bg_partial, (int)blocks, plan[i].bg_total, plan[i].bg_ptr, plan[i].bg_off, plan[i].bg_n, nets[i].bg_accum, stream);
+  return rc;
 }
+
+int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) { return launch_chainw_group(&a, 1, mode, stream); }
 
 }  // namespace ndjir

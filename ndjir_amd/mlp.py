@@ -164,10 +164,108 @@ def _defer_bias_reduction(name, args):
     return tuple(args)
 
 
+_GROUP = None          # inside `chain_group()`: the chain launches recorded so far
+_NO_CHAIN_GROUP = bool(os.environ.get("NDJIR_NO_CHAIN_GROUP"))
+CHAIN_GROUP_MAX = 3     # nets per launch (ndjir_mlp_chain_group_end packs at most this many: kernel-argument limit)
+
+
+@contextlib.contextmanager
+def chain_group():
+    """Chain launches issued inside the block are collected and, at its end, launched through the library's group bracket
+    (ndjir_mlp_chain_group_begin / _end): nets of one mode on the same points that the 128-point-tile kernel can take
+    together run as ONE launch, a workgroup taking its tile through the nets in turn (the per-sample material nets,
+    python/renderer.py:113-128).  The launches keep their order; results are those of the separate launches bit for bit.
+    Outputs of the calls inside the block must not be read (by other launches) before the block ends."""
+    global _GROUP
+    if _GROUP is not None or _NO_CHAIN_GROUP:
+        yield
+        return
+    _GROUP = []
+    try:
+        yield
+    finally:
+        calls, _GROUP = _GROUP, None
+    _flush_chain_group(calls)
+
+
+def _width_class(W):
+    """0: a net with a hidden layer wider than 128 columns, 1: narrower (the two shapes of the 128-point-tile kernel)."""
+    hidden = [int(w.shape[1]) for w in W[:-1]]
+    return 0 if (max(hidden) if hidden else 0) > 128 else 1
+
+
+def _group_class(args):
+    """Nets that can share a launch have hidden layers of the same width class (the kernel's row-blocks-per-wave choice)."""
+    Ns, L, has_out = args[9], int(args[5]), bool(args[17])
+    hidden = [int(n) for j, n in enumerate(Ns) if not (has_out and j == L - 1)]
+    return (int(args[0]), int(args[1]), (max(hidden) if hidden else 0) <= 128)
+
+
+def _flush_chain_group(calls):
+    import ctypes
+    # runs of consecutive calls of one (mode, points, width class); the library decides which of them really share a launch
+    i = 0
+    while i < len(calls):
+        j = i + 1
+        key = _group_class(calls[i][3])
+        while j < len(calls) and j - i < CHAIN_GROUP_MAX and _group_class(calls[j][3]) == key:
+            j += 1
+        run = calls[i:j]
+        i = j
+        if len(run) == 1:
+            _launch_now(*run[0])
+            continue
+        so = lib.load()
+        so.ndjir_mlp_chain_group_end.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        n_launch = ctypes.c_int(0)
+        stream = torch.cuda.current_stream().cuda_stream
+        if PROFILE is None:
+            rc = so.ndjir_mlp_chain_group_begin()
+            if rc != 0:
+                raise lib.NdjirHipError(f"ndjir_mlp_chain_group_begin failed with status {rc}")
+            try:
+                for kind, flops, name, args, shape in run:
+                    lib.call(name, *args)
+            finally:
+                rc = so.ndjir_mlp_chain_group_end(ctypes.c_void_p(stream), ctypes.byref(n_launch))
+            if rc != 0:
+                raise lib.NdjirHipError(f"ndjir_mlp_chain_group_end failed with status {rc}")
+            continue
+        # profiling: one entry per group launch (the sum of its nets' algorithmic work; the input tile is counted once per
+        # net -- every net stages it again, from L2)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = so.ndjir_mlp_chain_group_begin()
+        if rc != 0:
+            raise lib.NdjirHipError(f"ndjir_mlp_chain_group_begin failed with status {rc}")
+        try:
+            for kind, flops, name, args, shape in run:
+                lib.call(name, *args)
+        finally:
+            rc = so.ndjir_mlp_chain_group_end(ctypes.c_void_p(stream), ctypes.byref(n_launch))
+        e1.record()
+        if rc != 0:
+            raise lib.NdjirHipError(f"ndjir_mlp_chain_group_end failed with status {rc}")
+        kind, _, name, args, _ = run[0]
+        sym = _launch_symbol(name, args)
+        if n_launch.value == 1:
+            sym = sym.replace("k_chainw<", "k_chainw_nets<")      # (the group instantiation of the same kernel body)
+        PROFILE.append((kind, sum(r[1] for r in run), e0, e1, " + ".join(r[4] for r in run),
+                        sum(_launch_bytes(r[2], r[3]) for r in run), sym, max(1, n_launch.value)))
+
+
 def _launch(kind, flops, name, *args, shape=""):
     deferred = _defer_bias_reduction(name, args)
     if deferred is not None:
         args = deferred
+    if _GROUP is not None and name in ("mlp_chain", "mlp_chain_ex"):
+        _GROUP.append((kind, flops, name, args, shape))
+        return
+    _launch_now(kind, flops, name, args, shape)
+
+
+def _launch_now(kind, flops, name, args, shape):
     if PROFILE is None:
         lib.call(name, *args)
         return
@@ -463,7 +561,12 @@ def _slot(am, i):
 def chain_workspace(device, bgrads):
     """Workspace of a chain launch that produces the bias gradients `bgrads` (list, None entries ok)."""
     total = sum(b.numel() for b in bgrads if b is not None)
-    return _workspace(device, lib.load().ndjir_mlp_chain_workspace(total)) if total else None
+    if not total:
+        return None
+    need = lib.load().ndjir_mlp_chain_workspace(total)
+    if _GROUP is not None:      # the launches of a group run together: each keeps its partial rows to itself
+        return torch.empty(need, device=device, dtype=torch.float32)
+    return _workspace(device, need)
 
 
 def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, keep_hidden=False, row_bias=None,
@@ -958,16 +1061,23 @@ class MultiMLP(Function):
         ld = x.shape[-1]
         x2 = x.detach().reshape(-1, ld).contiguous()
         train = any(ctx.needs_input_grad)
-        ys, saved, off = [], [x2], 0
-        btgts = []
+        per_net, off = [], 0
         for L, K0, div in net_cfg:
             rb = None
             if div > 0:
                 rb = params[off].detach().reshape(-1, params[off].shape[-1])
                 off += 1
-            W, b = list(params[off:off + L]), list(params[off + L:off + 2 * L])
+            per_net.append((rb, list(params[off:off + L]), list(params[off + L:off + 2 * L])))
             off += 2 * L
-            y, hidden, am = chain_forward(x2, W, b, beta, -1, 1.0, keep_hidden=train, row_bias=rb, row_bias_div=max(div, 1), K0=K0)
+        res = [None] * len(net_cfg)
+        # nets of one hidden-width class next to each other: consecutive launches of a class share a launch (chain_group)
+        with chain_group():
+            for n in sorted(range(len(net_cfg)), key=lambda i: (_width_class(per_net[i][1]), i)):
+                (L, K0, div), (rb, W, b) = net_cfg[n], per_net[n]
+                res[n] = chain_forward(x2, W, b, beta, -1, 1.0, keep_hidden=train, row_bias=rb, row_bias_div=max(div, 1), K0=K0)
+        ys, saved, btgts = [], [x2], []
+        for n, (y, hidden, am) in enumerate(res):
+            W, b = per_net[n][1], per_net[n][2]
             ys.append(y.view(x.shape[:-1] + (y.shape[-1],)))
             if train:
                 saved += hidden + W + [am]
@@ -993,69 +1103,82 @@ class MultiMLP(Function):
         kmax = max(K0 for _, K0, _ in net_cfg)
         if need_x and kmax < ld and not lazy_pad:
             gx[:, kmax:].zero_()
-        # the widest net first: its chain assigns every column any net writes, the others accumulate
-        order = sorted(range(len(net_cfg)), key=lambda i: -net_cfg[i][1])
-        if need_x:
-            # ... unless the widest net(s) received no gradient: the first chain that runs assigns only its own K0 columns, and
-            # the columns between them and the widest net's K0 would stay uninitialised
-            live = [net_cfg[i][1] for i in order if gys[i] is not None]
-            if live and live[0] < kmax:
-                gx[:, live[0]:kmax].zero_()
         spos, ppos, sp, pp = [], [], 1, 4
         for L, K0, div in net_cfg:
             spos.append(sp)
             ppos.append(pp)
             sp += 2 * L
             pp += 2 * L + (1 if div > 0 else 0)
+        Wn = [list(saved[spos[n] + net_cfg[n][0] - 1:spos[n] + 2 * net_cfg[n][0] - 1]) for n in range(len(net_cfg))]
+        # the widest net first: its chain assigns every column any net writes, the others accumulate.  After it, the nets of
+        # its hidden-width class, then the other class: consecutive launches of a class share a launch (chain_group)
+        widest = min(range(len(net_cfg)), key=lambda i: (-net_cfg[i][1], i))
+        order = sorted(range(len(net_cfg)),
+                       key=lambda i: (i != widest, _width_class(Wn[i]) != _width_class(Wn[widest]), -net_cfg[i][1], i))
+        if need_x:
+            # ... unless the widest net(s) received no gradient: the first chain that runs assigns only its own K0 columns, and
+            # the columns between them and the widest net's K0 would stay uninitialised
+            live = [net_cfg[i][1] for i in order if gys[i] is not None]
+            if live and live[0] < kmax:
+                gx[:, live[0]:kmax].zero_()
         out = [None] * (pp - 4)
         first = True
-        for n in order:
+        state = []
+        # phase 1: the data-path chains (recorded, launched together at the end of the block)
+        with chain_group():
+            for n in order:
+                L, K0, div = net_cfg[n]
+                gy = gys[n]
+                if gy is None:
+                    continue
+                pos, poff = spos[n], ppos[n]
+                A = [x2[:, :K0]] + list(saved[pos:pos + L - 1])
+                W = Wn[n]
+                am = saved[pos + 2 * L - 1]
+                wo = poff + (1 if div > 0 else 0)
+                nW = ctx.needs_input_grad[wo:wo + L]
+                nb = ctx.needs_input_grad[wo + L:wo + 2 * L]
+                gy2 = gy.reshape(P, -1).contiguous()
+                steps = L if need_x else L - 1
+                deltas, bgrads = [None] * L, [None] * L
+                deltas[L - 1] = gy2
+                gb_last = None
+                # accumulate-in-place gradient buffers (set_grad_buffer): all of the net's biases or none (one flag per chain)
+                btgt = [t if nb[j] else None for j, t in enumerate(ctx.btgts[n])]
+                if any(nb[j] and btgt[j] is None for j in range(L)):
+                    btgt = [None] * L
+                bg_acc = 2 if any(t is not None for t in btgt) else 0
+                dm = amax_slots(dev, L) if steps > 0 else None
+                if steps > 0:
+                    Wp, Ks, Ns, side_in, side_out, ld_side, bg, side_am = [], [], [], [], [], [], [], []
+                    for i in range(steps):
+                        j = L - 1 - i
+                        Wp.append(_packed(W[j], True))
+                        Ks.append(W[j].shape[1])
+                        Ns.append(W[j].shape[0])
+                        if i < L - 1:
+                            width = W[j - 1].shape[1]
+                            deltas[j - 1] = torch.empty((P, width), device=dev, dtype=torch.float32)
+                            bgrads[j - 1] = btgt[j - 1] if btgt[j - 1] is not None else torch.empty((width,), device=dev, dtype=torch.float32)
+                            side_in.append(A[j]); side_out.append(deltas[j - 1]); ld_side.append(A[j].shape[1]); bg.append(bgrads[j - 1])
+                            side_am.append(_slot(dm, j - 1))
+                        else:
+                            side_in.append(None); side_out.append(None); ld_side.append(0); bg.append(None); side_am.append(None)
+                    if any(nW) and nb[L - 1]:
+                        gb_last = btgt[L - 1] if btgt[L - 1] is not None else torch.empty((gy2.shape[1],), device=dev, dtype=torch.float32)
+                    flops = 2.0 * P * sum(k * m for k, m in zip(Ks, Ns))
+                    _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
+                            side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
+                            (0 if first else 1) | bg_acc, 1 if need_x else 0, float(beta), -1, 1.0, 0, None, K0, gb_last,
+                            chain_workspace(dev, bg + [gb_last]), side_am, _slot(dm, L - 1), shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)) + ("" if first else " (+=)"))
+                    first = False
+                state.append((n, A, W, am, dm, deltas, bgrads, btgt, gb_last, gy2, nW, nb))
+        # phase 2: what reads the chains' outputs -- row-term gradients, weight gradients, bias gradients
+        for n, A, W, am, dm, deltas, bgrads, btgt, gb_last, gy2, nW, nb in state:
             L, K0, div = net_cfg[n]
-            gy = gys[n]
-            if gy is None:
-                continue
-            pos, poff = spos[n], ppos[n]
-            A = [x2[:, :K0]] + list(saved[pos:pos + L - 1])
-            W = list(saved[pos + L - 1:pos + 2 * L - 1])
-            am = saved[pos + 2 * L - 1]
-            need_rb = div > 0 and ctx.needs_input_grad[poff]
+            poff = ppos[n]
             wo = poff + (1 if div > 0 else 0)
-            nW = ctx.needs_input_grad[wo:wo + L]
-            nb = ctx.needs_input_grad[wo + L:wo + 2 * L]
-            gy2 = gy.reshape(P, -1).contiguous()
-            steps = L if need_x else L - 1
-            deltas, bgrads = [None] * L, [None] * L
-            deltas[L - 1] = gy2
-            gb_last = None
-            # accumulate-in-place gradient buffers (set_grad_buffer): all of the net's biases or none (one flag per chain)
-            btgt = [t if nb[j] else None for j, t in enumerate(ctx.btgts[n])]
-            if any(nb[j] and btgt[j] is None for j in range(L)):
-                btgt = [None] * L
-            bg_acc = 2 if any(t is not None for t in btgt) else 0
-            dm = amax_slots(dev, L) if steps > 0 else None
-            if steps > 0:
-                Wp, Ks, Ns, side_in, side_out, ld_side, bg, side_am = [], [], [], [], [], [], [], []
-                for i in range(steps):
-                    j = L - 1 - i
-                    Wp.append(_packed(W[j], True))
-                    Ks.append(W[j].shape[1])
-                    Ns.append(W[j].shape[0])
-                    if i < L - 1:
-                        width = W[j - 1].shape[1]
-                        deltas[j - 1] = torch.empty((P, width), device=dev, dtype=torch.float32)
-                        bgrads[j - 1] = btgt[j - 1] if btgt[j - 1] is not None else torch.empty((width,), device=dev, dtype=torch.float32)
-                        side_in.append(A[j]); side_out.append(deltas[j - 1]); ld_side.append(A[j].shape[1]); bg.append(bgrads[j - 1])
-                        side_am.append(_slot(dm, j - 1))
-                    else:
-                        side_in.append(None); side_out.append(None); ld_side.append(0); bg.append(None); side_am.append(None)
-                if any(nW) and nb[L - 1]:
-                    gb_last = btgt[L - 1] if btgt[L - 1] is not None else torch.empty((gy2.shape[1],), device=dev, dtype=torch.float32)
-                flops = 2.0 * P * sum(k * m for k, m in zip(Ks, Ns))
-                _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
-                        side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
-                        (0 if first else 1) | bg_acc, 1 if need_x else 0, float(beta), -1, 1.0, 0, None, K0, gb_last,
-                        chain_workspace(dev, bg + [gb_last]), side_am, _slot(dm, L - 1), shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)) + ("" if first else " (+=)"))
-                first = False
+            need_rb = div > 0 and ctx.needs_input_grad[poff]
             if need_rb:
                 d0 = deltas[0] if L > 1 else gy2
                 G = P // div

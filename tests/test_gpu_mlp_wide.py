@@ -252,3 +252,100 @@ def test_tile_loop_tangent_chain_1100_tiles(gpu, tile):
     names = [f"W{j}" for j in range(8)] + [f"b{j}" for j in range(8)]
     for nm, a, r in zip(names, grads, g64):
         assert _rel64(a, r) < 1e-3, (nm, _rel64(a, r))        # (fp32 vs fp64 through the beta = 100 second-order terms)
+
+
+def _material_like_nets(gpu, seed, ld):
+    """Five nets on one packed input (P, ld), shaped like the per-sample material nets of the default configuration: three
+    128-wide ones on 22 columns, a 256-wide one on 22 and a 256-wide one on 23 columns with a per-group row term."""
+    def net(K, Dh, L, No, s):
+        r = np.random.RandomState(seed + s)
+        dims = [K] + [Dh] * L + [No]
+        return ([torch.tensor(r.randn(dims[i], dims[i + 1]) * np.sqrt(2.0 / dims[i]), dtype=torch.float32, device=gpu).requires_grad_(True)
+                 for i in range(len(dims) - 1)],
+                [torch.tensor(r.randn(dims[i + 1]) * 0.1, dtype=torch.float32, device=gpu).requires_grad_(True) for i in range(len(dims) - 1)])
+    return [net(22, 128, 3, 2, 1), net(22, 256, 4, 3, 2), net(22, 128, 3, 2, 3), net(22, 128, 3, 6, 4), net(23, 256, 4, 3, 5)]
+
+
+def _run_multi(gpu, P, ld, div, grouped):
+    from ndjir_amd import mlp
+    nets = _material_like_nets(gpu, 40, ld)
+    rng = np.random.RandomState(9)
+    x = torch.tensor(rng.randn(P, ld), dtype=torch.float32, device=gpu, requires_grad=True)
+    rt = torch.tensor(rng.randn(P // div, 256) * 0.3, dtype=torch.float32, device=gpu, requires_grad=True)
+    call = [(W, b) for W, b in nets[:4]] + [(nets[4][0], [None] + nets[4][1][1:])]
+    old = mlp._NO_CHAIN_GROUP
+    mlp._NO_CHAIN_GROUP = not grouped
+    mlp.PROFILE = []
+    try:
+        ys = mlp.multi_mlp(x, call, widths=[22, 22, 22, 22, 23], row_terms=[None, None, None, None, (rt, div)])
+        gs = [torch.tensor(np.random.RandomState(70 + i).randn(*y.shape), dtype=torch.float32, device=gpu) for i, y in enumerate(ys)]
+        leaves = [x, rt] + [t for W, b in nets for t in W + b if t is not nets[4][1][0]]
+        grads = torch.autograd.grad(ys, leaves, gs)
+        torch.cuda.synchronize()
+        launches = [(e[0], e[7], e[4]) for e in mlp.PROFILE if e[0].startswith("chain")]
+    finally:
+        mlp._NO_CHAIN_GROUP = old
+        mlp.PROFILE = None
+    return [y.detach().cpu() for y in ys], [g.cpu() for g in grads], launches
+
+
+def test_chain_group_is_bitwise_the_separate_launches(gpu, tile):
+    """mlp.chain_group / ndjir_mlp_chain_group_begin..end: the five per-sample nets of one MultiMLP as two launches forward
+    (the three 128-wide nets; the two 256-wide ones) and two backward, a workgroup looping over its tile's nets -- outputs,
+    the shared input gradient (assigned by the first net of the first launch, accumulated by all the others), the row-term
+    gradient and every weight gradient equal the five separate launches bit for bit (bias gradients, summed by LDS atomics
+    in either form, to round-off), at 3 tiles per workgroup."""
+    tile(128)
+    P, ld, div = 128 * 1600, 24, 128
+    y1, g1, l1 = _run_multi(gpu, P, ld, div, grouped=False)
+    y2, g2, l2 = _run_multi(gpu, P, ld, div, grouped=True)
+    assert len([l for l in l1 if l[0] == "chain_fwd"]) == 5 and len([l for l in l1 if l[0] == "chain_bwd"]) == 5
+    assert len([l for l in l2 if l[0] == "chain_fwd"]) == 2 and len([l for l in l2 if l[0] == "chain_bwd"]) == 2, l2
+    assert all(l[1] == 1 for l in l2), l2            # (the library issued ONE kernel launch per group)
+    for a, b in zip(y1, y2):
+        assert torch.equal(a, b)
+    for a, b in zip(g1, g2):
+        if a.dim() == 1:         # bias gradients: LDS float atomics, whose order varies between any two launches
+            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+        else:
+            assert torch.equal(a, b)
+
+
+def test_chain_group_bracket_falls_back_and_reports(gpu, tile):
+    """The C bracket itself: calls the wide kernel cannot take together (different numbers of points; a 64-point-tile launch)
+    are launched one by one in call order, `launches` says how many kernels ran; a second _begin, an _end without a group
+    and a 17th recorded call are argument errors."""
+    import ctypes
+    from ndjir_amd import lib, mlp
+    so = lib.load()
+    so.ndjir_mlp_chain_group_end.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n = ctypes.c_int(-1)
+    assert so.ndjir_mlp_chain_group_end(stream, ctypes.byref(n)) != 0            # no group open
+    dims = (40, 128, 128, 3)
+    Ws, bs = make(dims, 3, -1)
+    Ws, bs = [w.to(gpu) for w in Ws], [b.to(gpu) for b in bs]
+    xa = torch.randn(128 * 300, 40, device=gpu)
+    xb = torch.randn(128 * 301, 40, device=gpu)
+    ref = [mlp.chain_forward(x, Ws, bs)[0] for x in (xa, xa, xb)]
+    assert so.ndjir_mlp_chain_group_begin() == 0
+    assert so.ndjir_mlp_chain_group_begin() != 0                                    # already open
+    got = [mlp.chain_forward(x, Ws, bs)[0] for x in (xa, xa, xb)]                 # recorded
+    assert so.ndjir_mlp_chain_group_end(stream, ctypes.byref(n)) == 0
+    assert n.value == 2                  # (xa, xa) share a launch; xb has another number of points
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    tile(64)                             # forced 64-point tiles: nothing is grouped
+    assert so.ndjir_mlp_chain_group_begin() == 0
+    got = [mlp.chain_forward(x, Ws, bs)[0] for x in (xa, xa)]
+    assert so.ndjir_mlp_chain_group_end(stream, ctypes.byref(n)) == 0 and n.value == 2
+    for a, b in zip(ref[:2], got):
+        assert torch.equal(a, b)
+    tile(128)
+    assert so.ndjir_mlp_chain_group_begin() == 0
+    with pytest.raises(lib.NdjirHipError):
+        for _ in range(17):
+            mlp.chain_forward(xa, Ws, bs)
+    assert so.ndjir_mlp_chain_group_end(stream, ctypes.byref(n)) != 0               # the error is reported again at the end
+    torch.cuda.synchronize()
