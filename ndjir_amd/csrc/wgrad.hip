@@ -871,7 +871,12 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
 //     flight, double-buffered planes, split interleaved with the MFMAs by the compiler: 55.1 us;
 //   * 8-wave workgroup with specialised waves (4 multiply, 4 load two chunks ahead and split), one barrier per chunk: 73.8 us;
 //   * this tile template at 256 x 128 with eight waves, one workgroup per CU: 48.6 us alone, but +0.5 ms per step (its ragged
-//     leftovers need a second launch of this kernel).
+//     leftovers need a second launch of this kernel);
+//   * the two tiles that share an A operand as the two halves of ONE 512-thread workgroup (same code, barriers shared, so the
+//     second read of A hits L1): 101 us on a box where this kernel takes 60 -- the two independent workgroups of a CU hide
+//     each other's load and split phases, two halves in lockstep do not.
+// Also measured: segments laid out source by source (a source's strips next to its tiles, same XCD, so that their second read of
+// the other operand finds it in L2) instead of kind by kind: 8.25 vs 8.26 ms per step -- no difference.
 // PMC on the grouped kernel (profiles/r04_pmc_wgrad_group.txt): FETCH_SIZE = the algorithmic operand bytes, half of the L2
 // requests hit (the tile pair of a split), the matrix pipe busy 21 %, 63 % of the wave cycles waiting: ~10 bytes / clk / CU
 // of loads whatever the structure -- the rate MI355X_MICROARCH.md gives for HBM-bound global_load_dwordx4.
