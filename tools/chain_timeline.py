@@ -88,6 +88,30 @@ def main():
                 ids.setdefault(int(hw[b]) & 0xfffffff0, []).append(b)     # drop the wave-slot bits
             cnt = np.array([len(v) for v in ids.values()])
             print(f"  distinct (se, sh, cu, simd...) ids {len(ids)}; workgroups per id min/max {cnt.min()}/{cnt.max()}")
+    elif mode == "sub":          # sub-phase stamps of layer 2 (a build with -DNDJIR_X_SUBSTAMP): slot 5 = before / after each row block
+        dims2 = (259, 256, 256, 256, 3)
+        W2, b2 = make(dims2, 2)
+        xg = torch.randn(P, dims2[0], device="cuda")
+        which = os.environ.get("SUB_MODE", "fwd")
+        Wg = [w.clone().requires_grad_(which == "bwd") for w in W2]
+        bg = [b.clone().requires_grad_(which == "bwd") for b in b2]
+        if which == "fwd":
+            chain_forward(xg, W2, b2, keep_hidden=True)
+            torch.cuda.synchronize()
+            so.ndjir_mlp_debug_timeline(buf.data_ptr())
+            chain_forward(xg, W2, b2, keep_hidden=True)
+        else:
+            y = fused_mlp(xg, Wg, bg)
+            gy = torch.randn_like(y)
+            torch.cuda.synchronize()
+            so.ndjir_mlp_debug_timeline(buf.data_ptr())
+            torch.autograd.grad(y, Wg + bg, gy)
+        torch.cuda.synchronize()
+        so.ndjir_mlp_debug_timeline(None)
+        t = buf[:400].cpu().numpy().reshape(10, 5, 8).astype(np.int64)
+        print(which, "layer 2: k-loop end -> [before block 0, after 0, after 1, after 2, after 3] -> phase A end; per wave, relative to the layer's start")
+        for w in range(8):
+            print(f"  wave {w}: kloop {t[2, 1, w] - t[2, 0].min():6d} | " + " ".join(f"{t[5, i, w] - t[2, 0].min():6d}" for i in range(5)) + f" | A end {t[2, 2, w] - t[2, 0].min():6d}  barrier {t[2, 3, w] - t[2, 0].min():6d}  end {t[2, 4, w] - t[2, 0].min():6d}")
     else:
         dims2 = (259, 256, 256, 256, 3) if mode == "bwd" else (39, 128, 128, 128, 1)
         W2, b2 = make(dims2, 2)
