@@ -82,7 +82,11 @@ __device__ __forceinline__ void pack3_block(const float* __restrict__ W, int ldw
   }
   float sc, inv;
   scale_from_max(red[0], sc, inv);
-  if (threadIdx.x == 0) inv_out[nb] = inv;
+  if (threadIdx.x == 0) {
+    inv_out[nb] = inv;
+    // (the scale array is padded to a multiple of 4 floats: a packed buffer is a deterministic function of its matrix)
+    if (nb == (Np >> 5) - 1) for (int i = nb + 1; i < (((Np >> 5) + 3) & ~3); ++i) inv_out[i] = 0.f;
+  }
   for (int t = threadIdx.x; t < total; t += PACK_T) {
     int k, c;
     if (!transpose) { c = t & 31; k = t >> 5; } else { k = t % Kp; c = t / Kp; }

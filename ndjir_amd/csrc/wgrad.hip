@@ -863,8 +863,10 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
 // geometric net's dW_j = A_j^T delta_j + gbar_j^T s_j), each with its own operand scales: every work item writes a
 // de-scaled partial slab, the reduction sums the slabs of all sources of an output.
 // A source's K x N output is cut into regions, each tiled by one kind of work item (k_wgrad_group, two workgroups per CU):
-//   kind 0      128 x 128 tile (ragged edges masked), kind 1 = 32 x 128 strip (ragged K), kind 2 = 128 x 32 strip (ragged N),
-//   kind 3      streaming reduction for outputs <= 8 wide.
+//   kind 0      128 x 128 tile (ragged edges masked), kind 1 = 32 x 128 strip (ragged K <= 32 rows), kind 2 = 128 x 32 strip
+//   (ragged N), kind 4 = 64 x 128 item (ragged K of 33 .. 64 rows: the 39- / 43- / 52-wide first layers; -0.08 ms per step
+//   against two rows of strips -- while 32 x 256 / 256 x 32 strips, half as many items for the same bytes, measured +0.06 ms:
+//   their planes and registers are paid by every item of the launch), kind 3 = streaming reduction for outputs <= 8 wide.
 // Three other tile designs were written, tested bit-for-bit against these and measured in round 4 on 8 x (256 x 256 x 65 536)
 // (tools/wgrad_group_time.py; this kernel: 50.8 us per layer) -- none is in the tree:
 //   * one 4-wave workgroup per CU with 512 registers per lane, 128 x 256 tile, 16-byte loads, two chunks of operands in
@@ -987,6 +989,10 @@ __device__ __forceinline__ void wgrad_narrow_rows(const float* __restrict__ A, i
   }
 }
 
+// rows x columns of dW one item of a kind covers
+__host__ __device__ static inline int wgg_tile_k(int kind) { return kind == 1 ? WG_STRIP : kind == 4 ? 2 * WG_STRIP : WG_T; }
+__host__ __device__ static inline int wgg_tile_n(int kind) { return kind == 2 ? WG_STRIP : WG_T; }
+
 // workgroup -> (segment, split, tile): whole splits per XCD (workgroups are dealt round-robin to the 8 XCDs; first % 8 == 0,
 // count % 8 == 0), so that the tiles that share a range of points share an L2.  Returns false for an idle workgroup.
 __device__ __forceinline__ bool wgg_locate(const WggTable& a, int& si, int& split, int& tile) {
@@ -1061,12 +1067,12 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* _
     return;
   }
   const int ti = tile / g.tiles_n, tj = tile - ti * g.tiles_n;
-  const int k0 = g.k_off + ti * (kind == 1 ? WG_STRIP : WG_T), n0 = g.n_off + tj * (kind == 2 ? WG_STRIP : WG_T);
+  const int k0 = g.k_off + ti * wgg_tile_k(kind), n0 = g.n_off + tj * wgg_tile_n(kind);
   unsigned ma, mb;
   if (s.amax_a) ma = *s.amax_a;
-  else { const int k1 = k0 + (kind == 1 ? WG_STRIP : WG_T); ma = wgg_tile_absmax(s.A, s.lda, k0, k1 < g.k_end ? k1 : g.k_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds)); }
+  else { const int k1 = k0 + wgg_tile_k(kind); ma = wgg_tile_absmax(s.A, s.lda, k0, k1 < g.k_end ? k1 : g.k_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds)); }
   if (s.amax_b) mb = *s.amax_b;
-  else { const int n1 = n0 + (kind == 2 ? WG_STRIP : WG_T); mb = wgg_tile_absmax(s.B, s.ldb, n0, n1 < g.n_end ? n1 : g.n_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds)); }
+  else { const int n1 = n0 + wgg_tile_n(kind); mb = wgg_tile_absmax(s.B, s.ldb, n0, n1 < g.n_end ? n1 : g.n_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds)); }
   float sa, ia, sb, ib;
   wg_scale_from_max(ma, sa, ia);
   wg_scale_from_max(mb, sb, ib);
@@ -1074,6 +1080,8 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* _
     wgrad3_tile<2, 2, 2, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
   else if (kind == 1)
     wgrad3_tile<1, 4, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
+  else if (kind == 4)
+    wgrad3_tile<2, 2, 1, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
   else
     wgrad3_tile<4, 1, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
 }
@@ -1155,14 +1163,19 @@ static int wgg_regions(int K, int N, WggRegion* rg) {
   const int Nm = (rn != 0 && rn <= 2 * WG_STRIP) ? N - rn : N;
   if (Km > 0 && Nm > 0) rg[n++] = {0, 0, 0, Km, Nm, (Km + WG_T - 1) / WG_T, (Nm + WG_T - 1) / WG_T};
   if (Km > 0 && N > Nm) rg[n++] = {2, 0, Nm, Km, N, (Km + WG_T - 1) / WG_T, (N - Nm + WG_STRIP - 1) / WG_STRIP};
-  if (K > Km) rg[n++] = {1, Km, 0, K, N, (K - Km + WG_STRIP - 1) / WG_STRIP, (N + WG_T - 1) / WG_T};
+  if (K > Km) {
+    // rows [Km, K): up to 32 of them as one row of 32 x 128 strips, 33..64 as one row of 64 x 128 items (kind 4) -- two rows of
+    // strips would read B twice, and a strip's chunk loop costs what a tile's does (round 4: all strips of a step 0.25 ms)
+    if (K - Km > WG_STRIP) rg[n++] = {4, Km, 0, K, N, 1, (N + WG_T - 1) / WG_T};
+    else rg[n++] = {1, Km, 0, K, N, 1, (N + WG_T - 1) / WG_T};
+  }
   return n;
 }
 static double wgg_units(int K, int N) {        // work of one split in 128 x 128-tile equivalents
   WggRegion rg[4];
   const int n = wgg_regions(K, N, rg);
   double u = 0.0;
-  for (int i = 0; i < n; ++i) u += ((rg[i].kind == 1 || rg[i].kind == 2) ? 0.25 : 1.0) * rg[i].tiles_k * rg[i].tiles_n;
+  for (int i = 0; i < n; ++i) u += ((rg[i].kind == 1 || rg[i].kind == 2) ? 0.25 : rg[i].kind == 4 ? 0.5 : 1.0) * rg[i].tiles_k * rg[i].tiles_n;
   return u;
 }
 
@@ -1297,8 +1310,8 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
     // segments: the narrow items first (short, but each a serial chain: they finish under the tiles), then the 128 x 128
     // tiles of every source, then the strips (a quarter of a tile's work each: they fill the tail)
     int blocks = 0, nseg = 0;
-    static const int order[4] = {3, 0, 1, 2};
-    for (int q = 0; q < 4; ++q)
+    static const int order[5] = {3, 0, 4, 1, 2};
+    for (int q = 0; q < 5; ++q)
       for (int i = 0; i < ns; ++i) {
         const int kind = order[q];
         const WggSrc& s = tab.src[i];

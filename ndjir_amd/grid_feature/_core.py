@@ -18,6 +18,8 @@ Gradients w.r.t. a grid can be accumulated IN PLACE into a caller-owned buffer
 (`set_grad_buffer`), the torch analogue of nnabla's `accum` protocol -- a 512^3 x 4 grid is 2 GiB
 and must not be materialised once per backward call.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -54,12 +56,24 @@ def grad(outputs, inputs, grad_outputs=None):
 
 def set_grad_buffer(feature, buf):
     """Register `buf` (same shape as `feature`, fp32, GPU) as the accumulate-in-place gradient
-    buffer of `feature`.  Ops then scatter-add into `buf` and return no dense gradient."""
-    if buf is None:
-        _GRAD_BUFFERS.pop(feature.data_ptr(), None)
-    else:
+    buffer of `feature`.  Ops then scatter-add into `buf` and return no dense gradient.
+    The registry is keyed by the feature's address (the operators see detached views of the parameter, not the object):
+    a registration therefore ends with the registered tensor -- when `feature` is collected its entry goes with it, so that
+    a later tensor the allocator places at the same address never inherits a dead step's buffer (and with it a gradient of
+    None).  `parameter.clear_parameters` drops every registration."""
+    ptr = feature.data_ptr()
+    old = _GRAD_BUFFERS.pop(ptr, None)
+    if old is not None:
+        old[1].detach()                      # (its finalizer must not remove the entry that replaces it)
+    if buf is not None:
         assert buf.shape == feature.shape and buf.is_contiguous()
-        _GRAD_BUFFERS[feature.data_ptr()] = buf
+        _GRAD_BUFFERS[ptr] = (buf, weakref.finalize(feature, _GRAD_BUFFERS.pop, ptr, None))
+
+
+def clear_grad_buffers():
+    for _, fin in _GRAD_BUFFERS.values():
+        fin.detach()
+    _GRAD_BUFFERS.clear()
 
 
 def zero_touched(buf, query, min_=(-1, -1, -1), max_=(1, 1, 1), interp="linear"):
@@ -76,7 +90,8 @@ def zero_touched(buf, query, min_=(-1, -1, -1), max_=(1, 1, 1), interp="linear")
 
 
 def get_grad_buffer(feature):
-    return _GRAD_BUFFERS.get(feature.data_ptr())
+    e = _GRAD_BUFFERS.get(feature.data_ptr())
+    return e[0] if e is not None else None
 
 
 class Family:

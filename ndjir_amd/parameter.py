@@ -87,6 +87,9 @@ def clear_parameters():
     if m is not None:
         m.clear_grad_buffers()                       # ... and so do the accumulate-in-place gradient buffers
         m._ROWS_CACHE.clear()                        # ... and the row-block copies of first-layer weights
+    g = sys.modules.get("ndjir_amd.grid_feature._core")
+    if g is not None:
+        g.clear_grad_buffers()                       # ... and the grid operators' accumulate-in-place buffers (keyed by address)
 
 
 def save_parameters(path):
