@@ -21,3 +21,12 @@ def gpu():
     from ndjir_amd import lib
     lib.load()
     return torch.device("cuda:0")
+
+
+def pytest_collection_modifyitems(config, items):
+    """NDJIR_TEST_SHUFFLE=<seed>: run the collected tests in a seeded random order (finds state that leaks from one test
+    into another: the process-global registries of accumulate-in-place gradient buffers, packed-weight caches, tile settings)."""
+    seed = os.environ.get("NDJIR_TEST_SHUFFLE")
+    if seed:
+        import random
+        random.Random(int(seed)).shuffle(items)
