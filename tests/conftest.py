@@ -30,3 +30,18 @@ def pytest_collection_modifyitems(config, items):
     if seed:
         import random
         random.Random(int(seed)).shuffle(items)
+
+
+@pytest.fixture(autouse=True)
+def _poison_free_memory(request):
+    """NDJIR_TEST_POISON=<GiB>: before every GPU test, fill that much of the allocator's free memory with NaN and hand it
+    back -- the test's `torch.empty` buffers then start as NaN, so a kernel that reads memory nobody wrote shows up as a
+    parity failure instead of passing on zeros."""
+    gib = os.environ.get("NDJIR_TEST_POISON")
+    if gib and request.node.get_closest_marker("gpu") is not None:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+            chunks = [torch.full((1 << 28,), float("nan"), device="cuda") for _ in range(int(gib))]      # 1 GiB each
+            del chunks
+    yield
