@@ -10,6 +10,8 @@ every parameter is replicated, so one exchange per step sums the per-rank gradie
     rows into its dense buffer.  Result: every rank holds the same dense gradient as a single
     process would (up to fp32 summation order).
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -134,7 +136,12 @@ def _state(buf, capacity, world, group=None):
               ids_all=torch.zeros((world, capacity), dtype=torch.int32, device=dev),
               rows_all=torch.empty((world, capacity, D), dtype=torch.float32, device=dev),
               counts_all=torch.zeros(world, dtype=torch.int32, device=dev))
-    _STATE[buf.data_ptr()] = st
+    key = buf.data_ptr()
+    _STATE[key] = st
+    # the state is keyed by the buffer's address: it ends with the buffer, so that a later buffer placed at the same address
+    # starts from its own capacity and statistics (every rank frees its step's buffers at the same point of the program, so
+    # the states -- whose creation holds a collective -- stay in step)
+    weakref.finalize(buf, lambda k=key, s=st: _STATE.pop(k, None) if _STATE.get(k) is s else None)
     return st
 
 
