@@ -16,6 +16,7 @@ import weakref
 
 import torch
 from torch.autograd import Function
+from torch.multiprocessing.reductions import StorageWeakRef as _StorageRef
 
 from . import lib
 
@@ -331,8 +332,12 @@ def _packed(W, transpose):
         W = W.contiguous()
     key = (W.data_ptr(), W._version, tuple(W.shape), bool(transpose), get_math())
     hit = _PACK_CACHE.get(key)
-    owner = W._base if W._base is not None else W      # (a view of a long-lived tensor -- rows_except's cached copy -- counts as it)
-    if hit is not None and hit[0]() is owner:           # same live storage owner, same version
+    # valid while the STORAGE the entry was packed from is alive (same address + same version of a dead storage's successor
+    # is not the same matrix).  Not the tensor object: the operators see detached views and saved-tensor copies of a
+    # parameter, fresh objects on every call -- keyed by them, the row-block weights of the per-ray layers were re-packed
+    # every step (4 launches)
+    owner = _StorageRef(W.untyped_storage())
+    if hit is not None and hit[0].cdata == owner.cdata and not hit[0].expired():
         return hit[1]
     K, N = W.shape
     n = lib.load().ndjir_mlp_packed_size(K, N, int(transpose))
@@ -340,7 +345,7 @@ def _packed(W, transpose):
     lib.call("mlp_pack", W.detach().contiguous(), dst, K, N, int(transpose))
     if len(_PACK_CACHE) > 512:
         _PACK_CACHE.clear()
-    _PACK_CACHE[key] = (weakref.ref(owner), dst)
+    _PACK_CACHE[key] = (owner, dst)
     return dst
 
 
