@@ -1329,6 +1329,7 @@ class RowsExcept(Function):
         if ent[0] != W._version:          # refreshed in place: the copy keeps its address (packed-weight store, captured graphs)
             _refresh_rows(ent, W, a, b)
         ctx.ab = (a, b, tuple(W.shape))
+        ctx.set_materialize_grads(False)      # (no gradient = None, not a zero matrix to be filled and added: see backward)
         ctx.tgt = grad_target(W)
         if ctx.tgt is not None and not isinstance(ctx.tgt, SplitTarget):
             # the operators that consume the copy add their weight gradient straight into the parameter's two row blocks
@@ -1339,6 +1340,8 @@ class RowsExcept(Function):
     @staticmethod
     def backward(ctx, g):
         a, b, shape = ctx.ab
+        if g is None:            # every consumer added its weight gradient straight into the parameter's row blocks
+            return None, None, None
         if ctx.tgt is not None and not torch.is_grad_enabled():
             ctx.tgt[:a].add_(g[:a])
             ctx.tgt[b:].add_(g[a:])

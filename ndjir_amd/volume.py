@@ -33,6 +33,7 @@ class AlphaWeights(Function):
         lib.call("render_alpha_weights", B * R, N, Nb, *args, alpha_fg, trans, weights)
         ctx.save_for_backward(*args, trans)
         ctx.dims = (B, R, N, Nb)
+        ctx.set_materialize_grads(False)      # (an unused output's gradient arrives as None -- the kernel takes null --, not as zeros)
         return alpha_fg, trans, weights
 
     @staticmethod
@@ -252,6 +253,7 @@ class MaterialHead(Function):
         ctx.save_for_backward(*args)
         ctx.cfg = (B, R, N, cfg)
         ctx.mark_non_differentiable(aux)
+        ctx.set_materialize_grads(False)      # (no zero tensor for aux's "gradient")
         return V, aux, prior
 
     @staticmethod
