@@ -147,7 +147,7 @@ class GeometricMain(Function):
                 side_out.append(None)
                 side_am.append(None)
                 ld.append(0)
-        g0 = torch.zeros((P, K0), device=dev, dtype=torch.float32)
+        g0 = (torch.empty if bskip >= 0 else torch.zeros)((P, K0), device=dev, dtype=torch.float32)     # (skip layer: assigned, see mlp.FusedMLP.backward)
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain", 1, P, ones, 1, 1, L, Wp, [None] * L, bK, bN, side_in,
                 side_out, ld, [None] * L, g0, K0, 1 if bskip >= 0 else 0, 1, beta, bskip, scale, split,
                 g0 if bskip >= 0 else None, K0, None, None, side_am, None, shape=f"{P}:sdf 1-" + "-".join(map(str, bN)))
@@ -289,7 +289,7 @@ class GeometricMain(Function):
             else:
                 side_in.append(None); side_out.append(None); side_add.append(None); ld.append(0); bg.append(None)
                 side_am.append(None)
-        gx = torch.zeros((P, K0), device=dev, dtype=torch.float32) if need_x else None
+        gx = (torch.empty if bskip >= 0 else torch.zeros)((P, K0), device=dev, dtype=torch.float32) if need_x else None
         gb_last = btgt[L - 1] if btgt[L - 1] is not None else torch.empty((Ns[-1],), device=dev, dtype=torch.float32)     # bias gradient of the output layer
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain_ex", 1, P, gy, Ns[-1], Ns[-1], steps, Wp, [None] * steps, bK, bN,
                 side_in, side_out, ld, bg, gx, K0, (1 if (bskip >= 0 and need_x) else 0) | bg_acc, 1 if need_x else 0, beta,

@@ -971,7 +971,9 @@ class FusedMLP(Function):
             ldg = K0
             if need_x:
                 if bwd_skip >= 0:
-                    gx = torch.zeros((P, K0), device=x2.device, dtype=torch.float32)
+                    # (no zero fill: the skip layer ASSIGNS its input-part columns to this buffer -- every column, every row --
+                    # before the output layer adds to them; the NaN-poisoned test run checks that nothing is left unwritten)
+                    gx = torch.empty((P, K0), device=x2.device, dtype=torch.float32)
                 else:
                     # rows padded to 16 bytes: the output layer then stores float4 (K0 = 259, 262, 301 ...)
                     ldg = (K0 + 3) // 4 * 4

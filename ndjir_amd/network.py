@@ -520,7 +520,9 @@ def soft_visibility_light_network(x, light_dirs, feature, normal, conf, raw=Fals
             nx, npe = x.shape[-1], pe.shape[-1]
             Ws, bs = _mlp_params(nx + npe + sum(t.shape[-1] for t in per_ray[1:]), c.feature_size, c.layers, c.channels,
                                  conf.use_wn)
-            ray_in = torch.cat([t[:, :, 0, :] for t in per_ray], dim=-1)
+            # (a (B, R, 1, C) tensor loses its unit axis by a view: `select`'s backward would fill a zero tensor and copy into it)
+            ray_in = torch.cat([t.reshape(t.shape[0], t.shape[1], t.shape[3]) if t.shape[2] == 1 else t[:, :, 0, :] for t in per_ray],
+                               dim=-1)
             from .mlp import fused_mlp, linear, rows_except
             W0_ray = rows_except(Ws[0], nx, nx + npe)
             row_term = linear(ray_in.reshape(B * R, -1), W0_ray, bs[0]).view(B, R, -1)
