@@ -628,14 +628,26 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
           auto run = [&](auto ft, auto et) {
             if (MODE != 0) side_loads(I0{}, ft, et);
             if (MODE != 0) side_loads(I1{}, ft, et);
+            // (diagnostic build -DNDJIR_CHAIN_SUBSTAMP, tools/chain_timeline.py sub: stamps of layer 2's row blocks in timeline slot 5)
+#ifdef NDJIR_CHAIN_SUBSTAMP
+#define NDJIR_SUB(P) if (li == 2) stamp(5, P)
+#else
+#define NDJIR_SUB(P)
+#endif
+            NDJIR_SUB(0);
             hidden_block(I0{}, ft, et);
+            NDJIR_SUB(1);
             if constexpr (RPW > 2) { if (MODE != 0) side_loads(I2{}, ft, et); }
             hidden_block(I1{}, ft, et);
+            NDJIR_SUB(2);
             if constexpr (RPW > 2) {
               if (MODE != 0) side_loads(I3{}, ft, et);
               hidden_block(I2{}, ft, et);
+              NDJIR_SUB(3);
               hidden_block(I3{}, ft, et);
+              NDJIR_SUB(4);
             }
+#undef NDJIR_SUB
             if (MODE == 1) {
               side_store(I0{}, ft);
               side_store(I1{}, ft);

@@ -88,7 +88,7 @@ def main():
                 ids.setdefault(int(hw[b]) & 0xfffffff0, []).append(b)     # drop the wave-slot bits
             cnt = np.array([len(v) for v in ids.values()])
             print(f"  distinct (se, sh, cu, simd...) ids {len(ids)}; workgroups per id min/max {cnt.min()}/{cnt.max()}")
-    elif mode == "sub":          # sub-phase stamps of layer 2 (a build with -DNDJIR_X_SUBSTAMP): slot 5 = before / after each row block
+    elif mode == "sub":          # sub-phase stamps of layer 2 (tools/build_variant.sh sub mlp3w.hip -DNDJIR_CHAIN_SUBSTAMP, NDJIR_HIP_LIB=...): slot 5 = before / after each row block
         dims2 = (259, 256, 256, 256, 3)
         W2, b2 = make(dims2, 2)
         xg = torch.randn(P, dims2[0], device="cuda")
