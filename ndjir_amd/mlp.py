@@ -140,13 +140,8 @@ def _defer_bias_reduction(name, args):
             _BIAS_LAYOUT.clear()
     if not lay or lay[0] <= 0 or lay[1] <= 0:
         return None
-    # one reduction launch sums all deferred rows, workgroups in no particular order: a destination may appear in it once.  A
-    # net that runs twice per step (the base colour net on the perturbed points, the geometric net's first-order pass) keeps
-    # its own reduction for the second run -- it accumulates right away, stream-ordered against the flush
-    targets = [t for _, t in live] + ([in_bg] if in_bg is not None else [])
-    taken = {e[0].data_ptr() for e in _DEFERRED_BIAS}
-    if any(t.data_ptr() in taken for t in targets):
-        return None
+    # (a destination may be deferred more than once per step -- a net that runs twice, the geometric net's first-order pass:
+    # the grouped launch puts outputs that touch the same memory into different generations, one reduction launch each)
     blocks, row = lay
     x = args[2]
     region = _bias_region((x if torch.is_tensor(x) else x.t).device, blocks * row)
