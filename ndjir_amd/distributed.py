@@ -93,6 +93,8 @@ class SparseRows:
 _STATE = {}
 _GRID_GROUP = {}
 CHECK_EVERY = 64          # exchanges between two (host-synchronising) looks at the row counts
+HEADROOM = 1.25           # wire rows per rank = the largest list seen x this (an overflow vetoes one update and grows the wire;
+                          # every rank receives world x this many rows per exchange: 1.5 was 33 MB per rank at 8 ranks, now 28 MB)
 
 
 def grid_group(group=None):
@@ -158,7 +160,7 @@ def exchange_grid_rows_hip(buf, family, queries, min_=(-1.0, -1.0, -1.0), max_=(
     ranks' rows are added in place.
 
     No host synchronisation per step: `limit` (rows per rank on the wire) is fixed -- measured on the first exchange
-    with 50 % head-room -- and a device flag (`st["overflow"]`, returned with the handle) is raised when some rank listed
+    with 25 % head-room (`HEADROOM`) -- and a device flag (`st["overflow"]`, returned with the handle) is raised when some rank listed
     more; the caller vetoes that optimizer step on the device (Step.optimizer_step, which counts the vetoes) and `limit`
     grows at the next look, every CHECK_EVERY exchanges, from the running maximum the device keeps over ALL exchanges
     (`st["stats"]`).  List capacity = the worst case (every stencil cell distinct): lists
@@ -197,7 +199,7 @@ def exchange_grid_rows_hip(buf, family, queries, min_=(-1.0, -1.0, -1.0), max_=(
         # (the same number on every rank: it comes from the gathered counts and is clipped by the list capacity, which
         # `_state` made the same on every rank -- ranks that disagreed here would disagree on the size of the collective)
         assert most <= cap, "more distinct cells than stencil taps"
-        want = min(cap, max(4096, -(-int(most * 1.5) // 4096) * 4096))
+        want = min(cap, max(4096, -(-int(most * HEADROOM) // 4096) * 4096))
         if st["limit"] is None or want > st["limit"]:
             st["limit"] = want
             st["limit_dev"].fill_(want)
