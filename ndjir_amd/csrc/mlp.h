@@ -100,7 +100,7 @@ int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream);
 // n <= MAX_GROUP_NETS nets of one mode on the same number of points; NDJIR_ERR_UNSUPPORTED = launch them one by one
 int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stream);
 constexpr int CHAIN_MAX_GRID_BG = 512;   // workgroups of a chain launch that produces bias gradients
-inline long long chain_workspace(int bg_total) { return (long long)CHAIN_MAX_GRID_BG * bg_total; }
+inline long long chain_workspace(int bg_total) { return (long long)CHAIN_MAX_GRID_BG * ((bg_total + 3) & ~3); }      // (rows padded to 16 bytes)
 long long wgrad_workspace(int K, int N, long long P);
 // math: 0 fp32 MFMA, 1 bf16x6, 2 f16x3 (amax_a / amax_b: recorded maxima of A / B, null = computed by a pre-pass)
 int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N, long long P, float* out, int accum,

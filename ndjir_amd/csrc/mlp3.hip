@@ -1007,6 +1007,7 @@ int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream) {
     ++bg_n;
     bg_total += a.K0;
   }
+  bg_total = (bg_total + 3) & ~3;       // (partial rows a multiple of 16 bytes long: the step's reduction reads them with 16-byte loads)
   b.bg_total = bg_total;
   b.bg_lds = (int)(lds_bytes / 4);
   lds_bytes += (size_t)bg_total * 4;

@@ -813,6 +813,7 @@ static int wide_plan(const ChainArgs& a, int mode, WidePlan& p) {
     ++p.bg_n;
     bg_total += a.K0;
   }
+  bg_total = (bg_total + 3) & ~3;       // (partial rows a multiple of 16 bytes long: the step's reduction reads them with 16-byte loads)
   p.b.bg_total = p.bg_total = bg_total;
   if (bg_total > 0 && !a.bg_partial) return NDJIR_ERR_ARG;
   return NDJIR_OK;

@@ -912,11 +912,13 @@ struct WggOut {
   int first;                 // first workgroup of this output in the reduction launch
   int pstride, pad;          // (a weight gradient: KN; deferred bias gradients of a chain launch: the launch's partial-row length)
 };
-// 16-byte accesses in the reduction: contiguous destination, every slab and the destination 16-byte aligned
+// 16-byte accesses in the reduction: contiguous destination, every slab 16-byte aligned.  The DESTINATION only needs its 4 bytes:
+// gradients live at arbitrary float offsets of the step's flat bucket (round 4: 37 147 of a step's 39 835 reduction workgroups
+// took the 4-byte path for that reason alone) and gfx950 moves a dwordx4 at any 4-byte alignment (tools/ubench/unaligned.hip).
 __host__ __device__ static inline bool wgg_out_vec(const WggOut& o) {
-  return (o.KN & 3) == 0 && o.ldo == o.N && (o.pstride & 3) == 0 && (reinterpret_cast<uintptr_t>(o.out) & 15) == 0 &&
-         (reinterpret_cast<uintptr_t>(o.partial) & 15) == 0;
+  return (o.KN & 3) == 0 && o.ldo == o.N && (o.pstride & 3) == 0 && (reinterpret_cast<uintptr_t>(o.partial) & 15) == 0;
 }
+typedef float wgg_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // The whole group's work description lives in DEVICE memory (the head of the caller's workspace): a training step's ~57
 // operand pairs / ~150 segments do not fit the 4 KB of kernel arguments, and cutting the group into several launches costs
@@ -1117,10 +1119,10 @@ __device__ __forceinline__ void wgg_reduce_block(const WggOut& o, int blk, float
 #pragma unroll
       for (int q = 0; q < 8; ++q) t[v] += red[v * 256 + q * 32 + tx];
     }
-    if (VEC == 4) {            // contiguous, 16-byte aligned output
-      float4* dst = reinterpret_cast<float4*>(o.out + i);
-      float4 r = make_float4(t[0], t[1 % VEC], t[2 % VEC], t[3 % VEC]);
-      if (o.accum) { const float4 c = *dst; r.x += c.x; r.y += c.y; r.z += c.z; r.w += c.w; }
+    if (VEC == 4) {            // contiguous output, 4-byte aligned
+      wgg_f32x4u* dst = reinterpret_cast<wgg_f32x4u*>(o.out + i);
+      wgg_f32x4u r = {t[0], t[1 % VEC], t[2 % VEC], t[3 % VEC]};
+      if (o.accum) { const wgg_f32x4u c = *dst; r += c; }
       *dst = r;
     } else {
       const long long row = i / o.N;
