@@ -522,7 +522,15 @@ int ndjir_mlp_pack_entry_bytes(void);
  * buffer several operators share (python/train.py:136-140 zeroes the gradients once per iteration, every backward adds);
  * bit 2 (NDJIR_MATH_F16X3) = DEFER the bias-gradient reduction: the launch leaves its per-workgroup partial rows in
  * `workspace` (layout: ndjir_mlp_chain_bias_partials) and writes no bgrad / in_bgrad -- the caller sums them later, for
- * all launches of a step at once (ndjir_mlp_wgrad_group's extra outputs). */
+ * all launches of a step at once (ndjir_mlp_wgrad_group's extra outputs);
+ * bit 3 (NDJIR_MATH_F16X3, P % 32 == 0; NDJIR_ERR_UNSUPPORTED otherwise) = POINT-BLOCKED HIDDEN TENSORS: side_in / side_in2 /
+ * side_add / side_out / side_out2 hold element (p, f) at float offset ((p >> 5) * ld_side + f) * 32 + (p & 31) -- blocks of 32
+ * points, feature-major inside a block, same P * ld_side floats as the row-major tensor.  These tensors never leave the
+ * engine (forward writes them, backward / tangent / the weight gradients read them; the reference keeps nnabla's
+ * intermediate Variables of python/network.py:154-232 the same way), so their layout is free: in this one a lane of the
+ * 128-point-tile kernel moves its MFMA accumulator registers as they are -- register i of 32 lanes = 32 consecutive points of
+ * one feature = one 128-byte line -- and ndjir_mlp_wgrad_group reads 4 consecutive points of a feature (an MFMA operand
+ * group of its reduction over the points) as one 16-byte load.  X, Y, Xskip, row_bias and the bias gradients stay row-major. */
 int ndjir_mlp_chain(int bwd, long long P, const float* X, int ldx, int K0, int L,
                     const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
                     const float* const* side_in, float* const* side_out, const int* ld_side,
@@ -555,7 +563,8 @@ int ndjir_mlp_chain_ex(int mode, long long P, const float* X, int ldx, int K0, i
  * of the soft-visibility net, python/network.py:339-377, whose other inputs vary per light direction): it is
  * computed once per group instead of once per row, and the broadcast inputs are never materialised.  Its gradient
  * is the group-wise column sum of the first layer's delta: */
-int ndjir_mlp_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, hipStream_t stream);
+int ndjir_mlp_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, int blocked, hipStream_t stream);
+/* blocked != 0: X is point-blocked (ndjir_mlp_chain accum_y bit 3; G * div % 32 == 0). */
 /* Weight gradient of one layer: out (K x N) (+)= A^T B with A (P x K, row stride lda) the layer's
  * input activations and B (P x N, row stride ldb) its deltas (ndjir_amd/csrc/wgrad.hip; the
  * reference gets this from nnabla's affine backward, a cuBLAS GEMM).  `workspace` needs
@@ -576,7 +585,7 @@ int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb, int K, int
  * take a streaming path that needs none.  `workspace`: ndjir_mlp_wgrad_group_workspace(...) floats for the same sources / outputs / target_items
  * (work items the launch aims for: the point axis of every source is split accordingly; 0 = default, 4 per CU). */
 long long ndjir_mlp_wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id,
-                                          int n_out, const int* K, const int* N, int target_items);
+                                          int n_out, const int* K, const int* N, int target_items, const int* layout);
 /* (diagnostics) launches of the grouped kernel -- and of its reduction -- that the call issues: one per 24 operand pairs */
 int ndjir_mlp_wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n_out);
 /* n_extra reduce-only outputs ride in the same reduction launch: ex_out[i] (ex_n[i] floats) (+)= the sum of ex_S[i] partial
@@ -587,7 +596,11 @@ int ndjir_mlp_wgrad_group(int n_src, const float* const* A, const int* lda, cons
                           const long long* P, const unsigned* const* amax_a, const unsigned* const* amax_b, const int* out_id,
                           int n_out, float* const* out, const int* ldo, const int* K, const int* N, const int* accum,
                           float* workspace, int target_items, int n_extra, float* const* ex_out, const float* const* ex_partial,
-                          const int* ex_n, const int* ex_S, const int* ex_stride, const int* ex_accum, hipStream_t stream);
+                          const int* ex_n, const int* ex_S, const int* ex_stride, const int* ex_accum, const int* layout,
+                          hipStream_t stream);
+/* layout (host array of n_src ints, or NULL = every operand row-major): bit 0 = A[i] is point-blocked (ndjir_mlp_chain accum_y
+ * bit 3; lda[i] = its ld_side), bit 1 = B[i] is; a blocked operand needs P[i] % 32 == 0.  The same array goes to
+ * ndjir_mlp_wgrad_group_workspace (it decides which outputs <= 8 wide take the streaming path). */
 /* Bias gradient of a layer: out (N) (+)= column sums of its deltas X (P x N, row stride ldx); the
  * reference gets it from nnabla's affine backward (a reduction kernel per layer). */
 long long ndjir_mlp_colsum_workspace(int N, long long P);   /* floats */

@@ -117,6 +117,8 @@ static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int
   a.x_amax = x_amax;
   a.P = P; a.X = X; a.ldx = ldx; a.K0 = K0; a.K0p = round_up(K0, 8); a.L = L;
   a.Y = Y; a.ldy = ldy; a.accum_y = accum_y & 1; a.bg_accum = (accum_y >> 1) & 1; a.defer_bg_reduce = (accum_y >> 2) & 1;
+  a.side_blocked = (accum_y >> 3) & 1;
+  if (a.side_blocked && (g_math != NDJIR_MATH_F16X3 || (P & 31) != 0)) return NDJIR_ERR_UNSUPPORTED;
   a.has_output = has_output; a.beta = beta;
   a.skip_layer = skip_layer; a.skip_scale = skip_scale; a.skip_split = skip_split; a.Xskip = Xskip; a.ld_xskip = ld_xskip;
   int kin = K0;
@@ -304,11 +306,13 @@ extern "C" int ndjir_mlp_wgrad(const float* A, int lda, const float* B, int ldb,
 }
 
 extern "C" long long ndjir_mlp_wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P,
-                                                     const int* out_id, int n_out, const int* K, const int* N, int target_items) {
-  if (n_src <= 0 || n_out <= 0 || !lda || !P || !out_id || !K || !N) return 0;
+                                                     const int* out_id, int n_out, const int* K, const int* N, int target_items,
+                                                     const int* layout) {
+  if (n_src <= 0) return wgrad_group_workspace(0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, target_items, nullptr);   // (reduce-only calls)
+  if (n_out <= 0 || !lda || !P || !out_id || !K || !N) return 0;
   for (int i = 0; i < n_src; ++i)
     if (out_id[i] < 0 || out_id[i] >= n_out) return 0;
-  return wgrad_group_workspace(n_src, A, lda, P, out_id, n_out, K, N, target_items);
+  return wgrad_group_workspace(n_src, A, lda, P, out_id, n_out, K, N, target_items, layout);
 }
 
 extern "C" int ndjir_mlp_wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n_out) {
@@ -321,7 +325,7 @@ extern "C" int ndjir_mlp_wgrad_group(int n_src, const float* const* A, const int
                                      const int* out_id, int n_out, float* const* out, const int* ldo, const int* K, const int* N,
                                      const int* accum, float* workspace, int target_items, int n_extra, float* const* ex_out,
                                      const float* const* ex_partial, const int* ex_n, const int* ex_S, const int* ex_stride,
-                                     const int* ex_accum, hipStream_t stream) {
+                                     const int* ex_accum, const int* layout, hipStream_t stream) {
   if ((n_src <= 0 || n_out <= 0) && n_extra <= 0) return NDJIR_OK;
   if (n_src > 0 && (!A || !lda || !B || !ldb || !P || !out_id || !out || !ldo || !K || !N)) return NDJIR_ERR_ARG;
   if (!workspace || (n_extra > 0 && (!ex_out || !ex_partial || !ex_n || !ex_S || !ex_stride))) return NDJIR_ERR_ARG;
@@ -330,8 +334,10 @@ extern "C" int ndjir_mlp_wgrad_group(int n_src, const float* const* A, const int
     if (K[o] <= 0 || N[o] <= 0) return NDJIR_ERR_ARG;
   for (int i = 0; i < n_extra; ++i)
     if (!ex_out[i] || !ex_partial[i] || ex_n[i] <= 0 || ex_S[i] < 0 || ex_stride[i] < ex_n[i]) return NDJIR_ERR_ARG;
+  for (int i = 0; layout && i < n_src; ++i)
+    if ((layout[i] & ~3) != 0 || (layout[i] != 0 && (P[i] & 31) != 0)) return NDJIR_ERR_ARG;
   return launch_wgrad_group(n_src > 0 ? n_src : 0, A, lda, B, ldb, P, amax_a, amax_b, out_id, n_src > 0 ? n_out : 0, out, ldo, K, N, accum,
-                            workspace, target_items, n_extra > 0 ? n_extra : 0, ex_out, ex_partial, ex_n, ex_S, ex_stride, ex_accum, stream);
+                            workspace, target_items, n_extra > 0 ? n_extra : 0, ex_out, ex_partial, ex_n, ex_S, ex_stride, ex_accum, layout, stream);
 }
 
 extern "C" long long ndjir_mlp_colsum_workspace(int N, long long P) { return colsum_workspace(N, P); }
@@ -344,10 +350,11 @@ extern "C" int ndjir_mlp_colsum(const float* X, int ldx, int N, long long P, flo
   return launch_colsum(X, ldx, N, P, out, accum, workspace, stream);
 }
 
-extern "C" int ndjir_mlp_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, hipStream_t stream) {
+extern "C" int ndjir_mlp_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, int blocked, hipStream_t stream) {
   if (G <= 0 || N <= 0) return NDJIR_OK;
   if (!X || !out || ldx < N || div < 1) return NDJIR_ERR_ARG;
-  return launch_group_colsum(X, ldx, N, G, div, out, stream);
+  if (blocked && ((G * div) & 31) != 0) return NDJIR_ERR_ARG;
+  return launch_group_colsum(X, ldx, N, G, div, out, blocked, stream);
 }
 
 // Diagnostics: when `buf` (device, MAX_CHAIN_LAYERS * 5 * 8 int64) is non-null, subsequent chain

@@ -58,6 +58,12 @@ struct ChainArgs {
   long long* timeline;  // diagnostics (tools/chain_timeline.py): per-layer phase stamps of workgroup 0, else null
   struct ChainDry* dry; // queries (ndjir_mlp_chain_kernel, ndjir_mlp_chain_bias_partials): non-null = report the kernel the
                         // launcher picks, its grid and its bias-gradient partial layout, and return WITHOUT launching
+  int side_blocked;     // f16x3 engine: the hidden side tensors (side_in, side_in2, side_add, side_out, side_out2) are POINT-BLOCKED:
+                        // element (p, f) of a tensor of row stride ld lives at ((p >> 5) * ld + f) * 32 + (p & 31) -- blocks of 32
+                        // points, feature-major inside a block.  A lane of the 128-point-tile kernel then moves its accumulator
+                        // registers as they are (register i of 32 lanes = 32 consecutive points of one feature = one 128-byte line;
+                        // no quad transposes), and the weight-gradient kernel reads 4 consecutive points of a feature as one
+                        // 16-byte load.  Needs P % 32 == 0.  X, Y, Xskip, row_bias stay row-major.
   int defer_bg_reduce;  // backward / tangent: leave the per-workgroup bias-gradient partial rows in `bg_partial` ([grid][bg_total];
                         // layers with a bias gradient in order, then in_bgrad) -- the caller sums them later (one reduction
                         // launch for a whole step: ndjir_mlp_wgrad_group's extra outputs)
@@ -108,18 +114,20 @@ int launch_wgrad(const float* A, int lda, const float* B, int ldb, int K, int N,
 
 // many weight gradients in one launch + one split-reduction launch (f16x3 arithmetic; wgrad.hip "grouped weight gradients")
 long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id, int n_out,
-                                const int* K, const int* N, int target_items);
+                                const int* K, const int* N, int target_items, const int* layout);
 int wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n_out);
+// layout[i] (null = all row-major): bit 0 = A[i] is point-blocked (ChainArgs::side_blocked; lda = its row stride), bit 1 = B[i] is;
+// a blocked operand needs P[i] % 32 == 0.
 // extras: n_extra reduce-only outputs ex_out[i] (ex_n[i] floats) (+)= the sum of ex_S[i] partial rows ex_partial[i] + s * ex_stride[i]
 // (the deferred bias gradients of chain launches: ChainArgs::defer_bg_reduce), summed by the same reduction launch
 int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const float* const* B, const int* ldb, const long long* P,
                        const unsigned* const* amax_a, const unsigned* const* amax_b, const int* out_id, int n_out,
                        float* const* out, const int* ldo, const int* K, const int* N, const int* accum, float* workspace,
                        int target_items, int n_extra, float* const* ex_out, const float* const* ex_partial, const int* ex_n,
-                       const int* ex_S, const int* ex_stride, const int* ex_accum, hipStream_t stream);
+                       const int* ex_S, const int* ex_stride, const int* ex_accum, const int* layout, hipStream_t stream);
 
 long long colsum_workspace(int N, long long P);
-int launch_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, hipStream_t stream);
+int launch_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, int blocked, hipStream_t stream);
 int launch_colsum(const float* X, int ldx, int N, long long P, float* out, int accum, float* workspace,
                   hipStream_t stream);
 

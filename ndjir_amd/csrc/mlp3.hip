@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
       }
       if (round == 0) stamp(li, 1);
       __builtin_amdgcn_wave_barrier();     // (a later round reuses the staging tiles)
-      batched = BATCH_EPILOGUE && !last && nrounds == 1 && njobs > 0 && (l_ld & 3) == 0 && rows == TM && (!p_rowbias || (l_N & 3) == 0) &&
+      batched = BATCH_EPILOGUE && !a.side_blocked && !last && nrounds == 1 && njobs > 0 && (l_ld & 3) == 0 && rows == TM && (!p_rowbias || (l_N & 3) == 0) &&
                 (row0 + TM) < (1LL << 31);
 #pragma unroll
       for (int j = 0; j < 2; ++j) if (j < njobs && !((((jobs >> (8 * j)) & 31) * 32 + 31) < nlim)) batched = false;
@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
         // output layer, or a wave whose other block is ragged -- the barrier waits for that wave anyway.  Backward and
         // tangent keep the block-by-block fast path: their side loads come from HBM at the burst rate of the chip,
         // ~11 B / clk / CU, and requesting all of a wave's blocks at once measured 6 % slower than this spread-out order)
-        const bool fast = !BATCH_EPILOGUE && !last && (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && rows == TM && (!p_rowbias || (l_N & 3) == 0);
+        const bool fast = !BATCH_EPILOGUE && !a.side_blocked && !last && (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && rows == TM && (!p_rowbias || (l_N & 3) == 0);
         f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
         float* lp = stj + g * GPS + (lane >> 3) * 4;
         if (fast) {
@@ -716,7 +716,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
           }
         } else {
         const bool vec_ok = (n4 + 3 < nlim);
-        const bool vec_side = vec_ok && (l_ld & 3) == 0;
+        const bool vec_side = vec_ok && (l_ld & 3) == 0 && !a.side_blocked;
+        // element (row, column n4 + q) of a side tensor: row-major, or point-blocked (ChainArgs::side_blocked; this kernel only
+        // keeps such launches correct -- the layout is meant for the 128-point-tile kernel, mlp3w.hip)
+        const bool blk = a.side_blocked != 0;
+        auto sidx = [&](long long grow, long long off_rm, int q) -> long long {
+          return blk ? ((grow >> 5) * l_ld + (n4 + q)) * 32 + (grow & 31) : off_rm + q;
+        };
         f32x4 cm, bias4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) cm[q] = (n4 + q < nlim) ? 1.f : 0.f;
@@ -772,7 +778,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
               if (vec_side) *((gptr<f32x4>)(p_side_out + off)) = v;
               else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (n4 + q < l_N) p_side_out[off + q] = v[q];
+                for (int q = 0; q < 4; ++q) if (n4 + q < l_N) p_side_out[sidx(grow, off, q)] = v[q];
               }
             }
           } else {
@@ -780,9 +786,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
             if (mrow) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) if (n4 + q < nlim) {
-                hs[q] = p_side_in[off + q];
-                if (MODE == 1 && p_side_add) ex[q] = p_side_add[off + q];
-                if (MODE == 2 && p_side_in2) ex[q] = p_side_in2[off + q];
+                hs[q] = p_side_in[sidx(grow, off, q)];
+                if (MODE == 1 && p_side_add) ex[q] = p_side_add[sidx(grow, off, q)];
+                if (MODE == 2 && p_side_in2) ex[q] = p_side_in2[sidx(grow, off, q)];
               }
             }
 #pragma unroll
@@ -803,8 +809,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
             if (mrow) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) if (n4 + q < nlim) {
-                if (p_side_out) p_side_out[off + q] = v[q];
-                if (MODE == 2 && p_side_out2) p_side_out2[off + q] = x2[q];
+                if (p_side_out) p_side_out[sidx(grow, off, q)] = v[q];
+                if (MODE == 2 && p_side_out2) p_side_out2[sidx(grow, off, q)] = x2[q];
               }
             }
             colsum += v;
@@ -914,7 +920,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) k_chain3(ChainArgs a) {
           float s_row, inv_row;
           scale_from_max(s_rmax[cur][m], s_row, inv_row);
           put1(kk, m, v, s_row);
-          if (m < rows && ly.side_out) ly.side_out[(row0 + m) * ly.ld_side + kk] = v;
+          if (m < rows && ly.side_out)
+            ly.side_out[a.side_blocked ? (((row0 + m) >> 5) * ly.ld_side + kk) * 32 + ((row0 + m) & 31) : (row0 + m) * ly.ld_side + kk] = v;
         }
         // zero the tail up to the next multiple of 16
         const int wcat = base + K0, wpad = (wcat + 15) & ~15;

@@ -453,34 +453,64 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
 
         // ================= phase A (hidden layer): activation math on the accumulator registers =================
         if (active) {
-          const int lane_o = fresh_lane();
-          const int r_o = lane_o & 31, hh = lane_o >> 5;
-          const int fb = nb * 32 + 4 * hh;                  // first feature of register group 0
-          const float winv = p_winv[nb];
+          // lane-derived values: (re)assigned from a fresh opaque lane id at the top of every variant of `run` below, so that
+          // each variant's copies live inside its own code region (a copy shared by all variants is spilled once ANY of them
+          // runs out of registers -- and a scratch reload waits for `vmcnt(0)`, i.e. for every side load in flight)
+          int lane_o, r_o, hh, fb;                          // fb: first feature of register group 0
+          auto lane_values = [&]() { lane_o = fresh_lane(); r_o = lane_o & 31; hh = lane_o >> 5; fb = nb * 32 + 4 * hh; };
+          const float winv = pin(p_winv[nb]);               // (scalar register: uniform)
           const bool full = (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && (!p_rowbias || (l_N & 3) == 0);
           const long long tile_off = row0 * l_ld;           // uniform base + 32-bit lane offset: one address register per access
-          // the accumulator pairs become single values at once: acc1 is dead from here on
+          // the accumulator pairs become single values at once: acc1 is dead from then on.  Issued AFTER the first two blocks'
+          // side loads (their latency covers the 64 multiply-adds) and fenced: left to itself the scheduler sinks every sum
+          // to its use, acc1 stays live through the whole epilogue, and the lane's addresses go to scratch -- whose reloads
+          // (`s_waitcnt vmcnt(0)`: scratch and global loads share one in-order counter) then drain every side load in flight
+          auto sum_accs = [&]() {
 #pragma unroll
-          for (int J = 0; J < RPW; ++J)
+            for (int J = 0; J < RPW; ++J)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc0[J][i] = acc_sum(acc0[J][i], acc1[J][i]);
+              for (int i = 0; i < 16; ++i) acc0[J][i] = acc_sum(acc0[J][i], acc1[J][i]);
+            __builtin_amdgcn_sched_barrier(0);
+          };
           f32x4 bbv[4];                                     // forward: bias * beta log2(e)
-          if (MODE == 0) {
+          auto load_bias = [&](auto ft) {
+            constexpr bool FULL = decltype(ft)::value;
+            if (MODE == 0) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              if (full && p_bias) bbv[g] = *((gptr<const f32x4>)(p_bias + (unsigned)(fb + 8 * g))) * b2;
-              else {
+              for (int g = 0; g < 4; ++g) {
+                if (FULL && (l_ld & 3) == 0 && p_bias) bbv[g] = *((gptr<const f32x4>)(p_bias + (unsigned)(fb + 8 * g))) * b2;
+                else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bbv[g][q] = (p_bias && fb + 8 * g + q < l_N ? p_bias[fb + 8 * g + q] : 0.f) * b2;
+                  for (int q = 0; q < 4; ++q) bbv[g][q] = (p_bias && fb + 8 * g + q < l_N ? p_bias[fb + 8 * g + q] : 0.f) * b2;
+                }
               }
             }
-          }
+          };
           f32x4 hs[2][4], ex[2][4];                         // backward / tangent: side loads, one block ahead
           // side loads of block J (backward: stored activation + extra adjoint; tangent: stored activation + s)
-          auto side_loads = [&](auto jt, auto ft, auto et) {
+          auto side_loads = [&](auto jt, auto ft, auto et, auto lt) {
             constexpr int J = decltype(jt)::value;
             constexpr bool FULL = decltype(ft)::value;
             constexpr bool HAS_EX = decltype(et)::value;
+            constexpr bool BLK = decltype(lt)::value;
+            if (BLK) {
+              // point-blocked tensors: register (g, q) of the 32 lanes of a half-wave = 32 consecutive points of feature
+              // fb + 8 g + q = one 128-byte line; one address register, the feature in the instruction's offset field
+              const unsigned boff = ((unsigned)(rb0 + J) * (unsigned)l_ld + (unsigned)fb) * 32u + (unsigned)r_o;
+              const gptr<const float> b_in = p_side_in + tile_off + boff;
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hs[J & 1][g][q] = (FULL || fb + 8 * g + q < nlim) ? b_in[(8 * g + q) * 32] : 0.f;
+              if (HAS_EX) {
+                const gptr<const float> b_ex = p_side_ex + tile_off + boff;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) ex[J & 1][g][q] = (FULL || fb + 8 * g + q < nlim) ? b_ex[(8 * g + q) * 32] : 0.f;
+              }
+              return;
+            }
             const unsigned rowoff = (unsigned)((rb0 + J) * 32 + r_o) * (unsigned)l_ld + (unsigned)fb;
             // full rows: instruction g reads chunk (lane & 3) of point (r & ~3) + g; hidden_block transposes the quads back
             const unsigned rowoff_t = (unsigned)((rb0 + J) * 32 + (r_o & ~3)) * (unsigned)l_ld + (unsigned)(nb * 32 + 8 * (r_o & 3) + 4 * hh);
@@ -508,13 +538,22 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
           // activations (forward) / deltas (backward, tangent) of block J -> side_out.  The values stay in acc0 until phase B,
           // so the backward issues these stores AFTER the last block's side loads: loads and stores share one in-order
           // counter (vmcnt), and a block's loads queued behind its predecessor's stores cost 24 k instead of 10 k cycles per layer
-          auto side_store = [&](auto jt, auto ft) {
+          auto side_store = [&](auto jt, auto ft, auto lt) {
             constexpr int J = decltype(jt)::value;
             constexpr bool FULL = decltype(ft)::value;
+            constexpr bool BLK = decltype(lt)::value;
             if (!p_side_out) return;
             const unsigned rowoff = (unsigned)((rb0 + J) * 32 + r_o) * (unsigned)l_ld + (unsigned)fb;
             const gptr<float> b_out = p_side_out + tile_off;
             const int lim = MODE == 0 ? l_N : nlim;
+            if (BLK) {
+              const gptr<float> b_blk = b_out + (((unsigned)(rb0 + J) * (unsigned)l_ld + (unsigned)fb) * 32u + (unsigned)r_o);
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (FULL || fb + 8 * g + q < lim) b_blk[(8 * g + q) * 32] = acc0[J][4 * g + q];
+              return;
+            }
             if (FULL && MODE == 0) {
               // forward: 16 bytes per lane at the lane's own point (its epilogue is VALU-bound: the transposition below costs more
               // issue slots than the wider stores give back -- measured +2 %)
@@ -537,10 +576,11 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
                 for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < lim) b_out[rowoff + 8 * g + q] = acc0[J][4 * g + q];
             }
           };
-          auto hidden_block = [&](auto jt, auto ft, auto et) {
+          auto hidden_block = [&](auto jt, auto ft, auto et, auto lt) {
             constexpr int J = decltype(jt)::value;
             constexpr bool FULL = decltype(ft)::value;
             constexpr bool HAS_EX = decltype(et)::value;      // backward: an extra adjoint is added (tangent: always has s)
+            constexpr bool BLK = decltype(lt)::value;         // point-blocked side tensors: nothing to transpose
             const int R = (rb0 + J) * 32 + r_o;             // row of the tile
             const float sa = s_ainv[R];
             const unsigned rowoff = (unsigned)R * (unsigned)l_ld + (unsigned)fb;
@@ -569,7 +609,8 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
                 }
               }
             } else {
-              if (FULL) {                // the side loads came in by full rows: back to "four chunks of my point"
+              const float saw = sa * winv;
+              if (FULL && !BLK) {        // the side loads came in by full rows: back to "four chunks of my point"
                 quad_transpose(hs[J & 1], lane_o);
                 if (HAS_EX) quad_transpose(ex[J & 1], lane_o);
               }
@@ -579,9 +620,9 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                   const int i = 4 * g + q;
-                  const float zz = acc0[J][i] * sa * winv;
+                  const float zz = acc0[J][i] * saw;          // (sa, winv: powers of two -- one exact product)
                   const float e = __builtin_amdgcn_exp2f(nb2 * hs[J & 1][g][q]);
-                  const float sp = (1.f - e) * sc;
+                  const float sp = __builtin_fmaf(-e, sc, sc);   // softplus' (1 - e) * (skip scale)
                   float v;
                   if (MODE == 1) v = HAS_EX ? zz * sp + ex[J & 1][g][q] : zz * sp;
                   else { v = zz * sp; x2[q] = beta * zz * ex[J & 1][g][q] * e; }
@@ -595,14 +636,18 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
                 }
                 if (MODE == 2 && p_side_out2) {
                   const gptr<float> b_out2 = p_side_out2 + tile_off;
-                  if (FULL) ex[J & 1][g] = x2;      // (its s values are consumed: the second output leaves by full rows below)
+                  if (BLK) {
+                    const gptr<float> b_blk = b_out2 + (((unsigned)(rb0 + J) * (unsigned)l_ld + (unsigned)fb) * 32u + (unsigned)r_o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (FULL || fb + 8 * g + q < nlim) b_blk[(8 * g + q) * 32] = x2[q];
+                  } else if (FULL) ex[J & 1][g] = x2;      // (its s values are consumed: the second output leaves by full rows below)
                   else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < nlim) b_out2[rowoff + 8 * g + q] = x2[q];
                   }
                 }
               }
-              if (MODE == 2 && FULL && p_side_out2) {
+              if (MODE == 2 && FULL && !BLK && p_side_out2) {
                 const gptr<float> b_out2 = p_side_out2 + tile_off;
                 quad_transpose(ex[J & 1], lane_o);
                 const unsigned rowoff_t = (unsigned)((rb0 + J) * 32 + (r_o & ~3)) * (unsigned)l_ld + (unsigned)(nb * 32 + 8 * (r_o & 3) + 4 * hh);
@@ -611,7 +656,7 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
               }
             }
             // (backward / tangent: the block's side stores wait until every block's side loads have been consumed, see `run`)
-            if (MODE != 1) side_store(jt, ft);
+            if (MODE != 1) side_store(jt, ft, lt);
             // row maximum of the block's 16 values of this point: v_max ignores NaN; a value set holding an Inf (or only
             // NaN) goes through the bit-pattern filter.  One LDS atomic per lane (the two half-waves of a row: 2-way).
             float m = 0.f;
@@ -625,47 +670,68 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
             }
             atomicMax(&s_rmax[cur][R], __float_as_uint(m));
           };
-          auto run = [&](auto ft, auto et) {
-            if (MODE != 0) side_loads(I0{}, ft, et);
-            if (MODE != 0) side_loads(I1{}, ft, et);
+          auto run = [&](auto ft, auto et, auto lt) {
+            lane_values();
+            load_bias(ft);
+            if (MODE != 0) side_loads(I0{}, ft, et, lt);
+            if (MODE != 0) side_loads(I1{}, ft, et, lt);
+            sum_accs();
             // (diagnostic build -DNDJIR_CHAIN_SUBSTAMP, tools/chain_timeline.py sub: stamps of layer 2's row blocks in timeline slot 5)
 #ifdef NDJIR_CHAIN_SUBSTAMP
 #define NDJIR_SUB(P) if (li == 2) stamp(5, P)
 #else
 #define NDJIR_SUB(P)
 #endif
+            // (fences between the blocks: the loads of block J + 2 must not drift above the math of block J, whose registers
+            // they take over)
             NDJIR_SUB(0);
-            hidden_block(I0{}, ft, et);
+            hidden_block(I0{}, ft, et, lt);
+            __builtin_amdgcn_sched_barrier(0);
             NDJIR_SUB(1);
-            if constexpr (RPW > 2) { if (MODE != 0) side_loads(I2{}, ft, et); }
-            hidden_block(I1{}, ft, et);
+            if constexpr (RPW > 2) { if (MODE != 0) side_loads(I2{}, ft, et, lt); }
+            hidden_block(I1{}, ft, et, lt);
+            __builtin_amdgcn_sched_barrier(0);
             NDJIR_SUB(2);
             if constexpr (RPW > 2) {
-              if (MODE != 0) side_loads(I3{}, ft, et);
-              hidden_block(I2{}, ft, et);
+              if (MODE != 0) side_loads(I3{}, ft, et, lt);
+              hidden_block(I2{}, ft, et, lt);
+              __builtin_amdgcn_sched_barrier(0);
               NDJIR_SUB(3);
-              hidden_block(I3{}, ft, et);
+              hidden_block(I3{}, ft, et, lt);
+              __builtin_amdgcn_sched_barrier(0);
               NDJIR_SUB(4);
             }
 #undef NDJIR_SUB
             if (MODE == 1) {
-              side_store(I0{}, ft);
-              side_store(I1{}, ft);
-              if constexpr (RPW > 2) { side_store(I2{}, ft); side_store(I3{}, ft); }
+              side_store(I0{}, ft, lt);
+              side_store(I1{}, ft, lt);
+              if constexpr (RPW > 2) { side_store(I2{}, ft, lt); side_store(I3{}, ft, lt); }
             }
           };
-          if constexpr (MODE == 1) {
-            if (p_side_ex) { if (full) run(TT{}, TT{}); else run(FF{}, TT{}); }
-            else { if (full) run(TT{}, FF{}); else run(FF{}, FF{}); }
+          if (a.side_blocked) {
+            // (point-blocked side tensors: a block is "full" whatever the row stride)
+            const bool full_b = (nb * 32 + 31 < nlim) && (!p_rowbias || (l_N & 3) == 0);
+            if constexpr (MODE == 1) {
+              if (p_side_ex) { if (full_b) run(TT{}, TT{}, TT{}); else run(FF{}, TT{}, TT{}); }
+              else { if (full_b) run(TT{}, FF{}, TT{}); else run(FF{}, FF{}, TT{}); }
+            } else if constexpr (MODE == 2) {
+              if (full_b) run(TT{}, TT{}, TT{}); else run(FF{}, TT{}, TT{});
+            } else {
+              if (full_b) run(TT{}, FF{}, TT{}); else run(FF{}, FF{}, TT{});
+            }
+          } else if constexpr (MODE == 1) {
+            if (p_side_ex) { if (full) run(TT{}, TT{}, FF{}); else run(FF{}, TT{}, FF{}); }
+            else { if (full) run(TT{}, FF{}, FF{}); else run(FF{}, FF{}, FF{}); }
           } else if constexpr (MODE == 2) {
-            if (full) run(TT{}, TT{}); else run(FF{}, TT{});
+            if (full) run(TT{}, TT{}, FF{}); else run(FF{}, TT{}, FF{});
           } else {
-            if (full) run(TT{}, FF{}); else run(FF{}, FF{});
+            if (full) run(TT{}, FF{}, FF{}); else run(FF{}, FF{}, FF{});
           }
           // bias gradient: column sums of the deltas over the wave's points (its blocks first: they share the features) --
           // 16-lane rows by DPP (xor 1, xor 2, half mirror, mirror), then one LDS atomic per feature from the first lane of
           // every row
           if (MODE != 0 && p_bgrad) {
+            lane_values();
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               float c = acc0[0][i] + acc0[1][i];
@@ -727,7 +793,14 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
           float s_row, inv_row;
           scale_from_max(s_rmax[cur][m], s_row, inv_row);
           put1(kk, m, v, s_row);
-          if (ly.side_out) ly.side_out[(row0 + m) * ly.ld_side + kk] = v;
+          if (ly.side_out && !a.side_blocked) ly.side_out[(row0 + m) * ly.ld_side + kk] = v;
+        }
+        if (ly.side_out && a.side_blocked) {      // point-blocked: points fastest, full 128-byte lines (the tile's X is in L1 / L2)
+          float* so = ly.side_out + row0 * ly.ld_side;
+          for (int t = tid; t < K0 * TM; t += NTHREADS) {
+            const int m = t % TM, k = t / TM;
+            so[((unsigned)(m >> 5) * (unsigned)ly.ld_side + (unsigned)(base + k)) * 32u + (unsigned)(m & 31)] = X[(long long)m * a.ldx + k] * a.skip_scale;
+          }
         }
         // zero the tail up to the next multiple of 16
         const int wcat = base + K0, wpad = (wcat + 15) & ~15;
@@ -768,6 +841,7 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace x3w
 
+#ifndef NDJIR_NO_LAUNCHER      // (tools/isa_one.sh compiles ONE instantiation of the kernel above for a look at its ISA)
 // One net's part of a launch plan: the argument block with everything but the LDS offsets filled in.
 struct WidePlan {
   ChainArgs b;
@@ -903,5 +977,6 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
 }
 
 int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream) { return launch_chainw_group(&a, 1, mode, stream); }
+#endif
 
 }  // namespace ndjir

@@ -319,7 +319,12 @@ template <int WK, int WN, int BK, int BN>
 __device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int N,
                                             long long p_begin, long long p_end, float* __restrict__ out, int k0, int n0,
                                             int k_end, int n_end, float sa, float ia, float sb, float ib,
-                                            unsigned short* wg_lds) {
+                                            unsigned short* wg_lds, int lay = 0) {
+  // lay: bit 0 = A is point-blocked, bit 1 = B is (ChainArgs::side_blocked: element (p, f) at ((p >> 5) * ld + f) * 32 + (p & 31)).
+  // A 32-point chunk of TK features of a blocked operand is ONE contiguous run of TK * 128 bytes: thread t takes the
+  // 16-byte groups t, t + NT, ... of it (4 consecutive points of feature (group >> 3)) -- fully coalesced 16-byte loads, and
+  // exactly the 4-point groups the planes are written in.  (Row-major operands: a thread owns a feature column and reads
+  // its points one dword at a time.)  Blocked operands have P % 32 == 0 and splits of whole chunks: no ragged chunk.
   constexpr int NT = WK * WN * 64;                  // threads: one wave per (WK, WN) position
   constexpr int TK = WK * BK * 32, TN = WN * BN * 32;
   constexpr int PA = WG_C * TK / NT, PB = WG_C * TN / NT;          // points per thread and chunk (multiples of 4)
@@ -337,19 +342,44 @@ __device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A, int lda
   const bool acol = (k0 + fa) < k_end, bcol = (n0 + fb) < n_end;
   const float* Ap = A + (long long)(ga * PA) * lda + k0 + fa;
   const float* Bp = B + (long long)(gb * PB) * ldb + n0 + fb;
+  const bool blk_a = lay & 1, blk_b = lay & 2;
   auto load_chunk = [&](long long p0) {
-    const float* ap = Ap + p0 * lda;
-    const float* bp = Bp + p0 * ldb;
-    if (p0 + WG_C <= p_end) {
+    const bool whole = p0 + WG_C <= p_end;
+    if (blk_a) {
+      const wg_f32x4* ap = reinterpret_cast<const wg_f32x4*>(A + ((p0 >> 5) * lda + k0) * 32) + tid;
 #pragma unroll
-      for (int i = 0; i < PA; ++i) ra[i] = acol ? ap[(long long)i * lda] : 0.f;
-#pragma unroll
-      for (int i = 0; i < PB; ++i) rb[i] = bcol ? bp[(long long)i * ldb] : 0.f;
+      for (int i = 0; i < PA / 4; ++i) {
+        wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k0 + ((i * NT + tid) >> 3) < k_end) v = ap[i * NT];
+        ra[4 * i] = v[0]; ra[4 * i + 1] = v[1]; ra[4 * i + 2] = v[2]; ra[4 * i + 3] = v[3];
+      }
     } else {
+      const float* ap = Ap + p0 * lda;
+      if (whole) {
 #pragma unroll
-      for (int i = 0; i < PA; ++i) ra[i] = (acol && p0 + ga * PA + i < p_end) ? ap[(long long)i * lda] : 0.f;
+        for (int i = 0; i < PA; ++i) ra[i] = acol ? ap[(long long)i * lda] : 0.f;
+      } else {
 #pragma unroll
-      for (int i = 0; i < PB; ++i) rb[i] = (bcol && p0 + gb * PB + i < p_end) ? bp[(long long)i * ldb] : 0.f;
+        for (int i = 0; i < PA; ++i) ra[i] = (acol && p0 + ga * PA + i < p_end) ? ap[(long long)i * lda] : 0.f;
+      }
+    }
+    if (blk_b) {
+      const wg_f32x4* bp = reinterpret_cast<const wg_f32x4*>(B + ((p0 >> 5) * ldb + n0) * 32) + tid;
+#pragma unroll
+      for (int i = 0; i < PB / 4; ++i) {
+        wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n0 + ((i * NT + tid) >> 3) < n_end) v = bp[i * NT];
+        rb[4 * i] = v[0]; rb[4 * i + 1] = v[1]; rb[4 * i + 2] = v[2]; rb[4 * i + 3] = v[3];
+      }
+    } else {
+      const float* bp = Bp + p0 * ldb;
+      if (whole) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rb[i] = bcol ? bp[(long long)i * ldb] : 0.f;
+      } else {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rb[i] = (bcol && p0 + gb * PB + i < p_end) ? bp[(long long)i * ldb] : 0.f;
+      }
     }
   };
   auto split4 = [&](const float* v, float s, _Float16* d, int plane_stride) {
@@ -361,10 +391,20 @@ __device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A, int lda
     *reinterpret_cast<wg_f16x4*>(d + plane_stride) = pl;
   };
   auto store_chunk = [&]() {
+    if (blk_a) {       // group e = i * NT + tid: feature e >> 3, points 4 (e & 7) ..
 #pragma unroll
-    for (int g4 = 0; g4 < PA / 4; ++g4) split4(ra + 4 * g4, sa, As + fa * WG_CP + ga * PA + 4 * g4, TK * WG_CP);
+      for (int g4 = 0; g4 < PA / 4; ++g4) split4(ra + 4 * g4, sa, As + ((g4 * NT + tid) >> 3) * WG_CP + 4 * (tid & 7), TK * WG_CP);
+    } else {
 #pragma unroll
-    for (int g4 = 0; g4 < PB / 4; ++g4) split4(rb + 4 * g4, sb, Bs + fb * WG_CP + gb * PB + 4 * g4, TN * WG_CP);
+      for (int g4 = 0; g4 < PA / 4; ++g4) split4(ra + 4 * g4, sa, As + fa * WG_CP + ga * PA + 4 * g4, TK * WG_CP);
+    }
+    if (blk_b) {
+#pragma unroll
+      for (int g4 = 0; g4 < PB / 4; ++g4) split4(rb + 4 * g4, sb, Bs + ((g4 * NT + tid) >> 3) * WG_CP + 4 * (tid & 7), TN * WG_CP);
+    } else {
+#pragma unroll
+      for (int g4 = 0; g4 < PB / 4; ++g4) split4(rb + 4 * g4, sb, Bs + fb * WG_CP + gb * PB + 4 * g4, TN * WG_CP);
+    }
   };
 
   if (p_begin < p_end) {
@@ -720,18 +760,41 @@ int launch_colsum(const float* X, int ldx, int N, long long P, float* out, int a
 }
 
 // out[g][n] = sum over the `div` consecutive rows of group g of X[row][n]  (gradient of a per-group additive term)
-__global__ void __launch_bounds__(256) k_group_colsum(const float* __restrict__ X, int ldx, int N, int div, float* __restrict__ out) {
+// X point-blocked (ChainArgs::side_blocked), groups of whole 32-point blocks: lanes along the points of a block (128-byte lines),
+// 8 features per pass, 5 DPP-free shuffle steps per feature
+__global__ void __launch_bounds__(256) k_group_colsum_blocked(const float* __restrict__ X, int ldx, int N, int div, float* __restrict__ out) {
+  const long long gidx = blockIdx.x;
+  const int pp = threadIdx.x & 31, fq = threadIdx.x >> 5;
+  const long long b0 = gidx * (div >> 5);
+  for (int n0 = 0; n0 < N; n0 += 8) {
+    const int n = n0 + fq;
+    float acc = 0.f;
+    if (n < N)
+      for (int b = 0; b < (div >> 5); ++b) acc += X[((b0 + b) * ldx + n) * 32 + pp];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (pp == 0 && n < N) out[gidx * N + n] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_group_colsum(const float* __restrict__ X, int ldx, int N, int div, float* __restrict__ out,
+                                                      int blocked) {
   __shared__ float red[256];
   const long long gidx = blockIdx.x;
   const int TX = pow2_at_least(N), TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const float* Xg = X + gidx * (long long)div * ldx;
+  const long long r0 = gidx * (long long)div;
   for (int n0 = 0; n0 < N; n0 += TX) {
     const int n = n0 + tx;
     float acc = 0.f;
     if (n < N) {
+      if (blocked) {       // (groups that are not whole blocks: correct, uncoalesced)
+        for (int r = ty; r < div; r += TY) acc += X[(((r0 + r) >> 5) * ldx + n) * 32 + ((r0 + r) & 31)];
+      } else {
 #pragma unroll 8
-      for (int r = ty; r < div; r += TY) acc += Xg[(long long)r * ldx + n];
+        for (int r = ty; r < div; r += TY) acc += Xg[(long long)r * ldx + n];
+      }
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -744,8 +807,9 @@ __global__ void __launch_bounds__(256) k_group_colsum(const float* __restrict__ 
   }
 }
 
-int launch_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(k_group_colsum, dim3((unsigned)G), dim3(256), 0, stream, X, ldx, N, div, out);
+int launch_group_colsum(const float* X, int ldx, int N, long long G, int div, float* out, int blocked, hipStream_t stream) {
+  if (blocked && (div & 31) == 0) hipLaunchKernelGGL(k_group_colsum_blocked, dim3((unsigned)G), dim3(256), 0, stream, X, ldx, N, div, out);
+  else hipLaunchKernelGGL(k_group_colsum, dim3((unsigned)G), dim3(256), 0, stream, X, ldx, N, div, out, blocked);
   return ndjir_check_launch();
 }
 
@@ -897,7 +961,7 @@ struct WggSrc {
   long long P;
   long long rows;            // points per split (multiple of WG_C)
   int lda, ldb, K, N;
-  int S, pad;
+  int S, layout;             // layout: bit 0 = A point-blocked, bit 1 = B point-blocked (ChainArgs::side_blocked)
 };
 struct WggSeg {              // a run of consecutive workgroups tiling one region of one source's output with one kind of item
   int first, count;          // first workgroup (multiple of 8), workgroups (multiple of 8; the ones past S * tiles idle)
@@ -991,6 +1055,64 @@ __device__ __forceinline__ void wgrad_narrow_rows(const float* __restrict__ A, i
   }
 }
 
+// the same item with A point-blocked (the last hidden activation of a net whose output layer is <= 8 wide): thread = (feature,
+// block phase).  A feature's 32 points of a block are 128 contiguous bytes (8 x 16-byte loads in flight per thread); B's rows of
+// the item (<= WGG_NARROW_ROWS x 8 floats) are staged in LDS once, zero-padded to 8 columns, and read back as broadcasts.
+template <int NMAX>
+__device__ __forceinline__ void wgrad_narrow_rows_blocked(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                          int K, int N, long long p0, long long p1, float* __restrict__ part,
+                                                          float* lds) {
+  static_assert(NMAX == 8, "two 16-byte broadcasts per point");
+  float* Bs = lds;                                   // [rows][8]
+  float* red = lds + WGG_NARROW_ROWS * 8;            // [256]
+  const int rows = (int)(p1 - p0);                   // (multiple of 32)
+  for (int t = threadIdx.x; t < rows * 8; t += 256) {
+    const int r = t >> 3, n = t & 7;
+    Bs[t] = n < N ? B[(p0 + r) * ldb + n] : 0.f;
+  }
+  __syncthreads();
+  const int TX = pow2_at_least(K), TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int nblk = rows >> 5;
+  for (int k0 = 0; k0 < K; k0 += TX) {
+    const int k = k0 + tx;
+    float acc[NMAX];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
+    if (k < K) {
+      for (int b = ty; b < nblk; b += TY) {
+        const wg_f32x4* ap = reinterpret_cast<const wg_f32x4*>(A + (((p0 >> 5) + b) * lda + k) * 32);
+        wg_f32x4 a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = ap[i];
+        const wg_f32x4* bs = reinterpret_cast<const wg_f32x4*>(Bs + b * 32 * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const wg_f32x4 b0 = bs[(4 * i + q) * 2], b1 = bs[(4 * i + q) * 2 + 1];
+            const float av = a[i][q];
+            acc[0] = fmaf(av, b0[0], acc[0]); acc[1] = fmaf(av, b0[1], acc[1]); acc[2] = fmaf(av, b0[2], acc[2]); acc[3] = fmaf(av, b0[3], acc[3]);
+            acc[4] = fmaf(av, b1[0], acc[4]); acc[5] = fmaf(av, b1[1], acc[5]); acc[6] = fmaf(av, b1[2], acc[6]); acc[7] = fmaf(av, b1[3], acc[7]);
+          }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      if (n < N) {                                   // uniform
+        red[threadIdx.x] = acc[n];
+        __syncthreads();
+        for (int s = TY / 2; s > 0; s >>= 1) {
+          if (ty < s) red[threadIdx.x] += red[threadIdx.x + s * TX];
+          __syncthreads();
+        }
+        if (ty == 0 && k < K) part[(long long)k * N + n] = red[tx];
+        __syncthreads();
+      }
+    }
+  }
+}
+
 // rows x columns of dW one item of a kind covers
 __host__ __device__ static inline int wgg_tile_k(int kind) { return kind == 1 ? WG_STRIP : kind == 4 ? 2 * WG_STRIP : WG_T; }
 __host__ __device__ static inline int wgg_tile_n(int kind) { return kind == 2 ? WG_STRIP : WG_T; }
@@ -1016,9 +1138,16 @@ __device__ __forceinline__ bool wgg_locate(const WggTable& a, int& si, int& spli
 // source came without a recorded maximum (single-layer operators on a few hundred per-ray rows).  Every item de-scales its own
 // partial slab, so items of one source may use different scales -- each only has to bound the values the item multiplies.
 __device__ __forceinline__ unsigned wgg_tile_absmax(const float* __restrict__ X, int ld, int c0, int c1, long long p0, long long p1,
-                                                    unsigned* red) {
+                                                    unsigned* red, bool blocked = false) {
   unsigned m = 0;
   const int w = c1 - c0;
+  if (blocked) {          // point-blocked operand: 32 points of a feature are contiguous
+    for (long long b = (p0 >> 5) + (threadIdx.x >> 5); b < (p1 >> 5); b += WG_THREADS / 32)
+      for (int c = 0; c < w; ++c) {
+        const unsigned v = __float_as_uint(X[(b * ld + c0 + c) * 32 + (threadIdx.x & 31)]) & 0x7fffffffu;
+        if (v < 0x7f800000u && v > m) m = v;
+      }
+  } else
 #pragma unroll 4
   for (long long p = p0 + (threadIdx.x >> 6); p < p1; p += WG_THREADS / 64)
     for (int c = threadIdx.x & 63; c < w; c += 64) {
@@ -1065,27 +1194,28 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* _
   if (p_end > s.P) p_end = s.P;
   float* slab = s.partial + (long long)split * K * N;
   if (kind == 3) {
-    wgrad_narrow_rows<SW_NMAX>(s.A, s.lda, s.B, s.ldb, K, N, p_begin, p_end, slab, reinterpret_cast<float4*>(wg_lds));
+    if (s.layout & 1) wgrad_narrow_rows_blocked<SW_NMAX>(s.A, s.lda, s.B, s.ldb, K, N, p_begin, p_end, slab, reinterpret_cast<float*>(wg_lds));
+    else wgrad_narrow_rows<SW_NMAX>(s.A, s.lda, s.B, s.ldb, K, N, p_begin, p_end, slab, reinterpret_cast<float4*>(wg_lds));
     return;
   }
   const int ti = tile / g.tiles_n, tj = tile - ti * g.tiles_n;
   const int k0 = g.k_off + ti * wgg_tile_k(kind), n0 = g.n_off + tj * wgg_tile_n(kind);
   unsigned ma, mb;
   if (s.amax_a) ma = *s.amax_a;
-  else { const int k1 = k0 + wgg_tile_k(kind); ma = wgg_tile_absmax(s.A, s.lda, k0, k1 < g.k_end ? k1 : g.k_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds)); }
+  else { const int k1 = k0 + wgg_tile_k(kind); ma = wgg_tile_absmax(s.A, s.lda, k0, k1 < g.k_end ? k1 : g.k_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds), s.layout & 1); }
   if (s.amax_b) mb = *s.amax_b;
-  else { const int n1 = n0 + wgg_tile_n(kind); mb = wgg_tile_absmax(s.B, s.ldb, n0, n1 < g.n_end ? n1 : g.n_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds)); }
+  else { const int n1 = n0 + wgg_tile_n(kind); mb = wgg_tile_absmax(s.B, s.ldb, n0, n1 < g.n_end ? n1 : g.n_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds), s.layout & 2); }
   float sa, ia, sb, ib;
   wg_scale_from_max(ma, sa, ia);
   wg_scale_from_max(mb, sb, ib);
   if (kind == 0)
-    wgrad3_tile<2, 2, 2, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
+    wgrad3_tile<2, 2, 2, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout);
   else if (kind == 1)
-    wgrad3_tile<1, 4, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
+    wgrad3_tile<1, 4, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout);
   else if (kind == 4)
-    wgrad3_tile<2, 2, 1, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
+    wgrad3_tile<2, 2, 1, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout);
   else
-    wgrad3_tile<4, 1, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
+    wgrad3_tile<4, 1, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout);
 }
 
 // out (+)= sum over the S slabs: a workgroup owns 32 vectors (VEC floats each) of one output, 8 slab phases
@@ -1148,7 +1278,9 @@ __global__ void __launch_bounds__(256) k_wgrad_group_reduce(const WggTable* __re
   else wgg_reduce_block<1>(o, blk, red);
 }
 
-static inline bool wgg_narrow(const float* A, int lda, int K, int N) {
+static inline bool wgg_narrow(const float* A, int lda, int K, int N, int layout = 0) {
+  if ((layout & 2) != 0) return false;              // (B of a narrow output is the chain's input gradient: never blocked)
+  if ((layout & 1) != 0) return N <= SW_NMAX;       // blocked A: any K (wgrad_narrow_rows_blocked)
   return N <= SW_NMAX && (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
 }
 
@@ -1199,12 +1331,12 @@ static int wgg_chunk_end(int o0, int n_src, const long long* P, const int* out_i
 
 // splits / rows per split of the sources of outputs [o0, o1) -- one launch (same rule for the workspace size and the launch)
 static void wgg_split_plan(int o0, int o1, int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id,
-                           const int* K, const int* N, int target_items, int* S, long long* rows) {
+                           const int* K, const int* N, int target_items, int* S, long long* rows, const int* layout) {
   if (target_items <= 0) target_items = WGG_DEFAULT_ITEMS;
   double units = 0.0;               // main-tile equivalents x points
   for (int i = 0; i < n_src; ++i) {
     const int o = out_id[i];
-    if (o < o0 || o >= o1 || P[i] <= 0 || wgg_narrow(A ? A[i] : nullptr, lda[i], K[o], N[o])) continue;
+    if (o < o0 || o >= o1 || P[i] <= 0 || wgg_narrow(A ? A[i] : nullptr, lda[i], K[o], N[o], layout ? layout[i] : 0)) continue;
     units += wgg_units(K[o], N[o]) * (double)P[i];
   }
   long long target = (long long)(units / target_items);
@@ -1214,7 +1346,7 @@ static void wgg_split_plan(int o0, int o1, int n_src, const float* const* A, con
     const int o = out_id[i];
     if (o < o0 || o >= o1) continue;
     if (P[i] <= 0) { S[i] = 0; rows[i] = 0; continue; }
-    if (wgg_narrow(A ? A[i] : nullptr, lda[i], K[o], N[o])) {
+    if (wgg_narrow(A ? A[i] : nullptr, lda[i], K[o], N[o], layout ? layout[i] : 0)) {
       rows[i] = WGG_NARROW_ROWS;
       S[i] = (int)((P[i] + WGG_NARROW_ROWS - 1) / WGG_NARROW_ROWS);
       continue;
@@ -1240,7 +1372,7 @@ int wgrad_group_launches(int n_src, const long long* P, const int* out_id, int n
 }
 
 long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id, int n_out,
-                                const int* K, const int* N, int target_items) {
+                                const int* K, const int* N, int target_items, const int* layout) {
   if (n_src <= 0) return 2 * WGT_FLOATS + 4;          // (reduce-only calls: room for their tables)
   if (n_src > 65536) return 0;
   int* S = (int*)alloca(sizeof(int) * n_src);
@@ -1249,7 +1381,7 @@ long long wgrad_group_workspace(int n_src, const float* const* A, const int* lda
   for (int o0 = 0; o0 < n_out;) {
     const int o1 = wgg_chunk_end(o0, n_src, P, out_id, n_out);
     if (o1 == o0) return 0;
-    wgg_split_plan(o0, o1, n_src, A, lda, P, out_id, K, N, target_items, S, rows);
+    wgg_split_plan(o0, o1, n_src, A, lda, P, out_id, K, N, target_items, S, rows, layout);
     total += WGT_FLOATS;
     for (int o = o0; o < o1; ++o) {
       long long st = 0;
@@ -1266,7 +1398,7 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
                        const unsigned* const* amax_a, const unsigned* const* amax_b, const int* out_id, int n_out,
                        float* const* out, const int* ldo, const int* K, const int* N, const int* accum, float* workspace,
                        int target_items, int n_extra, float* const* ex_out, const float* const* ex_partial, const int* ex_n,
-                       const int* ex_S, const int* ex_stride, const int* ex_accum, hipStream_t stream) {
+                       const int* ex_S, const int* ex_stride, const int* ex_accum, const int* layout, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_group), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -1286,7 +1418,7 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
   for (int o0 = 0; o0 < n_out || ex_done < n_extra;) {
     const int o1 = o0 < n_out ? wgg_chunk_end(o0, n_src, P, out_id, n_out) : o0;
     if (o0 < n_out && o1 == o0) return NDJIR_ERR_UNSUPPORTED;       // one output with more sources than a table holds
-    wgg_split_plan(o0, o1, n_src, A, lda, P, out_id, K, N, target_items, S, rows);
+    wgg_split_plan(o0, o1, n_src, A, lda, P, out_id, K, N, target_items, S, rows, layout);
     WggTable* dtab = reinterpret_cast<WggTable*>(workspace + off);
     off += WGT_FLOATS;
     int ns = 0, no = 0;
@@ -1302,7 +1434,7 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
         s.A = A[i]; s.B = B[i]; s.amax_a = amax_a ? amax_a[i] : nullptr; s.amax_b = amax_b ? amax_b[i] : nullptr;
         s.partial = workspace + off + (long long)s_seen * kn;
         s_seen += S[i];
-        s.P = P[i]; s.rows = rows[i]; s.lda = lda[i]; s.ldb = ldb[i]; s.K = K[o]; s.N = N[o]; s.S = S[i]; s.pad = 0;
+        s.P = P[i]; s.rows = rows[i]; s.lda = lda[i]; s.ldb = ldb[i]; s.K = K[o]; s.N = N[o]; s.S = S[i]; s.layout = layout ? layout[i] : 0;
       }
       WggOut& w = tab.out[no++];
       w.out = out[o]; w.partial = workspace + off; w.KN = (int)kn; w.N = N[o]; w.ldo = ldo[o];
@@ -1319,7 +1451,7 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
         const WggSrc& s = tab.src[i];
         WggRegion rg[4];
         int nr = 0;
-        if (wgg_narrow(s.A, s.lda, s.K, s.N)) {
+        if (wgg_narrow(s.A, s.lda, s.K, s.N, s.layout)) {
           if (kind == 3) rg[nr++] = {3, 0, 0, s.K, s.N, 1, 1};
         } else {
           nr = wgg_regions(s.K, s.N, rg);

@@ -30,7 +30,7 @@ from torch.autograd import Function
 
 from . import lib
 from .grid_feature import _core
-from .mlp import _launch, _packed, _Strided, amax_slots, chain_workspace, colsum, grad_target, wgrad, wgrad_group
+from .mlp import _launch, _packed, _Strided, amax_slots, blocked_layout, chain_workspace, colsum, grad_target, pb, wgrad, wgrad_group
 
 
 
@@ -113,9 +113,12 @@ class GeometricMain(Function):
         y = _Strided(Z.view(-1)[2:])
         # recorded maxima (operand scales of the f16x3 weight-gradient kernel): am[j] <-> A[j]; sm[j] <-> s_store[j]
         am, sm = amax_slots(dev, L), amax_slots(dev, L)
+        # every hidden tensor of the node (A_1.., s, g-bar_1.., extras, deltas) point-blocked where the 128-point-tile kernel runs
+        blk = blocked_layout(P, [a.shape[1] for a in A[1:]], xf.is_cuda)
+        fl = 8 if blk else 0
         _launch("chain_fwd", _flops(P, Ks, Ns), "mlp_chain", 0, P, e, K0, K0, L, [_packed(w, False) for w in W],
                 [t.detach() for t in b], Ks, Ns, [None] * L, A[1:] + [None], [a.shape[1] for a in A[1:]] + [0],
-                [None] * L, y, ldz, 0, 1, beta, skip_at, scale, 0, None, 0, None, None,
+                [None] * L, y, ldz, fl, 1, beta, skip_at, scale, 0, None, 0, None, None,
                 [am[j + 1:j + 2] for j in range(L - 1)] + [None], am[0:1],
                 shape=f"{P}:geo {K0}-" + "-".join(map(str, Ns)))
 
@@ -149,7 +152,7 @@ class GeometricMain(Function):
                 ld.append(0)
         g0 = (torch.empty if bskip >= 0 else torch.zeros)((P, K0), device=dev, dtype=torch.float32)     # (skip layer: assigned, see mlp.FusedMLP.backward)
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain", 1, P, ones, 1, 1, L, Wp, [None] * L, bK, bN, side_in,
-                side_out, ld, [None] * L, g0, K0, 1 if bskip >= 0 else 0, 1, beta, bskip, scale, split,
+                side_out, ld, [None] * L, g0, K0, (1 if bskip >= 0 else 0) | fl, 1, beta, bskip, scale, split,
                 g0 if bskip >= 0 else None, K0, None, None, side_am, None, shape=f"{P}:sdf 1-" + "-".join(map(str, bN)))
 
         # ---- n = J_e(x)^T g_0 (one launch; it also completes Z and moves the sdf out of it) ----
@@ -167,7 +170,7 @@ class GeometricMain(Function):
         sdf = torch.empty((P, 1), device=dev, dtype=torch.float32)
         lib.call("geo_normal", P, M, e, K0, g0, K0, len(gqs), gqs, n, Z, ldz, D, sdf)
 
-        ctx.cfg = (M, skip_at, scale, min_, max_, L, tuple(x.shape), fam_names, bskip, split, ste)
+        ctx.cfg = (M, skip_at, scale, min_, max_, L, tuple(x.shape), fam_names, bskip, split, ste, blk)
         ctx.btgt = [grad_target(t) for t in b]       # accumulate-in-place gradient buffers of the biases (mlp.set_grad_buffer)
         ctx.A, ctx.s_store, ctx.s = A, s_store, s
         ctx.am, ctx.sm = am, sm
@@ -180,7 +183,8 @@ class GeometricMain(Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_sdf, g_feat, g_n, g_Z):
-        M, skip_at, scale, min_, max_, L, xshape, fam_names, bskip, split, ste = ctx.cfg
+        M, skip_at, scale, min_, max_, L, xshape, fam_names, bskip, split, ste, blk = ctx.cfg
+        fl = 8 if blk else 0
         saved = ctx.saved_tensors
         W = list(saved[:L])
         grids = list(saved[L:])
@@ -254,7 +258,7 @@ class GeometricMain(Function):
             bg[T - 1] = col_last
             _launch("chain_tan", _flops(P, Ks[:T], Ns[:T]), "mlp_chain_ex", 2, P, gb0, K0, K0, T,
                     [_packed(w, False) for w in W[:T]], [None] * T, Ks[:T], Ns[:T], side_in, side_out, ld, bg,
-                    None, 0, 0, 0, beta, skip_at, scale, 0, None, 0, side_in2, [None] * T, side_out2,
+                    None, 0, fl, 0, beta, skip_at, scale, 0, None, 0, side_in2, [None] * T, side_out2,
                     None, 0, None, chain_workspace(dev, bg), side_am, gm[0:1], shape=f"{P}:tan {K0}-" + "-".join(map(str, Ns[:T])))
 
         # ---- backward chain with the extra adjoints ----
@@ -292,7 +296,7 @@ class GeometricMain(Function):
         gx = (torch.empty if bskip >= 0 else torch.zeros)((P, K0), device=dev, dtype=torch.float32) if need_x else None
         gb_last = btgt[L - 1] if btgt[L - 1] is not None else torch.empty((Ns[-1],), device=dev, dtype=torch.float32)     # bias gradient of the output layer
         _launch("chain_bwd", _flops(P, bK, bN), "mlp_chain_ex", 1, P, gy, Ns[-1], Ns[-1], steps, Wp, [None] * steps, bK, bN,
-                side_in, side_out, ld, bg, gx, K0, (1 if (bskip >= 0 and need_x) else 0) | bg_acc, 1 if need_x else 0, beta,
+                side_in, side_out, ld, bg, gx, K0, (1 if (bskip >= 0 and need_x) else 0) | bg_acc | fl, 1 if need_x else 0, beta,
                 bskip, scale, split, gx if (bskip >= 0 and need_x) else None, K0, [None] * steps, side_add, [None] * steps,
                 None, 0, gb_last, chain_workspace(dev, bg + [gb_last]), side_am, dm[L - 1:L], shape=f"{P}:geo {Ns[-1]}-" + "-".join(map(str, bN)))
 
@@ -310,9 +314,9 @@ class GeometricMain(Function):
                 dst = wt if wt is not None else torch.empty(tuple(W[j].shape), device=dev, dtype=torch.float32)
                 if wt is None:
                     gW[j] = dst
-                src = [(A[j], deltas[j], am[j:j + 1], dm[j:j + 1])]
+                src = [(pb(A[j], blk and j > 0), pb(deltas[j], blk and j < L - 1), am[j:j + 1], dm[j:j + 1])]
                 if nbar is not None and j < L - 1:
-                    src.append((gbar[j], s[j], gm[j:j + 1], sm[j:j + 1]))
+                    src.append((pb(gbar[j], blk and j > 0), pb(s[j], blk), gm[j:j + 1], sm[j:j + 1]))
                 jobs.append((dst, wt is not None, src))
         wgrad_group(jobs)
         for j in range(L):

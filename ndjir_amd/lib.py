@@ -45,11 +45,12 @@ SIGS = {
     # ... in_bgrad workspace side_amax x_amax
     "mlp_chain": "ilpiii" + "PPAAPPAP" + "piiififipi" + "pp" + "Pp",
     "mlp_chain_ex": "ilpiii" + "PPAAPPAP" + "piiififipi" + "PPP" + "pi" + "pp" + "Pp",
-    "mlp_group_colsum": "piilip",
+    "mlp_group_colsum": "piilipi",
     "mlp_wgrad": "pipiiilpippp",
     # n_src A lda B ldb P amax_a amax_b out_id n_out out ldo K N accum workspace target_items n_extra ex_out ex_partial ex_n ex_S
     # ex_stride ex_accum
-    "mlp_wgrad_group": "iPAPALPPAiPAAAApi" + "iPPAAAA",
+    # ex_stride ex_accum layout
+    "mlp_wgrad_group": "iPAPALPPAiPAAAApi" + "iPPAAAA" + "A",
     "mlp_colsum": "piilpip",
     "render_alpha_weights": "iii" + "p" * 11,
     "render_alpha_weights_backward": "iii" + "p" * 16,
@@ -171,7 +172,7 @@ def load():
         _lib.ndjir_mlp_wgrad_group_workspace.argtypes = [ctypes.c_int, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_int),
                                                          ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_int),
                                                          ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
-                                                         ctypes.c_int]
+                                                         ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     return _lib
 
 

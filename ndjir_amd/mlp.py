@@ -558,6 +558,62 @@ def _slot(am, i):
     return am[i:i + 1] if am is not None else None
 
 
+_NO_BLOCKED = bool(os.environ.get("NDJIR_NO_BLOCKED"))      # A/B: hidden tensors row-major everywhere
+
+
+class PB:
+    """Point-blocked (P, K) matrix: the hidden tensors of a chain launched with `blocked=True` (ndjir_mlp_chain accum_y bit 3).
+    Element (p, f) lives at float offset ((p >> 5) * ld + f) * 32 + (p & 31) of the wrapped buffer -- blocks of 32 points,
+    feature-major inside a block; same P * ld floats as the row-major (P, ld) tensor it is allocated as.  Wraps a 2-D view that
+    starts at column 0 of its buffer; `pb[:, a:b]` = the feature range [a, b).  Only the engine's own kernels read these
+    (backward / tangent chains as side tensors, `wgrad_group` as operands, `mlp_group_colsum`)."""
+    is_cuda, dtype = True, torch.float32
+
+    def __init__(self, t, c0=0, c1=None):
+        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] % 32 == 0
+        self.t, self.c0, self.c1 = t, int(c0), int(t.shape[1] if c1 is None else c1)
+
+    @property
+    def shape(self):
+        return (self.t.shape[0], self.c1 - self.c0)
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def stride(self, i):
+        return self.t.stride(0) if i == 0 else 1
+
+    def is_contiguous(self):
+        return True
+
+    def data_ptr(self):
+        return self.t.data_ptr() + 128 * self.c0
+
+    def __getitem__(self, idx):
+        rows, cols = idx
+        assert rows == slice(None) and isinstance(cols, slice) and cols.step is None
+        a, b, _ = cols.indices(self.c1 - self.c0)
+        return PB(self.t, self.c0 + a, self.c0 + b)
+
+
+def pb(t, on=True):
+    """`t` as a point-blocked operand (when `on`)."""
+    return PB(t) if (on and t is not None) else t
+
+
+def blocked_layout(P, hidden_widths, is_cuda=True):
+    """Whether a net's hidden tensors are kept point-blocked (`PB`): f16x3 arithmetic, launches the 128-point-tile kernel
+    takes (its epilogue then moves accumulator registers as they are; the 64 / 32-point kernel only stays correct on the
+    layout), every weight gradient through the grouped kernel."""
+    if _NO_BLOCKED or _NO_GROUP or not is_cuda or get_math() != MATH_F16X3 or P % 128 != 0:
+        return False
+    tile = get_tile_rows()
+    if not (tile == 128 or (tile == 0 and P >= 32768)):
+        return False
+    return all(64 <= -(-int(w) // 32) * 32 <= 256 for w in hidden_widths)
+
+
 def chain_workspace(device, bgrads):
     """Workspace of a chain launch that produces the bias gradients `bgrads` (list, None entries ok)."""
     total = sum(b.numel() for b in bgrads if b is not None)
@@ -570,12 +626,14 @@ def chain_workspace(device, bgrads):
 
 
 def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0, keep_hidden=False, row_bias=None,
-                  row_bias_div=1, K0=None, out=None):
+                  row_bias_div=1, K0=None, out=None, blocked=False):
     """x (P, ld) contiguous; the net reads its first K0 columns (default: all).  Returns y (P, N_last), the list of stored activations A_1..A_{L-1} (inputs of layers
     1..L-1) when keep_hidden, and their recorded maxima (slot j <-> A_j, slot 0 = x; None unless keep_hidden).
     row_bias (P / row_bias_div, N_0): added to the first layer's pre-activation of each group of row_bias_div
-    consecutive rows.  out = (tensor or pointer wrapper, row stride): where y goes instead of a fresh (P, N_last) tensor."""
+    consecutive rows.  out = (tensor or pointer wrapper, row stride): where y goes instead of a fresh (P, N_last) tensor.
+    blocked: the stored activations are written point-blocked (`PB`; `blocked_layout` says when that pays)."""
     P, ldx = x.shape
+    blk = 8 if (blocked and keep_hidden) else 0
     K0 = ldx if K0 is None else int(K0)
     L = len(weights)
     Ks, Ns, Wp, hidden = [], [], [], []
@@ -600,13 +658,13 @@ def chain_forward(x, weights, biases, beta=100.0, skip_layer=-1, skip_scale=1.0,
     side_am = [_slot(am, j + 1) if (keep_hidden and j < L - 1) else None for j in range(L)]
     if row_bias is None:
         _launch("chain_fwd", flops, "mlp_chain", 0, P, x, ldx, K0, L, Wp, bl,
-                Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, ldy, 0, 1, float(beta),
+                Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, ldy, blk, 1, float(beta),
                 int(skip_layer), float(skip_scale), 0, None, 0, None, None, side_am, _slot(am, 0),
                 shape=f"{P}:{K0}-" + "-".join(map(str, Ns)))
     else:
         assert P % row_bias_div == 0 and tuple(row_bias.shape) == (P // row_bias_div, Ns[0])
         _launch("chain_fwd", flops, "mlp_chain_ex", 0, P, x, ldx, K0, L, Wp, bl,
-                Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, ldy, 0, 1, float(beta),
+                Ks, Ns, [None] * L, side_out, ld_side, [None] * L, y, ldy, blk, 1, float(beta),
                 int(skip_layer), float(skip_scale), 0, None, 0, [None] * L, [None] * L, [None] * L,
                 row_bias.detach().contiguous(), int(row_bias_div), None, None, side_am, _slot(am, 0),
                 shape=f"{P}:{K0}(+rows/{row_bias_div})-" + "-".join(map(str, Ns)))
@@ -635,6 +693,7 @@ def wgrad(A, B, out=None, accum=False, amax_a=None, amax_b=None):
     None = the kernel finds it with one extra pass over the tensor."""
     P, K = A.shape
     N = B.shape[1]
+    assert not isinstance(A, PB) and not isinstance(B, PB), "point-blocked operands go through wgrad_group"
     assert A.stride(1) == 1 and B.stride(1) == 1 and B.shape[0] == P
     ws = _workspace(A.device, lib.load().ndjir_mlp_wgrad_workspace(K, N, P))
     if out is None:
@@ -685,15 +744,15 @@ def _wgrad_group_launch(jobs, extras=()):
             return
         dev = extras[0][0].device
         ws = _WORKSPACE_G.get(dev)
-        need = int(lib.load().ndjir_mlp_wgrad_group_workspace(0, None, None, None, None, 0, None, None, 0))
+        need = int(lib.load().ndjir_mlp_wgrad_group_workspace(0, None, None, None, None, 0, None, None, 0, None))
         if ws is None or ws.numel() < need:
             ws = _WORKSPACE_G[dev] = torch.empty(max(need, 1 << 24), device=dev, dtype=torch.float32)
         ex = list(extras)
         lib.call("mlp_wgrad_group", 0, None, [], None, [], [], None, None, [], 0, None, [], [], [], [], ws, 0, len(ex),
                  [_Strided(e[0]) for e in ex], [_Strided(e[1]) for e in ex], [e[2] for e in ex], [e[3] for e in ex], [e[4] for e in ex],
-                 [1] * len(ex))
+                 [1] * len(ex), [])
         return
-    A, lda, B, ldb, Ps, ama, amb, oid, outs, ldo, Ks, Ns, acc = ([] for _ in range(13))
+    A, lda, B, ldb, Ps, ama, amb, oid, outs, ldo, Ks, Ns, acc, lay = ([] for _ in range(14))
     for o, (out, accum, srcs) in enumerate(jobs):
         K, N = out.shape
         assert out.stride(1) == 1 or N == 1
@@ -705,12 +764,13 @@ def _wgrad_group_launch(jobs, extras=()):
             A.append(_Strided(a)); lda.append(a.stride(0) if a.shape[0] > 1 else K)
             B.append(_Strided(b)); ldb.append(b.stride(0) if b.shape[0] > 1 else N)
             Ps.append(a.shape[0]); ama.append(ma); amb.append(mb); oid.append(o)
+            lay.append((1 if isinstance(a, PB) else 0) | (2 if isinstance(b, PB) else 0))
     dev = jobs[0][0].device
     n, m = len(A), len(jobs)
     vp = ctypes.c_void_p
     need = int(lib.load().ndjir_mlp_wgrad_group_workspace(
         n, (vp * n)(*[t.data_ptr() for t in A]), (ctypes.c_int * n)(*lda), (ctypes.c_longlong * n)(*Ps), (ctypes.c_int * n)(*oid),
-        m, (ctypes.c_int * m)(*Ks), (ctypes.c_int * m)(*Ns), int(WGRAD_GROUP_ITEMS)))
+        m, (ctypes.c_int * m)(*Ks), (ctypes.c_int * m)(*Ns), int(WGRAD_GROUP_ITEMS), (ctypes.c_int * n)(*lay)))
     ws = _WORKSPACE_G.get(dev)
     if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
@@ -721,7 +781,7 @@ def _wgrad_group_launch(jobs, extras=()):
     ex = list(extras)
     _launch("wgrad", flops, "mlp_wgrad_group", n, A, lda, B, ldb, Ps, ama, amb, oid, m, outs, ldo, Ks, Ns, acc, ws, int(WGRAD_GROUP_ITEMS),
             len(ex), [_Strided(e[0]) for e in ex], [_Strided(e[1]) for e in ex], [e[2] for e in ex], [e[3] for e in ex],
-            [e[4] for e in ex], [1] * len(ex),
+            [e[4] for e in ex], [1] * len(ex), lay,
             shape=f"group {m} out / {n} src {flops / 2e9:.1f} GMAC " + ",".join(f"{p}:{Ks[o]}x{Ns[o]}" for p, o in list(zip(Ps, oid))[:2]))
 
 
@@ -742,6 +802,7 @@ def wgrad_group(jobs):
         if ok:
             grouped.append((out, accum, srcs))
             continue
+        assert not any(isinstance(a, PB) or isinstance(b, PB) for a, b, _, _ in srcs), "point-blocked operands need the grouped kernel"
         first = not accum
         if not srcs and first:
             out.zero_()
@@ -878,10 +939,12 @@ class FusedMLP(Function):
             out = (_Strided(Zp.view(-1)[c:]), ldz)
             w_run = weights[:-1] + [_col_tail(weights[-1])]
             b_run = biases[:-1] + [biases[-1].detach()[1:] if torch.is_tensor(biases[-1]) else None]
+        blk = train and blocked_layout(x2.shape[0], [w.shape[1] for w in w_run[:-1]], x2.is_cuda)
         y, hidden, am = chain_forward(x2, w_run, b_run, beta, skip_layer, skip_scale,
-                                      keep_hidden=train, row_bias=rb, row_bias_div=row_bias_div, out=out)
+                                      keep_hidden=train, row_bias=rb, row_bias_div=row_bias_div, out=out, blocked=blk)
         if train:
             ctx.save_for_backward(x2, *hidden, *weights, am)
+            ctx.blk = blk
             ctx.cfg = (beta, skip_layer, skip_scale, L, tuple(x.shape))
             ctx.rb = (None if row_bias is None else tuple(row_bias.shape), int(row_bias_div))
             ctx.btgt = [grad_target(b) if torch.is_tensor(b) else None for b in biases]
@@ -898,6 +961,7 @@ class FusedMLP(Function):
         beta, skip_layer, skip_scale, L, xshape = ctx.cfg
         saved = ctx.saved_tensors
         x2 = saved[0]
+        blk = ctx.blk                        # hidden tensors (stored activations, deltas) are point-blocked (`PB`)
         A = [x2] + list(saved[1:L])          # A[j] = input activation of layer j
         W = list(saved[L:2 * L])
         am = saved[2 * L]                    # recorded maxima of A[j]
@@ -985,7 +1049,7 @@ class FusedMLP(Function):
                     gb_last = torch.empty((gy2.shape[1],), device=x2.device, dtype=torch.float32)
             _launch("chain_bwd", flops, "mlp_chain", 1, P, _Strided(gy2), gy2.stride(0), gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
                      side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
-                     (1 if bwd_skip >= 0 else 0) | bg_acc, 1 if need_x else 0,
+                     (1 if bwd_skip >= 0 else 0) | bg_acc | (8 if blk else 0), 1 if need_x else 0,
                      float(beta), int(bwd_skip), float(skip_scale), int(split),
                      gx if bwd_skip >= 0 else None, K0, gb_last, chain_workspace(x2.device, bg + [gb_last]),
                      side_am, _slot(dm, L - 1), shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)))
@@ -995,7 +1059,7 @@ class FusedMLP(Function):
             jobs = []           # every weight gradient of the net: one grouped launch (or queued: `deferred_wgrads`)
             for j in range(L):
                 if ctx.needs_input_grad[7 + j]:
-                    src = [(A[j], deltas[j], _slot(am, j), _slot(dm, j) if have_dm else None)]
+                    src = [(pb(A[j], blk and j > 0), pb(deltas[j], blk and j < L - 1), _slot(am, j), _slot(dm, j) if have_dm else None)]
                     if tail and j == L - 1:
                         # the gradient of W[:, 1:] added to / placed in the parameter's columns 1.. (row stride = its width)
                         wt = grad_target(saved[2 * L - 1])
@@ -1031,7 +1095,7 @@ class FusedMLP(Function):
             d0 = deltas[0]
             G = P // rb_div
             g_rb = torch.empty((G, d0.shape[1]), device=d0.device, dtype=torch.float32)
-            lib.call("mlp_group_colsum", _Strided(d0), d0.stride(0), d0.shape[1], G, rb_div, g_rb)
+            lib.call("mlp_group_colsum", _Strided(d0), d0.stride(0), d0.shape[1], G, rb_div, g_rb, 1 if (blk and L > 1) else 0)
             g_rb = g_rb.view(rb_shape)
         return (gx.reshape(xshape) if gx is not None else None, g_rb, None, None, None, None, None, *gW, *gb)
 
@@ -1072,11 +1136,14 @@ class MultiMLP(Function):
             per_net.append((rb, list(params[off:off + L]), list(params[off + L:off + 2 * L])))
             off += 2 * L
         res = [None] * len(net_cfg)
+        blks = [False] * len(net_cfg)
         # nets of one hidden-width class next to each other: consecutive launches of a class share a launch (chain_group)
         with chain_group():
             for n in sorted(range(len(net_cfg)), key=lambda i: (_width_class(per_net[i][1]), i)):
                 (L, K0, div), (rb, W, b) = net_cfg[n], per_net[n]
-                res[n] = chain_forward(x2, W, b, beta, -1, 1.0, keep_hidden=train, row_bias=rb, row_bias_div=max(div, 1), K0=K0)
+                blks[n] = train and blocked_layout(x2.shape[0], [w.shape[1] for w in W[:-1]], x2.is_cuda)
+                res[n] = chain_forward(x2, W, b, beta, -1, 1.0, keep_hidden=train, row_bias=rb, row_bias_div=max(div, 1), K0=K0,
+                                       blocked=blks[n])
         ys, saved, btgts = [], [x2], []
         for n, (y, hidden, am) in enumerate(res):
             W, b = per_net[n][1], per_net[n][2]
@@ -1089,6 +1156,7 @@ class MultiMLP(Function):
             ctx.cfg = (float(beta), tuple(net_cfg), tuple(x.shape), [tuple(p.shape) if torch.is_tensor(p) else None for p in params],
                        bool(lazy_pad))
             ctx.btgts = btgts
+            ctx.blks = blks
         return tuple(ys)
 
     @staticmethod
@@ -1134,6 +1202,7 @@ class MultiMLP(Function):
                 if gy is None:
                     continue
                 pos, poff = spos[n], ppos[n]
+                blk = ctx.blks[n]
                 A = [x2[:, :K0]] + list(saved[pos:pos + L - 1])
                 W = Wn[n]
                 am = saved[pos + 2 * L - 1]
@@ -1171,12 +1240,12 @@ class MultiMLP(Function):
                     flops = 2.0 * P * sum(k * m for k, m in zip(Ks, Ns))
                     _launch("chain_bwd", flops, "mlp_chain", 1, P, gy2, gy2.shape[1], gy2.shape[1], steps, Wp, [None] * steps, Ks, Ns,
                             side_in, side_out, ld_side, bg, _Strided(gx) if gx is not None else None, ldg,
-                            (0 if first else 1) | bg_acc, 1 if need_x else 0, float(beta), -1, 1.0, 0, None, K0, gb_last,
+                            (0 if first else 1) | bg_acc | (8 if blk else 0), 1 if need_x else 0, float(beta), -1, 1.0, 0, None, K0, gb_last,
                             chain_workspace(dev, bg + [gb_last]), side_am, _slot(dm, L - 1), shape=f"{P}:{gy2.shape[1]}-" + "-".join(map(str, Ns)) + ("" if first else " (+=)"))
                     first = False
-                state.append((n, A, W, am, dm, deltas, bgrads, btgt, gb_last, gy2, nW, nb))
+                state.append((n, A, W, am, dm, deltas, bgrads, btgt, gb_last, gy2, nW, nb, blk))
         # phase 2: what reads the chains' outputs -- row-term gradients, weight gradients, bias gradients
-        for n, A, W, am, dm, deltas, bgrads, btgt, gb_last, gy2, nW, nb in state:
+        for n, A, W, am, dm, deltas, bgrads, btgt, gb_last, gy2, nW, nb, blk in state:
             L, K0, div = net_cfg[n]
             poff = ppos[n]
             wo = poff + (1 if div > 0 else 0)
@@ -1185,12 +1254,12 @@ class MultiMLP(Function):
                 d0 = deltas[0] if L > 1 else gy2
                 G = P // div
                 g_rb = torch.empty((G, d0.shape[1]), device=dev, dtype=torch.float32)
-                lib.call("mlp_group_colsum", _Strided(d0), d0.stride(0), d0.shape[1], G, div, g_rb)
+                lib.call("mlp_group_colsum", _Strided(d0), d0.stride(0), d0.shape[1], G, div, g_rb, 1 if (blk and L > 1) else 0)
                 out[poff - 4] = g_rb.view(pshapes[poff - 4])
             jobs = []
             for j in range(L):
                 if nW[j]:
-                    src = [(A[j], deltas[j], _slot(am, j), _slot(dm, j))]
+                    src = [(pb(A[j], blk and j > 0), pb(deltas[j], blk and j < L - 1), _slot(am, j), _slot(dm, j))]
                     wt = grad_target(W[j])
                     if wt is not None:
                         jobs += wgrad_jobs(wt, *src[0])

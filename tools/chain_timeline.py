@@ -48,7 +48,7 @@ def show(buf, L, title):
 
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "fwd"
-    P = 65536
+    P = int(os.environ.get("TIMELINE_P", "65536"))      # (fewer points than 128 x CUs: NDJIR_MLP_TILE=128 keeps the 128-point-tile kernel)
     dims = (43, 256, 256, 256, 213, 256, 256, 256, 257)
     Ws, bs = make(dims, 1, 3)
     x = torch.randn(P, 43, device="cuda")

@@ -27,8 +27,16 @@ __global__ void __launch_bounds__(512) k_side(const float* __restrict__ in, floa
           size_t off;
           if (PAT == 0) off = base + (size_t)(J * 32 + (lane & 31)) * 256 + wave * 32 + 8 * g + 4 * (lane >> 5);
           else off = base + (size_t)(J * 32 + 8 * g + (lane >> 3)) * 256 + wave * 32 + 4 * (lane & 7);
+          if (PAT == 3) off = base + ((size_t)J * 256 + wave * 32 + 8 * g + 4 * (lane >> 5)) * 32 + (lane & 31) * 4;
+          if (PAT == 2) {
+            // point-blocked layout [row block][feature][32 points]: register q of group g = feature 8 g + 4 hh + q, one dword per lane
+            const size_t o2 = base + ((size_t)J * 256 + wave * 32 + 8 * g + 4 * (lane >> 5)) * 32 + (lane & 31);
+            if (MODE != 1) { v[g] = f32x4{in[o2], in[o2 + 32], in[o2 + 64], in[o2 + 96]}; }
+            else v[g] = f32x4{(float)o2, 1.f, 2.f, 3.f};
+          } else {
           if (MODE != 1) v[g] = *reinterpret_cast<const f32x4*>(in + off);
           else v[g] = f32x4{(float)off, 1.f, 2.f, 3.f};
+          }
           if (MODE == 0) acc += v[g];
         }
         if (MODE != 0) {
@@ -37,6 +45,12 @@ __global__ void __launch_bounds__(512) k_side(const float* __restrict__ in, floa
             size_t off;
             if (PAT == 0) off = base + (size_t)(J * 32 + (lane & 31)) * 256 + wave * 32 + 8 * g + 4 * (lane >> 5);
             else off = base + (size_t)(J * 32 + 8 * g + (lane >> 3)) * 256 + wave * 32 + 4 * (lane & 7);
+            if (PAT == 3) off = base + ((size_t)J * 256 + wave * 32 + 8 * g + 4 * (lane >> 5)) * 32 + (lane & 31) * 4;
+            if (PAT == 2) {
+              const size_t o2 = base + ((size_t)J * 256 + wave * 32 + 8 * g + 4 * (lane >> 5)) * 32 + (lane & 31);
+              const f32x4 w = v[g] * 1.5f;
+              out[o2] = w[0]; out[o2 + 32] = w[1]; out[o2 + 64] = w[2]; out[o2 + 96] = w[3];
+            } else
             *reinterpret_cast<f32x4*>(out + off) = v[g] * 1.5f;
           }
         }
@@ -80,5 +94,11 @@ int main(int argc, char** argv) {
   RUN(1, 0, "B: 8 rows x 128 B per instruction, load", 1)
   RUN(1, 1, "B: 8 rows x 128 B per instruction, store", 1)
   RUN(1, 2, "B: 8 rows x 128 B per instruction, load+store", 2)
+  RUN(2, 0, "C: point-blocked, dword (2 x 128 B lines), load", 1)
+  RUN(2, 1, "C: point-blocked, dword, store", 1)
+  RUN(2, 2, "C: point-blocked, dword, load+store", 2)
+  RUN(3, 0, "D: quad-blocked, dwordx4 (2 x 512 B), load", 1)
+  RUN(3, 1, "D: quad-blocked, dwordx4, store", 1)
+  RUN(3, 2, "D: quad-blocked, dwordx4, load+store", 2)
   return 0;
 }
