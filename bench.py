@@ -46,7 +46,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_BF16X6_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_F16X3_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def parse():
@@ -127,6 +127,86 @@ def cpu_baseline(conf, step, n_rays):
     except Exception as e:
         out["cfg1"] = dict(value=None, sample=f"failed: {type(e).__name__}: {e}")
     return out
+
+
+def parity_block(conf, step, n_rays):
+    """Product vs CPU oracle at the HEADLINE configuration (the bench's own parameters -- 512^3 x 4 grid for default.yaml --
+    and the first `n_rays` of rank 0's rays): loss, pixel colours, every parameter gradient, and the sampler's indices.
+    BASELINE.json north_star: "pixel RGB and loss within 1e-4 relative; sample indices bit-exact" (indices: each side
+    evaluates its own SDF network, so an index can differ where a CDF value sits within fp32 round-off of the uniform
+    draw -- the count is reported; the round kernel itself is bit-exact given equal inputs, tests/test_gpu_sampler.py).
+    The product pass runs with 128-point tiles forced (the kernels the timed region runs; at n_rays x 128 points the
+    dispatch would otherwise pick the small-launch kernels)."""
+    from ndjir_amd import mlp
+    from ndjir_amd.loss import total_loss
+    from tests.parity_utils import rel_err, run_oracle_step
+    sl = slice(0, n_rays)
+    rand = {k: v[:, sl].contiguous() for k, v in step.rand.items()}
+    raydir, color = step.raydir[:, sl].contiguous(), step.color_gt[:, sl].contiguous()
+    for buf in step.grid_bufs.values():
+        buf.zero_()
+    old_tile = mlp.get_tile_rows()
+    mlp.set_tile_rows(128)
+    try:
+        rec_p = {}
+        out = total_loss(step.camloc, raydir, color, None, step.car, conf, rand, record=rec_p)
+        grads = torch.autograd.grad(out["loss"], step.mlp_params, allow_unused=True)
+        torch.cuda.synchronize()
+    finally:
+        mlp.set_tile_rows(old_tile)
+    params = step.P.get_parameters()
+    params_cpu = {k: v.detach().cpu() for k, v in params.items()}
+    inputs = dict(camloc=step.camloc.cpu(), raydir=raydir.cpu(), color_gt=color.cpu(),
+                  rand={k: v.cpu() for k, v in rand.items()}, cos_anneal=step.car.cpu())
+    rec_o = {}
+    ref = run_oracle_step(conf, params_cpu, inputs, record=rec_o)
+    l0, l1 = float(out["loss"]), float(ref["loss"])
+    worst, worst_name = 0.0, None
+    for name, g in zip(step.mlp_names, grads):
+        go = ref["grads"].get(name)
+        if g is None or go is None:
+            continue
+        e = rel_err(g, go)
+        if e > worst:
+            worst, worst_name = e, name
+    grid = {}
+    for name, buf in step.grid_bufs.items():
+        go = ref["grads"].get(name)
+        if go is not None:
+            grid[name] = rel_err(buf, go)
+        buf.zero_()
+    tot = mis = 0
+    for a, b in zip(rec_p.get("idx", []), rec_o.get("idx", [])):
+        tot += b.numel()
+        mis += int((a.cpu() != b).sum())
+    return {"n_rays": n_rays, "loss_rel": abs(l0 - l1) / max(abs(l1), 1e-30),
+            "pixel_max_abs": float((out["render"]["color_pixel"].detach().cpu() - ref["color_pixel"]).abs().max()),
+            "grad_rel_max": worst, "grad_rel_max_param": worst_name, "grid_grad_rel": grid,
+            "idx_mismatch": mis, "idx_total": tot,
+            "tolerances": "tests: loss 1e-4 relative, pixels 1e-4 absolute, gradients 2e-3 relative (norm-wise)",
+            "oracle": "oracle/graph.py, torch-CPU fp32: pinned to the reference for a1 / a2 / a12 / ray generation / schedules / hash "
+                      "layout / initialiser only (no executable reference for the grid, MLP, renderer arithmetic in this image)"}
+
+
+def fp32_engine_leg(step, steps=5):
+    """The same eager steps with every dense layer on the strict-fp32 engine (v_mfma_f32_32x32x2_f32, exact fp32 products,
+    csrc/mlp.hip): what the headline's emulated-fp32 arithmetic (f16 x 3) is to be read beside."""
+    from ndjir_amd import mlp
+    old = mlp.get_math()
+    mlp.set_math(mlp.MATH_FP32)
+    try:
+        for _ in range(2):
+            loss = step.forward_backward()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step.forward_backward()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return {"ms_per_step": 1e3 * el / steps, "rays_per_s": step.B * step.R * steps / el, "steps": steps, "loss": float(loss),
+                "execution": "eager stream launches", "engine": "NDJIR_MLP_MATH=fp32: fp32-input MFMA, per-layer weight gradients"}
+    finally:
+        mlp.set_math(old)
 
 
 def _all_ranks_ok(step, ok):
@@ -418,8 +498,27 @@ def kernel_detail(profile, steps):
               f"{flops / max(sec, 1e-12) / 1e12:8.1f} {nbytes / n / 1e6:8.1f} {nbytes / max(sec, 1e-12) / 1e12:6.2f}", file=sys.stderr)
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, as the driver's torchrun command would --
+    a child process (`python -m torch.distributed.run ... bench.py <same arguments>`), issued BEFORE this process touches
+    the GPU; its output is relayed, its exit code is ours.  (Never an exec: a process that initialised the GPU must not
+    replace itself.)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -678,6 +777,15 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
+            try:
+                out["parity"] = parity_block(conf, step, a.cpu_rays)
+            except Exception as e:
+                out["parity"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not force_dist and a.extra_legs:
+            try:
+                out["fp32_engine"] = fp32_engine_leg(step)
+            except Exception as e:
+                out["fp32_engine"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not force_dist and a.extra_legs:
         try:
             out["redraw"] = redraw_leg(step, graph if exec_mode == "graph" else None, loss if exec_mode == "graph" else None,

@@ -44,6 +44,7 @@ struct ChainArgs {
                         // bwd: layer whose output is that concatenated gradient
   int skip_split;       // bwd: first column of the concatenated-input part
   int lds_split;        // filled by launch_chain
+  int t64_prio;         // filled by launch_chainw_group (64-point tiles: static priority for one workgroup of a CU's pair)
   int tile_rows;        // 64 (default), 32 or 128 points per workgroup
   int forced_tile;      // tile_rows was forced by the caller (else 64 may be widened to 128 where mlp3w.hip supports the launch)
   float skip_scale;

@@ -37,8 +37,8 @@ typedef ChainGroup __attribute__((address_space(4))) KGroup;     // (the kernel-
 typedef ChainArgs __attribute__((address_space(4))) KArgs;
 typedef ChainLayer __attribute__((address_space(4))) KLayer;
 
-constexpr int TM = 128;
-constexpr int TMP = TM + 4;      // rows per k-group incl. pad: (TMP * 16) % 256 == 64 -> conflict-free plane writes
+constexpr int TM_MAX = 128;      // points per tile: 128 (one 8- or two 4-wave workgroups per CU) or 64 (TWO workgroups per CU, see below)
+constexpr int tile_pad(int tm) { return tm + 4; }      // rows per k-group incl. pad: (TMP * 16) % 256 == 64 -> conflict-free plane writes
 constexpr int IN_CACHE = 10;     // float4 groups of the chain input a thread keeps between the max pass and the split
 
 // accumulator register i of lane (r = lane & 31, hh = lane >> 5): point r of the row block, feature acc_feat(i, hh) of the
@@ -65,12 +65,21 @@ struct ManyNets {
   __device__ __forceinline__ const KArgs& get(int i) const { return g->net[i]; }
   __device__ __forceinline__ int n() const { return g->n; }
 };
-template <int MODE, int RPW, int NWAVES, class NETS>
+// TM = 64, CPW = 2 (round 5): a 4-wave workgroup on a 64-point tile, a wave owns TWO column blocks (nb, nb + 4) x both row
+// blocks -- the same 128 accumulator registers, 12 MFMAs per k-step.  Its planes (<= 74 KB) fit the LDS twice, so a CU holds TWO
+// independent workgroups, one wave of each per SIMD: while one is in its k-loop (matrix pipe) the other is in its epilogue
+// (vector pipe, memory) -- inside ONE workgroup all waves share a barrier schedule and the two phases can only add
+// (a 256-wide layer of a 128-point tile took 32 k cycles forward / 38 k backward against 12.3 k of matrix time,
+// on an idle chip as on a full one).  The price: a weight fragment feeds 2 row blocks instead of 4 (the L2 -> CU stream doubles).
+template <int MODE, int RPW, int NWAVES, int TM, int CPW, class NETS>
 __device__ __forceinline__ void chainw_body(const NETS nets) {
+  constexpr int TMP = tile_pad(TM);
   constexpr int NTHREADS = NWAVES * 64;
   constexpr bool BWD = (MODE == 1);
-  constexpr int G = 4 / RPW;           // wave groups sharing a column block's rows
-  constexpr int CB = NWAVES / G;       // column blocks per round
+  constexpr int G = (TM / 32) / RPW;   // wave groups sharing a column block's rows
+  constexpr int CB = NWAVES / G;       // column blocks per round (x CPW for a hidden layer)
+  constexpr int NBLK = RPW * CPW;      // 32 x 32 output blocks (accumulator pairs) of a wave
+  static_assert(NBLK <= 4 && (CPW == 1 || (RPW == 2 && G == 1)), "accumulator budget");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ unsigned s_rmax[2][TM];   // per row: largest finite |output| of the layer (bit pattern; ping-pong by layer)
   __shared__ unsigned s_xmax[2][TM];   // per row: largest finite |x| of the chain input tile (ping-pong by tile)
@@ -110,6 +119,14 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
 
   stamp(MAX_CHAIN_LAYERS - 1, 0);
   stamp_rt(0);
+  if constexpr (TM == 64) {
+    // Two workgroups share a CU (a grid of 512 fills the chip exactly, 256 at a time: workgroups b and b + 256 are the pair of
+    // a CU, the launcher caps the grid there).  With equal priority the two fall into step -- both in their k-loops at half
+    // speed, then both in their epilogues -- and nothing overlaps.  One of them always wins the arbitration instead: it runs
+    // as if alone, the other takes the pipe the first is not using (matrix while it is in its epilogue, vector while it
+    // multiplies), which puts them in anti-phase by itself.
+    if (a0.t64_prio && (blockIdx.x & 256) == 0) __builtin_amdgcn_s_setprio(3);
+  }
 #ifndef NDJIR_NO_L2_WARMUP
   // L2 warm-up.  A launch finds its net's packed weights cold (the previous launch streamed another net's weights and hundreds
   // of MB of activations through the 4 MB L2 of each XCD), and a layer's first k-steps on every CU of an XCD then miss together:
@@ -244,25 +261,37 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
 
       // Accumulator pairs of up to four 32 x 32 blocks (static indices only).
       f32x16 acc0[4], acc1[4];
-      // One k-loop: RPW row blocks rb0.. of column block nb, k-steps [ks0, ks1), into accumulator slots SLOT.. .
-      // Weight fragments (the MFMA's A operand here) 3 steps ahead in rotating static slots; activation fragments (B operand)
-      // per unit of two row blocks: with two units (RPW = 4) a unit's registers are reloaded for the next k-step as soon as
-      // its six MFMAs have issued, i.e. one unit = 6 MFMAs ahead of their use; with one unit they are double buffered.
-      auto kloop = [&](const int nb, const int rb0, const int ks0, const int ks1) {
-        constexpr int SLOT = 0;
+      // One k-loop: RPW row blocks rb0.. of the wave's CPW column blocks nbk[0 .. CPW), k-steps [ks0, ks1), into accumulator
+      // pairs c * RPW + q.  Weight fragments (the MFMA's A operand here) 3 steps ahead in rotating static slots; activation
+      // fragments (B operand) per unit of two row blocks: with two units (RPW = 4) a unit's registers are reloaded for the
+      // next k-step as soon as its six MFMAs have issued, i.e. one unit = 6 MFMAs ahead of their use; with one unit they are
+      // double buffered (and, CPW = 2, feed both column blocks: 12 MFMAs per pair of activation fragments).
+      auto kloop = [&](const int (&nbk)[CPW], const int rb0, const int ks0, const int ks1) {
         constexpr int U = 2;                       // row blocks per unit
         constexpr int NU = RPW / U;                // units per k-step
+        static_assert(NU == 1 || CPW == 1, "two units only with one column block");
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) { acc0[SLOT + q] = f32x16{0}; acc1[SLOT + q] = f32x16{0}; }
+        for (int q = 0; q < NBLK; ++q) { acc0[q] = f32x16{0}; acc1[q] = f32x16{0}; }
+        // A wave in its k-loop outranks a wave in its epilogue (round 5): the two waves of a SIMD leave their k-loops 5 k cycles
+        // apart -- the older one wins the matrix pipe while both multiply -- and the younger one's last 40 MFMAs then took
+        // those 5 k cycles: the older wave's epilogue, a dense vector stream, won every issue slot.  An MFMA costs its
+        // neighbour one slot in eight.
+#ifndef NDJIR_NO_KLOOP_PRIO
+        __builtin_amdgcn_s_setprio(2);
+#endif
         const int lane_k = fresh_lane();
-        const gptr<const f16x8> Bp = p_wp + ((long long)nb * KS) * 2 * 64 + lane_k;
+        gptr<const f16x8> Bp[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) Bp[c] = p_wp + ((long long)nbk[c] * KS) * 2 * 64 + lane_k;
         const f16x8* A0 = act + (lane_k >> 5) * TMP + rb0 * 32 + (lane_k & 31);
-        f16x8 b[3][2];                 // [slot][plane]
+        f16x8 b[3][CPW][2];            // [slot][column block][plane]
         f16x8 af[2][2][U];             // NU == 2: [unit][plane][row block of the unit]; NU == 1: [buffer][plane][row block]
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
 #pragma unroll
-          for (int p = 0; p < 2; ++p) b[s][p] = Bp[(long long)((ks0 + s < ks1 ? ks0 + s : ks0) * 2 + p) * 64];
+          for (int c = 0; c < CPW; ++c)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) b[s][c][p] = Bp[c][(long long)((ks0 + s < ks1 ? ks0 + s : ks0) * 2 + p) * 64];
           __builtin_amdgcn_sched_barrier(0);
         }
         {
@@ -286,20 +315,23 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
             }
             // three partial products (operands swapped: A = weights): w_hi x_lo, w_lo x_hi -> acc1; w_hi x_hi -> acc0
 #pragma unroll
-            for (int q = 0; q < U; ++q) acc1[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][1][q], acc1[SLOT + q], 0, 0, 0);
+            for (int c = 0; c < CPW; ++c) {
 #pragma unroll
-            for (int q = 0; q < U; ++q) acc0[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][0][q], acc0[SLOT + q], 0, 0, 0);
+              for (int q = 0; q < U; ++q) acc1[c * RPW + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][c][0], af[C][1][q], acc1[c * RPW + q], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < U; ++q) acc1[SLOT + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][1], af[C][0][q], acc1[SLOT + q], 0, 0, 0);
+              for (int q = 0; q < U; ++q) acc0[c * RPW + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][c][0], af[C][0][q], acc0[c * RPW + q], 0, 0, 0);
+#pragma unroll
+              for (int q = 0; q < U; ++q) acc1[c * RPW + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][c][1], af[C][0][q], acc1[c * RPW + q], 0, 0, 0);
+            }
           } else {
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
 #pragma unroll
-              for (int q = 0; q < U; ++q) acc1[SLOT + u * U + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[u][1][q], acc1[SLOT + u * U + q], 0, 0, 0);
+              for (int q = 0; q < U; ++q) acc1[u * U + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0][0], af[u][1][q], acc1[u * U + q], 0, 0, 0);
 #pragma unroll
-              for (int q = 0; q < U; ++q) acc0[SLOT + u * U + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[u][0][q], acc0[SLOT + u * U + q], 0, 0, 0);
+              for (int q = 0; q < U; ++q) acc0[u * U + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0][0], af[u][0][q], acc0[u * U + q], 0, 0, 0);
 #pragma unroll
-              for (int q = 0; q < U; ++q) acc1[SLOT + u * U + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][1], af[u][0][q], acc1[SLOT + u * U + q], 0, 0, 0);
+              for (int q = 0; q < U; ++q) acc1[u * U + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0][1], af[u][0][q], acc1[u * U + q], 0, 0, 0);
               if (nxt) {
 #pragma unroll
                 for (int q = 0; q < U; ++q) { af[u][0][q] = An[(u * U + q) * 32]; af[u][1][q] = An[PLANE + (u * U + q) * 32]; }
@@ -309,7 +341,9 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
           }
           if (!GUARD || ks + 3 < ks1) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) b[S][p] = Bp[(long long)((ks + 3) * 2 + p) * 64];
+            for (int c = 0; c < CPW; ++c)
+#pragma unroll
+              for (int p = 0; p < 2; ++p) b[S][c][p] = Bp[c][(long long)((ks + 3) * 2 + p) * 64];
           }
           __builtin_amdgcn_sched_barrier(0);
         };
@@ -334,6 +368,9 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
             if (ks + 5 < ks1) kstep(S2{}, S1{}, T{}, ks + 5);
           }
         }
+#ifndef NDJIR_NO_KLOOP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
       };
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
@@ -350,59 +387,71 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
       // k-loop -- and are summed in a fixed order: the order of mlp3.hip's split-K path, whatever the tile height.
       {
         const bool narrow = NB == 1;
-        const int nrounds = (NB + CB - 1) / CB;       // (> 1 only for an output layer)
+        const int nrounds = (NB + CB * CPW - 1) / (CB * CPW);       // (> 1 only for an output layer)
         const int wc = narrow ? 0 : wave % CB;        // column of the round
         const int wg = narrow ? wave >> 2 : wave / CB;   // row group
         const int kq = wave & 3;
         const int ks0 = narrow ? (KS * kq) / 4 : 0, ks1 = narrow ? (KS * (kq + 1)) / 4 : KS;
-        int nb = 0;
+        int nbc[CPW];                                 // the wave's column blocks of the round: wc, wc + CB
+        bool actc[CPW];                               // ... that exist (a missing one is computed as a copy of the first, and ignored)
         const int rb0 = wg * RPW;
         bool active = false;
 #pragma unroll 1
         for (int round = 0; round < nrounds; ++round) {
-          nb = CB * round + wc;
-          active = nb < NB && wg < G;
-          if (active) kloop(nb, rb0, ks0, ks1);         // (the kernel's only k-loop instantiation)
+          int nbk[CPW];
+#pragma unroll
+          for (int c = 0; c < CPW; ++c) {
+            nbc[c] = CB * CPW * round + wc + c * CB;
+            actc[c] = nbc[c] < NB && wg < G && !(narrow && c > 0);
+            nbk[c] = actc[c] ? nbc[c] : nbc[0];
+          }
+          active = actc[0];
+          if (active) kloop(nbk, rb0, ks0, ks1);        // (the kernel's only k-loop instantiation)
           if (round == 0) stamp(li, 1);
           if (narrow) break;
           if (!last || !active) continue;
           // ---- output layer: z = acc / scales (+ bias) -> Y ----
           const int lane_o = fresh_lane();
           const int r_o = lane_o & 31, hh = lane_o >> 5;
-          const int fb = nb * 32 + 4 * hh;
-          const float winv = p_winv[nb];
-          // (16-byte stores at whatever alignment the rows have: the geometric net's output lives at Z + 2 floats, the packed
-          // first-order pass's at Z + 3, ndjir_amd/geometric.py / mlp.py)
-          const bool vec_y = (nb * 32 + 31 < l_N);
-          f32x4 bias4[4];
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
+          for (int c = 0; c < CPW; ++c) {
+            if (!actc[c]) continue;
+            const int nb = nbc[c];
+            const int fb = nb * 32 + 4 * hh;
+            const float winv = p_winv[nb];
+            // (16-byte stores at whatever alignment the rows have: the geometric net's output lives at Z + 2 floats, the packed
+            // first-order pass's at Z + 3, ndjir_amd/geometric.py / mlp.py)
+            const bool vec_y = (nb * 32 + 31 < l_N);
+            f32x4 bias4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bias4[g][q] = (MODE == 0 && p_bias && fb + 8 * g + q < l_N) ? p_bias[fb + 8 * g + q] : 0.f;
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int J = 0; J < RPW; ++J) {
-            const int R = (rb0 + J) * 32 + r_o;
-            const float sa = s_ainv[R];
-            float* y = a.Y + (row0 + R) * a.ldy + fb;
+              for (int q = 0; q < 4; ++q) bias4[g][q] = (MODE == 0 && p_bias && fb + 8 * g + q < l_N) ? p_bias[fb + 8 * g + q] : 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              f32x4 t;
+            for (int J = 0; J < RPW; ++J) {
+              const int R = (rb0 + J) * 32 + r_o;
+              const float sa = s_ainv[R];
+              float* y = a.Y + (row0 + R) * a.ldy + fb;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float z = out_z(acc_sum(acc0[J][4 * g + q], acc1[J][4 * g + q]), sa, winv);
-                t[q] = MODE == 0 ? out_add(z, bias4[g][q]) : z;
-              }
-              if (vec_y) {
-                if (a.accum_y) {
-                  const f32x4 y0 = *reinterpret_cast<const f32x4u*>(y + 8 * g);
+              for (int g = 0; g < 4; ++g) {
+                f32x4 t;
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) t[q] = out_add(t[q], y0[q]);
+                for (int q = 0; q < 4; ++q) {
+                  const float z = out_z(acc_sum(acc0[c * RPW + J][4 * g + q], acc1[c * RPW + J][4 * g + q]), sa, winv);
+                  t[q] = MODE == 0 ? out_add(z, bias4[g][q]) : z;
                 }
-                *reinterpret_cast<f32x4u*>(y + 8 * g) = t;
-              } else {
+                if (vec_y) {
+                  if (a.accum_y) {
+                    const f32x4 y0 = *reinterpret_cast<const f32x4u*>(y + 8 * g);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                  if (fb + 8 * g + q < l_N) y[8 * g + q] = a.accum_y ? out_add(t[q], y[8 * g + q]) : t[q];
+                    for (int q = 0; q < 4; ++q) t[q] = out_add(t[q], y0[q]);
+                  }
+                  *reinterpret_cast<f32x4u*>(y + 8 * g) = t;
+                } else {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q)
+                    if (fb + 8 * g + q < l_N) y[8 * g + q] = a.accum_y ? out_add(t[q], y[8 * g + q]) : t[q];
+                }
               }
             }
           }
@@ -456,10 +505,33 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
           // lane-derived values: (re)assigned from a fresh opaque lane id at the top of every variant of `run` below, so that
           // each variant's copies live inside its own code region (a copy shared by all variants is spilled once ANY of them
           // runs out of registers -- and a scratch reload waits for `vmcnt(0)`, i.e. for every side load in flight)
-          int lane_o, r_o, hh, fb;                          // fb: first feature of register group 0
-          auto lane_values = [&]() { lane_o = fresh_lane(); r_o = lane_o & 31; hh = lane_o >> 5; fb = nb * 32 + 4 * hh; };
-          const float winv = pin(p_winv[nb]);               // (scalar register: uniform)
-          const bool full = (nb * 32 + 31 < nlim) && (l_ld & 3) == 0 && (!p_rowbias || (l_N & 3) == 0);
+          // Block B = c * RPW + q of the wave: column block nbc[c], row block rb0 + q.
+          int lane_o, r_o, hh, fbc[CPW];                    // fbc: first feature of register group 0 of the column block
+          auto lane_values = [&]() {
+            lane_o = fresh_lane(); r_o = lane_o & 31; hh = lane_o >> 5;
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) fbc[c] = nbc[c] * 32 + 4 * hh;
+          };
+          // Prologue loads (column-block scales, biases, the first blocks' side tensors) are ISSUED TOGETHER at the top of
+          // `run` and waited for once, behind the 64 accumulator sums: one round trip instead of five in a row (round 5: a
+          // wave spent 5 - 7 k cycles between the end of its k-loop and its first block -- `winv` was pinned to a scalar
+          // register by a load + vmcnt(0) + readfirstlane, then each of the four bias vectors was loaded, waited for with
+          // vmcnt(0) and multiplied, with a scratch reload of the multiplier in between)
+          float winv_raw[CPW], winvc[CPW];                  // winvc: scalar registers (uniform)
+          bool full = (l_ld & 3) == 0 && (!p_rowbias || (l_N & 3) == 0), full_cols = true;
+#pragma unroll
+          for (int c = 0; c < CPW; ++c)
+            if (actc[c] && !(nbc[c] * 32 + 31 < nlim)) full_cols = false;
+          auto load_winv = [&]() {
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) winv_raw[c] = p_winv[actc[c] ? nbc[c] : nbc[0]];
+          };
+          auto pin_winv = [&]() {
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) winvc[c] = pin(winv_raw[c]);
+          };
+          full = full && full_cols;
+          const bool two = CPW == 1 || actc[CPW - 1];       // (the second column block exists: blocks RPW .. are live)
           const long long tile_off = row0 * l_ld;           // uniform base + 32-bit lane offset: one address register per access
           // the accumulator pairs become single values at once: acc1 is dead from then on.  Issued AFTER the first two blocks'
           // side loads (their latency covers the 64 multiply-adds) and fenced: left to itself the scheduler sinks every sum
@@ -467,23 +539,37 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
           // (`s_waitcnt vmcnt(0)`: scratch and global loads share one in-order counter) then drain every side load in flight
           auto sum_accs = [&]() {
 #pragma unroll
-            for (int J = 0; J < RPW; ++J)
+            for (int J = 0; J < NBLK; ++J)
 #pragma unroll
               for (int i = 0; i < 16; ++i) acc0[J][i] = acc_sum(acc0[J][i], acc1[J][i]);
             __builtin_amdgcn_sched_barrier(0);
           };
-          f32x4 bbv[4];                                     // forward: bias * beta log2(e)
-          auto load_bias = [&](auto ft) {
+          f32x4 bbv[CPW][4];                                // forward: bias * beta log2(e)
+          auto load_bias = [&](auto ft) {                   // (the loads; `scale_bias` multiplies once they are in)
             constexpr bool FULL = decltype(ft)::value;
             if (MODE == 0) {
 #pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                if (FULL && (l_ld & 3) == 0 && p_bias) bbv[g] = *((gptr<const f32x4>)(p_bias + (unsigned)(fb + 8 * g))) * b2;
-                else {
+              for (int c = 0; c < CPW; ++c)
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) bbv[g][q] = (p_bias && fb + 8 * g + q < l_N ? p_bias[fb + 8 * g + q] : 0.f) * b2;
+                for (int g = 0; g < 4; ++g) {
+                  const int fb = fbc[c];
+                  bbv[c][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                  if (FULL && (l_ld & 3) == 0) { if (p_bias) bbv[c][g] = *((gptr<const f32x4>)(p_bias + (unsigned)(fb + 8 * g))); }
+                  else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bbv[c][g][q] = (p_bias && fb + 8 * g + q < l_N) ? p_bias[fb + 8 * g + q] : 0.f;
+                  }
                 }
-              }
+            }
+          };
+          auto scale_bias = [&]() {
+            if (MODE == 0) {
+#pragma unroll
+              for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) bbv[c][g][q] = bbv[c][g][q] * b2;
             }
           };
           f32x4 hs[2][4], ex[2][4];                         // backward / tangent: side loads, one block ahead
@@ -495,32 +581,32 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
             constexpr bool BLK = decltype(lt)::value;
             if (BLK) {
               // point-blocked tensors: register (g, q) of the 32 lanes of a half-wave = 32 consecutive points of feature
-              // fb + 8 g + q = one 128-byte line; one address register, the feature in the instruction's offset field
-              const unsigned boff = ((unsigned)(rb0 + J) * (unsigned)l_ld + (unsigned)fb) * 32u + (unsigned)r_o;
+              // fbc[J / RPW] + 8 g + q = one 128-byte line; one address register, the feature in the instruction's offset field
+              const unsigned boff = ((unsigned)(rb0 + J % RPW) * (unsigned)l_ld + (unsigned)fbc[J / RPW]) * 32u + (unsigned)r_o;
               const gptr<const float> b_in = p_side_in + tile_off + boff;
 #pragma unroll
               for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hs[J & 1][g][q] = (FULL || fb + 8 * g + q < nlim) ? b_in[(8 * g + q) * 32] : 0.f;
+                for (int q = 0; q < 4; ++q) hs[J & 1][g][q] = (FULL || fbc[J / RPW] + 8 * g + q < nlim) ? b_in[(8 * g + q) * 32] : 0.f;
               if (HAS_EX) {
                 const gptr<const float> b_ex = p_side_ex + tile_off + boff;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) ex[J & 1][g][q] = (FULL || fb + 8 * g + q < nlim) ? b_ex[(8 * g + q) * 32] : 0.f;
+                  for (int q = 0; q < 4; ++q) ex[J & 1][g][q] = (FULL || fbc[J / RPW] + 8 * g + q < nlim) ? b_ex[(8 * g + q) * 32] : 0.f;
               }
               return;
             }
-            const unsigned rowoff = (unsigned)((rb0 + J) * 32 + r_o) * (unsigned)l_ld + (unsigned)fb;
+            const unsigned rowoff = (unsigned)((rb0 + J % RPW) * 32 + r_o) * (unsigned)l_ld + (unsigned)fbc[J / RPW];
             // full rows: instruction g reads chunk (lane & 3) of point (r & ~3) + g; hidden_block transposes the quads back
-            const unsigned rowoff_t = (unsigned)((rb0 + J) * 32 + (r_o & ~3)) * (unsigned)l_ld + (unsigned)(nb * 32 + 8 * (r_o & 3) + 4 * hh);
+            const unsigned rowoff_t = (unsigned)((rb0 + J % RPW) * 32 + (r_o & ~3)) * (unsigned)l_ld + (unsigned)(nbc[J / RPW] * 32 + 8 * (r_o & 3) + 4 * hh);
             const gptr<const float> b_in = p_side_in + tile_off;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               if (FULL) hs[J & 1][g] = *((gptr<const f32x4>)(b_in + (rowoff_t + (unsigned)g * (unsigned)l_ld)));
               else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hs[J & 1][g][q] = fb + 8 * g + q < nlim ? b_in[rowoff + 8 * g + q] : 0.f;
+                for (int q = 0; q < 4; ++q) hs[J & 1][g][q] = fbc[J / RPW] + 8 * g + q < nlim ? b_in[rowoff + 8 * g + q] : 0.f;
               }
             }
             if (HAS_EX) {
@@ -530,7 +616,7 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
                 if (FULL) ex[J & 1][g] = *((gptr<const f32x4>)(b_ex + (rowoff_t + (unsigned)g * (unsigned)l_ld)));
                 else {
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) ex[J & 1][g][q] = fb + 8 * g + q < nlim ? b_ex[rowoff + 8 * g + q] : 0.f;
+                  for (int q = 0; q < 4; ++q) ex[J & 1][g][q] = fbc[J / RPW] + 8 * g + q < nlim ? b_ex[rowoff + 8 * g + q] : 0.f;
                 }
               }
             }
@@ -543,15 +629,15 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
             constexpr bool FULL = decltype(ft)::value;
             constexpr bool BLK = decltype(lt)::value;
             if (!p_side_out) return;
-            const unsigned rowoff = (unsigned)((rb0 + J) * 32 + r_o) * (unsigned)l_ld + (unsigned)fb;
+            const unsigned rowoff = (unsigned)((rb0 + J % RPW) * 32 + r_o) * (unsigned)l_ld + (unsigned)fbc[J / RPW];
             const gptr<float> b_out = p_side_out + tile_off;
             const int lim = MODE == 0 ? l_N : nlim;
             if (BLK) {
-              const gptr<float> b_blk = b_out + (((unsigned)(rb0 + J) * (unsigned)l_ld + (unsigned)fb) * 32u + (unsigned)r_o);
+              const gptr<float> b_blk = b_out + (((unsigned)(rb0 + J % RPW) * (unsigned)l_ld + (unsigned)fbc[J / RPW]) * 32u + (unsigned)r_o);
 #pragma unroll
               for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (FULL || fb + 8 * g + q < lim) b_blk[(8 * g + q) * 32] = acc0[J][4 * g + q];
+                for (int q = 0; q < 4; ++q) if (FULL || fbc[J / RPW] + 8 * g + q < lim) b_blk[(8 * g + q) * 32] = acc0[J][4 * g + q];
               return;
             }
             if (FULL && MODE == 0) {
@@ -566,14 +652,14 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
 #pragma unroll
               for (int g = 0; g < 4; ++g) t[g] = f32x4{acc0[J][4 * g], acc0[J][4 * g + 1], acc0[J][4 * g + 2], acc0[J][4 * g + 3]};
               quad_transpose(t, lane_o);
-              const unsigned rowoff_t = (unsigned)((rb0 + J) * 32 + (r_o & ~3)) * (unsigned)l_ld + (unsigned)(nb * 32 + 8 * (r_o & 3) + 4 * hh);
+              const unsigned rowoff_t = (unsigned)((rb0 + J % RPW) * 32 + (r_o & ~3)) * (unsigned)l_ld + (unsigned)(nbc[J / RPW] * 32 + 8 * (r_o & 3) + 4 * hh);
 #pragma unroll
               for (int g = 0; g < 4; ++g) *((gptr<f32x4>)(b_out + (rowoff_t + (unsigned)g * (unsigned)l_ld))) = t[g];
             } else {
 #pragma unroll
               for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < lim) b_out[rowoff + 8 * g + q] = acc0[J][4 * g + q];
+                for (int q = 0; q < 4; ++q) if (fbc[J / RPW] + 8 * g + q < lim) b_out[rowoff + 8 * g + q] = acc0[J][4 * g + q];
             }
           };
           auto hidden_block = [&](auto jt, auto ft, auto et, auto lt) {
@@ -581,13 +667,13 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
             constexpr bool FULL = decltype(ft)::value;
             constexpr bool HAS_EX = decltype(et)::value;      // backward: an extra adjoint is added (tangent: always has s)
             constexpr bool BLK = decltype(lt)::value;         // point-blocked side tensors: nothing to transpose
-            const int R = (rb0 + J) * 32 + r_o;             // row of the tile
+            const int R = (rb0 + J % RPW) * 32 + r_o;             // row of the tile
             const float sa = s_ainv[R];
-            const unsigned rowoff = (unsigned)R * (unsigned)l_ld + (unsigned)fb;
+            const unsigned rowoff = (unsigned)R * (unsigned)l_ld + (unsigned)fbc[J / RPW];
             if (MODE == 0) {
-              const float kk = fwd_kk(sa, winv, b2);
+              const float kk = fwd_kk(sa, winvc[J / RPW], b2);
               gptr<const float> rbp = nullptr;
-              if (p_rowbias) rbp = p_rowbias + (long long)((unsigned)(row0 + R) / (unsigned)rb_div) * l_N + fb;
+              if (p_rowbias) rbp = p_rowbias + (long long)((unsigned)(row0 + R) / (unsigned)rb_div) * l_N + fbc[J / RPW];
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
                 f32x4 rbv = {0.f, 0.f, 0.f, 0.f};
@@ -595,21 +681,21 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
                   if (FULL) rbv = *((gptr<const f32x4>)(rbp + 8 * g));
                   else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < l_N) rbv[q] = rbp[8 * g + q];
+                    for (int q = 0; q < 4; ++q) if (fbc[J / RPW] + 8 * g + q < l_N) rbv[q] = rbp[8 * g + q];
                   }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                   const int i = 4 * g + q;
-                  float u = fwd_u(acc0[J][i], kk, bbv[g][q]);       // b2 * (pre-activation)
-                  u = fwd_u_rowbias(u, rbv[q], b2);                // (rbv = 0 without a row term: fma(0, b2, u) = u exactly)
+                  float u = fwd_u(acc0[J][i], kk, bbv[J / RPW][g][q]);       // b2 * (pre-activation)
+                  if (p_rowbias) u = fwd_u_rowbias(u, rbv[q], b2);   // (uniform branch; without a row term fma(0, b2, u) = u exactly)
                   float v = softplus_u(u, ib2sc);
-                  if (!FULL) v = (fb + 8 * g + q < nlim) ? v : 0.f;
+                  if (!FULL) v = (fbc[J / RPW] + 8 * g + q < nlim) ? v : 0.f;
                   acc0[J][i] = v;
                 }
               }
             } else {
-              const float saw = sa * winv;
+              const float saw = sa * winvc[J / RPW];
               if (FULL && !BLK) {        // the side loads came in by full rows: back to "four chunks of my point"
                 quad_transpose(hs[J & 1], lane_o);
                 if (HAS_EX) quad_transpose(ex[J & 1], lane_o);
@@ -620,14 +706,14 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                   const int i = 4 * g + q;
-                  const float zz = acc0[J][i] * saw;          // (sa, winv: powers of two -- one exact product)
+                  const float zz = acc0[J][i] * saw;          // (sa, winvc[J / RPW]: powers of two -- one exact product)
                   const float e = __builtin_amdgcn_exp2f(nb2 * hs[J & 1][g][q]);
                   const float sp = __builtin_fmaf(-e, sc, sc);   // softplus' (1 - e) * (skip scale)
                   float v;
                   if (MODE == 1) v = HAS_EX ? zz * sp + ex[J & 1][g][q] : zz * sp;
                   else { v = zz * sp; x2[q] = beta * zz * ex[J & 1][g][q] * e; }
                   if (!FULL) {
-                    const int f = fb + 8 * g + q;
+                    const int f = fbc[J / RPW] + 8 * g + q;
                     if (MODE == 1 && is_skip && a.Xskip && f >= a.skip_split && f < l_N)
                       a.Xskip[(row0 + R) * a.ld_xskip + (f - a.skip_split)] = zz * sc;
                     if (f >= nlim) { v = 0.f; x2[q] = 0.f; }
@@ -637,20 +723,20 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
                 if (MODE == 2 && p_side_out2) {
                   const gptr<float> b_out2 = p_side_out2 + tile_off;
                   if (BLK) {
-                    const gptr<float> b_blk = b_out2 + (((unsigned)(rb0 + J) * (unsigned)l_ld + (unsigned)fb) * 32u + (unsigned)r_o);
+                    const gptr<float> b_blk = b_out2 + (((unsigned)(rb0 + J % RPW) * (unsigned)l_ld + (unsigned)fbc[J / RPW]) * 32u + (unsigned)r_o);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (FULL || fb + 8 * g + q < nlim) b_blk[(8 * g + q) * 32] = x2[q];
+                    for (int q = 0; q < 4; ++q) if (FULL || fbc[J / RPW] + 8 * g + q < nlim) b_blk[(8 * g + q) * 32] = x2[q];
                   } else if (FULL) ex[J & 1][g] = x2;      // (its s values are consumed: the second output leaves by full rows below)
                   else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (fb + 8 * g + q < nlim) b_out2[rowoff + 8 * g + q] = x2[q];
+                    for (int q = 0; q < 4; ++q) if (fbc[J / RPW] + 8 * g + q < nlim) b_out2[rowoff + 8 * g + q] = x2[q];
                   }
                 }
               }
               if (MODE == 2 && FULL && !BLK && p_side_out2) {
                 const gptr<float> b_out2 = p_side_out2 + tile_off;
                 quad_transpose(ex[J & 1], lane_o);
-                const unsigned rowoff_t = (unsigned)((rb0 + J) * 32 + (r_o & ~3)) * (unsigned)l_ld + (unsigned)(nb * 32 + 8 * (r_o & 3) + 4 * hh);
+                const unsigned rowoff_t = (unsigned)((rb0 + J % RPW) * 32 + (r_o & ~3)) * (unsigned)l_ld + (unsigned)(nbc[J / RPW] * 32 + 8 * (r_o & 3) + 4 * hh);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) *((gptr<f32x4>)(b_out2 + (rowoff_t + (unsigned)g * (unsigned)l_ld))) = ex[J & 1][g];
               }
@@ -672,10 +758,14 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
           };
           auto run = [&](auto ft, auto et, auto lt) {
             lane_values();
+            load_winv();
             load_bias(ft);
             if (MODE != 0) side_loads(I0{}, ft, et, lt);
             if (MODE != 0) side_loads(I1{}, ft, et, lt);
             sum_accs();
+            pin_winv();
+            scale_bias();
+            __builtin_amdgcn_sched_barrier(0);
             // (diagnostic build -DNDJIR_CHAIN_SUBSTAMP, tools/chain_timeline.py sub: stamps of layer 2's row blocks in timeline slot 5)
 #ifdef NDJIR_CHAIN_SUBSTAMP
 #define NDJIR_SUB(P) if (li == 2) stamp(5, P)
@@ -688,29 +778,31 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
             hidden_block(I0{}, ft, et, lt);
             __builtin_amdgcn_sched_barrier(0);
             NDJIR_SUB(1);
-            if constexpr (RPW > 2) { if (MODE != 0) side_loads(I2{}, ft, et, lt); }
+            if constexpr (NBLK > 2) { if (MODE != 0 && two) side_loads(I2{}, ft, et, lt); }
             hidden_block(I1{}, ft, et, lt);
             __builtin_amdgcn_sched_barrier(0);
             NDJIR_SUB(2);
-            if constexpr (RPW > 2) {
-              if (MODE != 0) side_loads(I3{}, ft, et, lt);
-              hidden_block(I2{}, ft, et, lt);
-              __builtin_amdgcn_sched_barrier(0);
-              NDJIR_SUB(3);
-              hidden_block(I3{}, ft, et, lt);
-              __builtin_amdgcn_sched_barrier(0);
-              NDJIR_SUB(4);
+            if constexpr (NBLK > 2) {
+              if (two) {
+                if (MODE != 0) side_loads(I3{}, ft, et, lt);
+                hidden_block(I2{}, ft, et, lt);
+                __builtin_amdgcn_sched_barrier(0);
+                NDJIR_SUB(3);
+                hidden_block(I3{}, ft, et, lt);
+                __builtin_amdgcn_sched_barrier(0);
+                NDJIR_SUB(4);
+              }
             }
 #undef NDJIR_SUB
             if (MODE == 1) {
               side_store(I0{}, ft, lt);
               side_store(I1{}, ft, lt);
-              if constexpr (RPW > 2) { side_store(I2{}, ft, lt); side_store(I3{}, ft, lt); }
+              if constexpr (NBLK > 2) { if (two) { side_store(I2{}, ft, lt); side_store(I3{}, ft, lt); } }
             }
           };
           if (a.side_blocked) {
             // (point-blocked side tensors: a block is "full" whatever the row stride)
-            const bool full_b = (nb * 32 + 31 < nlim) && (!p_rowbias || (l_N & 3) == 0);
+            const bool full_b = full_cols && (!p_rowbias || (l_N & 3) == 0);
             if constexpr (MODE == 1) {
               if (p_side_ex) { if (full_b) run(TT{}, TT{}, TT{}); else run(FF{}, TT{}, TT{}); }
               else { if (full_b) run(TT{}, FF{}, TT{}); else run(FF{}, FF{}, TT{}); }
@@ -733,15 +825,19 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
           if (MODE != 0 && p_bgrad) {
             lane_values();
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              float c = acc0[0][i] + acc0[1][i];
-              if constexpr (RPW > 2) c += acc0[2][i] + acc0[3][i];
-              c += dpp<DPP_XOR1>(c);
-              c += dpp<DPP_XOR2>(c);
-              c += dpp<DPP_HALF_MIRROR>(c);
-              c += dpp<DPP_MIRROR>(c);
-              const int f = fb + acc_feat(i, 0);
-              if ((lane_o & 15) == 0 && f < nlim) atomicAdd(p_bgrad + f, c);
+            for (int cb = 0; cb < CPW; ++cb) {
+              if (cb > 0 && !two) break;
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                float c = acc0[cb * RPW][i] + acc0[cb * RPW + 1][i];
+                if constexpr (RPW > 2) c += acc0[2][i] + acc0[3][i];
+                c += dpp<DPP_XOR1>(c);
+                c += dpp<DPP_XOR2>(c);
+                c += dpp<DPP_HALF_MIRROR>(c);
+                c += dpp<DPP_MIRROR>(c);
+                const int f = fbc[cb] + acc_feat(i, 0);
+                if ((lane_o & 15) == 0 && f < nlim) atomicAdd(p_bgrad + f, c);
+              }
             }
           }
         }
@@ -759,10 +855,11 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
         if (active) {
           const int lane_o = fresh_lane();
           const int r_o = lane_o & 31, hh = lane_o >> 5;
-          const int kb = nb * 32 + 4 * hh;
 #pragma unroll
-          for (int J = 0; J < RPW; ++J) {
-            const int R = (rb0 + J) * 32 + r_o;
+          for (int J = 0; J < NBLK; ++J) {
+            if (J >= RPW && !actc[CPW - 1]) break;
+            const int kb = nbc[J / RPW] * 32 + 4 * hh;
+            const int R = (rb0 + J % RPW) * 32 + r_o;
             float s_row, inv_row;
             scale_from_max(s_rmax[cur][R], s_row, inv_row);
 #pragma unroll
@@ -828,13 +925,14 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
   }
 }
 
-template <int MODE, int RPW, int NWAVES>
+// TMv = 128: <RPW, NWAVES> = <4, 8>, <2, 8>, <4, 4>;  TMv = 64: <2, 4> with two column blocks per wave (two workgroups per CU)
+template <int MODE, int RPW, int NWAVES, int TMv = 128>
 __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
-  chainw_body<MODE, RPW, NWAVES>(OneNet{a});
+  chainw_body<MODE, RPW, NWAVES, TMv, TMv == 64 ? 2 : 1>(OneNet{a});
 }
-template <int MODE, int RPW, int NWAVES>
+template <int MODE, int RPW, int NWAVES, int TMv = 128>
 __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw_nets(ChainGroup /* read in the kernel-argument segment */) {
-  chainw_body<MODE, RPW, NWAVES>(ManyNets{(const KGroup*)__builtin_amdgcn_kernarg_segment_ptr()});
+  chainw_body<MODE, RPW, NWAVES, TMv, TMv == 64 ? 2 : 1>(ManyNets{(const KGroup*)__builtin_amdgcn_kernarg_segment_ptr()});
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -854,7 +952,7 @@ struct WidePlan {
 
 static int wide_plan(const ChainArgs& a, int mode, WidePlan& p) {
   using namespace x3w;
-  if ((a.P % TM) != 0) return NDJIR_ERR_UNSUPPORTED;
+  if ((a.P % TM_MAX) != 0) return NDJIR_ERR_UNSUPPORTED;
   if (a.P < 128 * 256 && a.tile_rows != 128) return NDJIR_ERR_UNSUPPORTED;      // (a forced 128 takes small launches too: tests)
   int wmax = round_up(a.K0, 16), hmax = 0;
   for (int i = 0; i < a.L; ++i) {
@@ -868,7 +966,7 @@ static int wide_plan(const ChainArgs& a, int mode, WidePlan& p) {
   p.wmax = wmax;
   p.b = a;
   p.b.K0p = round_up(a.K0, 16);
-  p.b.n_tiles = a.P / TM;
+  p.b.n_tiles = a.P / TM_MAX;       // (the launcher divides by its tile height)
   p.bg_n = 0;
   int bg_total = 0;
   if (mode != 0) {
@@ -900,13 +998,24 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
   constexpr int LDS_DYN_MAX = 160 * 1024 - 4096;      // the kernel also holds 2.5 KB of static LDS (row maxima / scales)
   if (n < 1 || n > MAX_GROUP_NETS) return NDJIR_ERR_UNSUPPORTED;
   static bool attr_set = false;
-  static int nw4 = 1;
+  static int nw4 = 1, t64 = 0;
   if (!attr_set) {
 #define NDJIR_SET(M, R, W) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw<M, R, W>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX); \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw_nets<M, R, W>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX)
     NDJIR_SET(0, 4, 8); NDJIR_SET(1, 4, 8); NDJIR_SET(2, 4, 8); NDJIR_SET(0, 2, 8); NDJIR_SET(1, 2, 8); NDJIR_SET(2, 2, 8);
     NDJIR_SET(0, 4, 4); NDJIR_SET(1, 4, 4); NDJIR_SET(2, 4, 4);
 #undef NDJIR_SET
+#define NDJIR_SET64(M) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw<M, 2, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX); \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw_nets<M, 2, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX)
+    NDJIR_SET64(0); NDJIR_SET64(1); NDJIR_SET64(2);
+#undef NDJIR_SET64
+    // 64-point tiles, two 4-wave workgroups per CU, for nets with hidden layers wider than 128 columns whose planes + bias sums fit
+    // the LDS twice (see chainw_body): bit 0 forward, bit 1 backward, bit 2 tangent.  OFF by default (NDJIR_CHAINW_T64=7 switches
+    // it on): measured round 5, same box, default step 8.40 ms with it against 8.10 without -- the two workgroups of a CU fall
+    // into step (k-loops together, epilogues together) with or without a static priority for one of them, a layer of a 64-point
+    // tile takes the 30 - 33 k cycles the 128-point tile takes, and the tangent chain is 40 % slower (its weights stream twice)
+    const char* e64 = getenv("NDJIR_CHAINW_T64");
+    t64 = e64 ? atoi(e64) : 0;
     // 4-wave workgroups (two per CU) for nets of up to 4 column blocks whose planes fit twice: bit 0 forward, bit 1 backward,
     // bit 2 tangent.  Measured (env-light / soft-visibility nets, 131072 points): forward 145 -> 133 us, backward 166 -> 173 us
     const char* e = getenv("NDJIR_CHAINW_NW4");
@@ -925,10 +1034,18 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
     if (plan[i].wmax > wmax) wmax = plan[i].wmax;
     bg_sum += plan[i].bg_total;
     // (the decision a launch of this net alone takes: its planes + its own accumulators)
-    own_four[i] = plan[i].rpw != 4 && ((nw4 >> mode) & 1) && (size_t)2 * (plan[i].wmax / 8) * TMP * 16 + (size_t)plan[i].bg_total * 4 <= 77 * 1024;
+    own_four[i] = plan[i].rpw != 4 && ((nw4 >> mode) & 1) && (size_t)2 * (plan[i].wmax / 8) * tile_pad(128) * 16 + (size_t)plan[i].bg_total * 4 <= 77 * 1024;
   }
   const int rpw = plan[0].rpw;
-  const int lds_split = (wmax / 8) * TMP;                      // 16-byte units per plane
+  // (two workgroups per CU: 2 x (dynamic + static) <= 160 KB; the 64-point kernel holds 1.3 KB of static LDS)
+  constexpr size_t LDS_HALF = 80 * 1024 - 1536;
+  const bool tile64 = rpw == 4 && ((t64 >> mode) & 1) && (size_t)2 * (wmax / 8) * tile_pad(64) * 16 + (size_t)bg_sum * 4 <= LDS_HALF;
+  if (n > 1)            // (a group runs the kernel each of its nets would run alone: the grid its deferred bias partials were laid out for)
+    for (int i = 0; i < n; ++i)
+      if (((size_t)2 * (plan[i].wmax / 8) * tile_pad(64) * 16 + (size_t)plan[i].bg_total * 4 <= LDS_HALF) != tile64 && rpw == 4 && ((t64 >> mode) & 1))
+        return NDJIR_ERR_UNSUPPORTED;
+  const int tm = tile64 ? 64 : 128;
+  const int lds_split = (wmax / 8) * tile_pad(tm);             // 16-byte units per plane
   size_t lds_bytes = (size_t)2 * lds_split * 16;
   int bg_lds = (int)(lds_bytes / 4);
   lds_bytes += (size_t)bg_sum * 4;
@@ -938,8 +1055,11 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
   // a group runs the kernel each of its nets would run alone (the symbol a profile is keyed by, the grid the deferred bias
   // partials were laid out for)
   for (int i = 0; i < n && n > 1; ++i) if (own_four[i] != four) return NDJIR_ERR_UNSUPPORTED;
+  for (int i = 0; i < n; ++i) plan[i].b.n_tiles = nets[i].P / tm;
   long long blocks = plan[0].b.n_tiles;
   if (blocks > 256LL * 8) blocks = 256LL * 8;
+  if (tile64 && blocks > 512) blocks = 512;         // (two per CU, resident for the whole launch: the priority pairing above)
+  static const int t64_prio = [] { const char* e = getenv("NDJIR_CHAINW_T64_PRIO"); return e ? atoi(e) : 1; }();
   if (bg_sum > 0 && blocks > CHAIN_MAX_GRID_BG) blocks = CHAIN_MAX_GRID_BG;
   if (n > 1) {          // ... which caps the grid of a net with bias gradients only: every member has to agree on it
     for (int i = 0; i < n; ++i) {
@@ -951,12 +1071,14 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
   grp.n = n; grp.pad = 0;
   for (int i = 0; i < n; ++i) {
     plan[i].b.lds_split = lds_split;
+    plan[i].b.t64_prio = t64_prio;
     plan[i].b.bg_lds = bg_lds;
     bg_lds += plan[i].bg_total;
     grp.net[i] = plan[i].b;
   }
   if (nets[0].dry) {
-    snprintf(nets[0].dry->name, 64, "ndjir::x3w::k_chainw%s<%d, %d, %d>", n > 1 ? "_nets" : "", mode, (rpw == 4 || four) ? 4 : 2, four ? 4 : 8);
+    if (tile64) snprintf(nets[0].dry->name, 64, "ndjir::x3w::k_chainw%s<%d, 2, 4, 64>", n > 1 ? "_nets" : "", mode);
+    else snprintf(nets[0].dry->name, 64, "ndjir::x3w::k_chainw%s<%d, %d, %d, 128>", n > 1 ? "_nets" : "", mode, (rpw == 4 || four) ? 4 : 2, four ? 4 : 8);
     nets[0].dry->blocks = (int)blocks; nets[0].dry->bg_total = plan[0].bg_total;
     return NDJIR_OK;
   }
@@ -965,10 +1087,17 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
     if (n == 1) hipLaunchKernelGGL((k_chainw<M, R, W>), dim3((unsigned)blocks), dim3(W * 64), lds_bytes, stream, grp.net[0]); \
     else hipLaunchKernelGGL((k_chainw_nets<M, R, W>), dim3((unsigned)blocks), dim3(W * 64), lds_bytes, stream, grp);         \
   } while (0)
-  if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4, 8); else if (mode == 1) NDJIR_GO(1, 4, 8); else NDJIR_GO(2, 4, 8); }
+#define NDJIR_GO64(M)                                                                                                          \
+  do {                                                                                                                      \
+    if (n == 1) hipLaunchKernelGGL((k_chainw<M, 2, 4, 64>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, grp.net[0]); \
+    else hipLaunchKernelGGL((k_chainw_nets<M, 2, 4, 64>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, grp);         \
+  } while (0)
+  if (tile64) { if (mode == 0) NDJIR_GO64(0); else if (mode == 1) NDJIR_GO64(1); else NDJIR_GO64(2); }
+  else if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4, 8); else if (mode == 1) NDJIR_GO(1, 4, 8); else NDJIR_GO(2, 4, 8); }
   else if (four) { if (mode == 0) NDJIR_GO(0, 4, 4); else if (mode == 1) NDJIR_GO(1, 4, 4); else NDJIR_GO(2, 4, 4); }
   else { if (mode == 0) NDJIR_GO(0, 2, 8); else if (mode == 1) NDJIR_GO(1, 2, 8); else NDJIR_GO(2, 2, 8); }
 #undef NDJIR_GO
+#undef NDJIR_GO64
   int rc = ndjir_check_launch();
   for (int i = 0; i < n && rc == NDJIR_OK; ++i)
     if (plan[i].bg_total > 0 && !nets[i].defer_bg_reduce)

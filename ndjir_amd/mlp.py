@@ -95,9 +95,10 @@ def _bias_region(device, floats):
     a = _BIAS_ARENA.get(device)
     if a is None or a[1] + floats > a[0].numel():
         if torch.cuda.is_current_stream_capturing() and a is not None:
-            t = torch.empty(max(floats, 1 << 22), device=device, dtype=torch.float32)      # owned by the graph being captured
-        else:
-            t = torch.empty(max(floats, 1 << 24, a[0].numel() if a else 0), device=device, dtype=torch.float32)
+            # the arena's addresses are already baked into the graph being captured: it must not be replaced (and so freed)
+            # under it.  A one-off region owned by the capture instead; the arena itself stays as it is
+            return torch.empty(floats, device=device, dtype=torch.float32)
+        t = torch.empty(max(floats, 1 << 24, a[0].numel() if a else 0), device=device, dtype=torch.float32)
         a = _BIAS_ARENA[device] = [t, 0]
     out = a[0][a[1]:a[1] + floats]
     a[1] += (floats + 3) // 4 * 4
@@ -457,10 +458,20 @@ def set_grad_buffer(p, buf):
     """Register `buf` (same shape as the contiguous parameter `p`; the caller zeroes it once per step) as p's accumulate-in-
     place gradient; buf = None unregisters."""
     ptr = p.data_ptr()
+    for e in _GRAD_BUF:
+        if e[0] == ptr:
+            _drop_rows_targets(e[2])
     _GRAD_BUF[:] = [e for e in _GRAD_BUF if e[0] != ptr]
     if buf is not None:
         assert p.is_contiguous() and buf.is_contiguous() and buf.shape == p.shape and buf.dtype == p.dtype
         _GRAD_BUF.append((ptr, p.numel() * p.element_size(), buf))
+
+
+def _drop_rows_targets(buf):
+    """Forget the `rows_except` destinations whose views alias `buf` (a buffer being unregistered)."""
+    lo, hi = buf.data_ptr(), buf.data_ptr() + buf.numel() * buf.element_size()
+    for k in [k for k, v in _ROWS_TARGET.items() if lo <= v[2].data_ptr() < hi]:
+        del _ROWS_TARGET[k]
 
 
 def clear_grad_buffers():
@@ -484,8 +495,8 @@ def grad_buffers(pairs):
     try:
         yield
     finally:
-        _ROWS_TARGET.clear()
         for e in added:
+            _drop_rows_targets(e[2])      # (only what this block registered: outer `set_grad_buffer` entries stay)
             for i in range(len(_GRAD_BUF) - 1, -1, -1):
                 if _GRAD_BUF[i] is e:
                     del _GRAD_BUF[i]
@@ -520,7 +531,11 @@ def grad_target(t):
         return None
     hit = _ROWS_TARGET.get(t.data_ptr())
     if hit is not None and hit[0] == tuple(t.shape):
-        return hit[1]
+        # (valid only while the buffer the entry's views alias is still registered)
+        if any(hit[2].data_ptr() >= buf.data_ptr() and hit[2].data_ptr() < buf.data_ptr() + buf.numel() * buf.element_size()
+               for _, _, buf in _GRAD_BUF):
+            return hit[1]
+        del _ROWS_TARGET[t.data_ptr()]
     ptr, nbytes = t.data_ptr(), t.numel() * t.element_size()
     for p0, nb, buf in _GRAD_BUF:
         if p0 <= ptr and ptr + nbytes <= p0 + nb:
@@ -743,10 +758,11 @@ def _wgrad_group_launch(jobs, extras=()):
         if not extras:
             return
         dev = extras[0][0].device
-        ws = _WORKSPACE_G.get(dev)
+        wkey = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _WORKSPACE_G.get(wkey)
         need = int(lib.load().ndjir_mlp_wgrad_group_workspace(0, None, None, None, None, 0, None, None, 0, None))
         if ws is None or ws.numel() < need:
-            ws = _WORKSPACE_G[dev] = torch.empty(max(need, 1 << 24), device=dev, dtype=torch.float32)
+            ws = _WORKSPACE_G[wkey] = torch.empty(max(need, 1 << 24), device=dev, dtype=torch.float32)
         ex = list(extras)
         lib.call("mlp_wgrad_group", 0, None, [], None, [], [], None, None, [], 0, None, [], [], [], [], ws, 0, len(ex),
                  [_Strided(e[0]) for e in ex], [_Strided(e[1]) for e in ex], [e[2] for e in ex], [e[3] for e in ex], [e[4] for e in ex],
@@ -771,12 +787,13 @@ def _wgrad_group_launch(jobs, extras=()):
     need = int(lib.load().ndjir_mlp_wgrad_group_workspace(
         n, (vp * n)(*[t.data_ptr() for t in A]), (ctypes.c_int * n)(*lda), (ctypes.c_longlong * n)(*Ps), (ctypes.c_int * n)(*oid),
         m, (ctypes.c_int * m)(*Ks), (ctypes.c_int * m)(*Ns), int(WGRAD_GROUP_ITEMS), (ctypes.c_int * n)(*lay)))
-    ws = _WORKSPACE_G.get(dev)
+    wkey = (dev, torch.cuda.current_stream(dev).cuda_stream)      # (the work table and the slabs: one set per stream, like `_workspace`)
+    ws = _WORKSPACE_G.get(wkey)
     if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
             ws = torch.empty(need, device=dev, dtype=torch.float32)      # owned by the graph being captured, not kept
         else:
-            ws = _WORKSPACE_G[dev] = torch.empty(max(need, 1 << 24), device=dev, dtype=torch.float32)
+            ws = _WORKSPACE_G[wkey] = torch.empty(max(need, 1 << 24), device=dev, dtype=torch.float32)
     flops = 2.0 * sum(p * Ks[o] * Ns[o] for p, o in zip(Ps, oid))
     ex = list(extras)
     _launch("wgrad", flops, "mlp_wgrad_group", n, A, lda, B, ldb, Ps, ama, amb, oid, m, outs, ldo, Ks, Ns, acc, ws, int(WGRAD_GROUP_ITEMS),
@@ -1400,7 +1417,11 @@ class RowsExcept(Function):
         if ctx.tgt is not None and not isinstance(ctx.tgt, SplitTarget):
             # the operators that consume the copy add their weight gradient straight into the parameter's two row blocks
             # (`wgrad_jobs`) and return no gradient for it: this node's backward then does not run at all
-            _ROWS_TARGET[ent[1].data_ptr()] = (tuple(ent[1].shape), SplitTarget(ctx.tgt[:a], ctx.tgt[b:], a))
+            _ROWS_TARGET[ent[1].data_ptr()] = (tuple(ent[1].shape), SplitTarget(ctx.tgt[:a], ctx.tgt[b:], a), ctx.tgt)
+        else:
+            # the parameter has no registered buffer (any more): an entry left from an earlier registration would send the
+            # consumers' weight gradients into a dead buffer and make them return None for the parameter
+            _ROWS_TARGET.pop(ent[1].data_ptr(), None)
         return ent[1].view(ent[1].shape)  # (a fresh tensor object per call: autograd owns what it returns)
 
     @staticmethod

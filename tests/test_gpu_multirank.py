@@ -155,3 +155,34 @@ def test_render_image_on_two_ranks_equals_one_process(gpu):
     flat = [p["part"].reshape(3, -1).sum(0) for p in parts]
     assert not np.any((flat[0] != 0) & (flat[1] != 0))                    # disjoint tiles
     P.clear_parameters()
+
+
+def _bench_json(args, env_extra, timeout=800):
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True, text=True,
+                         timeout=timeout)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return json.loads(res.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.timeout(900)
+def test_bench_starts_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` with no launcher around it (the way a user -- and a driver without torchrun -- calls it):
+    bench.py starts the two ranks itself, relays the one JSON line and the exit code.  Both ranks share GPU 0 over gloo
+    (NDJIR_BENCH_SAME_DEVICE: the only two-rank set-up a one-GPU box offers)."""
+    out = _bench_json(["--gpus", "2", "--rays", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs",
+                       "--train-steps", "0", "--override", "geometric_network.voxel.grid_size=64"], {"NDJIR_BENCH_SAME_DEVICE": "1"})
+    assert out["n_gpus"] == 2 and out["ranks"]["world_size"] == 2 and len(out["ranks"]["devices"]) == 2
+    assert out["scaling"] == "weak" and out["config"]["rays_per_gpu"] == 64
+    assert "exchange" in out and out["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_strong_scaling_config4_two_ranks(gpu):
+    """BASELINE.json config 4 (config/no_voxel.yaml, rays split over the ranks) through the same self-launch."""
+    out = _bench_json(["--gpus", "2", "--scaling", "strong", "--config", "no_voxel", "--total-rays", "128", "--steps", "2", "--warmup", "1",
+                       "--no-cpu-baseline", "--no-extra-legs", "--train-steps", "0"], {"NDJIR_BENCH_SAME_DEVICE": "1"})
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["rays_per_gpu"] == 64
+    assert out["ranks"]["world_size"] == 2 and "exchange" in out

@@ -106,7 +106,9 @@ def test_sampler_end_to_end_indices(gpu):
     for a, b in zip(rec_p["idx"], rec_o["idx"]):
         tot += b.numel()
         mis += int((a.cpu() != b).sum())
-    assert mis <= 2e-3 * tot, (mis, tot)
+    print(f"\nsampler end to end: {mis} of {tot} sample indices differ ({mis / tot:.2e})")
+    # measured (round 5, MI355X): 0 - 2 of 4 096; the bound is 3 x the largest rate seen, SURVEY 7 expects << 1e-4 at full size
+    assert mis <= 1.5e-3 * tot, (mis, tot)
 
 
 def test_importance_round_capacity(gpu):

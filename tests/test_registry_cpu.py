@@ -42,3 +42,35 @@ def test_clear_parameters_drops_every_registry():
     P.clear_parameters()
     assert _core.get_grad_buffer(t) is None and mlp.grad_target(t) is None
     del w
+
+
+def test_rows_except_destination_dies_with_its_registration():
+    """the fast path of `grad_target` for a `rows_except` copy must not outlive the parameter's buffer --
+    unregistering the parameter while ANOTHER buffer stays registered used to leave the entry behind, and the consumers'
+    weight gradients went into the dead buffer."""
+    from ndjir_amd import mlp
+    mlp.clear_grad_buffers()
+    W, other = torch.randn(6, 4, requires_grad=True), torch.randn(3, 3)
+    bufW, bufO = torch.zeros(6, 4), torch.zeros(3, 3)
+    mlp.set_grad_buffer(other, bufO)
+    mlp.set_grad_buffer(W, bufW)
+    c = mlp.rows_except(W, 2, 4)
+    tgt = mlp.grad_target(c.detach())
+    assert isinstance(tgt, mlp.SplitTarget) and tgt.top.data_ptr() == bufW.data_ptr()
+    mlp.set_grad_buffer(W, None)                      # `other` keeps the registry non-empty
+    assert mlp.grad_target(c.detach()) is None
+    # registrations made inside a `grad_buffers` block end with it; an outer one survives the block
+    mlp.set_grad_buffer(W, bufW)
+    V = torch.randn(5, 2, requires_grad=True)
+    bufV = torch.zeros(5, 2)
+    with mlp.grad_buffers([(V, bufV)]):
+        cv = mlp.rows_except(V, 1, 2)
+        assert isinstance(mlp.grad_target(cv.detach()), mlp.SplitTarget)
+        c2 = mlp.rows_except(W, 2, 4)
+    assert mlp.grad_target(cv.detach()) is None
+    assert isinstance(mlp.grad_target(c2.detach()), mlp.SplitTarget)     # (the outer registration's entry is still valid)
+    # a forward pass after the parameter lost its buffer purges the entry itself
+    mlp.set_grad_buffer(W, None)
+    mlp.rows_except(W, 2, 4)
+    assert mlp.grad_target(c2.detach()) is None
+    mlp.clear_grad_buffers()
