@@ -150,7 +150,8 @@ def parity_block(conf, step, n_rays):
     try:
         rec_p = {}
         out = total_loss(step.camloc, raydir, color, None, step.car, conf, rand, record=rec_p)
-        grads = torch.autograd.grad(out["loss"], step.mlp_params, allow_unused=True)
+        # (the grid parameters too: their gradients arrive in the step's accumulate-in-place buffers, zeroed above)
+        grads = torch.autograd.grad(out["loss"], step.mlp_params + step.grid_params, allow_unused=True)[:len(step.mlp_params)]
         torch.cuda.synchronize()
     finally:
         mlp.set_tile_rows(old_tile)

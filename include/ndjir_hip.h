@@ -110,7 +110,12 @@ int ndjir_sparse_rows_apply(const int* ids, const float* rows, const int* counts
                             int skip_rank, float* grad_feature, int D, hipStream_t stream);
 /* stats (device, 2 ints, may be null): [0] running maximum of the counts over all exchanges (the host sizes `limit` from it
  * at its next look, whichever exchange overflowed), [1] number of exchanges that overflowed */
-int ndjir_sparse_rows_overflow(const int* counts, int world, int limit, int* flag, int* stats, hipStream_t stream);
+int ndjir_sparse_rows_overflow(const int* counts, int world, int limit, int* flag, int* stats, int counts_stride, hipStream_t stream);
+/* Packed wire: with counts == NULL, ndjir_sparse_rows_apply / _zero read every rank's count from a header of
+ * ndjir_sparse_rows_header() = 4 ints in front of its ids -- [count, list capacity the rank needs, 0, 0] --, the id lists being
+ * (world, limit + 4) ints (rows unchanged): the counts then travel with the ids instead of in a collective of their own
+ * (ndjir_sparse_rows_overflow reads them with counts_stride = limit + 4; dense counts: counts_stride = 1). */
+int ndjir_sparse_rows_header(void);
 /* (`limit`: device int here -- the call may be replayed from a captured HIP graph after the limit has grown; it is also the
  * row stride of the communicated lists; `capacity`: that of this rank's own list) */
 int ndjir_sparse_rows_zero(const int* ids, const int* counts, int world, int capacity, const int* limit, int own_rank,

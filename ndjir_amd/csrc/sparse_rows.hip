@@ -12,6 +12,11 @@
 
 namespace ndjir {
 
+// Packed wire (counts == nullptr): every rank's list travels with a header of ROWS_HDR ints in front of its ids --
+// [count, capacity the rank needs, 0, 0] -- so that the counts need no collective of their own: the id lists are then
+// (world, limit + ROWS_HDR) ints, the rows stay (world, limit, D).
+constexpr int ROWS_HDR = 4;
+
 // buf[cell] += row for every listed row of every rank but `skip_rank` (this rank's own rows are already in buf)
 template <int D4>
 __global__ void __launch_bounds__(256) k_rows_apply(const int* __restrict__ ids, const float4* __restrict__ rows,
@@ -26,10 +31,12 @@ __global__ void __launch_bounds__(256) k_rows_apply(const int* __restrict__ ids,
     const long long row = t / D;
     const int d = (int)(t - row * D);
     const int r = (int)(row / limit), i = (int)(row - (long long)r * limit);
-    if (r == skip_rank || i >= counts[r]) continue;
+    const int cnt = counts ? counts[r] : ids[(long long)r * (cap + ROWS_HDR)];
+    if (r == skip_rank || i >= cnt) continue;
     const long long e = (long long)r * cap + i;
     const float v = rowf[e * D + d];
-    if (v != 0.f) atomicAdd(buf + (long long)ids[e] * D + d, v);
+    const int cell = counts ? ids[e] : ids[(long long)r * (cap + ROWS_HDR) + ROWS_HDR + i];
+    if (v != 0.f) atomicAdd(buf + (long long)cell * D + d, v);
   }
 }
 
@@ -50,8 +57,10 @@ __global__ void __launch_bounds__(256) k_rows_zero(const int* __restrict__ ids, 
     int cell;
     if (t < remote) {
       const int r = (int)(t / limit), i = (int)(t - (long long)r * limit);
-      if ((own_ids && r == own_rank) || i >= counts[r]) continue;
-      cell = ids[(long long)r * limit + i];          // (packed lists: row stride = the communicated size)
+      const int cnt = counts ? counts[r] : ids[(long long)r * (limit + ROWS_HDR)];
+      if ((own_ids && r == own_rank) || i >= cnt) continue;
+      cell = counts ? ids[(long long)r * limit + i]          // (packed lists: row stride = the communicated size)
+                    : ids[(long long)r * (limit + ROWS_HDR) + ROWS_HDR + i];
     } else {
       cell = own_ids[t - remote];
     }
@@ -74,10 +83,13 @@ __global__ void __launch_bounds__(256) k_rows_clear_bitmap(const int* __restrict
 // maximum of the counts over all exchanges -- what the host sizes `limit` from at its next look, whichever exchange
 // overflowed --, [1] number of exchanges that overflowed.
 __global__ void k_rows_overflow(const int* __restrict__ counts, int world, int limit, int* __restrict__ flag,
-                                int* __restrict__ stats) {
+                                int* __restrict__ stats, int stride) {
   bool over = false;
   int most = 0;
-  for (int r = threadIdx.x; r < world; r += 64) { over |= counts[r] > limit; most = counts[r] > most ? counts[r] : most; }
+  for (int r = threadIdx.x; r < world; r += 64) {
+    const int c = counts[(long long)r * stride];
+    over |= c > limit; most = c > most ? c : most;
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(most, off); most = o > most ? o : most; }
   const bool any_over = __any(over);
@@ -99,7 +111,7 @@ using namespace ndjir;
 extern "C" int ndjir_sparse_rows_apply(const int* ids, const float* rows, const int* counts, int world, int capacity, int limit,
                                        int skip_rank, float* buf, int D, hipStream_t stream) {
   if (world <= 0 || capacity <= 0 || limit <= 0) return NDJIR_OK;
-  if (!ids || !rows || !counts || !buf || limit > capacity) return NDJIR_ERR_ARG;
+  if (!ids || !rows || !buf || limit > capacity) return NDJIR_ERR_ARG;      // (counts == null: packed wire, see ROWS_HDR)
   if (D != 4 && D != 8) return NDJIR_ERR_UNSUPPORTED;
   const int blocks = blocks_for((long long)world * limit * D);
   if (D == 4) hipLaunchKernelGGL(k_rows_apply<1>, dim3(blocks), dim3(256), 0, stream, ids, reinterpret_cast<const float4*>(rows), counts,
@@ -112,7 +124,7 @@ extern "C" int ndjir_sparse_rows_apply(const int* ids, const float* rows, const 
 extern "C" int ndjir_sparse_rows_zero(const int* ids, const int* counts, int world, int capacity, const int* limit, int own_rank,
                                       const int* own_ids, const int* own_count, float* buf, int D, hipStream_t stream) {
   if (world <= 0 || capacity <= 0) return NDJIR_OK;
-  if (!ids || !counts || !buf || !limit || ((own_ids == nullptr) != (own_count == nullptr))) return NDJIR_ERR_ARG;
+  if (!ids || !buf || !limit || ((own_ids == nullptr) != (own_count == nullptr))) return NDJIR_ERR_ARG;
   if (D != 4 && D != 8) return NDJIR_ERR_UNSUPPORTED;
   const int blocks = blocks_for((long long)(world + 1) * capacity);      // grid-stride over world x *limit (+ own rows)
   if (D == 4) hipLaunchKernelGGL(k_rows_zero<1>, dim3(blocks), dim3(256), 0, stream, ids, counts, world, capacity, limit, own_rank, own_ids,
@@ -129,9 +141,12 @@ extern "C" int ndjir_sparse_rows_clear_bitmap(const int* ids, const int* count, 
   return ndjir_check_launch();
 }
 
-extern "C" int ndjir_sparse_rows_overflow(const int* counts, int world, int limit, int* flag, int* stats, hipStream_t stream) {
+extern "C" int ndjir_sparse_rows_overflow(const int* counts, int world, int limit, int* flag, int* stats, int counts_stride,
+                                          hipStream_t stream) {
   if (world <= 0) return NDJIR_OK;
-  if (!counts || !flag) return NDJIR_ERR_ARG;
-  hipLaunchKernelGGL(k_rows_overflow, dim3(1), dim3(64), 0, stream, counts, world, limit, flag, stats);
+  if (!counts || !flag || counts_stride < 1) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_rows_overflow, dim3(1), dim3(64), 0, stream, counts, world, limit, flag, stats, counts_stride);
   return ndjir_check_launch();
 }
+
+extern "C" int ndjir_sparse_rows_header(void) { return ndjir::ROWS_HDR; }

@@ -73,7 +73,7 @@ def allreduce_sparse_rows(buf, cell_ids, group=None, return_remote=False):
 
 
 class SparseRows:
-    """What the HIP-path exchange keeps for a buffer: every rank's packed cell ids (world, cap), their counts (world),
+    """What the HIP-path exchange keeps for a buffer: every rank's packed wire -- header + cell ids, (world, limit + HDR) --,
     the number of rows per rank that were communicated (`limit`) and this rank's own full list -- together the rows
     that hold gradient in the local dense buffer after the exchange.  `zero(buf)` clears exactly those.
     The tensors are allocated once per buffer (worst-case capacity) and rewritten by every exchange, so a HIP graph
@@ -85,59 +85,73 @@ class SparseRows:
     def zero(self, buf):
         from . import lib
         st = self.st
-        # (the communicated lists are packed with row stride *limit_dev; cap = capacity of this rank's own list)
-        lib.call("sparse_rows_zero", st["ids_all"], st["counts_all"], st["world"], st["cap"], st["limit_dev"], self.rank,
+        # (the communicated lists are packed with row stride *limit_dev + HDR, the counts sit in their headers: counts = None;
+        # cap = capacity of this rank's own list)
+        lib.call("sparse_rows_zero", st["wire_all"], None, st["world"], st["cap"], st["limit_dev"], self.rank,
                  st["ids"], st["count"], buf, buf.shape[-1])
 
 
 _STATE = {}
-_GRID_GROUP = {}
+_GRID_GROUP = weakref.WeakKeyDictionary()      # parent group object -> its second communicator (None: the default group)
+_GRID_GROUP_DEFAULT = []
 CHECK_EVERY = 64          # exchanges between two (host-synchronising) looks at the row counts
-HEADROOM = 1.25           # wire rows per rank = the largest list seen x this (an overflow vetoes one update and grows the wire;
-                          # every rank receives world x this many rows per exchange: 1.5 was 33 MB per rank at 8 ranks, now 28 MB)
+HEADROOM = 1.5            # wire rows per rank = the largest list seen x this.  An overflow vetoes every optimizer step until the
+                          # next look (up to CHECK_EVERY - 1 of them) -- 25 % proved too tight a margin for lists that grow
+                          # while the geometry evolves; the price is 5 MB more per exchange at 8 ranks
+HDR = 4                   # ints in front of a rank's ids on the wire: [count, list capacity it needs, 0, 0] (csrc/sparse_rows.hip)
 
 
 def grid_group(group=None):
     """A second communicator for the sparse grid exchange, so that it progresses beside the MLP bucket's all-reduce
     (collectives of ONE group execute in issue order on its stream).  Created lazily, once per parent group."""
-    key = id(group)
-    if key not in _GRID_GROUP:
-        ranks = list(range(dist.get_world_size(group))) if group is None else dist.get_process_group_ranks(group)
-        _GRID_GROUP[key] = dist.new_group(ranks=ranks)
-    return _GRID_GROUP[key]
+    if group is None:
+        if not _GRID_GROUP_DEFAULT or _GRID_GROUP_DEFAULT[0][0] is not dist.group.WORLD:
+            # (keyed by the default group OBJECT: a re-initialised process group gets a fresh communicator)
+            _GRID_GROUP_DEFAULT[:] = [(dist.group.WORLD, dist.new_group(ranks=list(range(dist.get_world_size()))))]
+        return _GRID_GROUP_DEFAULT[0][1]
+    if group not in _GRID_GROUP:
+        _GRID_GROUP[group] = dist.new_group(ranks=dist.get_process_group_ranks(group))
+    return _GRID_GROUP[group]
 
 
-def _state(buf, capacity, world, group=None):
-    """Exchange state of a dense gradient buffer: the packed lists (own and gathered), counts, flags, statistics.  Created at
+def _state(buf, capacity, world, group=None, grow=False):
+    """Exchange state of a dense gradient buffer: the packed lists (own and gathered), flags, statistics.  Created at
     the buffer's first exchange -- on every rank in the same call, so it may hold a collective: the list CAPACITY is the
     maximum over the ranks of their worst cases (every stencil cell of the rank's query points distinct), because the wire
     size derived from it must be the same number everywhere even when the ranks have different numbers of query points.
-    Fixed from then on: a rank whose query points outgrow it is an error (re-creating the state on one rank alone would
-    issue a collective the others do not)."""
+    A rank whose query points outgrow it cannot re-create the state on its own (that would issue a collective the others
+    do not): it announces the capacity it needs in its wire header, and at the next look every rank -- all read the same
+    gathered headers -- re-creates its state together (`grow`).  One rank (no collective involved): re-created at once."""
     st = _STATE.get(buf.data_ptr())
     D = buf.shape[-1]
     cells = buf.numel() // D
-    if st is not None and st["cells"] == cells and st["world"] == world:
-        if capacity > st["cap"]:
-            raise RuntimeError(f"sparse grid exchange: {capacity} stencil cells exceed the list capacity {st['cap']} fixed at the "
-                               "buffer's first exchange (the number of query points per rank grew)")
-        return st
+    if st is not None and st["cells"] == cells and st["world"] == world and not grow:
+        if capacity > st["cap"] and world == 1:
+            st = None                         # (falls through: a fresh, larger state)
+        else:
+            if st["need_host"] != min(capacity, cells):      # (> cap: the lists are cut at cap, the overflow flag vetoes the step,
+                st["need_host"] = min(capacity, cells)       # and the next look grows every rank's state together)
+                st["need"].fill_(st["need_host"])
+            return st
     dev = buf.device
     if world > 1:
         caps = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(caps, torch.tensor([capacity], dtype=torch.int64, device=dev), group=group)
-        capacity = min(cells, max(int(c.item()) for c in caps))
+        capacity = max(int(c.item()) for c in caps)
+    capacity = min(cells, capacity)
+    own = torch.zeros(capacity + HDR, dtype=torch.int32, device=dev)      # this rank's wire: header + ids
     st = dict(cells=cells, cap=capacity, world=world, limit=None, calls=0,
               bitmap=torch.zeros((cells + 31) // 32, dtype=torch.int32, device=dev),
-              count=torch.zeros(1, dtype=torch.int32, device=dev),
+              own=own, count=own[0:1], need=own[1:2], ids=own[HDR:],
               overflow=torch.zeros(1, dtype=torch.int32, device=dev),
               stats=torch.zeros(2, dtype=torch.int32, device=dev),
               limit_dev=torch.zeros(1, dtype=torch.int32, device=dev),
-              ids=torch.empty(capacity, dtype=torch.int32, device=dev),
               rows=torch.empty((capacity, D), dtype=torch.float32, device=dev),
-              ids_all=torch.zeros((world, capacity), dtype=torch.int32, device=dev),
-              rows_all=torch.empty((world, capacity, D), dtype=torch.float32, device=dev),
-              counts_all=torch.zeros(world, dtype=torch.int32, device=dev))
+              wire_all=torch.zeros(world * (capacity + HDR), dtype=torch.int32, device=dev),
+              rows_all=torch.empty((world, capacity, D), dtype=torch.float32, device=dev))
+    st["need"].fill_(capacity)
+    st["need_host"] = capacity
+    st["counts_all"] = st["wire_all"][:world * HDR].view(world, HDR)[:, 0]      # (re-pointed at every exchange: the wire's headers)
     key = buf.data_ptr()
     _STATE[key] = st
     # the state is keyed by the buffer's address: it ends with the buffer, so that a later buffer placed at the same address
@@ -175,8 +189,12 @@ def exchange_grid_rows_hip(buf, family, queries, min_=(-1.0, -1.0, -1.0), max_=(
     else:
         gs, sub, nd = [buf.shape[1]] * 3, 3, (2 if topo == 1 else 1)
     cells = buf.numel() // D
-    cap = min(cells, sum(q.numel() // 3 for q in queries) * sub * _TAPS[interp] ** nd)
-    st = _state(buf, cap, world, group)
+    need = min(cells, sum(q.numel() // 3 for q in queries) * sub * _TAPS[interp] ** nd)
+    st = _state(buf, need, world, group)
+    gg = grid_group(group) if world > 1 else group
+    if "flat" not in st:
+        st["flat"] = _flat_gather_supported(gg, buf.device) if dist.is_initialized() else True
+    flat = st["flat"]
     cap = st["cap"]
     st["count"].zero_()
     for q in queries:
@@ -184,37 +202,53 @@ def exchange_grid_rows_hip(buf, family, queries, min_=(-1.0, -1.0, -1.0), max_=(
         lib.call("grid_pack_rows", topo, interp, q.shape[0], buf, q, gs, D, list(min_), list(max_), st["bitmap"], st["ids"],
                  st["rows"], st["count"], cap)
     lib.call("sparse_rows_clear_bitmap", st["ids"], st["count"], cap, st["bitmap"])
-    counts = st["counts_all"]
-    gg = grid_group(group) if world > 1 else group
-    if "flat" not in st:
-        st["flat"] = _flat_gather_supported(gg, buf.device) if dist.is_initialized() else True
-    flat = st["flat"]
-    _gather_into(counts, st["count"], world, gg, flat)
     st["calls"] += 1
-    if st["limit"] is None or st["calls"] % CHECK_EVERY == 0:
-        # the only host synchronisation, once per CHECK_EVERY exchanges: the largest list of THIS exchange and the running
-        # maximum the device has kept over all exchanges since the last look (k_rows_overflow), so that an overflow on any of
-        # the steps in between grows the limit, not only one on the step that happens to be looked at
-        most = max(int(counts.max().item()), int(st["stats"][0].item()))
-        # (the same number on every rank: it comes from the gathered counts and is clipped by the list capacity, which
-        # `_state` made the same on every rank -- ranks that disagreed here would disagree on the size of the collective)
-        assert most <= cap, "more distinct cells than stencil taps"
-        want = min(cap, max(4096, -(-int(most * HEADROOM) // 4096) * 4096))
-        if st["limit"] is None or want > st["limit"]:
-            st["limit"] = want
-            st["limit_dev"].fill_(want)
+    if st["limit"] is None:
+        # first exchange of the buffer: the wire size comes from the counts, which therefore travel alone this once
+        first = torch.zeros((world, HDR), dtype=torch.int32, device=buf.device)
+        _gather_into(first, st["own"][:HDR], world, gg, flat)
+        most = int(first[:, 0].max().item())
+        st["limit"] = min(cap, max(4096, -(-int(most * HEADROOM) // 4096) * 4096))
+        st["limit_dev"].fill_(st["limit"])
+    elif st.get("pending_limit"):
+        # a wire size decided at the previous look takes effect HERE, not there: until this exchange, `limit_dev` has to
+        # describe the wire the previous exchange left behind (the re-arm that ran since read it as that wire's stride)
+        st["limit"] = st.pop("pending_limit")
+        st["limit_dev"].fill_(st["limit"])
     m = st["limit"]
-    # every rank's first m rows, packed (world, m): the layout all_gather_into_tensor fills without per-rank copies
-    ids = st["ids_all"].view(-1)[:world * m].view(world, m)
+    # TWO collectives per exchange: every rank's header + first m ids, packed (world, m + HDR) -- the counts ride in the
+    # headers --, and its first m rows (world, m, D): the layouts all_gather_into_tensor fills without per-rank copies
+    wire = st["wire_all"][:world * (m + HDR)].view(world, m + HDR)
     rows = st["rows_all"].view(-1)[:world * m * D].view(world, m, D)
-    _gather_into(ids, st["ids"][:m], world, gg, flat)
+    _gather_into(wire, st["own"][:m + HDR], world, gg, flat)
     _gather_into(rows, st["rows"][:m], world, gg, flat)
-    lib.call("sparse_rows_overflow", counts, world, m, st["overflow"], st["stats"])
-    lib.call("sparse_rows_apply", ids, rows, counts, world, m, m, rank, buf, D)
+    st["counts_all"] = wire[:, 0]
+    lib.call("sparse_rows_overflow", wire, world, m, st["overflow"], st["stats"], m + HDR)
+    lib.call("sparse_rows_apply", wire, rows, None, world, m, m, rank, buf, D)
+    if st["calls"] % CHECK_EVERY == 0:
+        # the only host synchronisation, once per CHECK_EVERY exchanges: the running maximum the device has kept over all
+        # exchanges since the last look (k_rows_overflow: an overflow on ANY step in between grows the wire) and the list
+        # capacities the ranks announced.  Every rank reads the same gathered headers, so every rank takes the same branch.
+        most = int(st["stats"][0].item())
+        need_all = int(wire[:, 1].max().item())
+        if need_all > cap:
+            new = _state(buf, need_all, world, group, grow=True)      # (collective: all ranks are here together)
+            new["limit"], new["calls"], new["flat"] = m, st["calls"], flat
+            new["limit_dev"].fill_(m)
+            new["stats"].copy_(st["stats"])
+            new["overflow"].copy_(st["overflow"])
+            # the lists of THIS exchange move over: the next re-arm clears the rows they name
+            new["wire_all"][:world * (m + HDR)].copy_(st["wire_all"][:world * (m + HDR)])
+            new["own"][:cap + HDR].copy_(st["own"])
+            new["need"].fill_(new["need_host"])
+            st, cap = new, new["cap"]
+        want = min(cap, max(4096, -(-int(most * HEADROOM) // 4096) * 4096))
+        if want > st["limit"]:
+            st["pending_limit"] = want
     return SparseRows(st, rank)
 
 
-_FLAT_GATHER = {}      # (group, device type) -> does the backend implement all_gather_into_tensor
+_FLAT_GATHER = {}      # (backend name, device type) -> does the backend implement all_gather_into_tensor
 
 
 def _flat_gather_supported(group, device):
@@ -222,7 +256,8 @@ def _flat_gather_supported(group, device):
     probes at the same point of the same call sequence and a backend's capability is the same on all of them.  The exchanges
     themselves never catch an error around a collective: a failure on one rank must not make it issue a different
     collective than the others."""
-    key = (id(group), device.type)
+    # (keyed by the backend, not by id(group): Python may hand a destroyed group's id to a new one of another backend)
+    key = (dist.get_backend(group), device.type)
     if key not in _FLAT_GATHER:
         world = dist.get_world_size(group)
         probe_out = torch.zeros(world, dtype=torch.int32, device=device)

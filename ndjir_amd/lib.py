@@ -103,7 +103,7 @@ SIGS = {
     "sparse_rows_clear_bitmap": "qqiq",
     "grid_pack_rows": "iiippIiFFqqpqi",
     "sparse_rows_apply": "qpqiiiipi",
-    "sparse_rows_overflow": "qiiqq",
+    "sparse_rows_overflow": "qiiqqi",
     "sparse_rows_zero": "qqiiqiqqpi",
     "generate_raydir_camloc": "iixxqpipp",
     "solver_adam_begin": "xffqq",
@@ -269,7 +269,7 @@ def symbols():
                                             "ndjir_mlp_chain_workspace", "ndjir_mlp_set_math", "ndjir_mlp_get_math",
                                             "ndjir_mlp_set_tile_rows", "ndjir_mlp_get_tile_rows", "ndjir_mlp_pack_entry_bytes",
                                             "ndjir_mlp_debug_timeline", "ndjir_mlp_chain_kernel", "ndjir_mlp_chain_bias_partials", "ndjir_loss_terms_workspace",
-                                            "ndjir_mlp_chain_group_begin", "ndjir_mlp_chain_group_end"]
+                                            "ndjir_mlp_chain_group_begin", "ndjir_mlp_chain_group_end", "ndjir_sparse_rows_header"]
 
 
 def hash_num_params(G0, growth_factor, T0, L, D):

@@ -57,6 +57,8 @@ class Step:
         self.touched_ptb = None  # ... and their perturbed twins (x_fg + the noise of THAT step: redraw_rand may follow)
         self.remote_rows = {}    # multi-GPU: grid rows received from the other ranks in the previous exchange
         self.mask_sum = torch.zeros((), device=device)   # multi-GPU: all-reduced sum of the ray masks
+        self._tail = torch.zeros(4, device=device)       # [mask sum, object-mask sum, 0, 0]: re-bound to the bucket's tail below
+        self._rays_version, self._tail_version = 0, -1
         self.vetoed_steps = torch.zeros(1, dtype=torch.int32, device=device)   # optimizer steps skipped because an exchange overflowed
         self.x_fg = None
         self.mlp_names = None
@@ -75,7 +77,13 @@ class Step:
         # accumulate dL/dW and dL/db straight into its views (ndjir_amd.mlp.set_grad_buffer = nnabla's accum protocol,
         # python/train.py:136-140: gradients are zeroed once per iteration, every backward adds): autograd neither sums the
         # contributions of parameters used by two operators nor materialises slice gradients, and no copy packs the bucket.
-        self.flat_grad = torch.zeros(sum(p.numel() for p in self.mlp_params), device=device)
+        # (+ 4 trailing floats, N > 1: [sum of the ray masks, sum of the object masks, 0, 0] of the batch the NEXT step will
+        # see -- they ride with this step's all-reduce of the bucket instead of a scalar all-reduce of their own)
+        n_flat = sum(p.numel() for p in self.mlp_params)
+        self._bucket = torch.zeros(n_flat + 4, device=device)
+        self.flat_grad = self._bucket[:n_flat]
+        self._tail = self._bucket[n_flat:]
+        self._tail_version = -1
         self.grad_views, off = [], 0
         from ndjir_amd import mlp
         self.in_place = device.type == "cuda" and not os.environ.get("NDJIR_NO_GRAD_BUFFERS")
@@ -110,6 +118,7 @@ class Step:
         """Feed the next iteration's rays (python/train.py:124-133: `raydir.d = ...`, `camloc.d = ...`, `color_gt.d = ...`,
         `obj_mask.d = ...`) into the step's persistent input tensors -- in place, so that a captured graph keeps reading
         them."""
+        self._rays_version += 1          # (mask counts reduced for the previous rays are void)
         self.camloc.copy_(camloc.reshape(self.camloc.shape))
         self.raydir.copy_(raydir.reshape(self.raydir.shape))
         self.color_gt.copy_(color_gt.reshape(self.color_gt.shape))
@@ -159,15 +168,27 @@ class Step:
             if torch.is_tensor(rows):          # generic torch path of the exchange (the HIP path re-arms in `compute`)
                 buf = self.grid_bufs[name]
                 buf.view(-1, buf.shape[-1]).index_fill_(0, rows, 0.0)
+        if self._tail_version == self._rays_version and self.mlp_names is not None:
+            # the previous exchange already summed the counts of these rays (`exchange`: the rays were in place before it ran
+            # -- a training loop calls `set_rays(next batch)` between `compute` and `exchange` to get this; every rank runs the
+            # same program, so every rank takes this branch together)
+            self.mask_sum.copy_(self._tail[0])
+            self.obj_mask_sum.copy_(self._tail[1])
+            return
+        self._local_mask_counts(self._tail)
+        dist.all_reduce(self._tail)
+        self.mask_sum.copy_(self._tail[0])
+        self.obj_mask_sum.copy_(self._tail[1])
+
+    def _local_mask_counts(self, out):
+        """out[0] = sum of this rank's ray masks (the mask depends on the rays only), out[1] = of its object masks (the RGB
+        term divides by the GLOBAL object-mask count, python/loss.py:62), for the rays currently in place."""
+        from ndjir_amd.sampler import SamplePoints
         with torch.no_grad():
             _, _, mask = SamplePoints(self.conf).t_near_far(self.camloc, self.raydir)
-            ms = mask.sum().reshape(())
-        dist.all_reduce(ms)
-        self.mask_sum.copy_(ms)
-        if self.conf.train.mask_weight > 0.0:      # the RGB term divides by the GLOBAL object-mask count (loss.py:62)
-            oms = self.obj_mask.sum().reshape(())
-            dist.all_reduce(oms)
-            self.obj_mask_sum.copy_(oms)
+            out[0] = mask.sum()
+            out[1] = self.obj_mask.sum() if self.conf.train.mask_weight > 0.0 else 0.0
+            out[2:].zero_()
 
     def compute(self, rearm=True):
         from ndjir_amd import mlp
@@ -238,7 +259,11 @@ class Step:
                 queries[name] = (pts, pre + fam)
             elif fam == "voxel" and pre == "":
                 queries[name] = (pts, [v.grid_size] * 3)           # generic torch path (CPU tests)
-        self.remote_rows = allreduce_step_gradients(self.flat_grad, self.grid_bufs, queries)
+        # the mask counts of the rays in place NOW (the next step's, if the caller fed them already; else this step's again)
+        # join the bucket: `pre_exchange` of the next step then needs no collective of its own
+        self._local_mask_counts(self._tail)
+        self._tail_version = self._rays_version
+        self.remote_rows = allreduce_step_gradients(self._bucket, self.grid_bufs, queries)
         # a rank that listed more rows than fit on the wire: this step's grid gradient is incomplete -> veto the update
         self.exchange_overflow = [h.st["overflow"] for h in self.remote_rows.values() if isinstance(h, SparseRows)]
 

@@ -53,7 +53,11 @@ def exchange(out, rank, world, dev):
     st["overflow"].zero_()
     buf, h = run()                                                # exchange 3: still cut (no look yet)
     rec["cut3_limit"] = st["limit"]
-    buf, h = run()                                                # exchange 4 = CHECK_EVERY: the host looks, the wire grows, this exchange is whole
+    buf, h = run()                                                # exchange 4 = CHECK_EVERY: the host looks (the counts rode with this
+    rec["look_limit"] = st["limit"]                               # exchange's ids: its own wire was already sized) ...
+    st["overflow"].zero_()
+    buf, h = run()                                                # ... exchange 5: the wire has grown, the sums are whole
+    st = h.st
     rec["grown_limit"] = st["limit"]
     rec["grown_ok"] = bool(torch.allclose(buf, dense, atol=1e-5))
     rec["overflowed_exchanges"] = int(st["stats"][1].item())

@@ -403,9 +403,9 @@ def test_sparse_row_exchange_kernels(gpu):
     m = 4096
     flag = torch.zeros(1, dtype=torch.int32, device=gpu)
     stats = torch.zeros(2, dtype=torch.int32, device=gpu)
-    lib.call("sparse_rows_overflow", counts, 2, cap, flag, stats)
+    lib.call("sparse_rows_overflow", counts, 2, cap, flag, stats, 1)
     assert int(flag) == 0 and stats.tolist() == [int(counts.max()), 0]
-    lib.call("sparse_rows_overflow", counts, 2, m, flag, stats)
+    lib.call("sparse_rows_overflow", counts, 2, m, flag, stats, 1)
     assert int(flag) == 1 and stats.tolist() == [int(counts.max()), 1]      # running maximum of the lists, overflowing exchanges
     buf = torch.zeros(G, G, G, D, device=gpu)
     lib.call("sparse_rows_apply", ids, rows, counts, 2, cap, m, 0, buf, D)
@@ -506,10 +506,10 @@ def test_grid_pack_rows_lists_every_nonzero_row_once(gpu, family, D):
     lib.call("sparse_rows_apply", ids_all, rows_all, counts, 2, cap, limit, 0, recv, D)
     assert torch.equal(recv, gf)
     flag = torch.zeros(1, dtype=torch.int32, device=gpu)
-    lib.call("sparse_rows_overflow", counts, 2, limit, flag, None)
+    lib.call("sparse_rows_overflow", counts, 2, limit, flag, None, 1)
     assert int(flag) == 0
     if n > 1:
-        lib.call("sparse_rows_overflow", counts, 2, n - 1, flag, None)
+        lib.call("sparse_rows_overflow", counts, 2, n - 1, flag, None, 1)
         assert int(flag) == 1
     lim_dev = torch.tensor([limit], dtype=torch.int32, device=gpu)
     packed = ids_all[:, :limit].contiguous()   # the communicated lists are packed with row stride `limit`
