@@ -104,8 +104,28 @@ __device__ __forceinline__ void split4(f32x4 v, float s, f16x4& ph, f16x4& pl) {
 #pragma clang fp contract(off)
   const f32x4 xs = v * s;
   ph = __builtin_convertvector(xs, f16x4);
+#ifndef NDJIR_SPLIT_MIX
   const f32x4 res = (xs - __builtin_convertvector(ph, f32x4)) * LO_SCALE;
   pl = __builtin_convertvector(res, f16x4);
+#else
+  // lo = f16((xs - hi) 2^11) = f16(fma(hi, -2^11, xs 2^11)) -- the same value (xs - hi is exact, and so are both products): one
+  // mixed-precision FMA per element that reads hi where it lies, as an f16 half of the packed pair, and writes its half of the
+  // packed result (v_fma_mixlo / mixhi_f16), instead of convert back + subtract + multiply + convert + pack: 2.5 vector
+  // instructions per element for the split instead of 4.  OPT-IN (-DNDJIR_SPLIT_MIX): bit-identical results (the step-parity
+  // and fp64-accuracy suites pass on it), but the step measured 0.4 % SLOWER on it in three same-box pairs (round 5) -- phase B
+  // is not bound by its vector instructions, and four opaque asm statements per group cost the scheduler its freedom.
+  // (xs 2^11 from xs, not v (s 2^11): an all-zero row carries the largest scale, whose product with 2^11 is inf.)
+  const f32x4 x2 = xs * LO_SCALE;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 hp = __builtin_bit_cast(u32x2, ph);
+  const float m = -LO_SCALE;
+  unsigned l01, l23;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(hp[0]), "v"(m), "v"(x2[0]));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(hp[0]), "v"(m), "v"(x2[1]));
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(hp[1]), "v"(m), "v"(x2[2]));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(hp[1]), "v"(m), "v"(x2[3]));
+  pl = __builtin_bit_cast(f16x4, u32x2{l01, l23});
+#endif
 }
 __device__ __forceinline__ void split1(float v, float s, _Float16& ph, _Float16& pl) {
 #pragma clang fp contract(off)

@@ -16,6 +16,18 @@ O=gpurun_out/profiles_new; mkdir -p $O
   echo "# python tools/exchange_bench.py   (GPU time of one rank's share of an 8-rank exchange at the bench size)"
   python tools/exchange_bench.py 2>/dev/null | tail -3
 } > $O/force_dist_1rank_rccl.txt 2>&1
+# per-kernel tables of BASELINE config 3 (triplaneline) and of `custom` (Lanczos voxel): differenced 4- and 12-step eager runs, as for the default step
+export TMPDIR=/tmp
+for c in triplaneline custom; do
+  for S in 4 12; do
+    rocprofv3 --kernel-trace --stats -d $O/ks -o run --output-format csv -- python3 bench.py --config $c --exec eager --steps $S --warmup 1 --no-cpu-baseline --no-extra-legs --train-steps 0 > /dev/null 2> $O/ks_${c}_err.txt
+    f=$(find $O/ks -name "*kernel_stats.csv" | head -1)
+    cp "$f" $O/ks_${c}_s$S.csv
+    rm -rf $O/ks
+  done
+  python tools/diff_summary.py $O/ks_${c}_s4.csv $O/ks_${c}_s12.csv 4 12 45 > $O/${c}_kernel_summary.txt
+  rm -f $O/ks_${c}_s4.csv $O/ks_${c}_s12.csv
+done
 python tools/render_bench.py > $O/render_bench.txt 2>/dev/null
 python tools/launch_list.py 2>&1 | grep -v "amdgpu.ids\|Warning\|_warn_once" > $O/stock_launches.txt
 tail -3 $O/configs.txt
