@@ -541,8 +541,18 @@ __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restr
       *reinterpret_cast<float4*>(vals + 4 * t) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    const long long tid = base + threadIdx.x;
-    if ((int)threadIdx.x < ppp && tid < total) {
+    // Lanes per point.  The 4 x 4 x 4 Lanczos stencil leaves room for 32 points per pass (table half full in the worst case):
+    // with one lane per point, 224 of the workgroup's 256 lanes sat out the insertion of 64 taps each (round 4: 413 us per
+    // launch, 1.7 ms per `custom` step).  Eight lanes share a point instead -- lane u takes the taps (i = u >> 1,
+    // j in {2 (u & 1), 2 (u & 1) + 1}, all k) of the stencil every one of them evaluates.
+#ifdef NDJIR_LANCZOS_LPP1
+    constexpr int LPP = 1;
+#else
+    constexpr int LPP = (I == LANCZOS && ND == 3) ? 8 : 1;
+#endif
+    const int pt = (int)threadIdx.x / LPP, sub = (int)threadIdx.x % LPP;
+    const long long tid = base + pt;
+    if (pt < ppp && tid < total) {
       const int s = (int)(tid / P);
       const long long b = tid - (long long)s * P;
       float q[3] = {query[b * 3], query[b * 3 + 1], query[b * 3 + 2]};
@@ -553,11 +563,26 @@ __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restr
 #pragma unroll
         for (int a = 0; a < ND; ++a) ggs[a] = gg_query[b * 3 + st.axis[a]] * st.scale[a] * st.ax[a].gm;
       }
+      if constexpr (LPP > 1) {
+        // this lane's slab of the stencil: axis-0 tap i0, axis-1 taps j0, j0 + 1 (selected, not indexed: the taps live in registers)
+        const int i0 = sub >> 1, j0 = 2 * (sub & 1);
+        auto sel = [](const auto (&arr)[4], int i) { return i == 0 ? arr[0] : i == 1 ? arr[1] : i == 2 ? arr[2] : arr[3]; };
+        st.ax[0].w[0] = sel(st.ax[0].w, i0); st.ax[0].dw[0] = sel(st.ax[0].dw, i0); st.ax[0].idx[0] = sel(st.ax[0].idx, i0);
+        const float w1a = sel(st.ax[1].w, j0), w1b = sel(st.ax[1].w, j0 + 1), d1a = sel(st.ax[1].dw, j0), d1b = sel(st.ax[1].dw, j0 + 1);
+        const unsigned x1a = sel(st.ax[1].idx, j0), x1b = sel(st.ax[1].idx, j0 + 1);
+        st.ax[1].w[0] = w1a; st.ax[1].w[1] = w1b; st.ax[1].dw[0] = d1a; st.ax[1].dw[1] = d1b; st.ax[1].idx[0] = x1a; st.ax[1].idx[1] = x1b;
+      }
+      constexpr int NI = LPP > 1 ? 1 : NT, NJ = LPP > 1 ? 2 : (ND > 1 ? NT : 1), NK = ND > 2 ? NT : 1;
       for (int d0 = 0; d0 < g.D; d0 += 4) {       // a cell of D floats = D / 4 float4 entries of the table
         float og[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) og[v] = grad_output[out_index<TOPO>(g, P, b, s, d0 + v)];
-        NDJIR_FOR_TAPS(ND, NT) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
           float w;
           if constexpr (MODE == 0) {
             w = tap_w(st, i, j, k);
@@ -1101,7 +1126,11 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
   const int per_point = taps * (g.D / 4);
   if (g.topo == TRILINE && g.D <= 8 && g.G[0] * g.D <= HASH_LDS_FLOATS && P >= 64LL * g.G[0] && !no_agg) {
     long long shares = 170;                                           // 3 lines x 170 = 510 workgroups
-    const long long max_shares = P / (8LL * g.G[0]);                  // >= 8 points per cell of the line and workgroup
+    // >= `div` points per cell of the line and workgroup.  Round 5: 8 -> 2.  At the step's 131 072 points and G = 2048 the old
+    // bound left 8 shares = 24 workgroups on a 256-CU chip (382 us per launch, 0.02 of the HBM roof: 16 384 points x 16 LDS
+    // atomics each, serially per workgroup); the flush it was protecting is cheap -- a line image is 2 048 requests of 32 bytes
+    static const long long div = [] { const char* e = getenv("NDJIR_LINE_SHARE_POINTS"); const int v = e ? atoi(e) : 2; return (long long)(v > 0 ? v : 2); }();
+    const long long max_shares = P / (div * g.G[0]);
     if (shares > max_shares) shares = max_shares;
     if (shares < 1) shares = 1;
     const size_t lds = (size_t)g.G[0] * g.D * sizeof(float);

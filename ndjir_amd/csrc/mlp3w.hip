@@ -71,35 +71,49 @@ struct ManyNets {
 // (vector pipe, memory) -- inside ONE workgroup all waves share a barrier schedule and the two phases can only add
 // (a 256-wide layer of a 128-point tile took 32 k cycles forward / 38 k backward against 12.3 k of matrix time,
 // on an idle chip as on a full one).  The price: a weight fragment feeds 2 row blocks instead of 4 (the L2 -> CU stream doubles).
-template <int MODE, int RPW, int NWAVES, int TM, int CPW, class NETS>
+// TEAMS = 2 (round 5, TM = 64, CPW = 2, NWAVES = 4 waves PER TEAM): ONE 8-wave workgroup holds two independent 64-point tiles, one
+// per team of four waves (one wave of each team on every SIMD; each team has its own planes, row maxima and scales).  Both
+// teams run the same program -- everything below is written per team: `tid`, `wave`, NTHREADS, NWAVES are team-local -- but team
+// 1 runs it ONE BARRIER BEHIND team 0 (it passes one extra barrier before its first tile, team 0 one after its last), and a hidden
+// layer is cut into three barrier intervals: k-loop | activation epilogue | split.  A workgroup barrier releases when every wave
+// has arrived at A barrier, so the n-th barrier of team 0 pairs with the (n - 1)-th of team 1 and the intervals pair up as
+// (k-loop, split), (epilogue, k-loop), (split, epilogue): on every SIMD one wave multiplies while the other runs vector
+// instructions -- the overlap two free-running workgroups per CU did not find (they fell into step).  Weight fragments feed
+// 2 row blocks instead of 4, as in the 64-point-tile kernel above.
+template <int MODE, int RPW, int NWAVES, int TM, int CPW, int TEAMS, class NETS>
 __device__ __forceinline__ void chainw_body(const NETS nets) {
   constexpr int TMP = tile_pad(TM);
-  constexpr int NTHREADS = NWAVES * 64;
+  constexpr int NTHREADS = NWAVES * 64;      // (per team)
   constexpr bool BWD = (MODE == 1);
   constexpr int G = (TM / 32) / RPW;   // wave groups sharing a column block's rows
   constexpr int CB = NWAVES / G;       // column blocks per round (x CPW for a hidden layer)
   constexpr int NBLK = RPW * CPW;      // 32 x 32 output blocks (accumulator pairs) of a wave
   static_assert(NBLK <= 4 && (CPW == 1 || (RPW == 2 && G == 1)), "accumulator budget");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ unsigned s_rmax[2][TM];   // per row: largest finite |output| of the layer (bit pattern; ping-pong by layer)
-  __shared__ unsigned s_xmax[2][TM];   // per row: largest finite |x| of the chain input tile (ping-pong by tile)
-  __shared__ float s_ainv[TM];         // per row: 1 / scale of the planes the next k-loop reads
+  __shared__ unsigned s_rmax_t[TEAMS][2][TM];   // per row: largest finite |output| of the layer (bit pattern; ping-pong by layer)
+  __shared__ unsigned s_xmax_t[TEAMS][2][TM];   // per row: largest finite |x| of the chain input tile (ping-pong by tile)
+  __shared__ float s_ainv_t[TEAMS][TM];         // per row: 1 / scale of the planes the next k-loop reads
   const int n_nets = nets.n();
   const auto& a0 = nets.get(0);
   const int PLANE = a0.lds_split;      // 16-byte units per plane ( = k-groups * TMP ); one value for the whole group
-  f16x8* act = reinterpret_cast<f16x8*>(lds);
-  char* actb = reinterpret_cast<char*>(lds);
-  const int tid = threadIdx.x;
+  const int gwave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int team = TEAMS == 1 ? 0 : gwave / NWAVES;
+  unsigned (&s_rmax)[2][TM] = s_rmax_t[team];
+  unsigned (&s_xmax)[2][TM] = s_xmax_t[team];
+  float (&s_ainv)[TM] = s_ainv_t[team];
+  f16x8* act = reinterpret_cast<f16x8*>(lds) + (size_t)team * 2 * PLANE;      // (a team's two planes)
+  char* actb = reinterpret_cast<char*>(act);
+  const int tid = (int)threadIdx.x - team * NTHREADS;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = gwave - team * NWAVES;
   // an opaque copy of the lane id: addresses derived from it are formed where they are used instead of being hoisted out of
   // the tile / layer loops into registers that stay occupied (or spilled) through the k-loops
   auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
   auto stamp = [&](int li, int phase) {
-    if (a0.timeline && blockIdx.x == 0 && lane == 0) a0.timeline[(li * 5 + phase) * 8 + wave] = (long long)__builtin_amdgcn_s_memtime();
+    if (a0.timeline && blockIdx.x == 0 && lane == 0) a0.timeline[(li * 5 + phase) * 8 + gwave] = (long long)__builtin_amdgcn_s_memtime();
   };
   auto stamp_rt = [&](int phase) {
-    if (a0.timeline && blockIdx.x == 0 && lane == 0) a0.timeline[((MAX_CHAIN_LAYERS - 2) * 5 + phase) * 8 + wave] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (a0.timeline && blockIdx.x == 0 && lane == 0) a0.timeline[((MAX_CHAIN_LAYERS - 2) * 5 + phase) * 8 + gwave] = (long long)__builtin_amdgcn_s_memrealtime();
   };
   // write 4 consecutive features k..k+3 (k % 4 == 0) of row m, scaled by s, into the two planes
   auto put4 = [&](int k, int m, f32x4 v, float s) {
@@ -119,7 +133,7 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
 
   stamp(MAX_CHAIN_LAYERS - 1, 0);
   stamp_rt(0);
-  if constexpr (TM == 64) {
+  if constexpr (TM == 64 && TEAMS == 1) {
     // Two workgroups share a CU (a grid of 512 fills the chip exactly, 256 at a time: workgroups b and b + 256 are the pair of
     // a CU, the launcher caps the grid there).  With equal priority the two fall into step -- both in their k-loops at half
     // speed, then both in their epilogues -- and nothing overlaps.  One of them always wins the arbitration instead: it runs
@@ -156,11 +170,12 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
     }
   if (tid < 2 * TM) { (&s_rmax[0][0])[tid] = 0u; (&s_xmax[0][0])[tid] = 0u; }
   __syncthreads();
+  if (TEAMS == 2 && team == 1) __syncthreads();      // team 1 runs one barrier behind team 0 from here on
   int xpar = 0;                        // ping-pong slot of the input row maxima
   bool warm_pending = true;
 
   for (long long tile = blockIdx.x; tile < a0.n_tiles; tile += gridDim.x) {
-    const long long row0 = tile * TM;  // (the launcher guarantees P % TM == 0: every tile is full)
+    const long long row0 = (tile * TEAMS + team) * TM;  // (the launcher guarantees P % (TM * TEAMS) == 0: every tile is full)
    for (int ni = 0; ni < n_nets; ++ni) {
     const auto& a = nets.get(ni);
     float* const bsum = lds + a.bg_lds;
@@ -408,6 +423,7 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
           active = actc[0];
           if (active) kloop(nbk, rb0, ks0, ks1);        // (the kernel's only k-loop instantiation)
           if (round == 0) stamp(li, 1);
+          if (TEAMS == 2 && !last && !narrow) __syncthreads();      // a hidden layer's first interval ends here (see TEAMS above)
           if (narrow) break;
           if (!last || !active) continue;
           // ---- output layer: z = acc / scales (+ bias) -> Y ----
@@ -458,7 +474,7 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
         }   // rounds
         if (narrow) {
           __syncthreads();
-          float* part = lds;                       // [kq][m][n]: 4 x TM x 32 floats = 64 KB <= the planes
+          float* part = reinterpret_cast<float*>(actb);     // [kq][m][n]: 4 x TM x 32 floats <= the (team's) planes
           if (active) {
             const int lane_o = fresh_lane();
             const int r_o = lane_o & 31, hh = lane_o >> 5;
@@ -773,7 +789,7 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
 #define NDJIR_SUB(P)
 #endif
             // (fences between the blocks: the loads of block J + 2 must not drift above the math of block J, whose registers
-            // they take over)
+            // they take over; the forward pass, which has no side loads, measured the same with and without them)
             NDJIR_SUB(0);
             hidden_block(I0{}, ft, et, lt);
             __builtin_amdgcn_sched_barrier(0);
@@ -914,6 +930,7 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
   }
   stamp(MAX_CHAIN_LAYERS - 1, 3);
   stamp_rt(1);
+  if (TEAMS == 2 && team == 0) __syncthreads();      // (pairs with team 1's last barrier)
   if (MODE != 0) {
     __syncthreads();
     for (int ni = 0; ni < n_nets; ++ni) {
@@ -926,13 +943,16 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
 }
 
 // TMv = 128: <RPW, NWAVES> = <4, 8>, <2, 8>, <4, 4>;  TMv = 64: <2, 4> with two column blocks per wave (two workgroups per CU)
+//            <2, 8> with TMv = 64: two TEAMS of four waves in one workgroup, a 64-point tile each
 template <int MODE, int RPW, int NWAVES, int TMv = 128>
 __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw(ChainArgs a) {
-  chainw_body<MODE, RPW, NWAVES, TMv, TMv == 64 ? 2 : 1>(OneNet{a});
+  constexpr int TEAMS = (TMv == 64 && NWAVES == 8) ? 2 : 1;
+  chainw_body<MODE, RPW, NWAVES / TEAMS, TMv, TMv == 64 ? 2 : 1, TEAMS>(OneNet{a});
 }
 template <int MODE, int RPW, int NWAVES, int TMv = 128>
 __global__ void __launch_bounds__(NWAVES * 64, 2) k_chainw_nets(ChainGroup /* read in the kernel-argument segment */) {
-  chainw_body<MODE, RPW, NWAVES, TMv, TMv == 64 ? 2 : 1>(ManyNets{(const KGroup*)__builtin_amdgcn_kernarg_segment_ptr()});
+  constexpr int TEAMS = (TMv == 64 && NWAVES == 8) ? 2 : 1;
+  chainw_body<MODE, RPW, NWAVES / TEAMS, TMv, TMv == 64 ? 2 : 1, TEAMS>(ManyNets{(const KGroup*)__builtin_amdgcn_kernarg_segment_ptr()});
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -998,24 +1018,36 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
   constexpr int LDS_DYN_MAX = 160 * 1024 - 4096;      // the kernel also holds 2.5 KB of static LDS (row maxima / scales)
   if (n < 1 || n > MAX_GROUP_NETS) return NDJIR_ERR_UNSUPPORTED;
   static bool attr_set = false;
-  static int nw4 = 1, t64 = 0;
+  static int nw4 = 1, t64 = 0, teams_on = 0;
   if (!attr_set) {
 #define NDJIR_SET(M, R, W) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw<M, R, W>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX); \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw_nets<M, R, W>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX)
     NDJIR_SET(0, 4, 8); NDJIR_SET(1, 4, 8); NDJIR_SET(2, 4, 8); NDJIR_SET(0, 2, 8); NDJIR_SET(1, 2, 8); NDJIR_SET(2, 2, 8);
     NDJIR_SET(0, 4, 4); NDJIR_SET(1, 4, 4); NDJIR_SET(2, 4, 4);
 #undef NDJIR_SET
-#define NDJIR_SET64(M) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw<M, 2, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX); \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw_nets<M, 2, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX)
-    NDJIR_SET64(0); NDJIR_SET64(1); NDJIR_SET64(2);
-#undef NDJIR_SET64
-    // 64-point tiles, two 4-wave workgroups per CU, for nets with hidden layers wider than 128 columns whose planes + bias sums fit
-    // the LDS twice (see chainw_body): bit 0 forward, bit 1 backward, bit 2 tangent.  OFF by default (NDJIR_CHAINW_T64=7 switches
-    // it on): measured round 5, same box, default step 8.40 ms with it against 8.10 without -- the two workgroups of a CU fall
-    // into step (k-loops together, epilogues together) with or without a static priority for one of them, a layer of a 64-point
-    // tile takes the 30 - 33 k cycles the 128-point tile takes, and the tangent chain is 40 % slower (its weights stream twice)
+    // Two round-5 experiments, both measured slower and NOT built by default (-DNDJIR_CHAINW_EXPERIMENTS builds them:
+    // tools/build_variant.sh exp mlp3w.hip -DNDJIR_CHAINW_EXPERIMENTS; then NDJIR_CHAINW_T64=7 / NDJIR_CHAINW_TEAMS=7, bit 0
+    // forward, 1 backward, 2 tangent; nets with hidden layers wider than 128 columns whose planes + bias sums fit):
+    //   * T64: 64-point tiles, TWO 4-wave workgroups per CU (chainw_body, TM = 64 / CPW = 2).  Default step 8.40 ms against 8.10
+    //     (same box), with or without a static priority for one workgroup of a CU's pair: the two fall into step, a layer of a
+    //     64-point tile takes the 30 - 33 k cycles the 128-point tile takes, the tangent chain +40 % (weights stream twice).
+    //   * TEAMS: the same two tiles as two teams of ONE 8-wave workgroup, one barrier apart (chainw_body, TEAMS = 2), so that
+    //     the intervals pair up as (k-loop, split), (epilogue, k-loop), (split, epilogue).  9.62 ms against 8.13.  The pairing
+    //     works -- but a wave's activation epilogue ALONE on its SIMD takes 12 k cycles for its 64 elements (15 cycles per
+    //     vector instruction: dependent chains through exp / log), while the two waves of a SIMD in their epilogues TOGETHER
+    //     take 11 k for both: the epilogue is latency-bound per wave, and the lock-step schedule is what hides it.
+#ifdef NDJIR_CHAINW_EXPERIMENTS
+#define NDJIR_SETX(M, W) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw<M, 2, W, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX); \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chainw_nets<M, 2, W, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DYN_MAX)
+    NDJIR_SETX(0, 4); NDJIR_SETX(1, 4); NDJIR_SETX(2, 4); NDJIR_SETX(0, 8); NDJIR_SETX(1, 8); NDJIR_SETX(2, 8);
+#undef NDJIR_SETX
     const char* e64 = getenv("NDJIR_CHAINW_T64");
     t64 = e64 ? atoi(e64) : 0;
+    const char* et = getenv("NDJIR_CHAINW_TEAMS");
+    teams_on = et ? atoi(et) : 0;
+#else
+    t64 = 0; teams_on = 0;
+#endif
     // 4-wave workgroups (two per CU) for nets of up to 4 column blocks whose planes fit twice: bit 0 forward, bit 1 backward,
     // bit 2 tangent.  Measured (env-light / soft-visibility nets, 131072 points): forward 145 -> 133 us, backward 166 -> 173 us
     const char* e = getenv("NDJIR_CHAINW_NW4");
@@ -1044,9 +1076,12 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
     for (int i = 0; i < n; ++i)
       if (((size_t)2 * (plan[i].wmax / 8) * tile_pad(64) * 16 + (size_t)plan[i].bg_total * 4 <= LDS_HALF) != tile64 && rpw == 4 && ((t64 >> mode) & 1))
         return NDJIR_ERR_UNSUPPORTED;
-  const int tm = tile64 ? 64 : 128;
+  // two teams in one workgroup: both teams' planes + the bias sums in the one workgroup's LDS
+  const bool teams = !tile64 && rpw == 4 && ((teams_on >> mode) & 1) &&
+                     (size_t)2 * 2 * (wmax / 8) * tile_pad(64) * 16 + (size_t)bg_sum * 4 <= (size_t)LDS_DYN_MAX;
+  const int tm = (tile64 || teams) ? 64 : 128;
   const int lds_split = (wmax / 8) * tile_pad(tm);             // 16-byte units per plane
-  size_t lds_bytes = (size_t)2 * lds_split * 16;
+  size_t lds_bytes = (size_t)2 * lds_split * 16 * (teams ? 2 : 1);
   int bg_lds = (int)(lds_bytes / 4);
   lds_bytes += (size_t)bg_sum * 4;
   if (lds_bytes > LDS_DYN_MAX) return NDJIR_ERR_UNSUPPORTED;
@@ -1055,7 +1090,7 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
   // a group runs the kernel each of its nets would run alone (the symbol a profile is keyed by, the grid the deferred bias
   // partials were laid out for)
   for (int i = 0; i < n && n > 1; ++i) if (own_four[i] != four) return NDJIR_ERR_UNSUPPORTED;
-  for (int i = 0; i < n; ++i) plan[i].b.n_tiles = nets[i].P / tm;
+  for (int i = 0; i < n; ++i) plan[i].b.n_tiles = nets[i].P / (teams ? 128 : tm);
   long long blocks = plan[0].b.n_tiles;
   if (blocks > 256LL * 8) blocks = 256LL * 8;
   if (tile64 && blocks > 512) blocks = 512;         // (two per CU, resident for the whole launch: the priority pairing above)
@@ -1077,7 +1112,8 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
     grp.net[i] = plan[i].b;
   }
   if (nets[0].dry) {
-    if (tile64) snprintf(nets[0].dry->name, 64, "ndjir::x3w::k_chainw%s<%d, 2, 4, 64>", n > 1 ? "_nets" : "", mode);
+    if (teams) snprintf(nets[0].dry->name, 64, "ndjir::x3w::k_chainw%s<%d, 2, 8, 64>", n > 1 ? "_nets" : "", mode);
+    else if (tile64) snprintf(nets[0].dry->name, 64, "ndjir::x3w::k_chainw%s<%d, 2, 4, 64>", n > 1 ? "_nets" : "", mode);
     else snprintf(nets[0].dry->name, 64, "ndjir::x3w::k_chainw%s<%d, %d, %d, 128>", n > 1 ? "_nets" : "", mode, (rpw == 4 || four) ? 4 : 2, four ? 4 : 8);
     nets[0].dry->blocks = (int)blocks; nets[0].dry->bg_total = plan[0].bg_total;
     return NDJIR_OK;
@@ -1087,17 +1123,27 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
     if (n == 1) hipLaunchKernelGGL((k_chainw<M, R, W>), dim3((unsigned)blocks), dim3(W * 64), lds_bytes, stream, grp.net[0]); \
     else hipLaunchKernelGGL((k_chainw_nets<M, R, W>), dim3((unsigned)blocks), dim3(W * 64), lds_bytes, stream, grp);         \
   } while (0)
+#ifdef NDJIR_CHAINW_EXPERIMENTS
 #define NDJIR_GO64(M)                                                                                                          \
   do {                                                                                                                      \
     if (n == 1) hipLaunchKernelGGL((k_chainw<M, 2, 4, 64>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, grp.net[0]); \
     else hipLaunchKernelGGL((k_chainw_nets<M, 2, 4, 64>), dim3((unsigned)blocks), dim3(256), lds_bytes, stream, grp);         \
   } while (0)
-  if (tile64) { if (mode == 0) NDJIR_GO64(0); else if (mode == 1) NDJIR_GO64(1); else NDJIR_GO64(2); }
-  else if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4, 8); else if (mode == 1) NDJIR_GO(1, 4, 8); else NDJIR_GO(2, 4, 8); }
+#define NDJIR_GOT(M)                                                                                                           \
+  do {                                                                                                                      \
+    if (n == 1) hipLaunchKernelGGL((k_chainw<M, 2, 8, 64>), dim3((unsigned)blocks), dim3(512), lds_bytes, stream, grp.net[0]); \
+    else hipLaunchKernelGGL((k_chainw_nets<M, 2, 8, 64>), dim3((unsigned)blocks), dim3(512), lds_bytes, stream, grp);         \
+  } while (0)
+  if (teams) { if (mode == 0) NDJIR_GOT(0); else if (mode == 1) NDJIR_GOT(1); else NDJIR_GOT(2); }
+  else if (tile64) { if (mode == 0) NDJIR_GO64(0); else if (mode == 1) NDJIR_GO64(1); else NDJIR_GO64(2); }
+  else
+#endif
+  if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4, 8); else if (mode == 1) NDJIR_GO(1, 4, 8); else NDJIR_GO(2, 4, 8); }
   else if (four) { if (mode == 0) NDJIR_GO(0, 4, 4); else if (mode == 1) NDJIR_GO(1, 4, 4); else NDJIR_GO(2, 4, 4); }
   else { if (mode == 0) NDJIR_GO(0, 2, 8); else if (mode == 1) NDJIR_GO(1, 2, 8); else NDJIR_GO(2, 2, 8); }
 #undef NDJIR_GO
 #undef NDJIR_GO64
+#undef NDJIR_GOT
   int rc = ndjir_check_launch();
   for (int i = 0; i < n && rc == NDJIR_OK; ++i)
     if (plan[i].bg_total > 0 && !nets[i].defer_bg_reduce)
