@@ -333,6 +333,18 @@ int ndjir_render_specular_light_filament_backward(int R, int M, int C, const flo
                                                   const float* soft_vis, const float* env, float eps_dot, float weight,
                                                   const float* g, float* g_normal, float* g_roughness, float* g_specular_color,
                                                   float* g_soft_vis, float* g_env, hipStream_t stream);
+/* Every other branch of the specular BRDF in one launch each way (python/specular_brdf.py:40-199, python/renderer.py:141-161):
+ * model 0 filament | 1 ue4; sampling 0 importance | 1 uniform; split != 0: use_split_sum --
+ * weight * mean_m(soft_vis env) * mean_m(sBRDF cos) instead of weight * mean_m(sBRDF soft_vis env cos).  Shapes as for
+ * ndjir_render_specular_light_filament (which stays the default branch's kernel).  The half vector has no gradient. */
+int ndjir_render_specular_light(int R, int M, int C, int model, int sampling, int split, const float* normal, const float* view_dir,
+                                const float* light_dir, const float* roughness, const float* specular_color, const float* soft_vis,
+                                const float* env, float eps_dot, float weight, float* out, hipStream_t stream);
+int ndjir_render_specular_light_backward(int R, int M, int C, int model, int sampling, int split, const float* normal,
+                                         const float* view_dir, const float* light_dir, const float* roughness,
+                                         const float* specular_color, const float* soft_vis, const float* env, float eps_dot,
+                                         float weight, const float* g, float* g_normal, float* g_roughness, float* g_specular_color,
+                                         float* g_soft_vis, float* g_env, hipStream_t stream);
 
 /* Background head (python/network.py:543-556): h (P, 1 + F) = output of the background model's geometric net, x (P, nx) its
  * inverted-sphere sample coordinates, delta (P) the sample spacing.  alpha (P) = 1 - exp(-softplus_100(h_0) delta);

@@ -626,6 +626,198 @@ __global__ void __launch_bounds__(SH_THREADS) k_specular_light_bwd(int M, int C,
   }
 }
 
+// ---- every other branch of the specular BRDF (python/specular_brdf.py:40-199, python/renderer.py:141-161) -------------------
+// MODEL 0 filament (:40-118) | 1 ue4 (:121-191);  SAMPLING 0 importance | 1 uniform;  SPLIT: use_split_sum
+// (renderer.py:153-156:  mean_m(soft_vis env) * mean_m(sBRDF cos)  instead of  mean_m(sBRDF soft_vis env cos)).
+//   sBRDF_k = W(nol, nov; rough) K(noh, nol, nov, voh; rough) Fs_k(voh) mask
+//   filament: W = V1(nol) V1(nov), V1(u) = 1 / (u + sqrt(a2 + (1 - a2) u^2) + eps), a2 = rough^2, Fs = sc + (1 - sc)(1 - voh)^5,
+//             importance K = 4 voh / noh,  uniform K = pi D,  D = a2 / (pi (noh^2 (a2 - 1) + 1)^2 + eps)
+//   ue4:      W = G1(nol) G1(nov), G1(u) = u / (u (1 - k) + k + eps), k = (rough + 1)^2 / 8, Fs = sc + (1 - sc) 2^((-5.55473 voh - 6.98316) voh),
+//             importance K = voh / (noh nov),  uniform K = pi D / (4 nov nol) with a2 = rough^4
+// One workgroup per ray, lanes over the M light directions; the half vector carries no gradient (view and light directions are
+// inputs without one), so voh is a constant of the backward pass.  The default branch (filament, importance, no split sum) keeps
+// its own kernels above and inside k_direct_light.
+struct SpecG {
+  float S;                 // W K mask
+  float W, K;
+  float dW_dnol, dW_dnov, dW_dr;          // partials of W (r = roughness)
+  float dK_dnoh, dK_dnol, dK_dnov, dK_dr; // partials of K
+  float f;                 // Fresnel weight: Fs_k = sc_k + (1 - sc_k) f
+};
+
+template <int MODEL, int SAMPLING>
+__device__ __forceinline__ SpecG spec_general(const SpecTerms& t, float r) {
+  constexpr float PI = 3.14159265358979323846f, eps = 1e-6f;
+  SpecG o;
+  float a2, da2_dr;
+  if (MODEL == 0) { a2 = r * r; da2_dr = 2.f * r; } else { a2 = r * r * r * r; da2_dr = 4.f * r * r * r; }
+  if (MODEL == 0) {
+    // (t.V1l, t.V1v, t.sl, t.sv_ are the filament terms with a2 = r^2)
+    const float om = 1.f - a2;
+    o.W = t.V1l * t.V1v;
+    const float dV1l_du = -t.V1l * t.V1l * (1.f + om * t.nol / t.sl), dV1v_du = -t.V1v * t.V1v * (1.f + om * t.nov / t.sv_);
+    const float dV1l_da = -t.V1l * t.V1l * (1.f - t.nol * t.nol) / (2.f * t.sl), dV1v_da = -t.V1v * t.V1v * (1.f - t.nov * t.nov) / (2.f * t.sv_);
+    o.dW_dnol = dV1l_du * t.V1v;
+    o.dW_dnov = t.V1l * dV1v_du;
+    o.dW_dr = (dV1l_da * t.V1v + t.V1l * dV1v_da) * da2_dr;
+    const float omv = 1.f - t.voh;
+    o.f = omv * omv * omv * omv * omv;
+  } else {
+    const float k = (r + 1.f) * (r + 1.f) * 0.125f, dk_dr = (r + 1.f) * 0.25f;
+    const float dl = t.nol * (1.f - k) + k + eps, dv = t.nov * (1.f - k) + k + eps;
+    const float G1l = t.nol / dl, G1v = t.nov / dv;
+    o.W = G1l * G1v;
+    o.dW_dnol = (k + eps) / (dl * dl) * G1v;
+    o.dW_dnov = G1l * (k + eps) / (dv * dv);
+    const float dG1l_dk = -t.nol * (1.f - t.nol) / (dl * dl), dG1v_dk = -t.nov * (1.f - t.nov) / (dv * dv);
+    o.dW_dr = (dG1l_dk * G1v + G1l * dG1v_dk) * dk_dr;
+    o.f = exp2f((-5.55473f * t.voh - 6.98316f) * t.voh);
+  }
+  o.dK_dnoh = o.dK_dnol = o.dK_dnov = o.dK_dr = 0.f;
+  if (SAMPLING == 0) {
+    if (MODEL == 0) { o.K = 4.f * t.voh / t.noh; o.dK_dnoh = -o.K / t.noh; }
+    else { o.K = t.voh / (t.noh * t.nov); o.dK_dnoh = -o.K / t.noh; o.dK_dnov = -o.K / t.nov; }
+  } else {
+    const float q = t.noh * t.noh * (a2 - 1.f) + 1.f;
+    const float den = PI * q * q + eps;
+    const float D = a2 / den;
+    const float dD_dnoh = -a2 * PI * 2.f * q * (2.f * t.noh * (a2 - 1.f)) / (den * den);
+    const float dD_da2 = 1.f / den - a2 * PI * 2.f * q * t.noh * t.noh / (den * den);
+    if (MODEL == 0) { o.K = PI * D; o.dK_dnoh = PI * dD_dnoh; o.dK_dr = PI * dD_da2 * da2_dr; }
+    else {
+      const float c = PI / (4.f * t.nov * t.nol);
+      o.K = c * D; o.dK_dnoh = c * dD_dnoh; o.dK_dr = c * dD_da2 * da2_dr;
+      o.dK_dnov = -o.K / t.nov; o.dK_dnol = -o.K / t.nol;
+    }
+  }
+  o.S = o.W * o.K * t.mask;
+  return o;
+}
+
+template <int MODEL, int SAMPLING, bool SPLIT>
+__global__ void __launch_bounds__(SH_THREADS) k_specular_light_g(int M, int C, const float* __restrict__ normal,
+                                                                 const float* __restrict__ view, const float* __restrict__ light,
+                                                                 const float* __restrict__ rough, const float* __restrict__ spec,
+                                                                 const float* __restrict__ soft_vis, const float* __restrict__ env,
+                                                                 float eps_dot, float weight, float* __restrict__ out) {
+  __shared__ float red[2];
+  const long long r = blockIdx.x;
+  const float nx = normal[r * 3], ny = normal[r * 3 + 1], nz = normal[r * 3 + 2];
+  const float vx = view[r * 3], vy = view[r * 3 + 1], vz = view[r * 3 + 2];
+  const float ro = rough[r];
+  float acc[3] = {0.f, 0.f, 0.f}, accA[3] = {0.f, 0.f, 0.f};
+  for (int m = threadIdx.x; m < M; m += SH_THREADS) {
+    const long long e = r * M + m;
+    const SpecTerms t = spec_terms(nx, ny, nz, vx, vy, vz, light[e * 3], light[e * 3 + 1], light[e * 3 + 2], ro, eps_dot);
+    const SpecG gq = spec_general<MODEL, SAMPLING>(t, ro);
+    const float sv = soft_vis[e];
+    for (int k = 0; k < 3; ++k) {
+      const float sc = spec[r * 3 + k];
+      const float Fs = sc + (1.f - sc) * gq.f;
+      const float ek = env[e * C + (C == 1 ? 0 : k)];
+      if (SPLIT) { acc[k] += gq.S * Fs * t.nol; accA[k] += sv * ek; }
+      else acc[k] += gq.S * Fs * sv * ek * t.nol;
+    }
+  }
+  for (int k = 0; k < 3; ++k) {
+    const float s = sh_block_sum(acc[k], red);
+    float a = 1.f;
+    if (SPLIT) a = sh_block_sum(accA[k], red) / (float)M;
+    if (threadIdx.x == 0) out[r * 3 + k] = weight * a * s / (float)M;
+  }
+}
+
+template <int MODEL, int SAMPLING, bool SPLIT>
+__global__ void __launch_bounds__(SH_THREADS) k_specular_light_g_bwd(int M, int C, const float* __restrict__ normal,
+                                                                     const float* __restrict__ view, const float* __restrict__ light,
+                                                                     const float* __restrict__ rough, const float* __restrict__ spec,
+                                                                     const float* __restrict__ soft_vis, const float* __restrict__ env,
+                                                                     float eps_dot, float weight, const float* __restrict__ g,
+                                                                     float* __restrict__ g_normal, float* __restrict__ g_rough,
+                                                                     float* __restrict__ g_spec, float* __restrict__ g_soft_vis,
+                                                                     float* __restrict__ g_env) {
+  __shared__ float red[2];
+  const long long r = blockIdx.x;
+  const float nx = normal[r * 3], ny = normal[r * 3 + 1], nz = normal[r * 3 + 2];
+  const float vx = view[r * 3], vy = view[r * 3 + 1], vz = view[r * 3 + 2];
+  const float ro = rough[r];
+  const float wM = weight / (float)M;
+  float gk[3], sc[3];
+  for (int k = 0; k < 3; ++k) { gk[k] = g[r * 3 + k] * wM; sc[k] = spec[r * 3 + k]; }
+  // split sum: out_k = w A_k B_k, A_k = mean(sv env_k), B_k = mean(S Fs_k nol) -> each factor's gradient carries the other mean
+  float gA[3] = {0.f, 0.f, 0.f}, gB[3] = {gk[0], gk[1], gk[2]};
+  if (SPLIT) {
+    float sA[3] = {0.f, 0.f, 0.f}, sB[3] = {0.f, 0.f, 0.f};
+    for (int m = threadIdx.x; m < M; m += SH_THREADS) {
+      const long long e = r * M + m;
+      const SpecTerms t = spec_terms(nx, ny, nz, vx, vy, vz, light[e * 3], light[e * 3 + 1], light[e * 3 + 2], ro, eps_dot);
+      const SpecG gq = spec_general<MODEL, SAMPLING>(t, ro);
+      const float sv = soft_vis[e];
+      for (int k = 0; k < 3; ++k) {
+        sA[k] += sv * env[e * C + (C == 1 ? 0 : k)];
+        sB[k] += gq.S * (sc[k] + (1.f - sc[k]) * gq.f) * t.nol;
+      }
+    }
+    for (int k = 0; k < 3; ++k) {
+      const float A = sh_block_sum(sA[k], red) / (float)M, Bm = sh_block_sum(sB[k], red) / (float)M;
+      gA[k] = gk[k] * Bm;       // d out_k / d (sv env_k) per light
+      gB[k] = gk[k] * A;        // d out_k / d (S Fs_k nol) per light
+    }
+  }
+  float gn[3] = {0.f, 0.f, 0.f}, gr = 0.f, gsc[3] = {0.f, 0.f, 0.f};
+  for (int m = threadIdx.x; m < M; m += SH_THREADS) {
+    const long long e = r * M + m;
+    const float lx = light[e * 3], ly = light[e * 3 + 1], lz = light[e * 3 + 2];
+    const SpecTerms t = spec_terms(nx, ny, nz, vx, vy, vz, lx, ly, lz, ro, eps_dot);
+    const SpecG gq = spec_general<MODEL, SAMPLING>(t, ro);
+    const float sv = soft_vis[e];
+    float dS = 0.f, dnol = 0.f, dsv = 0.f;
+    float denv[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; ++k) {
+      const float ek = env[e * C + (C == 1 ? 0 : k)];
+      const float Fs = sc[k] + (1.f - sc[k]) * gq.f;
+      if (SPLIT) {
+        dsv += gA[k] * ek;
+        denv[C == 1 ? 0 : k] += gA[k] * sv;
+        dS += gB[k] * Fs * t.nol;
+        gsc[k] += gB[k] * gq.S * t.nol * (1.f - gq.f);
+        dnol += gB[k] * gq.S * Fs;
+      } else {
+        const float T = sv * ek * t.nol;
+        dsv += gk[k] * gq.S * Fs * ek * t.nol;
+        denv[C == 1 ? 0 : k] += gk[k] * gq.S * Fs * sv * t.nol;
+        dnol += gk[k] * gq.S * Fs * sv * ek;
+        dS += gk[k] * Fs * T;
+        gsc[k] += gk[k] * gq.S * T * (1.f - gq.f);
+      }
+    }
+    g_soft_vis[e] = dsv;
+    for (int k = 0; k < C; ++k) g_env[e * C + k] = denv[k];
+    const float dW = dS * gq.K * t.mask, dK = dS * gq.W * t.mask;
+    dnol += dW * gq.dW_dnol + dK * gq.dK_dnol;
+    const float dnov = dW * gq.dW_dnov + dK * gq.dK_dnov;
+    const float dnoh = dK * gq.dK_dnoh;
+    gr += dW * gq.dW_dr + dK * gq.dK_dr;
+    // clamped dots -> normal (clamp(min) passes the gradient where raw >= eps)
+    const float cl = (t.rnol >= eps_dot) ? dnol : 0.f, cv = (t.rnov >= eps_dot) ? dnov : 0.f, ch = (t.rnoh >= eps_dot) ? dnoh : 0.f;
+    gn[0] += cl * lx + cv * vx + ch * t.hx;
+    gn[1] += cl * ly + cv * vy + ch * t.hy;
+    gn[2] += cl * lz + cv * vz + ch * t.hz;
+  }
+  for (int k = 0; k < 3; ++k) {
+    const float s = sh_block_sum(gn[k], red);
+    if (threadIdx.x == 0) g_normal[r * 3 + k] = s;
+  }
+  for (int k = 0; k < 3; ++k) {
+    const float s = sh_block_sum(gsc[k], red);
+    if (threadIdx.x == 0) g_spec[r * 3 + k] = s;
+  }
+  {
+    const float s = sh_block_sum(gr, red);
+    if (threadIdx.x == 0) g_rough[r] = s;
+  }
+}
+
 // ---- background head (python/network.py:543-556) ---------------------------------------------------------------------------
 // h (P, 1 + F) = output of the background geometric net: density = softplus_100(h_0), alpha = 1 - exp(-density delta), and the
 // lighting net's per-sample input  [x (nx) | feature (F)]  (its per-ray inputs, the view direction and its encoding, enter
@@ -1020,6 +1212,49 @@ extern "C" int ndjir_render_specular_light_filament_backward(int R, int M, int C
                      specular_color, soft_vis, env, eps_dot, weight, g, g_normal, g_roughness, g_specular_color, g_soft_vis, g_env);
   return ndjir_check_launch();
 }
+
+// every model / sampling / split-sum combination (see k_specular_light_g)
+#define NDJIR_SPEC_DISPATCH(KERNEL, ...)                                                                                   \
+  do {                                                                                                                     \
+    const int key = (model << 2) | (sampling << 1) | (split ? 1 : 0);                                                      \
+    switch (key) {                                                                                                         \
+      case 0: hipLaunchKernelGGL((ndjir::KERNEL<0, 0, false>), dim3(R), dim3(ndjir::SH_THREADS), 0, stream, __VA_ARGS__); break; \
+      case 1: hipLaunchKernelGGL((ndjir::KERNEL<0, 0, true>), dim3(R), dim3(ndjir::SH_THREADS), 0, stream, __VA_ARGS__); break;  \
+      case 2: hipLaunchKernelGGL((ndjir::KERNEL<0, 1, false>), dim3(R), dim3(ndjir::SH_THREADS), 0, stream, __VA_ARGS__); break; \
+      case 3: hipLaunchKernelGGL((ndjir::KERNEL<0, 1, true>), dim3(R), dim3(ndjir::SH_THREADS), 0, stream, __VA_ARGS__); break;  \
+      case 4: hipLaunchKernelGGL((ndjir::KERNEL<1, 0, false>), dim3(R), dim3(ndjir::SH_THREADS), 0, stream, __VA_ARGS__); break; \
+      case 5: hipLaunchKernelGGL((ndjir::KERNEL<1, 0, true>), dim3(R), dim3(ndjir::SH_THREADS), 0, stream, __VA_ARGS__); break;  \
+      case 6: hipLaunchKernelGGL((ndjir::KERNEL<1, 1, false>), dim3(R), dim3(ndjir::SH_THREADS), 0, stream, __VA_ARGS__); break; \
+      default: hipLaunchKernelGGL((ndjir::KERNEL<1, 1, true>), dim3(R), dim3(ndjir::SH_THREADS), 0, stream, __VA_ARGS__); break; \
+    }                                                                                                                      \
+  } while (0)
+
+extern "C" int ndjir_render_specular_light(int R, int M, int C, int model, int sampling, int split, const float* normal,
+                                           const float* view_dir, const float* light_dir, const float* roughness,
+                                           const float* specular_color, const float* soft_vis, const float* env, float eps_dot,
+                                           float weight, float* out, hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  if (M < 1 || (C != 1 && C != 3) || model < 0 || model > 1 || sampling < 0 || sampling > 1) return NDJIR_ERR_UNSUPPORTED;
+  if (!normal || !view_dir || !light_dir || !roughness || !specular_color || !soft_vis || !env || !out) return NDJIR_ERR_ARG;
+  NDJIR_SPEC_DISPATCH(k_specular_light_g, M, C, normal, view_dir, light_dir, roughness, specular_color, soft_vis, env, eps_dot, weight, out);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_render_specular_light_backward(int R, int M, int C, int model, int sampling, int split, const float* normal,
+                                                    const float* view_dir, const float* light_dir, const float* roughness,
+                                                    const float* specular_color, const float* soft_vis, const float* env,
+                                                    float eps_dot, float weight, const float* g, float* g_normal, float* g_roughness,
+                                                    float* g_specular_color, float* g_soft_vis, float* g_env, hipStream_t stream) {
+  if (R <= 0) return NDJIR_OK;
+  if (M < 1 || (C != 1 && C != 3) || model < 0 || model > 1 || sampling < 0 || sampling > 1) return NDJIR_ERR_UNSUPPORTED;
+  if (!normal || !view_dir || !light_dir || !roughness || !specular_color || !soft_vis || !env || !g || !g_normal ||
+      !g_roughness || !g_specular_color || !g_soft_vis || !g_env)
+    return NDJIR_ERR_ARG;
+  NDJIR_SPEC_DISPATCH(k_specular_light_g_bwd, M, C, normal, view_dir, light_dir, roughness, specular_color, soft_vis, env, eps_dot, weight,
+                      g, g_normal, g_roughness, g_specular_color, g_soft_vis, g_env);
+  return ndjir_check_launch();
+}
+#undef NDJIR_SPEC_DISPATCH
 
 // ---- positional encoding (python/network.py:96-117) ----------------------------------------------------
 // out[p] = [x (C), cos(x_i 2^k) (C*M, band fastest), sin(x_i 2^k) (C*M)]; the reference builds it from

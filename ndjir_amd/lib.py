@@ -78,6 +78,8 @@ SIGS = {
     "render_diffuse_light_backward": "iiippppfpppp",
     "render_specular_light_filament": "iii" + "p" * 7 + "ffp",
     "render_specular_light_filament_backward": "iii" + "p" * 7 + "ff" + "p" * 6,
+    "render_specular_light": "iiiiii" + "p" * 7 + "ffp",
+    "render_specular_light_backward": "iiiiii" + "p" * 7 + "ff" + "p" * 6,
     "render_background_head": "liippppp",
     "render_background_head_backward": "liippppp",
     "render_gain": "ipfffp",

@@ -23,7 +23,7 @@ from .network import (background_network, base_color_network, material_nets_raw,
                       soft_visibility_light_network, specular_reflectance_network)
 from .sampler import sample_importance_directions, sample_points, sample_uniform_directions
 from .specular_brdf import dot, specular_brdf_model
-from .volume import (LIGHT_ACTS, alpha_weights, diffuse_light, direct_light, integrate, integrate_many, material_head, pixel_compose,
+from .volume import (LIGHT_ACTS, alpha_weights, diffuse_light, direct_light, integrate, integrate_many, material_head, pixel_compose, specular_light,
                      pixel_normal, specular_light_filament)
 
 
@@ -231,7 +231,14 @@ def pb_render(x_fg, t_fg, x_bg, t_bg, camloc, raydir, mask, cos_anneal_ratio, co
             # BRDF algebra and the light integral fused (csrc/render.hip)
             spec_pixel = specular_light_filament(normal_pixel, view_dir.reshape(B, R, 3), imp_dir, roughness_pixel,
                                                  spec_refl_pixel, soft_vis, env, conf.renderer.eps_dot, sb.weight)
+        elif (sb.model in ("filament", "ue4") and sb.sampling in ("importance", "uniform") and imp_dir.is_cuda
+              and not (ii.use_me and ii.use_me_on_specular) and env.shape[-1] in (1, 3) and spec_refl_pixel.shape[-1] == 3
+              and not os.environ.get("NDJIR_NO_FUSED_BRDF")):
+            # ue4 model, uniform sampling, split sum: the same fusion, one templated kernel pair (csrc/render.hip k_specular_light_g)
+            spec_pixel = specular_light(normal_pixel, view_dir.reshape(B, R, 3), imp_dir, roughness_pixel, spec_refl_pixel,
+                                        soft_vis, env, conf.renderer.eps_dot, sb.weight, sb.model, sb.sampling, sb.use_split_sum)
         else:
+            # (stock-op composite: the implicit-illumination term on the specular lobe, 1- or 2-channel reflectance, CPU)
             sBRDF, cos = specular_brdf_model(normal_pixel, view_dir, imp_dir, roughness_pixel, spec_refl_pixel, conf)
             if sb.use_split_sum:
                 spec_pixel = (soft_vis * env).mean(dim=2) * (sBRDF * cos).mean(dim=2)

@@ -234,6 +234,39 @@ def specular_light_filament(normal, view_dir, light_dir, roughness, specular_col
     return SpecularLightFilament.apply(normal, view_dir, light_dir, roughness, specular_color, soft_vis, env, eps_dot, weight)
 
 
+class SpecularLight(Function):
+    """renderer.py:141-161 for every other branch of the specular BRDF (python/specular_brdf.py:40-199): model filament | ue4,
+    sampling importance | uniform, with or without the split sum -- BRDF algebra and the light integral(s) in one launch each
+    way (csrc/render.hip k_specular_light_g).  Shapes as SpecularLightFilament; cfg = (model, sampling, split)."""
+
+    @staticmethod
+    def forward(ctx, normal, view_dir, light_dir, roughness, specular_color, soft_vis, env, eps_dot, weight, cfg):
+        B, R, M, C = env.shape
+        args = [_c(normal), _c(view_dir), _c(light_dir), _c(roughness), _c(specular_color), _c(soft_vis), _c(env)]
+        out = torch.empty((B, R, 3), device=env.device, dtype=torch.float32)
+        lib.call("render_specular_light", B * R, M, C, *cfg, *args, float(eps_dot), float(weight), out)
+        ctx.save_for_backward(*args)
+        ctx.cfg = (B, R, M, C, float(eps_dot), float(weight), tuple(cfg))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        B, R, M, C, eps, weight, cfg = ctx.cfg
+        normal, view, light, rough, spec, sv, env = ctx.saved_tensors
+        gn, gr, gs = torch.empty_like(normal), torch.empty_like(rough), torch.empty_like(spec)
+        gsv, genv = torch.empty_like(sv), torch.empty_like(env)
+        lib.call("render_specular_light_backward", B * R, M, C, *cfg, normal, view, light, rough, spec, sv, env, eps, weight,
+                 g.contiguous(), gn, gr, gs, gsv, genv)
+        return gn, None, None, gr, gs, gsv, genv, None, None, None
+
+
+def specular_light(normal, view_dir, light_dir, roughness, specular_color, soft_vis, env, eps_dot, weight, model, sampling,
+                   use_split_sum):
+    cfg = ({"filament": 0, "ue4": 1}[model], {"importance": 0, "uniform": 1}[sampling], 1 if use_split_sum else 0)
+    return SpecularLight.apply(normal, view_dir, light_dir, roughness, specular_color, soft_vis, env, eps_dot, weight, cfg)
+
+
 class MaterialHead(Function):
     """Output activations of the per-sample material nets and the prior integrands in one launch
     (csrc/render.hip; network.py:262, 335, 423, 456-463, 498-508 and loss.py:117-166).

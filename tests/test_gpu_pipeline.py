@@ -164,14 +164,15 @@ def test_step_parity_other_sample_counts(gpu, name, ov, N):
 
 @pytest.mark.parametrize("ov", [["specular_brdf.model=ue4"], ["specular_brdf.model=ue4", "specular_brdf.sampling=uniform"],
                                 ["specular_brdf.sampling=uniform"], ["specular_brdf.use_split_sum=True"],
+                                ["specular_brdf.model=ue4", "specular_brdf.use_split_sum=True"],
                                 ["specular_reflectance_network.fixme=true", "train.specular_reflectance_prior_weight=0"], ["implicit_illumination_network.use_me=false"],
                                 ["roughness_network.use_normal=false", "photogrammetric_light_network.use_inverse_distance=false"]],
-                         ids=["ue4-importance", "ue4-uniform", "filament-uniform", "filament-split-sum", "fixed-specular",
+                         ids=["ue4-importance", "ue4-uniform", "filament-uniform", "filament-split-sum", "ue4-split-sum", "fixed-specular",
                               "no-implicit-light", "mixed-prefix-widths"])
 def test_step_parity_brdf_variants(gpu, ov):
     """The non-default BRDF branches (python/specular_brdf.py:121-191 ue4; uniform sampling :104-110; split sum
-    python/renderer.py:152-154) run as stock-op composites on the GPU (only the default filament + importance integral
-    is a fused kernel); a fixed specular reflectance / no implicit light take the renderer's net-by-net branch instead of the
+    python/renderer.py:152-154) run on the templated kernel pair csrc/render.hip k_specular_light_g (round 5; the default filament +
+    importance integral keeps its own kernels); a fixed specular reflectance / no implicit light take the renderer's net-by-net branch instead of the
     fused material head (the fixed reflectance has no std output, so its prior term is switched off: python/loss.py:154 divides
     by it); a roughness net without the normal and a photogrammetric net without the inverse distance change the prefix
     widths the nets read of the packed sample inputs (262 / 259 / 259 / 262 / 262 columns): whole-step parity with the oracle,
