@@ -771,11 +771,16 @@ __global__ void __launch_bounds__(256) k_group_colsum_blocked(const float* __res
   // workgroup waiting for 4 loads at a time: 65 us per launch in the step, round 5)
   for (int n0 = 0; n0 < N; n0 += 32) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int bb = 0; bb < nb; bb += 4) {            // 16 independent loads per lane, then their sums
+      float v[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 8 * j + fq;
-      if (n < N)
-        for (int b = 0; b < nb; ++b) acc[j] += X[((b0 + b) * ldx + n) * 32 + pp];
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 8 * j + fq;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v[j][b] = (n < N && bb + b < nb) ? X[((b0 + bb + b) * ldx + n) * 32 + pp] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
