@@ -91,7 +91,9 @@ class SparseRows:
                  st["ids"], st["count"], buf, buf.shape[-1])
 
 
-_STATE = {}
+from .registry import REG
+
+_STATE = REG.exchange_state      # (ndjir_amd/registry.py)
 _GRID_GROUP = weakref.WeakKeyDictionary()      # parent group object -> its second communicator (None: the default group)
 _GRID_GROUP_DEFAULT = []
 CHECK_EVERY = 64          # exchanges between two (host-synchronising) looks at the row counts

@@ -25,7 +25,9 @@ from torch.autograd import Function
 
 from .. import lib
 
-_GRAD_BUFFERS = {}
+from ..registry import REG
+
+_GRAD_BUFFERS = REG.grid_grad_buffers      # (ndjir_amd/registry.py)
 
 # nnabla distinguishes `nn.grad` (uses the *registered backward functions*, a differentiable graph)
 # from `.backward()` (uses `backward_impl`).  torch has one backward, so the distinction is a mode:

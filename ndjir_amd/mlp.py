@@ -19,8 +19,9 @@ from torch.autograd import Function
 from torch.multiprocessing.reductions import StorageWeakRef as _StorageRef
 
 from . import lib
+from .registry import REG
 
-_PACK_CACHE = {}
+_PACK_CACHE = REG.pack_cache      # (the address-keyed state lives in ONE object: ndjir_amd/registry.py)
 
 MATH_FP32, MATH_BF16X6, MATH_F16X3 = 0, 1, 2
 
@@ -451,7 +452,7 @@ def repack_tracked():
 # buffer and return no gradient for it, so autograd neither sums the contributions of a parameter used by two operators
 # (the geometric and base-colour nets run twice per step) nor materialises slice gradients of a first-layer weight that one
 # operator reads by rows.  ndjir_amd/step.py registers views of one flat bucket -- also what the multi-GPU step all-reduces.
-_GRAD_BUF = []         # (first byte, bytes, buffer) per registered parameter
+_GRAD_BUF = REG.grad_buf         # (first byte, bytes, buffer) per registered parameter
 
 
 def set_grad_buffer(p, buf):
@@ -512,7 +513,7 @@ class SplitTarget:
         self.top, self.bottom, self.a = top, bottom, a
 
 
-_ROWS_TARGET = {}      # first byte of a rows_except copy -> (shape, SplitTarget); valid while the buffers are registered
+_ROWS_TARGET = REG.rows_target      # first byte of a rows_except copy -> (shape, SplitTarget, owner view); valid while the buffers are registered
 
 
 def wgrad_jobs(target, A, B, amax_a, amax_b):
@@ -917,7 +918,7 @@ class _Strided:
         return self.t.data_ptr()
 
 
-_TAIL_CACHE = {}
+_TAIL_CACHE = REG.tail_cache
 
 
 def _col_tail(W):
@@ -1375,7 +1376,7 @@ class ColSumOp(Function):
         return gz.reshape(1, -1).expand(ctx.rows, -1)
 
 
-_ROWS_CACHE = {}
+_ROWS_CACHE = REG.rows_cache
 
 
 def _refresh_rows(ent, W, a, b):

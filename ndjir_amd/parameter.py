@@ -90,6 +90,8 @@ def clear_parameters():
     g = sys.modules.get("ndjir_amd.grid_feature._core")
     if g is not None:
         g.clear_grad_buffers()                       # ... and the grid operators' accumulate-in-place buffers (keyed by address)
+    from .registry import REG
+    REG.clear()                                      # ... and whatever else was keyed by the addresses of what just went away
 
 
 def save_parameters(path):

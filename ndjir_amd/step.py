@@ -52,6 +52,8 @@ class Step:
         self.obj_mask = torch.ones(B, R, 1, device=device)
         self.obj_mask_sum = torch.zeros((), device=device)   # multi-GPU: all-reduced sum of the object masks
         self.P = P
+        from ndjir_amd.registry import REG
+        self.registry = REG              # address-keyed state derived from this step's parameters and buffers
         self.grid_bufs = {}
         self.touched = None      # query points whose cells hold gradient from the previous step ...
         self.touched_ptb = None  # ... and their perturbed twins (x_fg + the noise of THAT step: redraw_rand may follow)
@@ -97,6 +99,17 @@ class Step:
             self.grad_views.append(v)
             if self.in_place and p.is_contiguous():
                 self._grad_pairs.append((p, v))
+
+    def close(self):
+        """End of the step's life: everything it registered under its tensors' addresses -- grid gradient buffers, exchange
+        state, packed weights -- leaves the registry (ndjir_amd/registry.py) together with the parameters themselves."""
+        from ndjir_amd.grid_feature import set_grad_buffer
+        for name, p in self.P.get_parameters().items():
+            if name in self.grid_bufs:
+                set_grad_buffer(p, None)
+        self.grid_bufs = {}
+        self.remote_rows = {}
+        self.P.clear_parameters()        # (-> Registry.clear())
 
     def _create_parameters(self):
         """The parameters come into being when the networks first run (python/network.py's `PF.affine` scopes): one forward

@@ -74,3 +74,21 @@ def test_rows_except_destination_dies_with_its_registration():
     mlp.rows_except(W, 2, 4)
     assert mlp.grad_target(c2.detach()) is None
     mlp.clear_grad_buffers()
+
+
+def test_one_registry_owns_the_address_keyed_state():
+    """ndjir_amd/registry.py: the modules' containers ARE the registry's; `clear_parameters` empties all of them."""
+    import torch
+    from ndjir_amd import mlp, distributed, parameter as P
+    from ndjir_amd.grid_feature import _core
+    from ndjir_amd.registry import REG
+    assert mlp._PACK_CACHE is REG.pack_cache and mlp._GRAD_BUF is REG.grad_buf
+    assert mlp._ROWS_TARGET is REG.rows_target and mlp._ROWS_CACHE is REG.rows_cache
+    assert _core._GRAD_BUFFERS is REG.grid_grad_buffers and distributed._STATE is REG.exchange_state
+    w = torch.zeros(4, 4)
+    mlp.set_grad_buffer(w, torch.zeros(4, 4))
+    f = torch.zeros(2, 3)
+    _core.set_grad_buffer(f, torch.zeros(2, 3))
+    assert REG.sizes()["grad_buf"] == 1 and REG.sizes()["grid_grad_buffers"] == 1
+    P.clear_parameters()
+    assert all(n == 0 for n in REG.sizes().values()), REG.sizes()
