@@ -21,6 +21,14 @@ constexpr int WG_THREADS = 256;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Pointers that a kernel reads out of a table in device memory (k_wgrad_group) are GENERIC to the compiler: their loads become
+// flat_load, which counts in lgkmcnt as well as vmcnt -- the first `s_waitcnt lgkmcnt(0)` in front of an LDS-fed MFMA then waits
+// for every prefetched global load, and the chunk loop ran at HBM latency (9 k cycles per chunk against 768 cycles of MFMA,
+// found in round 5).  Device functions reached from such kernels move their pointers into the global address space first.
+#define WG_G __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ WG_G T* wg_global(T* p) { return (WG_G T*)p; }
+
 // Tile = (WK*BK*32) x (WN*BN*32) outputs: WK x WN waves, each BK x BN MFMA blocks.  <2,2,2,2> is the
 // 128 x 128 main tile; <1,4,1,1> (32 x 128) and <4,1,1,1> (128 x 32) cover the ragged strips of shapes
 // like 259 x 256 or 256 x 257 without paying for a whole extra tile.  (k_off, n_off) = origin of the
@@ -314,12 +322,31 @@ __host__ __device__ __forceinline__ void wg_scale_from_max(unsigned mbits, float
   inv = b.f;
 }
 
+#ifdef WGG_TIMELINE      // tools/wgrad_timeline.py: s_memtime stamps of the chunk loop's phases (wave 0 of two workgroups)
+__device__ long long wgg_stamps[2][64][12];
+#define WGG_STAMP(i)                                                                                      \
+  do {                                                                                                    \
+    const int ck_ = (int)((p0 - p_begin) / WG_C);                                                        \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 1200) && ck_ < 64) {                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+      wgg_stamps[blockIdx.x != 0][ck_][i] = __builtin_readcyclecounter();                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }                                                                                                     \
+  } while (0)
+#else
+#define WGG_STAMP(i)
+#endif
+
 // One output tile of dW over the points [p_begin, p_end): `out` = this split's (K x N) partial slab.
-template <int WK, int WN, int BK, int BN>
-__device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int N,
-                                            long long p_begin, long long p_end, float* __restrict__ out, int k0, int n0,
+template <int WK, int WN, int BK, int BN, int LAY = -1>
+__device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A_, int lda, const float* __restrict__ B_, int ldb, int N,
+                                            long long p_begin, long long p_end, float* __restrict__ out_, int k0, int n0,
                                             int k_end, int n_end, float sa, float ia, float sb, float ib,
-                                            unsigned short* wg_lds, int lay = 0) {
+                                            unsigned short* wg_lds, int lay_rt = 0) {
+  const int lay = LAY >= 0 ? LAY : lay_rt;          // (the main tile is instantiated per layout: one straight chunk loop each)
+  const WG_G float* A = wg_global(A_);
+  const WG_G float* B = wg_global(B_);
+  WG_G float* out = wg_global(out_);
   // lay: bit 0 = A is point-blocked, bit 1 = B is (ChainArgs::side_blocked: element (p, f) at ((p >> 5) * ld + f) * 32 + (p & 31)).
   // A 32-point chunk of TK features of a blocked operand is ONE contiguous run of TK * 128 bytes: thread t takes the
   // 16-byte groups t, t + NT, ... of it (4 consecutive points of feature (group >> 3)) -- fully coalesced 16-byte loads, and
@@ -337,112 +364,179 @@ __device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A, int lda
   const int wk = wave / WN, wn = wave % WN;
 
   f32x16 acc0[BK][BN] = {}, acc1[BK][BN] = {};
-  float ra[PA], rb[PB];
+  // Two register sets: the loads of chunks c + 1 and c + 2 are in flight while chunk c is multiplied (one chunk of 32 KB per
+  // workgroup in flight left the loop waiting on HBM latency: 9 k cycles per chunk against 768 cycles of MFMA -- round 5).
+  float ra[2][PA], rb[2][PB];
   const int fa = tid % TK, ga = tid / TK, fb = tid % TN, gb = tid / TN;   // feature column, point group
   const bool acol = (k0 + fa) < k_end, bcol = (n0 + fb) < n_end;
-  const float* Ap = A + (long long)(ga * PA) * lda + k0 + fa;
-  const float* Bp = B + (long long)(gb * PB) * ldb + n0 + fb;
+  const WG_G float* Ap = A + (long long)(ga * PA) * lda + k0 + fa;
+  const WG_G float* Bp = B + (long long)(gb * PB) * ldb + n0 + fb;
   const bool blk_a = lay & 1, blk_b = lay & 2;
-  auto load_chunk = [&](long long p0) {
+  auto load_chunk = [&](long long p0, const int set) {
     const bool whole = p0 + WG_C <= p_end;
     if (blk_a) {
-      const wg_f32x4* ap = reinterpret_cast<const wg_f32x4*>(A + ((p0 >> 5) * lda + k0) * 32) + tid;
+      const WG_G wg_f32x4* ap = reinterpret_cast<const WG_G wg_f32x4*>(A + ((p0 >> 5) * lda + k0) * 32) + tid;
 #pragma unroll
       for (int i = 0; i < PA / 4; ++i) {
         wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (k0 + ((i * NT + tid) >> 3) < k_end) v = ap[i * NT];
-        ra[4 * i] = v[0]; ra[4 * i + 1] = v[1]; ra[4 * i + 2] = v[2]; ra[4 * i + 3] = v[3];
+        ra[set][4 * i] = v[0]; ra[set][4 * i + 1] = v[1]; ra[set][4 * i + 2] = v[2]; ra[set][4 * i + 3] = v[3];
       }
     } else {
-      const float* ap = Ap + p0 * lda;
+      const WG_G float* ap = Ap + p0 * lda;
       if (whole) {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) ra[i] = acol ? ap[(long long)i * lda] : 0.f;
+        for (int i = 0; i < PA; ++i) ra[set][i] = acol ? ap[(long long)i * lda] : 0.f;
       } else {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) ra[i] = (acol && p0 + ga * PA + i < p_end) ? ap[(long long)i * lda] : 0.f;
+        for (int i = 0; i < PA; ++i) ra[set][i] = (acol && p0 + ga * PA + i < p_end) ? ap[(long long)i * lda] : 0.f;
       }
     }
     if (blk_b) {
-      const wg_f32x4* bp = reinterpret_cast<const wg_f32x4*>(B + ((p0 >> 5) * ldb + n0) * 32) + tid;
+      const WG_G wg_f32x4* bp = reinterpret_cast<const WG_G wg_f32x4*>(B + ((p0 >> 5) * ldb + n0) * 32) + tid;
 #pragma unroll
       for (int i = 0; i < PB / 4; ++i) {
         wg_f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (n0 + ((i * NT + tid) >> 3) < n_end) v = bp[i * NT];
-        rb[4 * i] = v[0]; rb[4 * i + 1] = v[1]; rb[4 * i + 2] = v[2]; rb[4 * i + 3] = v[3];
+        rb[set][4 * i] = v[0]; rb[set][4 * i + 1] = v[1]; rb[set][4 * i + 2] = v[2]; rb[set][4 * i + 3] = v[3];
       }
     } else {
-      const float* bp = Bp + p0 * ldb;
+      const WG_G float* bp = Bp + p0 * ldb;
       if (whole) {
 #pragma unroll
-        for (int i = 0; i < PB; ++i) rb[i] = bcol ? bp[(long long)i * ldb] : 0.f;
+        for (int i = 0; i < PB; ++i) rb[set][i] = bcol ? bp[(long long)i * ldb] : 0.f;
       } else {
 #pragma unroll
-        for (int i = 0; i < PB; ++i) rb[i] = (bcol && p0 + gb * PB + i < p_end) ? bp[(long long)i * ldb] : 0.f;
+        for (int i = 0; i < PB; ++i) rb[set][i] = (bcol && p0 + gb * PB + i < p_end) ? bp[(long long)i * ldb] : 0.f;
       }
     }
   };
+  // hi = f16(x s), lo = f16((x s - hi) 2^11).  Three mixed-precision FMAs per element (v_fma_mix*: fp32 or f16 sources, fp32
+  // arithmetic, one rounding, the f16 result written to its half of the packed pair): hi = f16(fma(x, s, 0)); r = fma(x, -s, hi)
+  // = -(x s - hi), exact; lo = f16(fma(r, -2^11, 0)).  The same values as scale / convert / convert back / subtract / scale /
+  // convert / pack (7 instructions per element: 896 of a chunk's ~4800 cycles per wave were this split -- a wave64 vector
+  // instruction occupies its SIMD for 4 cycles, and the timeline shows the matrix and vector phases adding, not overlapping).
   auto split4 = [&](const float* v, float s, _Float16* d, int plane_stride) {
+#ifdef NDJIR_WGRAD_SPLIT7
     wg_f32x4 xs = {v[0] * s, v[1] * s, v[2] * s, v[3] * s};
     const wg_f16x4 ph = __builtin_convertvector(xs, wg_f16x4);
     const wg_f32x4 res = (xs - __builtin_convertvector(ph, wg_f32x4)) * 2048.f;
     const wg_f16x4 pl = __builtin_convertvector(res, wg_f16x4);
     *reinterpret_cast<wg_f16x4*>(d) = ph;
     *reinterpret_cast<wg_f16x4*>(d + plane_stride) = pl;
+#else
+    typedef unsigned wg_u32x2 __attribute__((ext_vector_type(2)));
+    const float ms = -s, m2k = -2048.f;
+    wg_u32x2 h, l;
+    float r0, r1, r2, r3;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[0]) : "v"(v[0]), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[0]) : "v"(v[1]), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[1]) : "v"(v[2]), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[1]) : "v"(v[3]), "v"(s));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v[0]), "v"(ms), "v"(h[0]));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v[1]), "v"(ms), "v"(h[0]));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(r2) : "v"(v[2]), "v"(ms), "v"(h[1]));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r3) : "v"(v[3]), "v"(ms), "v"(h[1]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l[0]) : "v"(r0), "v"(m2k));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l[0]) : "v"(r1), "v"(m2k));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(l[1]) : "v"(r2), "v"(m2k));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(l[1]) : "v"(r3), "v"(m2k));
+    *reinterpret_cast<wg_u32x2*>(d) = h;
+    *reinterpret_cast<wg_u32x2*>(d + plane_stride) = l;
+#endif
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](const int set) {
     if (blk_a) {       // group e = i * NT + tid: feature e >> 3, points 4 (e & 7) ..
 #pragma unroll
-      for (int g4 = 0; g4 < PA / 4; ++g4) split4(ra + 4 * g4, sa, As + ((g4 * NT + tid) >> 3) * WG_CP + 4 * (tid & 7), TK * WG_CP);
+      for (int g4 = 0; g4 < PA / 4; ++g4) split4(ra[set] + 4 * g4, sa, As + ((g4 * NT + tid) >> 3) * WG_CP + 4 * (tid & 7), TK * WG_CP);
     } else {
 #pragma unroll
-      for (int g4 = 0; g4 < PA / 4; ++g4) split4(ra + 4 * g4, sa, As + fa * WG_CP + ga * PA + 4 * g4, TK * WG_CP);
+      for (int g4 = 0; g4 < PA / 4; ++g4) split4(ra[set] + 4 * g4, sa, As + fa * WG_CP + ga * PA + 4 * g4, TK * WG_CP);
     }
     if (blk_b) {
 #pragma unroll
-      for (int g4 = 0; g4 < PB / 4; ++g4) split4(rb + 4 * g4, sb, Bs + ((g4 * NT + tid) >> 3) * WG_CP + 4 * (tid & 7), TN * WG_CP);
+      for (int g4 = 0; g4 < PB / 4; ++g4) split4(rb[set] + 4 * g4, sb, Bs + ((g4 * NT + tid) >> 3) * WG_CP + 4 * (tid & 7), TN * WG_CP);
     } else {
 #pragma unroll
-      for (int g4 = 0; g4 < PB / 4; ++g4) split4(rb + 4 * g4, sb, Bs + fb * WG_CP + gb * PB + 4 * g4, TN * WG_CP);
+      for (int g4 = 0; g4 < PB / 4; ++g4) split4(rb[set] + 4 * g4, sb, Bs + fb * WG_CP + gb * PB + 4 * g4, TN * WG_CP);
+    }
+  };
+  auto multiply_chunk = [&]() {
+#pragma unroll
+    for (int s = 0; s < WG_C / 16; ++s) {
+      wg_f16x8 av[BK][2], bv[BN][2];
+#pragma unroll
+      for (int i = 0; i < BK; ++i)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          av[i][p] = *reinterpret_cast<const wg_f16x8*>(As + p * TK * WG_CP + ((wk * BK + i) * 32 + r) * WG_CP + 16 * s + 8 * h);
+#pragma unroll
+      for (int j = 0; j < BN; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          bv[j][p] = *reinterpret_cast<const wg_f16x8*>(Bs + p * TN * WG_CP + ((wn * BN + j) * 32 + r) * WG_CP + 16 * s + 8 * h);
+#pragma unroll
+      for (int i = 0; i < BK; ++i)
+#pragma unroll
+        for (int j = 0; j < BN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][1], bv[j][0], acc1[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < BK; ++i)
+#pragma unroll
+        for (int j = 0; j < BN; ++j) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][0], bv[j][0], acc0[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < BK; ++i)
+#pragma unroll
+        for (int j = 0; j < BN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][0], bv[j][1], acc1[i][j], 0, 0, 0);
     }
   };
 
   if (p_begin < p_end) {
-    load_chunk(p_begin);
-    store_chunk();
+    // (loads past the item's last chunk re-read that chunk: every iteration issues the same number of loads, so the wait
+    // before a store names exactly the younger set's loads -- vmcnt is in-order)
+    const long long p_last = p_begin + (p_end - p_begin - 1) / WG_C * WG_C;
+    auto at = [&](long long p) { return p < p_last ? p : p_last; };
+    load_chunk(p_begin, 0);
+#ifdef NDJIR_WGRAD_DEPTH2
+    load_chunk(at(p_begin + WG_C), 1);
+#endif
+    store_chunk(0);
     __syncthreads();
-    for (long long p0 = p_begin; p0 < p_end; p0 += WG_C) {
+    for (long long p0 = p_begin;;) {
+#ifndef NDJIR_WGRAD_DEPTH2
       const bool more = p0 + WG_C < p_end;
-      if (more) load_chunk(p0 + WG_C);
-#pragma unroll
-      for (int s = 0; s < WG_C / 16; ++s) {
-        wg_f16x8 av[BK][2], bv[BN][2];
-#pragma unroll
-        for (int i = 0; i < BK; ++i)
-#pragma unroll
-          for (int p = 0; p < 2; ++p)
-            av[i][p] = *reinterpret_cast<const wg_f16x8*>(As + p * TK * WG_CP + ((wk * BK + i) * 32 + r) * WG_CP + 16 * s + 8 * h);
-#pragma unroll
-        for (int j = 0; j < BN; ++j)
-#pragma unroll
-          for (int p = 0; p < 2; ++p)
-            bv[j][p] = *reinterpret_cast<const wg_f16x8*>(Bs + p * TN * WG_CP + ((wn * BN + j) * 32 + r) * WG_CP + 16 * s + 8 * h);
-#pragma unroll
-        for (int i = 0; i < BK; ++i)
-#pragma unroll
-          for (int j = 0; j < BN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][1], bv[j][0], acc1[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < BK; ++i)
-#pragma unroll
-          for (int j = 0; j < BN; ++j) acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][0], bv[j][0], acc0[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < BK; ++i)
-#pragma unroll
-          for (int j = 0; j < BN; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[i][0], bv[j][1], acc1[i][j], 0, 0, 0);
-      }
+      WGG_STAMP(0);
+      if (more) load_chunk(p0 + WG_C, 0);
+      WGG_STAMP(1);
+      multiply_chunk();
+      WGG_STAMP(2);
       __syncthreads();                 // every wave is done with this chunk's planes
-      if (more) store_chunk();
+      WGG_STAMP(3);
+      if (!more) break;
+#ifdef WGG_TIMELINE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WGG_STAMP(4);
+#endif
+      store_chunk(0);
+      WGG_STAMP(5);
       __syncthreads();
+      WGG_STAMP(6);
+      p0 += WG_C;
+#else
+      load_chunk(at(p0 + 2 * WG_C), 0);
+      multiply_chunk();
+      __syncthreads();                 // every wave is done with this chunk's planes
+      p0 += WG_C;
+      if (p0 >= p_end) break;
+      store_chunk(1);
+      __syncthreads();
+      load_chunk(at(p0 + 2 * WG_C), 1);
+      multiply_chunk();
+      __syncthreads();
+      p0 += WG_C;
+      if (p0 >= p_end) break;
+      store_chunk(0);
+      __syncthreads();
+#endif
     }
   }
 
@@ -455,6 +549,270 @@ __device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A, int lda
       for (int i = 0; i < 16; ++i) {
         const int k = k0 + (wk * BK + bi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         if (k < k_end && n < n_end) out[(long long)k * N + n] = fmaf(acc1[bi][bj][i], 1.f / 2048.f, acc0[bi][bj][i]) * ia * ib;
+      }
+    }
+}
+
+// ---- the 128 x 128 main tile, software-pipelined (round 5) --------------------------------------------------------------------
+// What the chunk loop above costs a wave per 32-point chunk (tools/wgrad_timeline.py, 256 x 256 x 65536, both operands
+// blocked): issue loads 1270 cycles, 24 MFMAs + their LDS reads 1150, barrier 160, wait for the loads 500, split + LDS writes
+// 1340, barrier 170 -- 4800 cycles for 768 cycles of matrix work, and tools/ubench/coissue.hip shows why two workgroups per CU
+// do not hide it: on gfx950 the matrix pipe and the vector ALU of a SIMD do NOT overlap across waves (4 MFMA waves + 4 FMA
+// waves take the SUM of their solo times, whatever the priorities), while ONE wave that puts up to 4 vector instructions
+// behind each 32x32x16 MFMA gets them for free.  So the phases must interleave inside the wave:
+//   * LDS planes double-buffered (2 x 40 KB): while chunk c is multiplied out of one buffer, chunk c + 1 is split and written
+//     into the other -- one barrier per chunk, and the split's vector instructions sit in the MFMAs' shadows;
+//   * two register sets of raw operands: chunk c + 1 (being split) and chunk c + 2 (in flight); the moment a 4-point group of
+//     chunk c + 1 is written, its registers take the load of the same group of chunk c + 3 -- every load has two chunk times
+//     to arrive, and vmcnt (in order) never waits for a younger load;
+//   * ONE accumulator per block: lo = f16(x s - hi) unscaled, so hi hi' + hi lo' + lo hi' accumulate together (the matrix
+//     cores keep f16 denormals, tools/ubench/mfma_denorm.hip: x s is represented to 2^-22 relative or 2^-25 absolute at
+//     max |x s| in [2^14, 2^15), i.e. 2^-39 of the operand's largest element) -- 64 registers instead of 128, which is what
+//     makes room for the second operand set and a second fragment set (the next k-step's LDS reads under this one's MFMAs).
+// Loads past the item's last chunk re-read that chunk (L2 hits), its planes land in the buffer nobody reads.
+#ifdef WGP_FRAG2
+#define WGP_FS(s) (s)
+#else
+#define WGP_FS(s) 0
+#endif
+constexpr int WGP_CP = 32;                 // plane row pitch of the pipelined tile, in halves: 32 points, no padding
+constexpr int WGP_LDS = 2 * 2 * (WG_T + WG_T) * WGP_CP * 2;      // bytes: two buffers of [A hi][A lo][B hi][B lo]
+// A feature's 32 points = four 16-byte segments; segment q of feature f is stored at q ^ ((f >> 2) & 3): the 16 lanes of a
+// fragment read's pass (16 consecutive features, one segment) then cover all 64 banks, as do the 8-byte writes of a group.
+__device__ __forceinline__ int wgp_at(int f, int seg) { return f * WGP_CP + ((seg ^ ((f >> 2) & 3)) << 3); }
+
+template <int LAY, bool FULL>
+__device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int lda, const float* __restrict__ B_, int ldb, int N,
+                                            long long p_begin, long long p_end, float* __restrict__ out_, int k0, int n0,
+                                            int k_end, int n_end, float sa, float ia, float sb, float ib,
+                                            unsigned short* wg_lds) {
+  // FULL: the tile lies inside the K x N matrix (no feature masks).
+  constexpr int NT = 256, TK = WG_T, TN = WG_T;
+  constexpr bool BLA = (LAY & 1) != 0, BLB = (LAY & 2) != 0;
+  constexpr int PLA = TK * WGP_CP, PLB = TN * WGP_CP;     // halves per plane
+  constexpr int BUF = 2 * PLA + 2 * PLB;                  // halves per buffer: [A hi][A lo][B hi][B lo]
+  WG_G float* out = wg_global(out_);
+  _Float16* L = reinterpret_cast<_Float16*>(wg_lds);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wk = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[2][2] = {};
+  wg_f32x4 ra[2][4], rb[2][4];                            // [set][group]: 4 consecutive points of one feature
+
+  // Group g of a thread = 4 consecutive points (8-byte slot j of the feature's row: segment j >> 1, half j & 1).
+  // Blocked operand: 16-byte run e = g * NT + tid of the chunk -- feature g * 32 + (tid >> 3), slot tid & 7;
+  // row-major: feature tid & 127, slot (tid >> 7) * 4 + g.  A feature beyond the operand's width reads the last valid one and
+  // is multiplied by a scale of 0.  Buffer loads: the descriptor's base is the item's first row at the tile's first feature,
+  // the chunk moves in the SCALAR offset, the thread's place in the chunk is one 32-bit vector register per group and
+  // operand -- no vector address arithmetic in the loop.
+  const int ka = k_end - k0 - 1, nb = n_end - n0 - 1;     // last valid feature of the tile (>= 0)
+  const int fa_r = tid & 127, hf_r = tid >> 7, f_b = tid >> 3, j_b = tid & 7;
+  // LDS slot of group g inside a plane: blocked = lds0 + g * 32 rows; row-major = ldsr[g >> 1] + (g & 1) * 4
+  const int lds_blk = wgp_at(f_b, j_b >> 1) + (j_b & 1) * 4;
+  const int lds_row[2] = {wgp_at(fa_r, hf_r * 2), wgp_at(fa_r, hf_r * 2 + 1)};
+  auto lds_a = [&](int g) { return BLA ? lds_blk + g * 32 * WGP_CP : lds_row[g >> 1] + (g & 1) * 4; };
+  auto lds_b = [&](int g) { return BLB ? lds_blk + g * 32 * WGP_CP : lds_row[g >> 1] + (g & 1) * 4; };
+  const int pt_r = hf_r * 16;                             // first point of a row-major thread's groups
+  unsigned oa[4], ob[4];                                  // byte offset of the group's first element inside a chunk
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int fga = BLA ? g * 32 + f_b : fa_r, fgb = BLB ? g * 32 + f_b : fa_r;
+    const int fca = FULL ? fga : (fga < ka ? fga : ka), fcb = FULL ? fgb : (fgb < nb ? fgb : nb);
+    oa[g] = BLA ? (unsigned)((fca * 32 + 4 * j_b) * 4) : (unsigned)(((pt_r + 4 * g) * lda + fca) * 4);
+    ob[g] = BLB ? (unsigned)((fcb * 32 + 4 * j_b) * 4) : (unsigned)(((pt_r + 4 * g) * ldb + fcb) * 4);
+  }
+  auto scale_a = [&](int g) { return FULL || (BLA ? g * 32 + f_b : fa_r) <= ka ? sa : 0.f; };
+  auto scale_b = [&](int g) { return FULL || (BLB ? g * 32 + f_b : fa_r) <= nb ? sb : 0.f; };
+  auto uniform_ptr = [](const float* q) {      // (the item's operands are the same for every lane: keep the descriptors scalar)
+    const unsigned long long u = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+  };
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(BLA ? A_ + ((p_begin >> 5) * lda + k0) * 32 : A_ + p_begin * lda + k0), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(BLB ? B_ + ((p_begin >> 5) * ldb + n0) * 32 : B_ + p_begin * ldb + n0), 0, 0x7fffffff, 0x00020000);
+  const int n_rows = (int)(p_end - p_begin);
+  const int c_last = (n_rows - 1) / WG_C;                 // the item's last chunk
+  const int rag = n_rows - c_last * WG_C;                 // its rows (32: none missing)
+  const int cha = lda * 4 * WG_C, chb = ldb * 4 * WG_C;   // bytes per chunk (either layout: 32 rows of lda floats)
+  auto at = [&](int c) { return c < c_last ? c : c_last; };
+
+  // (row-major, ragged last chunk: a row past the item's end re-reads the item's last row -- never memory past the operand --
+  //  and the split zeroes it)
+  auto load_rows = [&](wg_f32x4& dst, const __amdgpu_buffer_rsrc_t& rs, unsigned off, int ld, int g, int c, int ch) {
+    const int so = c * ch;
+    if (rag < WG_C && c == c_last) {                      // (uniform)
+      const int row0 = pt_r + 4 * g;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int back = row0 + i - (rag - 1);            // rows past the last one
+        dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + (unsigned)((i - (back > 0 ? back : 0)) * ld * 4), so, 0));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, so + i * ld * 4, 0));
+    }
+  };
+  auto load_a = [&](const int set, const int g, int c) {
+    if (BLA) ra[set][g] = __builtin_bit_cast(wg_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, oa[g], c * cha, 0));
+    else load_rows(ra[set][g], rsa, oa[g], lda, g, c, cha);
+  };
+  auto load_b = [&](const int set, const int g, int c) {
+    if (BLB) rb[set][g] = __builtin_bit_cast(wg_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, ob[g], c * chb, 0));
+    else load_rows(rb[set][g], rsb, ob[g], ldb, g, c, chb);
+  };
+  // hi = f16(x s), lo = f16(x s - hi): both planes of a 4-point group, 8 bytes each
+  auto split_store = [&](wg_f32x4 v, float s, bool ragged, int pt0, _Float16* d, int plane) {
+#pragma clang fp contract(off)
+    if (ragged) {                        // (row-major operand, last chunk of the item: rows past p_end count as zeros)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = pt0 + i < rag ? v[i] : 0.f;
+    }
+    const wg_f32x4 xs = v * s;
+    const wg_f16x4 ph = __builtin_convertvector(xs, wg_f16x4);
+    const wg_f32x4 res = xs - __builtin_convertvector(ph, wg_f32x4);
+    const wg_f16x4 pl = __builtin_convertvector(res, wg_f16x4);
+    *reinterpret_cast<wg_f16x4*>(d) = ph;
+    *reinterpret_cast<wg_f16x4*>(d + plane) = pl;
+  };
+  // side item i (0..7) of an iteration: split + store group (i & 3) of A (i < 4) or B of chunk `cn` out of `set` into `buf`,
+  // then refill the group's registers with chunk `cr`
+  auto side = [&](const int i, const int set, const int buf, int cn_, int cr) {
+    const int g = i & 3;
+    // (a chunk past the item's end is split into planes of zeros: the chunk loop runs in pairs, and multiplying one chunk too
+    //  many must add nothing)
+    const float live = cn_ <= c_last ? 1.f : 0.f;
+    const int cn = at(cn_);
+    const bool ragged = rag < WG_C && cn == c_last;
+#ifdef WGP_NO_LOAD      // (experiment: the loop without its global loads -- the registers keep the first chunks)
+#define WGP_LOAD(x)
+#else
+#define WGP_LOAD(x) x
+#endif
+    if (i < 4) {
+      split_store(ra[set][g], scale_a(g) * live, !BLA && ragged, pt_r + 4 * g, L + buf * BUF + lds_a(g), PLA);
+      WGP_LOAD(load_a(set, g, cr));
+    } else {
+      split_store(rb[set][g], scale_b(g) * live, !BLB && ragged, pt_r + 4 * g, L + buf * BUF + 2 * PLA + lds_b(g), PLB);
+      WGP_LOAD(load_b(set, g, cr));
+    }
+  };
+
+  // fragment of block row i, plane pl, k-step s: feature (w * 2 + i) * 32 + r, segment 2 s + h
+  const int fr_a[2] = {wgp_at((wk * 2) * 32 + r, h), wgp_at((wk * 2) * 32 + r, 2 + h)};      // [k-step]; + i * 32 rows, + plane
+  const int fr_b[2] = {wgp_at((wn * 2) * 32 + r, h), wgp_at((wn * 2) * 32 + r, 2 + h)};
+#ifdef WGP_FRAG2
+  wg_f16x8 fa[2][2][2], fb[2][2][2];                      // [k-step][block][plane]
+#else
+  wg_f16x8 fa[1][2][2], fb[1][2][2];                      // [block][plane]: one k-step's fragments at a time
+#endif
+  auto frags = [&](const int s_, const int buf) {
+    const int s = s_;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        fa[WGP_FS(s)][i][pl] = *reinterpret_cast<const wg_f16x8*>(L + buf * BUF + pl * PLA + i * 32 * WGP_CP + fr_a[s]);
+        fb[WGP_FS(s)][i][pl] = *reinterpret_cast<const wg_f16x8*>(L + buf * BUF + 2 * PLA + pl * PLB + i * 32 * WGP_CP + fr_b[s]);
+      }
+  };
+  // MFMA q (0..11) of k-step s: product q >> 2 (lo hi', hi lo', hi hi') of block q & 3 -- two MFMAs into one accumulator
+  // are four apart
+  auto mfma1 = [&](const int s, const int q) {
+    const int pr = q >> 2, i = (q >> 1) & 1, j = q & 1;
+#ifdef WGP_NO_MFMA      // (experiment: what the loop costs without its matrix work)
+    acc[i][j][0] += (float)fa[WGP_FS(s)][i][pr == 0][0] + (float)fb[WGP_FS(s)][j][pr == 1][0];
+    return;
+#endif
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[WGP_FS(s)][i][pr == 0 ? 1 : 0], fb[WGP_FS(s)][j][pr == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+  };
+  auto mfma3 = [&](const int s, const int m) {
+    mfma1(s, 3 * m); mfma1(s, 3 * m + 1); mfma1(s, 3 * m + 2);
+  };
+  // one chunk: multiply `buf`, split chunk cn (set `set`) into the other buffer, refill `set` with chunk cr
+#ifdef WGG_TIMELINE
+  int tl_c = 0;
+#define WGP_STAMP(i)                                                                                       \
+  do {                                                                                                     \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 1200) && tl_c < 64) {                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      wgg_stamps[blockIdx.x != 0][tl_c][i] = (i) == 11 ? (long long)__builtin_amdgcn_s_memrealtime() : (long long)__builtin_readcyclecounter(); \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }                                                                                                      \
+  } while (0)
+#else
+#define WGP_STAMP(i)
+#endif
+  auto iteration = [&](const int buf, const int set, int cn, int cr) {
+    WGP_STAMP(0);
+    frags(0, buf);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      mfma3(0, m);
+#ifdef WGP_FRAG2
+      if (m == 0) frags(1, buf);
+#endif
+      side(m, set, buf ^ 1, cn, cr);
+      __builtin_amdgcn_sched_barrier(0);
+      WGP_STAMP(1 + m);
+    }
+#ifndef WGP_FRAG2
+    frags(1, buf);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      mfma3(1, m);
+      side(4 + m, set, buf ^ 1, cn, cr);
+      __builtin_amdgcn_sched_barrier(0);
+      WGP_STAMP(5 + m);
+    }
+    __syncthreads();
+    WGP_STAMP(9);
+    WGP_STAMP(11);
+#ifdef WGG_TIMELINE
+    ++tl_c;
+#endif
+  };
+
+  if (n_rows > 0) {
+    // (issue order = the order the iterations consume and refill in: A groups, then B groups, set by set)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) load_a(0, g, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) load_b(0, g, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) load_a(1, g, at(1));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) load_b(1, g, at(1));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      side(i, 0, 0, 0, at(2));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    for (int c = 0; c <= c_last; c += 2) {               // (pairs: one exit, the accumulators stay where they are)
+      iteration(0, 1, c + 1, at(c + 3));
+      iteration(1, 0, c + 2, at(c + 4));
+    }
+  }
+
+  const float de = ia * ib;
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+      const int n = n0 + (wn * 2 + bj) * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = k0 + (wk * 2 + bi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (FULL || (k < k_end && n < n_end)) out[(long long)k * N + n] = acc[bi][bj][i] * de;
       }
     }
 }
@@ -1023,9 +1381,12 @@ struct WggPiece {            // what one writer launch carries (<= 4 KB of kerne
 
 // streaming item for N <= 8 (K % 4 == 0, lda % 4 == 0, A 16-byte aligned): the body of k_wgrad_narrow over [p0, p1)
 template <int NMAX>
-__device__ __forceinline__ void wgrad_narrow_rows(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                  int K, int N, long long p0, long long p1, float* __restrict__ part,
+__device__ __forceinline__ void wgrad_narrow_rows(const float* __restrict__ A_, int lda, const float* __restrict__ B_, int ldb,
+                                                  int K, int N, long long p0, long long p1, float* __restrict__ part_,
                                                   float4* red) {
+  const WG_G float* A = wg_global(A_);
+  const WG_G float* B = wg_global(B_);
+  WG_G float* part = wg_global(part_);
   const int KQ = K >> 2;
   const int TX = pow2_at_least(KQ), TY = 256 / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -1037,8 +1398,9 @@ __device__ __forceinline__ void wgrad_narrow_rows(const float* __restrict__ A, i
     if (kq < KQ) {
 #pragma unroll 4
       for (long long p = p0 + ty; p < p1; p += TY) {
-        const float4 a = *reinterpret_cast<const float4*>(A + p * lda + 4 * kq);
-        const float* b = B + p * ldb;
+        const wg_f32x4 av = *reinterpret_cast<const WG_G wg_f32x4*>(A + p * lda + 4 * kq);
+        const float4 a = make_float4(av[0], av[1], av[2], av[3]);
+        const WG_G float* b = B + p * ldb;
 #pragma unroll
         for (int n = 0; n < NMAX; ++n) if (n < N) {
           const float bn = b[n];
@@ -1061,7 +1423,7 @@ __device__ __forceinline__ void wgrad_narrow_rows(const float* __restrict__ A, i
         }
         if (ty == 0 && kq < KQ) {
           const float4 t = red[tx];
-          float* o = part + (long long)(4 * kq) * N + n;
+          WG_G float* o = part + (long long)(4 * kq) * N + n;
           o[0] = t.x; o[N] = t.y; o[2 * N] = t.z; o[3 * N] = t.w;
         }
         __syncthreads();
@@ -1074,10 +1436,13 @@ __device__ __forceinline__ void wgrad_narrow_rows(const float* __restrict__ A, i
 // block phase).  A feature's 32 points of a block are 128 contiguous bytes (8 x 16-byte loads in flight per thread); B's rows of
 // the item (<= WGG_NARROW_ROWS x 8 floats) are staged in LDS once, zero-padded to 8 columns, and read back as broadcasts.
 template <int NMAX>
-__device__ __forceinline__ void wgrad_narrow_rows_blocked(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                          int K, int N, long long p0, long long p1, float* __restrict__ part,
+__device__ __forceinline__ void wgrad_narrow_rows_blocked(const float* __restrict__ A_, int lda, const float* __restrict__ B_, int ldb,
+                                                          int K, int N, long long p0, long long p1, float* __restrict__ part_,
                                                           float* lds) {
   static_assert(NMAX == 8, "two 16-byte broadcasts per point");
+  const WG_G float* A = wg_global(A_);
+  const WG_G float* B = wg_global(B_);
+  WG_G float* part = wg_global(part_);
   float* Bs = lds;                                   // [rows][8]
   float* red = lds + WGG_NARROW_ROWS * 8;            // [256]
   const int rows = (int)(p1 - p0);                   // (multiple of 32)
@@ -1096,7 +1461,7 @@ __device__ __forceinline__ void wgrad_narrow_rows_blocked(const float* __restric
     for (int n = 0; n < NMAX; ++n) acc[n] = 0.f;
     if (k < K) {
       for (int b = ty; b < nblk; b += TY) {
-        const wg_f32x4* ap = reinterpret_cast<const wg_f32x4*>(A + (((p0 >> 5) + b) * lda + k) * 32);
+        const WG_G wg_f32x4* ap = reinterpret_cast<const WG_G wg_f32x4*>(A + (((p0 >> 5) + b) * lda + k) * 32);
         wg_f32x4 a[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = ap[i];
@@ -1152,8 +1517,9 @@ __device__ __forceinline__ bool wgg_locate(const WggTable& a, int& si, int& spli
 // largest finite |X[p][c]| (bit pattern) over the rows [p0, p1) and columns [c0, c1): the operand scale of a work item whose
 // source came without a recorded maximum (single-layer operators on a few hundred per-ray rows).  Every item de-scales its own
 // partial slab, so items of one source may use different scales -- each only has to bound the values the item multiplies.
-__device__ __forceinline__ unsigned wgg_tile_absmax(const float* __restrict__ X, int ld, int c0, int c1, long long p0, long long p1,
+__device__ __forceinline__ unsigned wgg_tile_absmax(const float* __restrict__ X_, int ld, int c0, int c1, long long p0, long long p1,
                                                     unsigned* red, bool blocked = false) {
+  const WG_G float* X = wg_global(X_);
   unsigned m = 0;
   const int w = c1 - c0;
   if (blocked) {          // point-blocked operand: 32 points of a feature are contiguous
@@ -1223,9 +1589,32 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* _
   float sa, ia, sb, ib;
   wg_scale_from_max(ma, sa, ia);
   wg_scale_from_max(mb, sb, ib);
-  if (kind == 0)
-    wgrad3_tile<2, 2, 2, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout);
-  else if (kind == 1)
+#ifdef WGG_ONLY
+  wgrad3_pipe<WGG_ONLY, true>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
+  return;
+#endif
+#ifndef NDJIR_WGRAD_NO_PIPE
+  if (kind == 0) {
+    const int lay = s.layout & 3;
+    const bool full = g.k_end - k0 >= WG_T && g.n_end - n0 >= WG_T;
+#define WGG_PIPE(LAYV)                                                                                                          \
+    if (full) wgrad3_pipe<LAYV, true>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds); \
+    else wgrad3_pipe<LAYV, false>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds)
+    if (lay == 3) { WGG_PIPE(3); }
+    else if (lay == 1) { WGG_PIPE(1); }
+    else if (lay == 2) { WGG_PIPE(2); }
+    else { WGG_PIPE(0); }
+#undef WGG_PIPE
+    return;
+  }
+#endif
+  if (kind == 0) {
+    const int lay = s.layout & 3;
+    if (lay == 3) wgrad3_tile<2, 2, 2, 2, 3>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
+    else if (lay == 1) wgrad3_tile<2, 2, 2, 2, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
+    else if (lay == 2) wgrad3_tile<2, 2, 2, 2, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
+    else wgrad3_tile<2, 2, 2, 2, 0>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
+  } else if (kind == 1)
     wgrad3_tile<1, 4, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout);
   else if (kind == 4)
     wgrad3_tile<2, 2, 1, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout);
@@ -1242,12 +1631,12 @@ __device__ __forceinline__ void wgg_reduce_block(const WggOut& o, int blk, float
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
   if (i < o.KN) {
-    const float* p = o.partial + i;
+    const WG_G float* p = wg_global(o.partial) + i;
 #pragma unroll 4
     for (int sidx = ty; sidx < o.S; sidx += 8) {
       if (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(p + (long long)sidx * o.pstride);
-        acc[0] += t.x; acc[1 % VEC] += t.y; acc[2 % VEC] += t.z; acc[3 % VEC] += t.w;
+        const wg_f32x4 t = *reinterpret_cast<const WG_G wg_f32x4*>(p + (long long)sidx * o.pstride);
+        acc[0] += t[0]; acc[1 % VEC] += t[1]; acc[2 % VEC] += t[2]; acc[3 % VEC] += t[3];
       } else {
         acc[0] += p[(long long)sidx * o.pstride];
       }
@@ -1265,13 +1654,13 @@ __device__ __forceinline__ void wgg_reduce_block(const WggOut& o, int blk, float
       for (int q = 0; q < 8; ++q) t[v] += red[v * 256 + q * 32 + tx];
     }
     if (VEC == 4) {            // contiguous output, 4-byte aligned
-      wgg_f32x4u* dst = reinterpret_cast<wgg_f32x4u*>(o.out + i);
+      WG_G wgg_f32x4u* dst = reinterpret_cast<WG_G wgg_f32x4u*>(wg_global(o.out) + i);
       wgg_f32x4u r = {t[0], t[1 % VEC], t[2 % VEC], t[3 % VEC]};
       if (o.accum) { const wgg_f32x4u c = *dst; r += c; }
       *dst = r;
     } else {
       const long long row = i / o.N;
-      float* dst = o.out + row * o.ldo + (i - row * o.N);
+      WG_G float* dst = wg_global(o.out) + row * o.ldo + (i - row * o.N);
       *dst = o.accum ? *dst + t[0] : t[0];
     }
   }
@@ -1542,7 +1931,7 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
       s0 += pc.n_src; g0 += pc.n_seg; w0 += pc.n_out;
     }
     if (blocks > 0) {
-      hipLaunchKernelGGL(k_wgrad_group, dim3(blocks), dim3(WG_THREADS), 2 * (WG_T + WG_T) * WG_CP * sizeof(unsigned short), stream,
+      hipLaunchKernelGGL(k_wgrad_group, dim3(blocks), dim3(WG_THREADS), WGP_LDS, stream,
                          (const WggTable*)dtab);
       if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
     }
@@ -1558,3 +1947,9 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
 }
 
 }  // namespace ndjir
+
+#ifdef WGG_TIMELINE
+extern "C" int ndjir_debug_wgrad_stamps(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ndjir::wgg_stamps), sizeof(long long) * 2 * 64 * 12);
+}
+#endif

@@ -784,6 +784,12 @@ def _wgrad_group_launch(jobs, extras=()):
             lay.append((1 if isinstance(a, PB) else 0) | (2 if isinstance(b, PB) else 0))
     dev = jobs[0][0].device
     n, m = len(A), len(jobs)
+    if os.environ.get("NDJIR_WGRAD_DEBUG"):       # operand bytes of the launch by layout (0 row-major, 1 A / 2 B / 3 both blocked)
+        by = {}
+        for i in range(n):
+            by[lay[i]] = by.get(lay[i], 0) + 4e-6 * Ps[i] * (Ks[oid[i]] + Ns[oid[i]])
+        print("wgrad group:", n, "sources;", {k: round(v, 1) for k, v in sorted(by.items())}, "MB by layout;",
+              sorted({(Ps[i], Ks[oid[i]], Ns[oid[i]], lay[i]) for i in range(n)}), flush=True)
     vp = ctypes.c_void_p
     need = int(lib.load().ndjir_mlp_wgrad_group_workspace(
         n, (vp * n)(*[t.data_ptr() for t in A]), (ctypes.c_int * n)(*lda), (ctypes.c_longlong * n)(*Ps), (ctypes.c_int * n)(*oid),
