@@ -664,19 +664,42 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
     if (BLB) rb[set][g] = __builtin_bit_cast(wg_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, ob[g], c * chb, 0));
     else load_rows(rb[set][g], rsb, ob[g], ldb, g, c, chb);
   };
-  // hi = f16(x s), lo = f16(x s - hi): both planes of a 4-point group, 8 bytes each
+  // hi = f16(x s), lo = f16(x s - hi): both planes of a 4-point group, 8 bytes each.  Mixed-precision FMAs (v_fma_mix*: fp32 or
+  // f16 sources, fp32 arithmetic, one rounding): hi = f16(fma(x, s, 0)) written to its half of the packed pair, r = fma(x, s, -hi)
+  // (exact), lo = cvt_pk(r): 10 vector instructions per group where multiply / convert / convert back / subtract / convert
+  // takes 16 -- these do not hide under other waves' MFMAs (tools/ubench/coissue.hip), so they are chunk time.
   auto split_store = [&](wg_f32x4 v, float s, bool ragged, int pt0, _Float16* d, int plane) {
 #pragma clang fp contract(off)
     if (ragged) {                        // (row-major operand, last chunk of the item: rows past p_end count as zeros)
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = pt0 + i < rag ? v[i] : 0.f;
     }
+#ifdef WGP_SPLIT16
     const wg_f32x4 xs = v * s;
     const wg_f16x4 ph = __builtin_convertvector(xs, wg_f16x4);
     const wg_f32x4 res = xs - __builtin_convertvector(ph, wg_f32x4);
     const wg_f16x4 pl = __builtin_convertvector(res, wg_f16x4);
     *reinterpret_cast<wg_f16x4*>(d) = ph;
     *reinterpret_cast<wg_f16x4*>(d + plane) = pl;
+#else
+    typedef unsigned wg_u32x2 __attribute__((ext_vector_type(2)));
+    typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 wg_f16x2 __attribute__((ext_vector_type(2)));
+    wg_u32x2 hp;
+    float r0, r1, r2, r3;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hp[0]) : "v"(v[0]), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hp[0]) : "v"(v[1]), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hp[1]) : "v"(v[2]), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hp[1]) : "v"(v[3]), "v"(s));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(v[0]), "v"(s), "v"(hp[0]));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(v[1]), "v"(s), "v"(hp[0]));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r2) : "v"(v[2]), "v"(s), "v"(hp[1]));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r3) : "v"(v[3]), "v"(s), "v"(hp[1]));
+    const wg_f16x2 l01 = __builtin_convertvector(wg_f32x2{r0, r1}, wg_f16x2), l23 = __builtin_convertvector(wg_f32x2{r2, r3}, wg_f16x2);
+    const wg_u32x2 lp = {__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+    *reinterpret_cast<wg_u32x2*>(d) = hp;
+    *reinterpret_cast<wg_u32x2*>(d + plane) = lp;
+#endif
   };
   // side item i (0..7) of an iteration: split + store group (i & 3) of A (i < 4) or B of chunk `cn` out of `set` into `buf`,
   // then refill the group's registers with chunk `cr`

@@ -789,7 +789,7 @@ def _wgrad_group_launch(jobs, extras=()):
         for i in range(n):
             by[lay[i]] = by.get(lay[i], 0) + 4e-6 * Ps[i] * (Ks[oid[i]] + Ns[oid[i]])
         print("wgrad group:", n, "sources;", {k: round(v, 1) for k, v in sorted(by.items())}, "MB by layout;",
-              sorted({(Ps[i], Ks[oid[i]], Ns[oid[i]], lay[i]) for i in range(n)}), flush=True)
+              sorted(__import__("collections").Counter((Ps[i], Ks[oid[i]], Ns[oid[i]], lay[i]) for i in range(n)).items()), flush=True)
     vp = ctypes.c_void_p
     need = int(lib.load().ndjir_mlp_wgrad_group_workspace(
         n, (vp * n)(*[t.data_ptr() for t in A]), (ctypes.c_int * n)(*lda), (ctypes.c_longlong * n)(*Ps), (ctypes.c_int * n)(*oid),
