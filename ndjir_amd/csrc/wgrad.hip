@@ -577,17 +577,28 @@ __device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A_, int ld
 #endif
 constexpr int WGP_CP = 32;                 // plane row pitch of the pipelined tile, in halves: 32 points, no padding
 constexpr int WGP_LDS = 2 * 2 * (WG_T + WG_T) * WGP_CP * 2;      // bytes: two buffers of [A hi][A lo][B hi][B lo]
+constexpr int WGP_LDS_WIDE = 2 * 2 * (WG_T + 2 * WG_T) * WGP_CP * 2;      // the 128 x 256 tile's
 // A feature's 32 points = four 16-byte segments; segment q of feature f is stored at q ^ ((f >> 2) & 3): the 16 lanes of a
 // fragment read's pass (16 consecutive features, one segment) then cover all 64 banks, as do the 8-byte writes of a group.
 __device__ __forceinline__ int wgp_at(int f, int seg) { return f * WGP_CP + ((seg ^ ((f >> 2) & 3)) << 3); }
 
-template <int LAY, bool FULL>
+// NBJ = 32-column blocks per wave: 2 = the 128 x 128 tile (wave tile 64 x 64, two workgroups per CU), 4 = the 128 x 256 tile of
+// k_wgrad_group_wide (wave tile 64 x 128, ONE workgroup per CU with 512 registers per lane).  Why the wide tile: the 64 x 64
+// wave tile reads 16 KB of fragments out of LDS per chunk for 24 MFMAs, and with the planes' writes a CU moves 192 KB through
+// LDS per pair of chunks -- 1500 cycles at 128 B / clk against 1536 cycles of matrix work: the loop is LDS-bound (the variant
+// without MFMAs and without global loads still takes 20 of the 39 us per 256 x 256 x 65536 layer).  A 64 x 128 wave tile reads
+// 24 KB for 48 MFMAs, and the chunk's vector work (132 instructions) fits the MFMAs' shadows.
+template <int LAY, bool FULL, int NBJ>
 __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int lda, const float* __restrict__ B_, int ldb, int N,
                                             long long p_begin, long long p_end, float* __restrict__ out_, int k0, int n0,
                                             int k_end, int n_end, float sa, float ia, float sb, float ib,
                                             unsigned short* wg_lds) {
   // FULL: the tile lies inside the K x N matrix (no feature masks).
-  constexpr int NT = 256, TK = WG_T, TN = WG_T;
+  constexpr int NT = 256, TK = WG_T, TN = 64 * NBJ;
+  constexpr int GA = 4, GB = 2 * NBJ;                     // 4-point groups per thread and chunk
+  constexpr int NSIDE = GA + GB, NMF = 6 * NBJ;           // side items per chunk; MFMAs per k-step (2 x NBJ blocks x 3 products)
+  constexpr int MPS = NMF / (NSIDE / 2);                  // MFMAs in front of each side item (3 | 4)
+  static_assert(MPS * (NSIDE / 2) == NMF && (NSIDE % 2) == 0, "MFMAs per side item");
   constexpr bool BLA = (LAY & 1) != 0, BLB = (LAY & 2) != 0;
   constexpr int PLA = TK * WGP_CP, PLB = TN * WGP_CP;     // halves per plane
   constexpr int BUF = 2 * PLA + 2 * PLB;                  // halves per buffer: [A hi][A lo][B hi][B lo]
@@ -598,8 +609,8 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
   const int r = lane & 31, h = lane >> 5;
   const int wk = wave >> 1, wn = wave & 1;
 
-  f32x16 acc[2][2] = {};
-  wg_f32x4 ra[2][4], rb[2][4];                            // [set][group]: 4 consecutive points of one feature
+  f32x16 acc[2][NBJ] = {};
+  wg_f32x4 ra[2][GA], rb[2][GB];                          // [set][group]: 4 consecutive points of one feature
 
   // Group g of a thread = 4 consecutive points (8-byte slot j of the feature's row: segment j >> 1, half j & 1).
   // Blocked operand: 16-byte run e = g * NT + tid of the chunk -- feature g * 32 + (tid >> 3), slot tid & 7;
@@ -608,23 +619,34 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
   // the chunk moves in the SCALAR offset, the thread's place in the chunk is one 32-bit vector register per group and
   // operand -- no vector address arithmetic in the loop.
   const int ka = k_end - k0 - 1, nb = n_end - n0 - 1;     // last valid feature of the tile (>= 0)
-  const int fa_r = tid & 127, hf_r = tid >> 7, f_b = tid >> 3, j_b = tid & 7;
-  // LDS slot of group g inside a plane: blocked = lds0 + g * 32 rows; row-major = ldsr[g >> 1] + (g & 1) * 4
+  // row-major operand of T features: feature tid % T, the thread's 32 * T / 256 points start at (tid / T) * that
+  const int fa_r = tid & (TK - 1), fb_r = tid & (TN - 1), f_b = tid >> 3, j_b = tid & 7;
+  const int pta_r = (tid / TK) * (4 * GA), ptb_r = (tid / TN) * (4 * GB);
+  // LDS slot of group g inside a plane: blocked = lds_blk + g * 32 rows; row-major = slot (pt / 4 + g) of the feature's row
   const int lds_blk = wgp_at(f_b, j_b >> 1) + (j_b & 1) * 4;
-  const int lds_row[2] = {wgp_at(fa_r, hf_r * 2), wgp_at(fa_r, hf_r * 2 + 1)};
-  auto lds_a = [&](int g) { return BLA ? lds_blk + g * 32 * WGP_CP : lds_row[g >> 1] + (g & 1) * 4; };
-  auto lds_b = [&](int g) { return BLB ? lds_blk + g * 32 * WGP_CP : lds_row[g >> 1] + (g & 1) * 4; };
-  const int pt_r = hf_r * 16;                             // first point of a row-major thread's groups
-  unsigned oa[4], ob[4];                                  // byte offset of the group's first element inside a chunk
+  auto lds_a = [&](int g) {
+    const int j = pta_r / 4 + g;
+    return BLA ? lds_blk + g * 32 * WGP_CP : wgp_at(fa_r, j >> 1) + (j & 1) * 4;
+  };
+  auto lds_b = [&](int g) {
+    const int j = ptb_r / 4 + g;
+    return BLB ? lds_blk + g * 32 * WGP_CP : wgp_at(fb_r, j >> 1) + (j & 1) * 4;
+  };
+  unsigned oa[GA], ob[GB];                                // byte offset of the group's first element inside a chunk
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int fga = BLA ? g * 32 + f_b : fa_r, fgb = BLB ? g * 32 + f_b : fa_r;
-    const int fca = FULL ? fga : (fga < ka ? fga : ka), fcb = FULL ? fgb : (fgb < nb ? fgb : nb);
-    oa[g] = BLA ? (unsigned)((fca * 32 + 4 * j_b) * 4) : (unsigned)(((pt_r + 4 * g) * lda + fca) * 4);
-    ob[g] = BLB ? (unsigned)((fcb * 32 + 4 * j_b) * 4) : (unsigned)(((pt_r + 4 * g) * ldb + fcb) * 4);
+  for (int g = 0; g < GA; ++g) {
+    const int fga = BLA ? g * 32 + f_b : fa_r;
+    const int fca = FULL ? fga : (fga < ka ? fga : ka);
+    oa[g] = BLA ? (unsigned)((fca * 32 + 4 * j_b) * 4) : (unsigned)(((pta_r + 4 * g) * lda + fca) * 4);
+  }
+#pragma unroll
+  for (int g = 0; g < GB; ++g) {
+    const int fgb = BLB ? g * 32 + f_b : fb_r;
+    const int fcb = FULL ? fgb : (fgb < nb ? fgb : nb);
+    ob[g] = BLB ? (unsigned)((fcb * 32 + 4 * j_b) * 4) : (unsigned)(((ptb_r + 4 * g) * ldb + fcb) * 4);
   }
   auto scale_a = [&](int g) { return FULL || (BLA ? g * 32 + f_b : fa_r) <= ka ? sa : 0.f; };
-  auto scale_b = [&](int g) { return FULL || (BLB ? g * 32 + f_b : fa_r) <= nb ? sb : 0.f; };
+  auto scale_b = [&](int g) { return FULL || (BLB ? g * 32 + f_b : fb_r) <= nb ? sb : 0.f; };
   auto uniform_ptr = [](const float* q) {      // (the item's operands are the same for every lane: keep the descriptors scalar)
     const unsigned long long u = reinterpret_cast<unsigned long long>(q);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
@@ -642,10 +664,10 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
 
   // (row-major, ragged last chunk: a row past the item's end re-reads the item's last row -- never memory past the operand --
   //  and the split zeroes it)
-  auto load_rows = [&](wg_f32x4& dst, const __amdgpu_buffer_rsrc_t& rs, unsigned off, int ld, int g, int c, int ch) {
+  auto load_rows = [&](wg_f32x4& dst, const __amdgpu_buffer_rsrc_t& rs, unsigned off, int ld, int pt0, int g, int c, int ch) {
     const int so = c * ch;
     if (rag < WG_C && c == c_last) {                      // (uniform)
-      const int row0 = pt_r + 4 * g;
+      const int row0 = pt0 + 4 * g;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int back = row0 + i - (rag - 1);            // rows past the last one
@@ -658,11 +680,11 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
   };
   auto load_a = [&](const int set, const int g, int c) {
     if (BLA) ra[set][g] = __builtin_bit_cast(wg_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, oa[g], c * cha, 0));
-    else load_rows(ra[set][g], rsa, oa[g], lda, g, c, cha);
+    else load_rows(ra[set][g], rsa, oa[g], lda, pta_r, g, c, cha);
   };
   auto load_b = [&](const int set, const int g, int c) {
     if (BLB) rb[set][g] = __builtin_bit_cast(wg_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsb, ob[g], c * chb, 0));
-    else load_rows(rb[set][g], rsb, ob[g], ldb, g, c, chb);
+    else load_rows(rb[set][g], rsb, ob[g], ldb, ptb_r, g, c, chb);
   };
   // hi = f16(x s), lo = f16(x s - hi): both planes of a 4-point group, 8 bytes each.  Mixed-precision FMAs (v_fma_mix*: fp32 or
   // f16 sources, fp32 arithmetic, one rounding): hi = f16(fma(x, s, 0)) written to its half of the packed pair, r = fma(x, s, -hi)
@@ -701,59 +723,63 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
     *reinterpret_cast<wg_u32x2*>(d + plane) = lp;
 #endif
   };
-  // side item i (0..7) of an iteration: split + store group (i & 3) of A (i < 4) or B of chunk `cn` out of `set` into `buf`,
-  // then refill the group's registers with chunk `cr`
-  auto side = [&](const int i, const int set, const int buf, int cn_, int cr) {
-    const int g = i & 3;
-    // (a chunk past the item's end is split into planes of zeros: the chunk loop runs in pairs, and multiplying one chunk too
-    //  many must add nothing)
-    const float live = cn_ <= c_last ? 1.f : 0.f;
-    const int cn = at(cn_);
-    const bool ragged = rag < WG_C && cn == c_last;
 #ifdef WGP_NO_LOAD      // (experiment: the loop without its global loads -- the registers keep the first chunks)
 #define WGP_LOAD(x)
 #else
 #define WGP_LOAD(x) x
 #endif
-    if (i < 4) {
-      split_store(ra[set][g], scale_a(g) * live, !BLA && ragged, pt_r + 4 * g, L + buf * BUF + lds_a(g), PLA);
+  // side item i of an iteration: split + store group i of A (i < GA) or group i - GA of B of chunk `cn` out of `set` into
+  // `buf`, then refill the group's registers with chunk `cr`
+  auto side = [&](const int i, const int set, const int buf, int cn_, int cr) {
+    // (a chunk past the item's end is split into planes of zeros: the chunk loop runs in pairs, and multiplying one chunk too
+    //  many must add nothing)
+    const float live = cn_ <= c_last ? 1.f : 0.f;
+    const int cn = at(cn_);
+    const bool ragged = rag < WG_C && cn == c_last;
+    if (i < GA) {
+      const int g = i;
+      split_store(ra[set][g], scale_a(g) * live, !BLA && ragged, pta_r + 4 * g, L + buf * BUF + lds_a(g), PLA);
       WGP_LOAD(load_a(set, g, cr));
     } else {
-      split_store(rb[set][g], scale_b(g) * live, !BLB && ragged, pt_r + 4 * g, L + buf * BUF + 2 * PLA + lds_b(g), PLB);
+      const int g = i - GA;
+      split_store(rb[set][g], scale_b(g) * live, !BLB && ragged, ptb_r + 4 * g, L + buf * BUF + 2 * PLA + lds_b(g), PLB);
       WGP_LOAD(load_b(set, g, cr));
     }
   };
 
   // fragment of block row i, plane pl, k-step s: feature (w * 2 + i) * 32 + r, segment 2 s + h
   const int fr_a[2] = {wgp_at((wk * 2) * 32 + r, h), wgp_at((wk * 2) * 32 + r, 2 + h)};      // [k-step]; + i * 32 rows, + plane
-  const int fr_b[2] = {wgp_at((wn * 2) * 32 + r, h), wgp_at((wn * 2) * 32 + r, 2 + h)};
+  const int fr_b[2] = {wgp_at((wn * NBJ) * 32 + r, h), wgp_at((wn * NBJ) * 32 + r, 2 + h)};
 #ifdef WGP_FRAG2
-  wg_f16x8 fa[2][2][2], fb[2][2][2];                      // [k-step][block][plane]
+  wg_f16x8 fa[2][2][2], fb[2][NBJ][2];                    // [k-step][block][plane]
 #else
-  wg_f16x8 fa[1][2][2], fb[1][2][2];                      // [block][plane]: one k-step's fragments at a time
+  wg_f16x8 fa[1][2][2], fb[1][NBJ][2];                    // [block][plane]: one k-step's fragments at a time
 #endif
   auto frags = [&](const int s_, const int buf) {
     const int s = s_;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
+      for (int i = 0; i < 2; ++i)
         fa[WGP_FS(s)][i][pl] = *reinterpret_cast<const wg_f16x8*>(L + buf * BUF + pl * PLA + i * 32 * WGP_CP + fr_a[s]);
-        fb[WGP_FS(s)][i][pl] = *reinterpret_cast<const wg_f16x8*>(L + buf * BUF + 2 * PLA + pl * PLB + i * 32 * WGP_CP + fr_b[s]);
-      }
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j)
+        fb[WGP_FS(s)][j][pl] = *reinterpret_cast<const wg_f16x8*>(L + buf * BUF + 2 * PLA + pl * PLB + j * 32 * WGP_CP + fr_b[s]);
+    }
   };
-  // MFMA q (0..11) of k-step s: product q >> 2 (lo hi', hi lo', hi hi') of block q & 3 -- two MFMAs into one accumulator
-  // are four apart
+  // MFMA q (0 .. NMF - 1) of k-step s: product q / (2 NBJ) (lo hi', hi lo', hi hi') of block q % (2 NBJ) -- two MFMAs into
+  // one accumulator are 2 NBJ apart
   auto mfma1 = [&](const int s, const int q) {
-    const int pr = q >> 2, i = (q >> 1) & 1, j = q & 1;
+    const int pr = q / (2 * NBJ), bl = q % (2 * NBJ), i = bl / NBJ, j = bl % NBJ;
 #ifdef WGP_NO_MFMA      // (experiment: what the loop costs without its matrix work)
     acc[i][j][0] += (float)fa[WGP_FS(s)][i][pr == 0][0] + (float)fb[WGP_FS(s)][j][pr == 1][0];
     return;
 #endif
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[WGP_FS(s)][i][pr == 0 ? 1 : 0], fb[WGP_FS(s)][j][pr == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
   };
-  auto mfma3 = [&](const int s, const int m) {
-    mfma1(s, 3 * m); mfma1(s, 3 * m + 1); mfma1(s, 3 * m + 2);
+  auto mfmas = [&](const int s, const int m) {
+#pragma unroll
+    for (int q = 0; q < MPS; ++q) mfma1(s, MPS * m + q);
   };
   // one chunk: multiply `buf`, split chunk cn (set `set`) into the other buffer, refill `set` with chunk cr
 #ifdef WGG_TIMELINE
@@ -769,30 +795,47 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
 #else
 #define WGP_STAMP(i)
 #endif
+  // (with the compiler's split -- plain vector instructions the scheduler can classify -- ask for one MFMA, then a slice of the
+  //  side item's vector work, MPS times: the in-order front end issues nothing behind an MFMA that waits for the matrix pipe)
+#if defined(WGP_SPLIT16) && !defined(WGP_NO_INTERLEAVE)
+#define WGP_INTERLEAVE()                                               \
+  do {                                                                 \
+    for (int q_ = 0; q_ < MPS; ++q_) {                                 \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               \
+      __builtin_amdgcn_sched_group_barrier(0x002, 16 / MPS, 0);        \
+    }                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                 \
+    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                 \
+  } while (0)
+#else
+#define WGP_INTERLEAVE()
+#endif
   auto iteration = [&](const int buf, const int set, int cn, int cr) {
     WGP_STAMP(0);
     frags(0, buf);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      mfma3(0, m);
+    for (int m = 0; m < NSIDE / 2; ++m) {
+      mfmas(0, m);
 #ifdef WGP_FRAG2
       if (m == 0) frags(1, buf);
 #endif
       side(m, set, buf ^ 1, cn, cr);
+      WGP_INTERLEAVE();
       __builtin_amdgcn_sched_barrier(0);
-      WGP_STAMP(1 + m);
+      if (m < 4) WGP_STAMP(1 + m);
     }
 #ifndef WGP_FRAG2
     frags(1, buf);
     __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      mfma3(1, m);
-      side(4 + m, set, buf ^ 1, cn, cr);
+    for (int m = 0; m < NSIDE / 2; ++m) {
+      mfmas(1, m);
+      side(NSIDE / 2 + m, set, buf ^ 1, cn, cr);
+      WGP_INTERLEAVE();
       __builtin_amdgcn_sched_barrier(0);
-      WGP_STAMP(5 + m);
+      if (m < 4) WGP_STAMP(5 + m);
     }
     __syncthreads();
     WGP_STAMP(9);
@@ -805,17 +848,17 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
   if (n_rows > 0) {
     // (issue order = the order the iterations consume and refill in: A groups, then B groups, set by set)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) load_a(0, g, 0);
+    for (int g = 0; g < GA; ++g) load_a(0, g, 0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) load_b(0, g, 0);
+    for (int g = 0; g < GB; ++g) load_b(0, g, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) load_a(1, g, at(1));
+    for (int g = 0; g < GA; ++g) load_a(1, g, at(1));
 #pragma unroll
-    for (int g = 0; g < 4; ++g) load_b(1, g, at(1));
+    for (int g = 0; g < GB; ++g) load_b(1, g, at(1));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NSIDE; ++i) {
       side(i, 0, 0, 0, at(2));
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -830,8 +873,8 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-      const int n = n0 + (wn * 2 + bj) * 32 + r;
+    for (int bj = 0; bj < NBJ; ++bj) {
+      const int n = n0 + (wn * NBJ + bj) * 32 + r;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int k = k0 + (wk * 2 + bi) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -1518,12 +1561,12 @@ __device__ __forceinline__ void wgrad_narrow_rows_blocked(const float* __restric
 
 // rows x columns of dW one item of a kind covers
 __host__ __device__ static inline int wgg_tile_k(int kind) { return kind == 1 ? WG_STRIP : kind == 4 ? 2 * WG_STRIP : WG_T; }
-__host__ __device__ static inline int wgg_tile_n(int kind) { return kind == 2 ? WG_STRIP : WG_T; }
+__host__ __device__ static inline int wgg_tile_n(int kind) { return kind == 2 ? WG_STRIP : kind == 5 ? 2 * WG_T : WG_T; }
 
 // workgroup -> (segment, split, tile): whole splits per XCD (workgroups are dealt round-robin to the 8 XCDs; first % 8 == 0,
 // count % 8 == 0), so that the tiles that share a range of points share an L2.  Returns false for an idle workgroup.
-__device__ __forceinline__ bool wgg_locate(const WggTable& a, int& si, int& split, int& tile) {
-  const int b = blockIdx.x;
+__device__ __forceinline__ bool wgg_locate(const WggTable& a, int& si, int& split, int& tile, int block_base = 0) {
+  const int b = blockIdx.x + block_base;
   int lo = 0, hi = a.n_seg - 1;          // the last segment whose first workgroup is <= b
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -1585,11 +1628,47 @@ __global__ void __launch_bounds__(256) k_wgg_write(const WggPiece p, WggTable* _
   for (int i = tid; i < p.n_out * wo; i += 256) d[i] = a[i];
 }
 
-__global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* __restrict__ tab) {
+// The 128 x 256 items (kind 5) of a group: one workgroup per CU, 512 registers per lane, 96 KB of LDS -- see wgrad3_pipe.  Their
+// segments come first in the table: workgroups [0, wide blocks) are this launch's, the rest k_wgrad_group's.
+__global__ void __launch_bounds__(WG_THREADS, 1) k_wgrad_group_wide(const WggTable* __restrict__ tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
   const WggTable& a = *tab;
   int si, split, tile;
   if (!wgg_locate(a, si, split, tile)) return;
+  const WggSeg& g = a.seg[si];
+  const WggSrc& s = a.src[g.src];
+  const int K = s.K, N = s.N;
+  const long long p_begin = (long long)split * s.rows;
+  long long p_end = p_begin + s.rows;
+  if (p_end > s.P) p_end = s.P;
+  float* slab = s.partial + (long long)split * K * N;
+  const int ti = tile / g.tiles_n, tj = tile - ti * g.tiles_n;
+  const int k0 = g.k_off + ti * WG_T, n0 = g.n_off + tj * 2 * WG_T;
+  unsigned ma, mb;
+  if (s.amax_a) ma = *wg_global(s.amax_a);
+  else { const int k1 = k0 + WG_T; ma = wgg_tile_absmax(s.A, s.lda, k0, k1 < g.k_end ? k1 : g.k_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds), s.layout & 1); }
+  if (s.amax_b) mb = *wg_global(s.amax_b);
+  else { const int n1 = n0 + 2 * WG_T; mb = wgg_tile_absmax(s.B, s.ldb, n0, n1 < g.n_end ? n1 : g.n_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds), s.layout & 2); }
+  float sa, ia, sb, ib;
+  wg_scale_from_max(ma, sa, ia);
+  wg_scale_from_max(mb, sb, ib);
+  const int lay = s.layout & 3;
+  const bool full = g.k_end - k0 >= WG_T && g.n_end - n0 >= 2 * WG_T;
+#define WGG_PIPE(LAYV)                                                                                                          \
+    if (full) wgrad3_pipe<LAYV, true, 4>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds); \
+    else wgrad3_pipe<LAYV, false, 4>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds)
+  if (lay == 3) { WGG_PIPE(3); }
+  else if (lay == 1) { WGG_PIPE(1); }
+  else if (lay == 2) { WGG_PIPE(2); }
+  else { WGG_PIPE(0); }
+#undef WGG_PIPE
+}
+
+__global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* __restrict__ tab, int block_base) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short wg_lds[];
+  const WggTable& a = *tab;
+  int si, split, tile;
+  if (!wgg_locate(a, si, split, tile, block_base)) return;
   const WggSeg& g = a.seg[si];
   const WggSrc& s = a.src[g.src];
   const int K = s.K, N = s.N, kind = g.kind;
@@ -1605,15 +1684,15 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* _
   const int ti = tile / g.tiles_n, tj = tile - ti * g.tiles_n;
   const int k0 = g.k_off + ti * wgg_tile_k(kind), n0 = g.n_off + tj * wgg_tile_n(kind);
   unsigned ma, mb;
-  if (s.amax_a) ma = *s.amax_a;
+  if (s.amax_a) ma = *wg_global(s.amax_a);
   else { const int k1 = k0 + wgg_tile_k(kind); ma = wgg_tile_absmax(s.A, s.lda, k0, k1 < g.k_end ? k1 : g.k_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds), s.layout & 1); }
-  if (s.amax_b) mb = *s.amax_b;
+  if (s.amax_b) mb = *wg_global(s.amax_b);
   else { const int n1 = n0 + wgg_tile_n(kind); mb = wgg_tile_absmax(s.B, s.ldb, n0, n1 < g.n_end ? n1 : g.n_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds), s.layout & 2); }
   float sa, ia, sb, ib;
   wg_scale_from_max(ma, sa, ia);
   wg_scale_from_max(mb, sb, ib);
 #ifdef WGG_ONLY
-  wgrad3_pipe<WGG_ONLY, true>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
+  wgrad3_pipe<WGG_ONLY, true, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
   return;
 #endif
 #ifndef NDJIR_WGRAD_NO_PIPE
@@ -1621,8 +1700,8 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* _
     const int lay = s.layout & 3;
     const bool full = g.k_end - k0 >= WG_T && g.n_end - n0 >= WG_T;
 #define WGG_PIPE(LAYV)                                                                                                          \
-    if (full) wgrad3_pipe<LAYV, true>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds); \
-    else wgrad3_pipe<LAYV, false>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds)
+    if (full) wgrad3_pipe<LAYV, true, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds); \
+    else wgrad3_pipe<LAYV, false, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds)
     if (lay == 3) { WGG_PIPE(3); }
     else if (lay == 1) { WGG_PIPE(1); }
     else if (lay == 2) { WGG_PIPE(2); }
@@ -1717,12 +1796,25 @@ constexpr int WGG_DEFAULT_ITEMS = 2048;     // 128 x 128-tile equivalents a grou
 // tiles over [0, Km) x [0, Nm), remainders of at most 64 as 32-wide strips (K strip spans all of N, N strip spans [0, Km)),
 // larger remainders as a further (ragged) tile.
 struct WggRegion { int kind, k_off, n_off, k_end, n_end, tiles_k, tiles_n; };
+// The 128 x 256 items are OPT-IN (NDJIR_WGRAD_WIDE=1): measured on the same box, 256 x 256 x 65536 blocked, 43.7 us per layer with
+// them against 42.9 without (profiles/r05_wgrad_ab.txt) -- halving the LDS reads per MFMA buys nothing, because the loop's cost
+// is the SUM of its matrix, vector, LDS-write and load-issue time (tools/ubench/shadow.hip: one ds_write_b64 behind an MFMA costs
+// 20 cycles, a packed fp32 multiply 9, only ~4 plain vector instructions per MFMA are free), and one wave per SIMD has no
+// second wave to fill its barrier and LDS-latency gaps.
+static bool wgg_wide_enabled() {
+  static const bool on = getenv("NDJIR_WGRAD_WIDE") != nullptr;
+  return on;
+}
 static int wgg_regions(int K, int N, WggRegion* rg) {
   int n = 0;
   const int rk = K % WG_T, rn = N % WG_T;
   const int Km = (rk != 0 && rk <= 2 * WG_STRIP) ? K - rk : K;
   const int Nm = (rn != 0 && rn <= 2 * WG_STRIP) ? N - rn : N;
-  if (Km > 0 && Nm > 0) rg[n++] = {0, 0, 0, Km, Nm, (Km + WG_T - 1) / WG_T, (Nm + WG_T - 1) / WG_T};
+  // main region: 128 x 256 items (kind 5) over the columns they cover at least half of, 128 x 128 tiles over the rest
+  const int tw = wgg_wide_enabled() ? (Nm + WG_T - 1) / (2 * WG_T) : 0;
+  const int Nw = tw * 2 * WG_T < Nm ? tw * 2 * WG_T : (tw > 0 ? Nm : 0);
+  if (Km > 0 && Nw > 0) rg[n++] = {5, 0, 0, Km, Nw, (Km + WG_T - 1) / WG_T, tw};
+  if (Km > 0 && Nm > Nw) rg[n++] = {0, 0, Nw, Km, Nm, (Km + WG_T - 1) / WG_T, (Nm - Nw + WG_T - 1) / WG_T};
   if (Km > 0 && N > Nm) rg[n++] = {2, 0, Nm, Km, N, (Km + WG_T - 1) / WG_T, (N - Nm + WG_STRIP - 1) / WG_STRIP};
   if (K > Km) {
     // rows [Km, K): up to 32 of them as one row of 32 x 128 strips, 33..64 as one row of 64 x 128 items (kind 4) -- two rows of
@@ -1733,10 +1825,11 @@ static int wgg_regions(int K, int N, WggRegion* rg) {
   return n;
 }
 static double wgg_units(int K, int N) {        // work of one split in 128 x 128-tile equivalents
-  WggRegion rg[4];
+  WggRegion rg[5];
   const int n = wgg_regions(K, N, rg);
   double u = 0.0;
-  for (int i = 0; i < n; ++i) u += ((rg[i].kind == 1 || rg[i].kind == 2) ? 0.25 : rg[i].kind == 4 ? 0.5 : 1.0) * rg[i].tiles_k * rg[i].tiles_n;
+  for (int i = 0; i < n; ++i)
+    u += ((rg[i].kind == 1 || rg[i].kind == 2) ? 0.25 : rg[i].kind == 4 ? 0.5 : rg[i].kind == 5 ? 2.0 : 1.0) * rg[i].tiles_k * rg[i].tiles_n;
   return u;
 }
 
@@ -1749,7 +1842,7 @@ static int wgg_chunk_end(int o0, int n_src, const long long* P, const int* out_i
   while (o1 < n_out && o1 - o0 < WGT_MAX_OUT) {
     int cnt = 0;
     for (int i = 0; i < n_src; ++i) cnt += (out_id[i] == o1 && P[i] > 0);
-    if (ns + cnt > WGT_MAX_SRC || 3 * (ns + cnt) > WGT_MAX_SEG) break;      // (<= 3 regions per source)
+    if (ns + cnt > WGT_MAX_SRC || 4 * (ns + cnt) > WGT_MAX_SEG) break;      // (<= 4 regions per source)
     ns += cnt;
     ++o1;
   }
@@ -1829,6 +1922,7 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_group), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_group_wide), hipFuncAttributeMaxDynamicSharedMemorySize, WGP_LDS_WIDE);
     attr = true;
   }
   if (n_src > 65536) return NDJIR_ERR_ARG;
@@ -1870,13 +1964,15 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
     }
     // segments: the narrow items first (short, but each a serial chain: they finish under the tiles), then the 128 x 128
     // tiles of every source, then the strips (a quarter of a tile's work each: they fill the tail)
-    int blocks = 0, nseg = 0;
-    static const int order[5] = {3, 0, 4, 1, 2};
-    for (int q = 0; q < 5; ++q)
+    // (first of all the 128 x 256 items: they are another launch's, k_wgrad_group_wide's)
+    int blocks = 0, nseg = 0, wide_blocks = 0;
+    static const int order[6] = {5, 3, 0, 4, 1, 2};
+    for (int q = 0; q < 6; ++q) {
+      if (q == 1) wide_blocks = blocks;
       for (int i = 0; i < ns; ++i) {
         const int kind = order[q];
         const WggSrc& s = tab.src[i];
-        WggRegion rg[4];
+        WggRegion rg[5];
         int nr = 0;
         if (wgg_narrow(s.A, s.lda, s.K, s.N, s.layout)) {
           if (kind == 3) rg[nr++] = {3, 0, 0, s.K, s.N, 1, 1};
@@ -1895,6 +1991,7 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
           blocks += g.count;
         }
       }
+    }
     // the reduce-only outputs (deferred bias gradients) ride in the tables' free output slots
     for (; ex_done < n_extra && no < WGT_MAX_OUT; ++ex_done) {
       WggOut& w = tab.out[no++];
@@ -1953,9 +2050,13 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
       if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
       s0 += pc.n_src; g0 += pc.n_seg; w0 += pc.n_out;
     }
-    if (blocks > 0) {
-      hipLaunchKernelGGL(k_wgrad_group, dim3(blocks), dim3(WG_THREADS), WGP_LDS, stream,
-                         (const WggTable*)dtab);
+    if (wide_blocks > 0) {
+      hipLaunchKernelGGL(k_wgrad_group_wide, dim3(wide_blocks), dim3(WG_THREADS), WGP_LDS_WIDE, stream, (const WggTable*)dtab);
+      if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
+    }
+    if (blocks > wide_blocks) {
+      hipLaunchKernelGGL(k_wgrad_group, dim3(blocks - wide_blocks), dim3(WG_THREADS), WGP_LDS, stream,
+                         (const WggTable*)dtab, wide_blocks);
       if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
     }
     for (int g = 0; g < n_gen && no > 0; ++g) {
