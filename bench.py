@@ -782,11 +782,6 @@ def main():
                 out["parity"] = parity_block(conf, step, a.cpu_rays)
             except Exception as e:
                 out["parity"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not force_dist and a.extra_legs:
-            try:
-                out["fp32_engine"] = fp32_engine_leg(step)
-            except Exception as e:
-                out["fp32_engine"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not force_dist and a.extra_legs:
         try:
             out["redraw"] = redraw_leg(step, graph if exec_mode == "graph" else None, loss if exec_mode == "graph" else None,
@@ -804,6 +799,13 @@ def main():
             tl["scope"] = ("fwd+bwd + weight decay + finite-gradient guard + Adam update of every parameter "
                            "(python/train.py:136-148); reported beside the headline metric, not as it")
             out["train_step"] = tl
+    if world == 1 and not force_dist and a.extra_legs and rank == 0:
+        # (LAST user of `step`: switching the engine re-packs the weights, and the graphs captured above hold the addresses of
+        #  the packed copies they were captured with -- round 5's first placement, before the `redraw` replays, gave them NaNs)
+        try:
+            out["fp32_engine"] = fp32_engine_leg(step)
+        except Exception as e:
+            out["fp32_engine"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not force_dist and a.extra_legs:
         use_graph = (a.exec_mode or os.environ.get("NDJIR_BENCH_EXEC") or "graph") == "graph"
         try:

@@ -1796,13 +1796,14 @@ constexpr int WGG_DEFAULT_ITEMS = 2048;     // 128 x 128-tile equivalents a grou
 // tiles over [0, Km) x [0, Nm), remainders of at most 64 as 32-wide strips (K strip spans all of N, N strip spans [0, Km)),
 // larger remainders as a further (ragged) tile.
 struct WggRegion { int kind, k_off, n_off, k_end, n_end, tiles_k, tiles_n; };
-// The 128 x 256 items are OPT-IN (NDJIR_WGRAD_WIDE=1): measured on the same box, 256 x 256 x 65536 blocked, 43.7 us per layer with
-// them against 42.9 without (profiles/r05_wgrad_ab.txt) -- halving the LDS reads per MFMA buys nothing, because the loop's cost
-// is the SUM of its matrix, vector, LDS-write and load-issue time (tools/ubench/shadow.hip: one ds_write_b64 behind an MFMA costs
-// 20 cycles, a packed fp32 multiply 9, only ~4 plain vector instructions per MFMA are free), and one wave per SIMD has no
-// second wave to fill its barrier and LDS-latency gaps.
+// The 128 x 256 items: on by default (NDJIR_WGRAD_NO_WIDE=1 switches them off).  On 8 x (256 x 256 x 65536) alone they measure
+// what the 128 x 128 tile measures (43.7 against 42.9 us per layer, same box: halving the LDS reads per MFMA buys nothing there --
+// the loop's cost is the SUM of its matrix, vector, LDS-write and load-issue time, tools/ubench/shadow.hip, and one wave per SIMD
+// has no second wave to fill its barrier and LDS-latency gaps); in the STEP, whose 66 operand pairs include ragged and
+// mixed-layout shapes and whose tiles then read A half as often, they are worth 2.5 %: 7.93 / 7.92 / 7.91 ms against
+// 8.13 / 8.14 / 8.11 in three interleaved pairs on one box (profiles/r05_wgrad_ab.txt).
 static bool wgg_wide_enabled() {
-  static const bool on = getenv("NDJIR_WGRAD_WIDE") != nullptr;
+  static const bool on = getenv("NDJIR_WGRAD_NO_WIDE") == nullptr;
   return on;
 }
 static int wgg_regions(int K, int N, WggRegion* rg) {
