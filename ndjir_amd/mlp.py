@@ -81,7 +81,7 @@ def _launch_symbol(name, args):
         return chain_kernel_symbol(args[0], args[1], args[4], args[8], args[9], bool(args[17]), args[19], args[21],
                                    any(t is not None for t in args[13]) or (args[29 if name == "mlp_chain_ex" else 24] is not None))
     if name == "mlp_wgrad_group":
-        return "ndjir::k_wgrad_group (+ k_wgrad_group_reduce)"
+        return "ndjir::k_wgrad_group_wide + k_wgrad_group (+ k_wgrad_group_reduce)"
     if name == "mlp_wgrad":
         return "ndjir::k_wgrad3 / k_wgrad_narrow (+ split reduction)"
     return "ndjir::" + name
