@@ -625,3 +625,42 @@ def test_wgrad_group_same_and_overlapping_destinations(gpu):
         for job in ops:
             mlp.wgrad_group([job])
     assert float((Wg.cpu().double() - ref).norm() / ref.norm()) < 2e-6
+
+
+def _to_blocked(x):
+    """(P, K) row-major -> the same P * K floats point-blocked: element (p, f) at ((p >> 5) * K + f) * 32 + (p & 31)."""
+    P, K = x.shape
+    return x.reshape(P // 32, 32, K).permute(0, 2, 1).contiguous().reshape(P, K)
+
+
+@pytest.mark.parametrize("wide", [True, False])
+def test_wgrad_group_point_blocked_operands(gpu, wide, monkeypatch):
+    """Grouped weight gradients with point-blocked operands (`mlp.PB`: what the 128-point-tile chains write) in every layout
+    combination, vs fp64: full and ragged 128 x 128 tiles and 128 x 256 items (`k_wgrad_group_wide`; NDJIR_WGRAD_NO_WIDE is read
+    once per process, so the second parametrisation shrinks the item count instead and covers the other split lengths), a feature
+    range of a wider blocked buffer, narrow outputs with a blocked A, an odd number of 32-point chunks per item, two operand
+    pairs per output."""
+    from ndjir_amd import mlp
+    monkeypatch.setattr(mlp, "WGRAD_GROUP_ITEMS", 0 if wide else 96)
+    rng = np.random.RandomState(21)
+    shapes = [(4096, 256, 256, 3), (4096 + 32 * 3, 256, 213, 3), (2048, 128, 128, 3), (4096, 256, 256, 1), (4096, 259, 256, 2), (8192, 262, 128, 2),
+              (4096, 256, 257, 1), (2048, 256, 3, 1), (2048, 128, 1, 1), (4096, 213, 300, 3), (32, 256, 256, 3), (96, 128, 256, 3)]
+    jobs, refs = [], []
+    for i, (P, K, N, lay) in enumerate(shapes):
+        srcs, ref = [], torch.zeros(K, N, dtype=torch.float64)
+        for j in range(2 if i % 4 == 0 else 1):
+            A = torch.tensor(rng.randn(P, K + 8) * 10.0 ** (i % 3 - 1), dtype=torch.float32)      # (feature range [4, 4 + K) of a wider buffer)
+            B = torch.tensor(rng.randn(P, N) * (2.0 + j), dtype=torch.float32)
+            ref += A[:, 4:4 + K].double().t() @ B.double()
+            Ad = mlp.PB(_to_blocked(A.to(gpu)))[:, 4:4 + K] if lay & 1 else A.to(gpu)[:, 4:4 + K]
+            Bd = mlp.PB(_to_blocked(B.to(gpu))) if lay & 2 else B.to(gpu)
+            srcs.append((Ad, Bd, A.abs().max().reshape(1).to(gpu), (B.abs().max() * 1.5).reshape(1).to(gpu)))
+        accum = i % 2 == 0
+        base = torch.tensor(rng.randn(K, N), dtype=torch.float32)
+        out = base.to(gpu).clone() if accum else torch.full((K, N), float("nan"), device=gpu)
+        jobs.append((out, accum, srcs))
+        refs.append(ref + base.double() if accum else ref)
+    mlp.wgrad_group(jobs)
+    for (out, _, _), ref, sh in zip(jobs, refs, shapes):
+        err = float((out.cpu().double() - ref).norm() / ref.norm())
+        assert err < 2e-6, (sh, err)
