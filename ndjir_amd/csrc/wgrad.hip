@@ -570,11 +570,7 @@ __device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A_, int ld
 //     max |x s| in [2^14, 2^15), i.e. 2^-39 of the operand's largest element) -- 64 registers instead of 128, which is what
 //     makes room for the second operand set and a second fragment set (the next k-step's LDS reads under this one's MFMAs).
 // Loads past the item's last chunk re-read that chunk (L2 hits), its planes land in the buffer nobody reads.
-#ifdef WGP_FRAG2
-#define WGP_FS(s) (s)
-#else
-#define WGP_FS(s) 0
-#endif
+#define WGP_FS(s) (F2 ? (s) : 0)
 constexpr int WGP_CP = 32;                 // plane row pitch of the pipelined tile, in halves: 32 points, no padding
 constexpr int WGP_LDS = 2 * 2 * (WG_T + WG_T) * WGP_CP * 2;      // bytes: two buffers of [A hi][A lo][B hi][B lo]
 constexpr int WGP_LDS_WIDE = 2 * 2 * (WG_T + 2 * WG_T) * WGP_CP * 2;      // the 128 x 256 tile's
@@ -750,11 +746,14 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
   // fragment of block row i, plane pl, k-step s: feature (w * 2 + i) * 32 + r, segment 2 s + h
   const int fr_a[2] = {wgp_at((wk * 2) * 32 + r, h), wgp_at((wk * 2) * 32 + r, 2 + h)};      // [k-step]; + i * 32 rows, + plane
   const int fr_b[2] = {wgp_at((wn * NBJ) * 32 + r, h), wgp_at((wn * NBJ) * 32 + r, 2 + h)};
-#ifdef WGP_FRAG2
-  wg_f16x8 fa[2][2][2], fb[2][NBJ][2];                    // [k-step][block][plane]
+  // one k-step's fragments at a time where a second wave of the SIMD covers the LDS latency (128 x 128 tile: a second set
+  // measured 39.8 against 39.1 us); the one-wave-per-SIMD 128 x 256 item reads the second k-step's under the first's MFMAs
+#ifdef WGP_FRAG2_OFF
+  constexpr bool F2 = false;
 #else
-  wg_f16x8 fa[1][2][2], fb[1][NBJ][2];                    // [block][plane]: one k-step's fragments at a time
+  constexpr bool F2 = NBJ == 4;
 #endif
+  wg_f16x8 fa[F2 ? 2 : 1][2][2], fb[F2 ? 2 : 1][NBJ][2];  // [k-step][block][plane]
   auto frags = [&](const int s_, const int buf) {
     const int s = s_;
 #pragma unroll
@@ -817,18 +816,16 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
 #pragma unroll
     for (int m = 0; m < NSIDE / 2; ++m) {
       mfmas(0, m);
-#ifdef WGP_FRAG2
-      if (m == 0) frags(1, buf);
-#endif
+      if (F2 && m == 0) frags(1, buf);
       side(m, set, buf ^ 1, cn, cr);
       WGP_INTERLEAVE();
       __builtin_amdgcn_sched_barrier(0);
       if (m < 4) WGP_STAMP(1 + m);
     }
-#ifndef WGP_FRAG2
-    frags(1, buf);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    if (!F2) {
+      frags(1, buf);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int m = 0; m < NSIDE / 2; ++m) {
       mfmas(1, m);
