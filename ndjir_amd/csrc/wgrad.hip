@@ -811,7 +811,7 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
 #endif
   auto iteration = [&](const int buf, const int set, int cn, int cr) {
     WGP_STAMP(0);
-    frags(0, buf);
+    if (!F2) frags(0, buf);              // (F2: loaded by the previous iteration's tail / the prologue)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < NSIDE / 2; ++m) {
@@ -825,16 +825,35 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
     if (!F2) {
       frags(1, buf);
       __builtin_amdgcn_sched_barrier(0);
-    }
 #pragma unroll
-    for (int m = 0; m < NSIDE / 2; ++m) {
-      mfmas(1, m);
-      side(NSIDE / 2 + m, set, buf ^ 1, cn, cr);
-      WGP_INTERLEAVE();
+      for (int m = 0; m < NSIDE / 2; ++m) {
+        mfmas(1, m);
+        side(NSIDE / 2 + m, set, buf ^ 1, cn, cr);
+        WGP_INTERLEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        if (m < 4) WGP_STAMP(5 + m);
+      }
+      __syncthreads();
+    } else {
+      // One wave per SIMD: nobody covers the LDS latency of the next chunk's first fragments behind the barrier.  The second
+      // k-step's side items go behind its first NMF / 2 MFMAs, then the barrier, then the NEXT chunk's first fragments are
+      // requested (their registers are free: the first k-step's MFMAs are issued) and arrive under the last NMF / 2 MFMAs.
+      constexpr int HM = NMF / 2 / (NSIDE / 2);
+#pragma unroll
+      for (int m = 0; m < NSIDE / 2; ++m) {
+#pragma unroll
+        for (int q = 0; q < HM; ++q) mfma1(1, HM * m + q);
+        side(NSIDE / 2 + m, set, buf ^ 1, cn, cr);
+        __builtin_amdgcn_sched_barrier(0);
+        if (m < 4) WGP_STAMP(5 + m);
+      }
+      __syncthreads();
+      frags(0, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (m < 4) WGP_STAMP(5 + m);
+#pragma unroll
+      for (int q = NMF / 2; q < NMF; ++q) mfma1(1, q);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
     WGP_STAMP(9);
     WGP_STAMP(11);
 #ifdef WGG_TIMELINE
@@ -860,6 +879,7 @@ __device__ __forceinline__ void wgrad3_pipe(const float* __restrict__ A_, int ld
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
+    if (F2) frags(0, 0);
     for (int c = 0; c <= c_last; c += 2) {               // (pairs: one exit, the accumulators stay where they are)
       iteration(0, 1, c + 1, at(c + 3));
       iteration(1, 0, c + 2, at(c + 4));
@@ -1787,7 +1807,7 @@ static inline bool wgg_narrow(const float* A, int lda, int K, int N, int layout 
   return N <= SW_NMAX && (K & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
 }
 
-constexpr int WGG_DEFAULT_ITEMS = 2048;     // 128 x 128-tile equivalents a grouped launch aims for (8 per CU; 1024 .. 4096 measured within 1.5 %)
+constexpr int WGG_DEFAULT_ITEMS = 3072;     // 128 x 128-tile equivalents a grouped call aims for (12 per CU).  Round 5, with the one-workgroup-per-CU wide launch, whose tail counts: step 7.97 / 7.96 / 7.78 / 7.72 / 7.82 ms at 1024 / 1536 / 2048 / 3072 / 4096 (two sweeps, one box)
 
 // The regions of a K x N output and the kind of item that tiles each (at most 3), as the per-layer launcher cuts it: 128 x 128
 // tiles over [0, Km) x [0, Nm), remainders of at most 64 as 32-wide strips (K strip spans all of N, N strip spans [0, Km)),

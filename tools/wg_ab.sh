@@ -1,7 +1,3 @@
-python -m pytest tests/test_gpu_mlp.py -x -q -m gpu -k "wgrad" 2>&1 | tail -2
-for rep in 1 2 3; do
-  python bench.py --steps 20 --warmup 5 --no-extra-legs --no-cpu-baseline 2>/dev/null | tail -1 | cut -c60-200
-  NDJIR_HIP_LIB=$PWD/ndjir_amd/_lib/variants/wgp_f2off.so python bench.py --steps 20 --warmup 5 --no-extra-legs --no-cpu-baseline 2>/dev/null | tail -1 | cut -c60-200
+for rep in 1 2; do
+for it in 2048 2560 3072 3584; do echo -n "items $it: "; NDJIR_WGRAD_ITEMS=$it python bench.py --steps 20 --warmup 5 --no-extra-legs --no-cpu-baseline 2>/dev/null | tail -1 | cut -c60-95,155-190; done
 done
-echo "== f2 wide blocked"; WGT_ONE=1 WGT_BLOCKED=3 python tools/wgrad_group_time.py 8
-echo "== f2off wide blocked"; NDJIR_HIP_LIB=$PWD/ndjir_amd/_lib/variants/wgp_f2off.so WGT_ONE=1 WGT_BLOCKED=3 python tools/wgrad_group_time.py 8
