@@ -364,9 +364,9 @@ __device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A_, int ld
   const int wk = wave / WN, wn = wave % WN;
 
   f32x16 acc0[BK][BN] = {}, acc1[BK][BN] = {};
-  // Two register sets: the loads of chunks c + 1 and c + 2 are in flight while chunk c is multiplied (one chunk of 32 KB per
-  // workgroup in flight left the loop waiting on HBM latency: 9 k cycles per chunk against 768 cycles of MFMA -- round 5).
-  float ra[2][PA], rb[2][PB];
+  // (one register set: the next chunk's loads are in flight while this one is multiplied.  A second set spills at this
+  //  tile's 128 accumulator registers and ran 3 x slower -- the pipelined tile below gets its second set from a single accumulator)
+  float ra[1][PA], rb[1][PB];
   const int fa = tid % TK, ga = tid / TK, fb = tid % TN, gb = tid / TN;   // feature column, point group
   const bool acol = (k0 + fa) < k_end, bcol = (n0 + fb) < n_end;
   const WG_G float* Ap = A + (long long)(ga * PA) * lda + k0 + fa;
@@ -491,18 +491,10 @@ __device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A_, int ld
   };
 
   if (p_begin < p_end) {
-    // (loads past the item's last chunk re-read that chunk: every iteration issues the same number of loads, so the wait
-    // before a store names exactly the younger set's loads -- vmcnt is in-order)
-    const long long p_last = p_begin + (p_end - p_begin - 1) / WG_C * WG_C;
-    auto at = [&](long long p) { return p < p_last ? p : p_last; };
     load_chunk(p_begin, 0);
-#ifdef NDJIR_WGRAD_DEPTH2
-    load_chunk(at(p_begin + WG_C), 1);
-#endif
     store_chunk(0);
     __syncthreads();
     for (long long p0 = p_begin;;) {
-#ifndef NDJIR_WGRAD_DEPTH2
       const bool more = p0 + WG_C < p_end;
       WGG_STAMP(0);
       if (more) load_chunk(p0 + WG_C, 0);
@@ -521,22 +513,6 @@ __device__ __forceinline__ void wgrad3_tile(const float* __restrict__ A_, int ld
       __syncthreads();
       WGG_STAMP(6);
       p0 += WG_C;
-#else
-      load_chunk(at(p0 + 2 * WG_C), 0);
-      multiply_chunk();
-      __syncthreads();                 // every wave is done with this chunk's planes
-      p0 += WG_C;
-      if (p0 >= p_end) break;
-      store_chunk(1);
-      __syncthreads();
-      load_chunk(at(p0 + 2 * WG_C), 1);
-      multiply_chunk();
-      __syncthreads();
-      p0 += WG_C;
-      if (p0 >= p_end) break;
-      store_chunk(0);
-      __syncthreads();
-#endif
     }
   }
 
