@@ -1846,7 +1846,8 @@ static int wgg_chunk_end(int o0, int n_src, const long long* P, const int* out_i
 // splits / rows per split of the sources of outputs [o0, o1) -- one launch (same rule for the workspace size and the launch)
 static void wgg_split_plan(int o0, int o1, int n_src, const float* const* A, const int* lda, const long long* P, const int* out_id,
                            const int* K, const int* N, int target_items, int* S, long long* rows, const int* layout) {
-  if (target_items <= 0) target_items = WGG_DEFAULT_ITEMS;
+  const bool defaulted = target_items <= 0;
+  if (defaulted) target_items = WGG_DEFAULT_ITEMS;
   double units = 0.0;               // main-tile equivalents x points
   for (int i = 0; i < n_src; ++i) {
     const int o = out_id[i];
@@ -1856,6 +1857,39 @@ static void wgg_split_plan(int o0, int o1, int n_src, const float* const* A, con
   long long target = (long long)(units / target_items);
   target = (target + WG_C - 1) / WG_C * WG_C;
   if (target < 16 * WG_C) target = 16 * WG_C;
+  if (defaulted && wgg_wide_enabled()) {
+    // The wide items run one per CU and all take the same time: their launch costs ceil(items / 256) rounds, and a last round
+    // that is a third full is a tenth of the launch idle (the item-count sweep of round 5: 2560 items -> 4.2 rounds, 7.85 ms;
+    // 3072 -> 4.95 rounds, 7.73 ms).  Among the split lengths within 25 % of the nominal one take the one whose wide items
+    // fill their last round best (ties: the nearest).
+    auto wide_items = [&](long long t) {
+      long long w = 0;
+      for (int i = 0; i < n_src; ++i) {
+        const int o = out_id[i];
+        if (o < o0 || o >= o1 || P[i] <= 0 || wgg_narrow(A ? A[i] : nullptr, lda[i], K[o], N[o], layout ? layout[i] : 0)) continue;
+        WggRegion rg[5];
+        const int n = wgg_regions(K[o], N[o], rg);
+        long long s = (P[i] + t - 1) / t, r = ((P[i] + s - 1) / s + WG_C - 1) / WG_C * WG_C;
+        s = (P[i] + r - 1) / r;
+        for (int q = 0; q < n; ++q)
+          if (rg[q].kind == 5) w += s * rg[q].tiles_k * rg[q].tiles_n;
+      }
+      return w;
+    };
+    constexpr long long CUS = 256;
+    long long best = target;
+    double best_waste = 2.0;
+    for (long long t = target * 3 / 4 / WG_C * WG_C; t <= target * 5 / 4; t += WG_C) {
+      if (t < 16 * WG_C) continue;
+      const long long w = wide_items(t);
+      if (w <= 0) { best = target; break; }
+      const long long rounds = (w + CUS - 1) / CUS;
+      const double waste = (double)(rounds * CUS - w) / (double)(rounds * CUS);
+      const long long d = t > target ? t - target : target - t, db = best > target ? best - target : target - best;
+      if (waste < best_waste - 1e-9 || (waste < best_waste + 1e-9 && d < db)) { best_waste = waste; best = t; }
+    }
+    target = best;
+  }
   for (int i = 0; i < n_src; ++i) {
     const int o = out_id[i];
     if (o < o0 || o >= o1) continue;

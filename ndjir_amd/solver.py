@@ -111,6 +111,8 @@ class Adam:
         return (g.contiguous() if g is not None else None), False
 
     def _check(self):
+        if not self.params:          # (a configuration without this solver's parameter group: `no_voxel` has no feature grid)
+            return
         self.flag.zero_()
         dense, numel = [], []
         for k, p in zip(self.names, self.params):
@@ -139,6 +141,8 @@ class Adam:
         are raised (python/solver.py:67-69); None = unconditional, as nnabla's `update()`.  repack: refresh the tracked
         packed weights afterwards (`Solvers` does it once for both of its solvers instead: a hash grid's 2-D feature table
         would otherwise trigger a second launch)."""
+        if not self.params:
+            return
         fa, fb = guard_flags if guard_flags is not None else (None, None)
         lib.call("solver_adam_begin", self.state, self.beta1, self.beta2, fa, fb)
         scales = self._decay_scales
@@ -230,7 +234,18 @@ class Solvers:
         without leaving the stream.  loss: the step's loss as a 1-element device tensor (None: gradient guard only)."""
         self.solver_weight._check()
         self.solver_feat._check()
-        flags = (self.solver_weight.flag, self.solver_feat.flag)
+        flags = [self.solver_weight.flag, self.solver_feat.flag]
+        if flags[0] is None or flags[1] is None:
+            # A solver without parameters finds no inf / nan (the reference's check over an empty set, python/solver.py:67-69):
+            # its flag is a zero of our own, on the other solver's device.
+            live = flags[0] if flags[0] is not None else flags[1]
+            if live is None:
+                return
+            if getattr(self, "_zero_flag", None) is None or self._zero_flag.device != live.device:
+                self._zero_flag = torch.zeros(1, dtype=torch.int32, device=live.device)
+            self._zero_flag.zero_()
+            flags = [f if f is not None else self._zero_flag for f in flags]
+        flags = tuple(flags)
         if loss is not None:        # a NaN loss vetoes the step whatever the gradients look like: raise both flags
             lib.call("solver_veto_if_nan", 1, loss.detach().reshape(1), flags[0], flags[1])
         self.solver_weight.update(flags, repack=False)

@@ -229,3 +229,27 @@ def test_in_place_gradient_bucket_equals_autograd(gpu, variant, B):
     x = torch.randn(64, W.shape[0], device=gpu)
     g, = torch.autograd.grad(mlp.fused_mlp(x, [W], [None]).square().sum(), [W])
     assert g is not None and float(g.abs().max()) > 0 and torch.equal(step.flat_grad, before)
+
+
+def test_training_iteration_without_a_feature_grid(gpu):
+    """`no_voxel` (BASELINE config 4) has no grid parameters: the feature solver's group is empty, its guard finds nothing
+    (python/solver.py:67-69 over an empty set) and the weight solver still updates -- `bench.py --config no_voxel` crashed
+    in its training leg until round 5."""
+    from ndjir_amd import config as cfg
+    from ndjir_amd.step import Step
+    conf = cfg.load("no_voxel", [])
+    step = Step(conf, 16, gpu, 0, 1)
+    step.enable_training()
+    assert not step.solvers.solver_feat.params
+    w = step.mlp_params[0].detach().clone()
+    for _ in range(2):
+        step.train_step()
+    assert bool(torch.isfinite(step.loss).all())
+    assert float((step.mlp_params[0].detach() - w).abs().max()) > 0
+    t0 = step.solvers.solver_weight.step_count()
+    s = step.solvers
+    s.zero_grad(); s.weight_decay(); s.clip_grad_by_norm()
+    step.compute(rearm=False)
+    step.loss.fill_(float("nan"))            # a NaN loss still vetoes the update
+    step.optimizer_step()
+    assert step.solvers.solver_weight.step_count() == t0
