@@ -347,7 +347,11 @@ __device__ __forceinline__ void chainw_body(const NETS nets) {
               for (int q = 0; q < U; ++q) acc0[u * U + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0][0], af[u][0][q], acc0[u * U + q], 0, 0, 0);
 #pragma unroll
               for (int q = 0; q < U; ++q) acc1[u * U + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0][1], af[u][0][q], acc1[u * U + q], 0, 0, 0);
+#ifdef NDJIR_KLOOP_HALF_LDS      // (timing experiment, WRONG results: only the first unit's fragments are re-read -- half of the k-loop's LDS reads)
+              if (nxt && u == 0) {
+#else
               if (nxt) {
+#endif
 #pragma unroll
                 for (int q = 0; q < U; ++q) { af[u][0][q] = An[(u * U + q) * 32]; af[u][1][q] = An[PLANE + (u * U + q) * 32]; }
               }
