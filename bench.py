@@ -46,7 +46,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_BF16X6_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_F16X3_EFFECTIVE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def parse():
@@ -189,24 +189,48 @@ def parity_block(conf, step, n_rays):
                       "layout / initialiser only (no executable reference for the grid, MLP, renderer arithmetic in this image)"}
 
 
-def fp32_engine_leg(step, steps=5):
-    """The same eager steps with every dense layer on the strict-fp32 engine (v_mfma_f32_32x32x2_f32, exact fp32 products,
-    csrc/mlp.hip): what the headline's emulated-fp32 arithmetic (f16 x 3) is to be read beside."""
+def fp32_engine_leg(step, steps=10):
+    """The same step with every dense layer on the strict-fp32 engine (v_mfma_f32_32x32x2_f32, exact fp32 products,
+    csrc/mlp.hip): what the headline's emulated-fp32 arithmetic (f16 x 3) is to be read beside.  Captured into ITS OWN HIP
+    graph (own packed weights, held by the graph, released with it) and replayed, like the headline: a kernel-bound number,
+    not the host's launch rate (round 5 timed an eager loop here)."""
     from ndjir_amd import mlp
     old = mlp.get_math()
     mlp.set_math(mlp.MATH_FP32)
+    graph = None
     try:
         for _ in range(2):
             loss = step.forward_backward()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        for _ in range(3):
+            step.forward_backward()
+        torch.cuda.synchronize()
+        eager_ms = 1e3 * (time.perf_counter() - t0) / 3
+        mode, err = "eager stream launches", None
+        try:
+            graph, loss = capture_step(step)
+            mode = "one captured HIP graph per step, replayed"
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
+            torch.cuda.synchronize()
+        fn = graph.replay if graph is not None else step.forward_backward
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         for _ in range(steps):
-            loss = step.forward_backward()
+            r = fn()
+            loss = loss if graph is not None else r
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        return {"ms_per_step": 1e3 * el / steps, "rays_per_s": step.B * step.R * steps / el, "steps": steps, "loss": float(loss),
-                "execution": "eager stream launches", "engine": "NDJIR_MLP_MATH=fp32: fp32-input MFMA, per-layer weight gradients"}
+        out = {"ms_per_step": 1e3 * el / steps, "rays_per_s": step.B * step.R * steps / el, "steps": steps, "loss": float(loss),
+               "execution": mode, "eager_ms_per_step": eager_ms,
+               "engine": "NDJIR_MLP_MATH=fp32: fp32-input MFMA (157 TFLOP/s peak), per-layer weight gradients"}
+        if err is not None:
+            out["graph_capture_error"] = err
+        return out
     finally:
+        del graph
         mlp.set_math(old)
 
 
@@ -236,9 +260,16 @@ def capture_step(step):
     # N > 1: other threads of the process (the collective library's watchdog) keep issuing runtime calls
     kw = dict(capture_error_mode="thread_local") if multi else {}
     err, loss = None, None
+    from ndjir_amd import mlp
     try:
-        with torch.cuda.graph(g, **kw):
-            loss = step.compute()
+        # the graph keeps every library buffer it was captured with (packed weights, workspaces) alive for as long as it
+        # lives itself: a later engine / tile-height switch or a cache clean-up cannot pull them from under a replay
+        with mlp.hold_buffers() as held:
+            with torch.cuda.graph(g, **kw):
+                loss = step.compute()
+        g.ndjir_held = held
+        g.ndjir_engine = mlp.engine_state()
+        g.ndjir_exchange_generation = step.exchange_generation()
     except Exception as e:
         err = f"{type(e).__name__}: {e}"
     if not _all_ranks_ok(step, err is None):
@@ -264,6 +295,10 @@ def replay_step(step, graph):
         print(f"[rank {step.rank}] pre {a:.1f} ms, graph {b:.1f} ms, exchange {c:.1f} ms", file=sys.stderr, flush=True)
         return
     step.pre_exchange()
+    if step.multi and getattr(graph, "ndjir_exchange_generation", 0) != step.exchange_generation():
+        # the sparse exchange re-created its lists (grown capacity): the captured re-arm names the old ones
+        raise RuntimeError("the captured step is stale: the sparse grid exchange re-created its state since the capture "
+                           "(ndjir_amd/distributed.py SparseRows); capture again")
     graph.replay()
     if step.multi and torch.distributed.get_backend() != "nccl":
         torch.cuda.current_stream().synchronize()   # gloo stages through the host: it must see the replayed step's results
@@ -427,6 +462,25 @@ def committed_pmc_traffic(kernels):
                 tot += n * (2.0 * v["FETCH_SIZE"][1] + v["WRITE_SIZE"][1]) * 1024.0
                 cnt += n
         return tot / cnt if cnt else None
+    except Exception:
+        return None
+
+
+def committed_kernel_only_us(symbols):
+    """Kernel-only time per launch of a symbol -- or, for several symbols (a library call), the sum of their time per step --
+    from the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/<round>_bench_kernel_summary.txt:
+    columns kernel, calls/step, ms/step, %, avg us).  None if the file or the symbol is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{PROFILE_ROUND}_bench_kernel_summary.txt")
+    try:
+        rows = {}
+        for line in open(path).read().splitlines()[2:]:
+            parts = line.rsplit(None, 4)
+            if len(parts) == 5:
+                rows[parts[0].strip()] = (float(parts[1]), float(parts[2]), float(parts[4]))
+        if len(symbols) == 1:
+            return rows[symbols[0]][2] if symbols[0] in rows else None
+        tot = sum(rows[k][1] for k in symbols if k in rows)
+        return 1e3 * tot if tot > 0 else None
     except Exception:
         return None
 
@@ -686,32 +740,89 @@ def main():
         table = kernel_table(kr, profile_steps, peak)
         ks = kernel_report(profile, by_symbol=True)
         sym_table = kernel_table(ks, profile_steps, peak)
-        ksym = max(sym_table, key=lambda k: sym_table[k]["ms_per_step"]) if sym_table else "none"
-        dom = ks.get(ksym, dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0, tbps=0.0, mbytes_per_launch=0.0))
-        dom_kind = next((rec[0] for rec in profile if rec[6] == ksym), "none")
-        kname = kernel_description(ksym, math)
-        pmc_syms = (["ndjir::k_wgrad_group_wide", "ndjir::k_wgrad_group", "ndjir::k_wgrad_group_reduce"] if "k_wgrad_group" in ksym
-                    else [ksym])
+        # `roofline`: the dominant SINGLE kernel symbol (what rocprofv3's --stats table puts first); a library CALL that
+        # spans several kernels (the grouped weight gradients: 7-8 launches of three symbols) is reported beside it as
+        # `roofline_call`, never instead of it
+        call_syms = {rec[6] for rec in profile if rec[7] > 1 or "k_wgrad" in rec[6]}
+        single = {k: v for k, v in sym_table.items() if k not in call_syms}
+        ksym = max(single, key=lambda k: single[k]["ms_per_step"]) if single else "none"
+        csym = max((k for k in sym_table if k in call_syms), key=lambda k: sym_table[k]["ms_per_step"], default=None)
         peak_note = ("dense 16-bit MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 3 partial products per algorithmic FLOP" if x3 else
                      "dense bf16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 6 partial products per algorithmic FLOP" if x6 else
                      "fp32-input MFMA peak (MI355X_MICROARCH.md)")
         dtype = ("f32 (f16x2-split MFMA products, f32 accumulate; error vs fp64 below an fp32 FMA chain's)" if x3 else
                  "f32 (bf16x3-split MFMA products, f32 accumulate)" if x6 else "f32")
-        # Two yardsticks for that kernel: the matrix pipe (algorithmic FLOPs against the executed mix's peak) and HBM (the
-        # (P, width) fp32 tensors the launch must read / write once -- stored activations, deltas, input, output -- against
-        # 8 TB/s).  The block's top-level numbers are those of the limit the kernel is closer to.
-        roof_mfma = {"achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
-                     "algorithmic_gflop_per_launch": dom["gflop_per_launch"]}
-        roof_hbm = {"achieved": dom.get("tbps", 0.0) * 1e3, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": dom.get("tbps", 0.0) * 1e3 / PEAK_HBM_GBPS,
-                    "algorithmic_mbytes_per_launch": dom.get("mbytes_per_launch", 0.0),
-                    "note": "algorithmic bytes = every (points, width) fp32 tensor of the launch counted once (ndjir_amd/mlp.py "
-                            "_launch_bytes): chain input, output, per hidden layer the stored activation it reads and the delta / "
-                            "activation it writes; packed weights (L2-resident) not counted"}
-        hbm_bound = roof_hbm["frac"] >= roof_mfma["frac"]
-        roof_top = ({"bound": "hbm", "achieved": roof_hbm["achieved"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": roof_hbm["frac"]}
-                    if hbm_bound else
-                    {"bound": "mfma", "achieved": roof_mfma["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": roof_mfma["frac"]})
+        ridge = peak * 1e12 / (PEAK_HBM_GBPS * 1e9)      # FLOP per byte at which the two roofs meet
+
+        def roof_block(sym, pmc_syms, kernel_only_syms):
+            """Roofline of one symbol (or call): both yardsticks from the live HIP events; `bound` by the launch's arithmetic
+            intensity against the ridge (not by whichever fraction happens to be larger); the same fraction again from the
+            kernel-only average duration of the committed rocprofv3 summary; HBM traffic from the committed PMC passes."""
+            dom = ks.get(sym, dict(tflops=0.0, avg_us=0.0, launches=0, gflop_per_launch=0.0, tbps=0.0, mbytes_per_launch=0.0))
+            kind = next((rec[0] for rec in profile if rec[6] == sym), "none")
+            mfma = {"achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
+                    "algorithmic_gflop_per_launch": dom["gflop_per_launch"]}
+            hbm = {"achieved": dom.get("tbps", 0.0) * 1e3, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                   "frac": dom.get("tbps", 0.0) * 1e3 / PEAK_HBM_GBPS,
+                   "algorithmic_mbytes_per_launch": dom.get("mbytes_per_launch", 0.0),
+                   "note": "algorithmic bytes = every (points, width) fp32 tensor of the launch counted once (ndjir_amd/mlp.py "
+                           "_launch_bytes): chain input, output, per hidden layer the stored activation it reads and the delta / "
+                           "activation it writes; packed weights (L2-resident) not counted"}
+            nbytes = dom.get("mbytes_per_launch", 0.0) * 1e6
+            ai = dom["gflop_per_launch"] * 1e9 / nbytes if nbytes > 0 else float("inf")
+            hbm_bound = ai < ridge
+            top = ({"bound": "hbm", "achieved": hbm["achieved"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm["frac"]}
+                   if hbm_bound else
+                   {"bound": "mfma", "achieved": mfma["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": mfma["frac"]})
+            ko = committed_kernel_only_us(kernel_only_syms)
+            ko_block = None
+            if ko:
+                sec = ko * 1e-6
+                # (a call: `ko` is the kernel time of ALL its launches per step -> price the call's bytes / FLOPs per step)
+                per = dom["launches"] / max(profile_steps, 1) if len(kernel_only_syms) > 1 else 1.0
+                ko_block = {"avg_launch_us": ko,
+                            "frac": (per * nbytes / sec / 1e9 / PEAK_HBM_GBPS) if hbm_bound
+                                    else (per * dom["gflop_per_launch"] / sec / 1e3 / peak),
+                            "source": f"profiles/{PROFILE_ROUND}_bench_kernel_summary.txt (rocprofv3 --kernel-trace --stats of this "
+                                      "command, kernel-only durations: no launch gaps of the host-bound eager pass)"}
+            traffic = sum(t for t in (committed_pmc_traffic(x) for x in pmc_syms) if t) or None
+            return {**top,
+                    "traffic": traffic,
+                    "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) of " + " + ".join(pmc_syms) + " from the "
+                                    f"committed rocprofv3 --pmc passes of this command, profiles/{PROFILE_ROUND}_pmc_hbm_bench.txt, "
+                                    "beside `hbm.algorithmic_mbytes_per_launch` (null: no committed pass lists the symbol)",
+                    "arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge,
+                    "bound_rule": "hbm if algorithmic FLOP / algorithmic byte of the launch < ridge (executed-mix matrix peak / HBM peak), else mfma",
+                    "kernel_only": ko_block,
+                    "mfma": mfma, "hbm": hbm,
+                    "kernel_symbol": sym, "kernel": kernel_description(sym, math), "peak_note": peak_note,
+                    # the same algorithmic fp32 FLOP/s against the fp32-input MFMA peak (what an fp32 GEMM engine could
+                    # reach at best on this chip) and against the bf16x6 engine's effective peak (round 1's yardstick)
+                    "frac_of_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
+                    "frac_of_bf16x6_peak": dom["tflops"] / PEAK_BF16X6_EFFECTIVE_TFLOPS,
+                    "launches_per_step": dom["launches"] / max(profile_steps, 1), "avg_launch_us": dom["avg_us"],
+                    "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
+                    "kernel_class": kind,
+                    "ms_per_step": sym_table.get(sym, {}).get("ms_per_step")}
+        method = (("HIP events on the launching stream around every launch of the same K steps issued "
+                   "eagerly right after the timed graph replays (events cannot be recorded inside a "
+                   "captured graph)") if exec_mode == "graph" else
+                  ("HIP events on the launching stream around every launch of two untimed steps before "
+                   "the timed region (N > 1)") if world > 1 else
+                  "HIP events on the launching stream around every launch in the timed region")
+        roofline = roof_block(ksym, [ksym], [ksym])
+        roofline["note"] = ("the single kernel symbol with the largest time per step (`kernels_by_symbol` lists every kernel of the "
+                            "engine with both yardsticks, `kernels` the same launches by class; `roofline_call` = the largest "
+                            "multi-kernel library call); an event interval spans the launch gap of the host-bound eager pass as well "
+                            "as the kernel, a few % more than rocprofv3's kernel-only average (`kernel_only`)")
+        roofline["method"] = method
+        roofline_call = None
+        if csym is not None:
+            wg = ["ndjir::k_wgrad_group_wide", "ndjir::k_wgrad_group", "ndjir::k_wgrad_group_reduce"]
+            roofline_call = roof_block(csym, wg if "k_wgrad_group" in csym else [csym], wg if "k_wgrad_group" in csym else [csym])
+            roofline_call["note"] = ("the library call with the largest time per step: one event interval over its 7-8 kernel launches "
+                                     "(`kernel_only.avg_launch_us` = the sum of its symbols' per-step kernel time)")
+            roofline_call["method"] = method
         out = {
             "metric": "rays/sec (fwd+bwd) at 512 rays x 128 samples",
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -723,31 +834,8 @@ def main():
                                    f"total_loss fwd+bwd to all parameter gradients",
                        "rays_per_gpu": R, "samples_per_ray": N, "parallelism": f"ray-sharded x{world}",
                        **({"total_rays": a.total_rays} if a.scaling == "strong" else {})},
-            "roofline": {**roof_top,
-                         "traffic": (sum(t for t in (committed_pmc_traffic(x) for x in pmc_syms) if t) or None),
-                         "traffic_note": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) of " + " + ".join(pmc_syms) + " from the "
-                                         f"committed rocprofv3 --pmc passes of this command, profiles/{PROFILE_ROUND}_pmc_hbm_bench.txt, "
-                                         "beside `hbm.algorithmic_mbytes_per_launch` (null: no committed pass lists the symbol)",
-                         "mfma": roof_mfma, "hbm": roof_hbm,
-                         "kernel_symbol": ksym, "kernel": kname, "peak_note": peak_note,
-                         # the same algorithmic fp32 FLOP/s against the fp32-input MFMA peak (what an fp32 GEMM engine could
-                         # reach at best on this chip) and against the bf16x6 engine's effective peak (round 1's yardstick)
-                         "frac_of_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
-                         "frac_of_bf16x6_peak": dom["tflops"] / PEAK_BF16X6_EFFECTIVE_TFLOPS,
-                         "launches_per_step": dom["launches"] / max(profile_steps, 1), "avg_launch_us": dom["avg_us"],
-                         "algorithmic_gflop_per_launch": dom["gflop_per_launch"],
-                         "kernel_class": dom_kind,
-                         "ms_per_step": table.get(dom_kind, {}).get("ms_per_step"),
-                         "note": "the kernel symbol with the largest time per step (`kernels_by_symbol` lists every kernel of the "
-                                 "engine with both yardsticks, `kernels` the same launches by class); an event interval spans the "
-                                 "launch gap of the host-bound eager pass as well as the kernel, ~5-7 % more than rocprofv3's "
-                                 f"kernel-only average in profiles/{PROFILE_ROUND}_bench_kernel_summary.txt",
-                         "method": ("HIP events on the launching stream around every launch of the same K steps issued "
-                                    "eagerly right after the timed graph replays (events cannot be recorded inside a "
-                                    "captured graph)") if exec_mode == "graph" else
-                                   ("HIP events on the launching stream around every launch of two untimed steps before "
-                                    "the timed region (N > 1)") if world > 1 else
-                                   "HIP events on the launching stream around every launch in the timed region"},
+            "roofline": roofline,
+            "roofline_call": roofline_call,
             "kernels": table,
             "kernels_by_symbol": sym_table,
             "step_roofline": {"achieved": step_tflops, "peak": peak, "unit": "TFLOP/s",

@@ -120,6 +120,10 @@ int ndjir_sparse_rows_header(void);
  * row stride of the communicated lists; `capacity`: that of this rank's own list) */
 int ndjir_sparse_rows_zero(const int* ids, const int* counts, int world, int capacity, const int* limit, int own_rank,
                            const int* own_ids, const int* own_count, float* grad_feature, int D, hipStream_t stream);
+/* dense fall-back of the re-arm: clears all `n` floats of the buffer iff *own_count > capacity, i.e. iff ndjir_grid_pack_rows had
+ * to drop cells its list had no room for (those hold gradient no list names; the step that dropped them is vetoed through
+ * ndjir_sparse_rows_overflow).  One int read otherwise. */
+int ndjir_sparse_rows_zero_if_dropped(const int* own_count, int capacity, float* grad_feature, long long n, hipStream_t stream);
 NDJIR_DECL_VOXEL_FAMILY(cosine_voxel_feature)
 NDJIR_DECL_VOXEL_FAMILY(lanczos_voxel_feature)
 

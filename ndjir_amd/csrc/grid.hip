@@ -811,6 +811,12 @@ __global__ void __launch_bounds__(256) k_pack_rows(long long P, const float* __r
           ids[slot] = (int)cell;
 #pragma unroll
           for (int c = 0; c < D4; ++c) rows[(long long)slot * D4 + c] = v[c];
+        } else {
+          // no room in the list: the cell is NOT listed, so its bit must not stay set -- k_rows_clear_bitmap clears the bits of
+          // listed cells only, and a cell whose bit survived would never be listed (or exchanged) again.  *count keeps counting
+          // (another lane of the same cell may add once more): any value above the capacity reads "rows were dropped" -- the
+          // overflow flag vetoes the step and k_rows_zero clears the whole buffer (sparse_rows.hip)
+          atomicAnd(bitmap + (cell >> 5), ~bit);
         }
       }
     }

@@ -70,6 +70,16 @@ __global__ void __launch_bounds__(256) k_rows_zero(const int* __restrict__ ids, 
   }
 }
 
+// Dense fall-back of the re-arm: when this rank's list overflowed its capacity (*own_count > capacity), k_pack_rows dropped
+// cells that hold gradient in `buf` and that no list names -- k_rows_zero cannot clear them.  The step that dropped them is
+// vetoed (its count exceeds every wire size), and the whole buffer is cleared here so that nothing stale is added to the next
+// step's sums.  In every other step the kernel reads one int and returns.
+__global__ void __launch_bounds__(256) k_rows_zero_if_dropped(const int* __restrict__ own_count, int capacity, float4* __restrict__ buf,
+                                                              long long n4) {
+  if (*own_count <= capacity) return;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n4; t += (long long)gridDim.x * 256) buf[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // clears the bitmap words of the listed cells (every set bit belongs to a listed cell)
 __global__ void __launch_bounds__(256) k_rows_clear_bitmap(const int* __restrict__ ids, const int* __restrict__ count, int capacity,
                                                            unsigned* __restrict__ bitmap) {
@@ -131,6 +141,13 @@ extern "C" int ndjir_sparse_rows_zero(const int* ids, const int* counts, int wor
                                  own_count, buf);
   else hipLaunchKernelGGL(k_rows_zero<2>, dim3(blocks), dim3(256), 0, stream, ids, counts, world, capacity, limit, own_rank, own_ids,
                           own_count, buf);
+  return ndjir_check_launch();
+}
+
+extern "C" int ndjir_sparse_rows_zero_if_dropped(const int* own_count, int capacity, float* buf, long long n, hipStream_t stream) {
+  if (n <= 0) return NDJIR_OK;
+  if (!own_count || !buf || capacity < 0 || (n & 3) != 0) return NDJIR_ERR_ARG;
+  hipLaunchKernelGGL(k_rows_zero_if_dropped, dim3(2048), dim3(256), 0, stream, own_count, capacity, reinterpret_cast<float4*>(buf), n / 4);
   return ndjir_check_launch();
 }
 

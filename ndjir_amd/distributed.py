@@ -75,9 +75,13 @@ def allreduce_sparse_rows(buf, cell_ids, group=None, return_remote=False):
 class SparseRows:
     """What the HIP-path exchange keeps for a buffer: every rank's packed wire -- header + cell ids, (world, limit + HDR) --,
     the number of rows per rank that were communicated (`limit`) and this rank's own full list -- together the rows
-    that hold gradient in the local dense buffer after the exchange.  `zero(buf)` clears exactly those.
-    The tensors are allocated once per buffer (worst-case capacity) and rewritten by every exchange, so a HIP graph
-    that captured `zero` keeps reading the current lists."""
+    that hold gradient in the local dense buffer after the exchange.  `zero(buf)` clears exactly those -- and the whole
+    buffer after an exchange whose own list overflowed its capacity (cells were dropped that no list names).
+    The tensors are rewritten in place by every exchange, so a HIP graph that captured `zero` keeps reading the current
+    lists -- UNTIL the state is re-created (list capacity grown at a look, `_state(grow=True)`; one rank: at once): the new
+    state has new tensors, `generation` counts the re-creations of a buffer's state, and a graph captured before one must
+    be re-captured (`Step.exchange_generation()`; the old tensors are kept alive by the new state, so a stale replay clears
+    stale rows instead of touching freed memory)."""
 
     def __init__(self, st, rank):
         self.st, self.rank = st, rank
@@ -89,6 +93,7 @@ class SparseRows:
         # cap = capacity of this rank's own list)
         lib.call("sparse_rows_zero", st["wire_all"], None, st["world"], st["cap"], st["limit_dev"], self.rank,
                  st["ids"], st["count"], buf, buf.shape[-1])
+        lib.call("sparse_rows_zero_if_dropped", st["count"], st["cap"], buf, buf.numel())
 
 
 from .registry import REG
@@ -131,9 +136,11 @@ def _state(buf, capacity, world, group=None, grow=False):
         if capacity > st["cap"] and world == 1:
             st = None                         # (falls through: a fresh, larger state)
         else:
-            if st["need_host"] != min(capacity, cells):      # (> cap: the lists are cut at cap, the overflow flag vetoes the step,
-                st["need_host"] = min(capacity, cells)       # and the next look grows every rank's state together)
-                st["need"].fill_(st["need_host"])
+            if st["need_host"] != min(capacity, cells):      # (> cap: the lists are cut at cap, the overflow flag vetoes the step
+                st["need_host"] = min(capacity, cells)       # -- a count above cap exceeds every wire size -- the re-arm clears
+                st["need"].fill_(st["need_host"])            # the whole buffer, and the next look grows every rank's state together)
+            if st["need_host"] > st["cap"]:
+                st["dropped_possible"] = True
             return st
     dev = buf.device
     if world > 1:
@@ -153,6 +160,16 @@ def _state(buf, capacity, world, group=None, grow=False):
               rows_all=torch.empty((world, capacity, D), dtype=torch.float32, device=dev))
     st["need"].fill_(capacity)
     st["need_host"] = capacity
+    old = _STATE.get(buf.data_ptr())
+    if old is not None and old["cells"] == cells:
+        # a re-creation (grown capacity): captured graphs may still name the old tensors -- keep them alive, count the change
+        st["generation"], st["previous"] = old.get("generation", 0) + 1, old
+        old.pop("previous", None)            # (one predecessor is enough: a graph older than that was stale already)
+        # rows the old lists could not hold were dropped by k_pack_rows and are named by nobody: start clean
+        if old.get("dropped_possible"):
+            buf.zero_()
+    else:
+        st["generation"] = 0
     st["counts_all"] = st["wire_all"][:world * HDR].view(world, HDR)[:, 0]      # (re-pointed at every exchange: the wire's headers)
     key = buf.data_ptr()
     _STATE[key] = st

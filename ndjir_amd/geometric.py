@@ -30,7 +30,7 @@ from torch.autograd import Function
 
 from . import lib
 from .grid_feature import _core
-from .mlp import _launch, _packed, _Strided, amax_slots, blocked_layout, chain_workspace, colsum, grad_target, pb, wgrad, wgrad_group
+from .mlp import _launch, _packed, _Strided, amax_slots, blocked_layout, chain_workspace, engine_state, require_engine, colsum, grad_target, pb, wgrad, wgrad_group
 
 
 
@@ -171,6 +171,7 @@ class GeometricMain(Function):
         lib.call("geo_normal", P, M, e, K0, g0, K0, len(gqs), gqs, n, Z, ldz, D, sdf)
 
         ctx.cfg = (M, skip_at, scale, min_, max_, L, tuple(x.shape), fam_names, bskip, split, ste, blk)
+        ctx.engine = engine_state()
         ctx.btgt = [grad_target(t) for t in b]       # accumulate-in-place gradient buffers of the biases (mlp.set_grad_buffer)
         ctx.A, ctx.s_store, ctx.s = A, s_store, s
         ctx.am, ctx.sm = am, sm
@@ -184,6 +185,7 @@ class GeometricMain(Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_sdf, g_feat, g_n, g_Z):
         M, skip_at, scale, min_, max_, L, xshape, fam_names, bskip, split, ste, blk = ctx.cfg
+        require_engine(ctx.engine, blk)
         fl = 8 if blk else 0
         saved = ctx.saved_tensors
         W = list(saved[:L])

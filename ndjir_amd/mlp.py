@@ -103,6 +103,7 @@ def _bias_region(device, floats):
         a = _BIAS_ARENA[device] = [t, 0]
     out = a[0][a[1]:a[1] + floats]
     a[1] += (floats + 3) // 4 * 4
+    _held(a[0])
     return out
 
 
@@ -313,6 +314,31 @@ def _launch_bytes(name, args):
 
 _MATH_READY = False
 
+# Buffers a captured HIP graph depends on.  The library's caches (packed weights per (storage, version, engine), launch
+# workspaces, the bias arena) may drop or replace an entry long after a graph has baked its address in -- the pack cache is
+# cleared past 512 entries, an engine switch (`set_math`) fills it with the other engine's copies, a workspace is replaced when
+# a later launch needs a larger one.  Inside `hold_buffers()` every such buffer handed out is also appended to the block's
+# list; whoever captures a graph keeps that list for as long as the graph (bench.py `capture_step` hangs it on the graph
+# object): the memory then outlives its cache entry and a replay reads what it was captured with (round 5's `redraw` NaN
+# after the fp32 leg was worked around by ordering the legs; this removes the cause).
+_HOLD = None
+
+
+@contextlib.contextmanager
+def hold_buffers():
+    global _HOLD
+    prev, _HOLD = _HOLD, []
+    try:
+        yield _HOLD
+    finally:
+        _HOLD = prev
+
+
+def _held(t):
+    if _HOLD is not None and t is not None:
+        _HOLD.append(t)
+    return t
+
 
 def _packed(W, transpose):
     """MFMA-fragment-order copy of W (or W^T).  Untracked weights: cached per (storage, version).  Tracked weights
@@ -324,7 +350,7 @@ def _packed(W, transpose):
         _init_math()
         _MATH_READY = True
     if _TRACK is not None and get_math() == MATH_F16X3 and W.is_cuda and W.dim() == 2 and W.stride(1) == 1:
-        return _tracked(W, bool(transpose))
+        return _held(_tracked(W, bool(transpose)))
     if not W.is_contiguous():
         W = W.contiguous()
     key = (W.data_ptr(), W._version, tuple(W.shape), bool(transpose), get_math())
@@ -335,7 +361,7 @@ def _packed(W, transpose):
     # every step (4 launches)
     owner = _StorageRef(W.untyped_storage())
     if hit is not None and hit[0].cdata == owner.cdata and not hit[0].expired():
-        return hit[1]
+        return _held(hit[1])
     K, N = W.shape
     n = lib.load().ndjir_mlp_packed_size(K, N, int(transpose))
     dst = torch.empty(n, device=W.device, dtype=torch.float32)
@@ -343,7 +369,7 @@ def _packed(W, transpose):
     if len(_PACK_CACHE) > 512:
         _PACK_CACHE.clear()
     _PACK_CACHE[key] = (owner, dst)
-    return dst
+    return _held(dst)
 
 
 # ---- tracked weights: persistent packed copies, refreshed by ONE launch after the optimizer's update -----------------------
@@ -630,6 +656,22 @@ def blocked_layout(P, hidden_widths, is_cuda=True):
     return all(64 <= -(-int(w) // 32) * 32 <= 256 for w in hidden_widths)
 
 
+def engine_state():
+    """(arithmetic engine, forced tile height) of the MLP library: process-wide settings (`set_math`, `set_tile_rows`) that
+    decide the layout of the hidden tensors a forward pass stores."""
+    return (get_math(), get_tile_rows())
+
+
+def require_engine(saved, blocked):
+    """Backward passes call this with the `engine_state()` their forward pass ran under: point-blocked hidden tensors are only
+    readable by the engine and tile height that wrote them, so a switch between the two passes (or under a live captured
+    graph) is refused here, by name, instead of surfacing as NDJIR_ERR_UNSUPPORTED from a kernel launch."""
+    if blocked and saved is not None and saved != engine_state():
+        raise RuntimeError(f"ndjir_amd.mlp: the MLP engine changed between forward and backward ((math, tile_rows) {saved} -> "
+                           f"{engine_state()}); set_math / set_tile_rows must not be called while a forward pass's graph "
+                           f"(autograd or captured HIP graph) is alive")
+
+
 def chain_workspace(device, bgrads):
     """Workspace of a chain launch that produces the bias gradients `bgrads` (list, None entries ok)."""
     total = sum(b.numel() for b in bgrads if b is not None)
@@ -696,9 +738,11 @@ def _workspace(device, need):
     key = (device, torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else (device, 0)
     ws = _WORKSPACE.get(key)
     if ws is None or ws.numel() < need:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return torch.empty(need, device=device, dtype=torch.float32)      # owned by the graph being captured, not kept
         ws = torch.empty(max(need, 1 << 22), device=device, dtype=torch.float32)
         _WORKSPACE[key] = ws
-    return ws
+    return _held(ws)
 
 
 def wgrad(A, B, out=None, accum=False, amax_a=None, amax_b=None):
@@ -764,6 +808,7 @@ def _wgrad_group_launch(jobs, extras=()):
         need = int(lib.load().ndjir_mlp_wgrad_group_workspace(0, None, None, None, None, 0, None, None, 0, None))
         if ws is None or ws.numel() < need:
             ws = _WORKSPACE_G[wkey] = torch.empty(max(need, 1 << 24), device=dev, dtype=torch.float32)
+        _held(ws)
         ex = list(extras)
         lib.call("mlp_wgrad_group", 0, None, [], None, [], [], None, None, [], 0, None, [], [], [], [], ws, 0, len(ex),
                  [_Strided(e[0]) for e in ex], [_Strided(e[1]) for e in ex], [e[2] for e in ex], [e[3] for e in ex], [e[4] for e in ex],
@@ -801,6 +846,7 @@ def _wgrad_group_launch(jobs, extras=()):
             ws = torch.empty(need, device=dev, dtype=torch.float32)      # owned by the graph being captured, not kept
         else:
             ws = _WORKSPACE_G[wkey] = torch.empty(max(need, 1 << 24), device=dev, dtype=torch.float32)
+    _held(ws)
     flops = 2.0 * sum(p * Ks[o] * Ns[o] for p, o in zip(Ps, oid))
     ex = list(extras)
     _launch("wgrad", flops, "mlp_wgrad_group", n, A, lda, B, ldb, Ps, ama, amb, oid, m, outs, ldo, Ks, Ns, acc, ws, int(WGRAD_GROUP_ITEMS),
@@ -969,6 +1015,7 @@ class FusedMLP(Function):
         if train:
             ctx.save_for_backward(x2, *hidden, *weights, am)
             ctx.blk = blk
+            ctx.engine = engine_state()
             ctx.cfg = (beta, skip_layer, skip_scale, L, tuple(x.shape))
             ctx.rb = (None if row_bias is None else tuple(row_bias.shape), int(row_bias_div))
             ctx.btgt = [grad_target(b) if torch.is_tensor(b) else None for b in biases]
@@ -986,6 +1033,7 @@ class FusedMLP(Function):
         saved = ctx.saved_tensors
         x2 = saved[0]
         blk = ctx.blk                        # hidden tensors (stored activations, deltas) are point-blocked (`PB`)
+        require_engine(ctx.engine, blk)
         A = [x2] + list(saved[1:L])          # A[j] = input activation of layer j
         W = list(saved[L:2 * L])
         am = saved[2 * L]                    # recorded maxima of A[j]
@@ -1181,12 +1229,14 @@ class MultiMLP(Function):
                        bool(lazy_pad))
             ctx.btgts = btgts
             ctx.blks = blks
+            ctx.engine = engine_state()
         return tuple(ys)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *gys):
         beta, net_cfg, xshape, pshapes, lazy_pad = ctx.cfg
+        require_engine(ctx.engine, any(ctx.blks))
         saved = ctx.saved_tensors
         x2 = saved[0]
         P, ld = x2.shape

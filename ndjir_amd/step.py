@@ -61,6 +61,8 @@ class Step:
         self.mask_sum = torch.zeros((), device=device)   # multi-GPU: all-reduced sum of the ray masks
         self._tail = torch.zeros(4, device=device)       # [mask sum, object-mask sum, 0, 0]: re-bound to the bucket's tail below
         self._rays_version, self._tail_version = 0, -1
+        self._local_counts = torch.zeros(4, device=device)   # this rank's [mask sum, object-mask sum, 0, 0] of the rays in place
+        self._local_version = -1
         self.vetoed_steps = torch.zeros(1, dtype=torch.int32, device=device)   # optimizer steps skipped because an exchange overflowed
         self.x_fg = None
         self.mlp_names = None
@@ -71,6 +73,7 @@ class Step:
                 buf = torch.zeros_like(p)
                 set_grad_buffer(p, buf)
                 self.grid_bufs[name] = buf
+        self._owned = dict(P.get_parameters())       # what `close` releases
         params = P.get_parameters(grad_only=True)
         self.mlp_names = [k for k in params if not k.endswith("feature/F")]
         self.mlp_params = [params[k] for k in self.mlp_names]
@@ -101,15 +104,27 @@ class Step:
                 self._grad_pairs.append((p, v))
 
     def close(self):
-        """End of the step's life: everything it registered under its tensors' addresses -- grid gradient buffers, exchange
-        state, packed weights -- leaves the registry (ndjir_amd/registry.py) together with the parameters themselves."""
+        """End of the step's life: what IT registered under its tensors' addresses -- grid gradient buffers and their
+        exchange state, the packed copies of its weights -- leaves the registry (ndjir_amd/registry.py).  The parameter scope
+        itself is process-global (nnabla's protocol): it is cleared, with everything else keyed by parameter addresses, only
+        if it still holds this step's parameters -- a scope re-populated since (another Step, `load_parameters` into fresh
+        tensors) is left alone."""
         from ndjir_amd.grid_feature import set_grad_buffer
-        for name, p in self.P.get_parameters().items():
+        params = self.P.get_parameters()
+        owned = getattr(self, "_owned", {})
+        for name, p in owned.items():
             if name in self.grid_bufs:
                 set_grad_buffer(p, None)
+        for buf in self.grid_bufs.values():
+            self.registry.exchange_state.pop(buf.data_ptr(), None)
+        for p in owned.values():
+            self.registry.pack_cache.pop(p.data_ptr(), None)
         self.grid_bufs = {}
         self.remote_rows = {}
-        self.P.clear_parameters()        # (-> Registry.clear())
+        self._grad_pairs = []
+        if owned and all(params.get(k) is p for k, p in owned.items()):
+            self.P.clear_parameters()    # (-> Registry.clear(): the scope is still this step's)
+        self._owned = {}
 
     def _create_parameters(self):
         """The parameters come into being when the networks first run (python/network.py's `PF.affine` scopes): one forward
@@ -195,13 +210,19 @@ class Step:
 
     def _local_mask_counts(self, out):
         """out[0] = sum of this rank's ray masks (the mask depends on the rays only), out[1] = of its object masks (the RGB
-        term divides by the GLOBAL object-mask count, python/loss.py:62), for the rays currently in place."""
-        from ndjir_amd.sampler import SamplePoints
-        with torch.no_grad():
-            _, _, mask = SamplePoints(self.conf).t_near_far(self.camloc, self.raydir)
-            out[0] = mask.sum()
-            out[1] = self.obj_mask.sum() if self.conf.train.mask_weight > 0.0 else 0.0
-            out[2:].zero_()
+        term divides by the GLOBAL object-mask count, python/loss.py:62), for the rays currently in place.  Computed once
+        per `set_rays` (`_local_counts`): an `exchange` that follows a `pre_exchange` over the same rays copies 16 bytes
+        instead of intersecting the rays again."""
+        if self._local_version != self._rays_version:
+            from ndjir_amd.sampler import SamplePoints
+            with torch.no_grad():
+                _, _, mask = SamplePoints(self.conf).t_near_far(self.camloc, self.raydir)
+                loc = self._local_counts
+                loc[0] = mask.sum()
+                loc[1] = self.obj_mask.sum() if self.conf.train.mask_weight > 0.0 else 0.0
+                loc[2:].zero_()
+            self._local_version = self._rays_version
+        out.copy_(self._local_counts)
 
     def compute(self, rearm=True):
         from ndjir_amd import mlp
@@ -279,6 +300,13 @@ class Step:
         self.remote_rows = allreduce_step_gradients(self._bucket, self.grid_bufs, queries)
         # a rank that listed more rows than fit on the wire: this step's grid gradient is incomplete -> veto the update
         self.exchange_overflow = [h.st["overflow"] for h in self.remote_rows.values() if isinstance(h, SparseRows)]
+
+    def exchange_generation(self):
+        """Sum of the re-creation counts of the sparse exchange states (ndjir_amd/distributed.py `SparseRows`): a HIP graph
+        that captured `compute` (whose re-arm reads the exchange's lists) is valid only as long as this number is the one it
+        was captured under -- a grown list capacity re-creates the state with new tensors."""
+        from ndjir_amd.distributed import SparseRows
+        return sum(h.st.get("generation", 0) for h in self.remote_rows.values() if isinstance(h, SparseRows))
 
     def exchange_report(self):
         """Host-side numbers of the sparse grid exchange since the step was built (one synchronisation: reports / tests /

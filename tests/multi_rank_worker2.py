@@ -3,6 +3,9 @@ usage (under torch.distributed.run): python tests/multi_rank_worker2.py <mode> <
   exchange   the HIP sparse grid-gradient exchange at the launcher's world size (4, 8: 3 / 7 remote lists): result against a
              dense all-reduce; then a FORCED overflow (the wire size cut below the lists) -> device flag, statistics, an
              incomplete sum; then the wire size grows at the next look (every CHECK_EVERY exchanges) and the sum is whole again
+  grow       the query points GROW between exchanges beyond the list capacity the first exchange sized: rows
+             are dropped -> every such step is flagged, the re-arm clears the WHOLE buffer, no bitmap bit survives, and after
+             the look that grows the state the sums are whole again
   veto       the same overflow under a training Step: the optimizer step is vetoed on the device and counted
   render     renderer.render_image(rank, world): tiles round-robin over the ranks, partial images summed at the end"""
 import os
@@ -67,6 +70,65 @@ def exchange(out, rank, world, dev):
     torch.save(rec, os.path.join(out, f"rank{rank}.pt"))
 
 
+def grow(out, rank, world, dev):
+    from ndjir_amd import distributed as D
+    D.CHECK_EVERY = 4
+    G, C = 64, 4
+    torch.manual_seed(200 + rank)
+    x1 = torch.rand(400 + 50 * rank, 3, device=dev) * 2 - 1
+    x2 = torch.rand(6000 + 500 * rank, 3, device=dev) * 2 - 1            # 8 x as many stencil cells as the first list can hold
+
+    def grads(x):
+        ids = D.voxel_cell_ids(x, [G, G, G]).unique()
+        own = torch.zeros(G, G, G, C, device=dev)
+        own.view(-1, C)[ids] = torch.randn(ids.numel(), C, device=dev)
+        dense = own.clone()
+        dist.all_reduce(dense)
+        return own, dense, int(ids.numel())
+    own1, dense1, n1 = grads(x1)
+    own2, dense2, n2 = grads(x2)
+    buf = torch.zeros(G, G, G, C, device=dev)
+    rec = dict(world=world, n1=n1, n2=n2)
+
+    def run(own, x):
+        buf.copy_(own)
+        h = D.exchange_grid_rows_hip(buf, "voxel", [x])
+        torch.cuda.synchronize()
+        return h
+    h = run(own1, x1)                                                      # exchange 1: sizes the lists for x1
+    st = h.st
+    rec["cap1"], rec["ok1"] = st["cap"], bool(torch.allclose(buf, dense1, atol=1e-5))
+    h.zero(buf)
+    rec["zero1"] = int((buf != 0).sum().item()) == 0
+    flags, zeros, counts = [], [], []
+    for i in range(2):                                                     # exchanges 2, 3: x2 does not fit -> rows dropped
+        st["overflow"].zero_()
+        h = run(own2, x2)
+        flags.append(int(st["overflow"].item()))
+        counts.append(int(st["count"].item()))
+        h.zero(buf)                                                        # ... the re-arm must still leave NOTHING behind
+        torch.cuda.synchronize()
+        zeros.append(int((buf != 0).sum().item()) == 0)
+    rec["drop_flags"], rec["drop_zero"], rec["drop_counts"] = flags, zeros, counts
+    rec["bitmap_clean"] = int((st["bitmap"] != 0).sum().item()) == 0      # no bit of a dropped cell survives
+    gen0 = st.get("generation", 0)
+    st["overflow"].zero_()
+    h = run(own2, x2)                                                      # exchange 4 = the look: every rank grows its state
+    rec["look_flag"] = int(st["overflow"].item())
+    st = h.st
+    rec["cap2"], rec["generation_moved"] = st["cap"], st.get("generation", 0) == gen0 + 1
+    h.zero(buf)
+    st["overflow"].zero_()
+    h = run(own2, x2)                                                      # exchange 5: grown lists (and wire): whole again
+    st = h.st
+    rec["ok5"], rec["flag5"] = bool(torch.allclose(buf, dense2, atol=1e-5)), int(st["overflow"].item())
+    h.zero(buf)
+    rec["zero5"] = int((buf != 0).sum().item()) == 0
+    h = run(own2, x2)
+    rec["ok6"] = bool(torch.allclose(buf, dense2, atol=1e-5)) and int(h.st["overflow"].item()) == 0
+    torch.save(rec, os.path.join(out, f"rank{rank}.pt"))
+
+
 def veto(out, rank, world, dev):
     import bench
     from ndjir_amd import config as cfg, distributed as D
@@ -110,7 +172,7 @@ def main():
     dist.init_process_group("gloo")
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    {"exchange": exchange, "veto": veto, "render": render}[mode](out, rank, world, dev)
+    {"exchange": exchange, "grow": grow, "veto": veto, "render": render}[mode](out, rank, world, dev)
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()

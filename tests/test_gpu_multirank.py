@@ -121,6 +121,27 @@ def test_sparse_exchange_overflow_and_limit_growth(gpu, world):
 
 
 @pytest.mark.timeout(1200)
+def test_sparse_exchange_query_points_outgrow_the_list_capacity(gpu):
+    """the query count grows between exchanges beyond the capacity the first exchange sized the lists
+    for (world 2).  `k_pack_rows` then drops cells -- it must not leave their bitmap bits set (they would never be listed
+    again), every such exchange must raise the overflow flag (the optimizer step is vetoed), the re-arm must clear the whole
+    buffer (the dropped cells hold gradient no list names), and after the look at which every rank re-creates its state with
+    the announced capacity the sums equal the dense all-reduce again."""
+    world = 2
+    with tempfile.TemporaryDirectory() as out:
+        _launch(world, "grow", out, 29581)
+        recs = [torch.load(os.path.join(out, f"rank{r}.pt")) for r in range(world)]
+    for r, rec in enumerate(recs):
+        assert rec["ok1"] and rec["zero1"], (r, rec)
+        assert rec["n2"] > rec["cap1"], (r, rec)                                     # the second point set really does not fit
+        assert rec["drop_flags"] == [1, 1] and rec["drop_zero"] == [True, True], (r, rec)
+        assert all(c > rec["cap1"] for c in rec["drop_counts"]), (r, rec)            # the SAME count twice: no cell went missing
+        assert rec["bitmap_clean"] and rec["look_flag"] == 1, (r, rec)
+        assert rec["cap2"] >= rec["n2"] and rec["generation_moved"], (r, rec)
+        assert rec["ok5"] and rec["flag5"] == 0 and rec["zero5"] and rec["ok6"], (r, rec)
+
+
+@pytest.mark.timeout(1200)
 def test_overflowing_exchange_vetoes_the_optimizer_step(gpu):
     """Step.optimizer_step under an overflowing sparse exchange (4 ranks): the update is skipped on the device (solver step
     counter and weights unchanged, python/train.py:141-146's skip), counted once per step, and reported."""
@@ -193,3 +214,20 @@ def test_bench_strong_scaling_config4_two_ranks(gpu):
                        "--no-cpu-baseline", "--no-extra-legs", "--train-steps", "0"], {"NDJIR_BENCH_SAME_DEVICE": "1"})
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["rays_per_gpu"] == 64
     assert out["ranks"]["world_size"] == 2 and "exchange" in out
+
+
+@pytest.mark.timeout(1800)
+def test_bench_two_ranks_on_two_devices_over_rccl(gpu):
+    """The day a multi-GPU node is there (task 8): `bench.py --gpus 2` with one rank per DEVICE over RCCL --
+    not the shared-GPU gloo harness every other two-rank test has to use.  Skipped on a one-GPU box (the pool's gpurun boxes);
+    `torch.cuda.device_count()` does not initialise the GPU, so the skip costs nothing."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL with N > 1 cannot run on this box")
+    out = _bench_json(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs", "--train-steps", "2"], {},
+                      timeout=1500)
+    assert out["n_gpus"] == 2 and out["ranks"]["world_size"] == 2 and out["ranks"]["backend"] == "nccl"
+    pci = [d["pci"] for d in out["ranks"]["devices"]]
+    assert len(set(pci)) == 2 and None not in pci, pci                     # two ranks on two distinct devices
+    assert "exchange" in out and "warning" not in out["exchange"], out.get("exchange")
+    assert out["execution"].startswith("one captured HIP graph"), (out["execution"], out.get("graph_capture_error"))
+    assert np.isfinite(out["loss"]) and out["value"] > 0 and np.isfinite(out["train_step"]["loss_after"])

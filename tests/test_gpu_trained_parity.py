@@ -1,0 +1,178 @@
+"""Parity of the emulated-fp32 (f16 x 3) MLP engine AFTER training has moved the parameters (every
+other step-parity test runs on the sphere-initialised geometric net, Glorot nets and an N(0, 1e-3) grid).
+
+The f16 split's accuracy depends on the range of the operands inside a scaling group -- per point row (activations, deltas),
+per 32-column weight block, per TENSOR for the weight gradients' operands (csrc/wgrad.hip) -- so it is measured here where
+training has put them: >= 200 iterations of the reference's training step (python/train.py:124-148: new pixels from the device
+data feed, new random tensors, two Adam solvers at the post-warm-up learning rate) on a synthetic multi-view scene with
+config/default.yaml at a 64^3 grid, 512 rays.  Then ONE forward + backward of total_loss (python/loss.py:27-192) on the first
+32 rays, 128-point-tile kernels forced (the kernels the bench times), compared
+  (i)  with the CPU oracle (oracle/graph.py) in fp32 and fp64 on the trained parameters and the product's sample points:
+       loss 1e-4 relative, pixels 1e-4 absolute, every parameter gradient norm-wise at GRAD_RTOL (the parameters that need the
+       "3 x the fp32 oracle's own distance to fp64" fall-through are PRINTED);
+  (ii) element-wise with the strict-fp32 engine (v_mfma_f32_32x32x2_f32) on every MLP weight gradient:
+       max |d| / (|g| + 1e-3 max |g|) of each engine against the fp64 oracle -- the split engine may not be further from fp64
+       than the strict engine by more than a small factor, entry by entry, small entries included.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.parity_utils import rel_err, run_oracle_step
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-4
+PIXEL_TOL = 1e-4
+GRAD_RTOL = 2e-3
+ITERATIONS = 200
+
+
+def _smooth_scene(M, H, W, seed=11):
+    """Cameras of ndjir_amd.synthetic.make_scene with SMOOTH images (low-frequency colour fields instead of white noise), so
+    that the optimisation has something to fit and the weights move coherently."""
+    from ndjir_amd.synthetic import make_scene
+    images, masks, Ks, poses = make_scene(M, H, W, seed=seed)
+    yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
+    for m in range(M):
+        ph = 0.7 * m
+        images[m, :, :, 0] = 0.5 + 0.4 * np.sin(5.0 * xx + ph) * np.cos(3.0 * yy)
+        images[m, :, :, 1] = 0.5 + 0.4 * np.cos(4.0 * yy - ph)
+        images[m, :, :, 2] = 0.3 + 0.5 * xx * yy
+    return images.astype(np.float32), masks, Ks, poses
+
+
+def _elementwise(a, ref):
+    """max |a - ref| / (|ref| + 1e-3 max |ref|): an entry 1000 x below the tensor's largest is still held to a relative bound."""
+    a, ref = a.detach().cpu().double(), ref.detach().cpu().double()
+    floor = 1e-3 * float(ref.abs().max())
+    if floor == 0.0:
+        return float((a - ref).abs().max())
+    return float(((a - ref).abs() / (ref.abs() + floor)).max())
+
+
+@pytest.fixture
+def trained(gpu):
+    """(conf, step) after ITERATIONS training iterations; the step is closed afterwards."""
+    import copy
+    from ndjir_amd import config as cfg, mlp
+    from ndjir_amd.dataset import IDRRaySource
+    from ndjir_amd.step import Step
+    dev = gpu
+    conf = cfg.load("default", ["geometric_network.voxel.grid_size=64"])
+    R = 512
+    step = Step(conf, R, dev, 0, 1)
+    init = {k: v.detach().clone() for k, v in step.P.get_parameters().items()}
+    step.enable_training()
+    c2 = copy.deepcopy(conf)
+    c2.train.n_rays = R
+    src = IDRRaySource(*_smooth_scene(8, 128, 128), c2, rng=np.random.RandomState(313), device=dev)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    losses = []
+    for it in range(ITERATIONS):
+        color, _mask, raydir, camloc = src.next_batch(1)
+        step.set_rays(camloc, raydir, color)
+        step.redraw_rand(gen)
+        loss = step.train_step()
+        if it % 20 == 0 or it == ITERATIONS - 1:
+            losses.append(float(loss))
+    torch.cuda.synchronize()
+    yield conf, step, init, losses
+    mlp.track_weights(False)
+    step.close()
+
+
+@pytest.mark.timeout(2400)
+def test_split_engine_on_trained_weights(trained, monkeypatch):
+    from ndjir_amd import loss as loss_mod, mlp
+    from ndjir_amd.loss import total_loss
+    conf, step, init, losses = trained
+    params = step.P.get_parameters()
+    print(f"\ntraining: loss {losses[0]:.4f} -> {losses[-1]:.4f} over {ITERATIONS} iterations ({[round(x, 4) for x in losses]})")
+    assert all(np.isfinite(losses)), losses
+    assert int(step.solvers.solver_weight.step_count()) >= ITERATIONS - 2, "the guard vetoed training steps"
+    # the parameters are not where they started
+    moved = {k: rel_err(v, init[k]) for k, v in params.items() if v.requires_grad and v.numel() > 1}
+    gm = [moved[k] for k in moved if k.startswith("geometric-network/affine")]
+    print("moved (relative to the initial value): geometric layers", [f"{x:.2f}" for x in gm],
+          "| gain", float(params["geometric-network/gain"]) if "geometric-network/gain" in params else None)
+    assert min(gm) > 0.02, moved
+
+    n_rays = 32
+    sl = slice(0, n_rays)
+    rand = {k: v[:, sl].contiguous() for k, v in step.rand.items()}
+    raydir, color = step.raydir[:, sl].contiguous(), step.color_gt[:, sl].contiguous()
+    names = step.mlp_names
+    grid_names = list(step.grid_bufs)
+
+    def product_pass(samples=None):
+        if samples is not None:
+            monkeypatch.setattr(loss_mod, "sample_points", lambda *a, **k: tuple(t.detach().clone() for t in samples))
+        for buf in step.grid_bufs.values():
+            buf.zero_()
+        out = total_loss(step.camloc, raydir, color, None, step.car, conf, rand)
+        grads = torch.autograd.grad(out["loss"], step.mlp_params + step.grid_params, allow_unused=True)[:len(step.mlp_params)]
+        torch.cuda.synchronize()
+        res = dict(loss=float(out["loss"]), color=out["render"]["color_pixel"].detach().cpu(),
+                   grads={k: (g.detach().cpu() if g is not None else None) for k, g in zip(names, grads)},
+                   grid={k: step.grid_bufs[k].detach().cpu().clone() for k in grid_names},
+                   samples=tuple(out["samples"][k].detach() for k in ("x_fg", "t_fg", "x_bg", "t_bg", "mask")))
+        monkeypatch.undo()
+        return res
+
+    old_tile, old_math = mlp.get_tile_rows(), mlp.get_math()
+    mlp.set_tile_rows(128)
+    try:
+        assert mlp.get_math() == mlp.MATH_F16X3
+        x3 = product_pass()
+        mlp.set_math(mlp.MATH_FP32)
+        f32 = product_pass(samples=x3["samples"])
+    finally:
+        mlp.set_math(old_math)
+        mlp.set_tile_rows(old_tile)
+
+    params_cpu = {k: v.detach().cpu() for k, v in params.items()}
+    inputs = dict(camloc=step.camloc.cpu(), raydir=raydir.cpu(), color_gt=color.cpu(),
+                  rand={k: v.cpu() for k, v in rand.items()}, cos_anneal=step.car.cpu())
+    smp = tuple(t.cpu() for t in x3["samples"])
+    ref32 = run_oracle_step(conf, params_cpu, inputs, samples=smp)
+    ref64 = run_oracle_step(conf, params_cpu, inputs, dtype=torch.float64, samples=smp)
+
+    # ---- (i) the split engine against the oracle on the trained parameters ----
+    l0, l1 = x3["loss"], float(ref32["loss"])
+    print(f"loss: f16x3 {l0:.7f}  fp32 engine {f32['loss']:.7f}  oracle fp32 {l1:.7f}  oracle fp64 {float(ref64['loss']):.7f}")
+    assert abs(l0 - l1) <= LOSS_RTOL * abs(l1), (l0, l1)
+    assert abs(l0 - float(ref64["loss"])) <= LOSS_RTOL * abs(float(ref64["loss"]))
+    dc = float((x3["color"] - ref32["color_pixel"]).abs().max())
+    print(f"pixels: max |f16x3 - oracle fp32| = {dc:.2e}")
+    assert dc <= PIXEL_TOL, dc
+    fall_through = []
+    for k, g in ref32["grads"].items():
+        gp = x3["grads"].get(k, x3["grid"].get(k))
+        if g is None or gp is None:
+            continue
+        e = rel_err(gp, g)
+        if e >= GRAD_RTOL:
+            e64, o64 = rel_err(gp, ref64["grads"][k]), rel_err(g, ref64["grads"][k])
+            fall_through.append((k, e, e64, o64))
+            assert e64 <= 3 * o64, (k, e, e64, o64)
+    print("parameters that took the fp64 fall-through (norm-wise error vs fp32 oracle, vs fp64, fp32 oracle's own vs fp64):",
+          [(k, f"{e:.1e}", f"{e64:.1e}", f"{o64:.1e}") for k, e, e64, o64 in fall_through] or "none")
+
+    # ---- (ii) element-wise, every MLP weight gradient: split engine vs strict-fp32 engine, both against fp64 ----
+    worst = []
+    for k in names:
+        g64 = ref64["grads"].get(k)
+        a, b = x3["grads"].get(k), f32["grads"].get(k)
+        if g64 is None or a is None or b is None or g64.numel() < 2:
+            continue
+        e3, e32, d = _elementwise(a, g64), _elementwise(b, g64), _elementwise(a, b)
+        worst.append((e3, e32, d, k))
+    worst.sort(reverse=True)
+    print("element-wise max |d| / (|g| + 1e-3 max|g|) vs the fp64 oracle  [f16x3, strict fp32, f16x3 vs strict]:")
+    for e3, e32, d, k in worst[:12]:
+        print(f"  {k:60s} {e3:.2e} {e32:.2e} {d:.2e}")
+    for e3, e32, d, k in worst:
+        # entry by entry the split engine is no further from fp64 than 3 x the strict engine (+ an absolute floor of 2e-4 of
+        # the scaled entry: both engines' errors are round-off sums of random sign)
+        assert e3 <= 3.0 * e32 + 2e-4, (k, e3, e32)
