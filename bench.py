@@ -526,6 +526,12 @@ def kernel_description(sym, math):
                 "work table in device memory, P split over workgroups) + the split reduction k_wgrad_group_reduce (3 launches); "
                 "the event interval spans the call's 7-8 launches, rocprofv3's kernel-only sum of the same is ~12 % less")
     what = {"<0": "forward", "<1": "backward", "<2": "tangent"}.get(sym[sym.find("<"):sym.find("<") + 2], "")
+    if "k_chainp" in sym:
+        return (f"fused MLP {what} chain of a training pass on 128-point tiles, the tile's two 64-point halves software-pipelined "
+                "(csrc/mlp3p.hip: the k-loop MFMAs of one half carry the epilogue instructions of the other, one MFMA then one "
+                "slice of an epilogue item; template argument: mode): fp32 operands scaled by powers of two and split into 2 f16 "
+                "planes (lo unscaled), 3 v_mfma_f32_32x32x16_f16 partial products per fp32 product in ONE fp32 accumulator"
+                + ("; k_chainp_nets: up to three nets of one MultiMLP in one launch" if "k_chainp_nets" in sym else ""))
     if "k_chainw" in sym:
         return (f"fused MLP {what} chain on 128-point tiles, epilogue in the accumulator registers (csrc/mlp3w.hip; template "
                 "arguments: mode, row blocks per wave -- 4: nets up to 256 wide, 2: up to 128 wide --, waves per workgroup): fp32 "

@@ -528,6 +528,13 @@ int ndjir_mlp_get_math(void);
  * forward result does not depend on the tile height. */
 int ndjir_mlp_set_tile_rows(int rows);
 int ndjir_mlp_get_tile_rows(void);
+/* Which TRAINING-pass chain launches (every hidden layer stores its point-blocked side tensor) of nets wider than 128 columns
+ * run on the software-pipelined 128-point-tile kernel (csrc/mlp3p.hip): bit 0 forward, bit 1 backward, bit 2 tangent; 0 = none.
+ * That kernel keeps ONE fp32 accumulator per block: its results agree with the other f16x3 kernels to round-off (2e-6), not bit
+ * for bit -- passes without side tensors (the sampler's SDF rounds, the SDF volume, render_image) never run on it.  NDJIR_CHAINP
+ * sets the initial value. */
+int ndjir_mlp_set_chain_pipeline(int mask);
+int ndjir_mlp_get_chain_pipeline(void);
 long long ndjir_mlp_packed_size(int K, int N, int transpose);
 int ndjir_mlp_pack(const float* W, float* dst, int K, int N, int transpose, hipStream_t stream);
 /* f16x3 arithmetic: W (K, N) with row stride ldw (a column slice of a wider matrix packs without a copy) */

@@ -82,6 +82,16 @@ extern "C" int ndjir_mlp_set_tile_rows(int rows) {
 }
 extern "C" int ndjir_mlp_get_tile_rows(void) { return tile_rows_setting(); }
 
+// Which training-pass chain launches of nets wider than 128 columns run on the software-pipelined kernel (csrc/mlp3p.hip):
+// bit 0 forward, bit 1 backward, bit 2 tangent.  Results agree with the other kernels to round-off (one fp32 accumulator per
+// block instead of two).  Process-wide, like the engine and tile settings: not to be changed under a live captured graph.
+extern "C" int ndjir_mlp_set_chain_pipeline(int mask) {
+  if (mask < 0 || mask > 7) return NDJIR_ERR_ARG;
+  chain_pipeline(mask);
+  return NDJIR_OK;
+}
+extern "C" int ndjir_mlp_get_chain_pipeline(void) { return chain_pipeline(-1); }
+
 static int chain_impl(int bwd, long long P, const float* X, int ldx, int K0, int L,
                                const float* const* Wp, const float* const* bias, const int* Ks, const int* Ns,
                                const float* const* side_in, float* const* side_out, const int* ld_side,

@@ -106,6 +106,8 @@ int launch_chain3(const ChainArgs& a, int mode, hipStream_t stream);
 int launch_chainw(const ChainArgs& a, int mode, hipStream_t stream);
 // n <= MAX_GROUP_NETS nets of one mode on the same number of points; NDJIR_ERR_UNSUPPORTED = launch them one by one
 int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stream);
+// the software-pipelined 128-point-tile kernel (mlp3p.hip): mode mask of the launches it takes (set < 0: query)
+int chain_pipeline(int set);
 constexpr int CHAIN_MAX_GRID_BG = 512;   // workgroups of a chain launch that produces bias gradients
 inline long long chain_workspace(int bg_total) { return (long long)CHAIN_MAX_GRID_BG * ((bg_total + 3) & ~3); }      // (rows padded to 16 bytes)
 long long wgrad_workspace(int K, int N, long long P);

@@ -20,8 +20,18 @@
 // by one barrier.  Per layer and tile a weight fragment now feeds 2 row blocks instead of 4: the L2 -> CU weight stream
 // doubles (42 B / clk / CU at the matrix pipe's rate against the 52 measured by tools/ubench/wstream.hip).
 //
-// Arithmetic: every product, accumulation order, scale and forward expression is mlp3w.hip's (mlp3_util.h) -- a point's result is
-// bit-identical whichever of the three f16x3 kernels evaluates it (tests/test_gpu_mlp_wide.py).  The output layer (and a
+// Arithmetic: the same three f16 partial products per fp32 product under the same power-of-two scales (per point row, per
+// 32-column weight block) and the same forward expressions (mlp3_util.h) as mlp3.hip / mlp3w.hip -- but ONE fp32 accumulator per
+// 32 x 32 block instead of two (the representation csrc/wgrad.hip uses since round 5): lo = f16(x s - hi) is kept UNSCALED in
+// the planes, the packed weights' lo plane (stored x 2^11) is brought back by one v_pk_mul_f16 per fragment register, and
+// hi hi' + hi lo' + lo hi' accumulate together; the matrix cores keep f16 denormals (tools/ubench/mfma_denorm.hip), so x s is
+// held to 2^-22 relative or 2^-25 absolute with max |x s| in [2^14, 2^15).  That frees 64 of the wave's registers -- what lets
+// the two roles of a phase live side by side without scratch (a scratch reload waits on `vmcnt(0)`, i.e. on every side store
+// in flight: the first build of this kernel, with two accumulators, was bit-identical to mlp3w.hip and ran 4 x SLOWER for its
+// 2 800 spilled registers) -- and the epilogue's 64 accumulator sums.  Results agree with the other two kernels to round-off
+// (2e-6 relative), not bit for bit: this kernel therefore only takes the launches of a TRAINING pass (every hidden layer
+// stores its side tensor); forward passes without side tensors -- the sampler's SDF rounds, whose values of different
+// launches are merged bit for bit, the SDF volume, render_image -- stay on mlp3.hip / mlp3w.hip.  The output layer (and a
 // narrow split-K output layer) runs un-pipelined after the last hidden epilogue has drained.
 // Launched by launch_chainw_group (mlp3w.hip) for the nets it gives 4 row blocks per wave (hidden layers wider than 128
 // columns), point-blocked or row-major side tensors; NDJIR_CHAINP=0 keeps mlp3w.hip's kernel.
@@ -71,6 +81,53 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// pointers out of the argument blocks: forced into scalar registers (in the group kernel the compiler cannot always prove an
+// argument block's address uniform -- `pin` alone then fails with "illegal VGPR to SGPR copy")
+template <class T>
+__device__ __forceinline__ gptr<T> upin(T* p) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (gptr<T>)reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+// An empty asm statement makes a value opaque at this point of the program: it is ordered with the slot boundaries
+// (`sched_barrier`, themselves ordered side effects), so the arithmetic that consumes the value cannot be hoisted out of its slot
+// when the block is linearised -- a pure instruction has no other tie to the place it was written (seen: the fused multiply-adds
+// of all sixteen values of a block issued ahead of the first slot, 40 more live registers).
+__device__ __forceinline__ float here(float v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// single operations that must not be contracted into fused multiply-adds (the forward expressions of mlp3_util.h, taken apart
+// so that their pieces can be placed between the MFMAs of a slot)
+__device__ __forceinline__ float add_nc(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float mul_nc(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float sub_nc(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
+// the two-way split with an UNSCALED low part:  x s = hi + lo,  lo = f16(x s - hi)  (x s - hi is exact in fp32)
+__device__ __forceinline__ void split4u(f32x4 v, float s, f16x4& ph, f16x4& pl) {
+#pragma clang fp contract(off)
+  const f32x4 xs = v * s;
+  ph = __builtin_convertvector(xs, f16x4);
+  pl = __builtin_convertvector(xs - __builtin_convertvector(ph, f32x4), f16x4);
+}
+__device__ __forceinline__ void split1u(float v, float s, _Float16& ph, _Float16& pl) {
+#pragma clang fp contract(off)
+  const float xs = v * s;
+  ph = (_Float16)xs;
+  pl = (_Float16)(xs - (float)ph);
+}
+
 template <int MODE, class NETS>
 __device__ __forceinline__ void chainp_body(const NETS nets) {
   constexpr bool BWD = (MODE == 1);
@@ -78,6 +135,8 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
   __shared__ unsigned s_rmax[TM];       // per row: largest finite |output| of the layer in its epilogue (bit pattern)
   __shared__ unsigned s_xmax[2][TM];    // per row: largest finite |x| of the chain input tile (ping-pong by tile)
   __shared__ float s_ainv[TM];          // per row: 1 / scale of the planes' current content
+  __shared__ __attribute__((aligned(16))) float s_bias[2][256];   // forward: bias * beta log2(e) of the layer in its epilogue (ping-pong
+                                        // by layer; zero beyond the layer's width) -- 16 registers per lane the allocator does not have
   const int n_nets = nets.n();
   const auto& a0 = nets.get(0);
   const int PLANE = a0.lds_split;       // 16-byte units per plane
@@ -95,14 +154,14 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
   };
   auto put4 = [&](int k, int m, f32x4 v, float s) {
     f16x4 ph, pl;
-    split4(v, s, ph, pl);
+    split4u(v, s, ph, pl);
     char* p = actb + ((size_t)((k >> 3) * TMP + m) * 16 + (k & 7) * 2);
     *reinterpret_cast<f16x4*>(p) = ph;
     *reinterpret_cast<f16x4*>(p + (size_t)PLANE * 16) = pl;
   };
   auto put1 = [&](int k, int m, float v, float s) {
     _Float16 ph, pl;
-    split1(v, s, ph, pl);
+    split1u(v, s, ph, pl);
     char* p = actb + ((size_t)((k >> 3) * TMP + m) * 16 + (k & 7) * 2);
     *reinterpret_cast<_Float16*>(p) = ph;
     *reinterpret_cast<_Float16*>(p + (size_t)PLANE * 16) = pl;
@@ -212,8 +271,9 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
     __syncthreads();
     if (tile == blockIdx.x) stamp(MAX_CHAIN_LAYERS - 1, 1);
 
-    // Accumulator pairs of the wave's four 32 x 32 blocks: H0 = blocks 0, 1; H1 = blocks 2, 3 (static indices only).
-    f32x16 acc0[4], acc1[4];
+    // Accumulators of the wave's four 32 x 32 blocks: H0 = blocks 0, 1; H1 = blocks 2, 3 (static indices only).
+    f32x16 acc0[4];
+    const _Float16 LOU = (_Float16)LO_INV;          // 2^-11: the packed weights' lo plane back to its unscaled value
 
     // =====================================================================================================================
     // One phase:  K(layer liK, half HK)  ||  E(layer liE, half 1 - HK).   doK / doE: uniform.
@@ -226,64 +286,56 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
       // rows of the K half: their maxima were consumed by the previous phase's split -- re-arm them for the next phase's epilogue
       if (tid >= TM && tid < TM + HALF) s_rmax[HK * HALF + (tid - TM)] = 0u;
 
+      // forward: the bias table of layer liK, read by its two epilogues in the next two phases
+      if (MODE == 0 && HK == 0 && doK && tid < 256) {
+        const auto& lw = a.layers[liK];
+        s_bias[liK & 1][tid] = (lw.bias && tid < lw.N) ? lw.bias[tid] * (beta * LOG2E) : 0.f;
+      }
       // ---------------- K role: set-up ----------------
       const auto& lyK = a.layers[doK ? liK : 0];
       const int KS = doK ? (lyK.Kp + 15) >> 4 : 0;
       const bool activeK = doK && nb < (lyK.Np >> 5);
-      const gptr<const f16x8> p_wp = (gptr<const f16x8>)pin(lyK.Wp);
+      const gptr<const f16x8> p_wp = (gptr<const f16x8>)upin(lyK.Wp);
       f16x8 b[3][2];            // weight fragments [slot][plane], three k-steps ahead
       f16x8 af[2][2][2];        // activation fragments [buffer][plane][row block of the half]
       gptr<const f16x8> Bp = nullptr;
       const f16x8* A0 = nullptr;
-      if (activeK) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) { acc0[KB + q] = f32x16{0}; acc1[KB + q] = f32x16{0}; }
-        const int lane_k = fresh_lane();
-        Bp = p_wp + ((long long)nb * KS) * 2 * 64 + lane_k;
-        A0 = act + (lane_k >> 5) * TMP + KB * 32 + (lane_k & 31);
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-#pragma unroll
-          for (int p = 0; p < 2; ++p) b[s][p] = Bp[(long long)((s < KS ? s : 0) * 2 + p) * 64];
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) { af[0][0][q] = A0[q * 32]; af[0][1][q] = A0[PLANE + q * 32]; }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // one k-step of the half: slot S of the weight ring, buffer C of the activation fragments; the per-block MFMA order is
-      // mlp3w.hip's (w_hi x_lo -> acc1, w_hi x_hi -> acc0, w_lo x_hi -> acc1)
-      auto kstep = [&](auto stag, auto ctag, const int ks) {
+      // One k-step of the half: slot S of the weight ring, buffer C of the activation fragments; per block the MFMA order is
+      // w_hi x_lo, w_hi x_hi, w_lo x_hi into the block's one accumulator.  No branches: the prefetches past the last
+      // k-step re-read it (clamped indices) -- a branch would end the basic block, and with it the scheduling region in
+      // which the epilogue item's vector instructions are placed between these MFMAs.
+      auto kstep = [&](auto stag, auto ctag, const int ks, auto first_tag) {
         constexpr int S = decltype(stag)::value, C = decltype(ctag)::value;
-        const f16x8* An = A0 + 2 * (ks + 1) * TMP;
-        if (ks + 1 < KS) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const int ksn = ks + 1 < KS ? ks + 1 : KS - 1;
+        const f16x8* An = A0 + 2 * ksn * TMP;
 #pragma unroll
-          for (int q = 0; q < 2; ++q) { af[C ^ 1][0][q] = An[q * 32]; af[C ^ 1][1][q] = An[PLANE + q * 32]; }
-        }
+        for (int q = 0; q < 2; ++q) { af[C ^ 1][0][q] = An[q * 32]; af[C ^ 1][1][q] = An[PLANE + q * 32]; }
+        const f32x16 zero = f32x16{0};
 #pragma unroll
-        for (int q = 0; q < 2; ++q) acc1[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][1][q], acc1[KB + q], 0, 0, 0);
+        for (int q = 0; q < 2; ++q) acc0[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][1][q], FIRST ? zero : acc0[KB + q], 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 2; ++q) acc0[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][0][q], acc0[KB + q], 0, 0, 0);
+        const f16x8 blo = b[S][1] * LOU;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) acc1[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][1], af[C][0][q], acc1[KB + q], 0, 0, 0);
-        if (ks + 3 < KS) {
+        for (int q = 0; q < 2; ++q) acc0[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo, af[C][0][q], acc0[KB + q], 0, 0, 0);
+        const int ksw = ks + 3 < KS ? ks + 3 : KS - 1;
 #pragma unroll
-          for (int p = 0; p < 2; ++p) b[S][p] = Bp[(long long)((ks + 3) * 2 + p) * 64];
-        }
+        for (int p = 0; p < 2; ++p) b[S][p] = Bp[(long long)(ksw * 2 + p) * 64];
       };
 
       // ---------------- E role: set-up ----------------
       const auto& lyE = a.layers[doE ? liE : 0];
       const int NBE = lyE.Np >> 5;
       const bool activeE = doE && nb < NBE;
-      const gptr<const float> p_winv = pin(lyE.Wp + (long long)((lyE.Kp + 15) >> 4) * 16 * lyE.Np);
-      const gptr<const float> p_bias = pin(lyE.bias);
-      const gptr<const float> p_rowbias = pin((MODE == 0 && liE == 0) ? a.row_bias : nullptr);
+      const gptr<const float> p_winv = upin(lyE.Wp + (long long)((lyE.Kp + 15) >> 4) * 16 * lyE.Np);
+      const gptr<const float> p_bias = upin(lyE.bias);
+      const gptr<const float> p_rowbias = upin((MODE == 0 && liE == 0) ? a.row_bias : nullptr);
       const int rb_div = pin(a.row_bias_div > 0 ? a.row_bias_div : 1);
-      const gptr<const float> p_side_in = pin(lyE.side_in);
-      const gptr<const float> p_side_ex = pin(MODE == 1 ? lyE.side_add : lyE.side_in2);
-      const gptr<float> p_side_out = pin(lyE.side_out);
-      const gptr<float> p_side_out2 = pin(lyE.side_out2);
+      const gptr<const float> p_side_in = upin(lyE.side_in);
+      const gptr<const float> p_side_ex = upin(MODE == 1 ? lyE.side_add : lyE.side_in2);
+      const gptr<float> p_side_out = upin(lyE.side_out);
+      const gptr<float> p_side_out2 = upin(lyE.side_out2);
       float* const p_bgrad = (MODE != 0 && lyE.bgrad) ? bsum + pin(lyE.bg_off) : nullptr;
       const int l_N = pin(lyE.N);
       const int l_ld = pin(lyE.ld_side);
@@ -302,22 +354,26 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
         atomicMax(&s_rmax[HE * HALF + tid], __float_as_uint(xm));
       }
       int lane_o = 0, r_o = 0, hh = 0, fb = 0;
-      float winvc = 0.f, sa[2] = {0.f, 0.f}, mrow = 0.f;
-      f32x4 bbv[4];                       // forward: bias * beta log2(e)
+      float winvc = 0.f, sa[2] = {0.f, 0.f}, mrow[2] = {0.f, 0.f};
       f32x4 hs[3], ex[3];                 // backward / tangent: side loads of the activation items, three items ahead
+      float csum[16];                     // fast path, backward: column sums of the half's deltas (bias gradient)
       bool full = false;
+      // An item comes in a FAST form -- straight-line code: full column block, point-blocked side tensors, no per-row-group
+      // term, every side output present (backward: OPT = an extra adjoint is added) -- and in the general form (FULL: the
+      // block lies inside the layer's columns), which may branch.
       // side loads of activation item IT (block J = IT / 4 of the half, feature group g = IT % 4) into ring slot IT % 3
-      auto side_load = [&](auto it_tag, auto ft) {
+      auto side_load = [&](auto it_tag, auto fast_tag, auto opt_tag, auto full_tag) {
         constexpr int IT = decltype(it_tag)::value, J = IT / 4, g = IT % 4, SL = IT % 3;
-        constexpr bool FULL = decltype(ft)::value;
+        constexpr bool FAST = decltype(fast_tag)::value, OPT = decltype(opt_tag)::value, FULL = FAST || decltype(full_tag)::value;
         if constexpr (MODE != 0) {
+          const bool hx = MODE == 2 ? true : (FAST ? OPT : has_ex);
           const int rbJ = EB + J;
-          if (blk) {
+          if (FAST || blk) {
             const unsigned boff = ((unsigned)rbJ * (unsigned)l_ld + (unsigned)fb) * 32u + (unsigned)r_o;
             const gptr<const float> b_in = p_side_in + tile_off + boff;
 #pragma unroll
             for (int q = 0; q < 4; ++q) hs[SL][q] = (FULL || fb + 8 * g + q < nlim) ? b_in[(8 * g + q) * 32] : 0.f;
-            if (has_ex) {
+            if (hx) {
               const gptr<const float> b_ex = p_side_ex + tile_off + boff;
 #pragma unroll
               for (int q = 0; q < 4; ++q) ex[SL][q] = (FULL || fb + 8 * g + q < nlim) ? b_ex[(8 * g + q) * 32] : 0.f;
@@ -331,7 +387,7 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) hs[SL][q] = (fb + 8 * g + q < nlim) ? b_in[q] : 0.f;
             }
-            if (has_ex) {
+            if (hx) {
               const gptr<const float> b_ex = p_side_ex + tile_off + rowoff;
               if (FULL && (l_ld & 3) == 0) ex[SL] = *((gptr<const f32x4>)b_ex);
               else {
@@ -343,14 +399,18 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
         }
       };
       // activations (forward) / deltas (backward, tangent) of group g of block J -> side_out
-      auto side_store = [&](auto j_tag, auto g_tag, auto ft) {
+      auto side_store = [&](auto j_tag, auto g_tag, auto fast_tag, auto opt_tag, auto full_tag) {
         constexpr int J = decltype(j_tag)::value, g = decltype(g_tag)::value;
-        constexpr bool FULL = decltype(ft)::value;
-        if (!p_side_out) return;
+        constexpr bool FAST = decltype(fast_tag)::value, OPT = decltype(opt_tag)::value, FULL = FAST || decltype(full_tag)::value;
+        const bool so = FAST || p_side_out != nullptr;
+        if (!so) return;
+#ifdef NDJIR_CHAINP_X_NOSTORE      // (timing experiment, WRONG results: the fast form without its side stores)
+        if (FAST) return;
+#endif
         const int rbJ = EB + J;
         const int lim = MODE == 0 ? l_N : nlim;
         const gptr<float> b_out = p_side_out + tile_off;
-        if (blk) {
+        if (FAST || blk) {
           const gptr<float> b_blk = b_out + (((unsigned)rbJ * (unsigned)l_ld + (unsigned)fb) * 32u + (unsigned)r_o);
 #pragma unroll
           for (int q = 0; q < 4; ++q) if (FULL || fb + 8 * g + q < lim) b_blk[(8 * g + q) * 32] = acc0[EB + J][4 * g + q];
@@ -366,16 +426,17 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
       };
       // activation item IT: the math of 4 consecutive features of one row block, on the accumulator registers (mlp3w.hip's
       // hidden_block, one feature group at a time)
-      auto act_item = [&](auto it_tag, auto ft) {
+      auto act_item = [&](auto it_tag, auto fast_tag, auto opt_tag, auto full_tag) {
         constexpr int IT = decltype(it_tag)::value, J = IT / 4, g = IT % 4, SL = IT % 3;
-        constexpr bool FULL = decltype(ft)::value;
+        constexpr bool FAST = decltype(fast_tag)::value, FULL = FAST || decltype(full_tag)::value;
         const int rbJ = EB + J;
         const int R = rbJ * 32 + r_o;
-        if (g == 0) mrow = 0.f;
         if constexpr (MODE == 0) {
           const float kk = fwd_kk(sa[J], winvc, b2);
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(&s_bias[liE & 1][fb + 8 * g]);      // bias * beta log2(e)
+          const bool rbz = !FAST && p_rowbias != nullptr;
           f32x4 rbv = {0.f, 0.f, 0.f, 0.f};
-          if (p_rowbias) {
+          if (rbz) {
             const gptr<const float> rbp = p_rowbias + (long long)((unsigned)(row0 + R) / (unsigned)rb_div) * l_N + fb;
             if (FULL) rbv = *((gptr<const f32x4>)(rbp + 8 * g));
             else {
@@ -386,8 +447,8 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int i = 4 * g + q;
-            float u = fwd_u(acc0[EB + J][i], kk, bbv[g][q]);
-            if (p_rowbias) u = fwd_u_rowbias(u, rbv[q], b2);
+            float u = fwd_u(acc0[EB + J][i], kk, bb[q]);
+            if (rbz) u = fwd_u_rowbias(u, rbv[q], b2);
             float v = softplus_u(u, ib2sc);
             if (!FULL) v = (fb + 8 * g + q < nlim) ? v : 0.f;
             acc0[EB + J][i] = v;
@@ -402,7 +463,8 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
             const float e = __builtin_amdgcn_exp2f(nb2 * hs[SL][q]);
             const float sp = __builtin_fmaf(-e, sc, sc);
             float v;
-            if (MODE == 1) v = has_ex ? zz * sp + ex[SL][q] : zz * sp;
+            // (without an extra adjoint ex holds zeros: fma(zz, sp, 0) is the rounded product, the value mlp3w.hip computes)
+            if (MODE == 1) v = zz * sp + ex[SL][q];
             else { v = zz * sp; x2[q] = beta * zz * ex[SL][q] * e; }
             if (!FULL) {
               const int f = fb + 8 * g + q;
@@ -412,9 +474,9 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
             }
             acc0[EB + J][i] = v;
           }
-          if (MODE == 2 && p_side_out2) {
+          if (MODE == 2 && (FAST || p_side_out2)) {
             const gptr<float> b_out2 = p_side_out2 + tile_off;
-            if (blk) {
+            if (FAST || blk) {
               const gptr<float> b_blk = b_out2 + (((unsigned)rbJ * (unsigned)l_ld + (unsigned)fb) * 32u + (unsigned)r_o);
 #pragma unroll
               for (int q = 0; q < 4; ++q) if (FULL || fb + 8 * g + q < nlim) b_blk[(8 * g + q) * 32] = x2[q];
@@ -428,29 +490,39 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
             }
           }
         }
-        // (the backward's stores wait for the split items: every side load of the phase is consumed by then)
-        if (MODE != 1) side_store(IC<J>{}, IC<g>{}, ft);
+        // (the backward's stores wait for the split items: every side load of the phase is consumed by then; in the fast form
+        //  the forward's / tangent's are spread over the phase's 16 slots, one group every other slot -- `slot` below: with all
+        //  eight groups stored from the eight activation slots every CU of the chip writes its 64 KB at the same time and the
+        //  activation half of the phase runs at the HBM's pace, 10 - 13 k cycles for 3 k cycles of matrix work)
+        if (MODE != 1 && !FAST) side_store(IC<J>{}, IC<g>{}, fast_tag, opt_tag, full_tag);
+        float m = g == 0 ? 0.f : mrow[J];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mrow = fmaxf(mrow, fabsf(acc0[EB + J][4 * g + q]));
-        if (g == 3) {
-          // row maximum of the block's 16 values of this point (v_max ignores NaN; an Inf / all-NaN set goes through the filter)
-          float m = mrow;
+        for (int q = 0; q < 4; ++q) m = fmaxf(m, fabsf(acc0[EB + J][4 * g + q]));
+        mrow[J] = m;
+        // refill the ring slot just consumed with the loads of the item three ahead
+        if constexpr (MODE != 0 && IT + 3 < 8) side_load(IC<IT + 3>{}, fast_tag, opt_tag, full_tag);
+      };
+      // row maxima of the two blocks (after the 8 activation items): v_max ignores NaN; a set holding an Inf (or only NaN)
+      // goes through the bit-pattern filter.  One LDS atomic per lane and block.
+      auto rowmax_finish = [&]() {
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+          float m = mrow[J];
           if (!(m < 3.0e38f)) {
             unsigned mb = 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { const unsigned bb = finite_abs_bits(acc0[EB + J][i]); mb = bb > mb ? bb : mb; }
             m = __uint_as_float(mb);
           }
-          atomicMax(&s_rmax[R], __float_as_uint(m));
+          atomicMax(&s_rmax[(EB + J) * 32 + r_o], __float_as_uint(m));
         }
-        // refill the ring slot just consumed with the loads of the item three ahead
-        if constexpr (MODE != 0 && IT + 3 < 8) side_load(IC<IT + 3>{}, ft);
       };
       float s_row[2] = {1.f, 1.f};
       // split item IT (block J, feature group g): scale by the row's power of two, two f16 planes, in place; backward: the
       // group's delta store; two features of the bias gradient's column sums
-      auto split_item = [&](auto it_tag, auto ft) {
+      auto split_item = [&](auto it_tag, auto fast_tag, auto opt_tag, auto full_tag) {
         constexpr int IT = decltype(it_tag)::value, J = IT / 4, g = IT % 4;
+        constexpr bool FAST = decltype(fast_tag)::value;
         const int rbJ = EB + J;
         const int R = rbJ * 32 + r_o;
         if (g == 0) {
@@ -458,10 +530,10 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
           scale_from_max(s_rmax[R], s_row[J], inv_row);
         }
         put4(nb * 32 + 4 * hh + 8 * g, R, f32x4{acc0[EB + J][4 * g], acc0[EB + J][4 * g + 1], acc0[EB + J][4 * g + 2], acc0[EB + J][4 * g + 3]}, s_row[J]);
-        if (MODE == 1) side_store(IC<J>{}, IC<g>{}, ft);
-        if (MODE != 0 && p_bgrad) {
-          // bias gradient: column sums of the deltas over the wave's 64 points of the half -- 16-lane rows by DPP, one LDS
-          // atomic per feature from the first lane of every row
+        if (MODE == 1) side_store(IC<J>{}, IC<g>{}, fast_tag, opt_tag, full_tag);
+        if (MODE != 0 && (FAST ? MODE == 1 : p_bgrad != nullptr)) {
+          // bias gradient: column sums of the deltas over the wave's 64 points of the half -- 16-lane rows by DPP; the LDS
+          // atomics (first lane of every row) follow the last slot in the fast form
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const int i = 2 * IT + t;
@@ -470,8 +542,11 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
             c += dpp<DPP_XOR2>(c);
             c += dpp<DPP_HALF_MIRROR>(c);
             c += dpp<DPP_MIRROR>(c);
-            const int f = fb + acc_feat(i, 0);
-            if ((lane_o & 15) == 0 && f < nlim) atomicAdd(p_bgrad + f, c);
+            if (FAST) csum[i] = c;
+            else {
+              const int f = fb + acc_feat(i, 0);
+              if ((lane_o & 15) == 0 && f < nlim) atomicAdd(p_bgrad + f, c);
+            }
           }
         }
       };
@@ -482,88 +557,291 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
         full = blk ? (full_cols && (!p_rowbias || (l_N & 3) == 0))
                    : ((l_ld & 3) == 0 && (!p_rowbias || (l_N & 3) == 0) && full_cols);
         const float winv_raw = p_winv[nb];
-        if (MODE == 0) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            bbv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (full && (l_ld & 3) == 0) { if (p_bias) bbv[g] = *((gptr<const f32x4>)(p_bias + (unsigned)(fb + 8 * g))); }
-            else {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) bbv[g][q] = (p_bias && fb + 8 * g + q < l_N) ? p_bias[fb + 8 * g + q] : 0.f;
-            }
-          }
-        }
         if (MODE != 0) {
-          if (full) { side_load(IC<0>{}, TT{}); side_load(IC<1>{}, TT{}); side_load(IC<2>{}, TT{}); }
-          else { side_load(IC<0>{}, FF{}); side_load(IC<1>{}, FF{}); side_load(IC<2>{}, FF{}); }
+          if (full) { side_load(IC<0>{}, FF{}, FF{}, TT{}); side_load(IC<1>{}, FF{}, FF{}, TT{}); side_load(IC<2>{}, FF{}, FF{}, TT{}); }
+          else { side_load(IC<0>{}, FF{}, FF{}, FF{}); side_load(IC<1>{}, FF{}, FF{}, FF{}); side_load(IC<2>{}, FF{}, FF{}, FF{}); }
         }
         sa[0] = s_ainv[EB * 32 + r_o];
         sa[1] = s_ainv[(EB + 1) * 32 + r_o];
-        // the accumulator pairs of the E half become single values at once (acc1 of these blocks is dead from here on)
-#pragma unroll
-        for (int J = 0; J < 2; ++J)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc0[EB + J][i] = acc_sum(acc0[EB + J][i], acc1[EB + J][i]);
         winvc = pin(winv_raw);
-        if (MODE == 0) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bbv[g][q] = bbv[g][q] * b2;
-        }
         __builtin_amdgcn_sched_barrier(0);
       }
 
       // ---------------- the 16 slots ----------------
-      auto hint = [&]() {
-        // one MFMA, then a share of the slot's vector / transcendental / memory instructions, six times
-#ifndef NDJIR_CHAINP_NO_HINT
+      // ---------------- K role: first fragments (after the E role's set-up: its loads and the fragments would otherwise be live
+      // together with it, and the allocator spills them) ----------------
+      auto k_preload = [&]() {
+       if (activeK) {
+        // (no zero-initialisation: the first k-step's MFMAs take the constant 0 as their addend, so the K half's accumulators
+        //  come to life inside slot 0 -- after the E half's second accumulators have died in its set-up)
+        const int lane_k = fresh_lane();
+        Bp = p_wp + ((long long)nb * KS) * 2 * 64 + lane_k;
+        A0 = act + (lane_k >> 5) * TMP + KB * 32 + (lane_k & 31);
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-          __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) b[s][p] = Bp[(long long)((s < KS ? s : KS - 1) * 2 + p) * 64];
+          __builtin_amdgcn_sched_barrier(0);
         }
-#endif
-      };
-      auto slot = [&](auto i_tag) {
-        constexpr int I = decltype(i_tag)::value;
-        if (activeK && I < KS) kstep(IC<I % 3>{}, IC<I % 2>{}, I);
-        if (activeE) {
-          if constexpr (I < 8) { if (full) act_item(IC<I>{}, TT{}); else act_item(IC<I>{}, FF{}); }
-          else { if (full) split_item(IC<I - 8>{}, TT{}); else split_item(IC<I - 8>{}, FF{}); }
-        }
-        hint();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { af[0][0][q] = A0[q * 32]; af[0][1][q] = A0[PLANE + q * 32]; }
         __builtin_amdgcn_sched_barrier(0);
+       }
       };
-      slot(IC<0>{}); slot(IC<1>{}); slot(IC<2>{}); slot(IC<3>{});
-      slot(IC<4>{}); slot(IC<5>{}); slot(IC<6>{}); slot(IC<7>{});
-      if (doE) {
-        // every wave has contributed its row maxima of the E half
-        lds_barrier();
-        if (tid < HALF) {
-          const int row = HE * HALF + tid;
-          float s_r, inv_r;
-          scale_from_max(s_rmax[row], s_r, inv_r);
-          s_ainv[row] = inv_r;            // read by the epilogue of the next layer on this half, two barriers on
-          if (lyE.side_amax) {
-            const float wm = wave_max(__uint_as_float(s_rmax[row]));
-            if (lane == 0) atomicMax(lyE.side_amax, __float_as_uint(wm));
+      // ---------------- fast path: the pieces of a slot ----------------
+      f16x8 blo;                          // this k-step's weight lo fragment, unscaled
+      f32x4 fu, fa, fm;                   // item temporaries: forward u, exp / log, max(u, 0); backward zz, e, softplus'
+      f32x4 bbn = {0.f, 0.f, 0.f, 0.f};   // forward: bias * beta log2(e) of the NEXT item (read one slot ahead)
+      f32x4 xs4, bk4;                     // split temporaries
+      f16x4 ph4;
+      // MFMA j of slot I's k-step: j = 2 * product + row block of the half; activation fragments of buffer I % 2
+      // (-DNDJIR_CHAINP_X_AF1: one buffer, each fragment re-read right behind the last MFMA that uses it -- 16 registers less, but
+      //  the hi planes then arrive two MFMAs before their first use and every slot waits for the LDS)
+#ifdef NDJIR_CHAINP_X_AF1
+#define NDJIR_AFC(I) 0
+#else
+#define NDJIR_AFC(I) ((I) % 2)
+#endif
+      auto mfma_j = [&](auto i_tag, auto j_tag) {
+        constexpr int I = decltype(i_tag)::value, Jv = decltype(j_tag)::value, S = I % 3, q = Jv & 1, pr = Jv >> 1, C = NDJIR_AFC(I);
+#ifdef NDJIR_CHAINP_X_NOMFMA      // (timing experiment, WRONG results: the fast form without its matrix work)
+        acc0[KB + q][0] += (float)b[S][0][0] + (float)af[C][pr == 0][q][0] + (float)blo[0];
+        return;
+#endif
+        const f32x16 zero = f32x16{0};
+        if constexpr (pr == 0) acc0[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][1][q], I == 0 ? zero : acc0[KB + q], 0, 0, 0);
+        else if constexpr (pr == 1) acc0[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][0][q], acc0[KB + q], 0, 0, 0);
+        else acc0[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo, af[C][0][q], acc0[KB + q], 0, 0, 0);
+      };
+      // the k-step's own loads, each behind the last MFMA that reads the registers it overwrites
+      auto k_side = [&](auto i_tag, auto j_tag) {
+        constexpr int I = decltype(i_tag)::value, Jv = decltype(j_tag)::value, S = I % 3;
+        const int ksn = I + 1 < KS ? I + 1 : KS - 1;
+        const f16x8* An = A0 + 2 * ksn * TMP;
+#ifdef NDJIR_CHAINP_X_NOPKMUL      // (timing experiment, WRONG results: the scaled lo plane as it is)
+        if constexpr (Jv == 0) blo = b[S][1];
+#else
+        if constexpr (Jv == 0) blo = b[S][1] * LOU;
+#endif
+#ifdef NDJIR_CHAINP_X_NOAF         // (timing experiment, WRONG results: the activation fragments are never re-read)
+        if constexpr (Jv == 3) {
+          const int ksw = I + 3 < KS ? I + 3 : KS - 1;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) b[S][p] = Bp[(long long)(ksw * 2 + p) * 64];
+        }
+        return;
+#endif
+#ifdef NDJIR_CHAINP_X_AF1
+        if constexpr (Jv == 1) { af[0][1][0] = An[PLANE]; af[0][1][1] = An[PLANE + 32]; }      // lo planes of the next k-step
+        if constexpr (Jv == 5) { af[0][0][0] = An[0]; af[0][0][1] = An[32]; }                   // hi planes of the next k-step
+#else
+        constexpr int Cn = (I % 2) ^ 1;
+        if constexpr (Jv == 0) { af[Cn][1][0] = An[PLANE]; af[Cn][1][1] = An[PLANE + 32]; }    // the next k-step's fragments: a slot ahead
+        if constexpr (Jv == 1) { af[Cn][0][0] = An[0]; af[Cn][0][1] = An[32]; }
+#endif
+        if constexpr (Jv == 3) {
+#ifdef NDJIR_CHAINP_X_WSAME      // (timing experiment, WRONG results: every k-step re-reads the first weight fragment -- an L1 hit)
+          const int ksw = 0;
+#else
+          const int ksw = I + 3 < KS ? I + 3 : KS - 1;
+#endif
+#pragma unroll
+          for (int p = 0; p < 2; ++p) b[S][p] = Bp[(long long)(ksw * 2 + p) * 64];
+        }
+      };
+      auto load_bias_next = [&](const int it) {      // forward: item `it`'s bias * beta log2(e) out of the LDS table
+        const int g = it & 3;
+        bbn = *reinterpret_cast<const f32x4*>(&s_bias[liE & 1][fb + 8 * g]);
+      };
+      // slice Jv of activation item IT (fast form: full block, point-blocked side tensors, every output present)
+      auto act_slice = [&](auto it_tag, auto j_tag, auto opt_tag) {
+        constexpr int IT = decltype(it_tag)::value, Jv = decltype(j_tag)::value, J = IT / 4, g = IT % 4, SL = IT % 3;
+        if constexpr (MODE == 0) {
+          if constexpr (Jv == 0) {
+            const float kk = fwd_kk(sa[J], winvc, b2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { fu[q] = fwd_u(acc0[EB + J][4 * g + q], kk, bbn[q]); fa[q] = __builtin_amdgcn_exp2f(-__builtin_fabsf(fu[q])); }
+          } else if constexpr (Jv == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { fa[q] = add_nc(1.f, fa[q]); fm[q] = __builtin_fmaxf(fu[q], 0.f); }
+          } else if constexpr (Jv == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fa[q] = __builtin_amdgcn_logf(fa[q]);
+          } else if constexpr (Jv == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc0[EB + J][4 * g + q] = mul_nc(add_nc(fm[q], fa[q]), ib2sc);
+          }
+        } else {
+          if constexpr (Jv == 0) {
+            const float saw = sa[J] * winvc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { fu[q] = acc0[EB + J][4 * g + q] * saw; fa[q] = nb2 * hs[SL][q]; }
+          } else if constexpr (Jv == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fa[q] = __builtin_amdgcn_exp2f(fa[q]);
+          } else if constexpr (Jv == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fm[q] = __builtin_fmaf(-fa[q], sc, sc);
+          } else if constexpr (Jv == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (MODE == 1) acc0[EB + J][4 * g + q] = fu[q] * fm[q] + ex[SL][q];
+              else { acc0[EB + J][4 * g + q] = fu[q] * fm[q]; fm[q] = beta * fu[q] * ex[SL][q] * fa[q]; }
+            }
           }
         }
-      }
-      stamp(stamp_li, stamp_ph + 1);
-      slot(IC<8>{}); slot(IC<9>{}); slot(IC<10>{}); slot(IC<11>{});
-      slot(IC<12>{}); slot(IC<13>{}); slot(IC<14>{}); slot(IC<15>{});
+        if constexpr (Jv == 4) {
+          float m = g == 0 ? 0.f : mrow[J];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) m = fmaxf(m, fabsf(acc0[EB + J][4 * g + q]));
+          mrow[J] = m;
+          if constexpr (MODE == 0 && IT + 1 < 8) load_bias_next(IT + 1);
+          if constexpr (MODE == 2) {        // the tangent's second output: stored at once (its values are not kept)
+            const gptr<float> b_blk = p_side_out2 + tile_off + (((unsigned)(EB + J) * (unsigned)l_ld + (unsigned)fb) * 32u + (unsigned)r_o);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b_blk[(8 * g + q) * 32] = fm[q];
+          }
+        }
+        if constexpr (Jv == 5) {
+          if constexpr (MODE != 0 && IT + 3 < 8) side_load(IC<IT + 3>{}, TT{}, opt_tag, TT{});
+          // forward / tangent: store group (IT - 1) / 2, computed in slot (IT - 1) / 2 -- one group every other slot
+          if constexpr (MODE != 1 && (IT & 1) == 1) side_store(IC<((IT - 1) / 2) / 4>{}, IC<((IT - 1) / 2) % 4>{}, TT{}, opt_tag, TT{});
+        }
+      };
+      // slice Jv of split item IT: x s -> hi = f16(x s), lo = f16(x s - hi), both planes in place
+      auto split_slice = [&](auto it_tag, auto j_tag, auto opt_tag) {
+        constexpr int IT = decltype(it_tag)::value, Jv = decltype(j_tag)::value, J = IT / 4, g = IT % 4;
+        if constexpr (Jv == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xs4[q] = mul_nc(acc0[EB + J][4 * g + q], s_row[J]);
+        } else if constexpr (Jv == 1) {
+          ph4 = __builtin_convertvector(xs4, f16x4);
+        } else if constexpr (Jv == 2) {
+          bk4 = __builtin_convertvector(ph4, f32x4);
+        } else if constexpr (Jv == 3) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xs4[q] = sub_nc(xs4[q], bk4[q]);
+        } else if constexpr (Jv == 4) {
+          const f16x4 pl4 = __builtin_convertvector(xs4, f16x4);
+          const int k = nb * 32 + 4 * hh + 8 * g, R = (EB + J) * 32 + r_o;
+          char* pp = actb + ((size_t)((k >> 3) * TMP + R) * 16 + (k & 7) * 2);
+          *reinterpret_cast<f16x4*>(pp) = ph4;
+          *reinterpret_cast<f16x4*>(pp + (size_t)PLANE * 16) = pl4;
+        } else {
+          if constexpr (MODE == 1) side_store(IC<J>{}, IC<g>{}, TT{}, opt_tag, TT{});
+          else if constexpr ((IT & 1) == 1) side_store(IC<((IT + 8 - 1) / 2) / 4>{}, IC<((IT + 8 - 1) / 2) % 4>{}, TT{}, opt_tag, TT{});
+        }
+        if constexpr (MODE == 1 && (Jv == 1 || Jv == 2)) {
+          // bias gradient: column sums of the half's deltas, one feature per slice (the LDS atomics follow the last slot)
+          const int i = 2 * IT + (Jv - 1);
+          float c = acc0[EB][i] + acc0[EB + 1][i];
+          c += dpp<DPP_XOR1>(c);
+          c += dpp<DPP_XOR2>(c);
+          c += dpp<DPP_HALF_MIRROR>(c);
+          c += dpp<DPP_MIRROR>(c);
+          csum[i] = c;
+        }
+      };
+      // FAST: straight-line epilogue items (this wave's block is full, side tensors point-blocked and present, no per-row-group
+      // term).  KCOND: the k-step of a slot sits behind a uniform branch (fewer than 16 k-steps -- a first layer --, no K role in
+      // the phase, or a wave without a column block in layer liK); otherwise the slot is one basic block and the scheduler places
+      // the item's instructions between the MFMAs.
+      const bool fast_e = activeE && full && blk && !p_rowbias && p_side_out != nullptr &&
+                          (MODE != 2 || p_side_out2 != nullptr) && (MODE == 0 || ((p_bgrad != nullptr) == (MODE == 1)));
+      const bool fast_k = activeK && KS >= 16;
+      const bool opt = MODE == 1 && p_side_ex != nullptr;
+      auto slots = [&](auto fast_tag, auto opt_tag, auto kcond_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value, KCOND = decltype(kcond_tag)::value;
+        auto slot = [&](auto i_tag) {
+          constexpr int I = decltype(i_tag)::value;
+          if constexpr (FAST) {
+            if constexpr (KCOND) { if (activeK && I < KS) kstep(IC<I % 3>{}, IC<I % 2>{}, I, std::integral_constant<bool, I == 0>{}); }
+            // six steps: [MFMA j of the k-step] [the k-step's own loads that may follow it] [slice j of the epilogue item], fenced --
+            // the order the matrix pipe wants (one MFMA, ~6 vector instructions, the next MFMA ...) written down instead of
+            // asked for: left to `sched_group_barrier` the MFMAs of a slot clustered at its head and the item's dependent
+            // chain (fma -> exp -> add -> log -> add -> mul per value) followed them, and a wave that waits on the saturated
+            // matrix pipe blocks its SIMD's vector issue (tools/ubench/coissue.hip): matrix and vector time added up again
+#ifdef NDJIR_CHAINP_X_NOITEM      // (timing experiment, WRONG results: the fast form without its epilogue items)
+#define NDJIR_ITEM(Jv)
+#else
+#define NDJIR_ITEM(Jv) if constexpr (I < 8) act_slice(IC<I>{}, IC<Jv>{}, opt_tag); else split_slice(IC<I - 8>{}, IC<Jv>{}, opt_tag);
+#endif
+#define NDJIR_STEP(Jv)                                                                                   \
+            if constexpr (!KCOND) { mfma_j(i_tag, IC<Jv>{}); __builtin_amdgcn_sched_barrier(0); k_side(i_tag, IC<Jv>{}); } \
+            NDJIR_ITEM(Jv) \
+            __builtin_amdgcn_sched_barrier(0);
+            NDJIR_STEP(0) NDJIR_STEP(1) NDJIR_STEP(2) NDJIR_STEP(3) NDJIR_STEP(4) NDJIR_STEP(5)
+#undef NDJIR_STEP
+#undef NDJIR_ITEM
+          } else {
+            if (activeK && I < KS) kstep(IC<I % 3>{}, IC<I % 2>{}, I, std::integral_constant<bool, I == 0>{});
+            if (activeE) {
+              if constexpr (I < 8) { if (full) act_item(IC<I>{}, FF{}, FF{}, TT{}); else act_item(IC<I>{}, FF{}, FF{}, FF{}); }
+              else { if (full) split_item(IC<I - 8>{}, FF{}, FF{}, TT{}); else split_item(IC<I - 8>{}, FF{}, FF{}, FF{}); }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#ifdef NDJIR_CHAINP_SUBSTAMP      // (diagnostic build: per-slot stamps of layer 2, waves 0 and 4 of workgroup 0, behind the regular timeline)
+          if (a0.timeline && blockIdx.x == 0 && lane == 0 && stamp_li == 2 && (wave & 3) == 0 && a0.timeline[399] >= 64)
+            a0.timeline[400 + (HK * 2 + (wave >> 2)) * 18 + I + 1] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+        };
+#ifdef NDJIR_CHAINP_SUBSTAMP
+        if (a0.timeline && blockIdx.x == 0 && lane == 0 && stamp_li == 2 && (wave & 3) == 0 && a0.timeline[399] >= 64)
+          a0.timeline[400 + (HK * 2 + (wave >> 2)) * 18] = (long long)__builtin_amdgcn_s_memtime();
+#endif
+        k_preload();        // (inside the variant: the fragments are born in the block that consumes them)
+        if constexpr (FAST && MODE == 0) load_bias_next(0);
+        slot(IC<0>{}); slot(IC<1>{}); slot(IC<2>{}); slot(IC<3>{});
+        slot(IC<4>{}); slot(IC<5>{}); slot(IC<6>{}); slot(IC<7>{});
+        if (activeE) rowmax_finish();
+        if (doE) {
+          // every wave has contributed its row maxima of the E half
+#ifndef NDJIR_CHAINP_X_NOMIDBAR      // (timing experiment, WRONG results: no barrier in front of the split)
+          lds_barrier();
+#endif
+          if (tid < HALF) {
+            const int row = HE * HALF + tid;
+            float s_r, inv_r;
+            scale_from_max(s_rmax[row], s_r, inv_r);
+            s_ainv[row] = inv_r;            // read by the epilogue of the next layer on this half, two barriers on
+            if (lyE.side_amax) {
+              const float wm = wave_max(__uint_as_float(s_rmax[row]));
+              if (lane == 0) atomicMax(lyE.side_amax, __float_as_uint(wm));
+            }
+          }
+        }
+        stamp(stamp_li, stamp_ph + 1);
+        if constexpr (FAST) {
+          float inv_row;
+          scale_from_max(s_rmax[EB * 32 + r_o], s_row[0], inv_row);
+          scale_from_max(s_rmax[(EB + 1) * 32 + r_o], s_row[1], inv_row);
+        }
+        slot(IC<8>{}); slot(IC<9>{}); slot(IC<10>{}); slot(IC<11>{});
+        slot(IC<12>{}); slot(IC<13>{}); slot(IC<14>{}); slot(IC<15>{});
+        if (FAST && MODE == 1) {
+          if ((lane_o & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) atomicAdd(p_bgrad + fb + acc_feat(i, 0), csum[i]);
+          }
+        }
+      };
+      auto slots_k = [&](auto fast_tag, auto opt_tag) {
+        if (fast_k) slots(fast_tag, opt_tag, FF{}); else slots(fast_tag, opt_tag, TT{});
+      };
+      if (fast_e) {
+        if constexpr (MODE == 1) { if (opt) slots_k(TT{}, TT{}); else slots_k(TT{}, FF{}); }
+        else slots_k(TT{}, FF{});
+      } else slots(FF{}, FF{}, TT{});
       // k-steps beyond the 16 slots (inputs wider than 256 columns): bare
       if (activeK) {
         for (int ks = 16; ks < KS; ks += 6) {
-          kstep(IC<1>{}, IC<0>{}, ks);
-          if (ks + 1 < KS) kstep(IC<2>{}, IC<1>{}, ks + 1);
-          if (ks + 2 < KS) kstep(IC<0>{}, IC<0>{}, ks + 2);
-          if (ks + 3 < KS) kstep(IC<1>{}, IC<1>{}, ks + 3);
-          if (ks + 4 < KS) kstep(IC<2>{}, IC<0>{}, ks + 4);
-          if (ks + 5 < KS) kstep(IC<0>{}, IC<1>{}, ks + 5);
+          kstep(IC<1>{}, IC<0>{}, ks, FF{});
+          if (ks + 1 < KS) kstep(IC<2>{}, IC<1>{}, ks + 1, FF{});
+          if (ks + 2 < KS) kstep(IC<0>{}, IC<0>{}, ks + 2, FF{});
+          if (ks + 3 < KS) kstep(IC<1>{}, IC<1>{}, ks + 3, FF{});
+          if (ks + 4 < KS) kstep(IC<2>{}, IC<0>{}, ks + 4, FF{});
+          if (ks + 5 < KS) kstep(IC<0>{}, IC<1>{}, ks + 5, FF{});
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -611,15 +889,15 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
       const auto& ly = a.layers[li];
       const int KS = (ly.Kp + 15) >> 4;
       const int NB = ly.Np >> 5;
-      const gptr<const f16x8> p_wp = (gptr<const f16x8>)pin(ly.Wp);
-      const gptr<const float> p_winv = pin(ly.Wp + (long long)KS * 16 * ly.Np);
-      const gptr<const float> p_bias = pin(ly.bias);
+      const gptr<const f16x8> p_wp = (gptr<const f16x8>)upin(ly.Wp);
+      const gptr<const float> p_winv = upin(ly.Wp + (long long)KS * 16 * ly.Np);
+      const gptr<const float> p_bias = upin(ly.bias);
       const int l_N = pin(ly.N);
       // plain k-loop of one half: blocks 2 H, 2 H + 1 of column block nbk, k-steps [ks0, ks1)
       auto kloop_half = [&](auto h_tag, const int nbk, const int ks0, const int ks1) {
         constexpr int H = decltype(h_tag)::value, KB = 2 * H;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { acc0[KB + q] = f32x16{0}; acc1[KB + q] = f32x16{0}; }
+        for (int q = 0; q < 2; ++q) acc0[KB + q] = f32x16{0};
         const int lane_k = fresh_lane();
         const gptr<const f16x8> Bp = p_wp + ((long long)nbk * KS) * 2 * 64 + lane_k;
         const f16x8* A0 = act + (lane_k >> 5) * TMP + KB * 32 + (lane_k & 31);
@@ -644,11 +922,12 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
             for (int q = 0; q < 2; ++q) { af[C ^ 1][0][q] = An[q * 32]; af[C ^ 1][1][q] = An[PLANE + q * 32]; }
           }
 #pragma unroll
-          for (int q = 0; q < 2; ++q) acc1[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][1][q], acc1[KB + q], 0, 0, 0);
+          for (int q = 0; q < 2; ++q) acc0[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][1][q], acc0[KB + q], 0, 0, 0);
 #pragma unroll
           for (int q = 0; q < 2; ++q) acc0[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][0], af[C][0][q], acc0[KB + q], 0, 0, 0);
+          const f16x8 blo = b[S][1] * LOU;
 #pragma unroll
-          for (int q = 0; q < 2; ++q) acc1[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[S][1], af[C][0][q], acc1[KB + q], 0, 0, 0);
+          for (int q = 0; q < 2; ++q) acc0[KB + q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo, af[C][0][q], acc0[KB + q], 0, 0, 0);
           if (ks + 3 < ks1) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) b[S][p] = Bp[(long long)((ks + 3) * 2 + p) * 64];
@@ -695,7 +974,7 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
               f32x4 t;
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                const float z = out_z(acc_sum(acc0[J][4 * g + q], acc1[J][4 * g + q]), sa, winv);
+                const float z = out_z(acc0[J][4 * g + q], sa, winv);
                 t[q] = MODE == 0 ? out_add(z, bias4[g][q]) : z;
               }
               if (vec_y) {
@@ -734,7 +1013,7 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
             for (int g = 0; g < 4; ++g) {
               f32x4 v;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = acc_sum(acc0[J][4 * g + q], acc1[J][4 * g + q]);
+              for (int q = 0; q < 4; ++q) v[q] = acc0[J][4 * g + q];
               *reinterpret_cast<f32x4*>(dst + 8 * g) = v;
             }
           }

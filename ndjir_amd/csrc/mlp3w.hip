@@ -964,6 +964,19 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 }  // namespace x3w
 
 #ifndef NDJIR_NO_LAUNCHER      // (tools/isa_one.sh compiles ONE instantiation of the kernel above for a look at its ISA)
+// mlp3p.hip: the same tile, planes and arithmetic with the two 64-point halves of the tile software-pipelined (round 6)
+int launch_chainp_group(const ChainGroup& grp, int mode, int blocks, size_t lds_bytes, hipStream_t stream);
+
+// Which modes of the <mode, 4, 8, 128> launches go to the pipelined kernel: bit 0 forward, bit 1 backward, bit 2 tangent (training
+// passes only, see launch_chainw_group).  set >= 0 sets it (ndjir_mlp_set_chain_pipeline); the first query reads NDJIR_CHAINP.
+constexpr int CHAINP_DEFAULT = 0;
+static int g_chainp = -1;
+int chain_pipeline(int set) {
+  if (set >= 0) g_chainp = set & 7;
+  if (g_chainp < 0) { const char* e = getenv("NDJIR_CHAINP"); g_chainp = e ? (atoi(e) & 7) : CHAINP_DEFAULT; }
+  return g_chainp;
+}
+
 // One net's part of a launch plan: the argument block with everything but the LDS offsets filled in.
 struct WidePlan {
   ChainArgs b;
@@ -1099,6 +1112,19 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
   if (blocks > 256LL * 8) blocks = 256LL * 8;
   if (tile64 && blocks > 512) blocks = 512;         // (two per CU, resident for the whole launch: the priority pairing above)
   static const int t64_prio = [] { const char* e = getenv("NDJIR_CHAINW_T64_PRIO"); return e ? atoi(e) : 1; }();
+  // the pipelined kernel (mlp3p.hip) for the <mode, 4, 8, 128> launches: bit 0 forward, bit 1 backward, bit 2 tangent (NDJIR_CHAINP=0:
+  // this file's kernel)
+  const int chainp = chain_pipeline(-1);
+  // ... for TRAINING passes only (point-blocked side tensors, every hidden layer of a forward launch stores its activation): the
+  // pipelined kernel accumulates the three partial products in ONE register (mlp3p.hip) -- its results agree with this file's
+  // and mlp3.hip's to round-off, not bit for bit, and forward values that are merged across launches (the sampler's SDF
+  // rounds, the SDF volume) must not depend on the launch's size
+  bool pipe = rpw == 4 && !tile64 && !teams && ((chainp >> mode) & 1);
+  for (int i = 0; i < n && pipe; ++i) {
+    if (!nets[i].side_blocked) pipe = false;
+    const int hidden = nets[i].has_output ? nets[i].L - 1 : nets[i].L;
+    for (int j = 0; j < hidden && pipe; ++j) if (!nets[i].layers[j].side_out) pipe = false;
+  }
   if (bg_sum > 0 && blocks > CHAIN_MAX_GRID_BG) blocks = CHAIN_MAX_GRID_BG;
   if (n > 1) {          // ... which caps the grid of a net with bias gradients only: every member has to agree on it
     for (int i = 0; i < n; ++i) {
@@ -1118,6 +1144,7 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
   if (nets[0].dry) {
     if (teams) snprintf(nets[0].dry->name, 64, "ndjir::x3w::k_chainw%s<%d, 2, 8, 64>", n > 1 ? "_nets" : "", mode);
     else if (tile64) snprintf(nets[0].dry->name, 64, "ndjir::x3w::k_chainw%s<%d, 2, 4, 64>", n > 1 ? "_nets" : "", mode);
+    else if (pipe) snprintf(nets[0].dry->name, 64, "ndjir::x3p::k_chainp%s<%d>", n > 1 ? "_nets" : "", mode);
     else snprintf(nets[0].dry->name, 64, "ndjir::x3w::k_chainw%s<%d, %d, %d, 128>", n > 1 ? "_nets" : "", mode, (rpw == 4 || four) ? 4 : 2, four ? 4 : 8);
     nets[0].dry->blocks = (int)blocks; nets[0].dry->bg_total = plan[0].bg_total;
     return NDJIR_OK;
@@ -1142,7 +1169,8 @@ int launch_chainw_group(const ChainArgs* nets, int n, int mode, hipStream_t stre
   else if (tile64) { if (mode == 0) NDJIR_GO64(0); else if (mode == 1) NDJIR_GO64(1); else NDJIR_GO64(2); }
   else
 #endif
-  if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4, 8); else if (mode == 1) NDJIR_GO(1, 4, 8); else NDJIR_GO(2, 4, 8); }
+  if (pipe) { const int rcp = launch_chainp_group(grp, mode, (int)blocks, lds_bytes, stream); if (rcp != NDJIR_OK) return rcp; }
+  else if (rpw == 4) { if (mode == 0) NDJIR_GO(0, 4, 8); else if (mode == 1) NDJIR_GO(1, 4, 8); else NDJIR_GO(2, 4, 8); }
   else if (four) { if (mode == 0) NDJIR_GO(0, 4, 4); else if (mode == 1) NDJIR_GO(1, 4, 4); else NDJIR_GO(2, 4, 4); }
   else { if (mode == 0) NDJIR_GO(0, 2, 8); else if (mode == 1) NDJIR_GO(1, 2, 8); else NDJIR_GO(2, 2, 8); }
 #undef NDJIR_GO

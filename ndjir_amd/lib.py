@@ -270,7 +270,7 @@ def symbols():
                                             "ndjir_hash_table_size", "ndjir_hash_num_params",
                                             "ndjir_mlp_packed_size", "ndjir_mlp_wgrad_workspace", "ndjir_mlp_wgrad_group_workspace", "ndjir_mlp_wgrad_group_launches", "ndjir_mlp_colsum_workspace",
                                             "ndjir_mlp_chain_workspace", "ndjir_mlp_set_math", "ndjir_mlp_get_math",
-                                            "ndjir_mlp_set_tile_rows", "ndjir_mlp_get_tile_rows", "ndjir_mlp_pack_entry_bytes",
+                                            "ndjir_mlp_set_tile_rows", "ndjir_mlp_get_tile_rows", "ndjir_mlp_set_chain_pipeline", "ndjir_mlp_get_chain_pipeline", "ndjir_mlp_pack_entry_bytes",
                                             "ndjir_mlp_debug_timeline", "ndjir_mlp_chain_kernel", "ndjir_mlp_chain_bias_partials", "ndjir_loss_terms_workspace",
                                             "ndjir_mlp_chain_group_begin", "ndjir_mlp_chain_group_end", "ndjir_sparse_rows_header"]
 

@@ -49,6 +49,18 @@ def get_tile_rows():
     return int(lib.load().ndjir_mlp_get_tile_rows())
 
 
+def set_chain_pipeline(mask):
+    """Which training-pass chain launches of nets wider than 128 columns run on the software-pipelined kernel (csrc/mlp3p.hip):
+    bit 0 forward, bit 1 backward, bit 2 tangent, 0 = none.  Results agree with the other kernels to round-off, not bit for
+    bit; like `set_math` / `set_tile_rows`, not to be changed under a live captured graph."""
+    if lib.load().ndjir_mlp_set_chain_pipeline(int(mask)) != 0:
+        raise ValueError(f"chain pipeline mask {mask}")
+
+
+def get_chain_pipeline():
+    return int(lib.load().ndjir_mlp_get_chain_pipeline())
+
+
 def _init_math():
     import os
     env = os.environ.get("NDJIR_MLP_MATH")
@@ -659,7 +671,7 @@ def blocked_layout(P, hidden_widths, is_cuda=True):
 def engine_state():
     """(arithmetic engine, forced tile height) of the MLP library: process-wide settings (`set_math`, `set_tile_rows`) that
     decide the layout of the hidden tensors a forward pass stores."""
-    return (get_math(), get_tile_rows())
+    return (get_math(), get_tile_rows(), get_chain_pipeline())
 
 
 def require_engine(saved, blocked):

@@ -1,7 +1,8 @@
-"""The 128-point-tile chain kernel (ndjir_amd/csrc/mlp3w.hip: operands swapped, epilogue in the accumulator registers)
-against the 64-point-tile kernel (mlp3.hip) and against fp64: a point's FORWARD result must be bit-identical whichever
-kernel evaluates it (the sampler merges SDF values of different launches bit for bit), the backward / tangent chains agree to
-round-off.  `ndjir_mlp_set_tile_rows(128)` sends launches of any size that the wide kernel supports (P % 128 == 0, hidden
+"""The 128-point-tile chain kernels (ndjir_amd/csrc/mlp3w.hip: operands swapped, epilogue in the accumulator registers;
+csrc/mlp3p.hip: the same tile with its two halves software-pipelined, one accumulator per block -- TRAINING passes of nets wider
+than 128 columns with point-blocked side tensors) against the 64-point-tile kernel (mlp3.hip) and against fp64: a point's FORWARD
+result of a pass WITHOUT side tensors must be bit-identical whichever kernel evaluates it (the sampler merges SDF values of
+different launches bit for bit); training passes, the backward / tangent chains agree to round-off.  `ndjir_mlp_set_tile_rows(128)` sends launches of any size that the wide kernel supports (P % 128 == 0, hidden
 layers of 2..8 column blocks, planes within the LDS) to it; by default only launches of >= 32768 points go there."""
 import numpy as np
 import pytest
@@ -12,12 +13,16 @@ from tests.test_gpu_mlp import make, ref_mlp
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def tile():
+@pytest.fixture(params=[0, 7], ids=["chainw", "chainp"])
+def tile(request):
+    """Setter of the forced tile height; every test that takes it runs twice -- with the training passes of nets wider than 128
+    columns on mlp3w.hip's kernel (the default) and on the software-pipelined kernel (mlp3p.hip; `set_chain_pipeline(7)`)."""
     from ndjir_amd import mlp
-    old = mlp.get_tile_rows()
+    old, old_pipe = mlp.get_tile_rows(), mlp.get_chain_pipeline()
+    mlp.set_chain_pipeline(request.param)
     yield mlp.set_tile_rows
     mlp.set_tile_rows(old)
+    mlp.set_chain_pipeline(old_pipe)
 
 
 CASES = [
@@ -46,15 +51,42 @@ def test_forward_is_bitwise_the_64_point_kernel(gpu, tile, dims, P, skip):
     for rows in (64, 32, 128):
         tile(rows)
         y, hidden, am = chain_forward(x, Wd, bd, 100.0, skip, scale, keep_hidden=True)
+        y_ng, _, _ = chain_forward(x, Wd, bd, 100.0, skip, scale, keep_hidden=False)
         torch.cuda.synchronize()
-        res[rows] = (y.clone(), [h.clone() for h in hidden], am.clone())
+        res[rows] = (y.clone(), [h.clone() for h in hidden], am.clone(), y_ng.clone())
     y64 = ref_mlp(x.cpu().double(), [w.double() for w in Ws], [b.double() for b in bs], 100.0, skip, scale)
     assert float((res[128][0].cpu().double() - y64).norm() / y64.norm()) < 2e-6
     for other in (64, 32):
+        # (row-major side tensors: mlp3w.hip's kernel at 128 rows, bit-identical by construction; so is the pass without side tensors)
         assert torch.equal(res[128][0], res[other][0]), f"output differs from the {other}-point tiles"
+        assert torch.equal(res[128][3], res[other][3]) and torch.equal(res[128][3], res[128][0]), "pass without side tensors differs"
         for j, (h_w, h_o) in enumerate(zip(res[128][1], res[other][1])):
             assert torch.equal(h_w, h_o), f"stored activation {j + 1} differs from the {other}-point tiles"
         assert torch.equal(res[128][2], res[other][2]), "recorded maxima differ"
+    # the training pass with POINT-BLOCKED side tensors: nets wider than 128 columns run on the pipelined kernel (mlp3p.hip, one
+    # accumulator per block) -- equal to round-off; narrower nets stay on mlp3w.hip -- equal bit for bit
+    tile(128)
+    yb, hb, amb = chain_forward(x, Wd, bd, 100.0, skip, scale, keep_hidden=True, blocked=True)
+    torch.cuda.synchronize()
+    from ndjir_amd import mlp
+    wide = max(dims[1:-1]) > 128 and mlp.get_chain_pipeline() != 0
+
+    def unblock(t):          # element (p, f) of a point-blocked (P, W) buffer lives at ((p >> 5) * W + f) * 32 + (p & 31)
+        Pn, Wn = t.shape
+        return t.reshape(Pn // 32, Wn, 32).permute(0, 2, 1).reshape(Pn, Wn)
+
+    def rel(a_, b_):
+        return float((a_.double() - b_.double()).norm() / max(float(b_.double().norm()), 1e-30))
+    if wide:
+        assert rel(yb, res[64][0]) < 2e-6, rel(yb, res[64][0])
+        assert float((yb.cpu().double() - y64).norm() / y64.norm()) < 2e-6
+        for j, (h_b, h_o) in enumerate(zip(hb, res[64][1])):
+            assert rel(unblock(h_b), h_o) < 2e-6, (j, rel(unblock(h_b), h_o))
+        assert torch.allclose(amb, res[64][2], rtol=1e-5, atol=0)        # (recorded maxima: positive floats)
+    else:
+        assert torch.equal(yb, res[64][0])
+        for j, (h_b, h_o) in enumerate(zip(hb, res[64][1])):
+            assert torch.equal(unblock(h_b), h_o), j
 
 
 @pytest.mark.parametrize("dims,P,skip", CASES)
@@ -85,7 +117,11 @@ def test_gradients_match_fp64_and_the_64_point_kernel(gpu, tile, dims, P, skip):
     def rel(a, b):
         return float((a.detach().cpu().double() - b.detach().cpu().double()).norm() / max(float(b.norm()), 1e-30))
 
-    assert torch.equal(y_w, y_o)
+    from ndjir_amd import mlp
+    if max(dims[1:-1]) > 128 and mlp.get_chain_pipeline() != 0:      # (training pass of a net wider than 128 columns on the pipelined kernel: equal to round-off)
+        assert rel(y_w, y_o) < 2e-6, rel(y_w, y_o)
+    else:
+        assert torch.equal(y_w, y_o)
     names = ["x"] + [f"W{j}" for j in range(len(Ws))] + [f"b{j}" for j in range(len(bs))]
     for n, a, o, r in zip(names, g_w, g_o, g64):
         assert rel(a, r) < 2e-5, (n, rel(a, r))
@@ -148,7 +184,12 @@ def test_geometric_double_backward_on_the_wide_kernel(gpu, tile, grid):
         loss = (sdf * cot[0].to(gpu)).sum() + (feat * cot[1].to(gpu)).sum() + (n * cot[2].to(gpu)).sum()
         g = torch.autograd.grad(loss, Wd + bd + ([Fd] if grid else []))
         res[rows] = (sdf, feat, n, g)
-    assert torch.equal(res[128][0], res[64][0]) and torch.equal(res[128][1], res[64][1])
+    from ndjir_amd import mlp
+    if mlp.get_chain_pipeline() != 0:      # (the main pass at 128 rows is a training pass of a 256-wide net: the pipelined kernel -- equal to round-off)
+        for i in (0, 1):
+            assert float((res[128][i] - res[64][i]).norm()) <= 2e-6 * float(res[64][i].norm()), i
+    else:
+        assert torch.equal(res[128][0], res[64][0]) and torch.equal(res[128][1], res[64][1])
     assert float((res[128][2] - res[64][2]).abs().max()) <= 1e-5 * float(res[64][2].abs().max())
     for a, o in zip(res[128][3], res[64][3]):
         assert float((a - o).norm() / max(float(o.norm()), 1e-30)) < 2e-5
@@ -190,6 +231,13 @@ def test_tile_loop_forward_2100_tiles(gpu, tile, dims, skip):
     tile(64)
     y64, hidden64, _ = chain_forward(x, Wd, bd, 100.0, skip, scale, keep_hidden=True)
     assert torch.equal(y, y64) and all(torch.equal(a, b) for a, b in zip(hidden, hidden64))
+    # the same tile loop with point-blocked side tensors: nets wider than 128 columns on the pipelined kernel (mlp3p.hip)
+    tile(0)
+    yb, hb, _ = chain_forward(x, Wd, bd, 100.0, skip, scale, keep_hidden=True, blocked=True)
+    assert _rel64(yb, y64.double()) < 2e-6
+    for j, (a, b) in enumerate(zip(hb, hidden64)):
+        Pn, Wn = a.shape
+        assert _rel64(a.reshape(Pn // 32, Wn, 32).permute(0, 2, 1).reshape(Pn, Wn), b.double()) < 2e-6, j
 
 
 @pytest.mark.parametrize("dims,skip", [((259, 256, 256, 256, 3), -1), ((39, 128, 128, 128, 1), -1), ((262, 128, 128, 128, 6), -1)])

@@ -26,14 +26,28 @@ def tile_rows(request):
     mlp.set_tile_rows(old)
 
 
-@pytest.mark.parametrize("variant,G,tile_rows", [("default", 32, 0), ("no_voxel", 8, 0), ("triplaneline", 64, 0), ("custom", 32, 0),
-                                                  ("ste", 32, 0), ("default", 32, 128), ("no_voxel", 8, 128), ("triplaneline", 64, 128)],
-                         indirect=["tile_rows"])
-def test_step_parity_given_samples(gpu, variant, G, tile_rows):
+@pytest.fixture
+def chain_pipeline(request):
+    """Mode mask of the software-pipelined chain kernel (csrc/mlp3p.hip) for the test; 0 = mlp3w.hip's kernel (the default)."""
+    from ndjir_amd import mlp
+    old = mlp.get_chain_pipeline()
+    mlp.set_chain_pipeline(request.param)
+    yield request.param
+    mlp.set_chain_pipeline(old)
+
+
+@pytest.mark.parametrize("variant,G,tile_rows,chain_pipeline",
+                         [("default", 32, 0, 0), ("no_voxel", 8, 0, 0), ("triplaneline", 64, 0, 0), ("custom", 32, 0, 0),
+                          ("ste", 32, 0, 0), ("default", 32, 128, 0), ("no_voxel", 8, 128, 0), ("triplaneline", 64, 128, 0),
+                          ("default", 32, 128, 7), ("no_voxel", 8, 128, 7), ("custom", 32, 128, 7)],
+                         indirect=["tile_rows", "chain_pipeline"])
+def test_step_parity_given_samples(gpu, variant, G, tile_rows, chain_pipeline):
     """Renderer + loss + backward parity with the oracle fed the product's sample points.  `ste` = config/ste.yaml
     (`voxel.use_ste`: the grid lookups stay out of n = d(sdf)/dx, python/grid_feature/voxel_feature.py:383-399).
     tile_rows = 128: the same step with every chain launch (forward, backward, tangent; 4 096 sample points, 8 192 light
-    directions, 1 024 background samples -- all multiples of 128) on the 128-point-tile kernel."""
+    directions, 1 024 background samples -- all multiples of 128) on the 128-point-tile kernel; chain_pipeline = 7: the training
+    passes of the nets wider than 128 columns (geometric main pass incl. its tangent and augmented backward chains, base colour,
+    photogrammetric, background) on the software-pipelined kernel (csrc/mlp3p.hip: one accumulator per block)."""
     conf = small_conf(grid_size=G, n_rays=16, variant=variant)
     prod = run_product_step(conf, B=2, R=16, device=gpu)
     s = prod["samples"]

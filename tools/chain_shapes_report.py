@@ -9,11 +9,11 @@ groups, cur = [], None
 for r in rows:
     n = r["Kernel_Name"]
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    if re.search(r"k_chain[\dw]?<0,|k_mlp_chain<0,", n):
+    if re.search(r"k_chain[\dw]?<0,|k_chainp(_nets)?<0>|k_mlp_chain<0,", n):
         cur = {"fwd": d, "bwd": 0.0, "wgrad": 0.0, "other": 0.0}
         groups.append(cur)
     elif cur is not None:
-        if re.search(r"k_chain[\dw]?<1,|k_mlp_chain<1,", n): cur["bwd"] += d
+        if re.search(r"k_chain[\dw]?<1,|k_chainp(_nets)?<1>|k_mlp_chain<1,", n): cur["bwd"] += d
         elif "k_wgrad" in n: cur["wgrad"] += d
         elif "ndjir" in n: cur["other"] += d
 reps = len(groups) // len(names)

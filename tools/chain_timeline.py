@@ -48,6 +48,9 @@ def show(buf, L, title):
             print(f"  wave {w}: " + " ".join(f"{t[li, i, w] - t[li, 0].min():7d}" for i in range(5)))
 
 
+BLOCKED = bool(os.environ.get("TIMELINE_BLOCKED"))      # point-blocked side tensors: the pipelined kernel (mlp3p.hip) takes the launch
+
+
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "fwd"
     P = int(os.environ.get("TIMELINE_P", "65536"))      # (fewer points than 128 x CUs: NDJIR_MLP_TILE=128 keeps the 128-point-tile kernel)
@@ -61,19 +64,28 @@ def main():
     so.ndjir_mlp_debug_timeline.argtypes = [ctypes.c_void_p]
     if mode in ("fwd", "fwd_nostore"):
         keep = mode == "fwd"
-        chain_forward(x, Ws, bs, 100.0, 3, 0.7071, keep_hidden=keep)
+        chain_forward(x, Ws, bs, 100.0, 3, 0.7071, keep_hidden=keep, blocked=BLOCKED)
         torch.cuda.synchronize()
         so.ndjir_mlp_debug_timeline(buf.data_ptr())
         reps = int(os.environ.get("TIMELINE_REPS", "1"))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):      # > 1: stamps of the last of a back-to-back series
-            chain_forward(x, Ws, bs, 100.0, 3, 0.7071, keep_hidden=keep)
+            chain_forward(x, Ws, bs, 100.0, 3, 0.7071, keep_hidden=keep, blocked=BLOCKED)
         e1.record()
         torch.cuda.synchronize()
         print(f"{reps} launches: {e0.elapsed_time(e1) * 1e3 / reps:.1f} us per launch by HIP events")
         so.ndjir_mlp_debug_timeline(None)
         show(buf[:400], 8, "geometric net forward chain (43-256-256-256-213|+43-256-256-256-257), tile of 64 points")
+        if NREC >= 64 and BLOCKED and os.environ.get("TIMELINE_SUB"):
+            # diagnostic build of mlp3p.hip (-DNDJIR_CHAINP_SUBSTAMP): per-slot stamps of layer 2
+            sub = buf[400:400 + 72].cpu().numpy().reshape(4, 18).astype(np.int64)
+            for ph in range(2):
+                for wv in range(2):
+                    r = sub[ph * 2 + wv]
+                    if r[0] > 0:
+                        print(f"phase (2, {ph}) wave {4 * wv}: cycles per slot", " ".join(f"{int(b - a_):5d}" for a_, b in zip(r[:-1], r[1:-1] if False else r[1:17])))
+            return
         if NREC:
             rec = buf[400:].cpu().numpy().reshape(NREC, 3)
             t0 = rec[:, 0].min()
