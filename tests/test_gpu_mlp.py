@@ -406,6 +406,29 @@ def test_f16x3_is_at_least_as_accurate_as_an_fp32_fma_chain(gpu):
     assert e3 < 2e-6
 
 
+def test_pipelined_kernel_one_accumulator_accuracy(gpu):
+    """csrc/mlp3p.hip keeps ONE fp32 accumulator per block (hi hi' + hi lo' + lo hi' summed together, lo unscaled) where
+    mlp3.hip / mlp3w.hip keep two: the same 8-layer net (forward with stored activations, backward) on 128-point tiles with the
+    pipeline switched on, against fp64 and beside the strict-fp32 engine and the two-accumulator kernels -- its error may not
+    exceed the fp32 FMA chain's by more than a quarter."""
+    from ndjir_amd import mlp
+    old_tile, old_pipe = mlp.get_tile_rows(), mlp.get_chain_pipeline()
+    try:
+        mlp.set_tile_rows(128)
+        e32, g32 = _geo_net_error(gpu, mlp.MATH_FP32)
+        e3, g3 = _geo_net_error(gpu, mlp.MATH_F16X3)
+        mlp.set_chain_pipeline(7)
+        e3p, g3p = _geo_net_error(gpu, mlp.MATH_F16X3)
+    finally:
+        mlp.set_tile_rows(old_tile)
+        mlp.set_chain_pipeline(old_pipe)
+    print(f"\nforward error vs fp64: fp32 chain {e32:.2e}  f16x3 two accumulators {e3:.2e}  one accumulator (pipelined) {e3p:.2e}")
+    print(f"gradient errors (x, W0, W4): fp32 {g32}  two accumulators {g3}  one accumulator {g3p}")
+    assert e3p <= 1.25 * e32 and e3p < 2e-6, (e3p, e32)
+    for a, b in zip(g3p, g32):
+        assert a <= 1.25 * b, (g3p, g32)
+
+
 @pytest.mark.parametrize("spread", [1e-6, 1e6])
 def test_f16x3_scaling_groups(gpu, spread):
     """Rows of very different magnitude in one tile (the activations of a tile share one power-of-two scale) and weight
