@@ -533,6 +533,11 @@ int ndjir_mlp_get_tile_rows(void);
  * That kernel keeps ONE fp32 accumulator per block: its results agree with the other f16x3 kernels to round-off (2e-6), not bit
  * for bit -- passes without side tensors (the sampler's SDF rounds, the SDF volume, render_image) never run on it.  NDJIR_CHAINP
  * sets the initial value. */
+/* y (P, N; row stride ldy) = x (P, K; ldx) W (K, N; ldw) + bias (may be null); transpose != 0: y = x W^T with W (N, K; ldw).  For
+ * FEW rows (the per-ray terms of the first layers of python/network.py:438, 528, 619 and their input gradients): exact fp32
+ * products (v_mfma_f32_32x32x2_f32), one wave per 32 x 32 output tile, operands read where they lie -- no packed weights. */
+int ndjir_mlp_small_affine(long long P, const float* x, int ldx, int K, const float* W, int ldw, int N, int transpose,
+                           const float* bias, float* y, int ldy, hipStream_t stream);
 int ndjir_mlp_set_chain_pipeline(int mask);
 int ndjir_mlp_get_chain_pipeline(void);
 long long ndjir_mlp_packed_size(int K, int N, int transpose);

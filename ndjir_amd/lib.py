@@ -108,6 +108,7 @@ SIGS = {
     "sparse_rows_overflow": "qiiqqi",
     "sparse_rows_zero": "qqiiqiqqpi",
     "sparse_rows_zero_if_dropped": "qipl",
+    "mlp_small_affine": "lpiipiiippi",
     "generate_raydir_camloc": "iixxqpipp",
     "solver_adam_begin": "xffqq",
     # n w g m v alpha_t beta1 beta2 eps decay zero_grad state

@@ -1373,12 +1373,23 @@ class MultiMLP(Function):
 #   MatMul(x, W, t)   y = x W^T if t else x W      one-layer chain launch on the packed (transposed) weights
 #   WGradOp(a, b)     Z = a^T b                    the weight-gradient kernel (reduction over the points)
 #   ColSumOp(g)       column sums                  the bias gradient
+SMALL_AFFINE_ROWS = int(os.environ.get("NDJIR_SMALL_AFFINE_ROWS", "4096"))      # launches of `linear` up to this many rows skip the chain kernel
+_NO_SMALL_AFFINE = bool(os.environ.get("NDJIR_NO_SMALL_AFFINE"))
+
+
 def _mm(x2, W, transpose, bias=None):
     P_, K = x2.shape
     N = W.shape[0] if transpose else W.shape[1]
     assert (W.shape[1] if transpose else W.shape[0]) == K, (tuple(x2.shape), tuple(W.shape), transpose)
     y = torch.empty((P_, N), device=x2.device, dtype=torch.float32)
     if P_ == 0:
+        return y
+    if (P_ <= SMALL_AFFINE_ROWS and x2.is_cuda and W.dim() == 2 and W.stride(1) == 1 and (bias is None or bias.is_contiguous())
+            and not _NO_SMALL_AFFINE):
+        # few rows (the per-ray terms of the first layers, their input gradients): one wave per 32 x 32 output tile on the fp32
+        # matrix instruction, straight from the unpacked weight -- the chain kernel runs such a launch on 16 CUs in 17 - 38 us
+        _launch("affine_small", 2.0 * P_ * K * N, "mlp_small_affine", P_, x2, x2.shape[1], K, _Strided(W.detach()), W.stride(0), N,
+                int(bool(transpose)), bias.detach() if bias is not None else None, y, N, shape=f"{P_}:{K}-{N}")
         return y
     _launch("chain_fwd", 2.0 * P_ * K * N, "mlp_chain", 0, P_, x2, x2.shape[1], K, 1, [_packed(W, bool(transpose))],
             [bias.detach() if bias is not None else None], [K], [N], [None], [None], [0], [None], y, N, 0, 1, 100.0, -1, 1.0, 0,

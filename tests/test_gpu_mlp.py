@@ -406,6 +406,30 @@ def test_f16x3_is_at_least_as_accurate_as_an_fp32_fma_chain(gpu):
     assert e3 < 2e-6
 
 
+@pytest.mark.parametrize("P,K,N", [(1, 27, 256), (37, 128, 262), (512, 262, 128), (512, 30, 1), (4096, 129, 33)])
+@pytest.mark.parametrize("transpose", [False, True])
+def test_small_affine_kernel(gpu, P, K, N, transpose):
+    """`linear` on few rows (csrc/affine.hip: the per-ray terms of python/network.py:438, 528, 619 and their input gradients):
+    ragged tiles in every dimension, odd K (a k-step of 2 with one half past the end), a weight that is a block of ROWS of a wider
+    parameter's column range (row stride > width), bias, both orientations -- against fp64, and the chain kernel's result for the
+    same call beside it."""
+    from ndjir_amd import lib, mlp
+    rng = np.random.RandomState(P + K + N)
+    x = torch.tensor(rng.randn(P, K), dtype=torch.float32, device=gpu)
+    Wfull = torch.tensor(rng.randn(K + 5, N + 7) if not transpose else rng.randn(N + 5, K + 7), dtype=torch.float32, device=gpu) / np.sqrt(K)
+    W = Wfull[2:2 + K, 3:3 + N] if not transpose else Wfull[2:2 + N, 3:3 + K]           # column stride 1, row stride > width
+    b = torch.tensor(rng.randn(N), dtype=torch.float32, device=gpu)
+    ref = x.double() @ (W.double().t() if transpose else W.double()) + b.double()
+    y = torch.full((P, N), float("nan"), device=gpu)
+    lib.call("mlp_small_affine", P, x, K, K, mlp._Strided(W), W.stride(0), N, int(transpose), b, y, N)
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * np.sqrt(K)
+    assert float((y.double() - ref).norm() / ref.norm()) < 1e-6
+    # the path `linear` takes for this many rows, with and without the switch
+    assert P <= mlp.SMALL_AFFINE_ROWS
+    y2 = mlp._mm(x, W, transpose, b)
+    assert torch.equal(y2, y)
+
+
 def test_pipelined_kernel_one_accumulator_accuracy(gpu):
     """csrc/mlp3p.hip keeps ONE fp32 accumulator per block (hi hi' + hi lo' + lo hi' summed together, lo unscaled) where
     mlp3.hip / mlp3w.hip keep two: the same 8-layer net (forward with stored activations, backward) on 128-point tiles with the
