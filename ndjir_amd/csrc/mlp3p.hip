@@ -90,15 +90,6 @@ __device__ __forceinline__ gptr<T> upin(T* p) {
   return (gptr<T>)reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
-// An empty asm statement makes a value opaque at this point of the program: it is ordered with the slot boundaries
-// (`sched_barrier`, themselves ordered side effects), so the arithmetic that consumes the value cannot be hoisted out of its slot
-// when the block is linearised -- a pure instruction has no other tie to the place it was written (seen: the fused multiply-adds
-// of all sixteen values of a block issued ahead of the first slot, 40 more live registers).
-__device__ __forceinline__ float here(float v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-
 // single operations that must not be contracted into fused multiply-adds (the forward expressions of mlp3_util.h, taken apart
 // so that their pieces can be placed between the MFMAs of a slot)
 __device__ __forceinline__ float add_nc(float a, float b) {
@@ -329,7 +320,6 @@ __device__ __forceinline__ void chainp_body(const NETS nets) {
       const int NBE = lyE.Np >> 5;
       const bool activeE = doE && nb < NBE;
       const gptr<const float> p_winv = upin(lyE.Wp + (long long)((lyE.Kp + 15) >> 4) * 16 * lyE.Np);
-      const gptr<const float> p_bias = upin(lyE.bias);
       const gptr<const float> p_rowbias = upin((MODE == 0 && liE == 0) ? a.row_bias : nullptr);
       const int rb_div = pin(a.row_bias_div > 0 ? a.row_bias_div : 1);
       const gptr<const float> p_side_in = upin(lyE.side_in);
