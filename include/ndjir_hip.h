@@ -124,6 +124,11 @@ int ndjir_sparse_rows_zero(const int* ids, const int* counts, int world, int cap
  * to drop cells its list had no room for (those hold gradient no list names; the step that dropped them is vetoed through
  * ndjir_sparse_rows_overflow).  One int read otherwise. */
 int ndjir_sparse_rows_zero_if_dropped(const int* own_count, int capacity, float* grad_feature, long long n, hipStream_t stream);
+/* round 6: the dense-voxel query of python/network.py:120-151 fused with the positional encoding of :96-117 -- rows
+ * e[p] = [x, cos(x_d 2^k), sin(x_d 2^k), feature(p)] (row stride lde >= 3 + 6 M + D) of N points in one launch; interp 0 linear /
+ * 1 cosine / 2 Lanczos; values bit-identical to <family>_query followed by ndjir_geo_encode */
+int ndjir_voxel_feature_query_encode(int N, int M, const float* query, const float* feature, const int* grid_sizes, int D,
+                                     const float* min, const float* max, int interp, float* e, int lde, hipStream_t stream);
 NDJIR_DECL_VOXEL_FAMILY(cosine_voxel_feature)
 NDJIR_DECL_VOXEL_FAMILY(lanczos_voxel_feature)
 

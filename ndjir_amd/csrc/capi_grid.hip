@@ -141,6 +141,14 @@ extern "C" int ndjir_voxel_feature_grad_query_grad_query(int N, float* gq, const
 }
 // No reference counterpart (the reference zero-fills gradients densely): zero only the cells the N query
 // points touch in an accumulate-in-place gradient buffer of the linear dense voxel grid.
+// [x | cos | sin | voxel feature] rows of the geometric net's input in one launch (interp 0 linear / 1 cosine / 2 Lanczos)
+extern "C" int ndjir_voxel_feature_query_encode(int N, int M, const float* query, const float* feature, const int* gs, int D,
+                                                const float* mn, const float* mx, int interp, float* e, int lde, hipStream_t st) {
+  if (N <= 0) return NDJIR_OK;
+  if (!query || !feature || !gs || !mn || !mx || !e || M < 0 || M > 30 || D < 1 || lde < 3 + 6 * M + D) return NDJIR_ERR_ARG;
+  return launch_voxel_query_encode(interp, voxel_desc(gs, D, mn, mx), N, M, query, feature, e, lde, st);
+}
+
 extern "C" int ndjir_voxel_feature_zero_touched(int N, float* gf, const float* query, const int* gs, int D, const float* mn,
                                                 const float* mx, hipStream_t st) {
   if (N <= 0) return NDJIR_OK;

@@ -249,6 +249,47 @@ __global__ void __launch_bounds__(256) k_query(long long P, float* __restrict__ 
   NDJIR_GRID_THREAD_EPILOGUE
 }
 
+// Dense voxel forward FUSED with the geometric net's input encoding (round 6; python/network.py:96-117 + :120-151 in one launch):
+// e[p] = [x, cos(x_d 2^k) (d major, k fastest), sin(...), voxel feature of p], row stride lde -- what k_query + k_geo_encode
+// (csrc/geo.hip) produce in two launches and an intermediate (P, D) tensor; the sampler's rounds of 8 192 points are bound by
+// launch latency, not by bytes.  One lane per (point, column); a feature column accumulates its taps in k_query's order with
+// k_query's weights: bit-identical values.
+template <int I>
+__global__ void __launch_bounds__(256) k_voxel_query_encode(long long P, int M, const float* __restrict__ query,
+                                                            const float* __restrict__ feature, GridDesc g, float* __restrict__ e,
+                                                            int lde) {
+  constexpr int TOPO = VOXEL, ND = 3, NT = NTaps<I>::v;
+  const int npe = 3 + 6 * M, W = npe + g.D;
+  const long long total = P * W;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long p = t / W;
+    int c = (int)(t - p * W);
+    const int c_out = c;
+    float v;
+    if (c < 3) v = query[p * 3 + c];
+    else if (c < npe) {
+      c -= 3;
+      const bool is_sin = c >= 3 * M;
+      if (is_sin) c -= 3 * M;
+      const float b = query[p * 3 + c / M] * (float)(1 << (c % M));
+      v = is_sin ? sinf(b) : cosf(b);
+    } else {
+      const int d = c - npe;
+      const float q[3] = {query[p * 3], query[p * 3 + 1], query[p * 3 + 2]};
+      Stencil<TOPO, I> st;
+      make_stencil<TOPO, I>(st, g, 0, q);
+      float acc = 0.f;
+      NDJIR_FOR_TAPS(ND, NT) {
+        const float f = feature[cell_offset(st, i, j, k) + d];
+        const float w = tap_w(st, i, j, k);
+        acc += w * f;
+      }
+      v = acc;
+    }
+    e[p * lde + c_out] = v;
+  }
+}
+
 // Tri-plane / tri-line forward, one lane per POINT: the three sub-grids of a point are gathered by the same lane, which then
 // owns the point's whole output row (D, 3) -- D * 3 contiguous floats, written as 16-byte stores.  (k_query's lane per
 // (sub-grid, point) stores D scalars at a stride of 12 bytes into rows that three lanes of different workgroups share:
@@ -1235,6 +1276,18 @@ int launch_pack_rows(int interp, const GridDesc& g, long long P, const float* gf
     else hipLaunchKernelGGL((k_pack_rows<TOPO, I, 2>), dim3(blocks), dim3(256), 0, stream, P, gf, query, g, bitmap, ids,
                             reinterpret_cast<float4*>(rows), count, capacity);
   })
+  return ndjir_check_launch();
+}
+
+int launch_voxel_query_encode(int interp, const GridDesc& g, long long P, int M, const float* query, const float* feature, float* e,
+                              int lde, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  if (g.topo != VOXEL) return NDJIR_ERR_UNSUPPORTED;
+  const int blocks = grid_blocks(P * (3 + 6 * M + g.D));
+  if (interp == LINEAR) hipLaunchKernelGGL((k_voxel_query_encode<LINEAR>), dim3(blocks), dim3(256), 0, stream, P, M, query, feature, g, e, lde);
+  else if (interp == COSINE) hipLaunchKernelGGL((k_voxel_query_encode<COSINE>), dim3(blocks), dim3(256), 0, stream, P, M, query, feature, g, e, lde);
+  else if (interp == LANCZOS) hipLaunchKernelGGL((k_voxel_query_encode<LANCZOS>), dim3(blocks), dim3(256), 0, stream, P, M, query, feature, g, e, lde);
+  else return NDJIR_ERR_UNSUPPORTED;
   return ndjir_check_launch();
 }
 

@@ -34,6 +34,9 @@ from .mlp import _launch, _packed, _Strided, amax_slots, blocked_layout, chain_w
 
 
 
+_NO_QUERY_ENCODE = bool(__import__("os").environ.get("NDJIR_NO_QUERY_ENCODE"))      # A/B: the voxel query and the input encoding as two launches
+
+
 def _enc_call(fam, name, P, C, *args):
     """entry point `name` of grid family `fam` (N = P * channels for the dense families)"""
     lib.call(f"{fam.prefix}_{name}", P * C, *args)
@@ -87,18 +90,25 @@ class GeometricMain(Function):
         enc = []                                           # (family, feature, shape args, channels, first column in e)
         col = npe = 3 + 6 * M
         segs = []
+        # one dense voxel grid (default / custom / ste): query and encoding in ONE launch, no intermediate (P, D) tensor
+        fused_enc = NG == 1 and fams[0].topo == "voxel" and not _NO_QUERY_ENCODE
         for fam, feat in zip(fams, grids):
             fd = feat.detach().contiguous()
             C = fam.channels(fd.shape, None)
             sa = fam.shape_args(fd.shape, None)
-            vf = torch.empty((P, C), device=dev, dtype=torch.float32)
-            _enc_call(fam, fam.fwd, P, C, vf, xf, fd, *sa, min_, max_, 0)
-            segs.append(vf)
+            if not fused_enc:
+                vf = torch.empty((P, C), device=dev, dtype=torch.float32)
+                _enc_call(fam, fam.fwd, P, C, vf, xf, fd, *sa, min_, max_, 0)
+                segs.append(vf)
             enc.append((fam, fd, sa, C, col))
             col += C
         K0 = col
         e = torch.empty((P, K0), device=dev, dtype=torch.float32)          # A_0 = [x, cos, sin, grid features]
-        lib.call("geo_encode", P, M, xf, len(segs), segs, [t.shape[1] for t in segs], e, K0)
+        if fused_enc:
+            fam, fd, sa, C, _ = enc[0]
+            lib.call("voxel_feature_query_encode", P, M, xf, fd, *sa, min_, max_, _core.interp_code(fam), e, K0)
+        else:
+            lib.call("geo_encode", P, M, xf, len(segs), segs, [t.shape[1] for t in segs], e, K0)
 
         # ---- forward chain ----
         Ks = [w.shape[0] for w in W]

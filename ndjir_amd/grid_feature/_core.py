@@ -141,6 +141,12 @@ class Family:
         return t.view(-1, P).t().contiguous() if self.topo == "hash" else t
 
 
+def interp_code(fam):
+    """0 linear / 1 cosine / 2 Lanczos: the interpolation of a family, as the entry points that take it as an argument count it
+    (ndjir_grid_pack_rows, ndjir_voxel_feature_query_encode)."""
+    return 1 if fam.prefix.startswith("cosine_") else 2 if fam.prefix.startswith("lanczos_") else 0
+
+
 def _flat(query):
     return query.detach().reshape(-1, 3).contiguous()
 

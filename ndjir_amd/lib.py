@@ -99,6 +99,7 @@ SIGS = {
     "squareplus_forward": "ippf",
     "squareplus_backward": "ipppfi",
     "voxel_feature_zero_touched": "ippIiFF",
+    "voxel_feature_query_encode": "iippIiFFipi",
     "voxel_feature_zero_touched_interp": "ippIiFFi",
     "voxel_feature_check_touched": "ippIiFFq",
     "voxel_feature_pack_rows": "ippIiFFqqpqi",

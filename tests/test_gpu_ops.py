@@ -588,3 +588,29 @@ def test_pixel_normal_matches_composite(gpu):
     w = torch.randn_like(ref)
     (a,), (b,) = torch.autograd.grad(out, [g32], w.float()), torch.autograd.grad(ref, [g64], w)
     assert float((a.double() - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("family", ["voxel", "cosine_voxel", "lanczos_voxel"])
+def test_voxel_query_encode_equals_query_then_encode(gpu, family):
+    """ndjir_voxel_feature_query_encode (csrc/grid.hip `k_voxel_query_encode`): the rows [x | cos | sin | feature] of the
+    geometric net's input in one launch -- bit for bit what <family>_query followed by ndjir_geo_encode produce (points inside,
+    on and outside the box; a ragged grid; a row stride wider than the row)."""
+    from ndjir_amd import lib
+    from ndjir_amd.grid_feature import _core
+    rng = np.random.RandomState(5)
+    P, M, D = 3000, 6, 4
+    gs = [9, 16, 12]
+    x = torch.tensor(rng.rand(P, 3) * 2.6 - 1.3, dtype=torch.float32, device=gpu)
+    x[:3] = torch.tensor([[-1.0, 1.0, 0.0], [1.0, -1.0, 1.0], [0.0, 0.0, 0.0]], device=gpu)
+    F = torch.tensor(rng.randn(*gs, D), dtype=torch.float32, device=gpu)
+    fam = _core.FAMILIES[family]
+    vf = torch.empty((P, D), device=gpu)
+    lib.call(f"{fam.prefix}_{fam.fwd}", P * D, vf, x, F, gs, D, [-1.0] * 3, [1.0] * 3, 0)
+    W = 3 + 6 * M + D
+    want = torch.empty((P, W), device=gpu)
+    lib.call("geo_encode", P, M, x, 1, [vf], [D], want, W)
+    lde = W + 5
+    got = torch.full((P, lde), float("nan"), device=gpu)
+    lib.call("voxel_feature_query_encode", P, M, x, F, gs, D, [-1.0] * 3, [1.0] * 3, _core.interp_code(fam), got, lde)
+    assert torch.equal(got[:, :W], want)
+    assert torch.isnan(got[:, W:]).all()
