@@ -151,6 +151,39 @@ def _flat(query):
     return query.detach().reshape(-1, 3).contiguous()
 
 
+class QueryEncode(Function):
+    """Rows [x | cos(x_d 2^k) | sin(x_d 2^k) | feature(x)] of the geometric network's input (python/network.py:96-117 + 120-151)
+    for a dense voxel family and a query that needs NO gradient, as ONE launch (`ndjir_voxel_feature_query_encode`, bit-identical
+    to the family's query followed by the encoding).  Backward: d/dfeature of the feature columns, as `Query`'s."""
+
+    @staticmethod
+    def forward(ctx, query, feature, fam, M, min_, max_):
+        assert fam.topo == "voxel" and feature.dim() == 4 and query.shape[-1] == 3
+        q = _flat(query)
+        f = feature.detach().contiguous()
+        P, D = q.shape[0], feature.shape[-1]
+        W = 3 + 6 * int(M) + D
+        out = torch.empty((P, W), device=q.device, dtype=torch.float32)
+        lib.call("voxel_feature_query_encode", P, int(M), q, f, list(f.shape[:3]), D, list(min_), list(max_), interp_code(fam), out, W)
+        ctx.save_for_backward(query, feature)
+        ctx.cfg = (fam, int(M), tuple(min_), tuple(max_))
+        return out.view(query.shape[:-1] + (W,))
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        query, feature = ctx.saved_tensors
+        fam, M, min_, max_ = ctx.cfg
+        gf = None
+        if ctx.needs_input_grad[1] and not _MODE["nn_grad"]:      # (nn.grad: the registered backward never touches the feature)
+            go = grad_output[..., 3 + 6 * M:].contiguous()
+            gf = GradFeature.apply(go, query, feature, fam, min_, max_, False, None)
+        return None, gf, None, None, None, None
+
+
+def query_encode(family, query, feature, M, min_=(-1, -1, -1), max_=(1, 1, 1)):
+    return QueryEncode.apply(query, feature, FAMILIES[family], int(M), tuple(float(v) for v in min_), tuple(float(v) for v in max_))
+
+
 class Query(Function):
     @staticmethod
     def forward(ctx, query, feature, fam, min_, max_, use_ste, boundary_check, hcfg):

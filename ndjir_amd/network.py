@@ -258,18 +258,15 @@ def geometric_network(x, conf, first_order_only=False, sdf_only=False, packed=Fa
         skip_layers = list(g.skip_layers)
         v = g.voxel
 
-        # nothing to differentiate and one dense voxel grid (the sampler's rounds, mesh extraction): query + encoding in one launch
+        # one dense voxel grid and a query that needs no gradient (the sampler's rounds, mesh extraction, the perturbed pass of
+        # python/renderer.py:186-193): query + encoding in one launch (differentiable w.r.t. the grid)
         vfeat = None
         fused_in = None
         fparam = P.get_parameters().get("geometric-network/voxel_feature/F") if v.type.endswith("voxel") else None
         if (fparam is not None and x.is_cuda and x.dtype == torch.float32 and M > 0 and x.shape[-1] == 3 and g.geometric_init
-                and not x.requires_grad and not torch.is_grad_enabled() and fparam.dim() == 4 and not _NO_QUERY_ENCODE):
+                and not x.requires_grad and fparam.dim() == 4 and not _NO_QUERY_ENCODE):
             from .grid_feature import _core
-            fam = _core.FAMILIES[v.type]
-            Kin = 3 + 6 * M + fparam.shape[-1]
-            fused_in = torch.empty(x.shape[:-1] + (Kin,), device=x.device, dtype=torch.float32)
-            lib.call("voxel_feature_query_encode", fused_in.numel() // Kin, M, x.detach().reshape(-1, 3).contiguous(), fparam.detach(),
-                     list(fparam.shape[:3]), fparam.shape[-1], [-1.0, -1.0, -1.0], [1.0, 1.0, 1.0], _core.interp_code(fam), fused_in, Kin)
+            fused_in = _core.query_encode(v.type, x, fparam, M)
         else:
             vfeat = query_on_grid(x, v.grid_size, v.feature_size, v.use_ste, v.type)
         if fused_in is not None:
