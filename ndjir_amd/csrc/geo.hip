@@ -110,6 +110,40 @@ __global__ void __launch_bounds__(256) k_geo_bwd_begin(long long P, int D, const
   }
 }
 
+// The same with D % 4 == 0 (the 256 feature channels): one lane per 16 bytes of the feature block -- the rows of gy (1 + D floats)
+// and of gZ start at odd float offsets, so the vectors are 4-byte aligned (correct on gfx950, within 10 % of the aligned rate:
+// tools/ubench/unaligned.hip) -- plus one lane for the sdf column and three for n-bar: 136 MB moved in ~35 instead of 64 us.
+typedef float geo_f4 __attribute__((ext_vector_type(4)));
+typedef geo_f4 geo_f4u __attribute__((aligned(4)));
+__global__ void __launch_bounds__(256) k_geo_bwd_begin_v4(long long P, int D, const float* __restrict__ g_sdf,
+                                                          const float* __restrict__ g_feat, int ldf, const float* __restrict__ g_n,
+                                                          const float* __restrict__ gZ, int ldz, float* __restrict__ gy,
+                                                          float* __restrict__ nbar) {
+  const int V = D >> 2, W = V + 4;                 // work items per row: V vectors, the sdf column, three n-bar components
+  const long long total = P * W;
+  RowCol rc((long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, W);
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256, rc.next()) {
+    const long long p = rc.p;
+    const int c = rc.c;
+    if (c < V) {
+      geo_f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (g_feat) v = *reinterpret_cast<const geo_f4u*>(g_feat + p * ldf + 4 * c);
+      if (gZ) {
+        const geo_f4 z = *reinterpret_cast<const geo_f4u*>(gZ + p * ldz + 3 + 4 * c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += z[q];
+      }
+      *reinterpret_cast<geo_f4u*>(gy + p * (1 + D) + 1 + 4 * c) = v;
+    } else if (c == V) gy[p * (1 + D)] = g_sdf ? g_sdf[p] : 0.f;
+    else if (nbar) {
+      const int d = c - V - 1;
+      float v = g_n ? g_n[p * 3 + d] : 0.f;
+      if (gZ) v += gZ[p * ldz + 3 + D + d];
+      nbar[p * 3 + d] = v;
+    }
+  }
+}
+
 // g-bar_0 = J_e(x) n-bar: [nbar | -sin(b) nbar_d 2^k | cos(b) nbar_d 2^k | ggo_0 | ggo_1 ...]
 __global__ void __launch_bounds__(256) k_geo_gbar0(long long P, int M, const float* __restrict__ e, int lde,
                                                    const float* __restrict__ nbar, GeoSegs s, float* __restrict__ gb0, int W) {
@@ -218,8 +252,12 @@ extern "C" int ndjir_geo_backward_begin(long long P, int D, const float* g_sdf, 
                                         const float* gZ, int ldz, float* gy, float* nbar, hipStream_t stream) {
   if (P <= 0) return NDJIR_OK;
   if (D < 0 || !gy || (g_feat && ldf < D) || (gZ && ldz < 6 + D)) return NDJIR_ERR_ARG;
-  hipLaunchKernelGGL(k_geo_bwd_begin, dim3(geo_blocks(P * (4 + D))), dim3(256), 0, stream, P, D, g_sdf, g_feat, ldf, g_n, gZ, ldz,
-                     gy, nbar);
+  if (D > 0 && (D & 3) == 0)
+    hipLaunchKernelGGL(k_geo_bwd_begin_v4, dim3(geo_blocks(P * (4 + D / 4))), dim3(256), 0, stream, P, D, g_sdf, g_feat, ldf, g_n, gZ,
+                       ldz, gy, nbar);
+  else
+    hipLaunchKernelGGL(k_geo_bwd_begin, dim3(geo_blocks(P * (4 + D))), dim3(256), 0, stream, P, D, g_sdf, g_feat, ldf, g_n, gZ, ldz,
+                       gy, nbar);
   return ndjir_check_launch();
 }
 

@@ -557,6 +557,13 @@ def test_geometric_glue_kernels(gpu):
     assert torch.equal(gy[:, 0], g_sdf) and torch.equal(gy[:, 1:], g_feat + gZ[:, 3:3 + D]) and torch.equal(nbar, g_n + gZ[:, 3 + D:6 + D])
     lib.call("geo_backward_begin", P, D, None, None, 0, None, gZ, ldz, gy, nbar)
     assert float(gy[:, 0].abs().max()) == 0.0 and torch.equal(gy[:, 1:], gZ[:, 3:3 + D]) and torch.equal(nbar, gZ[:, 3 + D:6 + D])
+    # ... and with a channel count that is not a multiple of 4 (the scalar kernel; D = 16 above takes 16-byte vectors at 4-byte alignment)
+    D2 = 7
+    ldz2 = (3 + D2 + 3 + 1 + 3) // 4 * 4
+    g_feat2, gZ2 = r(P, D2 + 2), r(P, ldz2)
+    gy2, nbar2 = torch.empty(P, 1 + D2, device=gpu), torch.empty(P, 3, device=gpu)
+    lib.call("geo_backward_begin", P, D2, g_sdf, _Strided(g_feat2[:, :D2]), D2 + 2, g_n, gZ2, ldz2, gy2, nbar2)
+    assert torch.equal(gy2[:, 0], g_sdf) and torch.equal(gy2[:, 1:], g_feat2[:, :D2] + gZ2[:, 3:3 + D2]) and torch.equal(nbar2, g_n + gZ2[:, 3 + D2:6 + D2])
 
     gb0 = torch.empty(P, K0, device=gpu)
     lib.call("geo_gbar0", P, M, e, K0, nbar, 2, [f0, f1], [C0, C1], gb0)
