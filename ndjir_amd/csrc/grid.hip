@@ -552,45 +552,58 @@ __global__ void __launch_bounds__(256) k_scatter(long long P, float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same scatters for the linear stencils with D = 4, pre-aggregated per workgroup.  The fp32 atomics
-// of a scatter resolve in the memory-side cache (the 8 XCD L2s are not coherent) at a rate that bounds
-// the kernel; consecutive lanes are consecutive samples of a ray, which revisit cells (runs inside a
-// cell, and 4 of 8 corners shared with the next cell).  Each workgroup therefore accumulates its 256
-// points x 8 corners in an LDS hash table (cell -> float4, LDS atomics) and issues one global atomic
-// per distinct cell and channel.
+// The same scatters for the dense topologies, pre-aggregated per workgroup.  The fp32 atomics of a scatter resolve in
+// the memory-side cache (the 8 XCD L2s are not coherent) at a rate that bounds the kernel, and that rate is per REQUEST
+// of up to 64 contiguous, 64-byte-aligned bytes, not per float (tools/ubench/atomics_shape.hip, profiles/r06_ubench.txt:
+// 20 G requests/s at 4 ... 64 bytes, bytes-bound beyond).  A stencil is a set of RUNS along the fastest axis -- 2 (linear)
+// or 4 (Lanczos) consecutive cells of D floats, 32 ... 128 contiguous bytes -- and consecutive samples of a ray revisit
+// cells.  Each workgroup therefore accumulates its points in an LDS hash table whose entries are the 64-byte-aligned
+// blocks of the gradient tensor (LDS atomics), and flushes every touched block with one lane per float: one request
+// per block.  Per point that is 4 x 1.25 requests (linear voxel, D = 4) instead of 8, 16 x 1.75 instead of 64 (Lanczos).
 // ------------------------------------------------------------------------------------------------
-constexpr int AGG_HT = 4096;      // slots; at most 2048 insertions per pass: 256 lanes x taps x D / 4 (voxel D = 4: 8 taps;
-                                  // tri-plane D <= 8: 4 taps x 2; tri-line D <= 8: 2 taps x 2)
+#ifndef NDJIR_AGG_ENT
+#define NDJIR_AGG_ENT 256
+#endif
+constexpr int AGG_ENT = NDJIR_AGG_ENT;     // table entries of 16 floats.  Best effort: a run that finds no slot within 8 probes is listed
+                                           // and flushed as it is (spread points have nothing to merge anyway); the table is kept
+                                           // small because a pass clears and scans all of it (1024 entries: 26 us per launch of the
+                                           // step's 65 536 points, 256: 16 us, 128: 35 us -- profiles/r06_scatter.txt)
+constexpr int AGG_OVER = 1024;             // list capacity in float4 chunks: the launcher keeps lanes x chunks per run within it
 
-// Points per pass and workgroup: as many as keep the table at most half full in the worst case (every tap of every
-// point a distinct cell): 2048 / (taps x float4 chunks per cell).  Linear: 256 (voxel, 8 taps) ; Lanczos voxel (64 taps): 32
-// -- its 4 x 4 x 4 neighbourhoods of consecutive ray samples overlap almost completely, which is exactly what the
-// table removes (3.4 ms -> see DESIGN 3.3).
+template <int NT, class T>
+__device__ __forceinline__ T pick_tap(const T (&a)[NT], int i) {      // selected, not indexed: the taps live in registers
+  if constexpr (NT == 2) return i == 0 ? a[0] : a[1];
+  else return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3];
+}
+
+// One lane per RUN: LPP = NT^(ND - 1) lanes share a point (4 linear voxel, 16 Lanczos voxel, 2 tri-plane, 1 tri-line), every
+// one of them evaluates the point's stencil and keeps its own (i, j); ppp = points per pass and workgroup (<= 256 / LPP).
 template <int TOPO, int I, int MODE>
 __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restrict__ gf, const float* __restrict__ gg_query,
                                                      const float* __restrict__ grad_output, const float* __restrict__ query,
                                                      GridDesc g, int ppp) {
   constexpr int ND = NDims<TOPO>::v, NT = NTaps<I>::v;
-  __shared__ int keys[AGG_HT];
-  __shared__ float vals[AGG_HT * 4];
+  constexpr int LPP = ND == 3 ? NT * NT : (ND == 2 ? NT : 1);
+  __shared__ int keys[AGG_ENT];
+  __shared__ float vals[AGG_ENT * 16];
+  __shared__ int over_key[AGG_OVER];         // float4 chunks that found no slot: chunk index in gf (-1: none) ...
+  __shared__ float over_val[AGG_OVER * 4];   // ... and value
+  __shared__ int n_over;
   const long long total = P * g.S;
   const long long per_pass = (long long)gridDim.x * ppp;
-  const int cw_log = (g.D == 8) ? 1 : 0;          // float4 chunks per table entry = 1 << cw_log
+  const int D4 = g.D >> 2;
+  for (int t = threadIdx.x; t < AGG_OVER; t += 256) over_key[t] = -1;
+  if (threadIdx.x == 0) n_over = 0;
+  // blocks are aligned in MEMORY, not relative to gf (a gradient tensor may be a slice of a flat buffer); a base that is not
+  // 16-byte aligned keeps the relative blocks -- still correct, a float4 chunk must not straddle two entries
+  int a0 = (int)((reinterpret_cast<uintptr_t>(gf) >> 2) & 15);
+  if (a0 & 3) a0 = 0;
   for (long long base = (long long)blockIdx.x * ppp; base < total; base += per_pass) {   // uniform per workgroup
-    for (int t = threadIdx.x; t < AGG_HT; t += 256) {
-      keys[t] = -1;
+    for (int t = threadIdx.x; t < AGG_ENT * 4; t += 256) {
+      if (t < AGG_ENT) keys[t] = -1;
       *reinterpret_cast<float4*>(vals + 4 * t) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    // Lanes per point.  The 4 x 4 x 4 Lanczos stencil leaves room for 32 points per pass (table half full in the worst case):
-    // with one lane per point, 224 of the workgroup's 256 lanes sat out the insertion of 64 taps each (round 4: 413 us per
-    // launch, 1.7 ms per `custom` step).  Eight lanes share a point instead -- lane u takes the taps (i = u >> 1,
-    // j in {2 (u & 1), 2 (u & 1) + 1}, all k) of the stencil every one of them evaluates.
-#ifdef NDJIR_LANCZOS_LPP1
-    constexpr int LPP = 1;
-#else
-    constexpr int LPP = (I == LANCZOS && ND == 3) ? 8 : 1;
-#endif
     const int pt = (int)threadIdx.x / LPP, sub = (int)threadIdx.x % LPP;
     const long long tid = base + pt;
     if (pt < ppp && tid < total) {
@@ -604,26 +617,28 @@ __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restr
 #pragma unroll
         for (int a = 0; a < ND; ++a) ggs[a] = gg_query[b * 3 + st.axis[a]] * st.scale[a] * st.ax[a].gm;
       }
-      if constexpr (LPP > 1) {
-        // this lane's slab of the stencil: axis-0 tap i0, axis-1 taps j0, j0 + 1 (selected, not indexed: the taps live in registers)
-        const int i0 = sub >> 1, j0 = 2 * (sub & 1);
-        auto sel = [](const auto (&arr)[4], int i) { return i == 0 ? arr[0] : i == 1 ? arr[1] : i == 2 ? arr[2] : arr[3]; };
-        st.ax[0].w[0] = sel(st.ax[0].w, i0); st.ax[0].dw[0] = sel(st.ax[0].dw, i0); st.ax[0].idx[0] = sel(st.ax[0].idx, i0);
-        const float w1a = sel(st.ax[1].w, j0), w1b = sel(st.ax[1].w, j0 + 1), d1a = sel(st.ax[1].dw, j0), d1b = sel(st.ax[1].dw, j0 + 1);
-        const unsigned x1a = sel(st.ax[1].idx, j0), x1b = sel(st.ax[1].idx, j0 + 1);
-        st.ax[1].w[0] = w1a; st.ax[1].w[1] = w1b; st.ax[1].dw[0] = d1a; st.ax[1].dw[1] = d1b; st.ax[1].idx[0] = x1a; st.ax[1].idx[1] = x1b;
+      if constexpr (ND >= 2) {                   // this lane's run: taps (i0, j0, all k) / (i0, all j)
+        const int i0 = ND == 3 ? sub / NT : sub;
+        const float w = pick_tap<NT>(st.ax[0].w, i0), dw = pick_tap<NT>(st.ax[0].dw, i0);
+        const unsigned ix = pick_tap<NT>(st.ax[0].idx, i0);
+        st.ax[0].w[0] = w; st.ax[0].dw[0] = dw; st.ax[0].idx[0] = ix;
       }
-      constexpr int NI = LPP > 1 ? 1 : NT, NJ = LPP > 1 ? 2 : (ND > 1 ? NT : 1), NK = ND > 2 ? NT : 1;
-      for (int d0 = 0; d0 < g.D; d0 += 4) {       // a cell of D floats = D / 4 float4 entries of the table
+      if constexpr (ND == 3) {
+        const int j0 = sub % NT;
+        const float w = pick_tap<NT>(st.ax[1].w, j0), dw = pick_tap<NT>(st.ax[1].dw, j0);
+        const unsigned ix = pick_tap<NT>(st.ax[1].idx, j0);
+        st.ax[1].w[0] = w; st.ax[1].dw[0] = dw; st.ax[1].idx[0] = ix;
+      }
+      int last_ek = -1;
+      int slot = -1;
+      int rec = -1;                               // first record of this run in the overflow list, once a chunk found no slot
+      for (int d0 = 0; d0 < g.D; d0 += 4) {       // a cell of D floats = D / 4 float4 chunks
         float og[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) og[v] = grad_output[out_index<TOPO>(g, P, b, s, d0 + v)];
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
+        for (int r = 0; r < NT; ++r) {
+          const int i = ND == 1 ? r : 0, j = ND == 2 ? r : 0, k = ND == 3 ? r : 0;
           float w;
           if constexpr (MODE == 0) {
             w = tap_w(st, i, j, k);
@@ -632,28 +647,170 @@ __global__ void __launch_bounds__(256) k_scatter_agg(long long P, float* __restr
 #pragma unroll
             for (int a = 0; a < ND; ++a) w += ggs[a] * tap_dw(st, a, i, j, k);
           }
-          const int key = (int)((cell_offset(st, i, j, k) + d0) >> 2);     // float4 index
-          // a table entry is a float4 (D = 4, 12, ...) or, for D = 8, the cell's two float4s side by side: the flush below
-          // then covers a whole 32-byte cell with one request
-          const int ek = key >> cw_log, ce = key & ((1 << cw_log) - 1);
-          unsigned slot = ((unsigned)ek * 2654435761u) >> (20 + cw_log);   // 12 (11) bits
-          while (true) {
-            const int old = atomicCAS(&keys[slot], -1, ek);
-            if (old == -1 || old == ek) break;
-            slot = (slot + 1) & ((AGG_HT >> cw_log) - 1);
+          const long long f = cell_offset(st, i, j, k) + d0 + a0;           // float index, block-aligned
+          const int ek = (int)(f >> 4), ce = (int)(f >> 2) & 3;
+          if (rec < 0 && ek != last_ek) {          // the taps of a run mostly share their block
+            unsigned h = ((unsigned)ek * 2654435761u) >> (32 - __builtin_ctz(AGG_ENT));
+            slot = -1;
+            for (int probe = 0; probe < 8; ++probe) {
+              const int old = atomicCAS(&keys[h], -1, ek);
+              if (old == -1 || old == ek) { slot = (int)h; break; }
+              h = (h + 1) & (AGG_ENT - 1);
+            }
+            last_ek = ek;
+            // no slot within 8 probes: this and the remaining chunks of the run go to the list, in the run's memory order
+            // (record r D4 + d0 / 4), so that the flush addresses them as the contiguous bytes they are
+            if (slot < 0) rec = atomicAdd(&n_over, NT * D4);
           }
+          if (rec < 0) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v) atomicAdd(&vals[4 * ((slot << cw_log) + ce) + v], og[v] * w);
+            for (int v = 0; v < 4; ++v) atomicAdd(&vals[16 * slot + 4 * ce + v], og[v] * w);
+          } else {
+            const int e = rec + r * D4 + (d0 >> 2);
+            over_key[e] = (int)((f - a0) >> 2);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) over_val[4 * e + v] = og[v] * w;
+          }
         }
       }
     }
     __syncthreads();
-    // one lane per FLOAT: the 4 (8) lanes of an entry address 16 (32) contiguous bytes, which the memory-side atomic unit takes
-    // as one request -- its rate is per request, not per float (tools/ubench/atomics_shape.hip: 20 G requests/s either way, i.e.
-    // 4 x (8 x) the floats per second of a lane-per-cell flush with one instruction per float)
-    for (int t = threadIdx.x; t < AGG_HT * 4; t += 256) {
-      const int ek = keys[t >> (2 + cw_log)];
-      if (ek >= 0) atomicAdd(gf + ((long long)ek << (2 + cw_log)) + (t & ((4 << cw_log) - 1)), vals[t]);
+    // one lane per FLOAT, 16 lanes per block: one request.  Floats that received nothing are exact zeros and are skipped --
+    // a block may reach past either end of the tensor, its untouched part is never addressed.
+    for (int t = threadIdx.x; t < AGG_ENT * 16; t += 256) {
+      const int ek = keys[t >> 4];
+      const float v = vals[t];
+      if (ek >= 0 && v != 0.f) atomicAdd(gf + (((long long)ek << 4) - a0 + (t & 15)), v);
+    }
+    // the list: 4 lanes per chunk, the chunks of a run side by side
+    const int no = n_over;
+    for (int t = threadIdx.x; t < no * 4; t += 256) {
+      const int e = t >> 2, key = over_key[e];
+      if (key >= 0) atomicAdd(gf + ((long long)key << 2) + (t & 3), over_val[t]);
+      if ((t & 3) == 0) over_key[e] = -1;          // (same wave instruction as the reads of its three neighbours)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) n_over = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lanczos voxel scatters (D = 4), one lane per FLOAT of the stencil.  A point's 4 x 4 x 4 taps of 4 floats are 16 runs of 64
+// contiguous bytes (4 cells along the fastest axis): 256 floats, one per lane of the workgroup -- lane (i, j, k, v) keeps its
+// place in the stencil and walks the workgroup's 64 points.  What the generic table kernel above paid for these stencils
+// (profiles/r06_scatter.txt: 185 / 230 us per launch of the step's 65 536 points, none of it in the flush):
+//   - every lane of a point repeated the 24 software sines of the stencil: here one lane per (point, axis) evaluates the
+//     axis taps once and hands them over in LDS;
+//   - a lane per tap inserted with 1 CAS + 4 LDS atomics whose lanes collide on the cells consecutive samples share: here
+//     a wave instruction is one point's slab of 4 runs, 64 different floats; the one or two 64-byte blocks of a run are
+//     claimed by its leader lanes only and the slot is passed on with a wave shuffle;
+//   - consecutive samples of a ray that stay on the same cells are summed in the lane's register first.
+// The table is best effort (256 blocks, 8 probes): a run that finds no slot goes to memory directly, which is also all a set of
+// spread points can do -- there a run is 1.75 requests of the memory-side atomic unit where a lane per tap issued 16.
+// Values are those of k_scatter: og * ((w0 * w1) * w2), resp. og * sum_a gg_a * tap_dw_a in the same order.
+// ------------------------------------------------------------------------------------------------
+#ifndef NDJIR_LZ_PTS
+#define NDJIR_LZ_PTS 64
+#endif
+#ifndef NDJIR_LZ_ENT
+#define NDJIR_LZ_ENT 256
+#endif
+constexpr int LZ_PTS = NDJIR_LZ_PTS;        // points per pass and workgroup
+constexpr int LZ_ENT = NDJIR_LZ_ENT;        // table entries of 16 floats
+static_assert(4 * LZ_PTS <= 256, "one lane per (point, axis) + one per point");
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_scatter_lanczos_voxel(long long P, float* __restrict__ gf, const float* __restrict__ gg_query,
+                                                               const float* __restrict__ grad_output, const float* __restrict__ query,
+                                                               GridDesc g) {
+  __shared__ float s_w[LZ_PTS][3][4], s_dw[LZ_PTS][3][4], s_gg[LZ_PTS][3], s_og[LZ_PTS][4];
+  __shared__ unsigned s_off[LZ_PTS][3][4];
+  __shared__ int keys[LZ_ENT];
+  __shared__ float vals[LZ_ENT * 16];
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int i = tid >> 6, j = (tid >> 4) & 3, k = (tid >> 2) & 3, v = tid & 3;
+  int a0 = (int)((reinterpret_cast<uintptr_t>(gf) >> 2) & 15);      // blocks are aligned in memory (see k_scatter_agg)
+  if (a0 & 3) a0 = 0;
+  for (long long base = (long long)blockIdx.x * LZ_PTS; base < P; base += (long long)gridDim.x * LZ_PTS) {   // uniform per workgroup
+    for (int t = tid; t < LZ_ENT * 4; t += 256) {
+      if (t < LZ_ENT) keys[t] = -1;
+      *reinterpret_cast<float4*>(vals + 4 * t) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < 3 * LZ_PTS) {
+      const int pt = tid / 3, a = tid - 3 * pt;
+      const long long b = base + pt;
+      if (b < P) {
+        const float G1 = (float)g.G[a] - 1.f, sc = G1 / (g.mx[a] - g.mn[a]);        // make_stencil<VOXEL>, axis a
+        const unsigned stride = a == 0 ? (unsigned)(g.G[1] * g.G[2] * g.D) : (a == 1 ? (unsigned)(g.G[2] * g.D) : (unsigned)g.D);
+        AxisTaps<LANCZOS> t;
+        axis_taps<LANCZOS>(t, (query[b * 3 + a] - g.mn[a]) * sc, G1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s_w[pt][a][r] = t.w[r]; s_dw[pt][a][r] = t.dw[r]; s_off[pt][a][r] = t.idx[r] * stride; }
+        if constexpr (MODE == 1) s_gg[pt][a] = gg_query[b * 3 + a] * sc * t.gm;
+      }
+    } else {
+      const int pt = tid - 3 * LZ_PTS;
+      if (base + pt < P) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_og[pt][c] = grad_output[(base + pt) * 4 + c];
+      }
+    }
+    __syncthreads();
+    const int npts = (int)((P - base) < (long long)LZ_PTS ? (P - base) : (long long)LZ_PTS);
+    // (cur, acc): the run of points whose stencil sits on the same cells; handed to the table when the wave moves on
+    auto hand_over = [&](unsigned o, float val) {
+      const long long f = (long long)o + a0;
+      const int ek = (int)(f >> 4), within = ((int)(f >> 2) & 3) * 4 + v;
+      // the blocks of a run: the cells of k = 0 ... kb - 1 in the first, the rest in the second; leaders = their first lanes
+      const int run0 = lane & ~15;
+      const int ek0 = __shfl(ek, run0);
+      const bool same0 = ek == ek0;
+      const unsigned long long m = __ballot(same0);
+      const int kb = __popcll((m >> run0) & 0x1111ull);
+      const int leader = same0 ? run0 : run0 + 4 * kb;
+      int slot = -1;
+      if (lane == leader) {
+        unsigned h = ((unsigned)ek * 2654435761u) >> (32 - __builtin_ctz(LZ_ENT));
+        for (int probe = 0; probe < 8; ++probe) {
+          const int old = atomicCAS(&keys[h], -1, ek);
+          if (old == -1 || old == ek) { slot = (int)h; break; }
+          h = (h + 1) & (LZ_ENT - 1);
+        }
+      }
+      slot = __shfl(slot, leader);
+      if (slot >= 0) atomicAdd(&vals[16 * slot + within], val);
+      else atomicAdd(gf + (long long)o + v, val);
+    };
+    unsigned cur = 0xffffffffu;
+    float acc = 0.f;
+    for (int pt = 0; pt < npts; ++pt) {
+      const float w0 = s_w[pt][0][i], w1 = s_w[pt][1][j], w2 = s_w[pt][2][k];
+      float w;
+      if constexpr (MODE == 0) {
+        w = w0 * w1;
+        w = w * w2;
+      } else {
+        const float d0w = s_dw[pt][0][i], d1w = s_dw[pt][1][j], d2w = s_dw[pt][2][k];
+        w = 0.f;
+        w += s_gg[pt][0] * ((d0w * w1) * w2);
+        w += s_gg[pt][1] * ((w0 * d1w) * w2);
+        w += s_gg[pt][2] * ((w0 * w1) * d2w);
+      }
+      const unsigned o = s_off[pt][0][i] + s_off[pt][1][j] + s_off[pt][2][k];
+      if (__any(o != cur)) {                       // wave-uniform: the shuffles of hand_over need every lane
+        if (pt > 0) hand_over(cur, acc);
+        cur = o;
+        acc = 0.f;
+      }
+      acc += s_og[pt][v] * w;
+    }
+    if (npts > 0) hand_over(cur, acc);
+    __syncthreads();
+    // one lane per FLOAT, 16 lanes per block: one request; untouched floats are exact zeros and are skipped (see k_scatter_agg)
+    for (int t = tid; t < LZ_ENT * 16; t += 256) {
+      const int ek = keys[t >> 4];
+      const float val = vals[t];
+      if (ek >= 0 && val != 0.f) atomicAdd(gf + (((long long)ek << 4) - a0 + (t & 15)), val);
     }
     __syncthreads();
   }
@@ -949,7 +1106,10 @@ __global__ void __launch_bounds__(256) k_tv(long long P, float* __restrict__ dst
   NDJIR_GRID_THREAD_EPILOGUE
 }
 
-// TV backward with the workgroup-level LDS aggregation of k_scatter_agg (dense topologies, D = 4)
+// TV backward with a workgroup-level LDS aggregation like k_scatter_agg's (dense topologies, D = 4 / 8).  Its four cells per point
+// are not a run and its points revisit cells heavily, so it keeps the exact table: cells (16 / 32 bytes) as entries, 4096 slots, at
+// most 256 x 4 x D / 4 insertions per pass (the small best-effort table of k_scatter_agg was 3 x slower here: 22 -> 80 us)
+constexpr int AGG_HT = 4096;
 template <int TOPO>
 __global__ void __launch_bounds__(256) k_tv_bwd_agg(long long P, float* __restrict__ dst, const float* __restrict__ grad_output,
                                                     const float* __restrict__ query, const float* __restrict__ feature,
@@ -1013,7 +1173,7 @@ __global__ void __launch_bounds__(256) k_tv_bwd_agg(long long P, float* __restri
       }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < AGG_HT * 4; t += 256) {       // (one lane per float, see k_scatter_agg)
+    for (int t = threadIdx.x; t < AGG_HT * 4; t += 256) {       // (one lane per float: the lanes of a cell form one request)
       const int ek = keys[t >> (2 + cw_log)];
       if (ek >= 0) atomicAdd(dst + ((long long)ek << (2 + cw_log)) + (t & ((4 << cw_log) - 1)), vals[t]);
     }
@@ -1203,9 +1363,18 @@ int launch_scatter(int interp, const GridDesc& g, long long P, int mode, float* 
   // (Round 2 also binned large spread point sets by tiles -- tri-plane, Lanczos voxel -- so that every cell had one owner;
   // with the request-shaped flushes of round 3 the aggregated path is within 10 % of it on the tri-plane, a training step
   // never reached its threshold, and its library-owned scratch was the one piece of cross-stream state: removed in round 4.)
+  static const bool lanczos_agg = getenv("NDJIR_LANCZOS_AGG") != nullptr;      // A/B switch: the generic table kernel
+  if (g.topo == VOXEL && interp == LANCZOS && g.D == 4 && !no_agg && !lanczos_agg) {
+    const long long want = (P + LZ_PTS - 1) / LZ_PTS;
+    const int lblocks = (int)(want > 8192 ? 8192 : want);
+    if (mode == 0) hipLaunchKernelGGL((k_scatter_lanczos_voxel<0>), dim3(lblocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
+    else hipLaunchKernelGGL((k_scatter_lanczos_voxel<1>), dim3(lblocks), dim3(256), 0, stream, P, gf, gg_query, grad_output, query, g);
+    return ndjir_check_launch();
+  }
+  const int lpp = taps / nt;                 // one lane per run along the fastest axis
   if (g.topo != HASH && (g.D & 3) == 0 && per_point <= 128 && !no_agg) {
-    int ppp = 2048 / per_point;
-    if (ppp > 256) ppp = 256;
+    int ppp = 256 / lpp;
+    while (ppp * per_point > AGG_OVER) ppp >>= 1;               // every chunk of a pass must fit the overflow list
     const long long want = (P * g.S + ppp - 1) / ppp;
     const int ablocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
 #define NDJIR_AGG_CASE(T, IV)                                                                                              \

@@ -296,6 +296,40 @@ def test_grad_buffer_accumulates_in_place(gpu):
         set_grad_buffer(f, None)
 
 
+@pytest.mark.parametrize("family,G,D", [("voxel", 64, 4), ("lanczos_voxel", 48, 4), ("triplane", 128, 8), ("voxel", 32, 8)])
+@pytest.mark.parametrize("offset", [0, 4, 12, 1])
+def test_scatter_of_ray_samples_into_a_slice_of_a_flat_buffer(gpu, family, G, D, offset):
+    """The aggregated scatters (csrc/grid.hip k_scatter_agg, k_scatter_lanczos_voxel) key their LDS tables by the 64-byte
+    blocks of MEMORY the gradient tensor covers, and a training step's gradient tensor is a slice of the flat gradient
+    buffer: bases 0 / 16 / 48 bytes into a block and one that is not 16-byte aligned (table blocks relative to the base)
+    give the float64 oracle's sums, on ray-ordered samples (runs of points inside one cell, shared stencil blocks: what
+    the tables and the per-lane run sums merge) that leave the box at both ends (clamped border cells)."""
+    from ndjir_amd.grid_feature import _core, set_grad_buffer
+    rng = np.random.RandomState(7)
+    R, N = 96, 128
+    o_ = rng.randn(R, 3); o_ = 1.6 * o_ / np.linalg.norm(o_, axis=1, keepdims=True)
+    d_ = rng.rand(R, 3) * 0.8 - 0.4 - o_; d_ /= np.linalg.norm(d_, axis=1, keepdims=True)
+    t = np.sort(np.concatenate([rng.rand(R, N // 2) * 2.4, 1.5 + rng.rand(R, N // 2) * 0.05], axis=1), axis=1)   # coarse + a dense band
+    q = (o_[:, None] + d_[:, None] * t[..., None]).reshape(-1, 3).astype(np.float32)
+    P = q.shape[0]
+    o = K.GridOracle(family)
+    fs = feature_shape(o, G, D, None)
+    f = T((rng.randn(*fs) * 0.01).astype(np.float32), gpu).requires_grad_(True)
+    og = rng.randn(P, o.query(q[:1], np.zeros(fs, np.float32)).shape[1]).astype(np.float32)
+    ref = o.grad_feature(og, q, fs)
+    flat = torch.zeros(f.numel() + 64, device=gpu)
+    assert flat.data_ptr() % 64 == 0
+    buf = flat[offset:offset + f.numel()].view(fs)
+    set_grad_buffer(f, buf)
+    try:
+        assert _core.grad_feature(family, T(og, gpu), T(q, gpu), f) is None
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(buf.cpu().numpy(), ref, atol=(5e-5 if o.lanczos else 5e-6) * max(1.0, np.abs(ref).max()))
+        assert float(flat[:offset].abs().sum()) == 0.0 and float(flat[offset + f.numel():].abs().sum()) == 0.0   # nothing outside
+    finally:
+        set_grad_buffer(f, None)
+
+
 def test_squareplus(gpu):
     from ndjir_amd.activation.squareplus import squareplus
     x = torch.randn(1000, device=gpu, requires_grad=True)

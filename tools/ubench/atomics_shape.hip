@@ -47,11 +47,11 @@ int main() {
   (void)hipMalloc(&buf, floats * 4); (void)hipMemset(buf, 0, floats * 4);
   unsigned* h = (unsigned*)malloc(n * 4);
   srand(412);
-  for (int D : {4, 8, 16, 32}) {
+  for (int D : {1, 2, 4, 8, 16, 32, 64}) {
     const long long cells = floats / D;
     for (long long i = 0; i < n; ++i) h[i] = ((unsigned)rand() * 32768u + (unsigned)rand()) & (unsigned)(cells - 1);
     (void)hipMalloc(&idx, n * 4); (void)hipMemcpy(idx, h, n * 4, hipMemcpyHostToDevice);
-    if (D == 4) run<4>(buf, idx, n, cells); else if (D == 8) run<8>(buf, idx, n, cells); else if (D == 16) run<16>(buf, idx, n, cells); else run<32>(buf, idx, n, cells);
+    if (D == 1) run<1>(buf, idx, n, cells); else if (D == 2) run<2>(buf, idx, n, cells); else if (D == 64) run<64>(buf, idx, n, cells); else if (D == 4) run<4>(buf, idx, n, cells); else if (D == 8) run<8>(buf, idx, n, cells); else if (D == 16) run<16>(buf, idx, n, cells); else run<32>(buf, idx, n, cells);
     (void)hipFree(idx);
   }
   return 0;
