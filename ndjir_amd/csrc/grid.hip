@@ -233,12 +233,33 @@ __global__ void __launch_bounds__(256) k_query(long long P, float* __restrict__ 
     float acc[VW];
 #pragma unroll
     for (int v = 0; v < VW; ++v) acc[v] = 0.f;
-    NDJIR_FOR_TAPS(ND, NT) {
-      float f[VW];
-      vload<VW>(f, feature + cell_offset(st, i, j, k) + d0);
-      float w = tap_w(st, i, j, k);
+    if constexpr (I == LANCZOS && ND == 3) {
+      // a slab of 16 gathers in flight before its products (same order of the sum): at 512^3 x 4 floats every run of 4 taps is
+      // a DRAM line, and the loop below left the compiler a few loads per wait
 #pragma unroll
-      for (int v = 0; v < VW; ++v) acc[v] += w * f[v];
+      for (int i = 0; i < NT; ++i) {
+        float f[NT * NT][VW];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int k = 0; k < NT; ++k) vload<VW>(f[j * NT + k], feature + cell_offset(st, i, j, k) + d0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int k = 0; k < NT; ++k) {
+            const float w = tap_w(st, i, j, k);
+#pragma unroll
+            for (int v = 0; v < VW; ++v) acc[v] += w * f[j * NT + k][v];
+          }
+      }
+    } else {
+      NDJIR_FOR_TAPS(ND, NT) {
+        float f[VW];
+        vload<VW>(f, feature + cell_offset(st, i, j, k) + d0);
+        float w = tap_w(st, i, j, k);
+#pragma unroll
+        for (int v = 0; v < VW; ++v) acc[v] += w * f[v];
+      }
     }
 #pragma unroll
     for (int v = 0; v < VW; ++v) {
@@ -287,6 +308,85 @@ __global__ void __launch_bounds__(256) k_voxel_query_encode(long long P, int M, 
       v = acc;
     }
     e[p * lde + c_out] = v;
+  }
+}
+
+// The same for the Lanczos stencil.  There a lane per (point, column) made every feature column repeat the 24 software sines of
+// the 4 x 4 x 4 stencil, in waves whose other lanes (the encoding columns) waited for it, and gathered its 64 taps a few at a
+// time: 55 us per launch, 0.37 ms per `custom` step.  Here a workgroup takes PTS points: one lane per (point, axis) evaluates
+// the axis taps once and hands weights and offsets over in LDS, then a lane per (point, feature column) issues all 64 gathers
+// and walks them in k_query's order with k_query's products ((w0 w1) w2, one fma per tap): bit-identical values again, 0.37 ->
+// 0.17 ms per step (profiles/r06_scatter.txt).
+template <int PTS>
+__global__ void __launch_bounds__(256) k_voxel_query_encode_lanczos(long long P, int M, const float* __restrict__ query,
+                                                                    const float* __restrict__ feature, GridDesc g,
+                                                                    float* __restrict__ e, int lde) {
+  __shared__ float s_w[PTS][3][4];
+  __shared__ unsigned s_off[PTS][3][4];
+  const int tid = (int)threadIdx.x;
+  const int npe = 3 + 6 * M;
+  // the encoding columns go to the waves that evaluate no taps when that leaves at least half of the workgroup
+  constexpr int TAP_LANES = (3 * PTS + 63) & ~63;
+  constexpr int ENC_FIRST = (256 - TAP_LANES >= 128) ? TAP_LANES : 0, ENC_LANES = 256 - ENC_FIRST;
+  for (long long base = (long long)blockIdx.x * PTS; base < P; base += (long long)gridDim.x * PTS) {   // uniform per workgroup
+    const int npts = (int)((P - base) < (long long)PTS ? (P - base) : (long long)PTS);
+    if (tid < 3 * npts) {
+      const int pt = tid / 3, a = tid - 3 * pt;
+      const float G1 = (float)g.G[a] - 1.f, sc = G1 / (g.mx[a] - g.mn[a]);        // make_stencil<VOXEL>, axis a
+      const unsigned stride = a == 0 ? (unsigned)(g.G[1] * g.G[2] * g.D) : (a == 1 ? (unsigned)(g.G[2] * g.D) : (unsigned)g.D);
+      AxisTaps<LANCZOS> t;
+      axis_taps<LANCZOS>(t, (query[(base + pt) * 3 + a] - g.mn[a]) * sc, G1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s_w[pt][a][r] = t.w[r]; s_off[pt][a][r] = t.idx[r] * stride; }
+    }
+    for (int u = tid - ENC_FIRST; u >= 0 && u < npts * npe; u += ENC_LANES) {     // the encoding columns
+      const int pt = u / npe;
+      int c = u - pt * npe;
+      const long long p = base + pt;
+      float v;
+      if (c < 3) v = query[p * 3 + c];
+      else {
+        int cc = c - 3;
+        const bool is_sin = cc >= 3 * M;
+        if (is_sin) cc -= 3 * M;
+        const float b = query[p * 3 + cc / M] * (float)(1 << (cc % M));
+        v = is_sin ? sinf(b) : cosf(b);
+      }
+      e[p * lde + c] = v;
+    }
+    __syncthreads();
+    for (int u = tid; u < npts * g.D; u += 256) {                 // the feature columns
+      const int pt = u / g.D, d = u - pt * g.D;
+      const float* fd = feature + d;
+      // all 64 gathers in flight before the first product (the grid is 2 GiB at 512^3 x 4: every run of 4 taps is a DRAM line)
+      float w0[4], w1[4], w2[4], f[64];
+      unsigned o0[4], o1[4], o2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        w0[r] = s_w[pt][0][r]; w1[r] = s_w[pt][1][r]; w2[r] = s_w[pt][2][r];
+        o0[r] = s_off[pt][0][r]; o1[r] = s_off[pt][1][r]; o2[r] = s_off[pt][2][r];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) f[(i * 4 + j) * 4 + k] = fd[(long long)(o0[i] + o1[j] + o2[k])];
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float w01 = w0[i] * w1[j];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float w = w01 * w2[k];
+            acc += w * f[(i * 4 + j) * 4 + k];
+          }
+        }
+      e[(base + pt) * lde + npe + d] = acc;
+    }
+    __syncthreads();
   }
 }
 
@@ -473,14 +573,36 @@ __global__ void __launch_bounds__(256) k_dquery(long long P, float* __restrict__
     for (int a = 0; a < ND; ++a)
 #pragma unroll
       for (int v = 0; v < VW; ++v) ga[a][v] = 0.f;
-    NDJIR_FOR_TAPS(ND, NT) {
-      float f[VW];
-      vload<VW>(f, feature + cell_offset(st, i, j, k) + d0);
+    if constexpr (I == LANCZOS && ND == 3) {      // slabs of 16 gathers in flight, see k_query
 #pragma unroll
-      for (int a = 0; a < ND; ++a) {
-        float dw = tap_dw(st, a, i, j, k);
+      for (int i = 0; i < NT; ++i) {
+        float f[NT * NT][VW];
 #pragma unroll
-        for (int v = 0; v < VW; ++v) ga[a][v] += dw * f[v];
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int k = 0; k < NT; ++k) vload<VW>(f[j * NT + k], feature + cell_offset(st, i, j, k) + d0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int k = 0; k < NT; ++k) {
+#pragma unroll
+            for (int a = 0; a < ND; ++a) {
+              const float dw = tap_dw(st, a, i, j, k);
+#pragma unroll
+              for (int v = 0; v < VW; ++v) ga[a][v] += dw * f[j * NT + k][v];
+            }
+          }
+      }
+    } else {
+      NDJIR_FOR_TAPS(ND, NT) {
+        float f[VW];
+        vload<VW>(f, feature + cell_offset(st, i, j, k) + d0);
+#pragma unroll
+        for (int a = 0; a < ND; ++a) {
+          float dw = tap_dw(st, a, i, j, k);
+#pragma unroll
+          for (int v = 0; v < VW; ++v) ga[a][v] += dw * f[v];
+        }
       }
     }
     if constexpr (MODE == 0) {
@@ -512,6 +634,93 @@ __global__ void __launch_bounds__(256) k_dquery(long long P, float* __restrict__
     }
   }
   NDJIR_GRID_THREAD_EPILOGUE
+}
+
+// The same two products for the Lanczos voxel stencil with D = 4, one lane per (point, channel).  k_dquery's lane per point
+// evaluates the stencil's 36 software sines / cosines and then walks 64 float4 gathers a few at a time: 67 us per launch of the
+// step's 65 536 points with one wave per SIMD.  Here (as in k_voxel_query_encode_lanczos) one lane per (point, axis) evaluates
+// the taps once and hands them over in LDS, and a lane per (point, channel) has all 64 gathers in flight before the first
+// product.  Sums in k_dquery's order (taps i, j, k; then channels 0 ... 3 on the point's first lane): bit-identical values.
+template <int MODE, bool ACCUM>
+__global__ void __launch_bounds__(256) k_dquery_lanczos_voxel(long long P, float* __restrict__ dst, const float* __restrict__ src,
+                                                              const float* __restrict__ query, const float* __restrict__ feature,
+                                                              GridDesc g) {
+  constexpr int PTS = 64;
+  __shared__ float s_w[PTS][3][4], s_dw[PTS][3][4], s_sc[PTS][3], s_gm[PTS][3];
+  __shared__ unsigned s_off[PTS][3][4];
+  const int tid = (int)threadIdx.x;
+  for (long long base = (long long)blockIdx.x * PTS; base < P; base += (long long)gridDim.x * PTS) {   // uniform per workgroup
+    const int npts = (int)((P - base) < (long long)PTS ? (P - base) : (long long)PTS);
+    if (tid < 3 * npts) {
+      const int pt = tid / 3, a = tid - 3 * pt;
+      const float G1 = (float)g.G[a] - 1.f, sc = G1 / (g.mx[a] - g.mn[a]);        // make_stencil<VOXEL>, axis a
+      const unsigned stride = a == 0 ? (unsigned)(g.G[1] * g.G[2] * g.D) : (a == 1 ? (unsigned)(g.G[2] * g.D) : (unsigned)g.D);
+      AxisTaps<LANCZOS> t;
+      axis_taps<LANCZOS>(t, (query[(base + pt) * 3 + a] - g.mn[a]) * sc, G1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s_w[pt][a][r] = t.w[r]; s_dw[pt][a][r] = t.dw[r]; s_off[pt][a][r] = t.idx[r] * stride; }
+      s_sc[pt][a] = sc;
+      s_gm[pt][a] = t.gm;
+    }
+    __syncthreads();
+    const int pt = tid >> 2, v = tid & 3;
+    const bool live = pt < npts;                       // (4 lanes of a point share their wave: the shuffles below stay uniform)
+    const long long p = base + (live ? pt : 0);
+    float ga[3] = {0.f, 0.f, 0.f};
+    if (live) {
+      const float* fd = feature + v;
+      float w0[4], w1[4], w2[4], d0[4], d1[4], d2[4], f[64];
+      unsigned o0[4], o1[4], o2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        w0[r] = s_w[pt][0][r]; w1[r] = s_w[pt][1][r]; w2[r] = s_w[pt][2][r];
+        d0[r] = s_dw[pt][0][r]; d1[r] = s_dw[pt][1][r]; d2[r] = s_dw[pt][2][r];
+        o0[r] = s_off[pt][0][r]; o1[r] = s_off[pt][1][r]; o2[r] = s_off[pt][2][r];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) f[(i * 4 + j) * 4 + k] = fd[(long long)(o0[i] + o1[j] + o2[k])];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float fv = f[(i * 4 + j) * 4 + k];
+            ga[0] += ((d0[i] * w1[j]) * w2[k]) * fv;        // tap_dw(st, a, i, j, k)
+            ga[1] += ((w0[i] * d1[j]) * w2[k]) * fv;
+            ga[2] += ((w0[i] * w1[j]) * d2[k]) * fv;
+          }
+    }
+    if constexpr (MODE == 0) {
+      // gq[a] += og[v] * scale[a] * gm[a] * ga[a][v], v = 0 ... 3 in turn, on the point's first lane
+      float gq[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int vv = 0; vv < 4; ++vv) {
+        const float og = src[p * 4 + vv];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float gav = __shfl(ga[a], (tid & 60) + vv);
+          gq[a] += og * s_sc[live ? pt : 0][a] * s_gm[live ? pt : 0][a] * gav;
+        }
+      }
+      if (live && v == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dst[p * 3 + a] += gq[a];
+      }
+    } else {
+      if (live) {
+        float r = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) r += src[p * 3 + a] * s_sc[pt][a] * s_gm[pt][a] * ga[a];
+        dst[p * 4 + v] = ACCUM ? dst[p * 4 + v] + r : r;
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1309,6 +1518,15 @@ int launch_dquery(int interp, const GridDesc& g, long long P, int mode, float* d
     return ndjir_check_launch();
   }
   if (mode == 0 && !accum) zero_fill(dst, P * 3, stream);
+  static const bool lz_point = getenv("NDJIR_LANCZOS_DQUERY_PER_POINT") != nullptr;      // A/B switch
+  if (g.topo == VOXEL && interp == LANCZOS && g.D == 4 && !lz_point) {
+    const long long want = (P + 63) / 64;
+    const dim3 lb((unsigned)(want > 8192 ? 8192 : want));
+    if (mode == 0) hipLaunchKernelGGL((k_dquery_lanczos_voxel<0, true>), lb, dim3(256), 0, stream, P, dst, src, query, feature, g);
+    else if (accum) hipLaunchKernelGGL((k_dquery_lanczos_voxel<1, true>), lb, dim3(256), 0, stream, P, dst, src, query, feature, g);
+    else hipLaunchKernelGGL((k_dquery_lanczos_voxel<1, false>), lb, dim3(256), 0, stream, P, dst, src, query, feature, g);
+    return ndjir_check_launch();
+  }
   int blocks = grid_blocks(P * g.S);
   NDJIR_DISPATCH_TI(g.topo, interp, NDJIR_DISPATCH_VW(pick_vw(g.D), {
     if (mode == 0) hipLaunchKernelGGL((k_dquery<TOPO, I, VW, 0, true>), dim3(blocks), dim3(256), 0, stream, P, dst, src, query, feature, g);
@@ -1455,7 +1673,14 @@ int launch_voxel_query_encode(int interp, const GridDesc& g, long long P, int M,
   const int blocks = grid_blocks(P * (3 + 6 * M + g.D));
   if (interp == LINEAR) hipLaunchKernelGGL((k_voxel_query_encode<LINEAR>), dim3(blocks), dim3(256), 0, stream, P, M, query, feature, g, e, lde);
   else if (interp == COSINE) hipLaunchKernelGGL((k_voxel_query_encode<COSINE>), dim3(blocks), dim3(256), 0, stream, P, M, query, feature, g, e, lde);
-  else if (interp == LANCZOS) hipLaunchKernelGGL((k_voxel_query_encode<LANCZOS>), dim3(blocks), dim3(256), 0, stream, P, M, query, feature, g, e, lde);
+  else if (interp == LANCZOS) {
+    static const bool per_column = getenv("NDJIR_LANCZOS_ENCODE_PER_COLUMN") != nullptr;      // A/B switch
+    // 64 points per workgroup; 16 while that leaves the chip short of workgroups (the sampler's rounds of 8 192 points: 18 -> 9 us)
+    const long long want = (P + 15) / 16, want64 = (P + 63) / 64;
+    if (per_column) hipLaunchKernelGGL((k_voxel_query_encode<LANCZOS>), dim3(blocks), dim3(256), 0, stream, P, M, query, feature, g, e, lde);
+    else if (want64 >= 512) hipLaunchKernelGGL((k_voxel_query_encode_lanczos<64>), dim3((unsigned)(want64 > 8192 ? 8192 : want64)), dim3(256), 0, stream, P, M, query, feature, g, e, lde);
+    else hipLaunchKernelGGL((k_voxel_query_encode_lanczos<16>), dim3((unsigned)want), dim3(256), 0, stream, P, M, query, feature, g, e, lde);
+  }
   else return NDJIR_ERR_UNSUPPORTED;
   return ndjir_check_launch();
 }
