@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include "mlp.h"
@@ -1426,6 +1427,7 @@ constexpr int WGT_MAX_SEG = 768;
 constexpr int WGT_MAX_OUT = 256;
 struct WggTable {
   int n_seg, n_out, pad0, pad1;
+  unsigned amax_fill[WGT_MAX_SRC][2];      // maxima of the operands that came without a recorded one (k_wgg_absmax), as bit patterns
   WggSrc src[WGT_MAX_SRC];
   WggSeg seg[WGT_MAX_SEG];
   WggOut out[WGT_MAX_OUT];
@@ -1573,41 +1575,58 @@ __device__ __forceinline__ bool wgg_locate(const WggTable& a, int& si, int& spli
   return split < a.src[a.seg[si].src].S;
 }
 
-// largest finite |X[p][c]| (bit pattern) over the rows [p0, p1) and columns [c0, c1): the operand scale of a work item whose
-// source came without a recorded maximum (single-layer operators on a few hundred per-ray rows).  Every item de-scales its own
-// partial slab, so items of one source may use different scales -- each only has to bound the values the item multiplies.
-__device__ __forceinline__ unsigned wgg_tile_absmax(const float* __restrict__ X_, int ld, int c0, int c1, long long p0, long long p1,
-                                                    unsigned* red, bool blocked = false) {
-  const WG_G float* X = wg_global(X_);
+// Operands without a recorded maximum (single-layer operators on per-ray rows, the nets of the 16 384-point passes): one pre-pass
+// over each such operand, many workgroups per operand, before the item launches.  (Rounds 4 - 5: every work item scanned its own
+// rows and columns first, one load per lane and step at memory latency -- 57 us for 512 rows, ~300 us for a split of 2 752; the
+// items of these sources were the long pole of both item launches, tools/wgrad_items.py.)  Largest finite |x| as a bit pattern.
+constexpr int WGG_AMAX_CHUNKS = 32;        // workgroups per operand
+__global__ void __launch_bounds__(256) k_wgg_absmax(WggTable* __restrict__ tab) {
+  __shared__ unsigned red[256];
+  const int i = (int)blockIdx.y >> 1, op = (int)blockIdx.y & 1;
+  const WggSrc& s = tab->src[i];
+  if (!((s.layout >> (8 + op)) & 1)) return;          // recorded, or a narrow source (fp32 items: no scale)
+  const WG_G float* X = wg_global(op ? s.B : s.A);
+  const int ld = op ? s.ldb : s.lda, W = op ? s.N : s.K;
+  const bool blocked = (s.layout >> op) & 1;
+  long long per = (s.P + WGG_AMAX_CHUNKS - 1) / WGG_AMAX_CHUNKS;
+  per = (per + 31) / 32 * 32;
+  const long long p0 = (long long)blockIdx.x * per;
+  long long p1 = p0 + per;
+  if (p1 > s.P) p1 = s.P;
   unsigned m = 0;
-  const int w = c1 - c0;
-  if (blocked) {          // point-blocked operand: 32 points of a feature are contiguous
-    for (long long b = (p0 >> 5) + (threadIdx.x >> 5); b < (p1 >> 5); b += WG_THREADS / 32)
-      for (int c = 0; c < w; ++c) {
-        const unsigned v = __float_as_uint(X[(b * ld + c0 + c) * 32 + (threadIdx.x & 31)]) & 0x7fffffffu;
-        if (v < 0x7f800000u && v > m) m = v;
+  if (p0 < p1) {
+    const long long n = (p1 - p0) * W;
+    constexpr int U = 8;
+    for (long long t0 = threadIdx.x; t0 < n; t0 += 256 * U) {
+      unsigned b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long t = t0 + 256 * u;
+        b[u] = 0u;
+        if (t < n) {
+          long long idx;
+          if (blocked) { const long long q = t >> 5; idx = (((p0 >> 5) + q / W) * ld + q % W) * 32 + (t & 31); }     // (32 points of a feature contiguous)
+          else idx = (p0 + t / W) * ld + t % W;
+          b[u] = __float_as_uint(X[idx]) & 0x7fffffffu;
+        }
       }
-  } else
-#pragma unroll 4
-  for (long long p = p0 + (threadIdx.x >> 6); p < p1; p += WG_THREADS / 64)
-    for (int c = threadIdx.x & 63; c < w; c += 64) {
-      const unsigned b = __float_as_uint(X[p * ld + c0 + c]) & 0x7fffffffu;
-      if (b < 0x7f800000u && b > m) m = b;
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (b[u] < 0x7f800000u && b[u] > m) m = b[u];
     }
+  }
   red[threadIdx.x] = m;
   __syncthreads();
-  for (int st = WG_THREADS / 2; st > 0; st >>= 1) {
+  for (int st = 128; st > 0; st >>= 1) {
     if ((int)threadIdx.x < st && red[threadIdx.x + st] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + st];
     __syncthreads();
   }
-  m = red[0];
-  __syncthreads();
-  return m;
+  if (threadIdx.x == 0 && red[0] > 0u) atomicMax(&tab->amax_fill[i][op], red[0]);
 }
 
 __global__ void __launch_bounds__(256) k_wgg_write(const WggPiece p, WggTable* __restrict__ t) {
   const int tid = threadIdx.x;
   if (tid == 0) { t->n_seg = p.tot_seg; t->n_out = p.tot_out; }
+  for (int i = tid; i < p.n_src * 2; i += 256) t->amax_fill[p.src0 + (i >> 1)][i & 1] = 0u;
   // (plain word copies: the structs are PODs of 4-byte-aligned members)
   const int ws = sizeof(WggSrc) / 4, wg = sizeof(WggSeg) / 4, wo = sizeof(WggOut) / 4;
   const unsigned* a = reinterpret_cast<const unsigned*>(p.src);
@@ -1621,6 +1640,19 @@ __global__ void __launch_bounds__(256) k_wgg_write(const WggPiece p, WggTable* _
   for (int i = tid; i < p.n_out * wo; i += 256) d[i] = a[i];
 }
 
+#ifdef WGG_ITEMLOG      // tools/wgrad_items.py: (kind, first and last 100 MHz tick) of every workgroup of the last k_wgrad_group launch
+__device__ long long wgg_item_log[16384][3];
+struct WggItemStamp {
+  int b;
+  __device__ WggItemStamp(int kind, int base = 0) : b((int)blockIdx.x + base) {
+    if (threadIdx.x == 0 && b < 16384) { wgg_item_log[b][0] = kind; wgg_item_log[b][1] = (long long)__builtin_amdgcn_s_memrealtime(); }
+  }
+  __device__ ~WggItemStamp() {
+    __syncthreads();
+    if (threadIdx.x == 0 && b < 16384) wgg_item_log[b][2] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+};
+#endif
 // The 128 x 256 items (kind 5) of a group: one workgroup per CU, 512 registers per lane, 96 KB of LDS -- see wgrad3_pipe.  Their
 // segments come first in the table: workgroups [0, wide blocks) are this launch's, the rest k_wgrad_group's.
 __global__ void __launch_bounds__(WG_THREADS, 1) k_wgrad_group_wide(const WggTable* __restrict__ tab) {
@@ -1629,6 +1661,9 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_wgrad_group_wide(const WggTab
   int si, split, tile;
   if (!wgg_locate(a, si, split, tile)) return;
   const WggSeg& g = a.seg[si];
+#ifdef WGG_ITEMLOG
+  WggItemStamp stamp_(g.kind + 16 * (a.src[g.src].layout & 3) + 64 * (a.src[g.src].P > 100000), 8192);
+#endif
   const WggSrc& s = a.src[g.src];
   const int K = s.K, N = s.N;
   const long long p_begin = (long long)split * s.rows;
@@ -1639,9 +1674,9 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_wgrad_group_wide(const WggTab
   const int k0 = g.k_off + ti * WG_T, n0 = g.n_off + tj * 2 * WG_T;
   unsigned ma, mb;
   if (s.amax_a) ma = *wg_global(s.amax_a);
-  else { const int k1 = k0 + WG_T; ma = wgg_tile_absmax(s.A, s.lda, k0, k1 < g.k_end ? k1 : g.k_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds), s.layout & 1); }
+  else ma = a.amax_fill[g.src][0];
   if (s.amax_b) mb = *wg_global(s.amax_b);
-  else { const int n1 = n0 + 2 * WG_T; mb = wgg_tile_absmax(s.B, s.ldb, n0, n1 < g.n_end ? n1 : g.n_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds), s.layout & 2); }
+  else mb = a.amax_fill[g.src][1];
   float sa, ia, sb, ib;
   wg_scale_from_max(ma, sa, ia);
   wg_scale_from_max(mb, sb, ib);
@@ -1663,6 +1698,9 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* _
   int si, split, tile;
   if (!wgg_locate(a, si, split, tile, block_base)) return;
   const WggSeg& g = a.seg[si];
+#ifdef WGG_ITEMLOG
+  WggItemStamp stamp_(g.kind + 16 * (a.src[g.src].layout & 3) + 64 * (a.src[g.src].P > 100000));
+#endif
   const WggSrc& s = a.src[g.src];
   const int K = s.K, N = s.N, kind = g.kind;
   const long long p_begin = (long long)split * s.rows;
@@ -1678,9 +1716,9 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* _
   const int k0 = g.k_off + ti * wgg_tile_k(kind), n0 = g.n_off + tj * wgg_tile_n(kind);
   unsigned ma, mb;
   if (s.amax_a) ma = *wg_global(s.amax_a);
-  else { const int k1 = k0 + wgg_tile_k(kind); ma = wgg_tile_absmax(s.A, s.lda, k0, k1 < g.k_end ? k1 : g.k_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds), s.layout & 1); }
+  else ma = a.amax_fill[g.src][0];
   if (s.amax_b) mb = *wg_global(s.amax_b);
-  else { const int n1 = n0 + wgg_tile_n(kind); mb = wgg_tile_absmax(s.B, s.ldb, n0, n1 < g.n_end ? n1 : g.n_end, p_begin, p_end, reinterpret_cast<unsigned*>(wg_lds), s.layout & 2); }
+  else mb = a.amax_fill[g.src][1];
   float sa, ia, sb, ib;
   wg_scale_from_max(ma, sa, ia);
   wg_scale_from_max(mb, sb, ib);
@@ -1710,11 +1748,11 @@ __global__ void __launch_bounds__(WG_THREADS, 2) k_wgrad_group(const WggTable* _
     else if (lay == 2) wgrad3_tile<2, 2, 2, 2, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
     else wgrad3_tile<2, 2, 2, 2, 0>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds);
   } else if (kind == 1)
-    wgrad3_tile<1, 4, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout);
+    wgrad3_tile<1, 4, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout & 3);
   else if (kind == 4)
-    wgrad3_tile<2, 2, 1, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout);
+    wgrad3_tile<2, 2, 1, 2>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout & 3);
   else
-    wgrad3_tile<4, 1, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout);
+    wgrad3_tile<4, 1, 1, 1>(s.A, s.lda, s.B, s.ldb, N, p_begin, p_end, slab, k0, n0, g.k_end, g.n_end, sa, ia, sb, ib, wg_lds, s.layout & 3);
 }
 
 // out (+)= sum over the S slabs: a workgroup owns 32 vectors (VEC floats each) of one output, 8 slab phases
@@ -1900,6 +1938,24 @@ static void wgg_split_plan(int o0, int o1, int n_src, const float* const* A, con
       continue;
     }
     long long s = (P[i] + target - 1) / target;
+    // A segment's workgroups are dealt to the 8 XCDs in eighths (wgg_locate) and padded to a multiple of 8: 21 splits x 2 tiles
+    // = 42 items in 48 workgroups leave the eighth XCD none -- and did so for every 256-wide layer: one XCD sat out most of both
+    // item launches (round 6, tools/wgrad_items.py: 909 us for 735 us of packed work).  Splits are rounded up so that
+    // splits x tiles of every region of the source is a multiple of 8.
+    static const bool no_round = getenv("NDJIR_WGG_NO_SPLIT_ROUNDING") != nullptr;      // A/B switch
+    if (!no_round) {
+      WggRegion rg[5];
+      const int nr = wgg_regions(K[o], N[o], rg);
+      int g = 8;
+      for (int q = 0; q < nr; ++q) {
+        int t = rg[q].tiles_k * rg[q].tiles_n, a = 8;
+        while (t % a) a >>= 1;                  // gcd(8, tiles)
+        if (a < g) g = a;
+      }
+      const long long m = 8 / g;
+      const long long s2 = (s + m - 1) / m * m;
+      if ((P[i] + s2 - 1) / s2 >= 8 * WG_C) s = s2;        // (keep splits of at least 8 chunks)
+    }
     long long r = (P[i] + s - 1) / s;
     r = (r + WG_C - 1) / WG_C * WG_C;
     S[i] = (int)((P[i] + r - 1) / r);
@@ -1971,6 +2027,7 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
     WggTable* dtab = reinterpret_cast<WggTable*>(workspace + off);
     off += WGT_FLOATS;
     int ns = 0, no = 0;
+    bool need_amax = false;
     for (int o = o0; o < o1; ++o) {
       // the slabs of an output's sources are consecutive: the reduction sums S_total slabs of K * N floats
       if (!out[o] || ldo[o] < N[o]) return NDJIR_ERR_ARG;
@@ -1983,23 +2040,44 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
         s.A = A[i]; s.B = B[i]; s.amax_a = amax_a ? amax_a[i] : nullptr; s.amax_b = amax_b ? amax_b[i] : nullptr;
         s.partial = workspace + off + (long long)s_seen * kn;
         s_seen += S[i];
-        s.P = P[i]; s.rows = rows[i]; s.lda = lda[i]; s.ldb = ldb[i]; s.K = K[o]; s.N = N[o]; s.S = S[i]; s.layout = layout ? layout[i] : 0;
+        s.P = P[i]; s.rows = rows[i]; s.lda = lda[i]; s.ldb = ldb[i]; s.K = K[o]; s.N = N[o]; s.S = S[i]; s.layout = layout ? (layout[i] & 3) : 0;
+        if (!wgg_narrow(s.A, s.lda, s.K, s.N, s.layout)) {          // bits 8 / 9: k_wgg_absmax finds the maximum of A / B
+          if (!s.amax_a) { s.layout |= 1 << 8; need_amax = true; }
+          if (!s.amax_b) { s.layout |= 1 << 9; need_amax = true; }
+        }
       }
       WggOut& w = tab.out[no++];
       w.out = out[o]; w.partial = workspace + off; w.KN = (int)kn; w.N = N[o]; w.ldo = ldo[o];
       w.S = s_seen; w.accum = accum ? accum[o] : 0; w.pstride = (int)kn; w.pad = 0;
       off += ((long long)s_seen * kn + 3) / 4 * 4;
     }
-    // segments: the narrow items first (short, but each a serial chain: they finish under the tiles), then the 128 x 128
-    // tiles of every source, then the strips (a quarter of a tile's work each: they fill the tail)
-    // (first of all the 128 x 256 items: they are another launch's, k_wgrad_group_wide's)
+    // segments: first of all the 128 x 256 items (another launch's: k_wgrad_group_wide), then the items of k_wgrad_group from the
+    // longest to the shortest (tools/wgrad_items.py, profiles/r06_wgrad_items.txt: a 64 x 128 item or a strip of a ~3 100-point
+    // split runs 160 - 250 us, a tile 150 - 175, a narrow output item of 128 points 10): the short ones fill the launch's tail.
+    // Rounds 4 - 5 issued the narrow items first ("they finish under the tiles") and the strips last; with this order, the
+    // layout order inside a kind and the split rounding of wgg_split_plan the two item launches take 819 + 490 us against
+    // 905 + 652 (same box, same build; packed work 756 + 430 us of the 256 / 512 workgroup slots), the step 7.30 against 7.45 ms.
+    // Also measured this round and NOT kept: the K / N remainders of <= 8 rows / columns (K = 259, 260, 262; N = 257: 360 strips
+    // for 1 ... 6 useful rows each) as fp32 streaming items over the point-blocked operand, 64 features per item -- they re-read
+    // 437 MB of operands the tiles of the same split have just read and run 100 - 145 us each: 7.47 ms against the strips' 7.43.
     int blocks = 0, nseg = 0, wide_blocks = 0;
-    static const int order[6] = {5, 3, 0, 4, 1, 2};
+    static int order[6] = {5, 4, 1, 2, 0, 3};
+    static const bool order_env = [] {
+      const char* e = getenv("NDJIR_WGG_ORDER");          // A/B switch, e.g. 530412 = the order of rounds 4 - 5
+      if (e && strlen(e) == 6) for (int i = 0; i < 6; ++i) order[i] = e[i] - '0';
+      return true;
+    }();
+    (void)order_env;
     for (int q = 0; q < 6; ++q) {
       if (q == 1) wide_blocks = blocks;
-      for (int i = 0; i < ns; ++i) {
+      // ... and inside a kind the sources with row-major operands first: 4-byte loads, 242 / 175 / 172 / 137 us per 128 x 256 item at
+      // layout 0 / 1 / 2 / 3.  (In source order the 48 layout-0 items of the 16 384-point passes started 690 us into a 970-us launch
+      // whose packed work is 725 us.)
+      for (int pass = 0; pass < 4 * ns; ++pass) {
+        const int lay_pass = pass / ns, i = pass - lay_pass * ns;
         const int kind = order[q];
         const WggSrc& s = tab.src[i];
+        if ((s.layout & 3) != lay_pass) continue;
         WggRegion rg[5];
         int nr = 0;
         if (wgg_narrow(s.A, s.lda, s.K, s.N, s.layout)) {
@@ -2019,6 +2097,17 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
           blocks += g.count;
         }
       }
+    }
+    static const bool dump = getenv("NDJIR_WGG_DUMP") != nullptr;       // the plan of every grouped call, on stderr (tools/wgg_plan.py)
+    if (dump) {
+      fprintf(stderr, "wgg call: %d sources, %d outputs, %d segments, %d workgroups (%d wide)\n", ns, no, nseg, blocks, wide_blocks);
+      for (int i = 0; i < ns; ++i)
+        fprintf(stderr, "  src %d: K %d N %d P %lld S %d rows %lld lda %d ldb %d layout %d\n", i, tab.src[i].K, tab.src[i].N, tab.src[i].P,
+                tab.src[i].S, tab.src[i].rows, tab.src[i].lda, tab.src[i].ldb, tab.src[i].layout);
+      for (int i = 0; i < nseg; ++i)
+        fprintf(stderr, "  seg %d: src %d kind %d tiles %d (%d per row) rows [%d, %d) cols [%d, %d) workgroups %d\n", i, tab.seg[i].src,
+                tab.seg[i].kind, tab.seg[i].tiles, tab.seg[i].tiles_n, tab.seg[i].k_off, tab.seg[i].k_end, tab.seg[i].n_off,
+                tab.seg[i].n_end, tab.seg[i].count);
     }
     // the reduce-only outputs (deferred bias gradients) ride in the tables' free output slots
     for (; ex_done < n_extra && no < WGT_MAX_OUT; ++ex_done) {
@@ -2078,6 +2167,10 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
       if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
       s0 += pc.n_src; g0 += pc.n_seg; w0 += pc.n_out;
     }
+    if (need_amax) {
+      hipLaunchKernelGGL(k_wgg_absmax, dim3(WGG_AMAX_CHUNKS, 2 * ns), dim3(256), 0, stream, dtab);
+      if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
+    }
     if (wide_blocks > 0) {
       hipLaunchKernelGGL(k_wgrad_group_wide, dim3(wide_blocks), dim3(WG_THREADS), WGP_LDS_WIDE, stream, (const WggTable*)dtab);
       if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
@@ -2100,6 +2193,11 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
 
 }  // namespace ndjir
 
+#ifdef WGG_ITEMLOG
+extern "C" int ndjir_debug_wgrad_items(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ndjir::wgg_item_log), sizeof(long long) * 16384 * 3);
+}
+#endif
 #ifdef WGG_TIMELINE
 extern "C" int ndjir_debug_wgrad_stamps(long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ndjir::wgg_stamps), sizeof(long long) * 2 * 64 * 12);
