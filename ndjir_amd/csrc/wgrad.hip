@@ -1580,11 +1580,11 @@ __device__ __forceinline__ bool wgg_locate(const WggTable& a, int& si, int& spli
 // rows and columns first, one load per lane and step at memory latency -- 57 us for 512 rows, ~300 us for a split of 2 752; the
 // items of these sources were the long pole of both item launches, tools/wgrad_items.py.)  Largest finite |x| as a bit pattern.
 constexpr int WGG_AMAX_CHUNKS = 32;        // workgroups per operand
-__global__ void __launch_bounds__(256) k_wgg_absmax(WggTable* __restrict__ tab) {
+struct WggAmaxJobs { short job[2 * WGT_MAX_SRC]; };      // 2 x source + operand, in the kernel arguments (1 KB)
+__global__ void __launch_bounds__(256) k_wgg_absmax(WggTable* __restrict__ tab, const WggAmaxJobs jobs) {
   __shared__ unsigned red[256];
-  const int i = (int)blockIdx.y >> 1, op = (int)blockIdx.y & 1;
+  const int i = (int)jobs.job[blockIdx.y] >> 1, op = (int)jobs.job[blockIdx.y] & 1;
   const WggSrc& s = tab->src[i];
-  if (!((s.layout >> (8 + op)) & 1)) return;          // recorded, or a narrow source (fp32 items: no scale)
   const WG_G float* X = wg_global(op ? s.B : s.A);
   const int ld = op ? s.ldb : s.lda, W = op ? s.N : s.K;
   const bool blocked = (s.layout >> op) & 1;
@@ -2026,8 +2026,8 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
     wgg_split_plan(o0, o1, n_src, A, lda, P, out_id, K, N, target_items, S, rows, layout);
     WggTable* dtab = reinterpret_cast<WggTable*>(workspace + off);
     off += WGT_FLOATS;
-    int ns = 0, no = 0;
-    bool need_amax = false;
+    int ns = 0, no = 0, n_amax = 0;
+    static thread_local WggAmaxJobs amax_jobs;
     for (int o = o0; o < o1; ++o) {
       // the slabs of an output's sources are consecutive: the reduction sums S_total slabs of K * N floats
       if (!out[o] || ldo[o] < N[o]) return NDJIR_ERR_ARG;
@@ -2041,9 +2041,9 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
         s.partial = workspace + off + (long long)s_seen * kn;
         s_seen += S[i];
         s.P = P[i]; s.rows = rows[i]; s.lda = lda[i]; s.ldb = ldb[i]; s.K = K[o]; s.N = N[o]; s.S = S[i]; s.layout = layout ? (layout[i] & 3) : 0;
-        if (!wgg_narrow(s.A, s.lda, s.K, s.N, s.layout)) {          // bits 8 / 9: k_wgg_absmax finds the maximum of A / B
-          if (!s.amax_a) { s.layout |= 1 << 8; need_amax = true; }
-          if (!s.amax_b) { s.layout |= 1 << 9; need_amax = true; }
+        if (!wgg_narrow(s.A, s.lda, s.K, s.N, s.layout)) {          // (narrow sources: fp32 items, no operand scale)
+          if (!s.amax_a) amax_jobs.job[n_amax++] = (short)(2 * (ns - 1));
+          if (!s.amax_b) amax_jobs.job[n_amax++] = (short)(2 * (ns - 1) + 1);
         }
       }
       WggOut& w = tab.out[no++];
@@ -2167,8 +2167,8 @@ int launch_wgrad_group(int n_src, const float* const* A, const int* lda, const f
       if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
       s0 += pc.n_src; g0 += pc.n_seg; w0 += pc.n_out;
     }
-    if (need_amax) {
-      hipLaunchKernelGGL(k_wgg_absmax, dim3(WGG_AMAX_CHUNKS, 2 * ns), dim3(256), 0, stream, dtab);
+    if (n_amax > 0) {
+      hipLaunchKernelGGL(k_wgg_absmax, dim3(WGG_AMAX_CHUNKS, n_amax), dim3(256), 0, stream, dtab, amax_jobs);
       if (ndjir_check_launch() != NDJIR_OK) return NDJIR_ERR_LAUNCH;
     }
     if (wide_blocks > 0) {

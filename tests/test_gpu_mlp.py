@@ -717,13 +717,15 @@ def _to_blocked(x):
     return x.reshape(P // 32, 32, K).permute(0, 2, 1).contiguous().reshape(P, K)
 
 
+@pytest.mark.parametrize("recorded", [True, False])
 @pytest.mark.parametrize("wide", [True, False])
-def test_wgrad_group_point_blocked_operands(gpu, wide, monkeypatch):
+def test_wgrad_group_point_blocked_operands(gpu, wide, recorded, monkeypatch):
     """Grouped weight gradients with point-blocked operands (`mlp.PB`: what the 128-point-tile chains write) in every layout
     combination, vs fp64: full and ragged 128 x 128 tiles and 128 x 256 items (`k_wgrad_group_wide`; NDJIR_WGRAD_NO_WIDE is read
     once per process, so the second parametrisation shrinks the item count instead and covers the other split lengths), a feature
     range of a wider blocked buffer, narrow outputs with a blocked A, an odd number of 32-point chunks per item, two operand
-    pairs per output."""
+    pairs per output.  recorded = False: no operand comes with a recorded maximum -- the call's pre-pass (`k_wgg_absmax`) finds them,
+    over row-major and point-blocked operands and feature ranges of wider buffers alike."""
     from ndjir_amd import mlp
     monkeypatch.setattr(mlp, "WGRAD_GROUP_ITEMS", 0 if wide else 96)
     rng = np.random.RandomState(21)
@@ -738,7 +740,7 @@ def test_wgrad_group_point_blocked_operands(gpu, wide, monkeypatch):
             ref += A[:, 4:4 + K].double().t() @ B.double()
             Ad = mlp.PB(_to_blocked(A.to(gpu)))[:, 4:4 + K] if lay & 1 else A.to(gpu)[:, 4:4 + K]
             Bd = mlp.PB(_to_blocked(B.to(gpu))) if lay & 2 else B.to(gpu)
-            srcs.append((Ad, Bd, A.abs().max().reshape(1).to(gpu), (B.abs().max() * 1.5).reshape(1).to(gpu)))
+            srcs.append((Ad, Bd, A.abs().max().reshape(1).to(gpu) if recorded else None, (B.abs().max() * 1.5).reshape(1).to(gpu) if recorded else None))
         accum = i % 2 == 0
         base = torch.tensor(rng.randn(K, N), dtype=torch.float32)
         out = base.to(gpu).clone() if accum else torch.full((K, N), float("nan"), device=gpu)
