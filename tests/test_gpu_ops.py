@@ -141,10 +141,12 @@ def test_grid_family_vs_oracle(gpu, family, P, G, hash_cfg):
     _family_check(gpu, family, P, G, hash_cfg)
 
 
-@pytest.mark.parametrize("family,P,G", [("triplane", 3000, 64), ("triline", 3000, 64), ("voxel", 3000, 16), ("lanczos_triplane", 200, 16)])
+@pytest.mark.parametrize("family,P,G", [("triplane", 3000, 64), ("triline", 3000, 64), ("voxel", 3000, 16), ("lanczos_triplane", 200, 16),
+                                        ("lanczos_voxel", 700, 12), ("cosine_voxel", 3000, 16)])
 def test_grid_family_eight_channels(gpu, family, P, G):
-    """feature_size = 8 (config/triplaneline.yaml): two float4 chunks per cell on the LDS-aggregated scatter path
-    (tri-plane / tri-line), the plain atomic path for the dense voxel and the Lanczos families."""
+    """feature_size = 8 (config/triplaneline.yaml): two float4 chunks per cell on the LDS-aggregated scatter path (k_scatter_agg:
+    a run of 2 / 4 cells is 64 / 128 bytes = 1 - 3 table blocks; the Lanczos voxel's 16 lanes per point leave 8 points per pass),
+    the per-point Lanczos gathers (the lane-per-channel kernels are D = 4 only)."""
     _family_check(gpu, family, P, G, None, D=8)
 
 
