@@ -1383,7 +1383,7 @@ constexpr int WGG_MAX_SRC = 20;      // per writer launch
 constexpr int WGG_MAX_SEG = 48;
 constexpr int WGG_MAX_OUT = 20;
 constexpr int WGG_NARROW_ROWS = 128;      // points per narrow work item: its row loop is a latency chain (32 steps of 4 rows), so
-                                          // items are kept short and issued FIRST -- a 1024-row item ran ~100 us and was the tail of every launch
+                                          // items are kept short (a 1024-row item ran ~100 us and was the tail of every launch) and, since round 6, issued LAST: they fill the tail
 
 struct WggSrc {
   const float* A;
