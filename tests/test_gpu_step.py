@@ -8,17 +8,19 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _step(gpu, overrides=(), R=32, G=32):
+def _step(gpu, overrides=(), R=32, G=32, config="default"):
     from ndjir_amd import config as cfg
     from ndjir_amd.step import Step
-    conf = cfg.load("default", [f"geometric_network.voxel.grid_size={G}"] + list(overrides))
+    conf = cfg.load(config, [f"geometric_network.voxel.grid_size={G}"] + list(overrides))
     return Step(conf, R, gpu, 0, 1)
 
 
-def test_rearm_after_redraw_clears_the_previous_steps_cells(gpu):
+@pytest.mark.parametrize("config,G", [("default", 32), ("custom", 32), ("triplaneline", 64)])      # (the tri-plane buffer is re-armed by a memset: sparse zeroing measured no faster, round 6)
+def test_rearm_after_redraw_clears_the_previous_steps_cells(gpu, config, G):
     """forward_backward, redraw_rand, forward_backward: the second step's grid gradient equals a run that zeroes the
-    whole buffer (the perturbed points of step 1 were formed with the noise of step 1, not the redrawn one)."""
-    step = _step(gpu)
+    whole buffer (the perturbed points of step 1 were formed with the noise of step 1, not the redrawn one).  Dense voxel
+    (linear; Lanczos: 4 x 4 x 4 taps); the tri-plane + tri-line buffers of config/triplaneline.yaml are re-armed whole."""
+    step = _step(gpu, G=G, config=config)
     gen = torch.Generator(device=gpu)
     gen.manual_seed(5)
     step.forward_backward()

@@ -8,7 +8,7 @@ import bench  # noqa: E402
 from ndjir_amd import config as cfg  # noqa: E402
 
 dev = torch.device("cuda", 0)
-conf = cfg.load("default", sys.argv[1:])
+conf = cfg.load(os.environ.get("LAUNCH_LIST_CONFIG", "default"), sys.argv[1:])
 step = bench.Step(conf, 512, dev, 0, 1)
 for _ in range(2):
     step.forward_backward()
