@@ -154,8 +154,9 @@ def _big_normal_init(std):
     return init
 
 
-def query_on_grid(x, G, D, use_ste, type):
-    """network.py:120-151."""
+def query_on_grid(x, G, D, use_ste, type, parts=False):
+    """network.py:120-151.  parts=True: the list of the grid's feature tensors instead of their concatenation (the tri-plane +
+    tri-line pair: a caller that packs them into a wider row itself saves the torch.cat)."""
     if type == "none":
         return None
     n = G ** 3 * D if type.endswith("voxel") else 3 * G * G * D
@@ -164,10 +165,11 @@ def query_on_grid(x, G, D, use_ste, type):
         pre = type[:-len("triplaneline")]
         feat0 = getattr(PF, pre + "query_on_triplane")(x, G, D, use_ste=use_ste, f_init=f_init)
         feat1 = getattr(PF, pre + "query_on_triline")(x, G, D, use_ste=use_ste)
-        return torch.cat([feat0, feat1], dim=-1)
+        return [feat0, feat1] if parts else torch.cat([feat0, feat1], dim=-1)
     pre, topo = ("", type) if "_" not in type else type.split("_", 1)
     pre = pre + "_" if pre else ""
-    return getattr(PF, f"{pre}query_on_{topo}")(x, G, D, use_ste=use_ste, f_init=f_init)
+    out = getattr(PF, f"{pre}query_on_{topo}")(x, G, D, use_ste=use_ste, f_init=f_init)
+    return [out] if parts else out
 
 
 # grid type -> [(grid-feature family, parameter scope)] in concatenation order (python/network.py:120-151; the cosine /
@@ -268,19 +270,21 @@ def geometric_network(x, conf, first_order_only=False, sdf_only=False, packed=Fa
             from .grid_feature import _core
             fused_in = _core.query_encode(v.type, x, fparam, M)
         else:
-            vfeat = query_on_grid(x, v.grid_size, v.feature_size, v.use_ste, v.type)
+            vfeat = query_on_grid(x, v.grid_size, v.feature_size, v.use_ste, v.type, parts=True)
         if fused_in is not None:
             inputs, pe_x = fused_in, None
         elif (vfeat is not None and x.is_cuda and x.dtype == torch.float32 and M > 0 and x.shape[-1] == 3 and g.geometric_init
-                and not vfeat.requires_grad and not x.requires_grad):
+                and not any(t.requires_grad for t in vfeat) and not x.requires_grad):
             # nothing to differentiate (sampler rounds, mesh extraction): encoding and grid features side by side in one launch
-            Kin = 3 + 6 * M + vfeat.shape[-1]
+            # (the tri-plane and tri-line features as two segments: no concatenation in between)
+            Cs = [t.shape[-1] for t in vfeat]
+            Kin = 3 + 6 * M + sum(Cs)
             inputs = torch.empty(x.shape[:-1] + (Kin,), device=x.device, dtype=torch.float32)
-            lib.call("geo_encode", inputs.numel() // Kin, M, x.contiguous(), 1, [vfeat.contiguous()], [vfeat.shape[-1]], inputs, Kin)
+            lib.call("geo_encode", inputs.numel() // Kin, M, x.contiguous(), len(vfeat), [t.contiguous() for t in vfeat], Cs, inputs, Kin)
             pe_x = None
         else:
             pe_x = positional_encoding(x, M) if M > 0 else x
-            inputs = torch.cat([pe_x, vfeat], dim=-1) if vfeat is not None else pe_x
+            inputs = torch.cat([pe_x] + list(vfeat), dim=-1) if vfeat is not None else pe_x
         h = inputs
 
         if not g.geometric_init:
