@@ -130,6 +130,32 @@ def test_triplane_scatter_every_point_in_one_cell(gpu):
     np.testing.assert_allclose(gf.detach().cpu().numpy(), ref, atol=2e-5 * scale)
 
 
+@pytest.mark.parametrize("family,G,D", [("voxel", 48, 4), ("triplane", 96, 8), ("lanczos_voxel", 40, 4), ("voxel", 24, 8)])
+def test_scatter_of_clustered_and_spread_points_mixed(gpu, family, G, D):
+    """Every other point in one small cluster, the rest spread over the grid, interleaved: inside one pass of k_scatter_agg /
+    k_scatter_lanczos_voxel some runs merge in the LDS table and others find it full and take the overflow list (resp. go to
+    memory directly) -- both paths of the same pass against the float64 oracle, grad_feature and grad_query_grad_feature."""
+    from ndjir_amd.grid_feature import _core
+    rng = np.random.RandomState(11)
+    P = 12000
+    q = (rng.rand(P, 3) * 2.2 - 1.1).astype(np.float32)
+    q[::2] = (0.31 + rng.rand(P // 2, 3) * 0.02).astype(np.float32)
+    o = K.GridOracle(family)
+    fs = feature_shape(o, G, D, None)
+    f = (rng.randn(*fs) * 0.01).astype(np.float32)
+    C = o.query(q[:1], f).shape[1]
+    og = rng.randn(P, C).astype(np.float32)
+    qd, fd, ogd = T(q, gpu).requires_grad_(True), T(f, gpu).requires_grad_(True), T(og, gpu).requires_grad_(True)
+    gf = _core.grad_feature(family, ogd, qd, fd)
+    ref = o.grad_feature(og, q, fs)
+    np.testing.assert_allclose(gf.detach().cpu().numpy(), ref, atol=(5e-5 if o.lanczos else 5e-6) * np.abs(ref).max())
+    ggq = rng.randn(P, 3).astype(np.float32)
+    gq = _core.grad_query(family, ogd, qd, fd)
+    g_f, = torch.autograd.grad(gq, [fd], T(ggq, gpu))
+    ref2 = o.grad_query_grad_feature(ggq, og, q, fs)
+    np.testing.assert_allclose(g_f.cpu().numpy(), ref2, atol=(2e-3 if o.lanczos else 2e-5) * np.abs(ref2).max())
+
+
 def _hip_family(family):
     from ndjir_amd.grid_feature import _core
     return _core
