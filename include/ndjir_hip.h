@@ -129,6 +129,11 @@ int ndjir_sparse_rows_zero_if_dropped(const int* own_count, int capacity, float*
  * 1 cosine / 2 Lanczos; values bit-identical to <family>_query followed by ndjir_geo_encode */
 int ndjir_voxel_feature_query_encode(int N, int M, const float* query, const float* feature, const int* grid_sizes, int D,
                                      const float* min, const float* max, int interp, float* e, int lde, hipStream_t stream);
+/* ... the same for the tri-plane + tri-line pair of `triplaneline` grids (python/network.py:137-147): rows [x | cos | sin | tri-plane
+ * feature (Dp, 3) | tri-line feature (Dl, 3)], bit-identical to the two <family>_query_on_* launches followed by ndjir_geo_encode */
+int ndjir_triplaneline_query_encode(int N, int M, const float* query, const float* plane_feature, int Gp, int Dp,
+                                    const float* line_feature, int Gl, int Dl, const float* min, const float* max, int interp,
+                                    float* e, int lde, hipStream_t stream);
 NDJIR_DECL_VOXEL_FAMILY(cosine_voxel_feature)
 NDJIR_DECL_VOXEL_FAMILY(lanczos_voxel_feature)
 

@@ -149,6 +149,18 @@ extern "C" int ndjir_voxel_feature_query_encode(int N, int M, const float* query
   return launch_voxel_query_encode(interp, voxel_desc(gs, D, mn, mx), N, M, query, feature, e, lde, st);
 }
 
+// ... and for the tri-plane + tri-line pair: rows [x | cos | sin | tri-plane feature (Dp, 3) | tri-line feature (Dl, 3)]
+extern "C" int ndjir_triplaneline_query_encode(int N, int M, const float* query, const float* plane, int Gp, int Dp, const float* line,
+                                               int Gl, int Dl, const float* mn, const float* mx, int interp, float* e, int lde,
+                                               hipStream_t st) {
+  if (N <= 0) return NDJIR_OK;
+  if (!query || !plane || !line || !mn || !mx || !e || M < 0 || M > 30 || Dp < 1 || Dl < 1 || Gp < 1 || Gl < 1 ||
+      lde < 3 + 6 * M + 3 * Dp + 3 * Dl)
+    return NDJIR_ERR_ARG;
+  return launch_tri_query_encode(interp, plane_desc(TRIPLANE, Gp, Dp, mn, mx), plane_desc(TRILINE, Gl, Dl, mn, mx), N, M, query, plane,
+                                 line, e, lde, st);
+}
+
 extern "C" int ndjir_voxel_feature_zero_touched(int N, float* gf, const float* query, const int* gs, int D, const float* mn,
                                                 const float* mx, hipStream_t st) {
   if (N <= 0) return NDJIR_OK;

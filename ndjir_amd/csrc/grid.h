@@ -23,6 +23,8 @@ struct GridDesc {
 int launch_query(int interp, const GridDesc& g, long long P, float* out, const float* query, const float* feature, bool accum, hipStream_t stream);
 int launch_voxel_query_encode(int interp, const GridDesc& g, long long P, int M, const float* query, const float* feature, float* e,
                               int lde, hipStream_t stream);
+int launch_tri_query_encode(int interp, const GridDesc& gp, const GridDesc& gl, long long P, int M, const float* query,
+                            const float* plane, const float* line, float* e, int lde, hipStream_t stream);
 int launch_dquery(int interp, const GridDesc& g, long long P, int mode, float* dst, const float* src, const float* query, const float* feature, bool accum, hipStream_t stream);
 int launch_mark_touched(const GridDesc& g, long long P, const float* query, unsigned* bitmap, hipStream_t stream);
 int launch_pack_rows(int interp, const GridDesc& g, long long P, const float* gf, const float* query, unsigned* bitmap, int* ids,

@@ -311,6 +311,57 @@ __global__ void __launch_bounds__(256) k_voxel_query_encode(long long P, int M, 
   }
 }
 
+// The tri-plane + tri-line pair of config/triplaneline.yaml (python/network.py:137-147: the two features concatenated behind the
+// encoding): e[p] = [x, cos, sin, tri-plane feature (Dp, 3), tri-line feature (Dl, 3)] in one launch -- what k_query_rows x 2 +
+// k_geo_encode produced in three (and the sampler's rounds a torch.cat besides).  One lane per (point, column); a feature column
+// (d, s) walks the taps of sub-grid s in k_query_rows' order with its products: bit-identical values.
+template <int I>
+__global__ void __launch_bounds__(256) k_tri_query_encode(long long P, int M, const float* __restrict__ query,
+                                                          const float* __restrict__ plane, GridDesc gp,
+                                                          const float* __restrict__ line, GridDesc gl, float* __restrict__ e, int lde) {
+  constexpr int NT = NTaps<I>::v;
+  const int npe = 3 + 6 * M, Cp = 3 * gp.D, W = npe + Cp + 3 * gl.D;
+  const long long total = P * W;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const long long p = t / W;
+    int c = (int)(t - p * W);
+    const int c_out = c;
+    float v;
+    if (c < 3) v = query[p * 3 + c];
+    else if (c < npe) {
+      c -= 3;
+      const bool is_sin = c >= 3 * M;
+      if (is_sin) c -= 3 * M;
+      const float b = query[p * 3 + c / M] * (float)(1 << (c % M));
+      v = is_sin ? sinf(b) : cosf(b);
+    } else {
+      const float q[3] = {query[p * 3], query[p * 3 + 1], query[p * 3 + 2]};
+      c -= npe;
+      float acc = 0.f;
+      if (c < Cp) {
+        const int d = c / 3, sub = c - 3 * d;                    // (D, 3): sub-grid fastest (reference layout)
+        Stencil<TRIPLANE, I> st;
+        make_stencil<TRIPLANE, I>(st, gp, sub, q);
+        NDJIR_FOR_TAPS(2, NT) {
+          const float w = tap_w(st, i, j, k);
+          acc += w * plane[cell_offset(st, i, j, k) + d];
+        }
+      } else {
+        c -= Cp;
+        const int d = c / 3, sub = c - 3 * d;
+        Stencil<TRILINE, I> st;
+        make_stencil<TRILINE, I>(st, gl, sub, q);
+        NDJIR_FOR_TAPS(1, NT) {
+          const float w = tap_w(st, i, j, k);
+          acc += w * line[cell_offset(st, i, j, k) + d];
+        }
+      }
+      v = acc;
+    }
+    e[p * lde + c_out] = v;
+  }
+}
+
 // The same for the Lanczos stencil.  There a lane per (point, column) made every feature column repeat the 24 software sines of
 // the 4 x 4 x 4 stencil, in waves whose other lanes (the encoding columns) waited for it, and gathered its 64 taps a few at a
 // time: 55 us per launch, 0.37 ms per `custom` step.  Here a workgroup takes PTS points: one lane per (point, axis) evaluates
@@ -1681,6 +1732,18 @@ int launch_voxel_query_encode(int interp, const GridDesc& g, long long P, int M,
     else if (want64 >= 512) hipLaunchKernelGGL((k_voxel_query_encode_lanczos<64>), dim3((unsigned)(want64 > 8192 ? 8192 : want64)), dim3(256), 0, stream, P, M, query, feature, g, e, lde);
     else hipLaunchKernelGGL((k_voxel_query_encode_lanczos<16>), dim3((unsigned)want), dim3(256), 0, stream, P, M, query, feature, g, e, lde);
   }
+  else return NDJIR_ERR_UNSUPPORTED;
+  return ndjir_check_launch();
+}
+
+int launch_tri_query_encode(int interp, const GridDesc& gp, const GridDesc& gl, long long P, int M, const float* query,
+                            const float* plane, const float* line, float* e, int lde, hipStream_t stream) {
+  if (P <= 0) return NDJIR_OK;
+  if (gp.topo != TRIPLANE || gl.topo != TRILINE) return NDJIR_ERR_UNSUPPORTED;
+  const int blocks = grid_blocks(P * (3 + 6 * M + 3 * gp.D + 3 * gl.D));
+  if (interp == LINEAR) hipLaunchKernelGGL((k_tri_query_encode<LINEAR>), dim3(blocks), dim3(256), 0, stream, P, M, query, plane, gp, line, gl, e, lde);
+  else if (interp == COSINE) hipLaunchKernelGGL((k_tri_query_encode<COSINE>), dim3(blocks), dim3(256), 0, stream, P, M, query, plane, gp, line, gl, e, lde);
+  else if (interp == LANCZOS) hipLaunchKernelGGL((k_tri_query_encode<LANCZOS>), dim3(blocks), dim3(256), 0, stream, P, M, query, plane, gp, line, gl, e, lde);
   else return NDJIR_ERR_UNSUPPORTED;
   return ndjir_check_launch();
 }

@@ -100,6 +100,7 @@ SIGS = {
     "squareplus_backward": "ipppfi",
     "voxel_feature_zero_touched": "ippIiFF",
     "voxel_feature_query_encode": "iippIiFFipi",
+    "triplaneline_query_encode": "iippiipiiFFipi",
     "voxel_feature_zero_touched_interp": "ippIiFFi",
     "voxel_feature_check_touched": "ippIiFFq",
     "voxel_feature_pack_rows": "ippIiFFqqpqi",

@@ -239,6 +239,7 @@ def _geometric_param_lists(conf):
     return Ws, bs, skip_at, scale
 
 
+_TRI_FUSED_MAX_POINTS = 16384     # (ndjir_amd/geometric.py TRI_FUSED_MAX_POINTS)
 _NO_QUERY_ENCODE = bool(os.environ.get("NDJIR_NO_QUERY_ENCODE"))      # A/B: the voxel query and the input encoding as two launches
 
 
@@ -269,6 +270,21 @@ def geometric_network(x, conf, first_order_only=False, sdf_only=False, packed=Fa
                 and not x.requires_grad and fparam.dim() == 4 and not _NO_QUERY_ENCODE):
             from .grid_feature import _core
             fused_in = _core.query_encode(v.type, x, fparam, M)
+        elif (v.type.endswith("triplaneline") and x.is_cuda and x.dtype == torch.float32 and M > 0 and x.shape[-1] == 3
+              and g.geometric_init and not x.requires_grad and not torch.is_grad_enabled() and not _NO_QUERY_ENCODE
+              and x.numel() // 3 <= _TRI_FUSED_MAX_POINTS
+              and "geometric-network/triplane_feature/F" in P.get_parameters() and "geometric-network/triline_feature/F" in P.get_parameters()):
+            # tri-plane + tri-line, nothing to differentiate (the sampler's rounds, mesh extraction): both queries and the encoding in
+            # one launch (ndjir_triplaneline_query_encode)
+            from .grid_feature import _core
+            Fp = P.get_parameters()["geometric-network/triplane_feature/F"]
+            Fl = P.get_parameters()["geometric-network/triline_feature/F"]
+            fam = _core.FAMILIES[v.type[:-len("triplaneline")] + "triplane"]
+            Kin = 3 + 6 * M + 3 * Fp.shape[-1] + 3 * Fl.shape[-1]
+            fused_in = torch.empty(x.shape[:-1] + (Kin,), device=x.device, dtype=torch.float32)
+            lib.call("triplaneline_query_encode", fused_in.numel() // Kin, M, x.contiguous(), Fp.detach().contiguous(), Fp.shape[1],
+                     Fp.shape[-1], Fl.detach().contiguous(), Fl.shape[1], Fl.shape[-1], [-1.0] * 3, [1.0] * 3, _core.interp_code(fam),
+                     fused_in, Kin)
         else:
             vfeat = query_on_grid(x, v.grid_size, v.feature_size, v.use_ste, v.type, parts=True)
         if fused_in is not None:

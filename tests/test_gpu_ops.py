@@ -683,3 +683,31 @@ def test_voxel_query_encode_equals_query_then_encode(gpu, family):
     lib.call("voxel_feature_query_encode", P, M, x, F, gs, D, [-1.0] * 3, [1.0] * 3, _core.interp_code(fam), got, lde)
     assert torch.equal(got[:, :W], want)
     assert torch.isnan(got[:, W:]).all()
+
+
+@pytest.mark.parametrize("pre", ["", "cosine_", "lanczos_"])
+def test_triplaneline_query_encode_equals_queries_then_encode(gpu, pre):
+    """ndjir_triplaneline_query_encode (csrc/grid.hip `k_tri_query_encode`): the rows [x | cos | sin | tri-plane feature (Dp, 3) |
+    tri-line feature (Dl, 3)] of the `triplaneline` geometric net's input in one launch -- bit for bit what the two
+    <family>_query_on_* launches followed by ndjir_geo_encode produce (points inside, on and outside the box; different grid
+    sizes and channel counts of plane and line; a row stride wider than the row)."""
+    from ndjir_amd import lib
+    from ndjir_amd.grid_feature import _core
+    rng = np.random.RandomState(6)
+    P, M, Gp, Dp, Gl, Dl = 3000, 6, 24, 8, 17, 4
+    x = torch.tensor(rng.rand(P, 3) * 2.6 - 1.3, dtype=torch.float32, device=gpu)
+    x[:3] = torch.tensor([[-1.0, 1.0, 0.0], [1.0, -1.0, 1.0], [0.0, 0.0, 0.0]], device=gpu)
+    Fp = torch.tensor(rng.randn(3, Gp, Gp, Dp), dtype=torch.float32, device=gpu)
+    Fl = torch.tensor(rng.randn(3, Gl, Dl), dtype=torch.float32, device=gpu)
+    fp, fl = _core.FAMILIES[pre + "triplane"], _core.FAMILIES[pre + "triline"]
+    vp, vl = torch.empty((P, 3 * Dp), device=gpu), torch.empty((P, 3 * Dl), device=gpu)
+    lib.call(f"{fp.prefix}_{fp.fwd}", P * 3 * Dp, vp, x, Fp, Gp, Dp, [-1.0] * 3, [1.0] * 3, 0)
+    lib.call(f"{fl.prefix}_{fl.fwd}", P * 3 * Dl, vl, x, Fl, Gl, Dl, [-1.0] * 3, [1.0] * 3, 0)
+    W = 3 + 6 * M + 3 * Dp + 3 * Dl
+    want = torch.empty((P, W), device=gpu)
+    lib.call("geo_encode", P, M, x, 2, [vp, vl], [3 * Dp, 3 * Dl], want, W)
+    lde = W + 3
+    got = torch.full((P, lde), float("nan"), device=gpu)
+    lib.call("triplaneline_query_encode", P, M, x, Fp, Gp, Dp, Fl, Gl, Dl, [-1.0] * 3, [1.0] * 3, _core.interp_code(fp), got, lde)
+    assert torch.equal(got[:, :W], want)
+    assert torch.isnan(got[:, W:]).all()
